@@ -1,0 +1,150 @@
+/* kf.h -- C-ABI of the MI355X-native batched Kalman filter / RTS smoother.
+ *
+ * This is the drop-in boundary for the one hot path of
+ * jessegrabowski/pymc_statespace: everything `pymc_statespace.filters` computes
+ * numerically.  The reference has NO native code and NO FFI for this path (it is a
+ * symbolic PyTensor scan), so each entry point cites the reference Python
+ * interface it replaces; the binding a maintainer adds on the reference side is
+ * the ctypes stub shown in INTEGRATION.md.
+ *
+ *   kf_filter_forward   <- BaseFilter.build_graph + kalman_step + update variants +
+ *                          _postprocess_scan_results
+ *                          (pymc_statespace/filters/kalman_filter.py:126-163,195-252,
+ *                           255-351,444-505,165-193), evaluated for B draws at once
+ *   kf_filter_backward  <- pytensor.grad through that scan (implicit in the reference:
+ *                          README.md:6; core/statespace.py:174 registers the Potential
+ *                          NUTS differentiates)
+ *   kf_smoother         <- KalmanSmoother.build_graph
+ *                          (pymc_statespace/filters/kalman_smoother.py:56-104)
+ *
+ * Conventions
+ *   - Plain C, no torch / HIP types in signatures.  `stream` is a hipStream_t passed
+ *     as void* (NULL = the null stream).  All calls are asynchronous on `stream`.
+ *   - Every data pointer is a DEVICE pointer to fp64 (the reference computes in
+ *     float64: kalman_filter.py:16).  The caller owns all buffers; the library
+ *     never allocates in a call, never frees and never keeps a pointer.
+ *   - Layouts are the reference's per-draw row-major layouts with ONE extra leading
+ *     axis B (the batch of parameter draws), draw-major:
+ *         y   [T][p]            shared by all draws   (or [B][T][p], KF_FLAG_Y_PER_DRAW)
+ *         a0  [B][m]     P0 [B][m][m]   T [B][m][m]   Z [B][p][m]
+ *         R   [B][m][r]  H  [B][p][p]   Q [B][r][r]   c [B][m]   d [B][p]
+ *     outputs (each tape pointer may be NULL = do not store):
+ *         logp   [B]            ll_obs [B][T]
+ *         filt_a [B][T][m]      pred_a [B][T+1][m]     (pred_a[:,0] = a0)
+ *         filt_P [B][T][m][m]   pred_P [B][T+1][m][m]  (pred_P[:,0] = P0)
+ *         info   [B]  int32     0 = ok; else ((t+1) << 8) | k : at time step t the
+ *                               leading minor k of F was not positive definite
+ *   - NaN in y marks a missing observation (kalman_filter.py:195-213).
+ *   - Return value: 0 ok; < 0 argument / HIP error (text via kf_last_error).
+ *     Numerical failures are reported per draw through `info`, like LAPACK.
+ *   - Threading: re-entrant per handle; one handle per (host thread, device).
+ */
+#ifndef KF_H_
+#define KF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KF_ABI_VERSION 1
+
+typedef struct kf_handle kf_handle;
+
+/* filter variants: FILTER_FACTORY keys of pymc_statespace/core/statespace.py:25-31 */
+enum {
+  KF_FILTER_STANDARD = 0,   /* StandardFilter         kalman_filter.py:255-284 */
+  KF_FILTER_CHOLESKY = 1,   /* CholeskyFilter         kalman_filter.py:287-318 */
+  KF_FILTER_UNIVARIATE = 2, /* UnivariateFilter       kalman_filter.py:444-505 */
+  KF_FILTER_SINGLE = 3      /* SingleTimeseriesFilter kalman_filter.py:321-351 (p == 1) */
+};
+
+/* flags */
+enum {
+  /* log(2 pi) is added n_observed times per step (textbook / statsmodels).  When
+   * clear, the reference's own counts are used: Standard/Single once per step
+   * (kalman_filter.py:281,:349), Cholesky p times (:314), Univariate once per
+   * non-degenerate scalar update (:503).  Identical for p == 1. */
+  KF_FLAG_MVN_CONST_EXACT = 1u << 0,
+  /* y is [B][T][p] instead of the shared [T][p] */
+  KF_FLAG_Y_PER_DRAW = 1u << 1
+};
+
+/* error codes */
+enum {
+  KF_OK = 0,
+  KF_ERR_ARG = -1,       /* bad dimension / NULL pointer / unsupported combination */
+  KF_ERR_HIP = -2,       /* a HIP runtime call failed */
+  KF_ERR_WORKSPACE = -3, /* workspace too small */
+  KF_ERR_UNSUPPORTED = -4
+};
+
+typedef struct kf_dims {
+  int64_t B;      /* draws */
+  int32_t T;      /* time steps (n_obs) */
+  int32_t p;      /* k_endog */
+  int32_t m;      /* k_states */
+  int32_t r;      /* k_posdef */
+  int32_t filter; /* KF_FILTER_* */
+  uint32_t flags; /* KF_FLAG_* */
+} kf_dims;
+
+int kf_abi_version(void);
+
+/* One handle per (process, device): holds the device id, kernel tuning and the last
+ * error text.  `device` is the HIP ordinal. */
+int kf_create(kf_handle** out, int device);
+void kf_destroy(kf_handle* h);
+const char* kf_last_error(const kf_handle* h);
+
+/* Tuning knob: lanes of a wavefront that cooperate on one draw (0 = choose from
+ * dims; valid: 4, 8, 16, 32, 64).  Fewer lanes per draw = more draws per wave. */
+int kf_set_lanes_per_draw(kf_handle* h, int lanes);
+
+/* Scratch the three entry points need for `dims` (max over them); may be 0. */
+int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes);
+
+/* Forward filter for B draws.  c, d may be NULL (= 0: initialize_intercepts,
+ * kalman_filter.py:36-51).  ll_obs / filt_* / pred_* / info may be NULL. */
+int kf_filter_forward(kf_handle* h, const kf_dims* dims,
+                      const double* y, const double* a0, const double* P0,
+                      const double* T, const double* Z, const double* R,
+                      const double* H, const double* Q,
+                      const double* c, const double* d,
+                      double* logp, double* ll_obs,
+                      double* filt_a, double* pred_a, double* filt_P, double* pred_P,
+                      int32_t* info, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Reverse-mode gradient of  sum_b g_logp[b]*logp[b] + sum_{b,t} g_ll_obs[b][t]*ll_obs[b][t]
+ * with respect to every input, per draw.  Needs the predicted tapes of a forward
+ * call on the same inputs (pred_a, pred_P).  g_logp or g_ll_obs may be NULL (= 0);
+ * any output gradient pointer may be NULL (= not wanted).  Gradients treat every
+ * matrix entry as an independent variable (what autodiff of the reference graph
+ * returns). */
+int kf_filter_backward(kf_handle* h, const kf_dims* dims,
+                       const double* y, const double* a0, const double* P0,
+                       const double* T, const double* Z, const double* R,
+                       const double* H, const double* Q,
+                       const double* c, const double* d,
+                       const double* pred_a, const double* pred_P,
+                       const double* g_logp, const double* g_ll_obs,
+                       double* g_a0, double* g_P0, double* g_T, double* g_Z,
+                       double* g_R, double* g_H, double* g_Q, double* g_c, double* g_d,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* RTS smoother over the filtered tapes: smooth_a [B][T][m], smooth_P [B][T][m][m].
+ * Only dims->B, T, m, r are used.  The gain uses the Moore-Penrose pseudo-inverse of
+ * the one-step prediction covariance with numpy's default cutoff 1e-15 * sigma_max
+ * (kalman_smoother.py:92). */
+int kf_smoother(kf_handle* h, const kf_dims* dims,
+                const double* T, const double* R, const double* Q,
+                const double* filt_a, const double* filt_P,
+                double* smooth_a, double* smooth_P,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KF_H_ */

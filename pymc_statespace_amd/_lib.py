@@ -1,0 +1,78 @@
+"""ctypes binding of libkf_hip.so -- the C-ABI declared in include/kf.h.
+
+There is deliberately NO fallback: if the HIP library is missing or does not load,
+importing the product fails loudly (a silent CPU path would void every parity claim).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkf_hip.so")
+
+KF_ABI_VERSION = 1
+
+KF_FILTER = {"standard": 0, "cholesky": 1, "univariate": 2, "single": 3}
+KF_FLAG_MVN_CONST_EXACT = 1 << 0
+KF_FLAG_Y_PER_DRAW = 1 << 1
+
+KF_OK, KF_ERR_ARG, KF_ERR_HIP, KF_ERR_WORKSPACE, KF_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+
+# every symbol include/kf.h declares (tests check the built library exports them all)
+EXPORTS = (
+    "kf_abi_version", "kf_create", "kf_destroy", "kf_last_error", "kf_set_lanes_per_draw",
+    "kf_workspace_bytes", "kf_filter_forward", "kf_filter_backward", "kf_smoother",
+)
+
+
+class KfDims(C.Structure):
+    _fields_ = [
+        ("B", C.c_int64), ("T", C.c_int32), ("p", C.c_int32), ("m", C.c_int32), ("r", C.c_int32),
+        ("filter", C.c_int32), ("flags", C.c_uint32),
+    ]
+
+
+class KfLibraryMissing(ImportError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libkf_hip.so (built by ``__graft_entry__.build()`` / ``make -C csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KfLibraryMissing(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
+            "pymc_statespace_amd/csrc`). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp, dp, ip = C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
+    lib.kf_abi_version.restype = C.c_int
+    lib.kf_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.kf_create.restype = C.c_int
+    lib.kf_destroy.argtypes = [C.c_void_p]
+    lib.kf_destroy.restype = None
+    lib.kf_last_error.argtypes = [C.c_void_p]
+    lib.kf_last_error.restype = C.c_char_p
+    lib.kf_set_lanes_per_draw.argtypes = [C.c_void_p, C.c_int]
+    lib.kf_set_lanes_per_draw.restype = C.c_int
+    lib.kf_workspace_bytes.argtypes = [C.c_void_p, C.POINTER(KfDims), C.POINTER(C.c_size_t)]
+    lib.kf_workspace_bytes.restype = C.c_int
+    lib.kf_filter_forward.argtypes = [vp, C.POINTER(KfDims)] + [dp] * 10 + [dp] * 6 + [ip, vp,
+                                                                                     C.c_size_t, vp]
+    lib.kf_filter_forward.restype = C.c_int
+    lib.kf_filter_backward.argtypes = [vp, C.POINTER(KfDims)] + [dp] * 10 + [dp] * 4 + [dp] * 9 + [
+        vp, C.c_size_t, vp]
+    lib.kf_filter_backward.restype = C.c_int
+    lib.kf_smoother.argtypes = [vp, C.POINTER(KfDims)] + [dp] * 5 + [dp] * 2 + [vp, C.c_size_t, vp]
+    lib.kf_smoother.restype = C.c_int
+    if lib.kf_abi_version() != KF_ABI_VERSION:
+        raise KfLibraryMissing(f"{LIB_PATH}: ABI version {lib.kf_abi_version()} != {KF_ABI_VERSION}")
+    _lib = lib
+    return lib

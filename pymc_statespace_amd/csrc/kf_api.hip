@@ -1,0 +1,176 @@
+// kf_api.hip -- the extern "C" surface declared in include/kf.h: argument checks,
+// kernel selection, launches.  No allocation, no synchronisation, no host copies here
+// (safe to capture in a hipGraph).
+#include <stdlib.h>
+
+#include "kf_internal.h"
+
+static thread_local char g_err[256] = "";
+
+extern "C" int kf_abi_version(void) { return KF_ABI_VERSION; }
+
+extern "C" int kf_create(kf_handle** out, int device) {
+  if (!out) return KF_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    snprintf(g_err, sizeof(g_err), "kf_create: no HIP device (%s)", hipGetErrorString(e));
+    return KF_ERR_HIP;
+  }
+  if (device < 0 || device >= ndev) {
+    snprintf(g_err, sizeof(g_err), "kf_create: device %d out of range [0,%d)", device, ndev);
+    return KF_ERR_ARG;
+  }
+  kf_handle* h = (kf_handle*)calloc(1, sizeof(kf_handle));
+  if (!h) return KF_ERR_ARG;
+  h->device = device;
+  h->lanes_per_draw = 0;
+  const char* env = getenv("KF_LANES_PER_DRAW");
+  if (env) h->lanes_per_draw = atoi(env);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
+  else h->n_cu = 256;
+  h->err[0] = 0;
+  *out = h;
+  return KF_OK;
+}
+
+extern "C" void kf_destroy(kf_handle* h) { free(h); }
+
+extern "C" const char* kf_last_error(const kf_handle* h) { return h ? h->err : g_err; }
+
+extern "C" int kf_set_lanes_per_draw(kf_handle* h, int lanes) {
+  if (!h) return KF_ERR_ARG;
+  if (lanes != 0 && lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64) {
+    KF_SET_ERR(h, "lanes_per_draw must be 0, 4, 8, 16, 32 or 64 (got %d)", lanes);
+    return KF_ERR_ARG;
+  }
+  h->lanes_per_draw = lanes;
+  return KF_OK;
+}
+
+int kf_pick_lanes(const kf_handle* h, int m, long B) {
+  if (h && h->lanes_per_draw) return h->lanes_per_draw;
+  int want = (m * m + 1) / 2;  // ~2 matrix elements per lane
+  int G = 4;
+  while (G < want && G < KF_WAVE) G *= 2;
+  // keep >= 2 wavefronts per SIMD (256 CUs x 4 SIMDs) when the batch is small
+  long n_simd = (h ? h->n_cu : 256) * 4L;
+  while (G < KF_WAVE && B * G / KF_WAVE < 2 * n_simd) G *= 2;
+  return G;
+}
+
+int kf_launch_forward_lds(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
+  if (a.p == 1) return kf_launch_forward_lds_p1(h, a, stream);
+  if (a.p == 2) return kf_launch_forward_lds_p2(h, a, stream);
+  if (a.p <= 4) return kf_launch_forward_lds_p4(h, a, stream);
+  if (a.p <= 8) return kf_launch_forward_lds_p8(h, a, stream);
+  return kf_launch_forward_lds_p0(h, a, stream);
+}
+
+static int check_dims(kf_handle* h, const kf_dims* d, bool need_p) {
+  if (!h) return KF_ERR_ARG;
+  if (!d) {
+    KF_SET_ERR(h, "dims is NULL");
+    return KF_ERR_ARG;
+  }
+  if (d->B < 1 || d->T < 1 || d->m < 1 || d->r < 1 || (need_p && d->p < 1)) {
+    KF_SET_ERR(h, "bad dims: B=%ld T=%d p=%d m=%d r=%d (all must be >= 1)", (long)d->B, d->T, d->p,
+               d->m, d->r);
+    return KF_ERR_ARG;
+  }
+  if (need_p) {
+    if (d->filter < KF_FILTER_STANDARD || d->filter > KF_FILTER_SINGLE) {
+      KF_SET_ERR(h, "unknown filter %d", d->filter);
+      return KF_ERR_ARG;
+    }
+    if (d->filter == KF_FILTER_SINGLE && d->p != 1) {
+      // assert_data_is_1d, pymc_statespace/filters/kalman_filter.py:19,:329
+      KF_SET_ERR(h, "UnivariateTimeSeries filter requires data be at most 1-dimensional");
+      return KF_ERR_ARG;
+    }
+    if (d->p > 255 || d->m > 32767) {
+      KF_SET_ERR(h, "p=%d m=%d out of range", d->p, d->m);
+      return KF_ERR_ARG;
+    }
+  }
+  return KF_OK;
+}
+
+extern "C" int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes) {
+  if (!h || !dims || !bytes) return KF_ERR_ARG;
+  *bytes = 0;  // the LDS-resident kernels keep all scratch on chip
+  return KF_OK;
+}
+
+extern "C" int kf_filter_forward(kf_handle* h, const kf_dims* dims, const double* y, const double* a0,
+                                 const double* P0, const double* T, const double* Z, const double* R,
+                                 const double* H, const double* Q, const double* c, const double* d,
+                                 double* logp, double* ll_obs, double* filt_a, double* pred_a,
+                                 double* filt_P, double* pred_P, int32_t* info, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  (void)workspace;
+  (void)workspace_bytes;
+  int rc = check_dims(h, dims, true);
+  if (rc) return rc;
+  if (!y || !a0 || !P0 || !T || !Z || !R || !H || !Q || !logp) {
+    KF_SET_ERR(h, "kf_filter_forward: y, a0, P0, T, Z, R, H, Q and logp must be non-NULL");
+    return KF_ERR_ARG;
+  }
+  KfFwdArgs a;
+  a.B = dims->B; a.T = dims->T; a.p = dims->p; a.m = dims->m; a.r = dims->r;
+  a.filter = dims->filter; a.flags = dims->flags;
+  a.y = y; a.a0 = a0; a.P0 = P0; a.Tm = T; a.Z = Z; a.R = R; a.H = H; a.Q = Q; a.c = c; a.d = d;
+  a.logp = logp; a.ll_obs = ll_obs; a.filt_a = filt_a; a.pred_a = pred_a; a.filt_P = filt_P;
+  a.pred_P = pred_P; a.info = info;
+  return kf_launch_forward_lds(h, a, (hipStream_t)stream);
+}
+
+extern "C" int kf_filter_backward(kf_handle* h, const kf_dims* dims, const double* y, const double* a0,
+                                  const double* P0, const double* T, const double* Z, const double* R,
+                                  const double* H, const double* Q, const double* c, const double* d,
+                                  const double* pred_a, const double* pred_P, const double* g_logp,
+                                  const double* g_ll_obs, double* g_a0, double* g_P0, double* g_T,
+                                  double* g_Z, double* g_R, double* g_H, double* g_Q, double* g_c,
+                                  double* g_d, void* workspace, size_t workspace_bytes, void* stream) {
+  (void)workspace;
+  (void)workspace_bytes;
+  int rc = check_dims(h, dims, true);
+  if (rc) return rc;
+  if (!y || !a0 || !P0 || !T || !Z || !R || !H || !Q || !pred_a || !pred_P) {
+    KF_SET_ERR(h, "kf_filter_backward: inputs and the predicted tapes must be non-NULL");
+    return KF_ERR_ARG;
+  }
+  if (!g_logp && !g_ll_obs) {
+    KF_SET_ERR(h, "kf_filter_backward: g_logp and g_ll_obs are both NULL");
+    return KF_ERR_ARG;
+  }
+  KfBwdArgs a;
+  a.B = dims->B; a.T = dims->T; a.p = dims->p; a.m = dims->m; a.r = dims->r;
+  a.filter = dims->filter; a.flags = dims->flags;
+  a.y = y; a.a0 = a0; a.P0 = P0; a.Tm = T; a.Z = Z; a.R = R; a.H = H; a.Q = Q; a.c = c; a.d = d;
+  a.pred_a = pred_a; a.pred_P = pred_P; a.g_logp = g_logp; a.g_ll_obs = g_ll_obs;
+  a.g_a0 = g_a0; a.g_P0 = g_P0; a.g_T = g_T; a.g_Z = g_Z; a.g_R = g_R; a.g_H = g_H; a.g_Q = g_Q;
+  a.g_c = g_c; a.g_d = g_d;
+  return kf_launch_backward_lds(h, a, (hipStream_t)stream);
+}
+
+extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, const double* R,
+                           const double* Q, const double* filt_a, const double* filt_P,
+                           double* smooth_a, double* smooth_P, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  (void)workspace;
+  (void)workspace_bytes;
+  int rc = check_dims(h, dims, false);
+  if (rc) return rc;
+  if (!T || !R || !Q || !filt_a || !filt_P || !smooth_a || !smooth_P) {
+    KF_SET_ERR(h, "kf_smoother: all pointers must be non-NULL");
+    return KF_ERR_ARG;
+  }
+  KfSmoothArgs a;
+  a.B = dims->B; a.T = dims->T; a.m = dims->m; a.r = dims->r;
+  a.Tm = T; a.R = R; a.Q = Q; a.filt_a = filt_a; a.filt_P = filt_P;
+  a.smooth_a = smooth_a; a.smooth_P = smooth_P;
+  return kf_launch_smoother_lds(h, a, (hipStream_t)stream);
+}

@@ -1,0 +1,128 @@
+// kf_internal.h -- shared declarations of the HIP implementation behind include/kf.h.
+// gfx950 (MI355X, CDNA4) only: 64-wide wavefronts, 160 KiB LDS per CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/kf.h"
+
+#define KF_WAVE 64
+#define KF_LDS_BYTES_MAX (160 * 1024)
+#define KF_LOG_2PI 1.8378770664093454835606594728112  // log(2*pi), MVN_CONST kalman_filter.py:16
+
+struct kf_handle {
+  int device;
+  int lanes_per_draw;  // 0 = auto
+  int n_cu;
+  char err[512];
+};
+
+// Arguments of the LDS-resident forward kernel (one struct, passed by value).
+struct KfFwdArgs {
+  long B;
+  int T, p, m, r;
+  int filter;
+  unsigned flags;
+  const double* y;
+  const double* a0;
+  const double* P0;
+  const double* Tm;
+  const double* Z;
+  const double* R;
+  const double* H;
+  const double* Q;
+  const double* c;
+  const double* d;
+  double* logp;
+  double* ll_obs;
+  double* filt_a;
+  double* pred_a;
+  double* filt_P;
+  double* pred_P;
+  int32_t* info;
+};
+
+struct KfBwdArgs {
+  long B;
+  int T, p, m, r;
+  int filter;
+  unsigned flags;
+  const double* y;
+  const double* a0;
+  const double* P0;
+  const double* Tm;
+  const double* Z;
+  const double* R;
+  const double* H;
+  const double* Q;
+  const double* c;
+  const double* d;
+  const double* pred_a;
+  const double* pred_P;
+  const double* g_logp;
+  const double* g_ll_obs;
+  double* g_a0;
+  double* g_P0;
+  double* g_T;
+  double* g_Z;
+  double* g_R;
+  double* g_H;
+  double* g_Q;
+  double* g_c;
+  double* g_d;
+};
+
+struct KfSmoothArgs {
+  long B;
+  int T, m, r;
+  const double* Tm;
+  const double* R;
+  const double* Q;
+  const double* filt_a;
+  const double* filt_P;
+  double* smooth_a;
+  double* smooth_P;
+};
+
+// per-draw LDS footprints (in doubles) -- shared by host launchers and kernels
+__host__ __device__ inline int kf_fwd_region_doubles(int m, int p) {
+  int mm = m * m, pm = p * m, pp = p * p;
+  int n = 5 * mm      // Pa, Pb, W, T, RQR
+          + 4 * pm    // Z, M, K, KF
+          + 3 * pp    // H, F, L
+          + 3 * m     // a, af, c
+          + 5 * p + 4;  // d, v, ym, obs, w (+3 scalars of the big-p path)
+  return n | 1;       // odd stride: neighbouring draws start on different LDS banks
+}
+__host__ __device__ inline int kf_pair_table_doubles(int m) {
+  int npair = m * (m + 1) / 2;
+  return (npair + 1) / 2 + 1;
+}
+
+// one object per KF_PMAX (kf_forward_lds.hip compiled 5x); kf_api.hip dispatches on p
+int kf_launch_forward_lds_p0(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward_lds_p1(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward_lds_p2(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward_lds_p4(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward_lds_p8(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward_lds(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_backward_lds(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_smoother_lds(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream);
+int kf_pick_lanes(const kf_handle* h, int m, long B);
+
+#define KF_SET_ERR(h, ...)                                 \
+  do {                                                     \
+    if (h) snprintf((h)->err, sizeof((h)->err), __VA_ARGS__); \
+  } while (0)
+
+#define KF_HIP_CHECK(h, expr)                                                     \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      KF_SET_ERR(h, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return KF_ERR_HIP;                                                          \
+    }                                                                             \
+  } while (0)

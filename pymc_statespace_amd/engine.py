@@ -1,0 +1,234 @@
+"""Host-side driver of the C-ABI (include/kf.h): torch tensors in HBM in, torch tensors out.
+
+torch is plumbing here -- device memory, the current HIP stream, ``torch.distributed`` -- the
+arithmetic is entirely in libkf_hip.so.  All tensors are fp64, contiguous, on the engine's
+device, with the batch-of-draws axis leading (layouts: include/kf.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+FILTER_TYPES = ("standard", "cholesky", "univariate", "single")
+
+
+class KalmanError(RuntimeError):
+    """Argument / HIP error reported by the library (negative return code)."""
+
+
+@dataclass
+class FilterResult:
+    logp: torch.Tensor                       # (B,)
+    ll_obs: Optional[torch.Tensor]           # (B,n)
+    filtered_states: Optional[torch.Tensor]  # (B,n,m)
+    predicted_states: Optional[torch.Tensor]  # (B,n+1,m)
+    filtered_covs: Optional[torch.Tensor]    # (B,n,m,m)
+    predicted_covs: Optional[torch.Tensor]   # (B,n+1,m,m)
+    info: torch.Tensor                       # (B,) int32
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class KalmanEngine:
+    """One ``kf_handle`` bound to one GPU."""
+
+    def __init__(self, device=None, lanes_per_draw: int = 0):
+        if not torch.cuda.is_available():
+            raise KalmanError("KalmanEngine needs a HIP device (torch.cuda.is_available() is False); "
+                              "there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        if self.device.type != "cuda":
+            raise KalmanError(f"device must be a cuda/HIP device, got {self.device}")
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        h = C.c_void_p()
+        rc = self.lib.kf_create(C.byref(h), idx)
+        if rc != 0:
+            raise KalmanError(f"kf_create failed ({rc}): {self.lib.kf_last_error(None).decode()}")
+        self._h = h
+        if lanes_per_draw:
+            self.set_lanes_per_draw(lanes_per_draw)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self.lib.kf_destroy(h)
+            self._h = None
+
+    # ------------------------------------------------------------------ utils
+    def _check(self, rc, what):
+        if rc != 0:
+            raise KalmanError(f"{what} failed ({rc}): {self.lib.kf_last_error(self._h).decode()}")
+
+    def set_lanes_per_draw(self, lanes: int):
+        self._check(self.lib.kf_set_lanes_per_draw(self._h, int(lanes)), "kf_set_lanes_per_draw")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def to_device(self, x, shape=None):
+        if x is None:
+            return None
+        if isinstance(x, torch.Tensor):
+            t = x.to(device=self.device, dtype=torch.float64)
+        else:
+            t = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64), device=self.device)
+        t = t.contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    @staticmethod
+    def _dims(B, n, p, m, r, filter_type="standard", mvn_const="reference", y_per_draw=False):
+        if filter_type not in FILTER_TYPES:
+            raise NotImplementedError(
+                "The following are valid filter types: " + ", ".join(FILTER_TYPES))
+        flags = 0
+        if mvn_const == "exact":
+            flags |= _lib.KF_FLAG_MVN_CONST_EXACT
+        elif mvn_const != "reference":
+            raise ValueError("mvn_const must be 'reference' or 'exact'")
+        if y_per_draw:
+            flags |= _lib.KF_FLAG_Y_PER_DRAW
+        return _lib.KfDims(B, n, p, m, r, _lib.KF_FILTER[filter_type], flags)
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, filter_type="standard",
+                mvn_const="reference", store_ll_obs=True, store_filtered=True,
+                store_predicted=True, out: Optional[FilterResult] = None) -> FilterResult:
+        """kf_filter_forward.  y (n,p) shared or (B,n,p); a0 (B,m); P0,T (B,m,m); Z (B,p,m);
+        R (B,m,r); H (B,p,p); Q (B,r,r); c (B,m); d (B,p)."""
+        T = self.to_device(T)
+        if T.ndim != 3 or T.shape[1] != T.shape[2]:
+            raise ValueError(f"T must be (B,m,m), got {tuple(T.shape)}")
+        B, m = T.shape[0], T.shape[1]
+        Z = self.to_device(Z)
+        if Z.ndim != 3 or Z.shape[0] != B or Z.shape[2] != m:
+            raise ValueError(f"Z must be (B,p,m) = ({B},p,{m}), got {tuple(Z.shape)}")
+        p = Z.shape[1]
+        R = self.to_device(R)
+        if R.ndim != 3 or R.shape[0] != B or R.shape[1] != m:
+            raise ValueError(f"R must be (B,m,r), got {tuple(R.shape)}")
+        r = R.shape[2]
+        y = self.to_device(y)
+        y_per_draw = y.ndim == 3
+        if y.ndim not in (2, 3) or y.shape[-1] != p or (y_per_draw and y.shape[0] != B):
+            raise ValueError(f"y must be (n,{p}) or ({B},n,{p}), got {tuple(y.shape)}")
+        n = y.shape[-2]
+        a0 = self.to_device(a0, (B, m))
+        P0 = self.to_device(P0, (B, m, m))
+        H = self.to_device(H, (B, p, p))
+        Q = self.to_device(Q, (B, r, r))
+        c = self.to_device(c, (B, m)) if c is not None else None
+        d = self.to_device(d, (B, p)) if d is not None else None
+        if filter_type == "single" and p != 1:
+            # assert_data_is_1d, reference filters/kalman_filter.py:19,:329
+            raise AssertionError("UnivariateTimeSeries filter requires data be at most 1-dimensional")
+
+        dims = self._dims(B, n, p, m, r, filter_type, mvn_const, y_per_draw)
+        dev, f64 = self.device, torch.float64
+        if out is None:
+            out = FilterResult(
+                logp=torch.empty(B, device=dev, dtype=f64),
+                ll_obs=torch.empty(B, n, device=dev, dtype=f64) if store_ll_obs else None,
+                filtered_states=torch.empty(B, n, m, device=dev, dtype=f64) if store_filtered else None,
+                predicted_states=torch.empty(B, n + 1, m, device=dev, dtype=f64) if store_predicted else None,
+                filtered_covs=torch.empty(B, n, m, m, device=dev, dtype=f64) if store_filtered else None,
+                predicted_covs=torch.empty(B, n + 1, m, m, device=dev, dtype=f64) if store_predicted else None,
+                info=torch.empty(B, device=dev, dtype=torch.int32),
+            )
+        rc = self.lib.kf_filter_forward(
+            self._h, C.byref(dims), _ptr(y), _ptr(a0), _ptr(P0), _ptr(T), _ptr(Z), _ptr(R), _ptr(H),
+            _ptr(Q), _ptr(c), _ptr(d), _ptr(out.logp), _ptr(out.ll_obs), _ptr(out.filtered_states),
+            _ptr(out.predicted_states), _ptr(out.filtered_covs), _ptr(out.predicted_covs),
+            _ptr(out.info), None, 0, self._stream())
+        self._check(rc, "kf_filter_forward")
+        return out
+
+    # --------------------------------------------------------------- backward
+    def backward(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, predicted_states,
+                 predicted_covs, g_logp=None, g_ll_obs=None, filter_type="standard",
+                 mvn_const="reference", want_cd=False):
+        """kf_filter_backward -> dict of per-draw gradients (a0,P0,T,Z,R,H,Q[,c,d])."""
+        T = self.to_device(T)
+        B, m = T.shape[0], T.shape[1]
+        Z = self.to_device(Z)
+        p = Z.shape[1]
+        R = self.to_device(R)
+        r = R.shape[2]
+        y = self.to_device(y)
+        y_per_draw = y.ndim == 3
+        n = y.shape[-2]
+        a0 = self.to_device(a0, (B, m))
+        P0 = self.to_device(P0, (B, m, m))
+        H = self.to_device(H, (B, p, p))
+        Q = self.to_device(Q, (B, r, r))
+        c = self.to_device(c, (B, m)) if c is not None else None
+        d = self.to_device(d, (B, p)) if d is not None else None
+        pa = self.to_device(predicted_states, (B, n + 1, m))
+        pP = self.to_device(predicted_covs, (B, n + 1, m, m))
+        g_logp = self.to_device(g_logp, (B,)) if g_logp is not None else None
+        g_ll = self.to_device(g_ll_obs, (B, n)) if g_ll_obs is not None else None
+        dims = self._dims(B, n, p, m, r, filter_type, mvn_const, y_per_draw)
+        dev, f64 = self.device, torch.float64
+        g = dict(
+            a0=torch.empty(B, m, device=dev, dtype=f64), P0=torch.empty(B, m, m, device=dev, dtype=f64),
+            T=torch.empty(B, m, m, device=dev, dtype=f64), Z=torch.empty(B, p, m, device=dev, dtype=f64),
+            R=torch.empty(B, m, r, device=dev, dtype=f64), H=torch.empty(B, p, p, device=dev, dtype=f64),
+            Q=torch.empty(B, r, r, device=dev, dtype=f64),
+        )
+        if want_cd:
+            g["c"] = torch.empty(B, m, device=dev, dtype=f64)
+            g["d"] = torch.empty(B, p, device=dev, dtype=f64)
+        rc = self.lib.kf_filter_backward(
+            self._h, C.byref(dims), _ptr(y), _ptr(a0), _ptr(P0), _ptr(T), _ptr(Z), _ptr(R), _ptr(H),
+            _ptr(Q), _ptr(c), _ptr(d), _ptr(pa), _ptr(pP), _ptr(g_logp), _ptr(g_ll),
+            _ptr(g["a0"]), _ptr(g["P0"]), _ptr(g["T"]), _ptr(g["Z"]), _ptr(g["R"]), _ptr(g["H"]),
+            _ptr(g["Q"]), _ptr(g.get("c")), _ptr(g.get("d")), None, 0, self._stream())
+        self._check(rc, "kf_filter_backward")
+        return g
+
+    # --------------------------------------------------------------- smoother
+    def smooth(self, T, R, Q, filtered_states, filtered_covs):
+        """kf_smoother -> (smoothed_states (B,n,m), smoothed_covs (B,n,m,m))."""
+        T = self.to_device(T)
+        B, m = T.shape[0], T.shape[1]
+        R = self.to_device(R)
+        r = R.shape[2]
+        Q = self.to_device(Q, (B, r, r))
+        fa = self.to_device(filtered_states)
+        n = fa.shape[1]
+        fa = self.to_device(fa, (B, n, m))
+        fP = self.to_device(filtered_covs, (B, n, m, m))
+        dims = self._dims(B, n, 1, m, r)
+        sa = torch.empty_like(fa)
+        sP = torch.empty_like(fP)
+        rc = self.lib.kf_smoother(self._h, C.byref(dims), _ptr(T), _ptr(R), _ptr(Q), _ptr(fa),
+                                  _ptr(fP), _ptr(sa), _ptr(sP), None, 0, self._stream())
+        self._check(rc, "kf_smoother")
+        return sa, sP
+
+
+_engines = {}
+
+
+def get_engine(device=None) -> KalmanEngine:
+    """Process-wide engine per device (one kf_handle per (process, device))."""
+    if not torch.cuda.is_available():
+        raise KalmanError("no HIP device visible; the MI355X path has no CPU fallback")
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if idx not in _engines:
+        _engines[idx] = KalmanEngine(torch.device("cuda", idx))
+    return _engines[idx]

@@ -1,0 +1,215 @@
+"""Host-side mirror of ``pymc_statespace.filters`` backed by the MI355X kernels.
+
+Same class names, same ``build_graph`` signatures and output order as the reference
+(reference pymc_statespace/filters/__init__.py:1-17, kalman_filter.py:126-163,
+kalman_smoother.py:56-85), so the classes slot into ``FILTER_FACTORY``
+(core/statespace.py:25-31).  Two ways in:
+
+* ``flt.build_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, mode=None)`` -- symbolic,
+  needs PyTensor; returns the reference's six TensorVariables, computed by one Op whose
+  ``perform``/``grad`` call the C-ABI (see ``op.py``).
+* ``flt(data, a0, P0, T, Z, R, H, Q, c=None, d=None)`` -- eager.  numpy in -> numpy out,
+  torch(HBM) in -> torch out.  Per-draw (2-D) matrices give the reference's shapes; matrices
+  with one extra LEADING axis B are a batch of draws and give B-leading outputs.
+
+Reference behaviours kept: ``ValueError`` for matrices that are not 2-D/3-D
+(filters/utilities.py:16-18), ``AssertionError`` for SingleTimeseriesFilter with p > 1
+(kalman_filter.py:19,:329), ``numpy.linalg.LinAlgError`` when F is not positive definite
+(what SciPy's ``dposv``/``dpotrf`` raise inside the reference graph).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .engine import KalmanEngine, get_engine
+
+MVN_CONST = float(np.log(2.0 * np.pi))
+PARAM_NAMES = ["c", "d", "T", "Z", "R", "H", "Q"]  # reference kalman_filter.py:17
+
+
+def _is_torch(*xs):
+    return any(isinstance(x, torch.Tensor) for x in xs if x is not None)
+
+
+def _np_or_t(x):
+    return x if isinstance(x, torch.Tensor) else np.asarray(x, dtype=np.float64)
+
+
+def _check_ndim(params, names, batched):
+    """split_vars_into_seq_and_nonseq, reference filters/utilities.py:1-20.
+
+    Eager calls interpret one extra leading axis as the batch of draws; a time-varying
+    (time-major 3-D) system is a later row of the scope table."""
+    for prm, name in zip(params, names):
+        nd = prm.ndim - (1 if batched else 0)
+        if nd == 2:
+            continue
+        if nd == 3:
+            raise NotImplementedError(
+                f"Matrix {name} is time varying (3-D); the MI355X path supports static system "
+                "matrices only")
+        raise ValueError(
+            f"Matrix {name} has {prm.ndim}, it should either 2 (static) or 3 (time varying).")
+
+
+class BaseFilter:
+    filter_type: str = ""
+
+    def __init__(self, mode=None, mvn_const: str = "reference", on_error: str = "raise",
+                 engine: Optional[KalmanEngine] = None):
+        self.mode = mode
+        self.mvn_const = mvn_const
+        self.on_error = on_error
+        self._engine = engine
+        self.seq_names: List[str] = []
+        self.non_seq_names: List[str] = list(PARAM_NAMES)
+
+    @property
+    def engine(self) -> KalmanEngine:
+        if self._engine is None:
+            self._engine = get_engine()
+        return self._engine
+
+    # -- symbolic (PyTensor) ---------------------------------------------------------------
+    def build_graph(self, data, a0, P0, T, Z, R, H, Q, c=None, d=None, mode=None):
+        """Reference signature (kalman_filter.py:126-128).  Returns
+        [filtered_states, predicted_states, filtered_covariances, predicted_covariances,
+         log_likelihood, ll_obs]."""
+        from .op import kalman_filter_graph  # imports pytensor; fails loudly without it
+
+        self.mode = mode
+        return kalman_filter_graph(data, a0, P0, T, Z, R, H, Q, c=c, d=d,
+                                   filter_type=self.filter_type, mvn_const=self.mvn_const)
+
+    def update(self, *args, **kwargs):
+        # reference BaseFilter.update raises (kalman_filter.py:225-229); the fused kernels
+        # have no separately callable update step.
+        raise NotImplementedError
+
+    # -- eager ---------------------------------------------------------------------------------
+    def __call__(self, data, a0, P0, T, Z, R, H, Q, c=None, d=None, *, outputs="all"):
+        """Evaluate on the GPU.  Returns the reference's list
+        [filtered_states, predicted_states, filtered_covs, predicted_covs, logp, ll_obs]
+        (or only ``[logp]`` for ``outputs="logp"``)."""
+        as_torch = _is_torch(data, a0, P0, T, Z, R, H, Q)
+        T_, Z_, R_, H_, Q_ = map(_np_or_t, (T, Z, R, H, Q))
+        batched = T_.ndim == 3 and P0 is not None and _np_or_t(P0).ndim == 3
+        _check_ndim([T_, Z_, R_, H_, Q_], ["T", "Z", "R", "H", "Q"], batched)
+
+        def lead(x, core_ndim):
+            x = _np_or_t(x)
+            if x.ndim > core_ndim and x.shape[-1] == 1 and core_ndim == 1:
+                x = x[..., 0]  # (m,1) column vectors of the reference
+            return x if batched else x[None]
+
+        data_ = _np_or_t(data)
+        p = Z_.shape[-2]
+        if data_.ndim == 3 and data_.shape[-1] == 1 and data_.shape[-2] == p:
+            data_ = data_[..., 0]  # reference data layout (n,p,1)
+        if data_.ndim == 2 and data_.shape[1] != p:
+            raise ValueError(f"data has {data_.shape[1]} columns but Z has {p} rows")
+
+        eng = self.engine
+        res = eng.forward(
+            data_, lead(a0, 1), lead(P0, 2), lead(T_, 2), lead(Z_, 2), lead(R_, 2), lead(H_, 2),
+            lead(Q_, 2), None if c is None else lead(c, 1), None if d is None else lead(d, 1),
+            filter_type=self.filter_type, mvn_const=self.mvn_const,
+            store_ll_obs=outputs == "all", store_filtered=outputs == "all",
+            store_predicted=outputs == "all")
+        info = res.info.cpu().numpy()
+        if self.on_error == "raise" and np.any(info != 0):
+            bad = int(np.flatnonzero(info)[0])
+            raise np.linalg.LinAlgError(
+                f"draw {bad}: {info[bad] & 0xff}-th leading minor of the innovation covariance F "
+                f"not positive definite at time step {(info[bad] >> 8) - 1}")
+
+        def fin(x, col=False):
+            if col:
+                x = x[..., None]
+            if not batched:
+                x = x[0]
+            return x if as_torch else x.cpu().numpy()
+
+        if outputs != "all":
+            return [fin(res.logp)]
+        return [fin(res.filtered_states, True), fin(res.predicted_states, True),
+                fin(res.filtered_covs), fin(res.predicted_covs), fin(res.logp), fin(res.ll_obs)]
+
+
+class StandardFilter(BaseFilter):
+    """reference kalman_filter.py:255-284"""
+    filter_type = "standard"
+
+
+class CholeskyFilter(BaseFilter):
+    """reference kalman_filter.py:287-318 (the L^-T solve is the mathematically correct one;
+    the reference's wrong-triangle solve for p > 1 is NOT reproduced -- SURVEY.md A8)"""
+    filter_type = "cholesky"
+
+
+class SingleTimeseriesFilter(BaseFilter):
+    """reference kalman_filter.py:321-351"""
+    filter_type = "single"
+
+
+class UnivariateFilter(BaseFilter):
+    """reference kalman_filter.py:444-505"""
+    filter_type = "univariate"
+
+
+class KalmanSmoother:
+    """reference kalman_smoother.py:11-104"""
+
+    def __init__(self, mode: Optional[str] = None, engine: Optional[KalmanEngine] = None):
+        self.mode = mode
+        self._engine = engine
+        self.seq_names: List[str] = []
+        self.non_seq_names: List[str] = ["T", "R", "Q"]
+
+    @property
+    def engine(self) -> KalmanEngine:
+        if self._engine is None:
+            self._engine = get_engine()
+        return self._engine
+
+    def build_graph(self, T, R, Q, filtered_states, filtered_covariances, mode=None):
+        from .op import kalman_smoother_graph
+
+        self.mode = mode
+        return kalman_smoother_graph(T, R, Q, filtered_states, filtered_covariances)
+
+    def __call__(self, T, R, Q, filtered_states, filtered_covariances):
+        as_torch = _is_torch(T, R, Q, filtered_states, filtered_covariances)
+        T_, R_, Q_ = map(_np_or_t, (T, R, Q))
+        fP = _np_or_t(filtered_covariances)
+        fa = _np_or_t(filtered_states)
+        batched = fP.ndim == 4
+        _check_ndim([T_, R_, Q_], ["T", "R", "Q"], batched)
+        m = T_.shape[-1]
+        if fa.shape[-1] == 1 and fa.ndim >= 2 and fa.shape[-2] == m:
+            fa = fa[..., 0]
+        if not batched:
+            T_, R_, Q_, fa, fP = T_[None], R_[None], Q_[None], fa[None], fP[None]
+        sa, sP = self.engine.smooth(T_, R_, Q_, fa, fP)
+        sa = sa[..., None]
+        if not batched:
+            sa, sP = sa[0], sP[0]
+        if as_torch:
+            return sa, sP
+        return sa.cpu().numpy(), sP.cpu().numpy()
+
+
+# the reference's FILTER_FACTORY keys (core/statespace.py:25-31); "steady_state" is out of
+# scope
+FILTER_FACTORY = {
+    "standard": StandardFilter,
+    "univariate": UnivariateFilter,
+    "single": SingleTimeseriesFilter,
+    "cholesky": CholeskyFilter,
+}
+
+__all__ = ["StandardFilter", "UnivariateFilter", "KalmanSmoother", "SingleTimeseriesFilter",
+           "CholeskyFilter", "FILTER_FACTORY", "BaseFilter"]
