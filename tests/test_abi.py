@@ -1,0 +1,69 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/kf.h declares, and rejects bad arguments without touching a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "kf.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(kf_[a-z_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    from pymc_statespace_amd import _lib
+
+    assert _header_functions() == sorted(_lib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    from pymc_statespace_amd import _lib
+
+    lib = _lib.load()
+    for name in _header_functions():
+        assert hasattr(lib, name), f"libkf_hip.so does not export {name}"
+    assert lib.kf_abi_version() == _lib.KF_ABI_VERSION
+
+
+def test_dims_struct_layout_matches_header():
+    from pymc_statespace_amd._lib import KfDims
+
+    # int64 B; int32 T,p,m,r,filter; uint32 flags  -> 8 + 6*4 = 32 bytes, no padding
+    assert C.sizeof(KfDims) == 32
+    assert KfDims.B.offset == 0 and KfDims.T.offset == 8 and KfDims.flags.offset == 28
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from pymc_statespace_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libkf_hip.so"))
+    with pytest.raises(_lib.KfLibraryMissing, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import torch
+
+    from pymc_statespace_amd import KalmanEngine, KalmanError
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(KalmanError, match="no CPU fallback"):
+        KalmanEngine()
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under pymc_statespace_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "pymc_statespace_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "kf_oracle" not in txt, f

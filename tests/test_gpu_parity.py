@@ -1,0 +1,284 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the oracle.
+
+Structure mirrors the reference's tests/test_kalman_filter.py (shape contract, missing data,
+statsmodels parity on Nile, last smoothed == last filtered), plus what the reference never
+pinned: p > 1, batches of draws, full BASELINE sizes.
+
+Tolerances (fp64, stated per BASELINE.json north_star):
+  * |dlogp| < 1e-8 absolute on the standardized synthetic workloads (|logp| ~ 1e2..1e4);
+  * rel 1e-9 on the raw-Nile fixtures (P0 = 1e6 I, |logp| ~ 6e5: two fp64 codes differ ~1e-10);
+  * tapes: rtol = atol = 1e-9.
+"""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import workloads as W
+from conftest import golden_files, h_is_diagonal, load_golden
+from oracle import c_oracle as co
+from oracle import kalman_numpy as kn
+
+pytestmark = pytest.mark.gpu
+
+FILTERS = ["standard", "cholesky", "univariate", "single"]
+TAPES = ["filtered_states", "predicted_states", "filtered_covs", "predicted_covs", "ll_obs"]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    from pymc_statespace_amd import KalmanEngine
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return KalmanEngine()
+
+
+def _args(w, y=None):
+    return (w["y"] if y is None else y, w["a0"], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"])
+
+
+def _np(res):
+    return dict(logp=res.logp.cpu().numpy(), ll_obs=res.ll_obs.cpu().numpy(),
+                filtered_states=res.filtered_states.cpu().numpy(),
+                predicted_states=res.predicted_states.cpu().numpy(),
+                filtered_covs=res.filtered_covs.cpu().numpy(),
+                predicted_covs=res.predicted_covs.cpu().numpy(), info=res.info.cpu().numpy())
+
+
+# ----------------------------------------------------------------------------------------------
+# golden vectors (statsmodels) -- reference tests/test_kalman_filter.py:226-241
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_files())
+@pytest.mark.parametrize("ft", FILTERS)
+def test_hip_matches_statsmodels_golden(eng, name, ft):
+    g = load_golden(name)
+    p = g["Z"].shape[1]
+    if ft == "single" and p != 1:
+        with pytest.raises(AssertionError, match="at most 1-dimensional"):
+            eng.forward(g["y"], g["a0"], g["P0"], g["T"], g["Z"], g["R"], g["H"], g["Q"],
+                        filter_type=ft)
+        return
+    if ft == "univariate" and not h_is_diagonal(g["H"]):
+        pytest.skip("UnivariateFilter uses diag(H) only (reference kalman_filter.py:493)")
+    out = _np(eng.forward(g["y"], g["a0"], g["P0"], g["T"], g["Z"], g["R"], g["H"], g["Q"],
+                          filter_type=ft, mvn_const="exact"))
+    tol = 2e-9 if name.startswith("nile_llt") else 1e-10
+    for ours, theirs in [("filtered_states", "filtered_state"), ("predicted_states", "predicted_state"),
+                         ("filtered_covs", "filtered_state_cov"),
+                         ("predicted_covs", "predicted_state_cov"), ("ll_obs", "llf_obs")]:
+        assert_allclose(out[ours], g[theirs], rtol=tol, atol=tol, err_msg=f"{name} {ft} {ours}")
+    assert_allclose(out["logp"], g["llf_obs"].sum(-1), rtol=tol, atol=1e-8)
+    assert not out["info"].any()
+
+
+def test_known_answers(eng):
+    """Nile LLT -606737.514026..., local level -641.5855784594156."""
+    g = load_golden("nile_llt.npz")
+    out = _np(eng.forward(g["y"], g["a0"], g["P0"], g["T"], g["Z"], g["R"], g["H"], g["Q"]))
+    assert_allclose(out["logp"][0], -606737.514026642, rtol=1e-10)
+    assert_allclose(out["filtered_states"][0, -1], [730.6659435031556, -17.64853509699647], rtol=1e-8)
+    g = load_golden("nile_local_level.npz")
+    out = _np(eng.forward(g["y"], g["a0"], g["P0"], g["T"], g["Z"], g["R"], g["H"], g["Q"]))
+    assert_allclose(out["logp"][0], -641.5855784594156, rtol=1e-13)
+    assert_allclose(out["filtered_states"][0, -1, 0], 798.3702926083578, rtol=1e-12)
+    assert_allclose(out["filtered_covs"][0, -1, 0, 0], 4032.1579418087827, rtol=1e-11)
+
+
+# ----------------------------------------------------------------------------------------------
+# HIP vs the numpy oracle on seeded inputs, every filter, both constant conventions
+# ----------------------------------------------------------------------------------------------
+CASES = {
+    "c2_arma11": lambda: W.arma11(B=130, n=200),
+    "headline_m10": lambda: W.structural(B=67, n=150),
+    "c4_varmax_m10": lambda: W.varmax(B=11, n=80, order=(2, 0)),
+    "c4_varmax_m15": lambda: W.varmax(B=9, n=60, order=(2, 1)),
+    "dense_p3m4": lambda: W.random_dense(19, 60, 3, 4, 2, seed=3),
+    "dense_p2m6_fullH": lambda: W.random_dense(7, 40, 2, 6, 3, seed=4, h_diag=False),
+    "dense_p9m12": lambda: W.random_dense(5, 30, 9, 12, 3, seed=5),
+    "dense_p1m33": lambda: W.random_dense(3, 25, 1, 33, 2, seed=7),
+    "dense_p1m1": lambda: W.random_dense(70, 30, 1, 1, 1, seed=8),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("ft", FILTERS)
+@pytest.mark.parametrize("mvn", ["reference", "exact"])
+def test_hip_matches_oracle(eng, case, ft, mvn):
+    w = CASES[case]()
+    if ft == "single" and w["p"] != 1:
+        pytest.skip("single is p == 1 only")
+    if ft == "univariate" and not h_is_diagonal(w["H"]):
+        pytest.skip("univariate uses diag(H) only")
+    out = _np(eng.forward(*_args(w), filter_type=ft, mvn_const=mvn))
+    ref = kn.kalman_filter(*_args(w), filter_type=ft, mvn_const=mvn, cholesky_triangle="correct")
+    assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8
+    for k in TAPES:
+        assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=f"{case} {ft} {k}")
+    assert_allclose(out["logp"], out["ll_obs"].sum(-1), rtol=1e-13, atol=1e-10)
+    assert_allclose(out["predicted_states"][:, 0], w["a0"])
+    assert_allclose(out["predicted_covs"][:, 0], w["P0"])
+
+
+@pytest.mark.parametrize("ft", ["standard", "cholesky", "univariate"])
+def test_missing_data_rows_and_cells(eng, ft):
+    """Whole-row NaN (what the reference tests) and single-cell NaN (row deletion)."""
+    w = W.random_dense(6, 40, 3, 4, 2, seed=8)
+    y = w["y"].copy()
+    y[[0, 3, 17, 39]] = np.nan
+    y[5, 0] = np.nan
+    y[9, 1:] = np.nan
+    out = _np(eng.forward(*_args(w, y), filter_type=ft, mvn_const="exact"))
+    ref = kn.kalman_filter(*_args(w, y), filter_type=ft, mvn_const="exact",
+                           cholesky_triangle="correct", partial_missing="delete")
+    assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8
+    for k in TAPES:
+        assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9)
+        assert not np.isnan(out[k]).any()
+    assert np.all(out["ll_obs"][:, [0, 3, 17, 39]] == 0.0)
+
+
+def test_per_draw_data_flag(eng):
+    w = W.structural(B=9, n=40)
+    rng = np.random.default_rng(0)
+    yb = w["y"][None] + 0.1 * rng.standard_normal((9, 40, 1))
+    out = _np(eng.forward(*_args(w, yb)))
+    for b in range(9):
+        ref = kn.kalman_filter(yb[b], w["a0"][b], w["P0"][b], w["T"][b], w["Z"][b], w["R"][b],
+                               w["H"][b], w["Q"][b])
+        assert abs(out["logp"][b] - ref["logp"][0]) < 1e-9
+
+
+def test_intercepts_c_d(eng):
+    w = W.random_dense(5, 30, 2, 4, 2, seed=31)
+    rng = np.random.default_rng(1)
+    c = 0.1 * rng.standard_normal((5, 4))
+    d = 0.1 * rng.standard_normal((5, 2))
+    out = _np(eng.forward(*_args(w), c=c, d=d))
+    ref = kn.kalman_filter(*_args(w), c=c, d=d)
+    assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-9
+    assert_allclose(out["predicted_states"], ref["predicted_states"], rtol=1e-10, atol=1e-10)
+
+
+# ----------------------------------------------------------------------------------------------
+# reference interface mirror -- tests/test_kalman_filter.py:66-99,159-222
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ft", FILTERS)
+@pytest.mark.parametrize("pmrn", [(1, 1, 1, 10), (1, 2, 2, 10), (1, 5, 2, 10), (1, 5, 1, 10),
+                                  (5, 5, 1, 10)])
+def test_reference_shapes_and_errors(ft, pmrn):
+    from pymc_statespace_amd.filters import FILTER_FACTORY
+
+    p, m, r, n = pmrn
+    w = W.reference_test_inputs(p, m, r, n)
+    inputs = (w["y"][..., None], w["a0"][0][:, None], w["P0"][0], w["T"][0], w["Z"][0], w["R"][0],
+              w["H"][0], w["Q"][0])
+    flt = FILTER_FACTORY[ft]()
+    if ft == "single" and p > 1:
+        with pytest.raises(AssertionError,
+                           match="UnivariateTimeSeries filter requires data be at most 1-dimensional"):
+            flt(*inputs)
+        return
+    outs = flt(*inputs)
+    shapes = [(n, m, 1), (n + 1, m, 1), (n, m, m), (n + 1, m, m), (), (n,)]
+    for o, s in zip(outs, shapes):
+        assert np.shape(o) == s
+    ref = kn.reference_outputs(*inputs, filter_type=ft)
+    assert_allclose(outs[4], ref[6], rtol=1e-11)
+    assert_allclose(outs[0], ref[0], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("ft", FILTERS)
+@pytest.mark.parametrize("p", [1, 5])
+def test_missing_row_gives_no_nan(ft, p):
+    from pymc_statespace_amd.filters import FILTER_FACTORY
+
+    if ft == "single" and p > 1:
+        pytest.skip("single is p == 1 only")
+    w = W.reference_test_inputs(p, 5, 1, 10, missing_rows=(4,))
+    outs = FILTER_FACTORY[ft]()(w["y"][..., None], w["a0"][0][:, None], w["P0"][0], w["T"][0],
+                                w["Z"][0], w["R"][0], w["H"][0], w["Q"][0])
+    for o in outs:
+        assert not np.any(np.isnan(o))
+
+
+def test_bad_ndim_raises_value_error():
+    from pymc_statespace_amd.filters import StandardFilter
+
+    w = W.reference_test_inputs(1, 2, 1, 5)
+    with pytest.raises(ValueError, match="it should either 2 .static. or 3 .time varying."):
+        StandardFilter()(w["y"], w["a0"][0], w["P0"][0], w["T"][0], w["Z"][0], w["R"][0],
+                         w["H"][0], w["Q"][0][0])
+
+
+def test_not_positive_definite_raises_linalgerror():
+    from pymc_statespace_amd.filters import StandardFilter
+
+    w = W.reference_test_inputs(1, 2, 1, 5)
+    H = np.array([[-10.0]])
+    with pytest.raises(np.linalg.LinAlgError, match="not positive definite at time step 0"):
+        StandardFilter()(w["y"], w["a0"][0], w["P0"][0], w["T"][0], w["Z"][0], w["R"][0], H,
+                         w["Q"][0])
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: C oracle on a sample + size-independent properties
+# ----------------------------------------------------------------------------------------------
+FULL = {
+    "c2": dict(ft="standard", sample=256),
+    "headline": dict(ft="standard", sample=96),
+    "c4_m10": dict(ft="univariate", sample=48),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FULL))
+def test_full_size_logp_and_properties(eng, name):
+    import torch
+
+    cfg = FULL[name]
+    w = W.WORKLOADS[name]()
+    B, n, m = w["B"], w["n"], w["m"]
+    dev = [eng.to_device(x) for x in _args(w)]
+    res = eng.forward(*dev, filter_type=cfg["ft"], mvn_const="exact", store_filtered=False,
+                      store_predicted=False)
+    torch.cuda.synchronize()
+    logp = res.logp.cpu().numpy()
+    assert np.isfinite(logp).all() and not res.info.cpu().numpy().any()
+    # (1) parity on a bounded sample of draws spread over the batch, |dlogp| < 1e-8
+    idx = np.linspace(0, B - 1, cfg["sample"]).astype(int)
+    ref = co.kalman_filter(w["y"], *[w[k][idx] for k in ("a0", "P0", "T", "Z", "R", "H", "Q")],
+                           filter_type=cfg["ft"], mvn_const="exact", full=False)
+    scale = np.maximum(1.0, np.abs(ref["logp"]) / 1e4)  # |logp| reaches 1e5 in c2 (sigma -> 0.05)
+    assert np.max(np.abs(logp[idx] - ref["logp"]) / scale) < 1e-8
+    # (2) logp == sum of ll_obs
+    assert_allclose(logp, res.ll_obs.sum(-1).cpu().numpy(), rtol=1e-12, atol=1e-9)
+    # (3) permuting the draws permutes the outputs (bit for bit) -- batch independence
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).to(dev[1].device)
+    res_p = eng.forward(dev[0], *[x[perm].contiguous() for x in dev[1:]], filter_type=cfg["ft"],
+                        mvn_const="exact", store_filtered=False, store_predicted=False)
+    assert torch.equal(res_p.logp, res.logp[perm])
+    # (4) lanes-per-draw is a pure scheduling knob: same bits
+    eng.set_lanes_per_draw(16 if m <= 4 else 32)
+    res_g = eng.forward(*dev, filter_type=cfg["ft"], mvn_const="exact", store_filtered=False,
+                        store_predicted=False)
+    eng.set_lanes_per_draw(0)
+    assert torch.equal(res_g.logp, res.logp)
+
+
+def test_full_size_tapes_headline(eng):
+    """Full-tape run at the headline size: tapes of sampled draws vs the C oracle."""
+    import torch
+
+    w = W.WORKLOADS["headline"]()
+    res = eng.forward(*_args(w), mvn_const="exact")
+    torch.cuda.synchronize()
+    idx = np.array([0, 1, 1777, 4095])
+    ref = co.kalman_filter(w["y"], *[w[k][idx] for k in ("a0", "P0", "T", "Z", "R", "H", "Q")],
+                           mvn_const="exact", full=True)
+    for k in TAPES:
+        got = getattr(res, k)[torch.as_tensor(idx)].cpu().numpy()
+        assert_allclose(got, ref[k], rtol=1e-9, atol=1e-9, err_msg=k)
+    # covariances stay symmetric and the predicted tape starts at (a0, P0)
+    pP = res.predicted_covs[:64]
+    assert torch.equal(pP, pP.transpose(-1, -2))
+    assert torch.equal(res.predicted_states[:, 0].cpu(), torch.as_tensor(w["a0"]))
