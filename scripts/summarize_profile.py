@@ -1,0 +1,76 @@
+"""Summarise a scripts/profile.sh output directory: per-kernel stats + HBM traffic per launch.
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  gfx950 correction
+(/opt/skills/guides/MI355X_MICROARCH.md, section HBM): FETCH_SIZE reads exactly 1/2 of the
+bytes of a wide coalesced streaming read -> the read side is reported raw AND doubled;
+WRITE_SIZE is exact for 16-B-per-lane streaming stores (8-B-per-lane stores uncalibrated).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def find(d, pat):
+    return sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+
+
+def kernel_stats(d):
+    rows = []
+    for f in find(d, "*kernel_stats.csv"):
+        rows += list(csv.DictReader(open(f)))
+    return rows
+
+
+def pmc(d, counter):
+    per = defaultdict(list)
+    for f in find(d, "*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == counter:
+                per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return per
+
+
+def main():
+    out = sys.argv[1]
+    print(f"# profile summary: {out}")
+    for tag in ("kt", "fetch", "write"):
+        f = os.path.join(out, f"bench_{tag}.json")
+        if os.path.exists(f):
+            for line in open(f):
+                if line.startswith("{"):
+                    j = json.loads(line)
+                    print(f"bench[{tag}]: value={j['value']:.4g} {j['unit']} ms_per_step={j['ms_per_step']:.4f} "
+                          f"kernel_ms={j['roofline']['kernel_ms']:.4f} achieved={j['roofline']['achieved']:.1f} GB/s "
+                          f"frac={j['roofline']['frac']:.4f}  [{j['config']['workload']}]")
+                    abytes = j["roofline"]["algorithmic_bytes_per_launch"]
+    print("\n## rocprofv3 --kernel-trace --stats (kernel_stats.csv)")
+    print(f"{'kernel':60s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}")
+    for r in sorted(kernel_stats(os.path.join(out, "kt")), key=lambda r: -float(r["TotalDurationNs"])):
+        print(f"{r['Name'][:60]:60s} {r['Calls']:>6s} {float(r['TotalDurationNs']) / 1e6:10.3f} "
+              f"{float(r['AverageNs']) / 1e3:10.2f} {float(r['Percentage']):6.2f}")
+    print("\n## HBM traffic per launch (separate --pmc passes)")
+    fetch = pmc(os.path.join(out, "pmc_fetch"), "FETCH_SIZE")
+    write = pmc(os.path.join(out, "pmc_write"), "WRITE_SIZE")
+    for k in sorted(set(fetch) | set(write)):
+        if "kf_" not in k:
+            continue
+        fk = fetch.get(k, [])
+        wk = write.get(k, [])
+        fmean = sum(fk) / len(fk) * 1024 if fk else float("nan")
+        wmean = sum(wk) / len(wk) * 1024 if wk else float("nan")
+        print(f"{k[:70]}")
+        print(f"   launches fetch/write passes: {len(fk)}/{len(wk)}")
+        print(f"   FETCH_SIZE raw  = {fmean / 1e9:.4f} GB/launch  (x2 gfx950 wide-read correction = {2 * fmean / 1e9:.4f} GB)")
+        print(f"   WRITE_SIZE      = {wmean / 1e9:.4f} GB/launch")
+        try:
+            print(f"   algorithmic     = {abytes / 1e9:.4f} GB/launch ; traffic(write + 2*fetch) = "
+                  f"{(wmean + 2 * fmean) / 1e9:.4f} GB ; traffic(write + fetch raw) = {(wmean + fmean) / 1e9:.4f} GB")
+        except NameError:
+            pass
+
+
+if __name__ == "__main__":
+    main()

@@ -183,7 +183,8 @@ def test_reference_shapes_and_errors(ft, pmrn):
     shapes = [(n, m, 1), (n + 1, m, 1), (n, m, m), (n + 1, m, m), (), (n,)]
     for o, s in zip(outs, shapes):
         assert np.shape(o) == s
-    ref = kn.reference_outputs(*inputs, filter_type=ft)
+    # (the reference's wrong-triangle Cholesky solve for p > 1 is not reproduced: SURVEY A8)
+    ref = kn.reference_outputs(*inputs, filter_type=ft, cholesky_triangle="correct")
     assert_allclose(outs[4], ref[6], rtol=1e-11)
     assert_allclose(outs[0], ref[0], rtol=1e-10, atol=1e-10)
 
