@@ -283,3 +283,85 @@ def test_full_size_tapes_headline(eng):
     pP = res.predicted_covs[:64]
     assert torch.equal(pP, pP.transpose(-1, -2))
     assert torch.equal(res.predicted_states[:, 0].cpu(), torch.as_tensor(w["a0"]))
+
+
+# ----------------------------------------------------------------------------------------------
+# RTS smoother -- reference kalman_smoother.py:56-104, tests/test_kalman_filter.py:212-241
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_files())
+def test_hip_smoother_matches_statsmodels_golden(eng, name):
+    g = load_golden(name)
+    res = eng.forward(g["y"], g["a0"], g["P0"], g["T"], g["Z"], g["R"], g["H"], g["Q"],
+                      mvn_const="exact")
+    sa, sP = eng.smooth(g["T"], g["R"], g["Q"], res.filtered_states, res.filtered_covs)
+    sa, sP = sa.cpu().numpy(), sP.cpu().numpy()
+    if name.startswith("nile_llt"):
+        # the reference's own tolerances: atol 1e-7, covariances from index 5 on (:236-241)
+        assert_allclose(sa, g["smoothed_state"], rtol=1e-7, atol=1e-7)
+        assert_allclose(sP[:, 5:], g["smoothed_state_cov"][:, 5:], rtol=1e-7, atol=1e-7)
+    elif name.startswith("arma11"):
+        # H = 0: P_hat is exactly rank deficient; pinv's rank decision sits at rounding level
+        assert_allclose(sa, g["smoothed_state"], rtol=1e-6, atol=1e-6)
+        assert_allclose(sP, g["smoothed_state_cov"], rtol=1e-2, atol=1e-2)
+    else:
+        assert_allclose(sa, g["smoothed_state"], rtol=1e-9, atol=1e-9)
+        assert_allclose(sP, g["smoothed_state_cov"], rtol=1e-9, atol=1e-9)
+    # last smoothed == last filtered (:212-222)
+    assert np.array_equal(sa[:, -1], res.filtered_states[:, -1].cpu().numpy())
+    assert np.array_equal(sP[:, -1], res.filtered_covs[:, -1].cpu().numpy())
+
+
+SMOOTH_CASES = {
+    "headline_m10": lambda: W.structural(B=33, n=120),
+    "c4_varmax_m15": lambda: W.varmax(B=7, n=60, order=(2, 1)),
+    "dense_p3m4": lambda: W.random_dense(19, 60, 3, 4, 2, seed=3),
+    "dense_p2m20_fullrank": lambda: W.random_dense(5, 40, 2, 20, 20, seed=6),
+    "dense_p1m33_fullrank": lambda: W.random_dense(3, 25, 1, 33, 33, seed=7),
+    "nile_local_level": lambda: W.nile_local_level(B=9),
+}
+
+
+@pytest.mark.parametrize("case", sorted(SMOOTH_CASES))
+@pytest.mark.parametrize("lanes", [0, 16])
+def test_hip_smoother_matches_oracle(eng, case, lanes):
+    w = SMOOTH_CASES[case]()
+    res = eng.forward(*_args(w))
+    eng.set_lanes_per_draw(lanes)
+    sa, sP = eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
+    eng.set_lanes_per_draw(0)
+    na, nP = kn.kalman_smoother(w["T"], w["R"], w["Q"], res.filtered_states.cpu().numpy(),
+                                res.filtered_covs.cpu().numpy())
+    assert_allclose(sa.cpu().numpy(), na, rtol=1e-9, atol=1e-9)
+    assert_allclose(sP.cpu().numpy(), nP, rtol=1e-9, atol=1e-9)
+
+
+def test_hip_smoother_singular_prediction_covariance(eng):
+    """Exactly singular P_hat (two perfectly correlated states): the pinv (Jacobi) path."""
+    w = W.reference_test_inputs(1, 2, 1, 30)
+    w["T"] = np.array([[[1.0, 0.0], [1.0, 0.0]]])
+    w["R"] = np.array([[[1.0], [1.0]]])
+    w["P0"] = np.array([[[1.0, 1.0], [1.0, 1.0]]])
+    w["y"] = np.cumsum(np.random.default_rng(0).standard_normal((30, 1)), axis=0)
+    res = eng.forward(*_args(w))
+    sa, sP = eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
+    na, nP = kn.kalman_smoother(w["T"], w["R"], w["Q"], res.filtered_states.cpu().numpy(),
+                                res.filtered_covs.cpu().numpy())
+    assert_allclose(sa.cpu().numpy(), na, rtol=1e-9, atol=1e-9)
+    assert_allclose(sP.cpu().numpy(), nP, rtol=1e-9, atol=1e-9)
+
+
+def test_reference_smoother_interface():
+    from pymc_statespace_amd.filters import KalmanSmoother, StandardFilter
+
+    p, m, r, n = 1, 5, 1, 10
+    w = W.reference_test_inputs(p, m, r, n)
+    inputs = (w["y"][..., None], w["a0"][0][:, None], w["P0"][0], w["T"][0], w["Z"][0], w["R"][0],
+              w["H"][0], w["Q"][0])
+    fs, ps, fc, pc, ll, llo = StandardFilter()(*inputs)
+    ss, sc = KalmanSmoother()(w["T"][0], w["R"][0], w["Q"][0], fs, fc)
+    assert ss.shape == (n, m, 1) and sc.shape == (n, m, m)
+    assert_allclose(fs[-1], ss[-1])  # reference tests/test_kalman_filter.py:212-222
+    assert_allclose(fc[-1], sc[-1])
+    ref = kn.reference_outputs(*inputs)
+    assert_allclose(ss, ref[2], rtol=1e-10, atol=1e-10)
+    assert_allclose(sc, ref[5], rtol=1e-10, atol=1e-10)
