@@ -69,6 +69,14 @@ int kf_launch_forward_lds(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) 
   return kf_launch_forward_lds_p0(h, a, stream);
 }
 
+int kf_launch_backward_lds(kf_handle* h, const KfBwdArgs& a, hipStream_t stream) {
+  if (a.p == 1) return kf_launch_backward_lds_p1(h, a, stream);
+  if (a.p == 2) return kf_launch_backward_lds_p2(h, a, stream);
+  if (a.p <= 4) return kf_launch_backward_lds_p4(h, a, stream);
+  if (a.p <= 8) return kf_launch_backward_lds_p8(h, a, stream);
+  return kf_launch_backward_lds_p0(h, a, stream);
+}
+
 static int check_dims(kf_handle* h, const kf_dims* d, bool need_p) {
   if (!h) return KF_ERR_ARG;
   if (!d) {

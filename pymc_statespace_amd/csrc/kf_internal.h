@@ -109,6 +109,11 @@ int kf_launch_forward_lds_p2(kf_handle* h, const KfFwdArgs& a, hipStream_t strea
 int kf_launch_forward_lds_p4(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 int kf_launch_forward_lds_p8(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 int kf_launch_forward_lds(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_backward_lds_p0(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward_lds_p1(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward_lds_p2(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward_lds_p4(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward_lds_p8(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_backward_lds(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_smoother_lds(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream);
 int kf_pick_lanes(const kf_handle* h, int m, long B);
