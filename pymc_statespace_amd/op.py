@@ -1,0 +1,235 @@
+"""PyTensor adapter: the Op that lets the HIP kernels stand in for the reference's scan inside a
+PyMC model (``PyMCStateSpace.build_statespace_graph()``, reference core/statespace.py:146-174).
+
+Pattern follows the reference's only custom Op, ``SolveDiscreteARE``
+(reference utils/pytensor_scipy.py:11-60): ``__props__``, ``make_node`` (``as_tensor_variable``,
+one ``Apply``), ``perform(node, inputs, output_storage)``, ``infer_shape``, a gradient.  The
+gradient is a second Op whose ``perform`` calls ``kf_filter_backward``.
+
+PyTensor / PyMC are not installed in the build image, so the Op classes are created lazily and
+everything numeric lives in the plain functions ``perform_filter`` / ``perform_filter_grad`` /
+``perform_smoother`` (exercised by the GPU tests); the Op methods only move arrays in and out
+of them.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .engine import get_engine
+
+GRAD_INPUT_NAMES = ("a0", "P0", "T", "Z", "R", "H", "Q", "c", "d")
+
+
+# --------------------------------------------------------------------------------------------
+# numeric bodies (no PyTensor needed)
+# --------------------------------------------------------------------------------------------
+def _col(x):
+    x = np.asarray(x, dtype=np.float64)
+    return x[:, 0] if x.ndim == 2 and x.shape[1] == 1 else x
+
+
+def perform_filter(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standard",
+                   mvn_const="reference", engine=None):
+    """One draw, reference layouts in (data (n,p,1), a0 (m,1), c (m,1), d (p,1)) -> the six
+    reference outputs [filtered_states (n,m,1), predicted_states (n+1,m,1), filtered_covs,
+    predicted_covs, logp (), ll_obs (n,)] as numpy arrays."""
+    eng = engine or get_engine()
+    data = np.asarray(data, dtype=np.float64)
+    if data.ndim == 3:
+        data = data[..., 0]
+    res = eng.forward(data, _col(a0)[None], np.asarray(P0)[None], np.asarray(T)[None],
+                      np.asarray(Z)[None], np.asarray(R)[None], np.asarray(H)[None],
+                      np.asarray(Q)[None], _col(c)[None], _col(d)[None],
+                      filter_type=filter_type, mvn_const=mvn_const)
+    info = int(res.info[0].item())
+    if info != 0:
+        raise np.linalg.LinAlgError(
+            f"{info & 0xff}-th leading minor of the innovation covariance not positive definite "
+            f"at time step {(info >> 8) - 1}")
+    return [
+        res.filtered_states[0].cpu().numpy()[..., None],
+        res.predicted_states[0].cpu().numpy()[..., None],
+        res.filtered_covs[0].cpu().numpy(),
+        res.predicted_covs[0].cpu().numpy(),
+        np.asarray(res.logp[0].item(), dtype=np.float64),
+        res.ll_obs[0].cpu().numpy(),
+    ]
+
+
+def perform_filter_grad(data, a0, P0, T, Z, R, H, Q, c, d, predicted_states, predicted_covs,
+                        g_logp, g_ll_obs, filter_type="standard", mvn_const="reference",
+                        engine=None):
+    """Gradients of g_logp*logp + <g_ll_obs, ll_obs> w.r.t. (a0,P0,T,Z,R,H,Q,c,d), shaped like
+    the inputs (a0 (m,1), c (m,1), d (p,1))."""
+    eng = engine or get_engine()
+    data = np.asarray(data, dtype=np.float64)
+    if data.ndim == 3:
+        data = data[..., 0]
+    pa = np.asarray(predicted_states, dtype=np.float64)
+    if pa.ndim == 3:
+        pa = pa[..., 0]
+    g = eng.backward(data, _col(a0)[None], np.asarray(P0)[None], np.asarray(T)[None],
+                     np.asarray(Z)[None], np.asarray(R)[None], np.asarray(H)[None],
+                     np.asarray(Q)[None], _col(c)[None], _col(d)[None],
+                     predicted_states=pa[None], predicted_covs=np.asarray(predicted_covs)[None],
+                     g_logp=np.atleast_1d(np.asarray(g_logp, dtype=np.float64)),
+                     g_ll_obs=np.asarray(g_ll_obs, dtype=np.float64)[None],
+                     filter_type=filter_type, mvn_const=mvn_const, want_cd=True)
+    out = {k: g[k][0].cpu().numpy() for k in GRAD_INPUT_NAMES}
+    for k in ("a0", "c", "d"):
+        out[k] = out[k][:, None]
+    return [out[k] for k in GRAD_INPUT_NAMES]
+
+
+def perform_smoother(T, R, Q, filtered_states, filtered_covs, engine=None):
+    eng = engine or get_engine()
+    fa = np.asarray(filtered_states, dtype=np.float64)
+    if fa.ndim == 3:
+        fa = fa[..., 0]
+    sa, sP = eng.smooth(np.asarray(T)[None], np.asarray(R)[None], np.asarray(Q)[None], fa[None],
+                        np.asarray(filtered_covs)[None])
+    return [sa[0].cpu().numpy()[..., None], sP[0].cpu().numpy()]
+
+
+# --------------------------------------------------------------------------------------------
+# PyTensor Ops (built on first use)
+# --------------------------------------------------------------------------------------------
+_OPS = None
+
+
+def _build_ops():
+    global _OPS
+    if _OPS is not None:
+        return _OPS
+    try:
+        import pytensor
+        import pytensor.tensor as pt
+        from pytensor.gradient import DisconnectedType, grad_not_implemented
+        from pytensor.graph.basic import Apply
+        from pytensor.graph.op import Op
+    except ImportError as e:  # pragma: no cover - PyTensor is absent from the build image
+        raise ImportError(
+            "build_graph() needs PyTensor (pip install pytensor pymc). The eager call "
+            "`flt(data, a0, P0, T, Z, R, H, Q)` works without it.") from e
+
+    f64 = "float64"
+
+    class KalmanFilterGradOp(Op):
+        __props__ = ("filter_type", "mvn_const")
+
+        def __init__(self, filter_type="standard", mvn_const="reference"):
+            self.filter_type, self.mvn_const = filter_type, mvn_const
+
+        def make_node(self, *args):
+            args = [pt.as_tensor_variable(a) for a in args]
+            # inputs: data a0 P0 T Z R H Q c d predicted_states predicted_covs g_logp g_ll_obs
+            outs = [args[i].type() for i in range(1, 10)]
+            return Apply(self, args, outs)
+
+        def perform(self, node, inputs, output_storage):
+            grads = perform_filter_grad(*inputs, filter_type=self.filter_type,
+                                        mvn_const=self.mvn_const)
+            for storage, g in zip(output_storage, grads):
+                storage[0] = np.ascontiguousarray(g, dtype=np.float64)
+
+        def infer_shape(self, fgraph, node, shapes):
+            return [shapes[i] for i in range(1, 10)]
+
+    class KalmanFilterOp(Op):
+        """[filtered_states, predicted_states, filtered_covs, predicted_covs, logp, ll_obs]
+        = Op(data, a0, P0, T, Z, R, H, Q, c, d)   -- reference kalman_filter.py:184-191."""
+        __props__ = ("filter_type", "mvn_const")
+
+        def __init__(self, filter_type="standard", mvn_const="reference"):
+            self.filter_type, self.mvn_const = filter_type, mvn_const
+
+        def make_node(self, data, a0, P0, T, Z, R, H, Q, c, d):
+            ins = [pt.as_tensor_variable(x) for x in (data, a0, P0, T, Z, R, H, Q, c, d)]
+            outs = [pt.tensor3(dtype=f64), pt.tensor3(dtype=f64), pt.tensor3(dtype=f64),
+                    pt.tensor3(dtype=f64), pt.scalar(dtype=f64), pt.vector(dtype=f64)]
+            return Apply(self, ins, outs)
+
+        def perform(self, node, inputs, output_storage):
+            outs = perform_filter(*inputs, filter_type=self.filter_type, mvn_const=self.mvn_const)
+            for storage, o in zip(output_storage, outs):
+                storage[0] = np.ascontiguousarray(o, dtype=np.float64)
+
+        def infer_shape(self, fgraph, node, shapes):
+            n = shapes[0][0]
+            m = shapes[3][0]
+            return [(n, m, 1), (n + 1, m, 1), (n, m, m), (n + 1, m, m), (), (n,)]
+
+        def connection_pattern(self, node):
+            # data is never differentiated; every system matrix reaches every output
+            return [[False] * 6] + [[True] * 6 for _ in range(9)]
+
+        def L_op(self, inputs, outputs, output_grads):
+            for i in range(4):
+                if not isinstance(output_grads[i].type, DisconnectedType):
+                    return [DisconnectedType()()] + [
+                        grad_not_implemented(
+                            self, k, inputs[k],
+                            "gradients flow through log_likelihood / ll_obs only; the state and "
+                            "covariance tapes are not differentiated by the HIP backward kernel")
+                        for k in range(1, 10)]
+            g_logp, g_ll = output_grads[4], output_grads[5]
+            if isinstance(g_logp.type, DisconnectedType):
+                g_logp = pt.zeros_like(outputs[4])
+            if isinstance(g_ll.type, DisconnectedType):
+                g_ll = pt.zeros_like(outputs[5])
+            grads = KalmanFilterGradOp(self.filter_type, self.mvn_const)(
+                *inputs, outputs[1], outputs[3], g_logp, g_ll)
+            return [DisconnectedType()()] + list(grads)
+
+    class KalmanSmootherOp(Op):
+        """(smoothed_states, smoothed_covs) = Op(T, R, Q, filtered_states, filtered_covs)
+        -- reference kalman_smoother.py:56-85."""
+        __props__ = ()
+
+        def make_node(self, T, R, Q, filtered_states, filtered_covs):
+            ins = [pt.as_tensor_variable(x) for x in (T, R, Q, filtered_states, filtered_covs)]
+            return Apply(self, ins, [pt.tensor3(dtype=f64), pt.tensor3(dtype=f64)])
+
+        def perform(self, node, inputs, output_storage):
+            outs = perform_smoother(*inputs)
+            for storage, o in zip(output_storage, outs):
+                storage[0] = np.ascontiguousarray(o, dtype=np.float64)
+
+        def infer_shape(self, fgraph, node, shapes):
+            return [shapes[3], shapes[4]]
+
+        def L_op(self, inputs, outputs, output_grads):
+            return [grad_not_implemented(self, k, inputs[k], "the RTS smoother is not differentiated")
+                    for k in range(5)]
+
+    _OPS = dict(pt=pt, pytensor=pytensor, KalmanFilterOp=KalmanFilterOp,
+                KalmanFilterGradOp=KalmanFilterGradOp, KalmanSmootherOp=KalmanSmootherOp)
+    return _OPS
+
+
+def kalman_filter_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type="standard",
+                        mvn_const="reference"):
+    """Symbolic equivalent of BaseFilter.build_graph (reference kalman_filter.py:126-163).
+    Static (2-D) system matrices only; c, d default to zeros (initialize_intercepts :36-51)."""
+    ops = _build_ops()
+    pt = ops["pt"]
+    T, Z, R, H, Q = (pt.as_tensor_variable(x) for x in (T, Z, R, H, Q))
+    for prm, name in zip((T, Z, R, H, Q), ("T", "Z", "R", "H", "Q")):
+        if prm.ndim == 3:
+            raise NotImplementedError(
+                f"Matrix {name} is time varying (3-D); the MI355X path supports static system "
+                "matrices only")
+        if prm.ndim != 2:
+            # reference filters/utilities.py:16-18
+            raise ValueError(
+                f"Matrix {name} has {prm.ndim}, it should either 2 (static) or 3 (time varying).")
+    if c is None:
+        c = pt.zeros((T.shape[0], 1))
+    if d is None:
+        d = pt.zeros((Z.shape[0], 1))
+    return list(ops["KalmanFilterOp"](filter_type, mvn_const)(data, a0, P0, T, Z, R, H, Q, c, d))
+
+
+def kalman_smoother_graph(T, R, Q, filtered_states, filtered_covariances):
+    ops = _build_ops()
+    return tuple(ops["KalmanSmootherOp"]()(T, R, Q, filtered_states, filtered_covariances))

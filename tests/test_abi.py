@@ -67,3 +67,27 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "kf_oracle" not in txt, f
+
+
+def test_build_graph_needs_pytensor_and_says_so():
+    """The symbolic entry point mirrors the reference signature; without PyTensor (absent from
+    this image) it must fail with a clear ImportError, not fall back to anything."""
+    import importlib.util
+
+    from pymc_statespace_amd.filters import KalmanSmoother, StandardFilter
+
+    if importlib.util.find_spec("pytensor") is not None:
+        pytest.skip("PyTensor present")
+    with pytest.raises(ImportError, match="needs PyTensor"):
+        StandardFilter().build_graph(None, None, None, None, None, None, None, None)
+    with pytest.raises(ImportError, match="needs PyTensor"):
+        KalmanSmoother().build_graph(None, None, None, None, None)
+
+
+def test_filter_factory_keys_match_reference():
+    from pymc_statespace_amd.filters import FILTER_FACTORY
+
+    # reference core/statespace.py:25-31 minus "steady_state" (out of scope, SURVEY section 2)
+    assert set(FILTER_FACTORY) == {"standard", "univariate", "single", "cholesky"}
+    for cls in FILTER_FACTORY.values():
+        assert hasattr(cls, "build_graph") and callable(cls)

@@ -453,3 +453,39 @@ def test_hip_gradient_directional_derivative_full_size(eng):
     fd = (logp_at(h) - logp_at(-h)) / (2 * h)
     rel = ((analytic - fd).abs() / (1.0 + fd.abs())).max().item()
     assert rel < 1e-5, rel
+
+
+# ----------------------------------------------------------------------------------------------
+# the PyTensor Op's numeric bodies (op.py) -- what perform()/grad() execute
+# ----------------------------------------------------------------------------------------------
+def test_op_perform_bodies_match_oracle():
+    from oracle import kalman_torch as kt
+    from pymc_statespace_amd import op
+
+    g = load_golden("nile_llt.npz")
+    n, m, p = g["y"].shape[0], 2, 1
+    inputs = [g["y"][..., None], g["a0"][0][:, None], g["P0"][0], g["T"][0], g["Z"][0], g["R"][0],
+              g["H"][0], g["Q"][0], np.zeros((m, 1)), np.zeros((p, 1))]
+    outs = op.perform_filter(*inputs)
+    ref = kn.reference_outputs(*inputs[:8])
+    shapes = [(n, m, 1), (n + 1, m, 1), (n, m, m), (n + 1, m, m), (), (n,)]
+    for o, s in zip(outs, shapes):
+        assert np.shape(o) == s
+    assert_allclose(outs[4], ref[6], rtol=1e-10)
+    assert_allclose(outs[0], ref[0], rtol=1e-8, atol=1e-8)
+    ss, sc = op.perform_smoother(inputs[3], inputs[5], inputs[7], outs[0], outs[2])
+    assert ss.shape == (n, m, 1) and sc.shape == (n, m, m)
+    assert_allclose(ss, ref[2], rtol=1e-6, atol=1e-6)
+
+    w = W.structural(B=1, n=25)
+    inputs = [w["y"][..., None], w["a0"][0][:, None], w["P0"][0], w["T"][0], w["Z"][0], w["R"][0],
+              w["H"][0], w["Q"][0], np.zeros((10, 1)), np.zeros((1, 1))]
+    outs = op.perform_filter(*inputs)
+    gl = np.linspace(-1, 1, 25)
+    grads = op.perform_filter_grad(*inputs, outs[1], outs[3], np.asarray(0.7), gl)
+    _, _, gt = kt.logp_and_grads(w["y"], w["a0"], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"],
+                                 g_logp=np.array([0.7]), g_ll_obs=gl[None])
+    for name, gr, x in zip(op.GRAD_INPUT_NAMES, grads, inputs[1:]):
+        assert gr.shape == x.shape, name
+        assert_allclose(gr.reshape(gt[name][0].shape), gt[name][0], rtol=1e-9, atol=1e-10,
+                        err_msg=name)
