@@ -99,9 +99,15 @@ int kf_create(kf_handle** out, int device);
 void kf_destroy(kf_handle* h);
 const char* kf_last_error(const kf_handle* h);
 
-/* Tuning knob: lanes of a wavefront that cooperate on one draw (0 = choose from
- * dims; valid: 4, 8, 16, 32, 64).  Fewer lanes per draw = more draws per wave. */
+/* Tuning knob: lanes of a wavefront that cooperate on one draw (0 = choose from dims).
+ * LDS kernels take 4, 8, 16, 32 or 64; the row-split forward kernels take m*H (H lanes per
+ * row of P) for the compiled H; other values fall back to the automatic choice. */
 int kf_set_lanes_per_draw(kf_handle* h, int lanes);
+
+/* Forward-kernel selection (default AUTO: the register-resident "row" kernels when
+ * p == 1 and m <= 10, else the LDS-resident generic kernel).  Results agree to rounding. */
+enum { KF_KERNEL_AUTO = 0, KF_KERNEL_LDS = 1, KF_KERNEL_ROW = 2 };
+int kf_set_forward_kernel(kf_handle* h, int kernel);
 
 /* Scratch the three entry points need for `dims` (max over them); may be 0. */
 int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes);

@@ -110,14 +110,14 @@ def canonicalize(data, a0, P0, T, Z, R, H, Q, c=None, d=None):
         c_b, f7 = np.zeros((1, m)), False  # initialize_intercepts :36-51 (zeros)
     else:
         c = np.asarray(c, dtype=np.float64)
-        if c.shape[-1] == 1 and c.ndim >= 2:
+        if c.shape[-1] == 1 and c.ndim >= 2 and c.shape[-2] == m:
             c = c[..., 0]
         c_b, f7 = _as_batch(c, 1)
     if d is None:
         d_b, f8 = np.zeros((1, p)), False
     else:
         d = np.asarray(d, dtype=np.float64)
-        if d.shape[-1] == 1 and d.ndim >= 2:
+        if d.shape[-1] == 1 and d.ndim >= 2 and d.shape[-2] == p:
             d = d[..., 0]
         d_b, f8 = _as_batch(d, 1)
 

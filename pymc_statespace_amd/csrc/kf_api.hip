@@ -26,6 +26,9 @@ extern "C" int kf_create(kf_handle** out, int device) {
   if (!h) return KF_ERR_ARG;
   h->device = device;
   h->lanes_per_draw = 0;
+  h->forward_kernel = KF_KERNEL_AUTO;
+  const char* envk = getenv("KF_FORWARD_KERNEL");
+  if (envk) h->forward_kernel = !strcmp(envk, "lds") ? KF_KERNEL_LDS : !strcmp(envk, "row") ? KF_KERNEL_ROW : KF_KERNEL_AUTO;
   const char* env = getenv("KF_LANES_PER_DRAW");
   if (env) h->lanes_per_draw = atoi(env);
   hipDeviceProp_t prop;
@@ -42,16 +45,83 @@ extern "C" const char* kf_last_error(const kf_handle* h) { return h ? h->err : g
 
 extern "C" int kf_set_lanes_per_draw(kf_handle* h, int lanes) {
   if (!h) return KF_ERR_ARG;
-  if (lanes != 0 && lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64) {
-    KF_SET_ERR(h, "lanes_per_draw must be 0, 4, 8, 16, 32 or 64 (got %d)", lanes);
+  if (lanes < 0 || lanes > 64) {
+    KF_SET_ERR(h, "lanes_per_draw must be in [0, 64] (got %d)", lanes);
     return KF_ERR_ARG;
   }
   h->lanes_per_draw = lanes;
   return KF_OK;
 }
 
+extern "C" int kf_set_forward_kernel(kf_handle* h, int kernel) {
+  if (!h) return KF_ERR_ARG;
+  if (kernel != KF_KERNEL_AUTO && kernel != KF_KERNEL_LDS && kernel != KF_KERNEL_ROW) {
+    KF_SET_ERR(h, "unknown forward kernel %d", kernel);
+    return KF_ERR_ARG;
+  }
+  h->forward_kernel = kernel;
+  return KF_OK;
+}
+
+// lanes per row for the row-split kernels: split the O(m^3) products over more lanes while
+// the batch is too small to give every SIMD two wavefronts.
+static int kf_pick_row_split(const kf_handle* h, int m, long B) {
+  // Measured on MI355X (m = 10): with one row-owner wave per SIMD or more (B*m/64 waves >=
+  // #SIMDs) the plain row kernel has the shortest instruction stream per draw; below that,
+  // H = 3 lanes per row (two waves per SIMD at B = 4096) is ~1.4x faster.
+  const long n_simd = (h ? h->n_cu : 256) * 4L;
+  const long waves_h1 = (B * m + KF_WAVE - 1) / KF_WAVE;
+  if (waves_h1 >= n_simd) return 1;
+  switch (m) {
+    case 10: return 3;
+    case 8: return 2;
+    case 6: return 3;
+    case 4: return 2;
+    default: return 1;
+  }
+}
+
+int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
+  const bool row_ok = a.p == 1 && a.m <= KF_ROW_M_MAX;
+  if (h->forward_kernel == KF_KERNEL_ROW && !row_ok) {
+    KF_SET_ERR(h, "forward(row): needs p == 1 and m <= %d (got p=%d m=%d)", KF_ROW_M_MAX, a.p, a.m);
+    return KF_ERR_UNSUPPORTED;
+  }
+  if (row_ok && h->forward_kernel != KF_KERNEL_LDS) {
+    if (a.m % 2 == 0) {
+      // lanes per row H: explicit (lanes_per_draw = m*H) or chosen from the batch size;
+      // H == 1 is the plain row-owner kernel below
+      int H = 0;
+      if (h->lanes_per_draw > 0 && h->lanes_per_draw % a.m == 0) H = h->lanes_per_draw / a.m;
+      if (H == 0) H = kf_pick_row_split(h, a.m, a.B);
+#define KF_TRY_SPLIT(M_, H_) \
+  if (a.m == M_ && H == H_) return kf_launch_forward_rowsplit_m##M_##_h##H_(h, a, stream);
+      KF_TRY_SPLIT(10, 2) KF_TRY_SPLIT(10, 3) KF_TRY_SPLIT(10, 5)
+      KF_TRY_SPLIT(8, 2) KF_TRY_SPLIT(8, 4)
+      KF_TRY_SPLIT(6, 3)
+      KF_TRY_SPLIT(4, 2)
+#undef KF_TRY_SPLIT
+    }
+    switch (a.m) {
+      case 1: return kf_launch_forward_row_m1(h, a, stream);
+      case 2: return kf_launch_forward_row_m2(h, a, stream);
+      case 3: return kf_launch_forward_row_m3(h, a, stream);
+      case 4: return kf_launch_forward_row_m4(h, a, stream);
+      case 5: return kf_launch_forward_row_m5(h, a, stream);
+      case 6: return kf_launch_forward_row_m6(h, a, stream);
+      case 7: return kf_launch_forward_row_m7(h, a, stream);
+      case 8: return kf_launch_forward_row_m8(h, a, stream);
+      case 9: return kf_launch_forward_row_m9(h, a, stream);
+      default: return kf_launch_forward_row_m10(h, a, stream);
+    }
+  }
+  return kf_launch_forward_lds(h, a, stream);
+}
+
 int kf_pick_lanes(const kf_handle* h, int m, long B) {
-  if (h && h->lanes_per_draw) return h->lanes_per_draw;
+  if (h && (h->lanes_per_draw == 4 || h->lanes_per_draw == 8 || h->lanes_per_draw == 16 ||
+            h->lanes_per_draw == 32 || h->lanes_per_draw == 64))
+    return h->lanes_per_draw;
   int want = (m * m + 1) / 2;  // ~2 matrix elements per lane
   int G = 4;
   while (G < want && G < KF_WAVE) G *= 2;
@@ -132,7 +202,7 @@ extern "C" int kf_filter_forward(kf_handle* h, const kf_dims* dims, const double
   a.y = y; a.a0 = a0; a.P0 = P0; a.Tm = T; a.Z = Z; a.R = R; a.H = H; a.Q = Q; a.c = c; a.d = d;
   a.logp = logp; a.ll_obs = ll_obs; a.filt_a = filt_a; a.pred_a = pred_a; a.filt_P = filt_P;
   a.pred_P = pred_P; a.info = info;
-  return kf_launch_forward_lds(h, a, (hipStream_t)stream);
+  return kf_launch_forward(h, a, (hipStream_t)stream);
 }
 
 extern "C" int kf_filter_backward(kf_handle* h, const kf_dims* dims, const double* y, const double* a0,

@@ -16,6 +16,7 @@
 struct kf_handle {
   int device;
   int lanes_per_draw;  // 0 = auto
+  int forward_kernel;  // KF_KERNEL_AUTO / _LDS / _ROW
   int n_cu;
   char err[512];
 };
@@ -109,6 +110,20 @@ int kf_launch_forward_lds_p2(kf_handle* h, const KfFwdArgs& a, hipStream_t strea
 int kf_launch_forward_lds_p4(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 int kf_launch_forward_lds_p8(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 int kf_launch_forward_lds(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+// register-resident row-owner kernels, one object per compile-time k_states (kf_forward_row.hip)
+#define KF_ROW_M_MAX 10
+#define KF_DECL_ROW(M) int kf_launch_forward_row_m##M(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+KF_DECL_ROW(1) KF_DECL_ROW(2) KF_DECL_ROW(3) KF_DECL_ROW(4) KF_DECL_ROW(5)
+KF_DECL_ROW(6) KF_DECL_ROW(7) KF_DECL_ROW(8) KF_DECL_ROW(9) KF_DECL_ROW(10)
+// row-split kernels (kf_forward_rowsplit.hip), one object per (even k_states, lanes per row)
+int kf_launch_forward_rowsplit_m10_h2(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward_rowsplit_m10_h3(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward_rowsplit_m10_h5(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward_rowsplit_m8_h2(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward_rowsplit_m8_h4(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward_rowsplit_m6_h3(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward_rowsplit_m4_h2(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 int kf_launch_backward_lds_p0(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_backward_lds_p1(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_backward_lds_p2(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);

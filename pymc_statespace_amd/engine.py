@@ -73,6 +73,11 @@ class KalmanEngine:
     def set_lanes_per_draw(self, lanes: int):
         self._check(self.lib.kf_set_lanes_per_draw(self._h, int(lanes)), "kf_set_lanes_per_draw")
 
+    def set_forward_kernel(self, kernel: str):
+        """'auto' | 'lds' (generic LDS-resident) | 'row' (register-resident, p == 1, m <= 10)."""
+        code = {"auto": 0, "lds": 1, "row": 2}[kernel]
+        self._check(self.lib.kf_set_forward_kernel(self._h, code), "kf_set_forward_kernel")
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 

@@ -489,3 +489,71 @@ def test_op_perform_bodies_match_oracle():
         assert gr.shape == x.shape, name
         assert_allclose(gr.reshape(gt[name][0].shape), gt[name][0], rtol=1e-9, atol=1e-10,
                         err_msg=name)
+
+
+# ----------------------------------------------------------------------------------------------
+# forward kernel families: LDS-resident generic vs register-resident row / row-split (p == 1)
+# ----------------------------------------------------------------------------------------------
+SPLITS = {10: (1, 2, 3, 5), 8: (1, 2, 4), 6: (1, 3), 4: (1, 2), 2: (1,)}
+
+
+@pytest.mark.parametrize("m", range(1, 11))
+@pytest.mark.parametrize("ft", FILTERS)
+def test_row_kernels_match_oracle(eng, m, ft):
+    B = 41  # not a multiple of the draws-per-wave of any variant: exercises the tail clones
+    w = W.random_dense(B, 70, 1, m, max(1, m // 2), seed=100 + m)
+    y = w["y"].copy()
+    y[[3, 17, 69]] = np.nan
+    rng = np.random.default_rng(m)
+    c = 0.1 * rng.standard_normal((B, m))
+    d = 0.1 * rng.standard_normal((B, 1))
+    ref = kn.kalman_filter(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact")
+    eng.set_forward_kernel("row")
+    try:
+        outs = []
+        for H in SPLITS.get(m, (1,)):
+            eng.set_lanes_per_draw(m * H)
+            out = _np(eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact"))
+            assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8, (m, H)
+            for k in TAPES:
+                assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=f"m={m} H={H} {k}")
+            assert not out["info"].any()
+            outs.append(out)
+        # lanes-per-row is a pure scheduling knob: the split variants agree bit for bit
+        for o in outs[2:]:
+            for k in TAPES + ["logp"]:
+                assert np.array_equal(o[k], outs[1][k]), k
+    finally:
+        eng.set_forward_kernel("auto")
+        eng.set_lanes_per_draw(0)
+
+
+def test_kernel_families_agree_at_headline_size(eng):
+    import torch
+
+    w = W.WORKLOADS["headline"]()
+    dev = [eng.to_device(x) for x in _args(w)]
+    res = {}
+    try:
+        for kern, lanes in (("lds", 0), ("row", 10), ("row", 30)):
+            eng.set_forward_kernel(kern)
+            eng.set_lanes_per_draw(lanes)
+            r = eng.forward(*dev, mvn_const="exact", store_filtered=False, store_predicted=True)
+            torch.cuda.synchronize()
+            res[(kern, lanes)] = (r.logp.clone(), r.predicted_covs[::512, -1].clone(), r.ll_obs[::512].clone())
+    finally:
+        eng.set_forward_kernel("auto")
+        eng.set_lanes_per_draw(0)
+    base = res[("lds", 0)]
+    for key, val in res.items():
+        assert (val[0] - base[0]).abs().max().item() < 1e-8, key
+        assert torch.allclose(val[1], base[1], rtol=1e-10, atol=1e-12), key
+        assert torch.allclose(val[2], base[2], rtol=1e-10, atol=1e-11), key
+
+
+def test_row_kernel_not_positive_definite_reports_info(eng):
+    w = W.reference_test_inputs(1, 2, 1, 5)
+    H = np.array([[[-10.0]]])
+    res = eng.forward(w["y"], w["a0"], w["P0"], w["T"], w["Z"], w["R"], H, w["Q"])
+    assert int(res.info[0].item()) == ((0 + 1) << 8) | 1
+    assert np.isnan(res.logp[0].item())
