@@ -191,7 +191,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "kf_fwd_lds_kernel", "kernel_ms": kern_ms,
+                "kernel": eng.forward_kernel_name(B, n, p, m, r), "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_launch": abytes,
             },
         }

@@ -108,6 +108,8 @@ int kf_set_lanes_per_draw(kf_handle* h, int lanes);
  * p == 1 and m <= 10, else the LDS-resident generic kernel).  Results agree to rounding. */
 enum { KF_KERNEL_AUTO = 0, KF_KERNEL_LDS = 1, KF_KERNEL_ROW = 2 };
 int kf_set_forward_kernel(kf_handle* h, int kernel);
+/* Name of the kernel kf_filter_forward would launch for `dims` (for profiles / bench logs). */
+const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* dims);
 
 /* Scratch the three entry points need for `dims` (max over them); may be 0. */
 int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes);

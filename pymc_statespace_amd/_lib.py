@@ -22,7 +22,7 @@ KF_OK, KF_ERR_ARG, KF_ERR_HIP, KF_ERR_WORKSPACE, KF_ERR_UNSUPPORTED = 0, -1, -2,
 # every symbol include/kf.h declares (tests check the built library exports them all)
 EXPORTS = (
     "kf_abi_version", "kf_create", "kf_destroy", "kf_last_error", "kf_set_lanes_per_draw",
-    "kf_set_forward_kernel",
+    "kf_set_forward_kernel", "kf_forward_kernel_name",
     "kf_workspace_bytes", "kf_filter_forward", "kf_filter_backward", "kf_smoother",
 )
 
@@ -65,6 +65,8 @@ def load():
     lib.kf_set_lanes_per_draw.restype = C.c_int
     lib.kf_set_forward_kernel.argtypes = [C.c_void_p, C.c_int]
     lib.kf_set_forward_kernel.restype = C.c_int
+    lib.kf_forward_kernel_name.argtypes = [C.c_void_p, C.POINTER(KfDims)]
+    lib.kf_forward_kernel_name.restype = C.c_char_p
     lib.kf_workspace_bytes.argtypes = [C.c_void_p, C.POINTER(KfDims), C.POINTER(C.c_size_t)]
     lib.kf_workspace_bytes.restype = C.c_int
     lib.kf_filter_forward.argtypes = [vp, C.POINTER(KfDims)] + [dp] * 10 + [dp] * 6 + [ip, vp,

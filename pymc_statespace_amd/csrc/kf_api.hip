@@ -81,6 +81,23 @@ static int kf_pick_row_split(const kf_handle* h, int m, long B) {
   }
 }
 
+static int kf_split_for(const kf_handle* h, int m, long B) {
+  int H = 0;
+  if (h->lanes_per_draw > 0 && h->lanes_per_draw % m == 0) H = h->lanes_per_draw / m;
+  if (H == 0) H = kf_pick_row_split(h, m, B);
+  const bool have = (m == 10 && (H == 2 || H == 3 || H == 5)) || (m == 8 && (H == 2 || H == 4)) ||
+                    (m == 6 && H == 3) || (m == 4 && H == 2);
+  return (m % 2 == 0 && have) ? H : 1;
+}
+
+extern "C" const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* d) {
+  if (!h || !d) return "";
+  const bool row_ok = d->p == 1 && d->m <= KF_ROW_M_MAX;
+  if (row_ok && h->forward_kernel != KF_KERNEL_LDS)
+    return kf_split_for(h, d->m, d->B) > 1 ? "kf_fwd_rowsplit_kernel" : "kf_fwd_row_kernel";
+  return "kf_fwd_lds_kernel";
+}
+
 int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
   const bool row_ok = a.p == 1 && a.m <= KF_ROW_M_MAX;
   if (h->forward_kernel == KF_KERNEL_ROW && !row_ok) {
@@ -91,9 +108,7 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
     if (a.m % 2 == 0) {
       // lanes per row H: explicit (lanes_per_draw = m*H) or chosen from the batch size;
       // H == 1 is the plain row-owner kernel below
-      int H = 0;
-      if (h->lanes_per_draw > 0 && h->lanes_per_draw % a.m == 0) H = h->lanes_per_draw / a.m;
-      if (H == 0) H = kf_pick_row_split(h, a.m, a.B);
+      const int H = kf_split_for(h, a.m, a.B);
 #define KF_TRY_SPLIT(M_, H_) \
   if (a.m == M_ && H == H_) return kf_launch_forward_rowsplit_m##M_##_h##H_(h, a, stream);
       KF_TRY_SPLIT(10, 2) KF_TRY_SPLIT(10, 3) KF_TRY_SPLIT(10, 5)

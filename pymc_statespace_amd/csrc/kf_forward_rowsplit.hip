@@ -135,12 +135,14 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_rowsplit_kernel(const KfFwdArg
   // ---- coalesced tape staging slots (see kf_forward_row.hip) ----------------------------------------
   const bool stage_fP = A.filt_P != nullptr, stage_pP = A.pred_P != nullptr;
   int st_lds[C::NST];
+  bool st_on[C::NST];
   double* gfP[C::NST];
   double* gpP[C::NST];
 #pragma unroll
   for (int q = 0; q < C::NST; ++q) {
     int e = 2 * lane + 2 * KF_WAVE * q;
-    if (e >= C::TILE) e -= C::TILE;      // surplus slots repeat a live slot (same bytes, same address)
+    st_on[q] = e < C::TILE;              // surplus slots of the last round store nothing
+    if (e >= C::TILE) e -= C::TILE;
     int dr = e / MM;
     const int off = e - dr * MM;
     st_lds[q] = dr * C::STRIDE + MM + off;  // tile X of draw dr; tile Y = + MM
@@ -205,8 +207,9 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_rowsplit_kernel(const KfFwdArg
     if (pending_pP) {
 #pragma unroll
       for (int q = 0; q < C::NST; ++q) {
-        st_stream(reinterpret_cast<double2_t*>(gpP[q]),
-                  *reinterpret_cast<const double2_t*>(smem + st_lds[q] + MM));
+        if (st_on[q])
+          st_stream(reinterpret_cast<double2_t*>(gpP[q]),
+                    *reinterpret_cast<const double2_t*>(smem + st_lds[q] + MM));
         gpP[q] += MM;
       }
     }
@@ -274,8 +277,9 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_rowsplit_kernel(const KfFwdArg
     if (stage_fP) {
 #pragma unroll
       for (int q = 0; q < C::NST; ++q) {
-        st_stream(reinterpret_cast<double2_t*>(gfP[q]),
-                  *reinterpret_cast<const double2_t*>(smem + st_lds[q]));
+        if (st_on[q])
+          st_stream(reinterpret_cast<double2_t*>(gfP[q]),
+                    *reinterpret_cast<const double2_t*>(smem + st_lds[q]));
         gfP[q] += MM;
       }
     }
@@ -365,8 +369,9 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_rowsplit_kernel(const KfFwdArg
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < C::NST; ++q)
-      st_stream(reinterpret_cast<double2_t*>(gpP[q]),
-                *reinterpret_cast<const double2_t*>(smem + st_lds[q] + MM));
+      if (st_on[q])
+        st_stream(reinterpret_cast<double2_t*>(gpP[q]),
+                  *reinterpret_cast<const double2_t*>(smem + st_lds[q] + MM));
   }
   if (n & (C::RING - 1)) flush_ring(n & ~(C::RING - 1), n & (C::RING - 1));
   if (live && lid == 0) {

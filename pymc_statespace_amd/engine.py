@@ -78,6 +78,10 @@ class KalmanEngine:
         code = {"auto": 0, "lds": 1, "row": 2}[kernel]
         self._check(self.lib.kf_set_forward_kernel(self._h, code), "kf_set_forward_kernel")
 
+    def forward_kernel_name(self, B, n, p, m, r) -> str:
+        dims = self._dims(B, n, p, m, r)
+        return self.lib.kf_forward_kernel_name(self._h, C.byref(dims)).decode()
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
