@@ -93,12 +93,15 @@ static int kf_split_for(const kf_handle* h, int m, long B) {
 extern "C" const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* d) {
   if (!h || !d) return "";
   const bool row_ok = d->p == 1 && d->m <= KF_ROW_M_MAX;
+  if (!kf_forward_lds_fits(d->m, d->p)) return "big_gemm_kernel";
   if (row_ok && h->forward_kernel != KF_KERNEL_LDS)
     return kf_split_for(h, d->m, d->B) > 1 ? "kf_fwd_rowsplit_kernel" : "kf_fwd_row_kernel";
   return "kf_fwd_lds_kernel";
 }
 
-int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
+int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
+                      hipStream_t stream) {
+  if (!kf_forward_lds_fits(a.m, a.p)) return kf_launch_forward_big(h, a, workspace, workspace_bytes, stream);
   const bool row_ok = a.p == 1 && a.m <= KF_ROW_M_MAX;
   if (h->forward_kernel == KF_KERNEL_ROW && !row_ok) {
     KF_SET_ERR(h, "forward(row): needs p == 1 and m <= %d (got p=%d m=%d)", KF_ROW_M_MAX, a.p, a.m);
@@ -193,7 +196,9 @@ static int check_dims(kf_handle* h, const kf_dims* d, bool need_p) {
 
 extern "C" int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes) {
   if (!h || !dims || !bytes) return KF_ERR_ARG;
-  *bytes = 0;  // the LDS-resident kernels keep all scratch on chip
+  *bytes = 0;  // the LDS- and register-resident kernels keep all scratch on chip
+  if (dims->m >= 1 && dims->p >= 1 && !kf_forward_lds_fits(dims->m, dims->p))
+    *bytes = kf_forward_big_workspace_bytes(dims->B, dims->m);
   return KF_OK;
 }
 
@@ -203,8 +208,6 @@ extern "C" int kf_filter_forward(kf_handle* h, const kf_dims* dims, const double
                                  double* logp, double* ll_obs, double* filt_a, double* pred_a,
                                  double* filt_P, double* pred_P, int32_t* info, void* workspace,
                                  size_t workspace_bytes, void* stream) {
-  (void)workspace;
-  (void)workspace_bytes;
   int rc = check_dims(h, dims, true);
   if (rc) return rc;
   if (!y || !a0 || !P0 || !T || !Z || !R || !H || !Q || !logp) {
@@ -217,7 +220,7 @@ extern "C" int kf_filter_forward(kf_handle* h, const kf_dims* dims, const double
   a.y = y; a.a0 = a0; a.P0 = P0; a.Tm = T; a.Z = Z; a.R = R; a.H = H; a.Q = Q; a.c = c; a.d = d;
   a.logp = logp; a.ll_obs = ll_obs; a.filt_a = filt_a; a.pred_a = pred_a; a.filt_P = filt_P;
   a.pred_P = pred_P; a.info = info;
-  return kf_launch_forward(h, a, (hipStream_t)stream);
+  return kf_launch_forward(h, a, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int kf_filter_backward(kf_handle* h, const kf_dims* dims, const double* y, const double* a0,

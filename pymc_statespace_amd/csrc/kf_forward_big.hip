@@ -1,0 +1,438 @@
+// kf_forward_big.hip -- forward Kalman filter for LARGE state dimension (per-draw tiles do not
+// fit LDS: m > ~40, e.g. BASELINE config C5, m = 367).
+//
+// Same contract as the small-m kernels (reference pymc_statespace/filters/kalman_filter.py:
+// 126-252, 255-351, 444-505).  Here the covariance lives in HBM/L2 (caller-provided workspace,
+// 4 B m^2 doubles) and every time step is a short sequence of launches on the caller's stream:
+//
+//   big_update   one workgroup per draw: mask, v, M = P Z', F, chol(F), K, ll, a_f,
+//                P_f = P - K M' - M K' + (K F) K' (rank-p, expanded Joseph form :277),
+//                a_hat = T a_f + c; filtered tapes
+//   big_gemm     W = T P_f            batched over draws, fp64 MFMA (v_mfma_f64_16x16x4_f64)
+//   big_gemm     S = W T' + R Q R'    same kernel, B operand transposed, RQR' in the epilogue
+//   big_sym      P_hat = (S + S')/2 (:221) through 32x32 LDS transposes; predicted tapes
+//
+// The two m x m x m products are >99% of the flops (m = 367: 2 x 98.9 MFLOP per draw-step) and
+// are real contractions, so they run on the matrix cores: 64x64 output tile per 256-thread
+// workgroup, four waves of 2x2 MFMA 16x16 tiles, K staged through LDS in chunks of 16.
+#include "kf_internal.h"
+
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int GT = 64;   // output tile edge
+constexpr int GK = 16;   // K chunk
+constexpr int GLD = GT + 1;  // LDS row stride (doubles) -- odd: conflict-free column access
+
+// C[b] (m x m) = A[b] (m x m) * op(B[b])  (+ E[b]);  op = identity or transpose.
+// grid: (tiles_n, tiles_m, draws)  block: 256
+template <bool TRANS_B, bool ADD_E>
+__global__ __launch_bounds__(256) void big_gemm_kernel(const double* __restrict__ A, long strideA,
+                                                       const double* __restrict__ Bm, long strideB,
+                                                       const double* __restrict__ E, long strideE,
+                                                       double* __restrict__ Cm, long strideC, int m) {
+  __shared__ double As[GK][GLD];  // As[k][r]  (A tile, k-major)
+  __shared__ double Bs[GK][GLD];  // Bs[k][c]
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1;  // 2 x 2 waves, 32 x 32 each
+  const long b = blockIdx.z;
+  const int r0 = blockIdx.y * GT, c0 = blockIdx.x * GT;
+  const double* Ab = A + b * strideA;
+  const double* Bb = Bm + b * strideB;
+
+  double4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int li = lane & 15, lk = lane >> 4;
+
+  for (int k0 = 0; k0 < m; k0 += GK) {
+    // ---- stage A tile: rows r0..r0+63, cols k0..k0+15 (16 contiguous doubles per row) --------
+    for (int e = tid; e < GT * GK; e += 256) {
+      int rr = e / GK, kk = e - rr * GK;
+      int gr = r0 + rr, gk = k0 + kk;
+      As[kk][rr] = (gr < m && gk < m) ? Ab[(long)gr * m + gk] : 0.0;
+    }
+    if (TRANS_B) {
+      // op(B)[k][c] = B[c][k]: rows c0..c0+63 of B, cols k0..k0+15
+      for (int e = tid; e < GT * GK; e += 256) {
+        int cc = e / GK, kk = e - cc * GK;
+        int gc = c0 + cc, gk = k0 + kk;
+        Bs[kk][cc] = (gc < m && gk < m) ? Bb[(long)gc * m + gk] : 0.0;
+      }
+    } else {
+      for (int e = tid; e < GT * GK; e += 256) {
+        int kk = e / GT, cc = e - kk * GT;
+        int gc = c0 + cc, gk = k0 + kk;
+        Bs[kk][cc] = (gc < m && gk < m) ? Bb[(long)gk * m + gc] : 0.0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < GK; ks += 4) {
+      double af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = As[ks + lk][wr * 32 + i * 16 + li];  // A[i=l&15][k=l>>4]
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = Bs[ks + lk][wc * 32 + j * 16 + li];  // B[k=l>>4][j=l&15]
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: D[row = (l>>4) + 4*reg][col = l&15] ---------------------------------------------
+  double* Cb = Cm + b * strideC;
+  const double* Eb = ADD_E ? E + b * strideE : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        int gr = r0 + wr * 32 + i * 16 + lk + 4 * rg;
+        int gc = c0 + wc * 32 + j * 16 + li;
+        if (gr < m && gc < m) {
+          double v = acc[i][j][rg];
+          if (ADD_E) v += Eb[(long)gr * m + gc];
+          Cb[(long)gr * m + gc] = v;
+        }
+      }
+}
+
+// RQR' per draw, initial state into the workspace, predicted tape slot 0
+__global__ __launch_bounds__(256) void big_init_kernel(const KfFwdArgs A, double* a_ws, double* P_ws,
+                                                       double* RQR_ws) {
+  const long b = blockIdx.y;
+  const int m = A.m, r = A.r, n = A.T;
+  const long mm = (long)m * m;
+  const double* gR = A.R + b * (long)m * r;
+  const double* gQ = A.Q + b * (long)r * r;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < mm; e += (long)gridDim.x * 256) {
+    int i = (int)(e / m), j = (int)(e - (long)i * m);
+    double s = 0.0;
+    for (int l = 0; l < r; ++l) {
+      double rq = 0.0;
+      for (int k = 0; k < r; ++k) rq += gR[i * r + k] * gQ[k * r + l];
+      s += rq * gR[j * r + l];
+    }
+    RQR_ws[b * mm + e] = s;
+    double p0 = A.P0[b * mm + e];
+    P_ws[b * mm + e] = p0;
+    if (A.pred_P) A.pred_P[b * (long)(n + 1) * mm + e] = p0;
+    if (e < m) {
+      double a0 = A.a0[b * m + e];
+      a_ws[b * m + e] = a0;
+      if (A.pred_a) A.pred_a[b * (long)(n + 1) * m + e] = a0;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    A.logp[b] = 0.0;
+    if (A.info) A.info[b] = 0;
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// one workgroup (256 threads) per draw; dynamic LDS: Z (p m), M (m p), K (m p), KF (m p), af (m),
+// a (m), H/F/L (3 p p), v, ym, ob, misc
+__global__ __launch_bounds__(256) void big_update_kernel(const KfFwdArgs A, int t, double* a_ws,
+                                                         const double* P_ws, double* Pf_ws) {
+  extern __shared__ double sm[];
+  const long b = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m = A.m, p = A.p, n = A.T;
+  const long mm = (long)m * m;
+  const int pm = p * m, pp = p * p;
+  double* Zl = sm;
+  double* M = Zl + pm;
+  double* K = M + pm;
+  double* KF = K + pm;
+  double* al = KF + pm;
+  double* af = al + m;
+  double* Hl = af + m;
+  double* F = Hl + pp;
+  double* L = F + pp;
+  double* vl = L + pp;
+  double* ym = vl + p;
+  double* ob = ym + p;
+  double* wv = ob + p;      // p + 4 scratch
+  const double* P = P_ws + b * mm;
+  double* Pf = Pf_ws + b * mm;
+  double* a = a_ws + b * m;
+  const bool univariate = A.filter == KF_FILTER_UNIVARIATE;
+  const bool exact_const = (A.flags & KF_FLAG_MVN_CONST_EXACT) != 0;
+  const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;
+  const double* yt = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n * p : 0L) + (long)t * p;
+
+  for (int e = tid; e < pm; e += 256) Zl[e] = A.Z[b * pm + e];
+  for (int e = tid; e < pp; e += 256) Hl[e] = A.H[b * pp + e];
+  for (int e = tid; e < m; e += 256) al[e] = a[e];
+  for (int q = tid; q < p; q += 256) {
+    double yv = yt[q];
+    bool miss = yv != yv;
+    ym[q] = miss ? 0.0 : yv;
+    ob[q] = miss ? 0.0 : 1.0;
+  }
+  __syncthreads();
+  double nobs = 0.0;
+  for (int q = 0; q < p; ++q) nobs += ob[q];
+  double ll = 0.0;
+
+  if (!univariate) {
+    // v and M = P Z' (wave per row of P, lanes over k: coalesced)
+    for (int q = tid; q < p; q += 256) {
+      double s = ym[q] + dsign * (A.d ? A.d[b * p + q] : 0.0);
+      for (int j = 0; j < m; ++j) s -= Zl[q * m + j] * al[j];
+      vl[q] = ob[q] != 0.0 ? s : 0.0;
+    }
+    for (int j = wave; j < m; j += 4) {
+      for (int q = 0; q < p; ++q) {
+        double s = 0.0;
+        for (int k = lane; k < m; k += 64) s += P[(long)j * m + k] * Zl[q * m + k];
+        s = wave_sum(s);
+        if (lane == 0) M[j * p + q] = ob[q] != 0.0 ? s : 0.0;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < pp; e += 256) {
+      int q1 = e / p, q2 = e - q1 * p;
+      double s;
+      if (ob[q1] != 0.0 && ob[q2] != 0.0) {
+        s = Hl[e];
+        for (int j = 0; j < m; ++j) s += Zl[q1 * m + j] * M[j * p + q2];
+      } else {
+        s = (q1 == q2) ? 1.0 : 0.0;
+      }
+      F[e] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {  // p x p Cholesky, quad form, log det (serial: p is small)
+      int fail = 0;
+      for (int j = 0; j < p; ++j) {
+        double s = F[j * p + j];
+        for (int k = 0; k < j; ++k) s -= L[j * p + k] * L[j * p + k];
+        if (!(s > 0.0) && fail == 0) fail = j + 1;
+        double dj = sqrt(s);
+        L[j * p + j] = dj;
+        for (int i = j + 1; i < p; ++i) {
+          double t_ = F[i * p + j];
+          for (int k = 0; k < j; ++k) t_ -= L[i * p + k] * L[j * p + k];
+          L[i * p + j] = t_ / dj;
+        }
+      }
+      double q2 = 0.0, ld = 0.0;
+      for (int i = 0; i < p; ++i) {
+        double t_ = vl[i];
+        for (int k = 0; k < i; ++k) t_ -= L[i * p + k] * wv[k];
+        t_ /= L[i * p + i];
+        wv[i] = t_;
+        q2 += t_ * t_;
+        ld += log(L[i * p + i]);
+      }
+      double nconst = exact_const ? nobs : (A.filter == KF_FILTER_CHOLESKY ? (double)p : 1.0);
+      wv[p] = (nobs == 0.0) ? 0.0 : (-0.5 * (nconst * KF_LOG_2PI + q2) - ld);
+      if (fail != 0 && A.info && A.info[b] == 0) A.info[b] = ((t + 1) << 8) | fail;
+    }
+    __syncthreads();
+    ll = wv[p];
+    for (int j = tid; j < m; j += 256) {  // K row j = M row j F^-1
+      for (int i = 0; i < p; ++i) {
+        double t_ = M[j * p + i];
+        for (int k = 0; k < i; ++k) t_ -= L[i * p + k] * K[j * p + k];
+        K[j * p + i] = t_ / L[i * p + i];
+      }
+      for (int i = p - 1; i >= 0; --i) {
+        double t_ = K[j * p + i];
+        for (int k = i + 1; k < p; ++k) t_ -= L[k * p + i] * K[j * p + k];
+        K[j * p + i] = t_ / L[i * p + i];
+      }
+      double s = al[j];
+      for (int q = 0; q < p; ++q) s += K[j * p + q] * vl[q];
+      af[j] = s;
+      for (int q = 0; q < p; ++q) {
+        double kf = 0.0;
+        for (int q2 = 0; q2 < p; ++q2) kf += K[j * p + q2] * F[q2 * p + q];
+        KF[j * p + q] = kf;
+      }
+    }
+    __syncthreads();
+    double* o_fP = A.filt_P ? A.filt_P + (b * (long)n + t) * mm : nullptr;
+    for (long e = tid; e < mm; e += 256) {
+      int i = (int)(e / m), j = (int)(e - (long)i * m);
+      double s = P[e];
+      for (int q = 0; q < p; ++q) {
+        double kj = K[j * p + q];
+        s -= K[i * p + q] * M[j * p + q];
+        s -= M[i * p + q] * kj;
+        s += KF[i * p + q] * kj;
+      }
+      Pf[e] = s;
+      if (o_fP) __builtin_nontemporal_store(s, o_fP + e);
+    }
+  } else {
+    // UnivariateFilter (:460-505): p sequential scalar updates on (al, Pf)
+    for (long e = tid; e < mm; e += 256) Pf[e] = P[e];
+    __threadfence_block();
+    __syncthreads();
+    double llsum = 0.0, ncount = 0.0;
+    for (int q = 0; q < p; ++q) {
+      const bool obs = ob[q] != 0.0;
+      for (int j = wave; j < m; j += 4) {
+        double s = 0.0;
+        for (int k = lane; k < m; k += 64) s += Pf[(long)j * m + k] * Zl[q * m + k];
+        s = wave_sum(s);
+        if (lane == 0) M[j] = obs ? s : 0.0;
+      }
+      __syncthreads();
+      double vq = ym[q] - (A.d ? A.d[b * p + q] : 0.0);
+      double Fq = obs ? Hl[q * p + q] : 0.0;
+      for (int j = 0; j < m; ++j) {
+        vq -= Zl[q * m + j] * al[j];
+        if (obs) Fq += Zl[q * m + j] * M[j];
+      }
+      if (!obs) vq = 0.0;
+      const bool degenerate = (Fq == 0.0) || !obs;
+      if (degenerate) Fq += 1e-8;
+      const double keep = degenerate ? 0.0 : 1.0;
+      const double invF = 1.0 / Fq;
+      __syncthreads();  // everyone has read al before it changes
+      for (int j = tid; j < m; j += 256) al[j] += (M[j] * invF * keep) * (vq * keep);
+      for (long e = tid; e < mm; e += 256) {
+        int i = (int)(e / m), j = (int)(e - (long)i * m);
+        double ki = M[i] * invF * keep, kj = M[j] * invF * keep;
+        Pf[e] -= ki * kj * Fq * keep;
+      }
+      double lli = (log(Fq) + vq * vq * invF) * keep;
+      llsum += lli;
+      ncount += exact_const ? (obs ? 1.0 : 0.0) : ((lli != 0.0) ? 1.0 : 0.0);
+      __threadfence_block();
+      __syncthreads();
+    }
+    ll = -0.5 * (ncount * KF_LOG_2PI + llsum);
+    for (int j = tid; j < m; j += 256) af[j] = al[j];
+    if (A.filt_P) {
+      double* o_fP = A.filt_P + (b * (long)n + t) * mm;
+      for (long e = tid; e < mm; e += 256) __builtin_nontemporal_store(Pf[e], o_fP + e);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    A.logp[b] += ll;
+    if (A.ll_obs) A.ll_obs[b * (long)n + t] = ll;
+  }
+  if (A.filt_a)
+    for (int j = tid; j < m; j += 256) A.filt_a[(b * (long)n + t) * m + j] = af[j];
+  // a_hat = T a_f + c  (wave per row)
+  const double* Tb = A.Tm + b * mm;
+  for (int i = wave; i < m; i += 4) {
+    double s = 0.0;
+    for (int k = lane; k < m; k += 64) s += Tb[(long)i * m + k] * af[k];
+    s = wave_sum(s);
+    if (lane == 0) {
+      s += A.c ? A.c[b * m + i] : 0.0;
+      a[i] = s;
+      if (A.pred_a) A.pred_a[(b * (long)(n + 1) + t + 1) * m + i] = s;
+    }
+  }
+}
+
+// P = (S + S')/2 via 32 x 32 LDS transposes; predicted covariance tape
+__global__ __launch_bounds__(256) void big_sym_kernel(const double* __restrict__ S, double* __restrict__ P,
+                                                      double* pred_P, long tape_stride, int m) {
+  __shared__ double t1[32][33], t2[32][33];
+  const long b = blockIdx.z;
+  const long mm = (long)m * m;
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj < bi) return;  // tile pair (bi,bj) also writes (bj,bi)
+  const double* Sb = S + b * mm;
+  double* Pb = P + b * mm;
+  double* Tb = pred_P ? pred_P + b * tape_stride : nullptr;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int rr = ty; rr < 32; rr += 8) {
+    int r1 = bi * 32 + rr, c1 = bj * 32 + tx;
+    t1[rr][tx] = (r1 < m && c1 < m) ? Sb[(long)r1 * m + c1] : 0.0;
+    int r2 = bj * 32 + rr, c2 = bi * 32 + tx;
+    t2[rr][tx] = (r2 < m && c2 < m) ? Sb[(long)r2 * m + c2] : 0.0;
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8) {
+    int r1 = bi * 32 + rr, c1 = bj * 32 + tx;
+    if (r1 < m && c1 < m) {
+      double v = 0.5 * (t1[rr][tx] + t2[tx][rr]);
+      Pb[(long)r1 * m + c1] = v;
+      if (Tb) __builtin_nontemporal_store(v, Tb + (long)r1 * m + c1);
+    }
+    if (bi != bj) {
+      int r2 = bj * 32 + rr, c2 = bi * 32 + tx;
+      if (r2 < m && c2 < m) {
+        double v = 0.5 * (t2[rr][tx] + t1[tx][rr]);
+        Pb[(long)r2 * m + c2] = v;
+        if (Tb) __builtin_nontemporal_store(v, Tb + (long)r2 * m + c2);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+size_t kf_forward_big_workspace_bytes(long B, int m) {
+  size_t mm = (size_t)m * m;
+  return sizeof(double) * ((size_t)B * (4 * mm + m) + 64);
+}
+
+int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
+                          hipStream_t stream) {
+  const size_t need = kf_forward_big_workspace_bytes(a.B, a.m);
+  if (!workspace || workspace_bytes < need) {
+    KF_SET_ERR(h, "forward(big): m=%d needs a workspace of %zu bytes (got %zu); see kf_workspace_bytes",
+               a.m, need, workspace_bytes);
+    return KF_ERR_WORKSPACE;
+  }
+  if (a.B > 65535) {
+    KF_SET_ERR(h, "forward(big): B=%ld > 65535 draws per call", a.B);
+    return KF_ERR_UNSUPPORTED;
+  }
+  const int m = a.m, p = a.p;
+  const size_t mm = (size_t)m * m;
+  double* ws = (double*)(((uintptr_t)workspace + 63) & ~(uintptr_t)63);
+  double* P_ws = ws;
+  double* Pf_ws = P_ws + a.B * mm;   // P_f, then S
+  double* W_ws = Pf_ws + a.B * mm;
+  double* RQR_ws = W_ws + a.B * mm;
+  double* a_ws = RQR_ws + a.B * mm;
+
+  size_t lds_upd = sizeof(double) * ((size_t)4 * p * m + 2 * m + 3 * p * p + 4 * p + 8);
+  if (lds_upd > KF_LDS_BYTES_MAX) {
+    KF_SET_ERR(h, "forward(big): p=%d m=%d needs %zu B of LDS in the update kernel", p, m, lds_upd);
+    return KF_ERR_UNSUPPORTED;
+  }
+  KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(big_update_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_upd));
+  const int init_blocks = (int)((mm + 255) / 256 < 64 ? (mm + 255) / 256 : 64);
+  hipLaunchKernelGGL(big_init_kernel, dim3(init_blocks, (unsigned)a.B), dim3(256), 0, stream, a, a_ws,
+                     P_ws, RQR_ws);
+  const int tg = (m + GT - 1) / GT, ts = (m + 31) / 32;
+  for (int t = 0; t < a.T; ++t) {
+    hipLaunchKernelGGL(big_update_kernel, dim3((unsigned)a.B), dim3(256), lds_upd, stream, a, t, a_ws,
+                       P_ws, Pf_ws);
+    hipLaunchKernelGGL((big_gemm_kernel<false, false>), dim3(tg, tg, (unsigned)a.B), dim3(256), 0, stream,
+                       a.Tm, (long)mm, Pf_ws, (long)mm, nullptr, 0L, W_ws, (long)mm, m);
+    hipLaunchKernelGGL((big_gemm_kernel<true, true>), dim3(tg, tg, (unsigned)a.B), dim3(256), 0, stream,
+                       W_ws, (long)mm, a.Tm, (long)mm, RQR_ws, (long)mm, Pf_ws, (long)mm, m);
+    hipLaunchKernelGGL(big_sym_kernel, dim3(ts, ts, (unsigned)a.B), dim3(256), 0, stream, Pf_ws, P_ws,
+                       a.pred_P ? a.pred_P + (size_t)(t + 1) * mm : nullptr, (long)(a.T + 1) * (long)mm, m);
+  }
+  KF_HIP_CHECK(h, hipGetLastError());
+  return KF_OK;
+}

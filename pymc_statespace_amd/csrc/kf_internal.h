@@ -123,7 +123,16 @@ int kf_launch_forward_rowsplit_m8_h2(kf_handle* h, const KfFwdArgs& a, hipStream
 int kf_launch_forward_rowsplit_m8_h4(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 int kf_launch_forward_rowsplit_m6_h3(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 int kf_launch_forward_rowsplit_m4_h2(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
-int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
+                      hipStream_t stream);
+// large-m path (kf_forward_big.hip): covariance in a caller-provided HBM workspace, MFMA GEMMs
+size_t kf_forward_big_workspace_bytes(long B, int m);
+int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
+                          hipStream_t stream);
+inline bool kf_forward_lds_fits(int m, int p) {
+  size_t lds = sizeof(double) * ((size_t)kf_pair_table_doubles(m) + (size_t)kf_fwd_region_doubles(m, p));
+  return lds <= KF_LDS_BYTES_MAX;
+}
 int kf_launch_backward_lds_p0(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_backward_lds_p1(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_backward_lds_p2(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);

@@ -82,6 +82,18 @@ class KalmanEngine:
         dims = self._dims(B, n, p, m, r)
         return self.lib.kf_forward_kernel_name(self._h, C.byref(dims)).decode()
 
+    def _workspace(self, dims):
+        """Scratch for the large-m path (kf_workspace_bytes); cached, grown on demand."""
+        nbytes = C.c_size_t(0)
+        self._check(self.lib.kf_workspace_bytes(self._h, C.byref(dims), C.byref(nbytes)),
+                    "kf_workspace_bytes")
+        if nbytes.value == 0:
+            return None, 0
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < nbytes.value:
+            self._ws = ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+        return ws, ws.numel()
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -156,11 +168,12 @@ class KalmanEngine:
                 predicted_covs=torch.empty(B, n + 1, m, m, device=dev, dtype=f64) if store_predicted else None,
                 info=torch.empty(B, device=dev, dtype=torch.int32),
             )
+        ws, ws_bytes = self._workspace(dims)
         rc = self.lib.kf_filter_forward(
             self._h, C.byref(dims), _ptr(y), _ptr(a0), _ptr(P0), _ptr(T), _ptr(Z), _ptr(R), _ptr(H),
             _ptr(Q), _ptr(c), _ptr(d), _ptr(out.logp), _ptr(out.ll_obs), _ptr(out.filtered_states),
             _ptr(out.predicted_states), _ptr(out.filtered_covs), _ptr(out.predicted_covs),
-            _ptr(out.info), None, 0, self._stream())
+            _ptr(out.info), _ptr(ws), ws_bytes, self._stream())
         self._check(rc, "kf_filter_forward")
         return out
 

@@ -557,3 +557,64 @@ def test_row_kernel_not_positive_definite_reports_info(eng):
     res = eng.forward(w["y"], w["a0"], w["P0"], w["T"], w["Z"], w["R"], H, w["Q"])
     assert int(res.info[0].item()) == ((0 + 1) << 8) | 1
     assert np.isnan(res.logp[0].item())
+
+
+# ----------------------------------------------------------------------------------------------
+# large state dimension: covariance in an HBM workspace, fp64-MFMA GEMMs (BASELINE config C5)
+# ----------------------------------------------------------------------------------------------
+BIG_CASES = {
+    "dense_p2m64": lambda: W.random_dense(3, 10, 2, 64, 8, seed=2),
+    "dense_p3m70": lambda: W.random_dense(2, 8, 3, 70, 5, seed=3),
+    "dense_p1m130": lambda: W.random_dense(2, 6, 1, 130, 3, seed=4),
+    "c5_daily_seasonal_m367": lambda: W.daily_seasonal(B=3, n=8),
+}
+
+
+@pytest.mark.parametrize("case", sorted(BIG_CASES))
+@pytest.mark.parametrize("ft", ["standard", "cholesky", "univariate"])
+def test_big_m_forward_matches_oracle(eng, case, ft):
+    w = BIG_CASES[case]()
+    y = w["y"].copy()
+    y[2] = np.nan
+    assert eng.forward_kernel_name(w["B"], w["n"], w["p"], w["m"], w["r"]) == "big_gemm_kernel"
+    out = _np(eng.forward(*_args(w, y), filter_type=ft, mvn_const="exact"))
+    ref = co.kalman_filter(*_args(w, y), filter_type=ft, mvn_const="exact")
+    assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8
+    for k in TAPES:
+        assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=f"{case} {ft} {k}")
+    assert np.all(out["ll_obs"][:, 2] == 0.0) and not out["info"].any()
+    # covariances stay exactly symmetric through the MFMA path
+    assert np.array_equal(out["predicted_covs"], np.swapaxes(out["predicted_covs"], -1, -2))
+
+
+def test_big_m_needs_workspace_and_says_so(eng):
+    import ctypes as C
+
+    import torch
+
+    from pymc_statespace_amd import _lib
+
+    w = W.random_dense(1, 3, 1, 80, 2, seed=9)
+    dims = _lib.KfDims(1, 3, 1, 80, 2, 0, 0)
+    nbytes = C.c_size_t(0)
+    assert eng.lib.kf_workspace_bytes(eng._h, C.byref(dims), C.byref(nbytes)) == 0
+    assert nbytes.value >= 8 * 4 * 80 * 80
+    d = [eng.to_device(x) for x in _args(w)]
+    logp = torch.empty(1, device=d[1].device, dtype=torch.float64)
+    ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    rc = eng.lib.kf_filter_forward(eng._h, C.byref(dims), *[ptr(x) for x in d], None, None, ptr(logp),
+                                   None, None, None, None, None, None, None, 0, None)
+    assert rc == _lib.KF_ERR_WORKSPACE
+    assert b"workspace" in eng.lib.kf_last_error(eng._h)
+
+
+def test_big_m_smoother_and_gradient_are_declared_unsupported(eng):
+    from pymc_statespace_amd import KalmanError
+
+    w = W.random_dense(1, 4, 1, 150, 2, seed=9)
+    res = eng.forward(*_args(w))
+    with pytest.raises(KalmanError, match="LDS"):
+        eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
+    with pytest.raises(KalmanError, match="LDS"):
+        eng.backward(*_args(w), predicted_states=res.predicted_states,
+                     predicted_covs=res.predicted_covs, g_logp=np.ones(1))
