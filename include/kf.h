@@ -104,9 +104,10 @@ const char* kf_last_error(const kf_handle* h);
  * row of P) for the compiled H; other values fall back to the automatic choice. */
 int kf_set_lanes_per_draw(kf_handle* h, int lanes);
 
-/* Forward-kernel selection (default AUTO: the register-resident "row" kernels when
- * p == 1 and m <= 10, else the LDS-resident generic kernel).  Results agree to rounding. */
-enum { KF_KERNEL_AUTO = 0, KF_KERNEL_LDS = 1, KF_KERNEL_ROW = 2 };
+/* Forward-kernel selection.  AUTO: p == 1 and m <= 4 -> one lane per draw ("lane"); p == 1
+ * and m <= 10 -> register-resident row-owner kernels ("row"); tiles that fit LDS -> generic
+ * LDS-resident kernel; else the workspace + MFMA path.  Results agree to rounding. */
+enum { KF_KERNEL_AUTO = 0, KF_KERNEL_LDS = 1, KF_KERNEL_ROW = 2, KF_KERNEL_LANE = 3 };
 int kf_set_forward_kernel(kf_handle* h, int kernel);
 /* Name of the kernel kf_filter_forward would launch for `dims` (for profiles / bench logs). */
 const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* dims);

@@ -28,7 +28,7 @@ extern "C" int kf_create(kf_handle** out, int device) {
   h->lanes_per_draw = 0;
   h->forward_kernel = KF_KERNEL_AUTO;
   const char* envk = getenv("KF_FORWARD_KERNEL");
-  if (envk) h->forward_kernel = !strcmp(envk, "lds") ? KF_KERNEL_LDS : !strcmp(envk, "row") ? KF_KERNEL_ROW : KF_KERNEL_AUTO;
+  if (envk) h->forward_kernel = !strcmp(envk, "lds") ? KF_KERNEL_LDS : !strcmp(envk, "row") ? KF_KERNEL_ROW : !strcmp(envk, "lane") ? KF_KERNEL_LANE : KF_KERNEL_AUTO;
   const char* env = getenv("KF_LANES_PER_DRAW");
   if (env) h->lanes_per_draw = atoi(env);
   hipDeviceProp_t prop;
@@ -55,7 +55,8 @@ extern "C" int kf_set_lanes_per_draw(kf_handle* h, int lanes) {
 
 extern "C" int kf_set_forward_kernel(kf_handle* h, int kernel) {
   if (!h) return KF_ERR_ARG;
-  if (kernel != KF_KERNEL_AUTO && kernel != KF_KERNEL_LDS && kernel != KF_KERNEL_ROW) {
+  if (kernel != KF_KERNEL_AUTO && kernel != KF_KERNEL_LDS && kernel != KF_KERNEL_ROW &&
+      kernel != KF_KERNEL_LANE) {
     KF_SET_ERR(h, "unknown forward kernel %d", kernel);
     return KF_ERR_ARG;
   }
@@ -94,7 +95,10 @@ extern "C" const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims*
   if (!h || !d) return "";
   const bool row_ok = d->p == 1 && d->m <= KF_ROW_M_MAX;
   if (!kf_forward_lds_fits(d->m, d->p)) return "big_gemm_kernel";
-  if (row_ok && h->forward_kernel != KF_KERNEL_LDS)
+  if (d->p == 1 && d->m <= KF_LANE_M_MAX &&
+      (h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_LANE))
+    return "kf_fwd_lane_kernel";
+  if (row_ok && h->forward_kernel != KF_KERNEL_LDS && h->forward_kernel != KF_KERNEL_LANE)
     return kf_split_for(h, d->m, d->B) > 1 ? "kf_fwd_rowsplit_kernel" : "kf_fwd_row_kernel";
   return "kf_fwd_lds_kernel";
 }
@@ -103,11 +107,24 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t 
                       hipStream_t stream) {
   if (!kf_forward_lds_fits(a.m, a.p)) return kf_launch_forward_big(h, a, workspace, workspace_bytes, stream);
   const bool row_ok = a.p == 1 && a.m <= KF_ROW_M_MAX;
+  const bool lane_ok = a.p == 1 && a.m <= KF_LANE_M_MAX;
+  if (h->forward_kernel == KF_KERNEL_LANE && !lane_ok) {
+    KF_SET_ERR(h, "forward(lane): needs p == 1 and m <= %d (got p=%d m=%d)", KF_LANE_M_MAX, a.p, a.m);
+    return KF_ERR_UNSUPPORTED;
+  }
+  if (lane_ok && (h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_LANE)) {
+    switch (a.m) {
+      case 1: return kf_launch_forward_lane_m1(h, a, stream);
+      case 2: return kf_launch_forward_lane_m2(h, a, stream);
+      case 3: return kf_launch_forward_lane_m3(h, a, stream);
+      default: return kf_launch_forward_lane_m4(h, a, stream);
+    }
+  }
   if (h->forward_kernel == KF_KERNEL_ROW && !row_ok) {
     KF_SET_ERR(h, "forward(row): needs p == 1 and m <= %d (got p=%d m=%d)", KF_ROW_M_MAX, a.p, a.m);
     return KF_ERR_UNSUPPORTED;
   }
-  if (row_ok && h->forward_kernel != KF_KERNEL_LDS) {
+  if (row_ok && h->forward_kernel != KF_KERNEL_LDS && h->forward_kernel != KF_KERNEL_LANE) {
     if (a.m % 2 == 0) {
       // lanes per row H: explicit (lanes_per_draw = m*H) or chosen from the batch size;
       // H == 1 is the plain row-owner kernel below

@@ -121,14 +121,21 @@ __host__ __device__ inline int bwd_region_doubles(int m, int p) {
   return (9 * m * m + 10 * p * m + 10 * p * p + 6 * m + 6 * p + 2) | 1;
 }
 
-template <int G>
+// MT > 0: compile-time k_states (loops unroll, LDS offsets become immediates); 0 = run time.
+template <int G, int MT>
 __global__ __launch_bounds__(KF_WAVE) void kf_bwd_lds_kernel(const KfBwdArgs A) {
   extern __shared__ double smem[];
   constexpr int DPB = KF_WAVE / G;
   const int lane = threadIdx.x;
   const int lig = lane % G;
   const int grp = lane / G;
-  const int m = A.m, p = A.p, r = A.r, n = A.T;
+  const int m = MT > 0 ? MT : A.m;
+#if KF_PMAX == 1
+  const int p = 1;
+#else
+  const int p = A.p;
+#endif
+  const int r = A.r, n = A.T;
   const int mm = m * m, pm = p * m, pp = p * p;
   const int npair = m * (m + 1) / 2;
 
@@ -535,10 +542,21 @@ int launch_g(kf_handle* h, const KfBwdArgs& a, hipStream_t stream) {
                KF_LDS_BYTES_MAX);
     return KF_ERR_UNSUPPORTED;
   }
-  KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kf_bwd_lds_kernel<G>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   long blocks = (a.B + dpb - 1) / dpb;
-  hipLaunchKernelGGL(kf_bwd_lds_kernel<G>, dim3((unsigned)blocks), dim3(KF_WAVE), lds, stream, a);
+#define KF_BWD_LAUNCH(MT_)                                                                          \
+  do {                                                                                              \
+    KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kf_bwd_lds_kernel<G, MT_>),   \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
+    hipLaunchKernelGGL((kf_bwd_lds_kernel<G, MT_>), dim3((unsigned)blocks), dim3(KF_WAVE), lds,     \
+                       stream, a);                                                                  \
+  } while (0)
+#if KF_PMAX == 1
+  if (a.m == 10 && G == 64) KF_BWD_LAUNCH(10);
+  else KF_BWD_LAUNCH(0);
+#else
+  KF_BWD_LAUNCH(0);
+#endif
+#undef KF_BWD_LAUNCH
   KF_HIP_CHECK(h, hipGetLastError());
   return KF_OK;
 }

@@ -16,7 +16,7 @@
 struct kf_handle {
   int device;
   int lanes_per_draw;  // 0 = auto
-  int forward_kernel;  // KF_KERNEL_AUTO / _LDS / _ROW
+  int forward_kernel;  // KF_KERNEL_AUTO / _LDS / _ROW / _LANE
   int n_cu;
   char err[512];
 };
@@ -123,6 +123,12 @@ int kf_launch_forward_rowsplit_m8_h2(kf_handle* h, const KfFwdArgs& a, hipStream
 int kf_launch_forward_rowsplit_m8_h4(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 int kf_launch_forward_rowsplit_m6_h3(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 int kf_launch_forward_rowsplit_m4_h2(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+// lane-per-draw kernels for tiny m (kf_forward_lane.hip)
+#define KF_LANE_M_MAX 4
+int kf_launch_forward_lane_m1(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward_lane_m2(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward_lane_m3(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward_lane_m4(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
                       hipStream_t stream);
 // large-m path (kf_forward_big.hip): covariance in a caller-provided HBM workspace, MFMA GEMMs

@@ -74,8 +74,9 @@ class KalmanEngine:
         self._check(self.lib.kf_set_lanes_per_draw(self._h, int(lanes)), "kf_set_lanes_per_draw")
 
     def set_forward_kernel(self, kernel: str):
-        """'auto' | 'lds' (generic LDS-resident) | 'row' (register-resident, p == 1, m <= 10)."""
-        code = {"auto": 0, "lds": 1, "row": 2}[kernel]
+        """'auto' | 'lds' (generic LDS-resident) | 'row' (register-resident, p == 1, m <= 10)
+        | 'lane' (one lane per draw, p == 1, m <= 4)."""
+        code = {"auto": 0, "lds": 1, "row": 2, "lane": 3}[kernel]
         self._check(self.lib.kf_set_forward_kernel(self._h, code), "kf_set_forward_kernel")
 
     def forward_kernel_name(self, B, n, p, m, r) -> str:

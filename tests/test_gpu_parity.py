@@ -618,3 +618,27 @@ def test_big_m_smoother_and_gradient_are_declared_unsupported(eng):
     with pytest.raises(KalmanError, match="LDS"):
         eng.backward(*_args(w), predicted_states=res.predicted_states,
                      predicted_covs=res.predicted_covs, g_logp=np.ones(1))
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 4])
+@pytest.mark.parametrize("ft", FILTERS)
+def test_lane_kernels_match_oracle(eng, m, ft):
+    """One lane per draw (p == 1, m <= 4): BASELINE configs C1 / C2."""
+    B = 130
+    w = W.random_dense(B, 70, 1, m, max(1, m // 2), seed=200 + m)
+    y = w["y"].copy()
+    y[[0, 17, 69]] = np.nan
+    rng = np.random.default_rng(m)
+    c = 0.1 * rng.standard_normal((B, m))
+    d = 0.1 * rng.standard_normal((B, 1))
+    ref = kn.kalman_filter(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact")
+    assert eng.forward_kernel_name(B, 70, 1, m, w["r"]) == "kf_fwd_lane_kernel"
+    eng.set_forward_kernel("lane")
+    try:
+        out = _np(eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact"))
+    finally:
+        eng.set_forward_kernel("auto")
+    assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8
+    for k in TAPES:
+        assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=f"m={m} {k}")
+    assert not out["info"].any()
