@@ -14,19 +14,22 @@
 //
 // The two m x m x m products are >99% of the flops (m = 367: 2 x 98.9 MFLOP per draw-step) and
 // are real contractions, so they run on the matrix cores: 64x64 output tile per 256-thread
-// workgroup, four waves of 2x2 MFMA 16x16 tiles, K staged through LDS in chunks of 16.
+// workgroup, four waves of 2x2 MFMA 16x16 tiles, K staged through LDS in chunks of 32 with the
+// next chunk prefetched into registers.
 #include "kf_internal.h"
 
 namespace {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int GT = 64;   // output tile edge
-constexpr int GK = 16;   // K chunk
+constexpr int GT = 64;   // output tile edge (128 x 128 tiles measured slower: 1 wave/SIMD, 14.9 vs 17.0 TF)
+constexpr int GK = 32;   // K chunk
 constexpr int GLD = GT + 1;  // LDS row stride (doubles) -- odd: conflict-free column access
+constexpr int GPT = GT * GK / 256;  // staged elements per thread and operand
 
 // C[b] (m x m) = A[b] (m x m) * op(B[b])  (+ E[b]);  op = identity or transpose.
-// grid: (tiles_n, tiles_m, draws)  block: 256
+// grid: (tiles_n, tiles_m, draws)  block: 256.  Software pipeline: the next K chunk is fetched
+// from HBM/L2 into registers while the MFMAs of the current chunk run out of LDS.
 template <bool TRANS_B, bool ADD_E>
 __global__ __launch_bounds__(256) void big_gemm_kernel(const double* __restrict__ A, long strideA,
                                                        const double* __restrict__ Bm, long strideB,
@@ -36,53 +39,76 @@ __global__ __launch_bounds__(256) void big_gemm_kernel(const double* __restrict_
   __shared__ double Bs[GK][GLD];  // Bs[k][c]
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int wr = wave >> 1, wc = wave & 1;  // 2 x 2 waves, 32 x 32 each
+  const int wr = wave >> 1, wc = wave & 1;  // 2 x 2 waves, GT/2 x GT/2 each
   const long b = blockIdx.z;
   const int r0 = blockIdx.y * GT, c0 = blockIdx.x * GT;
   const double* Ab = A + b * strideA;
   const double* Bb = Bm + b * strideB;
 
-  double4_t acc[2][2];
+  constexpr int WT = GT / 32;  // MFMA tiles per wave and dimension
+  double4_t acc[WT][WT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < WT; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
   const int li = lane & 15, lk = lane >> 4;
+  double ra[GPT], rb[GPT];
 
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < GPT; ++q) {
+      const int e = tid + 256 * q;
+      {  // A tile: rows r0.., cols k0.. (GK contiguous doubles per row)
+        const int rr = e / GK, kk = e - rr * GK;
+        const int gr = r0 + rr, gk = k0 + kk;
+        ra[q] = (gr < m && gk < m) ? Ab[(long)gr * m + gk] : 0.0;
+      }
+      if (TRANS_B) {  // op(B)[k][c] = B[c][k]
+        const int cc = e / GK, kk = e - cc * GK;
+        const int gc = c0 + cc, gk = k0 + kk;
+        rb[q] = (gc < m && gk < m) ? Bb[(long)gc * m + gk] : 0.0;
+      } else {
+        const int kk = e / GT, cc = e - kk * GT;
+        const int gc = c0 + cc, gk = k0 + kk;
+        rb[q] = (gc < m && gk < m) ? Bb[(long)gk * m + gc] : 0.0;
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int q = 0; q < GPT; ++q) {
+      const int e = tid + 256 * q;
+      {
+        const int rr = e / GK, kk = e - rr * GK;
+        As[kk][rr] = ra[q];
+      }
+      if (TRANS_B) {
+        const int cc = e / GK, kk = e - cc * GK;
+        Bs[kk][cc] = rb[q];
+      } else {
+        const int kk = e / GT, cc = e - kk * GT;
+        Bs[kk][cc] = rb[q];
+      }
+    }
+  };
+
+  fetch(0);
   for (int k0 = 0; k0 < m; k0 += GK) {
-    // ---- stage A tile: rows r0..r0+63, cols k0..k0+15 (16 contiguous doubles per row) --------
-    for (int e = tid; e < GT * GK; e += 256) {
-      int rr = e / GK, kk = e - rr * GK;
-      int gr = r0 + rr, gk = k0 + kk;
-      As[kk][rr] = (gr < m && gk < m) ? Ab[(long)gr * m + gk] : 0.0;
-    }
-    if (TRANS_B) {
-      // op(B)[k][c] = B[c][k]: rows c0..c0+63 of B, cols k0..k0+15
-      for (int e = tid; e < GT * GK; e += 256) {
-        int cc = e / GK, kk = e - cc * GK;
-        int gc = c0 + cc, gk = k0 + kk;
-        Bs[kk][cc] = (gc < m && gk < m) ? Bb[(long)gc * m + gk] : 0.0;
-      }
-    } else {
-      for (int e = tid; e < GT * GK; e += 256) {
-        int kk = e / GT, cc = e - kk * GT;
-        int gc = c0 + cc, gk = k0 + kk;
-        Bs[kk][cc] = (gc < m && gk < m) ? Bb[(long)gk * m + gc] : 0.0;
-      }
-    }
+    stage();
     __syncthreads();
+    if (k0 + GK < m) fetch(k0 + GK);  // in flight during the MFMAs below
 #pragma unroll
     for (int ks = 0; ks < GK; ks += 4) {
-      double af[2], bf[2];
+      double af[WT], bf[WT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = As[ks + lk][wr * 32 + i * 16 + li];  // A[i=l&15][k=l>>4]
+      for (int i = 0; i < WT; ++i) af[i] = As[ks + lk][wr * (GT / 2) + i * 16 + li];  // A[i=l&15][k=l>>4]
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = Bs[ks + lk][wc * 32 + j * 16 + li];  // B[k=l>>4][j=l&15]
+      for (int j = 0; j < WT; ++j) bf[j] = Bs[ks + lk][wc * (GT / 2) + j * 16 + li];  // B[k=l>>4][j=l&15]
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
@@ -91,13 +117,13 @@ __global__ __launch_bounds__(256) void big_gemm_kernel(const double* __restrict_
   double* Cb = Cm + b * strideC;
   const double* Eb = ADD_E ? E + b * strideE : nullptr;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WT; ++j)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        int gr = r0 + wr * 32 + i * 16 + lk + 4 * rg;
-        int gc = c0 + wc * 32 + j * 16 + li;
+        int gr = r0 + wr * (GT / 2) + i * 16 + lk + 4 * rg;
+        int gc = c0 + wc * (GT / 2) + j * 16 + li;
         if (gr < m && gc < m) {
           double v = acc[i][j][rg];
           if (ADD_E) v += Eb[(long)gr * m + gc];
