@@ -69,7 +69,18 @@ enum {
    * non-degenerate scalar update (:503).  Identical for p == 1. */
   KF_FLAG_MVN_CONST_EXACT = 1u << 0,
   /* y is [B][T][p] instead of the shared [T][p] */
-  KF_FLAG_Y_PER_DRAW = 1u << 1
+  KF_FLAG_Y_PER_DRAW = 1u << 1,
+  /* Time-varying system matrices: the flagged matrix is [B][T][rows][cols] (per draw: time on
+   * axis 0, the reference's 3-D convention, filters/utilities.py:1-20) and step t uses slice t
+   * for both its update and its predict (kalman_filter.py:231-252).  Forward filter only. */
+  KF_FLAG_TV_T = 1u << 4,
+  KF_FLAG_TV_Z = 1u << 5,
+  KF_FLAG_TV_R = 1u << 6,
+  KF_FLAG_TV_H = 1u << 7,
+  KF_FLAG_TV_Q = 1u << 8,
+  KF_FLAG_TV_C = 1u << 9,
+  KF_FLAG_TV_D = 1u << 10,
+  KF_FLAG_TV_ANY = 0x7f0u
 };
 
 /* error codes */

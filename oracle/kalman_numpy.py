@@ -307,6 +307,81 @@ def update_univariate(a, P, y, d, Z, H, nan_mask, mvn_const):
 # --------------------------------------------------------------------------- #
 # whole filter
 # --------------------------------------------------------------------------- #
+def _split_time_varying(x, name, time_varying, core_ndim):
+    """Time-varying matrices carry a time axis in front of the core axes (reference: a 3-D
+    matrix = time on axis 0, filters/utilities.py:1-20); with a draw axis it is (B,n,...).
+    Returns an array shaped (B|1, n|1, ...core)."""
+    x = np.asarray(x, dtype=np.float64)
+    if name in time_varying:
+        if x.ndim == core_ndim + 1:
+            return x[None]
+        if x.ndim == core_ndim + 2:
+            return x
+        raise ValueError(f"time-varying {name}: bad ndim {x.ndim}")
+    if x.ndim == core_ndim:
+        return x[None, None]
+    if x.ndim == core_ndim + 1:
+        return x[:, None]
+    raise ValueError(f"{name}: bad ndim {x.ndim}")
+
+
+def kalman_filter_time_varying(data, a0, P0, T, Z, R, H, Q, c=None, d=None, time_varying=(),
+                               filter_type="standard", mvn_const="reference"):
+    """BaseFilter.build_graph with sequences (kalman_filter.py:126-163, unpack_args :92-124):
+    step t uses slice t of every time-varying matrix for its update AND its predict.
+    Whole-row missing data only.  Same outputs as ``kalman_filter``."""
+    tv = set(time_varying)
+    data = np.asarray(data, dtype=np.float64)
+    if data.ndim == 3 and data.shape[-1] == 1:
+        data = data[..., 0]
+    P0 = np.asarray(P0, dtype=np.float64)
+    batched = P0.ndim == 3
+    P0b = P0 if batched else P0[None]
+    a0 = np.asarray(a0, dtype=np.float64)
+    if a0.ndim >= 2 and a0.shape[-1] == 1 and a0.shape[-2] == P0b.shape[-1]:
+        a0 = a0[..., 0]
+    a0b = a0 if a0.ndim == 2 else a0[None]
+    B, m = P0b.shape[0], P0b.shape[1]
+    n = data.shape[-2]
+    Tm = _split_time_varying(T, "T", tv, 2)
+    Zm = _split_time_varying(Z, "Z", tv, 2)
+    Rm = _split_time_varying(R, "R", tv, 2)
+    Hm = _split_time_varying(H, "H", tv, 2)
+    Qm = _split_time_varying(Q, "Q", tv, 2)
+    p = Zm.shape[-2]
+    cm = np.zeros((1, 1, m)) if c is None else _split_time_varying(np.asarray(c).reshape(np.asarray(c).shape[:-1]) if np.asarray(c).shape[-1] == 1 and np.asarray(c).ndim > 1 and np.asarray(c).shape[-2] == m else c, "c", tv, 1)
+    dm = np.zeros((1, 1, p)) if d is None else _split_time_varying(np.asarray(d).reshape(np.asarray(d).shape[:-1]) if np.asarray(d).shape[-1] == 1 and np.asarray(d).ndim > 1 and np.asarray(d).shape[-2] == p else d, "d", tv, 1)
+
+    def at(x, t):
+        xt = x[:, t if x.shape[1] > 1 else 0]
+        return np.broadcast_to(xt, (B,) + xt.shape[1:])
+
+    a = np.broadcast_to(a0b, (B, m)).copy()
+    P = np.broadcast_to(P0b, (B, m, m)).copy()
+    fa = np.empty((B, n, m)); pa = np.empty((B, n + 1, m))
+    fP = np.empty((B, n, m, m)); pP = np.empty((B, n + 1, m, m))
+    ll_obs = np.empty((B, n))
+    pa[:, 0], pP[:, 0] = a, P
+    for t in range(n):
+        y = np.broadcast_to(data[t] if data.ndim == 2 else data[:, t], (B, p))
+        Tt, Zt, Rt, Ht, Qt, ct, dt = (at(x, t) for x in (Tm, Zm, Rm, Hm, Qm, cm, dm))
+        y_m, Z_m, H_m, all_nan, nan_mask = handle_missing_values(y, Zt, Ht, "delete")
+        if filter_type == "standard":
+            a_f, P_f, ll = update_standard(a, P, y_m, dt, Z_m, H_m, all_nan, nan_mask, mvn_const, "delete")
+        elif filter_type == "cholesky":
+            a_f, P_f, ll = update_cholesky(a, P, y_m, dt, Z_m, H_m, all_nan, nan_mask, mvn_const,
+                                           "delete", "correct")
+        elif filter_type == "single":
+            a_f, P_f, ll = update_single(a, P, y_m, dt, Z_m, H_m, all_nan, nan_mask, mvn_const)
+        else:
+            a_f, P_f, ll = update_univariate(a, P, y_m, dt, Z_m, H_m, nan_mask, mvn_const)
+        a, P = predict(a_f, P_f, ct, Tt, Rt @ Qt @ _T(Rt))
+        fa[:, t], fP[:, t], ll_obs[:, t] = a_f, P_f, ll
+        pa[:, t + 1], pP[:, t + 1] = a, P
+    return dict(filtered_states=fa, predicted_states=pa, filtered_covs=fP, predicted_covs=pP,
+                logp=ll_obs.sum(axis=-1), ll_obs=ll_obs, batched=batched)
+
+
 def kalman_filter(data, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type="standard",
                   mvn_const="reference", cholesky_triangle="reference",
                   partial_missing="reference"):

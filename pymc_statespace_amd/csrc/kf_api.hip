@@ -94,6 +94,7 @@ static int kf_split_for(const kf_handle* h, int m, long B) {
 extern "C" const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* d) {
   if (!h || !d) return "";
   const bool row_ok = d->p == 1 && d->m <= KF_ROW_M_MAX;
+  if (d->flags & KF_FLAG_TV_ANY) return "kf_fwd_lds_kernel";
   if (!kf_forward_lds_fits(d->m, d->p)) return "big_gemm_kernel";
   if (d->p == 1 && d->m <= KF_LANE_M_MAX &&
       (h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_LANE))
@@ -105,6 +106,17 @@ extern "C" const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims*
 
 int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
                       hipStream_t stream) {
+  if (a.flags & KF_FLAG_TV_ANY) {
+    if (((a.flags & KF_FLAG_TV_C) && !a.c) || ((a.flags & KF_FLAG_TV_D) && !a.d)) {
+      KF_SET_ERR(h, "time-varying c / d flagged but the pointer is NULL");
+      return KF_ERR_ARG;
+    }
+    if (!kf_forward_lds_fits(a.m, a.p)) {
+      KF_SET_ERR(h, "time-varying system matrices need the LDS-resident kernel (m=%d p=%d too large)", a.m, a.p);
+      return KF_ERR_UNSUPPORTED;
+    }
+    return kf_launch_forward_lds(h, a, stream);
+  }
   if (!kf_forward_lds_fits(a.m, a.p)) return kf_launch_forward_big(h, a, workspace, workspace_bytes, stream);
   const bool row_ok = a.p == 1 && a.m <= KF_ROW_M_MAX;
   const bool lane_ok = a.p == 1 && a.m <= KF_LANE_M_MAX;
@@ -254,6 +266,10 @@ extern "C" int kf_filter_backward(kf_handle* h, const kf_dims* dims, const doubl
   if (!y || !a0 || !P0 || !T || !Z || !R || !H || !Q || !pred_a || !pred_P) {
     KF_SET_ERR(h, "kf_filter_backward: inputs and the predicted tapes must be non-NULL");
     return KF_ERR_ARG;
+  }
+  if (dims->flags & KF_FLAG_TV_ANY) {
+    KF_SET_ERR(h, "kf_filter_backward: time-varying system matrices are not supported yet");
+    return KF_ERR_UNSUPPORTED;
   }
   if (!g_logp && !g_ll_obs) {
     KF_SET_ERR(h, "kf_filter_backward: g_logp and g_ll_obs are both NULL");

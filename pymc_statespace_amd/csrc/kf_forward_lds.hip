@@ -179,6 +179,12 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lds_kernel(const KfFwdArgs A) 
   const int m = A.m, p = A.p, r = A.r, n = A.T;
   const int mm = m * m, pm = p * m, pp = p * p;
   const int npair = m * (m + 1) / 2;
+  // time-varying system matrices ([B][T][.][.], reference: time on axis 0 of a 3-D matrix,
+  // filters/utilities.py:1-20): reloaded into the LDS tiles at the top of every step
+  const bool tvT = A.flags & KF_FLAG_TV_T, tvZ = A.flags & KF_FLAG_TV_Z, tvR = A.flags & KF_FLAG_TV_R;
+  const bool tvH = A.flags & KF_FLAG_TV_H, tvQ = A.flags & KF_FLAG_TV_Q, tvC = A.flags & KF_FLAG_TV_C;
+  const bool tvD = A.flags & KF_FLAG_TV_D;
+  const bool tv_any = (A.flags & KF_FLAG_TV_ANY) != 0;
 
   long b = (long)blockIdx.x * DPB + grp;
   const bool live = b < A.B;  // tail groups compute a clone of the last draw, store nothing
@@ -216,25 +222,25 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lds_kernel(const KfFwdArgs A) 
 
   // ---- per-draw constants into LDS --------------------------------------------------
   {
-    const double* gT = A.Tm + b * mm;
+    const double* gT = A.Tm + (tvT ? b * n : b) * mm;
     const double* gP = A.P0 + b * mm;
     for (int e = lig; e < mm; e += G) {
       Tl[e] = gT[e];
       Pa[e] = gP[e];
     }
-    const double* gZ = A.Z + b * pm;
+    const double* gZ = A.Z + (tvZ ? b * n : b) * pm;
     for (int e = lig; e < pm; e += G) Zl[e] = gZ[e];
-    const double* gH = A.H + b * pp;
+    const double* gH = A.H + (tvH ? b * n : b) * pp;
     for (int e = lig; e < pp; e += G) Hl[e] = gH[e];
     const double* ga = A.a0 + b * m;
     for (int e = lig; e < m; e += G) {
       al[e] = ga[e];
-      cl[e] = A.c ? A.c[b * m + e] : 0.0;
+      cl[e] = A.c ? A.c[(tvC ? b * n : b) * m + e] : 0.0;
     }
-    for (int e = lig; e < p; e += G) dl[e] = A.d ? A.d[b * p + e] : 0.0;
+    for (int e = lig; e < p; e += G) dl[e] = A.d ? A.d[(tvD ? b * n : b) * p + e] : 0.0;
     // R Q R' once per draw (the reference recomputes it every step, kalman_filter.py:218)
-    const double* gR = A.R + b * (long)m * r;
-    const double* gQ = A.Q + b * (long)r * r;
+    const double* gR = A.R + (tvR ? b * n : b) * (long)m * r;
+    const double* gQ = A.Q + (tvQ ? b * n : b) * (long)r * r;
     for (int e = lig; e < mm; e += G) {
       int i = e / m, j = e - i * m;
       double s = 0.0;
@@ -276,6 +282,28 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lds_kernel(const KfFwdArgs A) 
   int info = 0;
 
   for (int t = 0; t < n; ++t) {
+    if (tv_any && t > 0) {  // (t == 0 was loaded above)
+      const long bt = b * n + t;
+      if (tvT) for (int e = lig; e < mm; e += G) Tl[e] = A.Tm[bt * mm + e];
+      if (tvZ) for (int e = lig; e < pm; e += G) Zl[e] = A.Z[bt * pm + e];
+      if (tvH) for (int e = lig; e < pp; e += G) Hl[e] = A.H[bt * pp + e];
+      if (tvC) for (int e = lig; e < m; e += G) cl[e] = A.c[bt * m + e];
+      if (tvD) for (int e = lig; e < p; e += G) dl[e] = A.d[bt * p + e];
+      if (tvR || tvQ) {
+        const double* gR = A.R + (tvR ? bt : b) * (long)m * r;
+        const double* gQ = A.Q + (tvQ ? bt : b) * (long)r * r;
+        for (int e = lig; e < mm; e += G) {
+          int i = e / m, j = e - i * m;
+          double s = 0.0;
+          for (int l = 0; l < r; ++l) {
+            double rq = 0.0;
+            for (int k = 0; k < r; ++k) rq += gR[i * r + k] * gQ[k * r + l];
+            s += rq * gR[j * r + l];
+          }
+          RQR[e] = s;
+        }
+      }
+    }
     // ---- observation + mask (handle_missing_values :195-213) --------------------------
     for (int q = lig; q < p; q += G) {
       double yv = ybase[(long)t * p + q];

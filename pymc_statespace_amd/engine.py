@@ -127,37 +127,57 @@ class KalmanEngine:
     # ---------------------------------------------------------------- forward
     def forward(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, filter_type="standard",
                 mvn_const="reference", store_ll_obs=True, store_filtered=True,
-                store_predicted=True, out: Optional[FilterResult] = None) -> FilterResult:
+                store_predicted=True, time_varying=(), out: Optional[FilterResult] = None) -> FilterResult:
         """kf_filter_forward.  y (n,p) shared or (B,n,p); a0 (B,m); P0,T (B,m,m); Z (B,p,m);
-        R (B,m,r); H (B,p,p); Q (B,r,r); c (B,m); d (B,p)."""
-        T = self.to_device(T)
-        if T.ndim != 3 or T.shape[1] != T.shape[2]:
-            raise ValueError(f"T must be (B,m,m), got {tuple(T.shape)}")
-        B, m = T.shape[0], T.shape[1]
+        R (B,m,r); H (B,p,p); Q (B,r,r); c (B,m); d (B,p).  Names listed in ``time_varying``
+        (subset of T,Z,R,H,Q,c,d) carry an extra time axis after the draw axis: (B,n,...)."""
+        tv = set(time_varying)
+        if not tv <= set(_lib.KF_FLAG_TV):
+            raise ValueError(f"time_varying must be a subset of {sorted(_lib.KF_FLAG_TV)}")
+        P0 = self.to_device(P0)
+        if P0.ndim != 3 or P0.shape[1] != P0.shape[2]:
+            raise ValueError(f"P0 must be (B,m,m), got {tuple(P0.shape)}")
+        B, m = P0.shape[0], P0.shape[1]
         Z = self.to_device(Z)
-        if Z.ndim != 3 or Z.shape[0] != B or Z.shape[2] != m:
-            raise ValueError(f"Z must be (B,p,m) = ({B},p,{m}), got {tuple(Z.shape)}")
-        p = Z.shape[1]
+        if Z.ndim != (4 if "Z" in tv else 3) or Z.shape[0] != B or Z.shape[-1] != m:
+            raise ValueError(f"Z must be (B,[n,]p,m) with B={B}, m={m}; got {tuple(Z.shape)}")
+        p = Z.shape[-2]
         R = self.to_device(R)
-        if R.ndim != 3 or R.shape[0] != B or R.shape[1] != m:
-            raise ValueError(f"R must be (B,m,r), got {tuple(R.shape)}")
-        r = R.shape[2]
+        if R.ndim != (4 if "R" in tv else 3) or R.shape[0] != B or R.shape[-2] != m:
+            raise ValueError(f"R must be (B,[n,]m,r), got {tuple(R.shape)}")
+        r = R.shape[-1]
         y = self.to_device(y)
         y_per_draw = y.ndim == 3
         if y.ndim not in (2, 3) or y.shape[-1] != p or (y_per_draw and y.shape[0] != B):
             raise ValueError(f"y must be (n,{p}) or ({B},n,{p}), got {tuple(y.shape)}")
         n = y.shape[-2]
+
+        def shp(name, *core):
+            return (B, n) + core if name in tv else (B,) + core
+
+        def tvcheck(name, x, *core):
+            # assert_time_varying_dim_correct, reference filters/kalman_filter.py:20-23,:79-90
+            if name in tv and x is not None and x.ndim == 2 + len(core) and x.shape[1] != n:
+                raise AssertionError(
+                    "The first dimension of a time varying matrix (the time dimension) must be "
+                    "equal to the first dimension of the data (the time dimension).")
+            return self.to_device(x, shp(name, *core)) if x is not None else None
+
         a0 = self.to_device(a0, (B, m))
-        P0 = self.to_device(P0, (B, m, m))
-        H = self.to_device(H, (B, p, p))
-        Q = self.to_device(Q, (B, r, r))
-        c = self.to_device(c, (B, m)) if c is not None else None
-        d = self.to_device(d, (B, p)) if d is not None else None
+        T = tvcheck("T", self.to_device(T), m, m)
+        Z = tvcheck("Z", Z, p, m)
+        R = tvcheck("R", R, m, r)
+        H = tvcheck("H", self.to_device(H), p, p)
+        Q = tvcheck("Q", self.to_device(Q), r, r)
+        c = tvcheck("c", self.to_device(c), m)
+        d = tvcheck("d", self.to_device(d), p)
         if filter_type == "single" and p != 1:
             # assert_data_is_1d, reference filters/kalman_filter.py:19,:329
             raise AssertionError("UnivariateTimeSeries filter requires data be at most 1-dimensional")
 
         dims = self._dims(B, n, p, m, r, filter_type, mvn_const, y_per_draw)
+        for name in tv:
+            dims.flags |= _lib.KF_FLAG_TV[name]
         dev, f64 = self.device, torch.float64
         if out is None:
             out = FilterResult(

@@ -39,20 +39,20 @@ def _np_or_t(x):
 
 
 def _check_ndim(params, names, batched):
-    """split_vars_into_seq_and_nonseq, reference filters/utilities.py:1-20.
-
-    Eager calls interpret one extra leading axis as the batch of draws; a time-varying
-    (time-major 3-D) system is a later row of the scope table."""
+    """split_vars_into_seq_and_nonseq, reference filters/utilities.py:1-20: per draw a 2-D
+    matrix is static, a 3-D one is time varying (time on axis 0).  With ``batched`` the draw
+    axis leads.  Returns the names of the time-varying matrices."""
+    seq = []
     for prm, name in zip(params, names):
         nd = prm.ndim - (1 if batched else 0)
         if nd == 2:
             continue
         if nd == 3:
-            raise NotImplementedError(
-                f"Matrix {name} is time varying (3-D); the MI355X path supports static system "
-                "matrices only")
+            seq.append(name)
+            continue
         raise ValueError(
             f"Matrix {name} has {prm.ndim}, it should either 2 (static) or 3 (time varying).")
+    return seq
 
 
 class BaseFilter:
@@ -96,8 +96,10 @@ class BaseFilter:
         (or only ``[logp]`` for ``outputs="logp"``)."""
         as_torch = _is_torch(data, a0, P0, T, Z, R, H, Q)
         T_, Z_, R_, H_, Q_ = map(_np_or_t, (T, Z, R, H, Q))
-        batched = T_.ndim == 3 and P0 is not None and _np_or_t(P0).ndim == 3
-        _check_ndim([T_, Z_, R_, H_, Q_], ["T", "Z", "R", "H", "Q"], batched)
+        batched = P0 is not None and _np_or_t(P0).ndim == 3
+        seq = _check_ndim([T_, Z_, R_, H_, Q_], ["T", "Z", "R", "H", "Q"], batched)
+        self.seq_names = seq
+        self.non_seq_names = [nm for nm in PARAM_NAMES if nm not in seq]
 
         def lead(x, core_ndim):
             x = _np_or_t(x)
@@ -118,7 +120,7 @@ class BaseFilter:
             lead(Q_, 2), None if c is None else lead(c, 1), None if d is None else lead(d, 1),
             filter_type=self.filter_type, mvn_const=self.mvn_const,
             store_ll_obs=outputs == "all", store_filtered=outputs == "all",
-            store_predicted=outputs == "all")
+            store_predicted=outputs == "all", time_varying=seq)
         info = res.info.cpu().numpy()
         if self.on_error == "raise" and np.any(info != 0):
             bad = int(np.flatnonzero(info)[0])
@@ -187,7 +189,9 @@ class KalmanSmoother:
         fP = _np_or_t(filtered_covariances)
         fa = _np_or_t(filtered_states)
         batched = fP.ndim == 4
-        _check_ndim([T_, R_, Q_], ["T", "R", "Q"], batched)
+        if _check_ndim([T_, R_, Q_], ["T", "R", "Q"], batched):
+            raise NotImplementedError(
+                "the MI355X smoother supports static T, R, Q only (time-varying: forward filter)")
         m = T_.shape[-1]
         if fa.shape[-1] == 1 and fa.ndim >= 2 and fa.shape[-2] == m:
             fa = fa[..., 0]
