@@ -164,6 +164,24 @@ int kf_smoother(kf_handle* h, const kf_dims* dims,
                 double* smooth_a, double* smooth_P,
                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- the step before the filter ---------------------------
+ * Batched theta -> matrix assembly: out[b][:] = tmpl[:], then out[b][dst[i]] = theta[b][src[i]]
+ * for i < n_map.  `out` is one flat block of `total` doubles per draw that the caller carves
+ * into (a0, P0, T, Z, R, H, Q); dst/src are device int32 index maps built once on the host from
+ * the model structure.  Replaces the per-draw set_subtensor sequence of the models' update()
+ * (pymc_statespace/models/SARIMAX.py:59-98, models/VARMAX.py:95-143). */
+int kf_assemble(kf_handle* h, int64_t B, int32_t n_theta, const double* theta, int64_t total,
+                const double* tmpl, int32_t n_map, const int32_t* dst, const int32_t* src,
+                double* out, void* stream);
+
+/* Batched discrete Lyapunov solve P = T P T' + S per draw, with S given ([B][m][m]) or, when
+ * S is NULL, S = R Q R' from R [B][m][r], Q [B][r][r].  Replaces
+ * solve_discrete_lyapunov(T, R Q R', method="bilinear") of the stationary initialisation
+ * (models/SARIMAX.py:100-107, models/VARMAX.py:145-150).  info[b] = 0 ok, 1 = the doubling
+ * iteration did not converge (spectral radius of T >= 1). */
+int kf_lyapunov(kf_handle* h, int64_t B, int32_t m, int32_t r, const double* T, const double* R,
+                const double* Q, const double* S, double* P, int32_t* info, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

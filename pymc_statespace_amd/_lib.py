@@ -25,6 +25,7 @@ EXPORTS = (
     "kf_abi_version", "kf_create", "kf_destroy", "kf_last_error", "kf_set_lanes_per_draw",
     "kf_set_forward_kernel", "kf_forward_kernel_name",
     "kf_workspace_bytes", "kf_filter_forward", "kf_filter_backward", "kf_smoother",
+    "kf_assemble", "kf_lyapunov",
 )
 
 
@@ -47,6 +48,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; load it FIRST so libkf_hip.so binds to the same HIP
+    # runtime the tensors live in (two runtimes in one process do not share devices/streams)
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise KfLibraryMissing(
             f"{LIB_PATH} not found: the HIP extension is not built. Run "
@@ -78,6 +83,10 @@ def load():
     lib.kf_filter_backward.restype = C.c_int
     lib.kf_smoother.argtypes = [vp, C.POINTER(KfDims)] + [dp] * 5 + [dp] * 2 + [vp, C.c_size_t, vp]
     lib.kf_smoother.restype = C.c_int
+    lib.kf_assemble.argtypes = [vp, C.c_int64, C.c_int32, dp, C.c_int64, dp, C.c_int32, dp, dp, dp, vp]
+    lib.kf_assemble.restype = C.c_int
+    lib.kf_lyapunov.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, dp, dp, dp, dp, dp, ip, vp]
+    lib.kf_lyapunov.restype = C.c_int
     if lib.kf_abi_version() != KF_ABI_VERSION:
         raise KfLibraryMissing(f"{LIB_PATH}: ABI version {lib.kf_abi_version()} != {KF_ABI_VERSION}")
     _lib = lib

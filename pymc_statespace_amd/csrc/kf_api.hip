@@ -303,3 +303,25 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
   a.smooth_a = smooth_a; a.smooth_P = smooth_P;
   return kf_launch_smoother_lds(h, a, (hipStream_t)stream);
 }
+
+extern "C" int kf_assemble(kf_handle* h, int64_t B, int32_t n_theta, const double* theta, int64_t total,
+                           const double* tmpl, int32_t n_map, const int32_t* dst, const int32_t* src,
+                           double* out, void* stream) {
+  if (!h) return KF_ERR_ARG;
+  if (B < 1 || n_theta < 0 || total < 1 || n_map < 0 || !tmpl || !out || (n_map > 0 && (!theta || !dst || !src))) {
+    KF_SET_ERR(h, "kf_assemble: bad arguments (B=%ld n_theta=%d total=%ld n_map=%d)", (long)B, n_theta,
+               (long)total, n_map);
+    return KF_ERR_ARG;
+  }
+  return kf_launch_assemble(h, B, n_theta, theta, total, tmpl, n_map, dst, src, out, (hipStream_t)stream);
+}
+
+extern "C" int kf_lyapunov(kf_handle* h, int64_t B, int32_t m, int32_t r, const double* T, const double* R,
+                           const double* Q, const double* S, double* P, int32_t* info, void* stream) {
+  if (!h) return KF_ERR_ARG;
+  if (B < 1 || m < 1 || !T || !P || (!S && (!R || !Q || r < 1))) {
+    KF_SET_ERR(h, "kf_lyapunov: need T, P and either S or (R, Q, r >= 1)");
+    return KF_ERR_ARG;
+  }
+  return kf_launch_lyapunov(h, B, m, r, T, R, Q, S, P, info, (hipStream_t)stream);
+}

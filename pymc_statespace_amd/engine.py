@@ -262,6 +262,41 @@ class KalmanEngine:
         return sa, sP
 
 
+    # ------------------------------------------------- before the filter (section 8f row 1)
+    def lyapunov(self, T, R=None, Q=None, S=None):
+        """kf_lyapunov: P (B,m,m) with P = T P T' + S, S given or R Q R'.  Returns (P, info)."""
+        T = self.to_device(T)
+        B, m = T.shape[0], T.shape[1]
+        if S is not None:
+            S = self.to_device(S, (B, m, m))
+            r = 0
+        else:
+            R = self.to_device(R)
+            r = R.shape[2]
+            R = self.to_device(R, (B, m, r))
+            Q = self.to_device(Q, (B, r, r))
+        P = torch.empty(B, m, m, device=self.device, dtype=torch.float64)
+        info = torch.empty(B, device=self.device, dtype=torch.int32)
+        rc = self.lib.kf_lyapunov(self._h, B, m, r, _ptr(T), _ptr(R), _ptr(Q), _ptr(S), _ptr(P),
+                                  _ptr(info), self._stream())
+        self._check(rc, "kf_lyapunov")
+        return P, info
+
+    def assemble(self, theta, template, dst, src):
+        """kf_assemble: out (B,total) = template with out[:, dst] = theta[:, src]."""
+        theta = self.to_device(theta)
+        B, n_theta = theta.shape
+        template = self.to_device(template)
+        total = template.numel()
+        dst = torch.as_tensor(np.asarray(dst, dtype=np.int32), device=self.device)
+        src = torch.as_tensor(np.asarray(src, dtype=np.int32), device=self.device)
+        out = torch.empty(B, total, device=self.device, dtype=torch.float64)
+        rc = self.lib.kf_assemble(self._h, B, n_theta, _ptr(theta), total, _ptr(template),
+                                  dst.numel(), _ptr(dst), _ptr(src), _ptr(out), self._stream())
+        self._check(rc, "kf_assemble")
+        return out
+
+
 _engines = {}
 
 
