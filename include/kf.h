@@ -182,6 +182,17 @@ int kf_assemble(kf_handle* h, int64_t B, int32_t n_theta, const double* theta, i
 int kf_lyapunov(kf_handle* h, int64_t B, int32_t m, int32_t r, const double* T, const double* R,
                 const double* Q, const double* S, double* P, int32_t* info, void* stream);
 
+/* ---- the step after the filter ----------------------------
+ * Batched conditional simulation: out[(b*n_sims + j)][t][:] = mu[b][t][:] + L[b][t] z[b][j][t][:]
+ * with L[b][t] = chol(cov[b][t] + jitter I); mu [B][n][k], cov [B][n][k][k] are a state tape
+ * and its covariance tape (filtered / predicted / smoothed), z [B][n_sims][n][k] standard
+ * normals supplied by the caller.  Replaces conditional_simulation / numba_mvn_draws
+ * (pymc_statespace/utils/simulation.py:7-26).  info[b] != 0: a block was not positive
+ * definite even with the jitter (encoded like kf_filter_forward's info). */
+int kf_conditional_simulation(kf_handle* h, int64_t B, int32_t n, int32_t k, int32_t n_sims,
+                              const double* mu, const double* cov, const double* z, double jitter,
+                              double* out, int32_t* info, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,7 @@ EXPORTS = (
     "kf_abi_version", "kf_create", "kf_destroy", "kf_last_error", "kf_set_lanes_per_draw",
     "kf_set_forward_kernel", "kf_forward_kernel_name",
     "kf_workspace_bytes", "kf_filter_forward", "kf_filter_backward", "kf_smoother",
-    "kf_assemble", "kf_lyapunov",
+    "kf_assemble", "kf_lyapunov", "kf_conditional_simulation",
 )
 
 
@@ -87,6 +87,9 @@ def load():
     lib.kf_assemble.restype = C.c_int
     lib.kf_lyapunov.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, dp, dp, dp, dp, dp, ip, vp]
     lib.kf_lyapunov.restype = C.c_int
+    lib.kf_conditional_simulation.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp,
+                                              C.c_double, dp, ip, vp]
+    lib.kf_conditional_simulation.restype = C.c_int
     if lib.kf_abi_version() != KF_ABI_VERSION:
         raise KfLibraryMissing(f"{LIB_PATH}: ABI version {lib.kf_abi_version()} != {KF_ABI_VERSION}")
     _lib = lib

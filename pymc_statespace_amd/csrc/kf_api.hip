@@ -325,3 +325,15 @@ extern "C" int kf_lyapunov(kf_handle* h, int64_t B, int32_t m, int32_t r, const 
   }
   return kf_launch_lyapunov(h, B, m, r, T, R, Q, S, P, info, (hipStream_t)stream);
 }
+
+extern "C" int kf_conditional_simulation(kf_handle* h, int64_t B, int32_t n, int32_t k, int32_t n_sims,
+                                         const double* mu, const double* cov, const double* z,
+                                         double jitter, double* out, int32_t* info, void* stream) {
+  if (!h) return KF_ERR_ARG;
+  if (B < 1 || n < 1 || k < 1 || n_sims < 1 || !mu || !cov || !z || !out || !(jitter >= 0.0)) {
+    KF_SET_ERR(h, "kf_conditional_simulation: bad arguments (B=%ld n=%d k=%d n_sims=%d)", (long)B, n, k,
+               n_sims);
+    return KF_ERR_ARG;
+  }
+  return kf_launch_simulate(h, B, n, k, n_sims, mu, cov, z, jitter, out, info, (hipStream_t)stream);
+}

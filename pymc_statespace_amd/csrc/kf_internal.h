@@ -149,6 +149,9 @@ int kf_launch_smoother_lds(kf_handle* h, const KfSmoothArgs& a, hipStream_t stre
 int kf_pick_lanes(const kf_handle* h, int m, long B);
 int kf_launch_lyapunov(kf_handle* h, long B, int m, int r, const double* T, const double* R,
                        const double* Q, const double* S, double* P, int32_t* info, hipStream_t stream);
+int kf_launch_simulate(kf_handle* h, long B, int n, int k, int n_sims, const double* mu,
+                       const double* cov, const double* z, double jitter, double* out, int32_t* info,
+                       hipStream_t stream);
 int kf_launch_assemble(kf_handle* h, long B, int n_theta, const double* theta, long total,
                        const double* tmpl, int n_map, const int32_t* dst, const int32_t* src,
                        double* out, hipStream_t stream);

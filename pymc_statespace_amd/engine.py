@@ -297,6 +297,27 @@ class KalmanEngine:
         return out
 
 
+    # -------------------------------------------------- after the filter (section 8f row 2)
+    def conditional_simulation(self, mus, covs, n_simulations=100, jitter=1e-10, generator=None, z=None):
+        """kf_conditional_simulation: mus (B,n,k), covs (B,n,k,k) -> (B*n_simulations, n, k), ordered
+        like the reference (sample-major: simulation j of sample i at row i*n_simulations + j)."""
+        mus = self.to_device(mus)
+        B, n, k = mus.shape
+        covs = self.to_device(covs, (B, n, k, k))
+        if z is None:
+            z = torch.randn(B, n_simulations, n, k, device=self.device, dtype=torch.float64,
+                            generator=generator)
+        else:
+            z = self.to_device(z, (B, n_simulations, n, k))
+        out = torch.empty(B * n_simulations, n, k, device=self.device, dtype=torch.float64)
+        info = torch.empty(B, device=self.device, dtype=torch.int32)
+        rc = self.lib.kf_conditional_simulation(self._h, B, n, k, n_simulations, _ptr(mus), _ptr(covs),
+                                                _ptr(z), float(jitter), _ptr(out), _ptr(info),
+                                                self._stream())
+        self._check(rc, "kf_conditional_simulation")
+        return out, info
+
+
 _engines = {}
 
 
