@@ -227,7 +227,7 @@ extern "C" int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_
   if (!h || !dims || !bytes) return KF_ERR_ARG;
   *bytes = 0;  // the LDS- and register-resident kernels keep all scratch on chip
   if (dims->m >= 1 && dims->p >= 1 && !kf_forward_lds_fits(dims->m, dims->p))
-    *bytes = kf_forward_big_workspace_bytes(dims->B, dims->m);
+    *bytes = kf_forward_big_workspace_bytes(dims->B, dims->m, dims->p);
   return KF_OK;
 }
 

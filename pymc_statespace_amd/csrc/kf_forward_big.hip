@@ -373,6 +373,236 @@ __global__ __launch_bounds__(256) void big_update_kernel(const KfFwdArgs A, int 
   }
 }
 
+
+// ---- split update for Standard / Cholesky / Single (parallel over rows and elements) ----------
+// (the fused big_update_kernel above, one workgroup per draw, remains the Univariate path)
+
+constexpr int BIG_PMAX = 8;   // observations handled per pass by the row kernels
+constexpr int MV_ROWS = 16;   // rows of P per workgroup in big_mvec_kernel
+
+// M[b][j][q] = sum_k P[b][j][k] Z[b][q][k]  (0 for missing q); wave per row, lanes over k
+__global__ __launch_bounds__(256) void big_mvec_kernel(const KfFwdArgs A, int t, const double* P_ws,
+                                                       double* M_ws) {
+  const long b = blockIdx.y;
+  const int m = A.m, p = A.p, n = A.T;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double* P = P_ws + b * (long)m * m;
+  const double* Zg = A.Z + b * (long)p * m;
+  const double* yt = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n * p : 0L) + (long)t * p;
+  for (int q0 = 0; q0 < p; q0 += BIG_PMAX) {
+    for (int rr = wave; rr < MV_ROWS; rr += 4) {
+      const int j = blockIdx.x * MV_ROWS + rr;
+      if (j >= m) break;
+      double acc[BIG_PMAX];
+#pragma unroll
+      for (int q = 0; q < BIG_PMAX; ++q) acc[q] = 0.0;
+      for (int k = lane; k < m; k += 64) {
+        const double pk = P[(long)j * m + k];
+#pragma unroll
+        for (int q = 0; q < BIG_PMAX; ++q)
+          if (q0 + q < p) acc[q] = fma(pk, Zg[(q0 + q) * m + k], acc[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < BIG_PMAX; ++q) {
+        if (q0 + q < p) {
+          double s = wave_sum(acc[q]);
+          const double yv = yt[q0 + q];
+          if (lane == 0) M_ws[(b * m + j) * p + q0 + q] = (yv != yv) ? 0.0 : s;
+        }
+      }
+    }
+  }
+}
+
+// per draw: v, F, chol, K, KF, a_f, ll, tapes of the filtered state, a_hat = T a_f + c
+__global__ __launch_bounds__(256) void big_gain_kernel(const KfFwdArgs A, int t, const double* a_ws,
+                                                       const double* M_ws, double* K_ws, double* KF_ws,
+                                                       double* af_ws) {
+  extern __shared__ double sm[];
+  const long b = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m = A.m, p = A.p, n = A.T;
+  const long mm = (long)m * m;
+  const int pm = p * m, pp = p * p;
+  double* Zl = sm;
+  double* M = Zl + pm;
+  double* K = M + pm;
+  double* al = K + pm;
+  double* af = al + m;
+  double* Hl = af + m;
+  double* F = Hl + pp;
+  double* L = F + pp;
+  double* vl = L + pp;
+  double* ym = vl + p;
+  double* ob = ym + p;
+  double* wv = ob + p;
+  const double* a = a_ws + b * m;
+  const bool exact_const = (A.flags & KF_FLAG_MVN_CONST_EXACT) != 0;
+  const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;
+  const double* yt = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n * p : 0L) + (long)t * p;
+  for (int e = tid; e < pm; e += 256) {
+    Zl[e] = A.Z[b * pm + e];
+    M[e] = M_ws[b * pm + e];
+  }
+  for (int e = tid; e < pp; e += 256) Hl[e] = A.H[b * pp + e];
+  for (int e = tid; e < m; e += 256) al[e] = a[e];
+  for (int q = tid; q < p; q += 256) {
+    double yv = yt[q];
+    bool miss = yv != yv;
+    ym[q] = miss ? 0.0 : yv;
+    ob[q] = miss ? 0.0 : 1.0;
+  }
+  __syncthreads();
+  double nobs = 0.0;
+  for (int q = 0; q < p; ++q) nobs += ob[q];
+  // v (p dots) and F (p*p dots) of length m: one wave per dot, lanes over the state index
+  for (int e = wave; e < p + pp; e += 4) {
+    if (e < p) {
+      const int q = e;
+      double s = 0.0;
+      for (int j = lane; j < m; j += 64) s += Zl[q * m + j] * al[j];
+      s = wave_sum(s);
+      if (lane == 0)
+        vl[q] = ob[q] != 0.0 ? (ym[q] + dsign * (A.d ? A.d[b * p + q] : 0.0)) - s : 0.0;
+    } else {
+      const int f = e - p, q1 = f / p, q2 = f - q1 * p;
+      double s = 0.0;
+      if (ob[q1] != 0.0 && ob[q2] != 0.0) {
+        for (int j = lane; j < m; j += 64) s += Zl[q1 * m + j] * M[j * p + q2];
+        s = wave_sum(s) + Hl[f];
+      } else {
+        s = (q1 == q2) ? 1.0 : 0.0;
+      }
+      if (lane == 0) F[f] = s;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int fail = 0;
+    for (int j = 0; j < p; ++j) {
+      double s = F[j * p + j];
+      for (int k = 0; k < j; ++k) s -= L[j * p + k] * L[j * p + k];
+      if (!(s > 0.0) && fail == 0) fail = j + 1;
+      double dj = sqrt(s);
+      L[j * p + j] = dj;
+      for (int i = j + 1; i < p; ++i) {
+        double t_ = F[i * p + j];
+        for (int k = 0; k < j; ++k) t_ -= L[i * p + k] * L[j * p + k];
+        L[i * p + j] = t_ / dj;
+      }
+    }
+    double q2 = 0.0, ld = 0.0;
+    for (int i = 0; i < p; ++i) {
+      double t_ = vl[i];
+      for (int k = 0; k < i; ++k) t_ -= L[i * p + k] * wv[k];
+      t_ /= L[i * p + i];
+      wv[i] = t_;
+      q2 += t_ * t_;
+      ld += log(L[i * p + i]);
+    }
+    double nconst = exact_const ? nobs : (A.filter == KF_FILTER_CHOLESKY ? (double)p : 1.0);
+    double ll = (nobs == 0.0) ? 0.0 : (-0.5 * (nconst * KF_LOG_2PI + q2) - ld);
+    A.logp[b] += ll;
+    if (A.ll_obs) A.ll_obs[b * (long)n + t] = ll;
+    if (fail != 0 && A.info && A.info[b] == 0) A.info[b] = ((t + 1) << 8) | fail;
+  }
+  __syncthreads();
+  for (int j = tid; j < m; j += 256) {
+    for (int i = 0; i < p; ++i) {
+      double t_ = M[j * p + i];
+      for (int k = 0; k < i; ++k) t_ -= L[i * p + k] * K[j * p + k];
+      K[j * p + i] = t_ / L[i * p + i];
+    }
+    for (int i = p - 1; i >= 0; --i) {
+      double t_ = K[j * p + i];
+      for (int k = i + 1; k < p; ++k) t_ -= L[k * p + i] * K[j * p + k];
+      K[j * p + i] = t_ / L[i * p + i];
+    }
+    double s = al[j];
+    for (int q = 0; q < p; ++q) {
+      s += K[j * p + q] * vl[q];
+      K_ws[b * pm + j * p + q] = K[j * p + q];
+    }
+    af_ws[b * m + j] = s;
+    if (A.filt_a) A.filt_a[(b * (long)n + t) * m + j] = s;
+    for (int q = 0; q < p; ++q) {
+      double kf = 0.0;
+      for (int q2 = 0; q2 < p; ++q2) kf += K[j * p + q2] * F[q2 * p + q];
+      KF_ws[b * pm + j * p + q] = kf;
+    }
+  }
+  (void)mm;
+  (void)af;
+}
+
+// a_hat = T a_f + c : wave per row of T, MV_ROWS rows per workgroup
+__global__ __launch_bounds__(256) void big_apred_kernel(const KfFwdArgs A, int t, const double* af_ws,
+                                                        double* a_ws) {
+  __shared__ double afs[1024];
+  const long b = blockIdx.y;
+  const int m = A.m, n = A.T;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double* Tb = A.Tm + b * (long)m * m;
+  const double* afg = af_ws + b * m;
+  const bool in_lds = m <= 1024;
+  if (in_lds) {
+    for (int k = threadIdx.x; k < m; k += 256) afs[k] = afg[k];
+    __syncthreads();
+  }
+  for (int rr = wave; rr < MV_ROWS; rr += 4) {
+    const int i = blockIdx.x * MV_ROWS + rr;
+    if (i >= m) break;
+    double s = 0.0;
+    for (int k = lane; k < m; k += 64) s += Tb[(long)i * m + k] * (in_lds ? afs[k] : afg[k]);
+    s = wave_sum(s);
+    if (lane == 0) {
+      s += A.c ? A.c[b * m + i] : 0.0;
+      a_ws[b * m + i] = s;
+      if (A.pred_a) A.pred_a[(b * (long)(n + 1) + t + 1) * m + i] = s;
+    }
+  }
+}
+
+// P_f = P - K M' - M K' + (K F) K'   elementwise, rows i0..i0+PF_ROWS of one draw per workgroup
+constexpr int PF_ROWS = 8;
+__global__ __launch_bounds__(256) void big_pf_kernel(const KfFwdArgs A, int t, const double* P_ws,
+                                                     const double* M_ws, const double* K_ws,
+                                                     const double* KF_ws, double* Pf_ws) {
+  extern __shared__ double sm[];
+  const long b = blockIdx.y;
+  const int m = A.m, p = A.p, n = A.T;
+  const long mm = (long)m * m;
+  const int pm = p * m;
+  double* M = sm;
+  double* K = M + pm;
+  for (int e = threadIdx.x; e < pm; e += 256) {
+    M[e] = M_ws[b * pm + e];
+    K[e] = K_ws[b * pm + e];
+  }
+  __syncthreads();
+  const double* KF = KF_ws + b * pm;
+  const double* P = P_ws + b * mm;
+  double* Pf = Pf_ws + b * mm;
+  double* o_fP = A.filt_P ? A.filt_P + (b * (long)n + t) * mm : nullptr;
+  const int i0 = blockIdx.x * PF_ROWS;
+  for (int rr = 0; rr < PF_ROWS; ++rr) {
+    const int i = i0 + rr;
+    if (i >= m) break;
+    for (int j = threadIdx.x; j < m; j += 256) {
+      const long e = (long)i * m + j;
+      double s = P[e];
+      for (int q = 0; q < p; ++q) {
+        const double kj = K[j * p + q];
+        s -= K[i * p + q] * M[j * p + q];
+        s -= M[i * p + q] * kj;
+        s += KF[i * p + q] * kj;
+      }
+      Pf[e] = s;
+      if (o_fP) __builtin_nontemporal_store(s, o_fP + e);
+    }
+  }
+}
+
 // P = (S + S')/2 via 32 x 32 LDS transposes; predicted covariance tape
 __global__ __launch_bounds__(256) void big_sym_kernel(const double* __restrict__ S, double* __restrict__ P,
                                                       double* pred_P, long tape_stride, int m) {
@@ -412,14 +642,14 @@ __global__ __launch_bounds__(256) void big_sym_kernel(const double* __restrict__
 
 }  // namespace
 
-size_t kf_forward_big_workspace_bytes(long B, int m) {
+size_t kf_forward_big_workspace_bytes(long B, int m, int p) {
   size_t mm = (size_t)m * m;
-  return sizeof(double) * ((size_t)B * (4 * mm + m) + 64);
+  return sizeof(double) * ((size_t)B * (4 * mm + 2 * m + 3 * (size_t)m * p) + 64);
 }
 
 int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
                           hipStream_t stream) {
-  const size_t need = kf_forward_big_workspace_bytes(a.B, a.m);
+  const size_t need = kf_forward_big_workspace_bytes(a.B, a.m, a.p);
   if (!workspace || workspace_bytes < need) {
     KF_SET_ERR(h, "forward(big): m=%d needs a workspace of %zu bytes (got %zu); see kf_workspace_bytes",
                a.m, need, workspace_bytes);
@@ -437,6 +667,10 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
   double* W_ws = Pf_ws + a.B * mm;
   double* RQR_ws = W_ws + a.B * mm;
   double* a_ws = RQR_ws + a.B * mm;
+  double* M_ws = a_ws + a.B * m;
+  double* K_ws = M_ws + a.B * (size_t)m * p;
+  double* KF_ws = K_ws + a.B * (size_t)m * p;
+  double* af_ws = KF_ws + a.B * (size_t)m * p;
 
   size_t lds_upd = sizeof(double) * ((size_t)4 * p * m + 2 * m + 3 * p * p + 4 * p + 8);
   if (lds_upd > KF_LDS_BYTES_MAX) {
@@ -449,9 +683,33 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
   hipLaunchKernelGGL(big_init_kernel, dim3(init_blocks, (unsigned)a.B), dim3(256), 0, stream, a, a_ws,
                      P_ws, RQR_ws);
   const int tg = (m + GT - 1) / GT, ts = (m + 31) / 32;
+  const bool fused_update = a.filter == KF_FILTER_UNIVARIATE;
+  const size_t lds_gain = sizeof(double) * ((size_t)3 * p * m + 2 * m + 3 * p * p + 4 * p + 8);
+  const size_t lds_pf = sizeof(double) * ((size_t)2 * p * m);
+  if (!fused_update) {
+    if (lds_gain > KF_LDS_BYTES_MAX || lds_pf > KF_LDS_BYTES_MAX) {
+      KF_SET_ERR(h, "forward(big): p=%d m=%d needs %zu B of LDS in the gain kernel", p, m, lds_gain);
+      return KF_ERR_UNSUPPORTED;
+    }
+    KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(big_gain_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gain));
+    KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(big_pf_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pf));
+  }
   for (int t = 0; t < a.T; ++t) {
-    hipLaunchKernelGGL(big_update_kernel, dim3((unsigned)a.B), dim3(256), lds_upd, stream, a, t, a_ws,
-                       P_ws, Pf_ws);
+    if (fused_update) {
+      hipLaunchKernelGGL(big_update_kernel, dim3((unsigned)a.B), dim3(256), lds_upd, stream, a, t, a_ws,
+                         P_ws, Pf_ws);
+    } else {
+      hipLaunchKernelGGL(big_mvec_kernel, dim3((m + MV_ROWS - 1) / MV_ROWS, (unsigned)a.B), dim3(256), 0,
+                         stream, a, t, P_ws, M_ws);
+      hipLaunchKernelGGL(big_gain_kernel, dim3((unsigned)a.B), dim3(256), lds_gain, stream, a, t, a_ws,
+                         M_ws, K_ws, KF_ws, af_ws);
+      hipLaunchKernelGGL(big_apred_kernel, dim3((m + MV_ROWS - 1) / MV_ROWS, (unsigned)a.B), dim3(256), 0,
+                         stream, a, t, af_ws, a_ws);
+      hipLaunchKernelGGL(big_pf_kernel, dim3((m + PF_ROWS - 1) / PF_ROWS, (unsigned)a.B), dim3(256), lds_pf,
+                         stream, a, t, P_ws, M_ws, K_ws, KF_ws, Pf_ws);
+    }
     hipLaunchKernelGGL((big_gemm_kernel<false, false>), dim3(tg, tg, (unsigned)a.B), dim3(256), 0, stream,
                        a.Tm, (long)mm, Pf_ws, (long)mm, nullptr, 0L, W_ws, (long)mm, m);
     hipLaunchKernelGGL((big_gemm_kernel<true, true>), dim3(tg, tg, (unsigned)a.B), dim3(256), 0, stream,

@@ -132,7 +132,7 @@ int kf_launch_forward_lane_m4(kf_handle* h, const KfFwdArgs& a, hipStream_t stre
 int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
                       hipStream_t stream);
 // large-m path (kf_forward_big.hip): covariance in a caller-provided HBM workspace, MFMA GEMMs
-size_t kf_forward_big_workspace_bytes(long B, int m);
+size_t kf_forward_big_workspace_bytes(long B, int m, int p);
 int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
                           hipStream_t stream);
 inline bool kf_forward_lds_fits(int m, int p) {
