@@ -14,7 +14,7 @@
 //
 // The two m x m x m products are >99% of the flops (m = 367: 2 x 98.9 MFLOP per draw-step) and
 // are real contractions, so they run on the matrix cores: 64x64 output tile per 256-thread
-// workgroup, four waves of 2x2 MFMA 16x16 tiles, K staged through LDS in chunks of 32 with the
+// workgroup (4 waves, 2x2 MFMA 16x16 tiles each), K staged through LDS in chunks of 32 with the
 // next chunk prefetched into registers.
 #include "kf_internal.h"
 
@@ -22,54 +22,59 @@ namespace {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int GT = 64;   // output tile edge (128 x 128 tiles measured slower: 1 wave/SIMD, 14.9 vs 17.0 TF)
-constexpr int GK = 32;   // K chunk
-constexpr int GLD = GT + 1;  // LDS row stride (doubles) -- odd: conflict-free column access
-constexpr int GPT = GT * GK / 256;  // staged elements per thread and operand
+constexpr int GTM = 64, GTN = 64;    // output tile; measured at m=367: 64x64 38 TF per GEMM, 128x64 and 128x128 slower
+constexpr int GK = 32;               // K chunk
+constexpr int GNT = 256;             // threads: 4 waves as 2 x 2, 32 x 32 per wave
+constexpr int GWR = 2, GWC = 2;
+constexpr int GTI = GTM / GWR / 16;  // MFMA tiles per wave, rows (2)
+constexpr int GTJ = GTN / GWC / 16;  // MFMA tiles per wave, cols (4)
+constexpr int GLDA = GTM + 1, GLDB = GTN + 1;  // odd LDS row strides
+constexpr int GPA = GTM * GK / GNT, GPB = GTN * GK / GNT;  // staged elements per thread
 
 // C[b] (m x m) = A[b] (m x m) * op(B[b])  (+ E[b]);  op = identity or transpose.
-// grid: (tiles_n, tiles_m, draws)  block: 256.  Software pipeline: the next K chunk is fetched
+// grid: (tiles_n, tiles_m, draws)  block: 512.  Software pipeline: the next K chunk is fetched
 // from HBM/L2 into registers while the MFMAs of the current chunk run out of LDS.
 template <bool TRANS_B, bool ADD_E>
-__global__ __launch_bounds__(256) void big_gemm_kernel(const double* __restrict__ A, long strideA,
+__global__ __launch_bounds__(GNT) void big_gemm_kernel(const double* __restrict__ A, long strideA,
                                                        const double* __restrict__ Bm, long strideB,
                                                        const double* __restrict__ E, long strideE,
                                                        double* __restrict__ Cm, long strideC, int m) {
-  __shared__ double As[GK][GLD];  // As[k][r]  (A tile, k-major)
-  __shared__ double Bs[GK][GLD];  // Bs[k][c]
+  __shared__ double As[GK][GLDA];  // As[k][r]  (A tile, k-major)
+  __shared__ double Bs[GK][GLDB];  // Bs[k][c]
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int wr = wave >> 1, wc = wave & 1;  // 2 x 2 waves, GT/2 x GT/2 each
+  const int wr = wave / GWC, wc = wave % GWC;
   const long b = blockIdx.z;
-  const int r0 = blockIdx.y * GT, c0 = blockIdx.x * GT;
+  const int r0 = blockIdx.y * GTM, c0 = blockIdx.x * GTN;
   const double* Ab = A + b * strideA;
   const double* Bb = Bm + b * strideB;
 
-  constexpr int WT = GT / 32;  // MFMA tiles per wave and dimension
-  double4_t acc[WT][WT];
+  double4_t acc[GTI][GTJ];
 #pragma unroll
-  for (int i = 0; i < WT; ++i)
+  for (int i = 0; i < GTI; ++i)
 #pragma unroll
-    for (int j = 0; j < WT; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < GTJ; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
   const int li = lane & 15, lk = lane >> 4;
-  double ra[GPT], rb[GPT];
+  double ra[GPA], rb[GPB];
 
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int q = 0; q < GPT; ++q) {
-      const int e = tid + 256 * q;
-      {  // A tile: rows r0.., cols k0.. (GK contiguous doubles per row)
-        const int rr = e / GK, kk = e - rr * GK;
-        const int gr = r0 + rr, gk = k0 + kk;
-        ra[q] = (gr < m && gk < m) ? Ab[(long)gr * m + gk] : 0.0;
-      }
+    for (int q = 0; q < GPA; ++q) {  // A tile: rows r0.., cols k0.. (GK contiguous doubles per row)
+      const int e = tid + GNT * q;
+      const int rr = e / GK, kk = e - rr * GK;
+      const int gr = r0 + rr, gk = k0 + kk;
+      ra[q] = (gr < m && gk < m) ? Ab[(long)gr * m + gk] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < GPB; ++q) {
+      const int e = tid + GNT * q;
       if (TRANS_B) {  // op(B)[k][c] = B[c][k]
         const int cc = e / GK, kk = e - cc * GK;
         const int gc = c0 + cc, gk = k0 + kk;
         rb[q] = (gc < m && gk < m) ? Bb[(long)gc * m + gk] : 0.0;
       } else {
-        const int kk = e / GT, cc = e - kk * GT;
+        const int kk = e / GTN, cc = e - kk * GTN;
         const int gc = c0 + cc, gk = k0 + kk;
         rb[q] = (gc < m && gk < m) ? Bb[(long)gk * m + gc] : 0.0;
       }
@@ -77,17 +82,19 @@ __global__ __launch_bounds__(256) void big_gemm_kernel(const double* __restrict_
   };
   auto stage = [&]() {
 #pragma unroll
-    for (int q = 0; q < GPT; ++q) {
-      const int e = tid + 256 * q;
-      {
-        const int rr = e / GK, kk = e - rr * GK;
-        As[kk][rr] = ra[q];
-      }
+    for (int q = 0; q < GPA; ++q) {
+      const int e = tid + GNT * q;
+      const int rr = e / GK, kk = e - rr * GK;
+      As[kk][rr] = ra[q];
+    }
+#pragma unroll
+    for (int q = 0; q < GPB; ++q) {
+      const int e = tid + GNT * q;
       if (TRANS_B) {
         const int cc = e / GK, kk = e - cc * GK;
         Bs[kk][cc] = rb[q];
       } else {
-        const int kk = e / GT, cc = e - kk * GT;
+        const int kk = e / GTN, cc = e - kk * GTN;
         Bs[kk][cc] = rb[q];
       }
     }
@@ -100,15 +107,15 @@ __global__ __launch_bounds__(256) void big_gemm_kernel(const double* __restrict_
     if (k0 + GK < m) fetch(k0 + GK);  // in flight during the MFMAs below
 #pragma unroll
     for (int ks = 0; ks < GK; ks += 4) {
-      double af[WT], bf[WT];
+      double af[GTI], bf[GTJ];
 #pragma unroll
-      for (int i = 0; i < WT; ++i) af[i] = As[ks + lk][wr * (GT / 2) + i * 16 + li];  // A[i=l&15][k=l>>4]
+      for (int i = 0; i < GTI; ++i) af[i] = As[ks + lk][wr * (GTM / GWR) + i * 16 + li];  // A[i=l&15][k=l>>4]
 #pragma unroll
-      for (int j = 0; j < WT; ++j) bf[j] = Bs[ks + lk][wc * (GT / 2) + j * 16 + li];  // B[k=l>>4][j=l&15]
+      for (int j = 0; j < GTJ; ++j) bf[j] = Bs[ks + lk][wc * (GTN / GWC) + j * 16 + li];  // B[k=l>>4][j=l&15]
 #pragma unroll
-      for (int i = 0; i < WT; ++i)
+      for (int i = 0; i < GTI; ++i)
 #pragma unroll
-        for (int j = 0; j < WT; ++j)
+        for (int j = 0; j < GTJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
@@ -117,13 +124,13 @@ __global__ __launch_bounds__(256) void big_gemm_kernel(const double* __restrict_
   double* Cb = Cm + b * strideC;
   const double* Eb = ADD_E ? E + b * strideE : nullptr;
 #pragma unroll
-  for (int i = 0; i < WT; ++i)
+  for (int i = 0; i < GTI; ++i)
 #pragma unroll
-    for (int j = 0; j < WT; ++j)
+    for (int j = 0; j < GTJ; ++j)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        int gr = r0 + wr * (GT / 2) + i * 16 + lk + 4 * rg;
-        int gc = c0 + wc * (GT / 2) + j * 16 + li;
+        int gr = r0 + wr * (GTM / GWR) + i * 16 + lk + 4 * rg;
+        int gc = c0 + wc * (GTN / GWC) + j * 16 + li;
         if (gr < m && gc < m) {
           double v = acc[i][j][rg];
           if (ADD_E) v += Eb[(long)gr * m + gc];
@@ -682,7 +689,7 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
   const int init_blocks = (int)((mm + 255) / 256 < 64 ? (mm + 255) / 256 : 64);
   hipLaunchKernelGGL(big_init_kernel, dim3(init_blocks, (unsigned)a.B), dim3(256), 0, stream, a, a_ws,
                      P_ws, RQR_ws);
-  const int tg = (m + GT - 1) / GT, ts = (m + 31) / 32;
+  const int tgm = (m + GTM - 1) / GTM, tgn = (m + GTN - 1) / GTN, ts = (m + 31) / 32;
   const bool fused_update = a.filter == KF_FILTER_UNIVARIATE;
   const size_t lds_gain = sizeof(double) * ((size_t)3 * p * m + 2 * m + 3 * p * p + 4 * p + 8);
   const size_t lds_pf = sizeof(double) * ((size_t)2 * p * m);
@@ -710,9 +717,9 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
       hipLaunchKernelGGL(big_pf_kernel, dim3((m + PF_ROWS - 1) / PF_ROWS, (unsigned)a.B), dim3(256), lds_pf,
                          stream, a, t, P_ws, M_ws, K_ws, KF_ws, Pf_ws);
     }
-    hipLaunchKernelGGL((big_gemm_kernel<false, false>), dim3(tg, tg, (unsigned)a.B), dim3(256), 0, stream,
+    hipLaunchKernelGGL((big_gemm_kernel<false, false>), dim3(tgn, tgm, (unsigned)a.B), dim3(GNT), 0, stream,
                        a.Tm, (long)mm, Pf_ws, (long)mm, nullptr, 0L, W_ws, (long)mm, m);
-    hipLaunchKernelGGL((big_gemm_kernel<true, true>), dim3(tg, tg, (unsigned)a.B), dim3(256), 0, stream,
+    hipLaunchKernelGGL((big_gemm_kernel<true, true>), dim3(tgn, tgm, (unsigned)a.B), dim3(GNT), 0, stream,
                        W_ws, (long)mm, a.Tm, (long)mm, RQR_ws, (long)mm, Pf_ws, (long)mm, m);
     hipLaunchKernelGGL(big_sym_kernel, dim3(ts, ts, (unsigned)a.B), dim3(256), 0, stream, Pf_ws, P_ws,
                        a.pred_P ? a.pred_P + (size_t)(t + 1) * mm : nullptr, (long)(a.T + 1) * (long)mm, m);
