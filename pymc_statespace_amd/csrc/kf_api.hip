@@ -194,6 +194,32 @@ int kf_launch_backward_lds(kf_handle* h, const KfBwdArgs& a, hipStream_t stream)
   return kf_launch_backward_lds_p0(h, a, stream);
 }
 
+int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, hipStream_t stream) {
+  // p == 1, even m <= 10: register-resident row-split adjoint (KF_FORWARD_KERNEL=lds forces the
+  // generic LDS-resident adjoint, e.g. for A/B tests)
+  if (a.p == 1 && a.m <= KF_ROW_M_MAX && a.m % 2 == 0 && h->forward_kernel != KF_KERNEL_LDS) {
+    int H = 0;
+    if (h->lanes_per_draw > 0 && h->lanes_per_draw % a.m == 0) H = h->lanes_per_draw / a.m;
+    if (H == 0) H = 1;  // measured at m = 10, B = 4096: H = 1 6.1 ms, H = 3 7.0 ms (LDS kernel 14.8 ms)
+#define KF_TRY_BSPLIT(M_, H_) \
+  if (a.m == M_ && H == H_) return kf_launch_backward_rowsplit_m##M_##_h##H_(h, a, stream);
+    KF_TRY_BSPLIT(10, 1)
+    KF_TRY_BSPLIT(10, 2)
+    KF_TRY_BSPLIT(10, 3)
+    KF_TRY_BSPLIT(10, 5)
+    KF_TRY_BSPLIT(8, 1)
+    KF_TRY_BSPLIT(8, 2)
+    KF_TRY_BSPLIT(8, 4)
+    KF_TRY_BSPLIT(6, 1)
+    KF_TRY_BSPLIT(6, 3)
+    KF_TRY_BSPLIT(4, 1)
+    KF_TRY_BSPLIT(4, 2)
+    KF_TRY_BSPLIT(2, 1)
+#undef KF_TRY_BSPLIT
+  }
+  return kf_launch_backward_lds(h, a, stream);
+}
+
 static int check_dims(kf_handle* h, const kf_dims* d, bool need_p) {
   if (!h) return KF_ERR_ARG;
   if (!d) {
@@ -282,7 +308,7 @@ extern "C" int kf_filter_backward(kf_handle* h, const kf_dims* dims, const doubl
   a.pred_a = pred_a; a.pred_P = pred_P; a.g_logp = g_logp; a.g_ll_obs = g_ll_obs;
   a.g_a0 = g_a0; a.g_P0 = g_P0; a.g_T = g_T; a.g_Z = g_Z; a.g_R = g_R; a.g_H = g_H; a.g_Q = g_Q;
   a.g_c = g_c; a.g_d = g_d;
-  return kf_launch_backward_lds(h, a, (hipStream_t)stream);
+  return kf_launch_backward(h, a, (hipStream_t)stream);
 }
 
 extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, const double* R,

@@ -144,7 +144,21 @@ int kf_launch_backward_lds_p1(kf_handle* h, const KfBwdArgs& a, hipStream_t stre
 int kf_launch_backward_lds_p2(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_backward_lds_p4(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_backward_lds_p8(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+// register-resident backward kernels (kf_backward_rowsplit.hip), p == 1, even m <= 10
+int kf_launch_backward_rowsplit_m10_h1(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward_rowsplit_m10_h2(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward_rowsplit_m10_h3(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward_rowsplit_m10_h5(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward_rowsplit_m8_h1(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward_rowsplit_m8_h2(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward_rowsplit_m8_h4(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward_rowsplit_m6_h1(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward_rowsplit_m6_h3(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward_rowsplit_m4_h1(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward_rowsplit_m4_h2(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward_rowsplit_m2_h1(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_backward_lds(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_smoother_lds(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream);
 int kf_pick_lanes(const kf_handle* h, int m, long B);
 int kf_launch_lyapunov(kf_handle* h, long B, int m, int r, const double* T, const double* R,

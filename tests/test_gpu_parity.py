@@ -709,3 +709,59 @@ def test_time_varying_gradient_is_declared_unsupported(eng):
                                     *([C.c_void_p(res.logp.data_ptr())] * 4), *([None] * 9), None, 0, None)
     assert rc == _lib.KF_ERR_UNSUPPORTED
     assert KalmanError is not None
+
+
+BWD_SPLITS = [(10, 1), (10, 2), (10, 3), (10, 5), (8, 1), (8, 2), (8, 4), (6, 1), (6, 3), (4, 1), (4, 2), (2, 1)]
+
+
+@pytest.mark.parametrize("mh", BWD_SPLITS, ids=[f"m{m}h{h}" for m, h in BWD_SPLITS])
+@pytest.mark.parametrize("ft", ["standard", "single", "univariate"])
+def test_register_resident_gradient_kernels_match_autograd(eng, mh, ft):
+    """kf_bwd_rowsplit_kernel (p == 1, even m <= 10), every compiled (m, lanes-per-row)."""
+    from oracle import kalman_torch as kt
+
+    m, H = mh
+    B, n = 13, 25  # 13: exercises the tail clones of every draws-per-wave
+    w = W.random_dense(B, n, 1, m, max(1, m // 2), seed=300 + m)
+    y = w["y"].copy()
+    y[2] = np.nan
+    y[-1] = np.nan
+    rng = np.random.default_rng(m * 10 + H)
+    g_logp = rng.standard_normal(B)
+    g_ll = rng.standard_normal((B, n))
+    c = 0.1 * rng.standard_normal((B, m))
+    d = 0.1 * rng.standard_normal((B, 1))
+    _, _, gt = kt.logp_and_grads(*_args(w, y), c=c, d=d, g_logp=g_logp, g_ll_obs=g_ll, filter_type=ft)
+    eng.set_lanes_per_draw(m * H)
+    try:
+        res = eng.forward(*_args(w, y), c=c, d=d, filter_type=ft)
+        g = eng.backward(*_args(w, y), c=c, d=d, predicted_states=res.predicted_states,
+                         predicted_covs=res.predicted_covs, g_logp=g_logp, g_ll_obs=g_ll,
+                         filter_type=ft, want_cd=True)
+    finally:
+        eng.set_lanes_per_draw(0)
+    for k in kt.NAMES:
+        a, b = g[k].cpu().numpy(), gt[k]
+        if ft == "univariate" and k in ("P0", "Q", "H"):
+            a, b = a + np.swapaxes(a, -1, -2), b + np.swapaxes(b, -1, -2)
+        assert np.max(np.abs(a - b)) / (1.0 + np.max(np.abs(b))) < 1e-10, k
+
+
+def test_gradient_kernel_families_agree_at_headline_size(eng):
+    import torch
+
+    w = W.WORKLOADS["headline"]()
+    dev = [eng.to_device(x) for x in _args(w)]
+    res = eng.forward(*dev, store_filtered=False, store_ll_obs=False)
+    ones = torch.ones(w["B"], device=dev[1].device, dtype=torch.float64)
+    out = {}
+    try:
+        for kern in ("lds", "auto"):
+            eng.set_forward_kernel(kern)
+            out[kern] = eng.backward(*dev, predicted_states=res.predicted_states,
+                                     predicted_covs=res.predicted_covs, g_logp=ones)
+    finally:
+        eng.set_forward_kernel("auto")
+    for k in ("a0", "P0", "T", "Z", "R", "H", "Q"):
+        scale = 1.0 + out["lds"][k].abs().max().item()
+        assert (out["lds"][k] - out["auto"][k]).abs().max().item() / scale < 1e-10, k
