@@ -123,14 +123,18 @@ __device__ void pinv_jacobi(double* D, double* V, double* Pi, double* ev, double
   wsync();
 }
 
-template <int G>
+// MT > 0: compile-time k_states -- the triangular solves then run on a register-resident
+// right-hand side (the run-time-m path round-trips every element through LDS: 2 m^2 dependent
+// LDS accesses per lane and step, which dominated the kernel at m = 10).
+template <int G, int MT>
 __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lds_kernel(const KfSmoothArgs A) {
   extern __shared__ double smem[];
   constexpr int DPB = KF_WAVE / G;
   const int lane = threadIdx.x;
   const int lig = lane % G;
   const int grp = lane / G;
-  const int m = A.m, r = A.r, n = A.T;
+  const int m = MT > 0 ? MT : A.m;
+  const int r = A.r, n = A.T;
   const int mm = m * m;
 
   long b = (long)blockIdx.x * DPB + grp;
@@ -231,16 +235,41 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lds_kernel(const KfSmoothAr
     }
     if (!__any(!ok)) {
       // X = P_hat^-1 W : one right-hand side (column of W) per lane, in place
-      for (int c = lig; c < m; c += G) {
-        for (int i = 0; i < m; ++i) {
-          double s = W[i * m + c];
-          for (int k = 0; k < i; ++k) s -= L[i * m + k] * W[k * m + c];
-          W[i * m + c] = s / Ld[i];
+      if (MT > 0) {
+        constexpr int MS = MT > 0 ? MT : 1;
+        for (int c = lig; c < MS; c += G) {
+          double x[MS];
+#pragma unroll
+          for (int i = 0; i < MS; ++i) x[i] = W[i * MS + c];
+#pragma unroll
+          for (int i = 0; i < MS; ++i) {
+            double s = x[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) s -= L[i * MS + k] * x[k];
+            x[i] = s / Ld[i];
+          }
+#pragma unroll
+          for (int i = MS - 1; i >= 0; --i) {
+            double s = x[i];
+#pragma unroll
+            for (int k = i + 1; k < MS; ++k) s -= L[k * MS + i] * x[k];
+            x[i] = s / Ld[i];
+          }
+#pragma unroll
+          for (int i = 0; i < MS; ++i) W[i * MS + c] = x[i];
         }
-        for (int i = m - 1; i >= 0; --i) {
-          double s = W[i * m + c];
-          for (int k = i + 1; k < m; ++k) s -= L[k * m + i] * W[k * m + c];
-          W[i * m + c] = s / Ld[i];
+      } else {
+        for (int c = lig; c < m; c += G) {
+          for (int i = 0; i < m; ++i) {
+            double s = W[i * m + c];
+            for (int k = 0; k < i; ++k) s -= L[i * m + k] * W[k * m + c];
+            W[i * m + c] = s / Ld[i];
+          }
+          for (int i = m - 1; i >= 0; --i) {
+            double s = W[i * m + c];
+            for (int k = i + 1; k < m; ++k) s -= L[k * m + i] * W[k * m + c];
+            W[i * m + c] = s / Ld[i];
+          }
         }
       }
     } else {
@@ -298,10 +327,24 @@ int launch_g(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream) {
                KF_LDS_BYTES_MAX);
     return KF_ERR_UNSUPPORTED;
   }
-  KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kf_smooth_lds_kernel<G>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   long blocks = (a.B + dpb - 1) / dpb;
-  hipLaunchKernelGGL(kf_smooth_lds_kernel<G>, dim3((unsigned)blocks), dim3(KF_WAVE), lds, stream, a);
+#define KF_SM_LAUNCH(MT_)                                                                            \
+  do {                                                                                               \
+    KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kf_smooth_lds_kernel<G, MT_>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+    hipLaunchKernelGGL((kf_smooth_lds_kernel<G, MT_>), dim3((unsigned)blocks), dim3(KF_WAVE), lds,   \
+                       stream, a);                                                                   \
+  } while (0)
+  switch (a.m) {
+    case 2: KF_SM_LAUNCH(2); break;
+    case 4: KF_SM_LAUNCH(4); break;
+    case 6: KF_SM_LAUNCH(6); break;
+    case 8: KF_SM_LAUNCH(8); break;
+    case 10: KF_SM_LAUNCH(10); break;
+    case 15: KF_SM_LAUNCH(15); break;
+    default: KF_SM_LAUNCH(0); break;
+  }
+#undef KF_SM_LAUNCH
   KF_HIP_CHECK(h, hipGetLastError());
   return KF_OK;
 }
