@@ -80,7 +80,12 @@ enum {
   KF_FLAG_TV_Q = 1u << 8,
   KF_FLAG_TV_C = 1u << 9,
   KF_FLAG_TV_D = 1u << 10,
-  KF_FLAG_TV_ANY = 0x7f0u
+  KF_FLAG_TV_ANY = 0x7f0u,
+  /* The caller asserts that every draw's H is diagonal (e.g. VARMAX measurement error,
+   * models/VARMAX.py:80-83).  Standard/CholeskyFilter with p > 1 and m <= 16 may then process the
+   * p observations of a step one at a time in the register-resident row kernel -- algebraically
+   * the same filter (results agree to rounding).  Off-diagonal entries are ignored when set. */
+  KF_FLAG_H_DIAGONAL = 1u << 11
 };
 
 /* error codes */
@@ -116,9 +121,10 @@ const char* kf_last_error(const kf_handle* h);
 int kf_set_lanes_per_draw(kf_handle* h, int lanes);
 
 /* Forward-kernel selection.  AUTO: p == 1 and m <= 4 -> one lane per draw ("lane"); p == 1
- * and m <= 10 -> register-resident row-owner kernels ("row"); tiles that fit LDS -> generic
- * LDS-resident kernel; else the workspace + MFMA path.  Results agree to rounding. */
-enum { KF_KERNEL_AUTO = 0, KF_KERNEL_LDS = 1, KF_KERNEL_ROW = 2, KF_KERNEL_LANE = 3 };
+ * and m <= 10 -> register-resident row-owner kernels ("row"); m <= 16 with p > 1 (UnivariateFilter,
+ * or KF_FLAG_H_DIAGONAL) or p == 1 -> the multivariate row kernel ("row"); tiles that fit LDS ->
+ * generic LDS-resident kernel; else the workspace + MFMA path.  Results agree to rounding. */
+enum { KF_KERNEL_AUTO = 0, KF_KERNEL_LDS = 1, KF_KERNEL_ROW = 2, KF_KERNEL_LANE = 3, KF_KERNEL_MFMA = 4 };
 int kf_set_forward_kernel(kf_handle* h, int kernel);
 /* Name of the kernel kf_filter_forward would launch for `dims` (for profiles / bench logs). */
 const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* dims);

@@ -42,7 +42,8 @@ Three reference quirks change results for p > 1 and are explicit switches
 ``partial_missing``    "reference": only the all-missing step is made safe
                        (``F + I*flag``); a partially missing step leaves a zero
                        row in F (singular).  "delete": proper row deletion
-                       (masked rows/cols of H zeroed, unit diagonal inserted).
+                       (masked rows/cols of H zeroed, unit diagonal inserted, the
+                       deleted entries of v zeroed -- d is not masked by :195-213).
 """
 from __future__ import annotations
 
@@ -187,6 +188,8 @@ def update_standard(a, P, y, d, Z, H, all_nan, nan_mask, mvn_const, partial_miss
     flag = all_nan.astype(np.float64)[:, None, None]
 
     v = y - np.einsum("bij,bj->bi", Z, a) - d
+    if partial_missing == "delete":
+        v = np.where(nan_mask, 0.0, v)  # a deleted row carries no innovation (d is not masked upstream)
     PZT = P @ _T(Z)
     F = Z @ PZT + H
     F_solve = F + eye_p * flag
@@ -224,6 +227,8 @@ def update_cholesky(a, P, y, d, Z, H, all_nan, nan_mask, mvn_const, partial_miss
     flag = all_nan.astype(np.float64)[:, None, None]
 
     v = y - np.einsum("bij,bj->bi", Z, a) - d
+    if partial_missing == "delete":
+        v = np.where(nan_mask, 0.0, v)  # a deleted row carries no innovation (d is not masked upstream)
     PZT = P @ _T(Z)
     F = Z @ PZT + H + eye_p * flag
     if partial_missing == "delete":

@@ -16,6 +16,7 @@ KF_ABI_VERSION = 1
 KF_FILTER = {"standard": 0, "cholesky": 1, "univariate": 2, "single": 3}
 KF_FLAG_MVN_CONST_EXACT = 1 << 0
 KF_FLAG_Y_PER_DRAW = 1 << 1
+KF_FLAG_H_DIAGONAL = 1 << 11
 KF_FLAG_TV = {"T": 1 << 4, "Z": 1 << 5, "R": 1 << 6, "H": 1 << 7, "Q": 1 << 8, "c": 1 << 9, "d": 1 << 10}
 
 KF_OK, KF_ERR_ARG, KF_ERR_HIP, KF_ERR_WORKSPACE, KF_ERR_UNSUPPORTED = 0, -1, -2, -3, -4

@@ -56,7 +56,7 @@ extern "C" int kf_set_lanes_per_draw(kf_handle* h, int lanes) {
 extern "C" int kf_set_forward_kernel(kf_handle* h, int kernel) {
   if (!h) return KF_ERR_ARG;
   if (kernel != KF_KERNEL_AUTO && kernel != KF_KERNEL_LDS && kernel != KF_KERNEL_ROW &&
-      kernel != KF_KERNEL_LANE) {
+      kernel != KF_KERNEL_LANE && kernel != KF_KERNEL_MFMA) {
     KF_SET_ERR(h, "unknown forward kernel %d", kernel);
     return KF_ERR_ARG;
   }
@@ -91,16 +91,71 @@ static int kf_split_for(const kf_handle* h, int m, long B) {
   return (m % 2 == 0 && have) ? H : 1;
 }
 
+// multivariate row kernel: eligible shapes and the (padded M, lanes per row H) instantiation
+static bool kf_mp_ok(const kf_handle* h, int m, int p, int T, int filter, unsigned flags) {
+  if (16.0 * ((double)T + 1.0) * m * m >= 2147483648.0) return false;  // 31-bit tape offsets per block
+  if (flags & KF_FLAG_TV_ANY) return false;
+  if (h->forward_kernel != KF_KERNEL_AUTO && h->forward_kernel != KF_KERNEL_ROW &&
+      h->forward_kernel != KF_KERNEL_MFMA)
+    return false;
+  if (m > KF_MP_M_MAX || p > KF_MP_P_MAX || p < 1) return false;
+  return p == 1 || filter == KF_FILTER_UNIVARIATE || (flags & KF_FLAG_H_DIAGONAL);
+}
+
+static void kf_mp_pick(const kf_handle* h, int m, long B, int* Mo, int* Ho) {
+  int M = m + (m & 1);
+  if (M < 4) M = 4;
+  // compiled lanes-per-row choices per M: {narrow, wide}
+  int h_narrow, h_wide;
+  switch (M) {
+    case 16: case 14: h_narrow = 2; h_wide = 4; break;
+    case 12: case 10: h_narrow = 2; h_wide = 3; break;
+    case 8: h_narrow = 2; h_wide = 4; break;
+    case 6: h_narrow = 1; h_wide = 3; break;
+    default: h_narrow = 1; h_wide = 2; break;
+  }
+  int H = 0;
+  if (h->lanes_per_draw > 0 && h->lanes_per_draw % M == 0) {
+    const int want = h->lanes_per_draw / M;
+    if (want == h_narrow || want == h_wide) H = want;
+  }
+  if (H == 0) {
+    // narrow rows while they still give every SIMD two wavefronts
+    const long n_simd = (h ? h->n_cu : 256) * 4L;
+    const long dpw = KF_WAVE / (M * h_narrow);
+    const long waves = (B + dpw - 1) / dpw;
+    H = (waves >= 2 * n_simd) ? h_narrow : h_wide;
+  }
+  *Mo = M;
+  *Ho = H;
+}
+
+static int kf_launch_forward_mp(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
+  int M, H;
+  kf_mp_pick(h, a.m, a.B, &M, &H);
+#define KF_TRY_MP(M_, H_) \
+  if (M == M_ && H == H_) return kf_launch_forward_rowsplit_mp_m##M_##_h##H_(h, a, stream);
+  KF_TRY_MP(16, 2) KF_TRY_MP(16, 4) KF_TRY_MP(14, 2) KF_TRY_MP(14, 4) KF_TRY_MP(12, 2) KF_TRY_MP(12, 3)
+  KF_TRY_MP(10, 2) KF_TRY_MP(10, 3) KF_TRY_MP(8, 2) KF_TRY_MP(8, 4) KF_TRY_MP(6, 1) KF_TRY_MP(6, 3)
+  KF_TRY_MP(4, 1) KF_TRY_MP(4, 2)
+#undef KF_TRY_MP
+  KF_SET_ERR(h, "forward(rowsplit_mp): no instantiation for M=%d H=%d", M, H);
+  return KF_ERR_UNSUPPORTED;
+}
+
 extern "C" const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* d) {
   if (!h || !d) return "";
   const bool row_ok = d->p == 1 && d->m <= KF_ROW_M_MAX;
   if (d->flags & KF_FLAG_TV_ANY) return "kf_fwd_lds_kernel";
   if (!kf_forward_lds_fits(d->m, d->p)) return "big_gemm_kernel";
+  if (h->forward_kernel == KF_KERNEL_MFMA)
+    return kf_mp_ok(h, d->m, d->p, d->T, d->filter, d->flags) ? "kf_fwd_mfma_kernel" : "";
   if (d->p == 1 && d->m <= KF_LANE_M_MAX &&
       (h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_LANE))
     return "kf_fwd_lane_kernel";
   if (row_ok && h->forward_kernel != KF_KERNEL_LDS && h->forward_kernel != KF_KERNEL_LANE)
     return kf_split_for(h, d->m, d->B) > 1 ? "kf_fwd_rowsplit_kernel" : "kf_fwd_row_kernel";
+  if (kf_mp_ok(h, d->m, d->p, d->T, d->filter, d->flags)) return "kf_fwd_rowsplit_mp_kernel";
   return "kf_fwd_lds_kernel";
 }
 
@@ -120,6 +175,15 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t 
   if (!kf_forward_lds_fits(a.m, a.p)) return kf_launch_forward_big(h, a, workspace, workspace_bytes, stream);
   const bool row_ok = a.p == 1 && a.m <= KF_ROW_M_MAX;
   const bool lane_ok = a.p == 1 && a.m <= KF_LANE_M_MAX;
+  const bool mp_ok = kf_mp_ok(h, a.m, a.p, a.T, a.filter, a.flags);
+  if (h->forward_kernel == KF_KERNEL_MFMA) {
+    if (!mp_ok) {
+      KF_SET_ERR(h, "forward(mfma): needs m <= %d, p <= %d, static matrices and p == 1 / the Univariate "
+                 "filter / KF_FLAG_H_DIAGONAL (got p=%d m=%d)", KF_MP_M_MAX, KF_MP_P_MAX, a.p, a.m);
+      return KF_ERR_UNSUPPORTED;
+    }
+    return kf_launch_forward_mfma(h, a, stream);
+  }
   if (h->forward_kernel == KF_KERNEL_LANE && !lane_ok) {
     KF_SET_ERR(h, "forward(lane): needs p == 1 and m <= %d (got p=%d m=%d)", KF_LANE_M_MAX, a.p, a.m);
     return KF_ERR_UNSUPPORTED;
@@ -132,8 +196,9 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t 
       default: return kf_launch_forward_lane_m4(h, a, stream);
     }
   }
-  if (h->forward_kernel == KF_KERNEL_ROW && !row_ok) {
-    KF_SET_ERR(h, "forward(row): needs p == 1 and m <= %d (got p=%d m=%d)", KF_ROW_M_MAX, a.p, a.m);
+  if (h->forward_kernel == KF_KERNEL_ROW && !row_ok && !mp_ok) {
+    KF_SET_ERR(h, "forward(row): needs m <= %d with p == 1, or m <= %d, p <= %d with the Univariate "
+               "filter / KF_FLAG_H_DIAGONAL (got p=%d m=%d)", KF_ROW_M_MAX, KF_MP_M_MAX, KF_MP_P_MAX, a.p, a.m);
     return KF_ERR_UNSUPPORTED;
   }
   if (row_ok && h->forward_kernel != KF_KERNEL_LDS && h->forward_kernel != KF_KERNEL_LANE) {
@@ -162,6 +227,7 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t 
       default: return kf_launch_forward_row_m10(h, a, stream);
     }
   }
+  if (mp_ok) return kf_launch_forward_mp(h, a, stream);
   return kf_launch_forward_lds(h, a, stream);
 }
 

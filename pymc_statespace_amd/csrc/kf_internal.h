@@ -123,6 +123,16 @@ int kf_launch_forward_rowsplit_m8_h2(kf_handle* h, const KfFwdArgs& a, hipStream
 int kf_launch_forward_rowsplit_m8_h4(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 int kf_launch_forward_rowsplit_m6_h3(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 int kf_launch_forward_rowsplit_m4_h2(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+// multivariate row-split kernels (kf_forward_rowsplit_mp.hip): runtime p <= 8, m <= padded even M
+#define KF_MP_M_MAX 16
+#define KF_MP_P_MAX 8
+#define KF_DECL_MP(M, H) \
+  int kf_launch_forward_rowsplit_mp_m##M##_h##H(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+KF_DECL_MP(16, 2) KF_DECL_MP(16, 4) KF_DECL_MP(14, 2) KF_DECL_MP(14, 4) KF_DECL_MP(12, 2) KF_DECL_MP(12, 3)
+KF_DECL_MP(10, 2) KF_DECL_MP(10, 3) KF_DECL_MP(8, 2) KF_DECL_MP(8, 4) KF_DECL_MP(6, 1) KF_DECL_MP(6, 3)
+KF_DECL_MP(4, 1) KF_DECL_MP(4, 2)
+// accumulator-layout kernel (kf_forward_mfma.hip): one wavefront per draw, m <= 16, p <= 8
+int kf_launch_forward_mfma(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 // lane-per-draw kernels for tiny m (kf_forward_lane.hip)
 #define KF_LANE_M_MAX 4
 int kf_launch_forward_lane_m1(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);

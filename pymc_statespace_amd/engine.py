@@ -74,13 +74,17 @@ class KalmanEngine:
         self._check(self.lib.kf_set_lanes_per_draw(self._h, int(lanes)), "kf_set_lanes_per_draw")
 
     def set_forward_kernel(self, kernel: str):
-        """'auto' | 'lds' (generic LDS-resident) | 'row' (register-resident, p == 1, m <= 10)
-        | 'lane' (one lane per draw, p == 1, m <= 4)."""
-        code = {"auto": 0, "lds": 1, "row": 2, "lane": 3}[kernel]
+        """'auto' | 'lds' (generic LDS-resident) | 'row' (register-resident: p == 1, m <= 10; or
+        m <= 16, p <= 8 with the Univariate filter / diagonal H) | 'lane' (one lane per draw,
+        p == 1, m <= 4) | 'mfma' (covariance in MFMA accumulator layout, one wavefront per draw:
+        m <= 16, p <= 8, same eligibility as the multivariate row kernel)."""
+        code = {"auto": 0, "lds": 1, "row": 2, "lane": 3, "mfma": 4}[kernel]
         self._check(self.lib.kf_set_forward_kernel(self._h, code), "kf_set_forward_kernel")
 
-    def forward_kernel_name(self, B, n, p, m, r) -> str:
-        dims = self._dims(B, n, p, m, r)
+    def forward_kernel_name(self, B, n, p, m, r, filter_type="standard", h_diagonal=False) -> str:
+        dims = self._dims(B, n, p, m, r, filter_type)
+        if h_diagonal:
+            dims.flags |= _lib.KF_FLAG_H_DIAGONAL
         return self.lib.kf_forward_kernel_name(self._h, C.byref(dims)).decode()
 
     def _workspace(self, dims):
@@ -127,10 +131,15 @@ class KalmanEngine:
     # ---------------------------------------------------------------- forward
     def forward(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, filter_type="standard",
                 mvn_const="reference", store_ll_obs=True, store_filtered=True,
-                store_predicted=True, time_varying=(), out: Optional[FilterResult] = None) -> FilterResult:
+                store_predicted=True, time_varying=(), h_diagonal: Optional[bool] = None,
+                out: Optional[FilterResult] = None) -> FilterResult:
         """kf_filter_forward.  y (n,p) shared or (B,n,p); a0 (B,m); P0,T (B,m,m); Z (B,p,m);
         R (B,m,r); H (B,p,p); Q (B,r,r); c (B,m); d (B,p).  Names listed in ``time_varying``
-        (subset of T,Z,R,H,Q,c,d) carry an extra time axis after the draw axis: (B,n,...)."""
+        (subset of T,Z,R,H,Q,c,d) carry an extra time axis after the draw axis: (B,n,...).
+
+        ``h_diagonal``: True asserts every draw's H is diagonal (KF_FLAG_H_DIAGONAL: lets the
+        Standard/Cholesky filters with p > 1, m <= 16 use the register-resident row kernel);
+        None checks H on the device (one small reduction + host sync) when it matters."""
         tv = set(time_varying)
         if not tv <= set(_lib.KF_FLAG_TV):
             raise ValueError(f"time_varying must be a subset of {sorted(_lib.KF_FLAG_TV)}")
@@ -178,6 +187,13 @@ class KalmanEngine:
         dims = self._dims(B, n, p, m, r, filter_type, mvn_const, y_per_draw)
         for name in tv:
             dims.flags |= _lib.KF_FLAG_TV[name]
+        if h_diagonal is None:
+            h_diagonal = False
+            if p > 1 and m <= 16 and p <= 8 and not tv and filter_type in ("standard", "cholesky"):
+                off = H - torch.diag_embed(torch.diagonal(H, dim1=-2, dim2=-1))
+                h_diagonal = not bool(torch.any(off != 0))
+        if h_diagonal:
+            dims.flags |= _lib.KF_FLAG_H_DIAGONAL
         dev, f64 = self.device, torch.float64
         if out is None:
             out = FilterResult(

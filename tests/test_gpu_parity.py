@@ -765,3 +765,179 @@ def test_gradient_kernel_families_agree_at_headline_size(eng):
     for k in ("a0", "P0", "T", "Z", "R", "H", "Q"):
         scale = 1.0 + out["lds"][k].abs().max().item()
         assert (out["lds"][k] - out["auto"][k]).abs().max().item() / scale < 1e-10, k
+
+
+# ----------------------------------------------------------------------------------------------
+# multivariate row kernel (kf_forward_rowsplit_mp.hip): p > 1 one observation at a time
+# (BASELINE config C4: VARMAX, p = 5, m = 15 / 10)
+# ----------------------------------------------------------------------------------------------
+MP_SHAPES = [(5, 15, 5), (5, 10, 5), (2, 16, 3), (3, 13, 4), (8, 12, 6), (4, 7, 3), (2, 6, 2),
+             (3, 3, 2), (2, 2, 1), (1, 12, 4), (1, 15, 3)]
+MP_H = {16: (2, 4), 14: (2, 4), 12: (2, 3), 10: (2, 3), 8: (2, 4), 6: (1, 3), 4: (1, 2)}
+
+
+@pytest.mark.parametrize("pmr", MP_SHAPES, ids=[f"p{p}m{m}r{r}" for p, m, r in MP_SHAPES])
+@pytest.mark.parametrize("ft", ["standard", "cholesky", "univariate", "single"])
+@pytest.mark.parametrize("mvn", ["reference", "exact"])
+def test_multivariate_row_kernels_match_oracle(eng, pmr, ft, mvn):
+    p, m, r = pmr
+    if ft == "single" and p != 1:
+        pytest.skip("single is p == 1 only")
+    if p == 1 and m <= 10:
+        pytest.skip("p == 1, m <= 10 runs the dedicated row kernels")
+    B = 23
+    w = W.random_dense(B, 75, p, m, r, seed=300 + 17 * p + m)
+    assert h_is_diagonal(w["H"])
+    y = w["y"].copy()
+    y[[3, 17, 74]] = np.nan              # whole rows
+    if p > 1:
+        y[5, 0] = np.nan                  # single cells: row deletion
+        y[64, 1:] = np.nan
+    rng = np.random.default_rng(m)
+    c = 0.1 * rng.standard_normal((B, m))
+    d = 0.1 * rng.standard_normal((B, p))
+    # partial rows: the reference counts log(2 pi) for the full p there, "exact" counts n_observed
+    ref = kn.kalman_filter(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const=mvn,
+                           cholesky_triangle="correct", partial_missing="delete")
+    M = max(4, m + (m & 1))
+    eng.set_forward_kernel("row")
+    try:
+        outs = []
+        for H in MP_H[M]:
+            eng.set_lanes_per_draw(M * H)
+            assert eng.forward_kernel_name(B, 75, p, m, r, ft, True) == "kf_fwd_rowsplit_mp_kernel"
+            out = _np(eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const=mvn))
+            assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8, (M, H)
+            for k in TAPES:
+                assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=f"M={M} H={H} {k}")
+            assert not out["info"].any()
+            assert np.all(out["ll_obs"][:, [3, 17, 74]] == 0.0)
+            outs.append(out)
+        for k in TAPES + ["logp"]:  # lanes-per-row only changes the order of the row sums
+            assert_allclose(outs[0][k], outs[1][k], rtol=1e-11, atol=1e-11, err_msg=k)
+    finally:
+        eng.set_forward_kernel("auto")
+        eng.set_lanes_per_draw(0)
+
+
+def test_multivariate_row_kernel_needs_diagonal_h(eng):
+    """Joint filters with a dense H stay on the LDS kernel (auto) / are refused (forced row)."""
+    w = W.random_dense(5, 20, 3, 8, 3, seed=5, h_diag=False)
+    assert eng.forward_kernel_name(5, 20, 3, 8, 3, "standard", False) == "kf_fwd_lds_kernel"
+    assert eng.forward_kernel_name(5, 20, 3, 8, 3, "univariate", False) == "kf_fwd_rowsplit_mp_kernel"
+    out = _np(eng.forward(*_args(w)))  # auto-detects the dense H
+    ref = kn.kalman_filter(*_args(w))
+    assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8
+    eng.set_forward_kernel("row")
+    try:
+        with pytest.raises(RuntimeError, match="KF_FLAG_H_DIAGONAL"):
+            eng.forward(*_args(w), h_diagonal=False)
+    finally:
+        eng.set_forward_kernel("auto")
+
+
+def test_multivariate_row_kernel_per_draw_data_and_partial_outputs(eng):
+    w = W.varmax(B=37, n=130, k=3, order=(1, 1))
+    rng = np.random.default_rng(3)
+    yb = w["y"][None] + 0.1 * rng.standard_normal((37,) + w["y"].shape)
+    name = eng.forward_kernel_name(37, 130, w["p"], w["m"], w["r"], "standard", True)
+    assert name == "kf_fwd_rowsplit_mp_kernel"
+    res = eng.forward(*_args(w, yb), store_filtered=False, store_ll_obs=False)
+    assert res.filtered_covs is None and res.ll_obs is None
+    ref = kn.kalman_filter(*_args(w, yb))
+    assert np.max(np.abs(res.logp.cpu().numpy() - ref["logp"])) < 1e-8
+    assert_allclose(res.predicted_covs.cpu().numpy(), ref["predicted_covs"], rtol=1e-9, atol=1e-9)
+    assert_allclose(res.predicted_states.cpu().numpy(), ref["predicted_states"], rtol=1e-9, atol=1e-9)
+
+
+def test_multivariate_row_kernel_not_positive_definite_reports_info(eng):
+    w = W.random_dense(4, 12, 3, 6, 2, seed=9)
+    H = w["H"].copy()
+    H[2, 1, 1] = -50.0
+    res = eng.forward(w["y"], w["a0"], w["P0"], w["T"], w["Z"], w["R"], H, w["Q"])
+    info = res.info.cpu().numpy()
+    assert info[2] == ((0 + 1) << 8) | 2 and not info[[0, 1, 3]].any()
+    lp = res.logp.cpu().numpy()
+    assert np.isnan(lp[2]) and np.isfinite(lp[[0, 1, 3]]).all()
+
+
+def test_kernel_families_agree_at_c4_size(eng):
+    import torch
+
+    w = W.varmax(B=512, n=1000)
+    dev = [eng.to_device(x) for x in _args(w)]
+    res = {}
+    try:
+        for kern in ("lds", "row"):
+            eng.set_forward_kernel(kern)
+            r = eng.forward(*dev, mvn_const="exact", store_filtered=False, h_diagonal=True)
+            torch.cuda.synchronize()
+            res[kern] = (r.logp.clone(), r.predicted_covs[::64, -1].clone(), r.ll_obs[::64].clone())
+    finally:
+        eng.set_forward_kernel("auto")
+    assert (res["row"][0] - res["lds"][0]).abs().max().item() < 1e-8
+    assert torch.allclose(res["row"][1], res["lds"][1], rtol=1e-9, atol=1e-11)
+    assert torch.allclose(res["row"][2], res["lds"][2], rtol=1e-9, atol=1e-10)
+
+
+# ----------------------------------------------------------------------------------------------
+# accumulator-layout kernel (kf_forward_mfma.hip): P in v_mfma_f64_16x16x4 layout, one wave per draw
+# ----------------------------------------------------------------------------------------------
+MFMA_SHAPES = [(1, m, max(1, m // 2)) for m in (1, 2, 3, 5, 8, 10, 11, 13, 16)] + \
+              [(5, 15, 5), (5, 10, 5), (2, 16, 3), (3, 13, 4), (8, 12, 6), (4, 7, 3), (3, 3, 2)]
+
+
+@pytest.mark.parametrize("pmr", MFMA_SHAPES, ids=[f"p{p}m{m}r{r}" for p, m, r in MFMA_SHAPES])
+@pytest.mark.parametrize("ft", ["standard", "cholesky", "univariate", "single"])
+@pytest.mark.parametrize("mvn", ["reference", "exact"])
+def test_mfma_kernel_matches_oracle(eng, pmr, ft, mvn):
+    p, m, r = pmr
+    if ft == "single" and p != 1:
+        pytest.skip("single is p == 1 only")
+    B = 19
+    w = W.random_dense(B, 139, p, m, r, seed=500 + 17 * p + m)
+    y = w["y"].copy()
+    y[[3, 17, 64, 138]] = np.nan
+    if p > 1:
+        y[5, 0] = np.nan
+        y[70, 1:] = np.nan
+    rng = np.random.default_rng(m)
+    c = 0.1 * rng.standard_normal((B, m))
+    d = 0.1 * rng.standard_normal((B, p))
+    ref = kn.kalman_filter(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const=mvn,
+                           cholesky_triangle="correct", partial_missing="delete")
+    eng.set_forward_kernel("mfma")
+    try:
+        out = _np(eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const=mvn))
+    finally:
+        eng.set_forward_kernel("auto")
+    assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8
+    for k in TAPES:
+        assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=k)
+    assert not out["info"].any()
+    assert np.all(out["ll_obs"][:, [3, 17, 64, 138]] == 0.0)
+    # the covariance tapes are bitwise symmetric by construction
+    assert np.array_equal(out["predicted_covs"][:, 1:], np.swapaxes(out["predicted_covs"][:, 1:], -1, -2))
+    assert np.array_equal(out["filtered_covs"], np.swapaxes(out["filtered_covs"], -1, -2))
+
+
+def test_mfma_kernel_per_draw_data_not_pd_and_partial_outputs(eng):
+    w = W.varmax(B=21, n=130, k=3, order=(1, 1))
+    rng = np.random.default_rng(3)
+    yb = w["y"][None] + 0.1 * rng.standard_normal((21,) + w["y"].shape)
+    H = w["H"].copy()
+    H[7, 1, 1] = -50.0
+    eng.set_forward_kernel("mfma")
+    try:
+        res = eng.forward(yb, w["a0"], w["P0"], w["T"], w["Z"], w["R"], H, w["Q"],
+                          store_filtered=False, store_ll_obs=False, h_diagonal=True)
+    finally:
+        eng.set_forward_kernel("auto")
+    assert res.filtered_covs is None and res.ll_obs is None
+    info = res.info.cpu().numpy()
+    good = np.arange(21) != 7
+    assert info[7] == ((0 + 1) << 8) | 2 and not info[good].any()
+    ref = kn.kalman_filter(yb, w["a0"], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"])
+    lp = res.logp.cpu().numpy()
+    assert np.isnan(lp[7]) and np.max(np.abs(lp[good] - ref["logp"][good])) < 1e-8
+    assert_allclose(res.predicted_covs.cpu().numpy()[good], ref["predicted_covs"][good], rtol=1e-9, atol=1e-9)
