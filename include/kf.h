@@ -120,10 +120,13 @@ const char* kf_last_error(const kf_handle* h);
  * row of P) for the compiled H; other values fall back to the automatic choice. */
 int kf_set_lanes_per_draw(kf_handle* h, int lanes);
 
-/* Forward-kernel selection.  AUTO: p == 1 and m <= 4 -> one lane per draw ("lane"); p == 1
- * and m <= 10 -> register-resident row-owner kernels ("row"); m <= 16 with p > 1 (UnivariateFilter,
- * or KF_FLAG_H_DIAGONAL) or p == 1 -> the multivariate row kernel ("row"); tiles that fit LDS ->
- * generic LDS-resident kernel; else the workspace + MFMA path.  Results agree to rounding. */
+/* Forward-kernel selection.  AUTO (static matrices): p == 1 and m <= 4 -> one lane per draw
+ * ("lane"); p == 1, m <= 6 (m <= 9 for large batches) -> register-resident row-owner kernels
+ * ("row"); m <= 16, p <= 8 with p == 1 / UnivariateFilter / KF_FLAG_H_DIAGONAL -> covariance in
+ * MFMA accumulator layout, one wavefront per draw ("mfma": m >= 10, or m >= 11 for p > 1) or the
+ * multivariate row kernel ("row"); other tiles that fit LDS -> generic LDS-resident kernel
+ * ("lds", also all time-varying models); else the workspace + MFMA GEMM path.  Results agree to
+ * rounding. */
 enum { KF_KERNEL_AUTO = 0, KF_KERNEL_LDS = 1, KF_KERNEL_ROW = 2, KF_KERNEL_LANE = 3, KF_KERNEL_MFMA = 4 };
 int kf_set_forward_kernel(kf_handle* h, int kernel);
 /* Name of the kernel kf_filter_forward would launch for `dims` (for profiles / bench logs). */

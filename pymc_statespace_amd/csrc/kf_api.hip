@@ -130,6 +130,19 @@ static void kf_mp_pick(const kf_handle* h, int m, long B, int* Mo, int* Ho) {
   *Ho = H;
 }
 
+// AUTO: accumulator-layout (MFMA) kernel instead of the row-owner kernels?  Measured on MI355X
+// (scripts/gpu_kernel_sweep.py): one wavefront per draw costs the same whatever m <= 16 is, the
+// row kernels pack 64/m draws per wavefront but pay LDS operand traffic ~ m^3.
+//   p == 1: m <= 6 row kernels; m = 7..9 MFMA while the batch is small; m >= 10 MFMA
+//   p  > 1: m >= 11 MFMA, below that the multivariate row kernel
+static bool kf_auto_mfma(const kf_handle* h, int m, int p, long B) {
+  if (p > 1) return m >= 11;
+  if (m >= 10) return true;
+  if (m <= 6) return false;
+  const long n_simd = (h ? h->n_cu : 256) * 4L;
+  return (B * m + KF_WAVE - 1) / KF_WAVE < 2 * n_simd;
+}
+
 static int kf_launch_forward_mp(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
   int M, H;
   kf_mp_pick(h, a.m, a.B, &M, &H);
@@ -153,9 +166,12 @@ extern "C" const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims*
   if (d->p == 1 && d->m <= KF_LANE_M_MAX &&
       (h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_LANE))
     return "kf_fwd_lane_kernel";
+  const bool mp_ok = kf_mp_ok(h, d->m, d->p, d->T, d->filter, d->flags);
+  if (h->forward_kernel == KF_KERNEL_AUTO && mp_ok && kf_auto_mfma(h, d->m, d->p, d->B))
+    return "kf_fwd_mfma_kernel";
   if (row_ok && h->forward_kernel != KF_KERNEL_LDS && h->forward_kernel != KF_KERNEL_LANE)
     return kf_split_for(h, d->m, d->B) > 1 ? "kf_fwd_rowsplit_kernel" : "kf_fwd_row_kernel";
-  if (kf_mp_ok(h, d->m, d->p, d->T, d->filter, d->flags)) return "kf_fwd_rowsplit_mp_kernel";
+  if (mp_ok) return "kf_fwd_rowsplit_mp_kernel";
   return "kf_fwd_lds_kernel";
 }
 
@@ -196,6 +212,8 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t 
       default: return kf_launch_forward_lane_m4(h, a, stream);
     }
   }
+  if (h->forward_kernel == KF_KERNEL_AUTO && mp_ok && kf_auto_mfma(h, a.m, a.p, a.B))
+    return kf_launch_forward_mfma(h, a, stream);
   if (h->forward_kernel == KF_KERNEL_ROW && !row_ok && !mp_ok) {
     KF_SET_ERR(h, "forward(row): needs m <= %d with p == 1, or m <= %d, p <= %d with the Univariate "
                "filter / KF_FLAG_H_DIAGONAL (got p=%d m=%d)", KF_ROW_M_MAX, KF_MP_M_MAX, KF_MP_P_MAX, a.p, a.m);

@@ -535,7 +535,7 @@ def test_kernel_families_agree_at_headline_size(eng):
     dev = [eng.to_device(x) for x in _args(w)]
     res = {}
     try:
-        for kern, lanes in (("lds", 0), ("row", 10), ("row", 30)):
+        for kern, lanes in (("lds", 0), ("row", 10), ("row", 30), ("mfma", 0), ("auto", 0)):
             eng.set_forward_kernel(kern)
             eng.set_lanes_per_draw(lanes)
             r = eng.forward(*dev, mvn_const="exact", store_filtered=False, store_predicted=True)
@@ -941,3 +941,22 @@ def test_mfma_kernel_per_draw_data_not_pd_and_partial_outputs(eng):
     lp = res.logp.cpu().numpy()
     assert np.isnan(lp[7]) and np.max(np.abs(lp[good] - ref["logp"][good])) < 1e-8
     assert_allclose(res.predicted_covs.cpu().numpy()[good], ref["predicted_covs"][good], rtol=1e-9, atol=1e-9)
+
+
+def test_auto_kernel_selection(eng):
+    """The documented AUTO rules (include/kf.h) -- names only, no launch."""
+    name = eng.forward_kernel_name
+    assert name(4096, 1000, 1, 2, 1) == "kf_fwd_lane_kernel"
+    assert name(4096, 1000, 1, 6, 3) == "kf_fwd_rowsplit_kernel"
+    assert name(65536, 1000, 1, 6, 3) == "kf_fwd_row_kernel"
+    assert name(4096, 1000, 1, 8, 3) == "kf_fwd_mfma_kernel"
+    assert name(65536, 1000, 1, 8, 3) == "kf_fwd_row_kernel"
+    assert name(4096, 1000, 1, 10, 5) == "kf_fwd_mfma_kernel"       # north star
+    assert name(65536, 1000, 1, 10, 5) == "kf_fwd_mfma_kernel"      # C3
+    assert name(4096, 1000, 1, 16, 5) == "kf_fwd_mfma_kernel"
+    assert name(4096, 1000, 1, 17, 5) == "kf_fwd_lds_kernel"
+    assert name(16384, 1000, 5, 15, 5, "standard", True) == "kf_fwd_mfma_kernel"   # C4
+    assert name(16384, 1000, 5, 10, 5, "standard", True) == "kf_fwd_rowsplit_mp_kernel"
+    assert name(16384, 1000, 5, 15, 5, "standard", False) == "kf_fwd_lds_kernel"   # dense H
+    assert name(16384, 1000, 5, 15, 5, "univariate", False) == "kf_fwd_mfma_kernel"
+    assert name(128, 1000, 1, 367, 3) == "big_gemm_kernel"          # C5
