@@ -190,8 +190,12 @@ class KalmanEngine:
         if h_diagonal is None:
             h_diagonal = False
             if p > 1 and m <= 16 and p <= 8 and not tv and filter_type in ("standard", "cholesky"):
-                off = H - torch.diag_embed(torch.diagonal(H, dim1=-2, dim2=-1))
-                h_diagonal = not bool(torch.any(off != 0))
+                # the check costs a few small launches and a host sync: remember the answer per tensor
+                key = (H.data_ptr(), H._version, tuple(H.shape))
+                if getattr(self, "_hdiag_key", None) != key:
+                    off = H - torch.diag_embed(torch.diagonal(H, dim1=-2, dim2=-1))
+                    self._hdiag_key, self._hdiag_val = key, not bool(torch.any(off != 0))
+                h_diagonal = self._hdiag_val
         if h_diagonal:
             dims.flags |= _lib.KF_FLAG_H_DIAGONAL
         dev, f64 = self.device, torch.float64

@@ -32,7 +32,8 @@ def timeit(fn, reps=3):
 rows = []
 CASES = [("c1", {}, "standard"), ("c2", {}, "standard"), ("headline", {}, "standard"),
          ("c3", {}, "cholesky"), ("c4_m10", {"B": 2048}, "standard"), ("c4", {"B": 2048}, "standard"),
-         ("c4", {"B": 2048}, "univariate"), ("c4", {"B": 16384}, "univariate")]
+         ("c4", {"B": 2048}, "univariate"), ("c4_m10", {"B": 16384}, "standard"),
+         ("c4", {"B": 16384}, "standard"), ("c4", {"B": 16384}, "univariate")]
 print("| workload | B | T | p,m,r | filter | kernel | fwd logp-only ms | fwd full-tape ms | evals/s (full) | HBM GB/s (full) | frac of 8 TB/s | bwd ms | smoother ms |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 for name, kw, ft in CASES:
@@ -59,7 +60,7 @@ for name, kw, ft in CASES:
         t_sm = float("nan")
     ab = algorithmic_bytes(B, n, p, m, r, True)
     gbs = ab / t_full / 1e9
-    print(f"| {name} | {B} | {n} | {p},{m},{r} | {ft} | {eng.forward_kernel_name(B, n, p, m, r)} | "
+    print(f"| {name} | {B} | {n} | {p},{m},{r} | {ft} | {eng.forward_kernel_name(B, n, p, m, r, ft, True)} | "
           f"{t_logp * 1e3:.3f} | {t_full * 1e3:.3f} | {B / t_full:.3e} | {gbs:.0f} | {gbs / 8000:.3f} | "
           f"{t_bwd * 1e3:.2f} | {t_sm * 1e3:.2f} |", flush=True)
     del d, res, res_l
