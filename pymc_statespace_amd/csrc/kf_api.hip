@@ -279,6 +279,23 @@ int kf_launch_backward_lds(kf_handle* h, const KfBwdArgs& a, hipStream_t stream)
 }
 
 int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, hipStream_t stream) {
+  // accumulator-layout adjoint (kf_backward_mfma.hip): scalar observations only, i.e. p == 1, the
+  // Univariate filter, or a diagonal H asserted by the caller (then g_H carries the diagonal and
+  // g_P0 the symmetric part)
+  const bool mfma_ok = a.m <= KF_MP_M_MAX && a.p <= KF_MP_P_MAX &&
+                       (a.p == 1 || a.filter == KF_FILTER_UNIVARIATE || (a.flags & KF_FLAG_H_DIAGONAL));
+  if (h->forward_kernel == KF_KERNEL_MFMA) {
+    if (!mfma_ok) {
+      KF_SET_ERR(h, "backward(mfma): needs m <= %d, p <= %d and p == 1 / the Univariate filter / "
+                 "KF_FLAG_H_DIAGONAL (got p=%d m=%d)", KF_MP_M_MAX, KF_MP_P_MAX, a.p, a.m);
+      return KF_ERR_UNSUPPORTED;
+    }
+    return kf_launch_backward_mfma(h, a, stream);
+  }
+  // measured (MI355X): m = 10, B = 4096: 3.2 ms vs 6.1 ms (row-split adjoint); C4 (p = 5, m = 15,
+  // B = 16384): 44 ms vs 396 ms (LDS adjoint); m = 2: 2.0 ms vs 0.9 ms -> small even m stays
+  if (h->forward_kernel == KF_KERNEL_AUTO && mfma_ok && (a.p > 1 || a.m >= 5 || (a.m & 1)))
+    return kf_launch_backward_mfma(h, a, stream);
   // p == 1, even m <= 10: register-resident row-split adjoint (KF_FORWARD_KERNEL=lds forces the
   // generic LDS-resident adjoint, e.g. for A/B tests)
   if (a.p == 1 && a.m <= KF_ROW_M_MAX && a.m % 2 == 0 && h->forward_kernel != KF_KERNEL_LDS) {

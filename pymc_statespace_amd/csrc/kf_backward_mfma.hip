@@ -1,0 +1,399 @@
+// kf_backward_mfma.hip -- reverse-mode gradient of the Kalman log-likelihood with the covariance
+// and its adjoint in MFMA accumulator layout (one wavefront per draw, k_states <= 16, p <= 8
+// observations processed one at a time, static system matrices).  Companion of
+// kf_forward_mfma.hip; consumes the predicted tapes of any forward kernel.
+//
+// Maths = kf_backward_rowsplit.hip's (derivation: oracle/kalman_adjoint_numpy.py): with scalar
+// observations the update is P_f = P - (P z)(z'P)/F and its adjoint is a handful of rank-one
+// terms; only the predict step keeps m x m x m products, and those run as MFMAs whose operands
+// are the register tiles themselves (kf_tile.h: a tile's registers are X as B operand and X' as
+// A operand):
+//     W   = T P_f          A = T' tile (static)   B = P_f
+//     Tb += 2 Gm W         A = Gm (symmetric)     B = W        accumulated in the MFMA C operand
+//     X1  = Gm T           A = Gm                 B = T tile (static)
+//     Sb  = T' X1          A = T tile             B = X1
+// Gm = sym(adjoint of the predicted P_{t+1}).  The adjoint of a SYMMETRIC intermediate may be
+// symmetrised freely (only its symmetric part reaches the gradients of the inputs), so the
+// adjoint tile is kept symmetric:  Sb <- Sb + Fb z z' + (u z' + z u')/2,  u = (ab_f v - 2 Sb M)/F.
+// Per time step (reverse): recompute the p scalar updates from the predicted tape (keeping
+// M_q, F_q, v_q, a^q in LDS), run the predict adjoint, then walk the observations backwards,
+// rebuilding P^q = P^{q+1} + M_q M_q'/F_q.
+//
+// Outputs: as kf_filter_backward documents.  g_P0 is exact (not symmetrised) for p == 1; for
+// p > 1 it is the symmetric part (the joint Standard/Cholesky update and the sequential one are
+// the same function of a symmetric P0, their entrywise partials differ by an antisymmetric
+// matrix), and g_H carries the diagonal only (the caller asserted a diagonal H).
+#include "kf_internal.h"
+#include "kf_tile.h"
+
+namespace {
+
+constexpr int TILE = 16;
+constexpr int PMAXQ = KF_MP_P_MAX;
+
+// dynamic LDS (doubles)
+__host__ __device__ inline int bwd_mfma_lds_doubles(int p) {
+  return 16 /*EX*/ + 2 * PMAXQ /*HD, DL*/ + 2 * PMAXQ /*HB, DB*/ + p * (2 * 16 /*ZC, ZR*/ + 3 * 16 /*MC, MP, AQ*/ + 4 /*SC*/ + 16 /*ZB*/ + 64 /*YB*/) + 64 /*GL*/ + 256 /*final tile*/;
+}
+
+// (capping the allocation at 128 VGPRs for a fourth wavefront per SIMD spills ~30 values and is
+// slower: 5.2 vs 3.9 ms at the north-star shape)
+// P1: p == 1 known at compile time -- Z, M, F, v of the step stay in registers between the
+// forward recompute and the adjoint instead of going through LDS
+template <int KS, bool P1>
+__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(3))) void kf_bwd_mfma_kernel(
+    const KfBwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const int c = lane & 15, g = lane >> 4;
+  const int permc = (c & 3) * 4 + (c >> 2);
+  const long b = blockIdx.x;
+  const int n = A.T, r_ = A.r, m = A.m, p = P1 ? 1 : A.p, mm = m * m;
+
+  double* EX = smem;                 // exchange: permuted write, two b128 reads give the row-indexed view
+  double* HD = EX + 16;
+  double* DL = HD + PMAXQ;
+  double* HB = DL + PMAXQ;           // final g_H diagonal / g_d
+  double* DB = HB + PMAXQ;
+  double* ZC = DB + PMAXQ;           // Z_q, column-indexed (zero padded)
+  double* ZR = ZC + 16 * p;          // Z_q, permuted
+  double* MC = ZR + 16 * p;          // M_q of the current step, column-indexed
+  double* MP = MC + 16 * p;          //   permuted
+  double* AQ = MP + 16 * p;          // a^q (state before observation q)
+  double* SC = AQ + 16 * p;          // F_q, v_q, 1/F_q
+  double* ZB = SC + 4 * p;           // accumulated g_Z
+  double* YB = ZB + 16 * p;          // y block of 64 steps
+  double* GL = YB + 64 * p;          // g_ll_obs block
+  double* FT = GL + 64;              // 16 x 16 tile: transpose of X1 per step, Gs at the end
+
+  const bool c_ok = c < m;
+  double TA[KS], TB[KS];  // T' tile (TA[s] = T[c][4s+g]) and T tile (TB[s] = T[4s+g][c])
+  bool on[KS];
+  int off[KS];
+  {
+    const double* gT = A.Tm + b * (long)mm;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = 4 * s + g;
+      on[s] = c_ok && k < m;
+      off[s] = k * m + c;
+      TA[s] = on[s] ? gT[c * m + k] : 0.0;
+      TB[s] = on[s] ? gT[k * m + c] : 0.0;
+    }
+    const double* gZ = A.Z + b * (long)p * m;
+    for (int e = lane; e < p * TILE; e += KF_WAVE) {
+      const int q = e >> 4, k = e & 15;
+      const double z = (k < m) ? gZ[q * m + k] : 0.0;
+      ZC[e] = z;
+      ZR[q * TILE + (k & 3) * 4 + (k >> 2)] = z;
+      ZB[e] = 0.0;
+    }
+    if (lane < p) {
+      HD[lane] = A.H[b * (long)p * p + lane * p + lane];
+      DL[lane] = A.d ? A.d[b * (long)p + lane] : 0.0;
+    }
+  }
+  const bool univariate = A.filter == KF_FILTER_UNIVARIATE;
+  const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;
+  const bool y_per_draw = (A.flags & KF_FLAG_Y_PER_DRAW) != 0;
+  const double* ybase = A.y + (y_per_draw ? b * (long)n * p : 0L);
+  const double* gpa = A.pred_a + b * (long)(n + 1) * m;
+  const double* gpP = A.pred_P + b * (long)(n + 1) * mm;
+  const double g_all = A.g_logp ? A.g_logp[b] : 0.0;
+  const double* gll = A.g_ll_obs ? A.g_ll_obs + b * (long)n : nullptr;
+
+  double zc1 = 0.0, zr1[4] = {0.0, 0.0, 0.0, 0.0}, H1 = 0.0, d1 = 0.0;
+  if (P1) {
+    const double* gZ = A.Z + b * (long)m;
+    zc1 = c_ok ? gZ[c] : 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) zr1[s] = (4 * s + g < m) ? gZ[4 * s + g] : 0.0;
+    H1 = A.H[b];
+    d1 = A.d ? A.d[b] : 0.0;
+  }
+  // adjoint state and accumulators
+  double PB[KS], TBv[KS], GS[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) PB[s] = TBv[s] = GS[s] = 0.0;
+  double4_t TBm = {0.0, 0.0, 0.0, 0.0};
+  double abp = 0.0, cb = 0.0, hbv = 0.0, dbv = 0.0;
+
+  double PN[KS], an;
+  auto prefetch = [&](int t) {
+    const double* rp = gpP + (long)t * mm;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) PN[s] = on[s] ? rp[off[s]] : 0.0;
+    an = c_ok ? gpa[(long)t * m + c] : 0.0;
+  };
+  auto stage_block = [&](int t) {  // y and g_ll_obs of the 64-step block that holds t
+    const int t0 = t & ~63;
+    const int cnt = (n - t0 < 64 ? n - t0 : 64);
+    for (int e = lane; e < cnt * p; e += KF_WAVE) YB[e] = ybase[(long)t0 * p + e];
+    if (lane < cnt) GL[lane] = gll ? gll[t0 + lane] : 0.0;
+    __syncthreads();
+  };
+  prefetch(n - 1);
+  stage_block(n - 1);
+
+  for (int t = n - 1; t >= 0; --t) {
+    double P[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) P[s] = PN[s];
+    double ac = an;
+    if (t > 0) prefetch(t - 1);
+    if ((t & 63) == 63 && t != n - 1) stage_block(t);
+    const double* yrow = YB + (t & 63) * p;
+    const double gt = g_all + GL[t & 63];
+
+    double k_Mc = 0.0, k_aq = 0.0, k_v = 0.0, k_invF = 0.0, k_Mr[4] = {0.0, 0.0, 0.0, 0.0};  // P1: kept in registers
+    // ---- forward recompute of the p scalar updates (kf_forward_mfma.hip, non-augmented form) -------
+#pragma unroll 1
+    for (int q = 0; q < p; ++q) {
+      const double yq = yrow[q];
+      const bool obs = !(yq != yq);
+      double zc, zr[4];
+      if (P1) {
+        zc = zc1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) zr[s] = zr1[s];
+      } else {
+        zc = ZC[q * TILE + c];
+        const double2_t z01 = *reinterpret_cast<const double2_t*>(ZR + q * TILE + 4 * g);
+        const double2_t z23 = *reinterpret_cast<const double2_t*>(ZR + q * TILE + 4 * g + 2);
+        zr[0] = z01.x; zr[1] = z01.y; zr[2] = z23.x; zr[3] = z23.y;
+      }
+      double pc = P[0] * zr[0];
+#pragma unroll
+      for (int s = 1; s < KS; ++s) pc = fma(P[s], zr[s], pc);
+      const double Mc = col_allsum(pc);
+      const double F = (P1 ? H1 : HD[q]) + row_allsum(zc * Mc);
+      const double zs = row_allsum(zc * ac);
+      const bool degenerate = !obs || (univariate && F == 0.0);
+      const double invF = degenerate ? 0.0 : fast_rcp(F);
+      const double v = degenerate ? 0.0 : (yq + dsign * (P1 ? d1 : DL[q])) - zs;
+      if (g == 0) {
+        if (!P1) MC[q * TILE + c] = Mc;
+        MP[q * TILE + permc] = Mc;
+        if (!P1) AQ[q * TILE + c] = ac;
+      }
+      if (!P1 && lane == 0) {
+        SC[4 * q] = F;
+        SC[4 * q + 1] = v;
+        SC[4 * q + 2] = invF;
+      }
+      __syncthreads();
+      const double2_t m01 = *reinterpret_cast<const double2_t*>(MP + q * TILE + 4 * g);
+      const double2_t m23 = *reinterpret_cast<const double2_t*>(MP + q * TILE + 4 * g + 2);
+      const double Mr[4] = {m01.x, m01.y, m23.x, m23.y};
+      if (P1) {
+        k_Mc = Mc; k_aq = ac; k_v = v; k_invF = invF;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) k_Mr[s] = Mr[s];
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) P[s] = fma(-(Mr[s] * Mc), invF, P[s]);
+      ac = fma(Mc * invF, v, ac);
+    }
+    // P = P_f, ac = a_f
+
+    // ---- adjoint of predict ---------------------------------------------------------------------------
+    if (g == 0) EX[permc] = abp;
+    __syncthreads();
+    double abr[4];
+    {
+      const double2_t a01 = *reinterpret_cast<const double2_t*>(EX + 4 * g);
+      const double2_t a23 = *reinterpret_cast<const double2_t*>(EX + 4 * g + 2);
+      abr[0] = a01.x; abr[1] = a01.y; abr[2] = a23.x; abr[3] = a23.y;
+    }
+    cb += abp;
+    double part = TB[0] * abr[0];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      TBv[s] = fma(abr[s], ac, TBv[s]);  // ab' a_f'
+      GS[s] += PB[s];                    // adjoint of R Q R'
+      if (s > 0) part = fma(TB[s], abr[s], part);
+    }
+    double abf = col_allsum(part);  // T' ab'
+    // X1 = Gm T ; Sb = T' X1 ; Tb += 2 X1 P_f  (A operand = X1' registers, from an LDS transpose:
+    // cheaper than the fourth product W = T P_f, Gm W)
+    double4_t X1 = {0.0, 0.0, 0.0, 0.0}, SBv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(PB[s], TB[s], X1, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) FT[(4 * s + g) * TILE + permc] = X1[s];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) SBv = __builtin_amdgcn_mfma_f64_16x16x4f64(TB[s], X1[s], SBv, 0, 0, 0);
+    __syncthreads();
+    {
+      // X1t registers: X1t[4s+g][c] = X1[c][4s+g]
+      const double2_t t01 = *reinterpret_cast<const double2_t*>(FT + c * TILE + 4 * g);
+      const double2_t t23 = *reinterpret_cast<const double2_t*>(FT + c * TILE + 4 * g + 2);
+      const double X1t[4] = {t01.x, t01.y, t23.x, t23.y};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) TBm = __builtin_amdgcn_mfma_f64_16x16x4f64(X1t[s], P[s], TBm, 0, 0, 0);
+    }
+    double SB[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) SB[s] = SBv[s];
+
+    // ---- adjoint of the scalar updates, last observation first ---------------------------------------
+#pragma unroll 1
+    for (int q = p - 1; q >= 0; --q) {
+      double Mc, aq, zc, Mr[4], zr[4], v, invF;
+      if (P1) {
+        Mc = k_Mc; aq = k_aq; zc = zc1; v = k_v; invF = k_invF;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { Mr[s] = k_Mr[s]; zr[s] = zr1[s]; }
+      } else {
+        Mc = MC[q * TILE + c];
+        aq = AQ[q * TILE + c];
+        zc = ZC[q * TILE + c];
+        const double2_t m01 = *reinterpret_cast<const double2_t*>(MP + q * TILE + 4 * g);
+        const double2_t m23 = *reinterpret_cast<const double2_t*>(MP + q * TILE + 4 * g + 2);
+        const double2_t z01 = *reinterpret_cast<const double2_t*>(ZR + q * TILE + 4 * g);
+        const double2_t z23 = *reinterpret_cast<const double2_t*>(ZR + q * TILE + 4 * g + 2);
+        Mr[0] = m01.x; Mr[1] = m01.y; Mr[2] = m23.x; Mr[3] = m23.y;
+        zr[0] = z01.x; zr[1] = z01.y; zr[2] = z23.x; zr[3] = z23.y;
+        v = SC[4 * q + 1];
+        invF = SC[4 * q + 2];
+      }
+      // P^q = P^{q+1} + M M'/F ;  s = Sb M
+      double sp = 0.0;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        P[s] = fma(Mr[s] * Mc, invF, P[s]);
+        sp = fma(SB[s], Mr[s], sp);
+      }
+      const double sc = col_allsum(sp);
+      const double beta = row_allsum(Mc * abf);
+      const double gamma = row_allsum(Mc * sc);
+      const double Fb = (gamma - beta * v) * invF * invF - 0.5 * gt * (invF - v * v * invF * invF);
+      const double vb = (beta - gt * v) * invF;
+      const double uc = (abf * v - 2.0 * sc) * invF;  // m1b + m2b
+      if (g == 0) EX[permc] = uc;
+      __syncthreads();
+      const double2_t u01 = *reinterpret_cast<const double2_t*>(EX + 4 * g);
+      const double2_t u23 = *reinterpret_cast<const double2_t*>(EX + 4 * g + 2);
+      const double ur[4] = {u01.x, u01.y, u23.x, u23.y};
+      double pp = P[0] * ur[0];
+#pragma unroll
+      for (int s = 1; s < KS; ++s) pp = fma(P[s], ur[s], pp);
+      const double pdot = col_allsum(pp);  // P^q (m1b + m2b)
+      if (g == 0) ZB[q * TILE + c] += fma(-aq, vb, fma(2.0 * Fb, Mc, pdot));
+      if (p == 1 && t == 0 && A.g_P0) {  // (p == 1 at run time also takes this path)
+        // exact (not symmetrised) entrywise gradient: Sb + (Fb z + m1b) z' - z s'/F
+        __syncthreads();
+        if (g == 0) EX[permc] = (abf * v - sc) * invF;  // m1b
+        __syncthreads();
+        const double2_t n01 = *reinterpret_cast<const double2_t*>(EX + 4 * g);
+        const double2_t n23 = *reinterpret_cast<const double2_t*>(EX + 4 * g + 2);
+        const double m1r[4] = {n01.x, n01.y, n23.x, n23.y};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          double gp = SB[s];
+          gp = fma(fma(Fb, zr[s], m1r[s]), zc, gp);
+          gp = fma(-zr[s] * invF, sc, gp);
+          if (on[s]) A.g_P0[b * (long)mm + off[s]] = gp;
+        }
+      }
+      // symmetrised adjoint of P^q ; adjoint of a^q
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        double sb = SB[s];
+        sb = fma(Fb * zr[s], zc, sb);
+        sb = fma(0.5 * ur[s], zc, sb);
+        sb = fma(0.5 * zr[s], uc, sb);
+        SB[s] = sb;
+      }
+      abf = fma(-zc, vb, abf);
+      if (c == q) {
+        hbv += Fb;
+        dbv += dsign * vb;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) PB[s] = SB[s];
+    abp = abf;
+  }
+
+  // ---- gradients out ----------------------------------------------------------------------------------------
+  __syncthreads();
+  if (g == 0 && c < p) {
+    HB[c] = hbv;
+    DB[c] = dbv;
+  }
+#pragma unroll
+  for (int s = 0; s < KS; ++s) FT[(4 * s + g) * TILE + c] = GS[s];
+  __syncthreads();
+  if (g == 0 && c_ok) {
+    if (A.g_a0) A.g_a0[b * (long)m + c] = abp;
+    if (A.g_c) A.g_c[b * (long)m + c] = cb;
+  }
+  if (A.g_Z)
+    for (int e = lane; e < p * m; e += KF_WAVE) {
+      const int q = e / m, k = e - q * m;
+      A.g_Z[b * (long)p * m + e] = ZB[q * TILE + k];
+    }
+  if (A.g_H)
+    for (int e = lane; e < p * p; e += KF_WAVE) {
+      const int q1 = e / p, q2 = e - q1 * p;
+      A.g_H[b * (long)p * p + e] = (q1 == q2) ? HB[q1] : 0.0;
+    }
+  if (A.g_d && lane < p) A.g_d[b * (long)p + lane] = DB[lane];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    if (!on[s]) continue;
+    if (A.g_T) A.g_T[b * (long)mm + off[s]] = fma(2.0, TBm[s], TBv[s]);
+    if (A.g_P0 && p > 1) A.g_P0[b * (long)mm + off[s]] = PB[s];
+  }
+  // R_b = Gs R (Q + Q') ;  Q_b = R' Gs R   (Gs in tile FT)
+  const double* gR = A.R + b * (long)m * r_;
+  const double* gQ = A.Q + b * (long)r_ * r_;
+  if (A.g_R)
+    for (int e = lane; e < m * r_; e += KF_WAVE) {
+      const int i = e / r_, l = e - i * r_;
+      double sacc = 0.0;
+      for (int k = 0; k < r_; ++k) {
+        double grk = 0.0;  // (Gs R)[i][k]
+        for (int j = 0; j < m; ++j) grk = fma(FT[i * TILE + j], gR[j * r_ + k], grk);
+        sacc = fma(grk, gQ[k * r_ + l] + gQ[l * r_ + k], sacc);
+      }
+      A.g_R[b * (long)m * r_ + e] = sacc;
+    }
+  if (A.g_Q)
+    for (int e = lane; e < r_ * r_; e += KF_WAVE) {
+      const int k = e / r_, l = e - k * r_;
+      double sacc = 0.0;
+      for (int i = 0; i < m; ++i) {
+        double grl = 0.0;
+        for (int j = 0; j < m; ++j) grl = fma(FT[i * TILE + j], gR[j * r_ + l], grl);
+        sacc = fma(gR[i * r_ + k], grl, sacc);
+      }
+      A.g_Q[b * (long)r_ * r_ + e] = sacc;
+    }
+}
+
+}  // namespace
+
+int kf_launch_backward_mfma(kf_handle* h, const KfBwdArgs& a, hipStream_t stream) {
+  if (a.m > TILE || a.p > PMAXQ || a.p < 1) {
+    KF_SET_ERR(h, "backward(mfma): m=%d p=%d out of range (m <= %d, p <= %d)", a.m, a.p, TILE, PMAXQ);
+    return KF_ERR_UNSUPPORTED;
+  }
+  const size_t lds = sizeof(double) * (size_t)bwd_mfma_lds_doubles(a.p);
+  const int ks = (a.m + 3) / 4;
+#define KF_BWD_MFMA_LAUNCH(KS_)                                                                        \
+  if (a.p == 1)                                                                                        \
+    hipLaunchKernelGGL((kf_bwd_mfma_kernel<KS_, true>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);  \
+  else                                                                                                 \
+    hipLaunchKernelGGL((kf_bwd_mfma_kernel<KS_, false>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a)
+  switch (ks) {
+    case 1: KF_BWD_MFMA_LAUNCH(1); break;
+    case 2: KF_BWD_MFMA_LAUNCH(2); break;
+    case 3: KF_BWD_MFMA_LAUNCH(3); break;
+    default: KF_BWD_MFMA_LAUNCH(4); break;
+  }
+#undef KF_BWD_MFMA_LAUNCH
+  KF_HIP_CHECK(h, hipGetLastError());
+  return KF_OK;
+}

@@ -167,6 +167,7 @@ int kf_launch_backward_rowsplit_m6_h3(kf_handle* h, const KfBwdArgs& a, hipStrea
 int kf_launch_backward_rowsplit_m4_h1(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_backward_rowsplit_m4_h2(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_backward_rowsplit_m2_h1(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward_mfma(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_backward_lds(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_smoother_lds(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream);

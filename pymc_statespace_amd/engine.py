@@ -221,8 +221,14 @@ class KalmanEngine:
     # --------------------------------------------------------------- backward
     def backward(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, predicted_states,
                  predicted_covs, g_logp=None, g_ll_obs=None, filter_type="standard",
-                 mvn_const="reference", want_cd=False):
-        """kf_filter_backward -> dict of per-draw gradients (a0,P0,T,Z,R,H,Q[,c,d])."""
+                 mvn_const="reference", want_cd=False, h_diagonal=False):
+        """kf_filter_backward -> dict of per-draw gradients (a0,P0,T,Z,R,H,Q[,c,d]).
+
+        ``h_diagonal=True`` (KF_FLAG_H_DIAGONAL) lets Standard/Cholesky with p > 1, m <= 16 use the
+        scalar-observation adjoint kernel: g["H"] then carries the diagonal only and g["P0"] the
+        symmetric part of the entrywise gradient (all a symmetric / diagonal parameterisation sees).
+        Unlike ``forward`` this is never auto-detected: a dense-H model that happens to be diagonal
+        at the current point still needs its off-diagonal partials."""
         T = self.to_device(T)
         B, m = T.shape[0], T.shape[1]
         Z = self.to_device(Z)
@@ -243,6 +249,8 @@ class KalmanEngine:
         g_logp = self.to_device(g_logp, (B,)) if g_logp is not None else None
         g_ll = self.to_device(g_ll_obs, (B, n)) if g_ll_obs is not None else None
         dims = self._dims(B, n, p, m, r, filter_type, mvn_const, y_per_draw)
+        if h_diagonal:
+            dims.flags |= _lib.KF_FLAG_H_DIAGONAL
         dev, f64 = self.device, torch.float64
         g = dict(
             a0=torch.empty(B, m, device=dev, dtype=f64), P0=torch.empty(B, m, m, device=dev, dtype=f64),
