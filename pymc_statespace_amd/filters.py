@@ -59,9 +59,10 @@ class BaseFilter:
     filter_type: str = ""
 
     def __init__(self, mode=None, mvn_const: str = "reference", on_error: str = "raise",
-                 engine: Optional[KalmanEngine] = None):
+                 engine: Optional[KalmanEngine] = None, h_diagonal: bool = False):
         self.mode = mode
         self.mvn_const = mvn_const
+        self.h_diagonal = h_diagonal  # H diagonal by construction: see include/kf.h KF_FLAG_H_DIAGONAL
         self.on_error = on_error
         self._engine = engine
         self.seq_names: List[str] = []
@@ -82,7 +83,8 @@ class BaseFilter:
 
         self.mode = mode
         return kalman_filter_graph(data, a0, P0, T, Z, R, H, Q, c=c, d=d,
-                                   filter_type=self.filter_type, mvn_const=self.mvn_const)
+                                   filter_type=self.filter_type, mvn_const=self.mvn_const,
+                                   h_diagonal=self.h_diagonal)
 
     def update(self, *args, **kwargs):
         # reference BaseFilter.update raises (kalman_filter.py:225-229); the fused kernels
@@ -120,7 +122,8 @@ class BaseFilter:
             lead(Q_, 2), None if c is None else lead(c, 1), None if d is None else lead(d, 1),
             filter_type=self.filter_type, mvn_const=self.mvn_const,
             store_ll_obs=outputs == "all", store_filtered=outputs == "all",
-            store_predicted=outputs == "all", time_varying=seq)
+            store_predicted=outputs == "all", time_varying=seq,
+            h_diagonal=True if self.h_diagonal else None)
         info = res.info.cpu().numpy()
         if self.on_error == "raise" and np.any(info != 0):
             bad = int(np.flatnonzero(info)[0])

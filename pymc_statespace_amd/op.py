@@ -29,7 +29,7 @@ def _col(x):
 
 
 def perform_filter(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standard",
-                   mvn_const="reference", engine=None):
+                   mvn_const="reference", h_diagonal=False, engine=None):
     """One draw, reference layouts in (data (n,p,1), a0 (m,1), c (m,1), d (p,1)) -> the six
     reference outputs [filtered_states (n,m,1), predicted_states (n+1,m,1), filtered_covs,
     predicted_covs, logp (), ll_obs (n,)] as numpy arrays."""
@@ -40,7 +40,8 @@ def perform_filter(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standard",
     res = eng.forward(data, _col(a0)[None], np.asarray(P0)[None], np.asarray(T)[None],
                       np.asarray(Z)[None], np.asarray(R)[None], np.asarray(H)[None],
                       np.asarray(Q)[None], _col(c)[None], _col(d)[None],
-                      filter_type=filter_type, mvn_const=mvn_const)
+                      filter_type=filter_type, mvn_const=mvn_const,
+                      h_diagonal=True if h_diagonal else None)
     info = int(res.info[0].item())
     if info != 0:
         raise np.linalg.LinAlgError(
@@ -58,7 +59,7 @@ def perform_filter(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standard",
 
 def perform_filter_grad(data, a0, P0, T, Z, R, H, Q, c, d, predicted_states, predicted_covs,
                         g_logp, g_ll_obs, filter_type="standard", mvn_const="reference",
-                        engine=None):
+                        h_diagonal=False, engine=None):
     """Gradients of g_logp*logp + <g_ll_obs, ll_obs> w.r.t. (a0,P0,T,Z,R,H,Q,c,d), shaped like
     the inputs (a0 (m,1), c (m,1), d (p,1))."""
     eng = engine or get_engine()
@@ -74,7 +75,8 @@ def perform_filter_grad(data, a0, P0, T, Z, R, H, Q, c, d, predicted_states, pre
                      predicted_states=pa[None], predicted_covs=np.asarray(predicted_covs)[None],
                      g_logp=np.atleast_1d(np.asarray(g_logp, dtype=np.float64)),
                      g_ll_obs=np.asarray(g_ll_obs, dtype=np.float64)[None],
-                     filter_type=filter_type, mvn_const=mvn_const, want_cd=True)
+                     filter_type=filter_type, mvn_const=mvn_const, want_cd=True,
+                     h_diagonal=h_diagonal)
     out = {k: g[k][0].cpu().numpy() for k in GRAD_INPUT_NAMES}
     for k in ("a0", "c", "d"):
         out[k] = out[k][:, None]
@@ -115,10 +117,10 @@ def _build_ops():
     f64 = "float64"
 
     class KalmanFilterGradOp(Op):
-        __props__ = ("filter_type", "mvn_const")
+        __props__ = ("filter_type", "mvn_const", "h_diagonal")
 
-        def __init__(self, filter_type="standard", mvn_const="reference"):
-            self.filter_type, self.mvn_const = filter_type, mvn_const
+        def __init__(self, filter_type="standard", mvn_const="reference", h_diagonal=False):
+            self.filter_type, self.mvn_const, self.h_diagonal = filter_type, mvn_const, bool(h_diagonal)
 
         def make_node(self, *args):
             args = [pt.as_tensor_variable(a) for a in args]
@@ -128,7 +130,7 @@ def _build_ops():
 
         def perform(self, node, inputs, output_storage):
             grads = perform_filter_grad(*inputs, filter_type=self.filter_type,
-                                        mvn_const=self.mvn_const)
+                                        mvn_const=self.mvn_const, h_diagonal=self.h_diagonal)
             for storage, g in zip(output_storage, grads):
                 storage[0] = np.ascontiguousarray(g, dtype=np.float64)
 
@@ -138,10 +140,10 @@ def _build_ops():
     class KalmanFilterOp(Op):
         """[filtered_states, predicted_states, filtered_covs, predicted_covs, logp, ll_obs]
         = Op(data, a0, P0, T, Z, R, H, Q, c, d)   -- reference kalman_filter.py:184-191."""
-        __props__ = ("filter_type", "mvn_const")
+        __props__ = ("filter_type", "mvn_const", "h_diagonal")
 
-        def __init__(self, filter_type="standard", mvn_const="reference"):
-            self.filter_type, self.mvn_const = filter_type, mvn_const
+        def __init__(self, filter_type="standard", mvn_const="reference", h_diagonal=False):
+            self.filter_type, self.mvn_const, self.h_diagonal = filter_type, mvn_const, bool(h_diagonal)
 
         def make_node(self, data, a0, P0, T, Z, R, H, Q, c, d):
             ins = [pt.as_tensor_variable(x) for x in (data, a0, P0, T, Z, R, H, Q, c, d)]
@@ -150,7 +152,8 @@ def _build_ops():
             return Apply(self, ins, outs)
 
         def perform(self, node, inputs, output_storage):
-            outs = perform_filter(*inputs, filter_type=self.filter_type, mvn_const=self.mvn_const)
+            outs = perform_filter(*inputs, filter_type=self.filter_type, mvn_const=self.mvn_const,
+                                  h_diagonal=self.h_diagonal)
             for storage, o in zip(output_storage, outs):
                 storage[0] = np.ascontiguousarray(o, dtype=np.float64)
 
@@ -177,7 +180,7 @@ def _build_ops():
                 g_logp = pt.zeros_like(outputs[4])
             if isinstance(g_ll.type, DisconnectedType):
                 g_ll = pt.zeros_like(outputs[5])
-            grads = KalmanFilterGradOp(self.filter_type, self.mvn_const)(
+            grads = KalmanFilterGradOp(self.filter_type, self.mvn_const, self.h_diagonal)(
                 *inputs, outputs[1], outputs[3], g_logp, g_ll)
             return [DisconnectedType()()] + list(grads)
 
@@ -208,9 +211,12 @@ def _build_ops():
 
 
 def kalman_filter_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type="standard",
-                        mvn_const="reference"):
+                        mvn_const="reference", h_diagonal=False):
     """Symbolic equivalent of BaseFilter.build_graph (reference kalman_filter.py:126-163).
-    Static (2-D) system matrices only; c, d default to zeros (initialize_intercepts :36-51)."""
+    Static (2-D) system matrices only; c, d default to zeros (initialize_intercepts :36-51).
+    ``h_diagonal=True``: the model's H is diagonal by construction (e.g. VARMAX measurement
+    error, reference models/VARMAX.py:80-83) -- the gradient then runs on the scalar-observation
+    adjoint kernel and is returned for diag(H) only (KF_FLAG_H_DIAGONAL, include/kf.h)."""
     ops = _build_ops()
     pt = ops["pt"]
     T, Z, R, H, Q = (pt.as_tensor_variable(x) for x in (T, Z, R, H, Q))
@@ -227,7 +233,8 @@ def kalman_filter_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type
         c = pt.zeros((T.shape[0], 1))
     if d is None:
         d = pt.zeros((Z.shape[0], 1))
-    return list(ops["KalmanFilterOp"](filter_type, mvn_const)(data, a0, P0, T, Z, R, H, Q, c, d))
+    return list(ops["KalmanFilterOp"](filter_type, mvn_const, h_diagonal)(
+        data, a0, P0, T, Z, R, H, Q, c, d))
 
 
 def kalman_smoother_graph(T, R, Q, filtered_states, filtered_covariances):

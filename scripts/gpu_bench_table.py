@@ -51,7 +51,8 @@ for name, kw, ft in CASES:
     gl = torch.ones(B, device="cuda", dtype=torch.float64)
     try:
         t_bwd = timeit(lambda: eng.backward(*d, predicted_states=res.predicted_states,
-                                            predicted_covs=res.predicted_covs, g_logp=gl, filter_type=ft), 2)
+                                            predicted_covs=res.predicted_covs, g_logp=gl, filter_type=ft,
+                                            h_diagonal=True), 2)
     except Exception as e:  # noqa: BLE001
         t_bwd = float("nan")
     try:
