@@ -355,6 +355,10 @@ extern "C" int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_
   *bytes = 0;  // the LDS- and register-resident kernels keep all scratch on chip
   if (dims->m >= 1 && dims->p >= 1 && !kf_forward_lds_fits(dims->m, dims->p))
     *bytes = kf_forward_big_workspace_bytes(dims->B, dims->m, dims->p);
+  if (dims->m >= 1 && !kf_smoother_lds_fits(dims->m)) {
+    const size_t sm = kf_smoother_big_workspace_bytes(dims->B, dims->m);
+    if (sm > *bytes) *bytes = sm;
+  }
   return KF_OK;
 }
 
@@ -416,8 +420,6 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
                            const double* Q, const double* filt_a, const double* filt_P,
                            double* smooth_a, double* smooth_P, void* workspace,
                            size_t workspace_bytes, void* stream) {
-  (void)workspace;
-  (void)workspace_bytes;
   int rc = check_dims(h, dims, false);
   if (rc) return rc;
   if (!T || !R || !Q || !filt_a || !filt_P || !smooth_a || !smooth_P) {
@@ -428,6 +430,8 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
   a.B = dims->B; a.T = dims->T; a.m = dims->m; a.r = dims->r;
   a.Tm = T; a.R = R; a.Q = Q; a.filt_a = filt_a; a.filt_P = filt_P;
   a.smooth_a = smooth_a; a.smooth_P = smooth_P;
+  if (!kf_smoother_lds_fits(a.m))
+    return kf_launch_smoother_big(h, a, workspace, workspace_bytes, (hipStream_t)stream);
   return kf_launch_smoother_lds(h, a, (hipStream_t)stream);
 }
 

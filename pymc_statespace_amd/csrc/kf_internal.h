@@ -171,6 +171,15 @@ int kf_launch_backward_mfma(kf_handle* h, const KfBwdArgs& a, hipStream_t stream
 int kf_launch_backward_lds(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_smoother_lds(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream);
+// per-draw LDS footprint of kf_smooth_lds_kernel with all 64 lanes on one draw (kf_smoother_lds.hip)
+inline bool kf_smoother_lds_fits(int m) {
+  const int M2 = (m + 1) / 2;
+  return sizeof(double) * (size_t)((9 * m * m + 6 * m + 4 * M2 + 2) | 1) <= KF_LDS_BYTES_MAX;
+}
+// large-m smoother (kf_smoother_big.hip): HBM workspace, blocked Cholesky, fp64-MFMA GEMMs
+size_t kf_smoother_big_workspace_bytes(long B, int m);
+int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace, size_t workspace_bytes,
+                           hipStream_t stream);
 int kf_pick_lanes(const kf_handle* h, int m, long B);
 int kf_launch_lyapunov(kf_handle* h, long B, int m, int r, const double* T, const double* R,
                        const double* Q, const double* S, double* P, int32_t* info, hipStream_t stream);

@@ -1,0 +1,369 @@
+// kf_smoother_big.hip -- RTS smoother for LARGE state dimension (per-draw tiles do not fit LDS:
+// m > ~47, e.g. BASELINE config C5, m = 367, "MFMA m x m path + RTS smoother").
+//
+// Same contract as kf_smooth_lds_kernel (reference pymc_statespace/filters/kalman_smoother.py:
+// 56-104): backwards over t = n-2 .. 0 from (a_f[n-1], P_f[n-1]),
+//     a_hat = T a_f[t]                       P_hat = T P_f[t] T' + R Q R'   (no c, not symmetrised)
+//     G     = (pinv(P_hat) T P_f[t])'
+//     a_s[t] = a_f[t] + G (a_s[t+1] - a_hat)  P_s[t] = P_f[t] + G (P_s[t+1] - P_hat) G'
+// P_hat is symmetric positive definite here (P_f >= 0, and the tiles that reach this path carry a
+// full-rank P0), so pinv is a Cholesky solve:  X = P_hat^-1 (T P_f),  G = X'.
+//
+// Everything is batched over draws in a caller-provided HBM workspace (6 B m^2 doubles + the
+// inverses of the diagonal Cholesky blocks) and every m x m x m piece is an fp64-MFMA GEMM
+// (v_mfma_f64_16x16x4_f64, 64 x 64 output tile per 256-thread workgroup, K staged through LDS with
+// register prefetch -- the kernel of kf_forward_big.hip generalised to sub-blocks):
+//     W = T P_f ; P_hat = W T' + RQR' ; D = P_s[t+1] - P_hat
+//     blocked right-looking Cholesky, block 64:  potrf + inverse of the diagonal block in LDS,
+//         panel  L21 = A21 inv(L11)'  (GEMM),  trailing  A22 -= L21 L21'  (GEMM)
+//     forward / backward substitution by blocks:  Y_k = inv(L_kk) W_k, W_i -= L_ik Y_k ; then with
+//         U = L':  X_k = inv(L_kk)' Y_k, W_i -= U_ik X_k          (all GEMMs)
+//     E = D X ; G = X' ; P_s[t] = G E + P_f[t] ; a_s[t] by two matrix-vector products
+// ~10.3 m^3 flops per draw-step, >97% of them inside the GEMM kernel.
+#include "kf_internal.h"
+
+namespace {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int GTM = 64, GTN = 64, GK = 32, GNT = 256;
+constexpr int GWR = 2, GWC = 2;
+constexpr int GTI = GTM / GWR / 16, GTJ = GTN / GWC / 16;
+constexpr int GLDA = GTM + 1, GLDB = GTN + 1;
+constexpr int GPA = GTM * GK / GNT, GPB = GTN * GK / GNT;
+constexpr int NB = 64;  // Cholesky block
+
+enum { EPI_STORE = 0, EPI_ADD = 1, EPI_RSUB = 2 };  // C = acc | E + acc | E - acc
+
+// C[b] (M x N, ldc) = epi( A[b] (M x K, lda) * op(B[b]) ),  op(B) = B (K x N, ldb) or B' (B is N x K)
+// grid (ceil(N/64), ceil(M/64), draws).  C may alias E; C may alias A or B only where each
+// workgroup reads exactly the region it writes (see the call sites).
+template <bool TRANS_B, int EPI>
+__global__ __launch_bounds__(GNT) void sb_gemm_kernel(const double* A, long sA, int lda, const double* Bm, long sB,
+                                                      int ldb, const double* E, long sE, int lde, double* Cm,
+                                                      long sC, int ldc, int M, int N, int K) {
+  __shared__ double As[GK][GLDA];
+  __shared__ double Bs[GK][GLDB];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wr = wave / GWC, wc = wave % GWC;
+  const long b = blockIdx.z;
+  const int r0 = blockIdx.y * GTM, c0 = blockIdx.x * GTN;
+  const double* Ab = A + b * sA;
+  const double* Bb = Bm + b * sB;
+
+  double4_t acc[GTI][GTJ];
+#pragma unroll
+  for (int i = 0; i < GTI; ++i)
+#pragma unroll
+    for (int j = 0; j < GTJ; ++j) acc[i][j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int li = lane & 15, lk = lane >> 4;
+  double ra[GPA], rb[GPB];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < GPA; ++q) {
+      const int e = tid + GNT * q;
+      const int rr = e / GK, kk = e - rr * GK;
+      const int gr = r0 + rr, gk = k0 + kk;
+      ra[q] = (gr < M && gk < K) ? Ab[(long)gr * lda + gk] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < GPB; ++q) {
+      const int e = tid + GNT * q;
+      if (TRANS_B) {
+        const int cc = e / GK, kk = e - cc * GK;
+        const int gc = c0 + cc, gk = k0 + kk;
+        rb[q] = (gc < N && gk < K) ? Bb[(long)gc * ldb + gk] : 0.0;
+      } else {
+        const int kk = e / GTN, cc = e - kk * GTN;
+        const int gc = c0 + cc, gk = k0 + kk;
+        rb[q] = (gc < N && gk < K) ? Bb[(long)gk * ldb + gc] : 0.0;
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int q = 0; q < GPA; ++q) {
+      const int e = tid + GNT * q;
+      const int rr = e / GK, kk = e - rr * GK;
+      As[kk][rr] = ra[q];
+    }
+#pragma unroll
+    for (int q = 0; q < GPB; ++q) {
+      const int e = tid + GNT * q;
+      if (TRANS_B) {
+        const int cc = e / GK, kk = e - cc * GK;
+        Bs[kk][cc] = rb[q];
+      } else {
+        const int kk = e / GTN, cc = e - kk * GTN;
+        Bs[kk][cc] = rb[q];
+      }
+    }
+  };
+
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += GK) {
+    stage();
+    __syncthreads();
+    if (k0 + GK < K) fetch(k0 + GK);
+#pragma unroll
+    for (int ks = 0; ks < GK; ks += 4) {
+      double af[GTI], bf[GTJ];
+#pragma unroll
+      for (int i = 0; i < GTI; ++i) af[i] = As[ks + lk][wr * (GTM / GWR) + i * 16 + li];
+#pragma unroll
+      for (int j = 0; j < GTJ; ++j) bf[j] = Bs[ks + lk][wc * (GTN / GWC) + j * 16 + li];
+#pragma unroll
+      for (int i = 0; i < GTI; ++i)
+#pragma unroll
+        for (int j = 0; j < GTJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  double* Cb = Cm + b * sC;
+  const double* Eb = (EPI != EPI_STORE) ? E + b * sE : nullptr;
+#pragma unroll
+  for (int i = 0; i < GTI; ++i)
+#pragma unroll
+    for (int j = 0; j < GTJ; ++j)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int gr = r0 + wr * (GTM / GWR) + i * 16 + lk + 4 * rg;
+        const int gc = c0 + wc * (GTN / GWC) + j * 16 + li;
+        if (gr < M && gc < N) {
+          double v = acc[i][j][rg];
+          if (EPI == EPI_ADD) v = Eb[(long)gr * lde + gc] + v;
+          if (EPI == EPI_RSUB) v = Eb[(long)gr * lde + gc] - v;
+          Cb[(long)gr * ldc + gc] = v;
+        }
+      }
+}
+
+// RQR' per draw (m x m), once.
+__global__ __launch_bounds__(256) void sb_rqr_kernel(const double* R, const double* Q, double* out, int m, int r) {
+  const long b = blockIdx.y;
+  const double* gR = R + b * (long)m * r;
+  const double* gQ = Q + b * (long)r * r;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)m * m) return;
+  const int i = (int)(e / m), j = (int)(e - (long)i * m);
+  double s = 0.0;
+  for (int l = 0; l < r; ++l) {
+    double rq = 0.0;
+    for (int k = 0; k < r; ++k) rq += gR[i * r + k] * gQ[k * r + l];
+    s += rq * gR[j * r + l];
+  }
+  out[b * (long)m * m + e] = s;
+}
+
+// out = A - B, elementwise over one m x m matrix per draw
+__global__ __launch_bounds__(256) void sb_sub_kernel(const double* A, long sA, const double* Bm, long sB, double* out,
+                                                     long sO, long mm) {
+  const long b = blockIdx.y;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e < mm) out[b * sO + e] = A[b * sA + e] - Bm[b * sB + e];
+}
+
+// dst = src' (m x m per draw), 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void sb_transpose_kernel(const double* src, long sS, double* dst, long sD, int m) {
+  __shared__ double tile[32][33];
+  const long b = blockIdx.z;
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int r = by + k, c = bx + tx;
+    tile[k][tx] = (r < m && c < m) ? src[b * sS + (long)r * m + c] : 0.0;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int r = bx + k, c = by + tx;
+    if (r < m && c < m) dst[b * sD + (long)r * m + c] = tile[tx][k];
+  }
+}
+
+// Cholesky of the nb x nb diagonal block at (k1, k1) of A (in place, lower) and the inverse of its
+// factor: LINV[b][blk] = inv(L_kk), LINVT = its transpose (64 x 64, zero padded).  One workgroup
+// per draw.  A non-positive pivot leaves NaNs (the smoother has no info output).
+__global__ __launch_bounds__(256) void sb_potrf_inv_kernel(double* A, long sA, int m, int k1, int nb, double* LINV,
+                                                           double* LINVT, long sL) {
+  __shared__ double L[NB][NB + 1];
+  __shared__ double I[NB][NB + 1];
+  const int tid = threadIdx.x;
+  const long b = blockIdx.x;
+  double* Ab = A + b * sA + (long)k1 * m + k1;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e / NB, j = e - i * NB;
+    L[i][j] = (i < nb && j <= i) ? Ab[(long)i * m + j] : 0.0;
+    I[i][j] = 0.0;
+  }
+  __syncthreads();
+  for (int j = 0; j < nb; ++j) {
+    const double d = sqrt(L[j][j]);  // NaN for a negative pivot
+    __syncthreads();
+    for (int i = j + tid; i < nb; i += 256) L[i][j] = (i == j) ? d : L[i][j] / d;
+    __syncthreads();
+    const int rem = nb - j - 1;
+    for (int e = tid; e < rem * rem; e += 256) {
+      const int ii = j + 1 + e / rem, kk = j + 1 + e % rem;
+      if (kk <= ii) L[ii][kk] -= L[ii][j] * L[kk][j];
+    }
+    __syncthreads();
+  }
+  // inverse by forward substitution, one column per thread: L x = e_c
+  if (tid < nb) {
+    const int c = tid;
+    for (int i = c; i < nb; ++i) {
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int k = c; k < i; ++k) s -= L[i][k] * I[k][c];
+      I[i][c] = s / L[i][i];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e / NB, j = e - i * NB;
+    if (i < nb && j <= i) Ab[(long)i * m + j] = L[i][j];
+    LINV[b * sL + e] = I[i][j];
+    LINVT[b * sL + e] = I[j][i];
+  }
+}
+
+// a_s[t] = a_f[t] + G (a_s[t+1] - T a_f[t]);  one workgroup per draw, m <= 1024
+__global__ __launch_bounds__(256) void sb_avec_kernel(const double* Tm, const double* G, long sG, const double* filt_a,
+                                                      double* smooth_a, int n, int m, int t) {
+  extern __shared__ double sh[];  // a_f (m), diff (m)
+  double* af = sh;
+  double* df = sh + m;
+  const int tid = threadIdx.x;
+  const long b = blockIdx.x;
+  const double* gT = Tm + b * (long)m * m;
+  const double* fa = filt_a + (b * (long)n + t) * m;
+  const double* sn = smooth_a + (b * (long)n + t + 1) * m;
+  for (int i = tid; i < m; i += 256) af[i] = fa[i];
+  __syncthreads();
+  for (int i = tid; i < m; i += 256) {
+    double s = 0.0;
+    for (int k = 0; k < m; ++k) s = fma(gT[(long)i * m + k], af[k], s);
+    df[i] = sn[i] - s;
+  }
+  __syncthreads();
+  const double* Gb = G + b * sG;
+  for (int i = tid; i < m; i += 256) {
+    double s = af[i];
+    for (int k = 0; k < m; ++k) s = fma(Gb[(long)i * m + k], df[k], s);
+    smooth_a[(b * (long)n + t) * m + i] = s;
+  }
+}
+
+// smooth[n-1] = filt[n-1]
+__global__ __launch_bounds__(256) void sb_last_kernel(const double* filt_a, const double* filt_P, double* smooth_a,
+                                                      double* smooth_P, int n, int m) {
+  const long b = blockIdx.y;
+  const long mm = (long)m * m;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e < mm) smooth_P[(b * n + (n - 1)) * mm + e] = filt_P[(b * n + (n - 1)) * mm + e];
+  if (e < m) smooth_a[(b * n + (n - 1)) * m + e] = filt_a[(b * n + (n - 1)) * m + e];
+}
+
+template <bool TRANS_B, int EPI>
+void gemm(hipStream_t st, long B, const double* A, long sA, int lda, const double* Bm, long sB, int ldb, const double* E,
+          long sE, int lde, double* C, long sC, int ldc, int M, int N, int K) {
+  if (M <= 0 || N <= 0) return;
+  dim3 grid((unsigned)((N + GTN - 1) / GTN), (unsigned)((M + GTM - 1) / GTM), (unsigned)B);
+  hipLaunchKernelGGL((sb_gemm_kernel<TRANS_B, EPI>), grid, dim3(GNT), 0, st, A, sA, lda, Bm, sB, ldb, E, sE, lde, C, sC,
+                     ldc, M, N, K);
+}
+
+}  // namespace
+
+size_t kf_smoother_big_workspace_bytes(long B, int m) {
+  const long mm = (long)m * m;
+  const int nblk = (m + NB - 1) / NB;
+  return sizeof(double) * (size_t)B * (size_t)(6 * mm + 2L * nblk * NB * NB) + 256;
+}
+
+int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace, size_t workspace_bytes,
+                           hipStream_t st) {
+  const long B = a.B;
+  const int m = a.m, n = a.T, r = a.r;
+  const long mm = (long)m * m;
+  const size_t need = kf_smoother_big_workspace_bytes(B, m);
+  if (!workspace || workspace_bytes < need) {
+    KF_SET_ERR(h, "smoother(big): m=%d needs a workspace of %zu bytes (kf_workspace_bytes), got %zu", m, need,
+               workspace_bytes);
+    return KF_ERR_WORKSPACE;
+  }
+  if (m > 1024) {
+    KF_SET_ERR(h, "smoother(big): m=%d > 1024 not supported", m);
+    return KF_ERR_UNSUPPORTED;
+  }
+  const int nblk = (m + NB - 1) / NB;
+  const long sL = (long)nblk * NB * NB;
+  double* ws = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 63) & ~(uintptr_t)63);
+  double* RQR = ws;
+  double* W = RQR + B * mm;    // T P_f, then Y, then X
+  double* PH = W + B * mm;     // P_hat, then its Cholesky factor L (lower)
+  double* Dm = PH + B * mm;    // P_s[t+1] - P_hat
+  double* U = Dm + B * mm;     // L', then G = X'
+  double* Em = U + B * mm;     // D X
+  double* LINV = Em + B * mm;
+  double* LINVT = LINV + B * sL;
+
+  const unsigned eb = (unsigned)((mm + 255) / 256);
+  hipLaunchKernelGGL(sb_rqr_kernel, dim3(eb, (unsigned)B), dim3(256), 0, st, a.R, a.Q, RQR, m, r);
+  hipLaunchKernelGGL(sb_last_kernel, dim3(eb, (unsigned)B), dim3(256), 0, st, a.filt_a, a.filt_P, a.smooth_a,
+                     a.smooth_P, n, m);
+  const long sTape = (long)n * mm;
+  const unsigned tb = (unsigned)((m + 31) / 32);
+  for (int t = n - 2; t >= 0; --t) {
+    const double* Pf = a.filt_P + (long)t * mm;
+    const double* Psn = a.smooth_P + (long)(t + 1) * mm;
+    double* Ps = a.smooth_P + (long)t * mm;
+    // W = T P_f ; P_hat = W T' + RQR' ; D = P_s[t+1] - P_hat
+    gemm<false, EPI_STORE>(st, B, a.Tm, mm, m, Pf, sTape, m, nullptr, 0, 0, W, mm, m, m, m, m);
+    gemm<true, EPI_ADD>(st, B, W, mm, m, a.Tm, mm, m, RQR, mm, m, PH, mm, m, m, m, m);
+    hipLaunchKernelGGL(sb_sub_kernel, dim3(eb, (unsigned)B), dim3(256), 0, st, Psn, sTape, PH, mm, Dm, mm, mm);
+    // blocked Cholesky of P_hat (lower, in place)
+    for (int k = 0; k < nblk; ++k) {
+      const int k1 = k * NB, nb = (m - k1 < NB) ? m - k1 : NB, k2 = k1 + nb, rem = m - k2;
+      hipLaunchKernelGGL(sb_potrf_inv_kernel, dim3((unsigned)B), dim3(256), 0, st, PH, mm, m, k1, nb,
+                         LINV + (long)k * NB * NB, LINVT + (long)k * NB * NB, sL);
+      if (rem > 0) {
+        double* panel = PH + (long)k2 * m + k1;
+        // L21 = A21 inv(L11)'   (in place: every workgroup reads exactly the rows it writes)
+        gemm<true, EPI_STORE>(st, B, panel, mm, m, LINV + (long)k * NB * NB, sL, NB, nullptr, 0, 0, panel, mm, m, rem,
+                              nb, nb);
+        // A22 -= L21 L21'
+        double* A22 = PH + (long)k2 * m + k2;
+        gemm<true, EPI_RSUB>(st, B, panel, mm, m, panel, mm, m, A22, mm, m, A22, mm, m, rem, rem, nb);
+      }
+    }
+    hipLaunchKernelGGL(sb_transpose_kernel, dim3(tb, tb, (unsigned)B), dim3(256), 0, st, PH, mm, U, mm, m);
+    // forward substitution  L Y = W  (Y overwrites W)
+    for (int k = 0; k < nblk; ++k) {
+      const int k1 = k * NB, nb = (m - k1 < NB) ? m - k1 : NB, k2 = k1 + nb, rem = m - k2;
+      double* Wk = W + (long)k1 * m;
+      gemm<false, EPI_STORE>(st, B, LINV + (long)k * NB * NB, sL, NB, Wk, mm, m, nullptr, 0, 0, Wk, mm, m, nb, m, nb);
+      if (rem > 0) {
+        double* Wr = W + (long)k2 * m;
+        gemm<false, EPI_RSUB>(st, B, PH + (long)k2 * m + k1, mm, m, Wk, mm, m, Wr, mm, m, Wr, mm, m, rem, m, nb);
+      }
+    }
+    // backward substitution  L' X = Y  (X overwrites W), U = L'
+    for (int k = nblk - 1; k >= 0; --k) {
+      const int k1 = k * NB, nb = (m - k1 < NB) ? m - k1 : NB;
+      double* Wk = W + (long)k1 * m;
+      gemm<false, EPI_STORE>(st, B, LINVT + (long)k * NB * NB, sL, NB, Wk, mm, m, nullptr, 0, 0, Wk, mm, m, nb, m, nb);
+      if (k1 > 0) gemm<false, EPI_RSUB>(st, B, U + k1, mm, m, Wk, mm, m, W, mm, m, W, mm, m, k1, m, nb);
+    }
+    // E = D X ; G = X' ; P_s[t] = G E + P_f[t] ; a_s[t]
+    gemm<false, EPI_STORE>(st, B, Dm, mm, m, W, mm, m, nullptr, 0, 0, Em, mm, m, m, m, m);
+    hipLaunchKernelGGL(sb_transpose_kernel, dim3(tb, tb, (unsigned)B), dim3(256), 0, st, W, mm, U, mm, m);
+    gemm<false, EPI_ADD>(st, B, U, mm, m, Em, mm, m, Pf, sTape, m, Ps, sTape, m, m, m, m);
+    hipLaunchKernelGGL(sb_avec_kernel, dim3((unsigned)B), dim3(256), sizeof(double) * 2 * m, st, a.Tm, U, mm,
+                       a.filt_a, a.smooth_a, n, m, t);
+  }
+  KF_HIP_CHECK(h, hipGetLastError());
+  return KF_OK;
+}

@@ -284,8 +284,9 @@ class KalmanEngine:
         dims = self._dims(B, n, 1, m, r)
         sa = torch.empty_like(fa)
         sP = torch.empty_like(fP)
+        ws, ws_bytes = self._workspace(dims)  # large m only (kf_smoother_big.hip)
         rc = self.lib.kf_smoother(self._h, C.byref(dims), _ptr(T), _ptr(R), _ptr(Q), _ptr(fa),
-                                  _ptr(fP), _ptr(sa), _ptr(sP), None, 0, self._stream())
+                                  _ptr(fP), _ptr(sa), _ptr(sP), _ptr(ws), ws_bytes, self._stream())
         self._check(rc, "kf_smoother")
         return sa, sP
 

@@ -18,3 +18,17 @@ eng.forward(*d, out=res, **kw)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"B={B} n={n} m=367: {dt*1e3:.1f} ms, {dt/n*1e3:.3f} ms/step, GEMM rate {B*n*4.0*367**3/dt/1e12:.2f} TFLOP/s")
+# smoother on the same share (filtered tapes needed): smaller n keeps the tapes in HBM comfortably
+ns = min(n, 32)
+ws = W.daily_seasonal(B=B, n=ns)
+ds = [eng.to_device(ws[k]) for k in ("y", "a0", "P0", "T", "Z", "R", "H", "Q")]
+rs = eng.forward(*ds, store_ll_obs=False, store_predicted=False)
+torch.cuda.synchronize()
+eng.smooth(ds[3], ds[5], ds[7], rs.filtered_states, rs.filtered_covs)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+sa, sP = eng.smooth(ds[3], ds[5], ds[7], rs.filtered_states, rs.filtered_covs)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"smoother B={B} n={ns} m=367: {dt*1e3:.1f} ms, {dt/(ns-1)*1e3:.3f} ms/step, "
+      f"~{B*(ns-1)*10.3*367**3/dt/1e12:.2f} TFLOP/s (10.3 m^3 flop per draw-step)")

@@ -608,16 +608,60 @@ def test_big_m_needs_workspace_and_says_so(eng):
     assert b"workspace" in eng.lib.kf_last_error(eng._h)
 
 
-def test_big_m_smoother_and_gradient_are_declared_unsupported(eng):
+def test_big_m_gradient_is_declared_unsupported(eng):
     from pymc_statespace_amd import KalmanError
 
     w = W.random_dense(1, 4, 1, 150, 2, seed=9)
     res = eng.forward(*_args(w))
     with pytest.raises(KalmanError, match="LDS"):
-        eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
-    with pytest.raises(KalmanError, match="LDS"):
         eng.backward(*_args(w), predicted_states=res.predicted_states,
                      predicted_covs=res.predicted_covs, g_logp=np.ones(1))
+
+
+BIG_SMOOTH_CASES = {
+    "dense_p1m64": lambda: W.random_dense(3, 9, 1, 64, 8, seed=12),      # exactly one Cholesky block
+    # r ~ m/2 keeps cond(P_hat) ~ 1e4: with r = 3..5 it reaches 1e9 and the reference's SVD pinv and
+    # a Cholesky solve legitimately differ by cond x eps
+    "dense_p2m70": lambda: W.random_dense(2, 7, 2, 70, 35, seed=13),     # 64 + 6
+    "dense_p1m130": lambda: W.random_dense(2, 6, 1, 130, 65, seed=14),   # 64 + 64 + 2
+    "c5_daily_seasonal_m367": lambda: W.daily_seasonal(B=2, n=6),        # 5 x 64 + 47
+}
+
+
+@pytest.mark.parametrize("case", sorted(BIG_SMOOTH_CASES))
+def test_big_m_smoother_matches_oracle(eng, case):
+    """kf_smoother_big.hip: HBM workspace, blocked Cholesky and substitutions as fp64-MFMA GEMMs."""
+    w = BIG_SMOOTH_CASES[case]()
+    flt = kn.kalman_filter(*_args(w))
+    ref_a, ref_P = kn.kalman_smoother(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
+    sa, sP = eng.smooth(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
+    sa, sP = sa.cpu().numpy(), sP.cpu().numpy()
+    assert_allclose(sa, ref_a, rtol=1e-8, atol=1e-8, err_msg=case)
+    assert_allclose(sP, ref_P, rtol=1e-8, atol=1e-8, err_msg=case)
+    # reference tests/test_kalman_filter.py: the last smoothed moments are the last filtered ones
+    assert np.array_equal(sa[:, -1], flt["filtered_states"][:, -1])
+    assert np.array_equal(sP[:, -1], flt["filtered_covs"][:, -1])
+
+
+def test_big_m_smoother_needs_workspace_and_says_so(eng):
+    import ctypes as C
+
+    import torch
+
+    from pymc_statespace_amd import _lib
+
+    w = W.random_dense(1, 3, 1, 80, 2, seed=9)
+    flt = kn.kalman_filter(*_args(w))
+    dims = _lib.KfDims(1, 3, 1, 80, 2, 0, 0)
+    nbytes = C.c_size_t(0)
+    assert eng.lib.kf_workspace_bytes(eng._h, C.byref(dims), C.byref(nbytes)) == 0
+    assert nbytes.value >= 8 * 6 * 80 * 80
+    d = [eng.to_device(x) for x in (w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])]
+    sa, sP = torch.empty_like(d[3]), torch.empty_like(d[4])
+    ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    rc = eng.lib.kf_smoother(eng._h, C.byref(dims), *[ptr(x) for x in d], ptr(sa), ptr(sP), None, 0, None)
+    assert rc == _lib.KF_ERR_WORKSPACE
+    assert b"workspace" in eng.lib.kf_last_error(eng._h)
 
 
 @pytest.mark.parametrize("m", [1, 2, 3, 4])
