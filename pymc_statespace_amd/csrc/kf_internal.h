@@ -86,6 +86,7 @@ struct KfSmoothArgs {
   const double* filt_P;
   double* smooth_a;
   double* smooth_P;
+  const int32_t* only_flagged;  // LDS kernel: when set, only draws with a non-zero flag are processed
 };
 
 // per-draw LDS footprints (in doubles) -- shared by host launchers and kernels
@@ -176,6 +177,10 @@ inline bool kf_smoother_lds_fits(int m) {
   const int M2 = (m + 1) / 2;
   return sizeof(double) * (size_t)((9 * m * m + 6 * m + 4 * M2 + 2) | 1) <= KF_LDS_BYTES_MAX;
 }
+// register-tile smoother (kf_smoother_mfma.hip): m <= 16, needs 4 B + 64 bytes of workspace (flags)
+size_t kf_smoother_mfma_workspace_bytes(long B);
+int kf_launch_smoother_mfma(kf_handle* h, const KfSmoothArgs& a, void* workspace, size_t workspace_bytes,
+                            hipStream_t stream);
 // large-m smoother (kf_smoother_big.hip): HBM workspace, blocked Cholesky, fp64-MFMA GEMMs
 size_t kf_smoother_big_workspace_bytes(long B, int m);
 int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace, size_t workspace_bytes,

@@ -140,6 +140,8 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lds_kernel(const KfSmoothAr
   long b = (long)blockIdx.x * DPB + grp;
   const bool live = b < A.B;
   if (!live) b = A.B - 1;
+  // fallback pass behind kf_smooth_mfma_kernel (launched with G = 64: one draw per wavefront)
+  if (A.only_flagged && DPB == 1 && A.only_flagged[b] == 0) return;
 
   double* S = smem + (size_t)grp * smooth_region_doubles(m);
   double* Ps = S;
@@ -353,6 +355,7 @@ int launch_g(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream) {
 
 int kf_launch_smoother_lds(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream) {
   int G = kf_pick_lanes(h, a.m, a.B);
+  if (a.only_flagged) G = KF_WAVE;
   while (G < KF_WAVE &&
          sizeof(double) * (size_t)(KF_WAVE / G) * smooth_region_doubles(a.m) > KF_LDS_BYTES_MAX / 2)
     G *= 2;
