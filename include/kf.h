@@ -132,7 +132,10 @@ int kf_set_forward_kernel(kf_handle* h, int kernel);
 /* Name of the kernel kf_filter_forward would launch for `dims` (for profiles / bench logs). */
 const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* dims);
 
-/* Scratch the three entry points need for `dims` (max over them); may be 0. */
+/* Scratch the three entry points need for `dims` (max over them); may be 0.  Non-zero for
+ * k_states too large for on-chip tiles (forward: m^2-sized covariance workspace; smoother for
+ * m > ~47: 6 B m^2 doubles) and, a few bytes per draw, for the register-tile smoother
+ * (5 <= m <= 16: per-draw flags; without them kf_smoother uses the slower LDS kernel). */
 int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes);
 
 /* Forward filter for B draws.  c, d may be NULL (= 0: initialize_intercepts,
@@ -151,7 +154,9 @@ int kf_filter_forward(kf_handle* h, const kf_dims* dims,
  * call on the same inputs (pred_a, pred_P).  g_logp or g_ll_obs may be NULL (= 0);
  * any output gradient pointer may be NULL (= not wanted).  Gradients treat every
  * matrix entry as an independent variable (what autodiff of the reference graph
- * returns). */
+ * returns).  With KF_FLAG_H_DIAGONAL and p > 1 (Standard/Cholesky on the scalar-observation
+ * kernels) g_H carries the diagonal only (off-diagonal entries 0) and g_P0 the symmetric part
+ * of the entrywise gradient -- all a diagonal-H / symmetric-P0 parameterisation can see. */
 int kf_filter_backward(kf_handle* h, const kf_dims* dims,
                        const double* y, const double* a0, const double* P0,
                        const double* T, const double* Z, const double* R,
@@ -166,7 +171,9 @@ int kf_filter_backward(kf_handle* h, const kf_dims* dims,
 /* RTS smoother over the filtered tapes: smooth_a [B][T][m], smooth_P [B][T][m][m].
  * Only dims->B, T, m, r are used.  The gain uses the Moore-Penrose pseudo-inverse of
  * the one-step prediction covariance with numpy's default cutoff 1e-15 * sigma_max
- * (kalman_smoother.py:92). */
+ * (kalman_smoother.py:92): a Cholesky / Gauss-Jordan solve whenever that covariance is safely
+ * positive definite, a Jacobi eigen-decomposition otherwise (m <= ~47; beyond that the
+ * workspace path requires positive definiteness).  `workspace`: see kf_workspace_bytes. */
 int kf_smoother(kf_handle* h, const kf_dims* dims,
                 const double* T, const double* R, const double* Q,
                 const double* filt_a, const double* filt_P,

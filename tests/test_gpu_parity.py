@@ -1067,3 +1067,21 @@ def test_mfma_gradient_needs_scalar_observations(eng):
                          predicted_covs=res.predicted_covs, g_logp=np.ones(3))
     finally:
         eng.set_forward_kernel("auto")
+
+
+def test_mfma_gradient_per_draw_data(eng):
+    from oracle import kalman_torch as kt
+
+    w = W.structural(B=4, n=40)
+    rng = np.random.default_rng(5)
+    yb = w["y"][None] + 0.1 * rng.standard_normal((4,) + w["y"].shape)
+    g_logp = rng.standard_normal(4)
+    res = eng.forward(yb, *_args(w)[1:])
+    g = eng.backward(yb, *_args(w)[1:], predicted_states=res.predicted_states,
+                     predicted_covs=res.predicted_covs, g_logp=g_logp)
+    for b in range(4):
+        sl = slice(b, b + 1)
+        _, _, gt = kt.logp_and_grads(yb[b], *[x[sl] for x in _args(w)[1:]], g_logp=g_logp[sl])
+        for k in ("a0", "P0", "T", "Z", "R", "H", "Q"):
+            a, ref = g[k][b].cpu().numpy(), gt[k][0]
+            assert np.max(np.abs(a - ref)) / (1.0 + np.max(np.abs(ref))) < 1e-10, (b, k)
