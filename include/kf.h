@@ -209,6 +209,33 @@ int kf_conditional_simulation(kf_handle* h, int64_t B, int32_t n, int32_t k, int
                               const double* mu, const double* cov, const double* z, double jitter,
                               double* out, int32_t* info, void* stream);
 
+/* ---- SteadyStateFilter and unconditional simulation -----------
+ * Batched steady-state covariance of the filter: the fixed point of
+ *     P <- T (P - P Z' (Z P Z' + H)^-1 Z P) T' + R Q R'
+ * per draw, i.e. solve_discrete_are(T', Z', R Q R', H) of SteadyStateFilter.build_graph
+ * (pymc_statespace/filters/kalman_filter.py:388-390).  The recursion is iterated from P_init
+ * ([B][m][m], NULL = R Q R') until the largest entrywise change is <= tol * (1 + max|P|) or
+ * max_iter steps.  info[b]: 0 converged, 1 max_iter reached, 2 Z P Z' + H not positive
+ * definite.  A SteadyStateFilter is then kf_filter_forward started from P (same results: at the
+ * fixed point the reference's frozen F_inv equals the F^-1 of every step). */
+int kf_dare(kf_handle* h, int64_t B, int32_t m, int32_t p, int32_t r, const double* T,
+            const double* Z, const double* R, const double* H, const double* Q,
+            const double* P_init, double* P, int32_t* info, int32_t max_iter, double tol,
+            void* stream);
+
+/* Batched unconditional simulation of the state space model, n_sims trajectories per draw:
+ * simulate_statespace / unconditional_simulations (pymc_statespace/utils/simulation.py:29-79)
+ * with their conventions -- innovations are `normals @ chol` (lower factor), the observation at
+ * step t reads the state at t-1, row 0 is (x0, Z x0) or zeros when x0 is NULL, H == 0 means no
+ * observation noise.  z_state [B][n_sims][n][r], z_obs [B][n_sims][n][p]: standard normals from
+ * the caller; states [B*n_sims][n][m], obs [B*n_sims][n][p].  info[b]: 1 = Q, 2 = H not
+ * positive definite.  m <= 64, r <= 16. */
+int kf_simulate_statespace(kf_handle* h, int64_t B, int32_t n_sims, int32_t n, int32_t p,
+                           int32_t m, int32_t r, const double* T, const double* Z,
+                           const double* R, const double* H, const double* Q, const double* x0,
+                           const double* z_state, const double* z_obs, double* states,
+                           double* obs, int32_t* info, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

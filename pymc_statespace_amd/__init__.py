@@ -16,11 +16,12 @@ from .filters import (  # noqa: E402
     KalmanSmoother,
     SingleTimeseriesFilter,
     StandardFilter,
+    SteadyStateFilter,
     UnivariateFilter,
 )
 
 __all__ = [
     "KalmanEngine", "KalmanError", "FilterResult", "get_engine", "StandardFilter",
-    "CholeskyFilter", "UnivariateFilter", "SingleTimeseriesFilter", "KalmanSmoother",
+    "CholeskyFilter", "UnivariateFilter", "SingleTimeseriesFilter", "SteadyStateFilter", "KalmanSmoother",
     "FILTER_FACTORY",
 ]

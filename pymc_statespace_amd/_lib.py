@@ -26,7 +26,7 @@ EXPORTS = (
     "kf_abi_version", "kf_create", "kf_destroy", "kf_last_error", "kf_set_lanes_per_draw",
     "kf_set_forward_kernel", "kf_forward_kernel_name",
     "kf_workspace_bytes", "kf_filter_forward", "kf_filter_backward", "kf_smoother",
-    "kf_assemble", "kf_lyapunov", "kf_conditional_simulation",
+    "kf_assemble", "kf_lyapunov", "kf_conditional_simulation", "kf_dare", "kf_simulate_statespace",
 )
 
 
@@ -91,6 +91,12 @@ def load():
     lib.kf_conditional_simulation.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp,
                                               C.c_double, dp, ip, vp]
     lib.kf_conditional_simulation.restype = C.c_int
+    lib.kf_dare.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp, dp, dp, dp, dp, ip,
+                            C.c_int32, C.c_double, vp]
+    lib.kf_dare.restype = C.c_int
+    lib.kf_simulate_statespace.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, ip, vp]
+    lib.kf_simulate_statespace.restype = C.c_int
     if lib.kf_abi_version() != KF_ABI_VERSION:
         raise KfLibraryMissing(f"{LIB_PATH}: ABI version {lib.kf_abi_version()} != {KF_ABI_VERSION}")
     _lib = lib

@@ -479,3 +479,29 @@ extern "C" int kf_conditional_simulation(kf_handle* h, int64_t B, int32_t n, int
   }
   return kf_launch_simulate(h, B, n, k, n_sims, mu, cov, z, jitter, out, info, (hipStream_t)stream);
 }
+
+extern "C" int kf_dare(kf_handle* h, int64_t B, int32_t m, int32_t p, int32_t r, const double* T, const double* Z,
+                       const double* R, const double* H, const double* Q, const double* P_init, double* P,
+                       int32_t* info, int32_t max_iter, double tol, void* stream) {
+  if (!h) return KF_ERR_ARG;
+  if (B < 1 || m < 1 || p < 1 || r < 1 || !T || !Z || !R || !H || !Q || !P || max_iter < 1 || !(tol >= 0.0)) {
+    KF_SET_ERR(h, "kf_dare: bad arguments (B=%ld m=%d p=%d r=%d max_iter=%d)", (long)B, m, p, r, max_iter);
+    return KF_ERR_ARG;
+  }
+  return kf_launch_dare(h, B, m, p, r, T, Z, R, H, Q, P_init, P, info, max_iter, tol, (hipStream_t)stream);
+}
+
+extern "C" int kf_simulate_statespace(kf_handle* h, int64_t B, int32_t n_sims, int32_t n, int32_t p, int32_t m,
+                                      int32_t r, const double* T, const double* Z, const double* R, const double* H,
+                                      const double* Q, const double* x0, const double* z_state, const double* z_obs,
+                                      double* states, double* obs, int32_t* info, void* stream) {
+  if (!h) return KF_ERR_ARG;
+  if (B < 1 || n_sims < 1 || n < 1 || p < 1 || m < 1 || r < 1 || !T || !Z || !R || !H || !Q || !z_state || !z_obs ||
+      !states || !obs) {
+    KF_SET_ERR(h, "kf_simulate_statespace: bad arguments (B=%ld n_sims=%d n=%d p=%d m=%d r=%d)", (long)B, n_sims, n,
+               p, m, r);
+    return KF_ERR_ARG;
+  }
+  return kf_launch_simulate_statespace(h, B, n_sims, n, p, m, r, T, Z, R, H, Q, x0, z_state, z_obs, states, obs, info,
+                                       (hipStream_t)stream);
+}

@@ -191,6 +191,13 @@ int kf_launch_lyapunov(kf_handle* h, long B, int m, int r, const double* T, cons
 int kf_launch_simulate(kf_handle* h, long B, int n, int k, int n_sims, const double* mu,
                        const double* cov, const double* z, double jitter, double* out, int32_t* info,
                        hipStream_t stream);
+int kf_launch_dare(kf_handle* h, long B, int m, int p, int r, const double* T, const double* Z, const double* R,
+                   const double* H, const double* Q, const double* Pinit, double* P, int32_t* info, int max_iter,
+                   double tol, hipStream_t stream);
+int kf_launch_simulate_statespace(kf_handle* h, long B, int n_sims, int n, int p, int m, int r, const double* T,
+                                  const double* Z, const double* R, const double* H, const double* Q,
+                                  const double* x0, const double* zs, const double* zo, double* states, double* obs,
+                                  int32_t* info, hipStream_t stream);
 int kf_launch_assemble(kf_handle* h, long B, int n_theta, const double* theta, long total,
                        const double* tmpl, int n_map, const int32_t* dst, const int32_t* src,
                        double* out, hipStream_t stream);

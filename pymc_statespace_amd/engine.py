@@ -346,6 +346,58 @@ class KalmanEngine:
         self._check(rc, "kf_conditional_simulation")
         return out, info
 
+    # ------------------------------------------------- SURVEY section 8f row 4
+    def dare(self, T, Z, R, H, Q, P_init=None, max_iter=100000, tol=1e-14):
+        """kf_dare: steady-state predicted covariance per draw, (P (B,m,m), info (B,) int32)."""
+        T = self.to_device(T)
+        B, m = T.shape[0], T.shape[1]
+        Z = self.to_device(Z)
+        p = Z.shape[1]
+        R = self.to_device(R)
+        r = R.shape[2]
+        Z = self.to_device(Z, (B, p, m))
+        H = self.to_device(H, (B, p, p))
+        Q = self.to_device(Q, (B, r, r))
+        P_init = self.to_device(P_init, (B, m, m)) if P_init is not None else None
+        P = torch.empty(B, m, m, device=self.device, dtype=torch.float64)
+        info = torch.empty(B, device=self.device, dtype=torch.int32)
+        rc = self.lib.kf_dare(self._h, B, m, p, r, _ptr(T), _ptr(Z), _ptr(R), _ptr(H), _ptr(Q), _ptr(P_init),
+                              _ptr(P), _ptr(info), int(max_iter), float(tol), self._stream())
+        self._check(rc, "kf_dare")
+        return P, info
+
+    def simulate_statespace(self, T, Z, R, H, Q, n_steps, n_simulations=1, x0=None, generator=None,
+                            z_state=None, z_obs=None):
+        """kf_simulate_statespace: (states (B*n_simulations, n_steps, m), obs (B*n_simulations, n_steps, p),
+        info (B,)).  Standard normals z_state (B,n_sims,n_steps,r) / z_obs (B,n_sims,n_steps,p) are drawn
+        with ``generator`` unless given."""
+        T = self.to_device(T)
+        B, m = T.shape[0], T.shape[1]
+        Z = self.to_device(Z)
+        p = Z.shape[1]
+        R = self.to_device(R)
+        r = R.shape[2]
+        H = self.to_device(H, (B, p, p))
+        Q = self.to_device(Q, (B, r, r))
+        x0 = self.to_device(x0, (B, m)) if x0 is not None else None
+        dev, f64 = self.device, torch.float64
+        if z_state is None:
+            z_state = torch.randn(B, n_simulations, n_steps, r, device=dev, dtype=f64, generator=generator)
+        else:
+            z_state = self.to_device(z_state, (B, n_simulations, n_steps, r))
+        if z_obs is None:
+            z_obs = torch.randn(B, n_simulations, n_steps, p, device=dev, dtype=f64, generator=generator)
+        else:
+            z_obs = self.to_device(z_obs, (B, n_simulations, n_steps, p))
+        states = torch.empty(B * n_simulations, n_steps, m, device=dev, dtype=f64)
+        obs = torch.empty(B * n_simulations, n_steps, p, device=dev, dtype=f64)
+        info = torch.empty(B, device=dev, dtype=torch.int32)
+        rc = self.lib.kf_simulate_statespace(self._h, B, n_simulations, n_steps, p, m, r, _ptr(T), _ptr(Z),
+                                             _ptr(R), _ptr(H), _ptr(Q), _ptr(x0), _ptr(z_state), _ptr(z_obs),
+                                             _ptr(states), _ptr(obs), _ptr(info), self._stream())
+        self._check(rc, "kf_simulate_statespace")
+        return states, obs, info
+
 
 _engines = {}
 

@@ -105,7 +105,7 @@ class BaseFilter:
 
         def lead(x, core_ndim):
             x = _np_or_t(x)
-            if x.ndim > core_ndim and x.shape[-1] == 1 and core_ndim == 1:
+            if x.ndim > core_ndim + (1 if batched else 0) and x.shape[-1] == 1 and core_ndim == 1:
                 x = x[..., 0]  # (m,1) column vectors of the reference
             return x if batched else x[None]
 
@@ -165,6 +165,67 @@ class UnivariateFilter(BaseFilter):
     filter_type = "univariate"
 
 
+class SteadyStateFilter(BaseFilter):
+    """reference kalman_filter.py:354-441: the covariance recursion is started from the solution
+    of the filtering Riccati equation (``solve_discrete_are(T', Z', R Q R', H)``, :388) and the
+    gain uses the frozen ``F_inv`` of that fixed point.  Here: ``kf_dare`` (batched fixed-point
+    iteration on the GPU) followed by the Standard recursion from ``P_steady`` -- at the fixed
+    point every step's ``F^-1`` IS the frozen one, so the outputs agree to the DARE tolerance.
+    Kept quirks: slot 0 of ``predicted_covariances`` is the caller's ``P0`` (:397,
+    ``_postprocess_scan_results(results, a0, P0)``), and the innovation ignores ``d`` (:400).
+    With missing observations the reference keeps the frozen gain although P has left the fixed
+    point (its recursion can then diverge); this filter uses the exact gain of the current P there.
+    Static system matrices only (:380-383).  Eager evaluation only: the symbolic ``build_graph``
+    raises (the gradient through the Riccati solve is not provided)."""
+    filter_type = "standard"
+
+    def build_graph(self, *args, **kwargs):
+        raise NotImplementedError(
+            "SteadyStateFilter: eager evaluation only on the MI355X path "
+            "(flt(data, a0, P0, T, Z, R, H, Q)); use StandardFilter inside a PyMC graph")
+
+    def __call__(self, data, a0, P0, T, Z, R, H, Q, c=None, d=None, *, outputs="all",
+                 max_iter=100000, tol=1e-14):
+        as_torch = _is_torch(data, a0, P0, T, Z, R, H, Q)
+        T_, Z_, R_, H_, Q_ = map(_np_or_t, (T, Z, R, H, Q))
+        P0_ = _np_or_t(P0)
+        batched = P0_.ndim == 3
+        if _check_ndim([T_, Z_, R_, H_, Q_], ["T", "Z", "R", "H", "Q"], batched):
+            raise ValueError("All system matrices must be time-invariant to use the SteadyStateFilter")
+
+        def lead(x):
+            return x if batched else x[None]
+
+        P_steady, info = self.engine.dare(lead(T_), lead(Z_), lead(R_), lead(H_), lead(Q_),
+                                          max_iter=max_iter, tol=tol)
+        bad = info.cpu().numpy()
+        if self.on_error == "raise" and np.any(bad != 0):
+            b = int(np.flatnonzero(bad)[0])
+            raise np.linalg.LinAlgError(
+                f"draw {b}: discrete Riccati iteration " +
+                ("did not converge" if bad[b] == 1 else "met a non positive definite Z P Z' + H"))
+        if not batched:
+            P_steady = P_steady[0]
+        if not as_torch:
+            P_steady = P_steady.cpu().numpy()
+        res = super().__call__(data, a0, P_steady, T, Z, R, H, Q, c=c, d=None, outputs=outputs)
+        if outputs == "all":
+            pc = res[3]
+            if isinstance(pc, torch.Tensor):
+                P0t = P0_ if isinstance(P0_, torch.Tensor) else torch.as_tensor(P0_, device=pc.device)
+                if batched:
+                    pc[:, 0] = P0t.to(pc.device)
+                else:
+                    pc[0] = P0t.to(pc.device)
+            else:
+                P0n = P0_.cpu().numpy() if isinstance(P0_, torch.Tensor) else P0_
+                if batched:
+                    pc[:, 0] = P0n
+                else:
+                    pc[0] = P0n
+        return res
+
+
 class KalmanSmoother:
     """reference kalman_smoother.py:11-104"""
 
@@ -209,14 +270,14 @@ class KalmanSmoother:
         return sa.cpu().numpy(), sP.cpu().numpy()
 
 
-# the reference's FILTER_FACTORY keys (core/statespace.py:25-31); "steady_state" is out of
-# scope
+# the reference's FILTER_FACTORY keys (core/statespace.py:25-31)
 FILTER_FACTORY = {
     "standard": StandardFilter,
+    "steady_state": SteadyStateFilter,
     "univariate": UnivariateFilter,
     "single": SingleTimeseriesFilter,
     "cholesky": CholeskyFilter,
 }
 
 __all__ = ["StandardFilter", "UnivariateFilter", "KalmanSmoother", "SingleTimeseriesFilter",
-           "CholeskyFilter", "FILTER_FACTORY", "BaseFilter"]
+           "CholeskyFilter", "SteadyStateFilter", "FILTER_FACTORY", "BaseFilter"]

@@ -87,7 +87,7 @@ def test_build_graph_needs_pytensor_and_says_so():
 def test_filter_factory_keys_match_reference():
     from pymc_statespace_amd.filters import FILTER_FACTORY
 
-    # reference core/statespace.py:25-31 minus "steady_state" (out of scope)
-    assert set(FILTER_FACTORY) == {"standard", "univariate", "single", "cholesky"}
+    # reference core/statespace.py:25-31
+    assert set(FILTER_FACTORY) == {"standard", "univariate", "single", "cholesky", "steady_state"}
     for cls in FILTER_FACTORY.values():
         assert hasattr(cls, "build_graph") and callable(cls)
