@@ -1085,3 +1085,37 @@ def test_mfma_gradient_per_draw_data(eng):
         for k in ("a0", "P0", "T", "Z", "R", "H", "Q"):
             a, ref = g[k][b].cpu().numpy(), gt[k][0]
             assert np.max(np.abs(a - ref)) / (1.0 + np.max(np.abs(ref))) < 1e-10, (b, k)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 128, 129])
+def test_register_tile_kernels_at_block_boundaries(eng, n):
+    """Series lengths around the 64-step staging / likelihood blocks of the MFMA kernels."""
+    from oracle import kalman_torch as kt
+
+    B, p, m, r = 5, 1, 10, 4
+    w = W.random_dense(B, n, p, m, r, seed=900 + n)
+    y = w["y"].copy()
+    if n == 1:
+        y[:] = 0.3  # standardising a single observation gives NaN
+    if n > 2:
+        y[n // 2] = np.nan
+    ref = kn.kalman_filter(*_args(w, y), mvn_const="exact")
+    eng.set_forward_kernel("mfma")
+    try:
+        out = _np(eng.forward(*_args(w, y), mvn_const="exact"))
+        res = eng.forward(*_args(w, y))
+        g = eng.backward(*_args(w, y), predicted_states=res.predicted_states,
+                         predicted_covs=res.predicted_covs, g_logp=np.ones(B))
+    finally:
+        eng.set_forward_kernel("auto")
+    assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8
+    for k in TAPES:
+        assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=f"n={n} {k}")
+    _, _, gt = kt.logp_and_grads(*_args(w, y), g_logp=np.ones(B))
+    for k in ("a0", "P0", "T", "Z", "R", "H", "Q"):
+        a, b = g[k].cpu().numpy(), gt[k]
+        assert np.max(np.abs(a - b)) / (1.0 + np.max(np.abs(b))) < 1e-10, (n, k)
+    sa, sP = eng.smooth(w["T"], w["R"], w["Q"], ref["filtered_states"], ref["filtered_covs"])
+    ra, rP = kn.kalman_smoother(w["T"], w["R"], w["Q"], ref["filtered_states"], ref["filtered_covs"])
+    assert_allclose(sa.cpu().numpy(), ra, rtol=1e-8, atol=1e-8)
+    assert_allclose(sP.cpu().numpy(), rP, rtol=1e-8, atol=1e-8)
