@@ -37,9 +37,10 @@ namespace {
 
 constexpr int TILE = 16;
 constexpr int PMAXQ = KF_MP_P_MAX;
-// dynamic LDS (doubles): transpose tile | M exchange | a exchange | ring | diag H | d | y block (64 p)
+// dynamic LDS (doubles): transpose tile | tape staging tile | M exchange | a exchange | ring | diag H | d | y block (64 p)
 // | Z, Z permuted (16 p each, non-augmented variant only).  3.9 KB at p = 1: never the occupancy limit.
-constexpr int OFF_EXM = TILE * TILE;
+constexpr int OFF_STG = TILE * TILE;              // tape staging tile (separate from the transpose tile)
+constexpr int OFF_EXM = OFF_STG + TILE * TILE;
 constexpr int OFF_EXA = OFF_EXM + TILE;
 constexpr int OFF_RG = OFF_EXA + TILE;
 constexpr int OFF_HD = OFF_RG + 128;
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   const int je = AUG ? 4 * KS : TILE;  // tile indices >= je are padding too (exact zeros)
 
   double* TR = smem;
+  double* STG = smem + OFF_STG;
   double* EXM = smem + OFF_EXM;
   double* EXA = smem + OFF_EXA;
   double* RG = smem + OFF_RG;
@@ -238,29 +240,28 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     o_pP += mm;
   }
 
-  // covariance tapes: registers -> compact m x m image in LDS (tile TR, free at both points of
-  // the step) -> 16 bytes per lane, consecutive lanes on consecutive addresses (full lines)
+  // covariance tapes: registers -> compact m x m image in LDS (tile STG) -> 16 bytes per lane,
+  // consecutive lanes on consecutive addresses (full lines).  Staging and flushing are separate
+  // so that the LDS round trip hides behind independent work (the MFMAs / the next update).
   const int nb128 = mm >> 1;
-  auto store_cov = [&](double* dst, const double (&Preg)[KS]) {
-#ifdef KF_MFMA_DIRECT_STORES
+  auto stage_cov = [&](const double (&Preg)[KS]) {
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      if (on[s]) st_off(dst, offb[s], Preg[s]);
-#else
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-      if (on[s]) TR[offb[s] >> 3] = Preg[s];
-    __syncthreads();
-    const double2_t v2 = *reinterpret_cast<const double2_t*>(TR + 2 * lane);
+      if (on[s]) STG[offb[s] >> 3] = Preg[s];
+  };
+  auto flush_cov = [&](double* dst) {
+    wave_lds_fence();
+    const double2_t v2 = *reinterpret_cast<const double2_t*>(STG + 2 * lane);
     if (lane < nb128) st_stream(reinterpret_cast<double2_t*>(dst) + lane, v2);
     else if ((mm & 1) && lane == nb128) st_stream(dst + mm - 1, v2.x);
     if (mm > 2 * KF_WAVE) {  // m > 11: a second round of lanes
-      const double2_t w2 = *reinterpret_cast<const double2_t*>(TR + 2 * (lane + KF_WAVE));
+      const double2_t w2 = *reinterpret_cast<const double2_t*>(STG + 2 * (lane + KF_WAVE));
       if (lane + KF_WAVE < nb128) st_stream(reinterpret_cast<double2_t*>(dst) + lane + KF_WAVE, w2);
       else if ((mm & 1) && lane + KF_WAVE == nb128) st_stream(dst + mm - 1, w2.x);
     }
-#endif
+    wave_lds_fence();
   };
+  bool pred_pending = false;  // a predicted covariance sits in STG, flushed inside the next update
 
   double logp = 0.0;  // every lane accumulates the same total
   int info = 0;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     if ((t & 63) == 0) {
       const int cnt = ((n - t) < 64 ? (n - t) : 64) * p;
       for (int e = lane; e < cnt; e += KF_WAVE) YB[e] = ybase[(long)t * p + e];
-      __syncthreads();
+      wave_lds_fence();
     }
     const double* yrow = YB + (t & 63) * p;
     double mant = 1.0, qs = 0.0;
@@ -360,12 +361,17 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       }
       ac = fma(Mc * invF, v, ac);
       if ((P1 || q == p - 1) && g == 0) EXA[permc] = ac;
-      __syncthreads();
+      wave_lds_fence();
       double Mr[4];
       {
         const double2_t m01 = *reinterpret_cast<const double2_t*>(EXM + 4 * g);
         const double2_t m23 = *reinterpret_cast<const double2_t*>(EXM + 4 * g + 2);
         Mr[0] = m01.x; Mr[1] = m01.y; Mr[2] = m23.x; Mr[3] = m23.y;
+      }
+      if (q == 0 && pred_pending) {  // predicted covariance of the previous step: tile -> HBM
+        flush_cov(o_pP);
+        o_pP += mm;
+        pred_pending = false;
       }
       // P -= M M'/F, bitwise symmetric (M_i * M_j commutes)
 #pragma unroll
@@ -396,10 +402,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       if (vec_on) st_off(o_fa, voff, ac);
       o_fa += m;
     }
-    if (o_fP) {
-      store_cov(o_fP, P);
-      o_fP += mm;
-    }
+    if (o_fP) stage_cov(P);  // flushed below, behind the MFMAs
     // ---- predict: a_hat = T a_f + c ; P_hat = sym(T P_f T' + RQR') ----------------------------------------
     double part = TA[0] * ar[0];
 #pragma unroll
@@ -412,10 +415,14 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
                    KS > 3 ? RQRh[KS > 3 ? 3 : 0] : 0.0};
 #pragma unroll
     for (int s = 0; s < KS; ++s) S = __builtin_amdgcn_mfma_f64_16x16x4f64(TAh[s], W2[s], S, 0, 0, 0);
+    if (o_fP) {
+      flush_cov(o_fP);
+      o_fP += mm;
+    }
     // transpose S/2 through LDS: element (i, j) at TR[i*16 + perm(j)]
 #pragma unroll
     for (int s = 0; s < KS; ++s) TR[(4 * s + g) * TILE + permc] = S[s];
-    __syncthreads();
+    wave_lds_fence();
     {
       const double2_t t01 = *reinterpret_cast<const double2_t*>(TR + c * TILE + 4 * g);
       P[0] = S[0] + t01.x;
@@ -431,11 +438,12 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       o_pa += m;
     }
     if (o_pP) {
-      store_cov(o_pP, P);
-      o_pP += mm;
+      stage_cov(P);
+      pred_pending = true;
     }
     if ((t & 63) == 63) flush_ring(t - 63, 64);
   }
+  if (pred_pending) flush_cov(o_pP);
   if (n & 63) flush_ring(n & ~63, n & 63);
   if (lane == 0) {
     A.logp[b] = logp;

@@ -22,6 +22,12 @@ __device__ __forceinline__ void st_stream(T* p, T v) {
 #endif
 }
 
+// Ordering point between LDS accesses of the lanes of ONE wavefront.  A wavefront's LDS
+// instructions execute in order, so a ds_read issued after a ds_write of another lane already
+// sees the data; only the compiler must not reorder them.  Unlike __syncthreads() this does not
+// emit `s_waitcnt lgkmcnt(0)` on the spot: the wait lands where the loaded value is first used.
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
