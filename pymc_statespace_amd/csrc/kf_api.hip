@@ -292,9 +292,10 @@ int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, hipStream_t stream) {
     }
     return kf_launch_backward_mfma(h, a, stream);
   }
-  // measured (MI355X): m = 10, B = 4096: 3.2 ms vs 6.1 ms (row-split adjoint); C4 (p = 5, m = 15,
-  // B = 16384): 44 ms vs 396 ms (LDS adjoint); m = 2: 2.0 ms vs 0.9 ms -> small even m stays
-  if (h->forward_kernel == KF_KERNEL_AUTO && mfma_ok && (a.p > 1 || a.m >= 5 || (a.m & 1)))
+  // measured (MI355X, scripts/probes/bwd_sweep.py): m = 10, B = 4096: 3.2 ms vs 6.1 ms (row-split
+  // adjoint); m = 8: 2.7 vs 4.4 ms; m = 6: 2.6 vs 2.4 ms (7.3 vs 17 ms at B = 32768) -> even m <= 6
+  // stays on the row-split adjoint; C4 (p = 5, m = 15, B = 16384): 44 ms vs 396 ms (LDS adjoint)
+  if (h->forward_kernel == KF_KERNEL_AUTO && mfma_ok && (a.p > 1 || a.m >= 7 || (a.m & 1)))
     return kf_launch_backward_mfma(h, a, stream);
   // p == 1, even m <= 10: register-resident row-split adjoint (KF_FORWARD_KERNEL=lds forces the
   // generic LDS-resident adjoint, e.g. for A/B tests)

@@ -33,7 +33,7 @@ constexpr int PMAXQ = KF_MP_P_MAX;
 
 // dynamic LDS (doubles)
 __host__ __device__ inline int bwd_mfma_lds_doubles(int p) {
-  return 16 /*EX*/ + 2 * PMAXQ /*HD, DL*/ + 2 * PMAXQ /*HB, DB*/ + p * (2 * 16 /*ZC, ZR*/ + 3 * 16 /*MC, MP, AQ*/ + 4 /*SC*/ + 16 /*ZB*/ + 64 /*YB*/) + 64 /*GL*/ + 256 /*final tile*/;
+  return 16 /*EX*/ + 2 * PMAXQ /*HD, DL*/ + 2 * PMAXQ /*HB, DB*/ + p * (2 * 16 /*ZC, ZR*/ + 3 * 16 /*MC, MP, AQ*/ + 4 /*SC*/ + 16 /*ZB*/ + 64 /*YB*/) + 64 /*GL*/ + 256 /*final tile*/ + 8 * KF_WAVE /*ACC*/;
 }
 
 // (capping the allocation at 128 VGPRs for a fourth wavefront per SIMD spills ~30 values and is
@@ -41,7 +41,7 @@ __host__ __device__ inline int bwd_mfma_lds_doubles(int p) {
 // P1: p == 1 known at compile time -- Z, M, F, v of the step stay in registers between the
 // forward recompute and the adjoint instead of going through LDS
 template <int KS, bool P1>
-__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(3))) void kf_bwd_mfma_kernel(
+__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3 ? 4 : 3))) void kf_bwd_mfma_kernel(
     const KfBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
@@ -65,6 +65,9 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(3))) vo
   double* YB = ZB + 16 * p;          // y block of 64 steps
   double* GL = YB + 64 * p;          // g_ll_obs block
   double* FT = GL + 64;              // 16 x 16 tile: transpose of X1 per step, Gs at the end
+  // per-lane accumulators that are touched once per step live in LDS, not in VGPRs (slot s of lane
+  // l at ACC[s*64 + l]: conflict-free): Gs = sum Gm (slots 0..3), sum ab' a_f' (slots 4..7)
+  double* ACC = FT + 256;
 
   const bool c_ok = c < m;
   double TA[KS], TB[KS];  // T' tile (TA[s] = T[c][4s+g]) and T tile (TB[s] = T[4s+g][c])
@@ -112,9 +115,13 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(3))) vo
     d1 = A.d ? A.d[b] : 0.0;
   }
   // adjoint state and accumulators
-  double PB[KS], TBv[KS], GS[KS];
+  double PB[KS];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) PB[s] = TBv[s] = GS[s] = 0.0;
+  for (int s = 0; s < KS; ++s) {
+    PB[s] = 0.0;
+    ACC[s * KF_WAVE + lane] = 0.0;
+    ACC[(4 + s) * KF_WAVE + lane] = 0.0;
+  }
   double4_t TBm = {0.0, 0.0, 0.0, 0.0};
   double abp = 0.0, cb = 0.0, hbv = 0.0, dbv = 0.0;
 
@@ -209,8 +216,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(3))) vo
     double part = TB[0] * abr[0];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      TBv[s] = fma(abr[s], ac, TBv[s]);  // ab' a_f'
-      GS[s] += PB[s];                    // adjoint of R Q R'
+      ACC[(4 + s) * KF_WAVE + lane] = fma(abr[s], ac, ACC[(4 + s) * KF_WAVE + lane]);  // ab' a_f'
+      ACC[s * KF_WAVE + lane] += PB[s];                                                // adjoint of R Q R'
       if (s > 0) part = fma(TB[s], abr[s], part);
     }
     double abf = col_allsum(part);  // T' ab'
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(3))) vo
     DB[c] = dbv;
   }
 #pragma unroll
-  for (int s = 0; s < KS; ++s) FT[(4 * s + g) * TILE + c] = GS[s];
+  for (int s = 0; s < KS; ++s) FT[(4 * s + g) * TILE + c] = ACC[s * KF_WAVE + lane];
   __syncthreads();
   if (g == 0 && c_ok) {
     if (A.g_a0) A.g_a0[b * (long)m + c] = abp;
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(3))) vo
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     if (!on[s]) continue;
-    if (A.g_T) A.g_T[b * (long)mm + off[s]] = fma(2.0, TBm[s], TBv[s]);
+    if (A.g_T) A.g_T[b * (long)mm + off[s]] = fma(2.0, TBm[s], ACC[(4 + s) * KF_WAVE + lane]);
     if (A.g_P0 && p > 1) A.g_P0[b * (long)mm + off[s]] = PB[s];
   }
   // R_b = Gs R (Q + Q') ;  Q_b = R' Gs R   (Gs in tile FT)
