@@ -134,7 +134,7 @@ const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* dims);
 
 /* Scratch the three entry points need for `dims` (max over them); may be 0.  Non-zero for
  * k_states too large for on-chip tiles (forward: m^2-sized covariance workspace; smoother for
- * m > ~47: 6 B m^2 doubles) and, a few bytes per draw, for the register-tile smoother
+ * m > ~47: 6 B m^2 doubles; gradient for m > ~45: 7 B m^2 + 2 B m T doubles) and, a few bytes per draw, for the register-tile smoother
  * (5 <= m <= 16: per-draw flags; without them kf_smoother uses the slower LDS kernel). */
 int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes);
 

@@ -278,7 +278,10 @@ int kf_launch_backward_lds(kf_handle* h, const KfBwdArgs& a, hipStream_t stream)
   return kf_launch_backward_lds_p0(h, a, stream);
 }
 
-int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, hipStream_t stream) {
+int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t workspace_bytes,
+                       hipStream_t stream) {
+  // tiles too large for LDS (m > ~45): workspace + MFMA-GEMM adjoint, scalar observations only
+  if (!kf_backward_lds_fits(a.m, a.p)) return kf_launch_backward_big(h, a, workspace, workspace_bytes, stream);
   // accumulator-layout adjoint (kf_backward_mfma.hip): scalar observations only, i.e. p == 1, the
   // Univariate filter, or a diagonal H asserted by the caller (then g_H carries the diagonal and
   // g_P0 the symmetric part)
@@ -360,6 +363,10 @@ extern "C" int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_
     const size_t sm = kf_smoother_mfma_workspace_bytes(dims->B);
     if (sm > *bytes) *bytes = sm;
   }
+  if (dims->m >= 1 && dims->p >= 1 && dims->T >= 1 && !kf_backward_lds_fits(dims->m, dims->p)) {
+    const size_t bw = kf_backward_big_workspace_bytes(dims->B, dims->m, dims->p, dims->T);
+    if (bw > *bytes) *bytes = bw;
+  }
   if (dims->m >= 1 && !kf_smoother_lds_fits(dims->m)) {
     const size_t sm = kf_smoother_big_workspace_bytes(dims->B, dims->m);
     if (sm > *bytes) *bytes = sm;
@@ -395,8 +402,6 @@ extern "C" int kf_filter_backward(kf_handle* h, const kf_dims* dims, const doubl
                                   const double* g_ll_obs, double* g_a0, double* g_P0, double* g_T,
                                   double* g_Z, double* g_R, double* g_H, double* g_Q, double* g_c,
                                   double* g_d, void* workspace, size_t workspace_bytes, void* stream) {
-  (void)workspace;
-  (void)workspace_bytes;
   int rc = check_dims(h, dims, true);
   if (rc) return rc;
   if (!y || !a0 || !P0 || !T || !Z || !R || !H || !Q || !pred_a || !pred_P) {
@@ -418,7 +423,7 @@ extern "C" int kf_filter_backward(kf_handle* h, const kf_dims* dims, const doubl
   a.pred_a = pred_a; a.pred_P = pred_P; a.g_logp = g_logp; a.g_ll_obs = g_ll_obs;
   a.g_a0 = g_a0; a.g_P0 = g_P0; a.g_T = g_T; a.g_Z = g_Z; a.g_R = g_R; a.g_H = g_H; a.g_Q = g_Q;
   a.g_c = g_c; a.g_d = g_d;
-  return kf_launch_backward(h, a, (hipStream_t)stream);
+  return kf_launch_backward(h, a, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, const double* R,

@@ -170,13 +170,28 @@ int kf_launch_backward_rowsplit_m4_h2(kf_handle* h, const KfBwdArgs& a, hipStrea
 int kf_launch_backward_rowsplit_m2_h1(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_backward_mfma(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 int kf_launch_backward_lds(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
-int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t workspace_bytes,
+                       hipStream_t stream);
 int kf_launch_smoother_lds(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream);
 // per-draw LDS footprint of kf_smooth_lds_kernel with all 64 lanes on one draw (kf_smoother_lds.hip)
 inline bool kf_smoother_lds_fits(int m) {
   const int M2 = (m + 1) / 2;
   return sizeof(double) * (size_t)((9 * m * m + 6 * m + 4 * M2 + 2) | 1) <= KF_LDS_BYTES_MAX;
 }
+// sub-block fp64-MFMA GEMM and transpose of kf_smoother_big.hip, shared with kf_backward_big.hip:
+// C (M x N, ldc) = epi(A (M x K, lda) * op(B)), epi 0: store, 1: E + acc, 2: E - acc; batched over B
+void kf_sb_gemm(hipStream_t st, long B, bool trans_b, int epi, const double* A, long sA, int lda, const double* Bm,
+                long sB, int ldb, const double* E, long sE, int lde, double* C, long sC, int ldc, int M, int N, int K);
+void kf_sb_transpose(hipStream_t st, long B, const double* src, long sS, double* dst, long sD, int m);
+// large-m adjoint (kf_backward_big.hip): scalar observations, HBM workspace
+inline bool kf_backward_lds_fits(int m, int p) {
+  const size_t lds = sizeof(double) * ((size_t)kf_pair_table_doubles(m) +
+                                       (size_t)((9 * m * m + 10 * p * m + 10 * p * p + 6 * m + 6 * p + 2) | 1));
+  return lds <= KF_LDS_BYTES_MAX;
+}
+size_t kf_backward_big_workspace_bytes(long B, int m, int p, int n);
+int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t workspace_bytes,
+                           hipStream_t stream);
 // register-tile smoother (kf_smoother_mfma.hip): m <= 16, needs 4 B + 64 bytes of workspace (flags)
 size_t kf_smoother_mfma_workspace_bytes(long B);
 int kf_launch_smoother_mfma(kf_handle* h, const KfSmoothArgs& a, void* workspace, size_t workspace_bytes,

@@ -277,6 +277,26 @@ void gemm(hipStream_t st, long B, const double* A, long sA, int lda, const doubl
 
 }  // namespace
 
+void kf_sb_gemm(hipStream_t st, long B, bool trans_b, int epi, const double* A, long sA, int lda, const double* Bm,
+                long sB, int ldb, const double* E, long sE, int lde, double* C, long sC, int ldc, int M, int N, int K) {
+#define KF_SB_CALL(TB_, EPI_) gemm<TB_, EPI_>(st, B, A, sA, lda, Bm, sB, ldb, E, sE, lde, C, sC, ldc, M, N, K)
+  if (trans_b) {
+    if (epi == EPI_STORE) KF_SB_CALL(true, EPI_STORE);
+    else if (epi == EPI_ADD) KF_SB_CALL(true, EPI_ADD);
+    else KF_SB_CALL(true, EPI_RSUB);
+  } else {
+    if (epi == EPI_STORE) KF_SB_CALL(false, EPI_STORE);
+    else if (epi == EPI_ADD) KF_SB_CALL(false, EPI_ADD);
+    else KF_SB_CALL(false, EPI_RSUB);
+  }
+#undef KF_SB_CALL
+}
+
+void kf_sb_transpose(hipStream_t st, long B, const double* src, long sS, double* dst, long sD, int m) {
+  const unsigned tb = (unsigned)((m + 31) / 32);
+  hipLaunchKernelGGL(sb_transpose_kernel, dim3(tb, tb, (unsigned)B), dim3(256), 0, st, src, sS, dst, sD, m);
+}
+
 size_t kf_smoother_big_workspace_bytes(long B, int m) {
   const long mm = (long)m * m;
   const int nblk = (m + NB - 1) / NB;

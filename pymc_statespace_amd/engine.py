@@ -261,11 +261,12 @@ class KalmanEngine:
         if want_cd:
             g["c"] = torch.empty(B, m, device=dev, dtype=f64)
             g["d"] = torch.empty(B, p, device=dev, dtype=f64)
+        ws, ws_bytes = self._workspace(dims)  # large m only (kf_backward_big.hip)
         rc = self.lib.kf_filter_backward(
             self._h, C.byref(dims), _ptr(y), _ptr(a0), _ptr(P0), _ptr(T), _ptr(Z), _ptr(R), _ptr(H),
             _ptr(Q), _ptr(c), _ptr(d), _ptr(pa), _ptr(pP), _ptr(g_logp), _ptr(g_ll),
             _ptr(g["a0"]), _ptr(g["P0"]), _ptr(g["T"]), _ptr(g["Z"]), _ptr(g["R"]), _ptr(g["H"]),
-            _ptr(g["Q"]), _ptr(g.get("c")), _ptr(g.get("d")), None, 0, self._stream())
+            _ptr(g["Q"]), _ptr(g.get("c")), _ptr(g.get("d")), _ptr(ws), ws_bytes, self._stream())
         self._check(rc, "kf_filter_backward")
         return g
 

@@ -32,3 +32,14 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"smoother B={B} n={ns} m=367: {dt*1e3:.1f} ms, {dt/(ns-1)*1e3:.3f} ms/step, "
       f"~{B*(ns-1)*10.3*367**3/dt/1e12:.2f} TFLOP/s (10.3 m^3 flop per draw-step)")
+# gradient on the same share (needs the predicted tapes)
+rg = eng.forward(*ds, store_ll_obs=False, store_filtered=False)
+ones = torch.ones(B, device="cuda", dtype=torch.float64)
+fn = lambda: eng.backward(*ds, predicted_states=rg.predicted_states, predicted_covs=rg.predicted_covs, g_logp=ones)
+fn(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+fn()
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"gradient B={B} n={ns} m=367: {dt*1e3:.1f} ms, {dt/ns*1e3:.3f} ms/step, "
+      f"~{B*ns*6.0*367**3/dt/1e12:.2f} TFLOP/s (3 GEMMs = 6 m^3 flop per draw-step)")

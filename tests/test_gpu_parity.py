@@ -608,14 +608,61 @@ def test_big_m_needs_workspace_and_says_so(eng):
     assert b"workspace" in eng.lib.kf_last_error(eng._h)
 
 
-def test_big_m_gradient_is_declared_unsupported(eng):
-    from pymc_statespace_amd import KalmanError
+BIG_GRAD_CASES = {
+    "dense_p1m64": (lambda: W.random_dense(3, 9, 1, 64, 8, seed=12), "standard"),
+    "dense_p1m70_single": (lambda: W.random_dense(2, 7, 1, 70, 5, seed=15), "single"),
+    "dense_p2m70": (lambda: W.random_dense(2, 7, 2, 70, 5, seed=13), "standard"),
+    "dense_p3m66_univariate": (lambda: W.random_dense(2, 6, 3, 66, 4, seed=16), "univariate"),
+    "c5_daily_seasonal_m367": (lambda: W.daily_seasonal(B=2, n=5), "standard"),
+}
 
-    w = W.random_dense(1, 4, 1, 150, 2, seed=9)
+
+@pytest.mark.parametrize("case", sorted(BIG_GRAD_CASES))
+def test_big_m_gradient_matches_autograd(eng, case):
+    """kf_backward_big.hip: HBM workspace, three fp64-MFMA GEMMs per step, scalar observations."""
+    from oracle import kalman_torch as kt
+
+    mk, ft = BIG_GRAD_CASES[case]
+    w = mk()
+    B, n, m, p = w["B"], w["n"], w["m"], w["p"]
+    y = w["y"].copy()
+    y[2] = np.nan
+    if p > 1:
+        y[4, 0] = np.nan
+    rng = np.random.default_rng(3)
+    g_logp = rng.standard_normal(B)
+    g_ll = rng.standard_normal((B, n))
+    c = 0.1 * rng.standard_normal((B, m))
+    d = 0.1 * rng.standard_normal((B, p))
+    _, _, gt = kt.logp_and_grads(*_args(w, y), c=c, d=d, g_logp=g_logp, g_ll_obs=g_ll, filter_type=ft)
+    res = eng.forward(*_args(w, y), c=c, d=d, filter_type=ft)
+    g = eng.backward(*_args(w, y), c=c, d=d, predicted_states=res.predicted_states,
+                     predicted_covs=res.predicted_covs, g_logp=g_logp, g_ll_obs=g_ll,
+                     filter_type=ft, want_cd=True, h_diagonal=True)
+    for k in kt.NAMES:
+        a, b = g[k].cpu().numpy(), gt[k]
+        if k == "H" and p > 1:
+            assert np.all(a[:, ~np.eye(p, dtype=bool)] == 0.0)
+            a, b = np.diagonal(a, axis1=-2, axis2=-1), np.diagonal(b, axis1=-2, axis2=-1)
+        elif k in ("P0", "Q") and (p > 1 or ft == "univariate"):
+            a, b = a + np.swapaxes(a, -1, -2), b + np.swapaxes(b, -1, -2)
+        assert np.max(np.abs(a - b)) / (1.0 + np.max(np.abs(b))) < 1e-9, (case, k)
+
+
+def test_big_m_gradient_needs_scalar_observations_and_workspace(eng):
+    import ctypes as C
+
+    from pymc_statespace_amd import KalmanError, _lib
+
+    w = W.random_dense(1, 4, 2, 70, 2, seed=9)
     res = eng.forward(*_args(w))
-    with pytest.raises(KalmanError, match="LDS"):
+    with pytest.raises(KalmanError, match="scalar observations"):
         eng.backward(*_args(w), predicted_states=res.predicted_states,
                      predicted_covs=res.predicted_covs, g_logp=np.ones(1))
+    dims = _lib.KfDims(1, 4, 2, 70, 2, 0, _lib.KF_FLAG_H_DIAGONAL)
+    nbytes = C.c_size_t(0)
+    assert eng.lib.kf_workspace_bytes(eng._h, C.byref(dims), C.byref(nbytes)) == 0
+    assert nbytes.value >= 8 * 7 * 70 * 70
 
 
 BIG_SMOOTH_CASES = {
