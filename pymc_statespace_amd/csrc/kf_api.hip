@@ -364,7 +364,7 @@ extern "C" int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_
     if (sm > *bytes) *bytes = sm;
   }
   if (dims->m >= 1 && dims->p >= 1 && dims->T >= 1 && !kf_backward_lds_fits(dims->m, dims->p)) {
-    const size_t bw = kf_backward_big_workspace_bytes(dims->B, dims->m, dims->p, dims->T);
+    const size_t bw = kf_backward_big_workspace_bytes(dims->B, dims->m, dims->p, dims->T, dims->r);
     if (bw > *bytes) *bytes = bw;
   }
   if (dims->m >= 1 && !kf_smoother_lds_fits(dims->m)) {

@@ -49,6 +49,7 @@ struct BbPtrs {
   double* hb;    // [B][p]
   double* db;    // [B][p]
   double* cb;    // [B][m]
+  double* GR;    // [B][m][r]  Gs R
 };
 
 // ---- forward recompute of step t + the O(m^2) bookkeeping of the predict adjoint ------------------------
@@ -251,45 +252,47 @@ __global__ __launch_bounds__(256) void bb_finish_kernel(const KfBwdArgs A, const
   const double* GS = W.GS + b * mm;
   const double* gR = A.R + b * (long)m * r;
   const double* gQ = A.Q + b * (long)r * r;
-  // R_b = Gs R (Q + Q') ; Q_b = R' Gs R
+  // GR = Gs R (Gs symmetric: column sums are coalesced) ; R_b = GR (Q + Q') ; Q_b = R' GR
+  double* GR = W.GR + b * (long)m * r;
+  for (int e = tid; e < m * r; e += 256) {
+    const int k = e / m, i = e - k * m;  // consecutive threads -> consecutive columns of Gs
+    double s = 0.0;
+    for (int j = 0; j < m; ++j) s = fma(GS[(long)j * m + i], gR[j * r + k], s);
+    GR[i * r + k] = s;
+  }
+  __syncthreads();
   if (A.g_R)
     for (int e = tid; e < m * r; e += 256) {
       const int i = e / r, l = e - i * r;
       double sacc = 0.0;
-      for (int k = 0; k < r; ++k) {
-        double grk = 0.0;
-        for (int j = 0; j < m; ++j) grk = fma(GS[(long)i * m + j], gR[j * r + k], grk);
-        sacc = fma(grk, gQ[k * r + l] + gQ[l * r + k], sacc);
-      }
+      for (int k = 0; k < r; ++k) sacc = fma(GR[i * r + k], gQ[k * r + l] + gQ[l * r + k], sacc);
       A.g_R[b * (long)m * r + e] = sacc;
     }
   if (A.g_Q)
     for (int e = tid; e < r * r; e += 256) {
       const int k = e / r, l = e - k * r;
       double sacc = 0.0;
-      for (int i = 0; i < m; ++i) {
-        double grl = 0.0;
-        for (int j = 0; j < m; ++j) grl = fma(GS[(long)i * m + j], gR[j * r + l], grl);
-        sacc = fma(gR[i * r + k], grl, sacc);
-      }
+      for (int i = 0; i < m; ++i) sacc = fma(gR[i * r + k], GR[i * r + l], sacc);
       A.g_Q[b * (long)r * r + e] = sacc;
     }
 }
 
-inline size_t bb_doubles(long B, int m, int p, int n) {
+inline size_t bb_doubles(long B, int m, int p, int n, int r) {
   const long mm = (long)m * m;
-  return (size_t)B * (size_t)(7 * mm + 2L * m * n + 3L * p * m + 4L * p + 3L * m + 2L * p);
+  return (size_t)B * (size_t)(7 * mm + 2L * m * n + 3L * p * m + 4L * p + 3L * m + 2L * p + (long)m * r);
 }
 
 }  // namespace
 
-size_t kf_backward_big_workspace_bytes(long B, int m, int p, int n) { return sizeof(double) * bb_doubles(B, m, p, n) + 256; }
+size_t kf_backward_big_workspace_bytes(long B, int m, int p, int n, int r) {
+  return sizeof(double) * bb_doubles(B, m, p, n, r) + 256;
+}
 
 int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t st) {
   const long B = a.B;
   const int m = a.m, p = a.p, n = a.T;
   const long mm = (long)m * m;
-  const size_t need = kf_backward_big_workspace_bytes(B, m, p, n);
+  const size_t need = kf_backward_big_workspace_bytes(B, m, p, n, a.r);
   if (!workspace || workspace_bytes < need) {
     KF_SET_ERR(h, "backward(big): m=%d needs a workspace of %zu bytes (kf_workspace_bytes), got %zu", m, need,
                workspace_bytes);
@@ -305,7 +308,7 @@ int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, si
     return KF_ERR_UNSUPPORTED;
   }
   double* ws = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 63) & ~(uintptr_t)63);
-  KF_HIP_CHECK(h, hipMemsetAsync(ws, 0, sizeof(double) * bb_doubles(B, m, p, n), st));
+  KF_HIP_CHECK(h, hipMemsetAsync(ws, 0, sizeof(double) * bb_doubles(B, m, p, n, a.r), st));
   BbPtrs W;
   double* q = ws;
   W.Pc = q; q += B * mm;
@@ -326,6 +329,7 @@ int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, si
   W.cb = q; q += B * (long)m;
   W.hb = q; q += B * (long)p;
   W.db = q; q += B * (long)p;
+  W.GR = q; q += B * (long)m * a.r;
 
   const size_t sh_f = sizeof(double) * (4 * m + NT / KF_WAVE);
   const size_t sh_a = sizeof(double) * (6 * m + NT / KF_WAVE);

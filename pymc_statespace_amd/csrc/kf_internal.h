@@ -189,7 +189,7 @@ inline bool kf_backward_lds_fits(int m, int p) {
                                        (size_t)((9 * m * m + 10 * p * m + 10 * p * p + 6 * m + 6 * p + 2) | 1));
   return lds <= KF_LDS_BYTES_MAX;
 }
-size_t kf_backward_big_workspace_bytes(long B, int m, int p, int n);
+size_t kf_backward_big_workspace_bytes(long B, int m, int p, int n, int r);
 int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t workspace_bytes,
                            hipStream_t stream);
 // register-tile smoother (kf_smoother_mfma.hip): m <= 16, needs 4 B + 64 bytes of workspace (flags)
