@@ -12,6 +12,7 @@
 // (m <= 4: 8..128 contiguous bytes per draw-step; consecutive time steps are adjacent in the
 // draw-major tapes, so plain write-back stores let L2 assemble full lines).
 #include "kf_internal.h"
+#include "kf_tile.h"
 
 #ifndef KF_LANE_M
 #error "compile with -DKF_LANE_M=<k_states>"
@@ -78,6 +79,10 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
   double logp = 0.0;
   int info = 0;
   double ynext = ybase[0];
+  // without the per-step tape the log is taken once per 16 steps: mantissa product, exponent sum
+  const bool want_ll = A.ll_obs != nullptr;  // wave-uniform
+  double mant = 1.0, qsum = 0.0;
+  int ex = 0, cnt = 0;
   for (int t = 0; t < n; ++t) {
     const double yv = ynext;
     if (t + 1 < n) ynext = ybase[t + 1];
@@ -102,10 +107,29 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
       F = 1.0;
     }
     if (!(F > 0.0) && info == 0 && !degenerate) info = ((t + 1) << 8) | 1;
-    const double invF = degenerate ? 0.0 : 1.0 / F;
+    const double invF = degenerate ? 0.0 : fast_rcp(F);
     if (degenerate) v = 0.0;
-    const double ll = degenerate ? 0.0 : -0.5 * (KF_LOG_2PI + log(F) + v * v * invF);
-    logp += ll;
+    double ll = 0.0;
+    if (want_ll) {
+      ll = degenerate ? 0.0 : -0.5 * (KF_LOG_2PI + log(F) + v * v * invF);
+      logp += ll;
+    } else {
+      if (!degenerate) {
+        int e2;
+        const double fm = frexp(F, &e2);
+        mant *= (F > 0.0) ? fm : __builtin_nan("");  // not PD: NaN, as log(F) would give
+        ex += e2;
+        qsum = fma(v * v, invF, qsum);
+        ++cnt;
+      }
+      if ((t & 15) == 15 || t == n - 1) {
+        logp += -0.5 * ((double)cnt * KF_LOG_2PI + log(mant) + 0.69314718055994530942 * (double)ex + qsum);
+        mant = 1.0;
+        qsum = 0.0;
+        ex = 0;
+        cnt = 0;
+      }
+    }
     double K[M], af[M], Pf[M][M];
 #pragma unroll
     for (int i = 0; i < M; ++i) {

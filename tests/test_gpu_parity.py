@@ -727,9 +727,13 @@ def test_lane_kernels_match_oracle(eng, m, ft):
     eng.set_forward_kernel("lane")
     try:
         out = _np(eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact"))
+        # without the ll_obs tape the kernel batches its logarithms (mantissa products)
+        lp_only = eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact", store_ll_obs=False,
+                              store_filtered=False, store_predicted=False).logp.cpu().numpy()
     finally:
         eng.set_forward_kernel("auto")
     assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8
+    assert np.max(np.abs(lp_only - ref["logp"])) < 1e-8
     for k in TAPES:
         assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=f"m={m} {k}")
     assert not out["info"].any()
