@@ -5,19 +5,25 @@
 // Maths = kf_backward_mfma.hip's (scalar-observation rank-one adjoints, symmetric adjoint tile;
 // derivation: oracle/kalman_adjoint_numpy.py); here every m x m matrix of a draw lives in a
 // caller-provided HBM workspace and a time step is a short sequence of launches:
-//   bb_fwd_step   per draw: recompute the p scalar updates from the predicted tape (M_q = P^q z_q
-//                 column-wise, F_q, v_q, P^{q+1} = P^q - M_q M_q'/F_q), a_f; Gs += Pb;
-//                 ab_f = T' ab';  rows of the rank-one part of T_b are parked for one final GEMM
-//   sb_gemm x3    X1 = Pb T ;  Sb = X1' T (X1' from a transpose kernel) ;  Tb_m += X1 P_f
-//   bb_adj_step   per draw, observations backwards: s = Sb M, beta, gamma, F_b, v_b, u;
-//                 P^q rebuilt in the pass that also forms P^q u;  Sb += F_b z z' + (u z' + z u')/2
+//   bb_colmatvec    out = Mat' x for a chunk of 64 columns (coalesced; Mat symmetric -> Mat x):
+//                   ab_f = T' ab',  M_q = P^q z_q,  s = Sb M_q
+//   bb_fwd_update   rows chunk of P^{q+1} = P^q - M_q M_q'/F_q ; every workgroup recomputes F_q, v_q
+//                   (two length-m dot products) instead of a cross-workgroup reduction; workgroup 0
+//                   keeps the vectors (a^q, a_f, the parked rows of the rank-one part of T_b); Gs += Pb
+//   sb_gemm x3      X1 = Pb T ;  Sb = X1' T (X1' from a transpose kernel) ;  Tb_m += X1 P_f
+//   bb_adj_update   columns chunk, observations backwards: beta, gamma, F_b, v_b, u recomputed per
+//                   workgroup; P^q rebuilt in the pass that also forms P^q u;
+//                   Sb += F_b z z' + (u z' + z u')/2
 // GEMMs: the fp64-MFMA sub-block kernel of kf_smoother_big.hip (declared in kf_internal.h).
 // g_P0: exact for p == 1, symmetric part for p > 1; g_H: diagonal only (see include/kf.h).
 #include "kf_internal.h"
 
 namespace {
 
-constexpr int NT = 512;
+constexpr int NT = 256;        // 64 columns x 4 row groups
+constexpr int CW = 64;         // columns per workgroup
+constexpr int RG = NT / CW;    // row groups
+constexpr int RCH = 16;        // rows per workgroup in the row-chunked elementwise kernel
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
   // red: NT/64 doubles of shared memory
@@ -40,11 +46,13 @@ struct BbPtrs {
   double* GS;    // [B][mm] sum of Gm
   double* AbT;   // [B][m][n] ab'_t as columns
   double* Af;    // [B][n][m] a_f,t as rows
-  double* MQ;    // [B][p][m]
-  double* AQ;    // [B][p][m]
-  double* SCq;   // [B][p][4]  F, v, 1/F
+  double* MQ;    // [B][p][m]      M_q
+  double* AQ;    // [B][p+1][m]    a^q (slot 0 unused: a^0 is the predicted tape), a^p = a_f
+  double* SCq;   // [B][p][4]      F, v, 1/F
+  double* SV;    // [B][m]         s = Sb M
   double* abp;   // [B][m] adjoint of the predicted state of step t+1
-  double* abf;   // [B][m]
+  double* abfA;  // [B][m] ab_f ping
+  double* abfB;  // [B][m] ab_f pong
   double* zb;    // [B][p][m]
   double* hb;    // [B][p]
   double* db;    // [B][p]
@@ -52,176 +60,169 @@ struct BbPtrs {
   double* GR;    // [B][m][r]  Gs R
 };
 
-// ---- forward recompute of step t + the O(m^2) bookkeeping of the predict adjoint ------------------------
-__global__ __launch_bounds__(NT) void bb_fwd_step_kernel(const KfBwdArgs A, const BbPtrs W, int t) {
+// out_j = sum_i Mat[i][j] x_i for one chunk of 64 columns: coalesced reads of a row-major matrix;
+// for a symmetric Mat this is Mat x.  grid (ceil(m/64), B).
+__global__ __launch_bounds__(NT) void bb_colmatvec_kernel(const double* Mat, long sM, const double* x, long sX,
+                                                          double* out, long sO, int m) {
+  extern __shared__ double sh[];  // x (m) | partial sums RG x CW
+  double* xs = sh;
+  double* part = sh + m;
+  const int tid = threadIdx.x;
+  const long b = blockIdx.y;
+  const int col = tid & (CW - 1), rg = tid / CW;
+  const int j = blockIdx.x * CW + col;
+  for (int i = tid; i < m; i += NT) xs[i] = x[b * sX + i];
+  __syncthreads();
+  double s = 0.0;
+  if (j < m) {
+    const double* Mb = Mat + b * sM + j;
+    for (int i = rg; i < m; i += RG) s = fma(Mb[(long)i * m], xs[i], s);
+  }
+  part[rg * CW + col] = s;
+  __syncthreads();
+  if (rg == 0 && j < m) out[b * sO + j] = (part[col] + part[CW + col]) + (part[2 * CW + col] + part[3 * CW + col]);
+}
+
+// ---- forward recompute, observation q of step t: P^{q+1} = P^q - M M'/F for a chunk of rows -------------
+// grid (ceil(m/RCH), B).  Every workgroup recomputes the scalars (two dot products of length m);
+// workgroup 0 also does the O(m) vector bookkeeping.
+__global__ __launch_bounds__(NT) void bb_fwd_update_kernel(const KfBwdArgs A, const BbPtrs W, int t, int q) {
   extern __shared__ double sh[];
   const int m = A.m, p = A.p, n = A.T;
-  double* av = sh;          // m  state
-  double* Ms = av + m;      // m  M_q
-  double* zs = Ms + m;      // m  Z_q
-  double* abs_ = zs + m;    // m  ab'
-  double* red = abs_ + m;   // NT/64
+  double* Ms = sh;        // m
+  double* red = Ms + m;   // NT/64
   const int tid = threadIdx.x;
-  const long b = blockIdx.x;
+  const long b = blockIdx.y;
   const long mm = (long)m * m;
-  const double* Ppred = A.pred_P + (b * (long)(n + 1) + t) * mm;
+  const double* src = (q == 0) ? A.pred_P + (b * (long)(n + 1) + t) * mm : W.Pc + b * mm;
+  const double* acur = (q == 0) ? A.pred_a + (b * (long)(n + 1) + t) * m : W.AQ + (b * (p + 1) + q) * (long)m;
+  const double* zq = A.Z + (b * p + q) * (long)m;
+  const double* Mq = W.MQ + (b * p + q) * (long)m;
   double* Pc = W.Pc + b * mm;
-  const bool univariate = A.filter == KF_FILTER_UNIVARIATE;
-  const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;
-  const double* yrow = A.y + (((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n : 0L) + t) * p;
-
+  double fpart = 0.0, apart = 0.0;
   for (int j = tid; j < m; j += NT) {
-    av[j] = A.pred_a[(b * (long)(n + 1) + t) * m + j];
-    abs_[j] = W.abp[b * m + j];
+    const double mj = Mq[j], zj = zq[j];
+    Ms[j] = mj;
+    fpart = fma(zj, mj, fpart);
+    apart = fma(zj, acur[j], apart);
   }
-  __syncthreads();
-  for (int q = 0; q < p; ++q) {
-    const double* src = (q == 0) ? Ppred : Pc;
-    for (int j = tid; j < m; j += NT) zs[j] = A.Z[(b * p + q) * (long)m + j];
-    __syncthreads();
-    // M_j = sum_i P[i][j] z_i  (P symmetric: column sums are coalesced)
+  const double F = A.H[(b * p + q) * (long)p + q] + block_sum(fpart, red);
+  const double za = block_sum(apart, red);
+  const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;
+  const double yq = A.y[(((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n : 0L) + t) * p + q];
+  const bool obs = !(yq != yq);
+  const bool degenerate = !obs || (A.filter == KF_FILTER_UNIVARIATE && F == 0.0);
+  const double invF = degenerate ? 0.0 : 1.0 / F;
+  const double v = degenerate ? 0.0 : (yq + dsign * (A.d ? A.d[b * p + q] : 0.0)) - za;
+  // rows [r0, r1) of P^{q+1}
+  const int r0 = blockIdx.x * RCH, r1 = (r0 + RCH < m) ? r0 + RCH : m;
+  for (long e = (long)r0 * m + tid; e < (long)r1 * m; e += NT) {
+    const int i = (int)(e / m), j = (int)(e - (long)i * m);
+    Pc[e] = fma(-(Ms[i] * Ms[j]), invF, src[e]);
+  }
+  if (q == 0) {  // Gs += Pb, once per step
+    const double* PB = W.PB + b * mm;
+    double* GS = W.GS + b * mm;
+    for (long e = (long)r0 * m + tid; e < (long)r1 * m; e += NT) GS[e] += PB[e];
+  }
+  if (blockIdx.x == 0) {
+    double* anext = W.AQ + (b * (p + 1) + q + 1) * (long)m;
     for (int j = tid; j < m; j += NT) {
-      double s = 0.0;
-      for (int i = 0; i < m; ++i) s = fma(src[(long)i * m + j], zs[i], s);
-      Ms[j] = s;
-    }
-    __syncthreads();
-    double fpart = 0.0, apart = 0.0;
-    for (int j = tid; j < m; j += NT) {
-      fpart = fma(zs[j], Ms[j], fpart);
-      apart = fma(zs[j], av[j], apart);
-    }
-    const double F = A.H[(b * p + q) * (long)p + q] + block_sum(fpart, red);
-    const double za = block_sum(apart, red);
-    const double yq = yrow[q];
-    const bool obs = !(yq != yq);
-    const bool degenerate = !obs || (univariate && F == 0.0);
-    const double invF = degenerate ? 0.0 : 1.0 / F;
-    const double v = degenerate ? 0.0 : (yq + dsign * (A.d ? A.d[b * p + q] : 0.0)) - za;
-    for (int j = tid; j < m; j += NT) {
-      W.MQ[(b * p + q) * (long)m + j] = Ms[j];
-      W.AQ[(b * p + q) * (long)m + j] = av[j];
+      const double an = fma(Ms[j] * invF, v, acur[j]);
+      anext[j] = an;
+      if (q == p - 1) {  // a_f and ab' parked for the final GEMM  sum_t ab'_t a_f,t' ;  c_b += ab'
+        const double ab = W.abp[b * m + j];
+        W.Af[(b * n + t) * (long)m + j] = an;
+        W.AbT[(b * m + j) * (long)n + t] = ab;
+        W.cb[b * m + j] += ab;
+      }
     }
     if (tid == 0) {
       W.SCq[(b * p + q) * 4] = F;
       W.SCq[(b * p + q) * 4 + 1] = v;
       W.SCq[(b * p + q) * 4 + 2] = invF;
     }
-    // P^{q+1} = P^q - M M'/F
-    for (long e = tid; e < mm; e += NT) {
-      const int i = (int)(e / m), j = (int)(e - (long)i * m);
-      Pc[e] = fma(-(Ms[i] * Ms[j]), invF, src[e]);
-    }
-    __syncthreads();
-    for (int j = tid; j < m; j += NT) av[j] = fma(Ms[j] * invF, v, av[j]);
-    __syncthreads();
-  }
-  // a_f and ab' parked for the final GEMM  sum_t ab'_t a_f,t' ;  c_b += ab'
-  for (int j = tid; j < m; j += NT) {
-    W.Af[(b * n + t) * (long)m + j] = av[j];
-    W.AbT[(b * m + j) * (long)n + t] = abs_[j];
-    W.cb[b * m + j] += abs_[j];
-  }
-  // Gs += Pb ;  ab_f = T' ab'
-  const double* PB = W.PB + b * mm;
-  double* GS = W.GS + b * mm;
-  for (long e = tid; e < mm; e += NT) GS[e] += PB[e];
-  const double* gT = A.Tm + b * mm;
-  for (int j = tid; j < m; j += NT) {
-    double s = 0.0;
-    for (int i = 0; i < m; ++i) s = fma(gT[(long)i * m + j], abs_[i], s);
-    W.abf[b * m + j] = s;
   }
 }
 
-// ---- adjoint of the p scalar updates of step t (Sb = T' Gm T is in W.SB) --------------------------------------
-__global__ __launch_bounds__(NT) void bb_adj_step_kernel(const KfBwdArgs A, const BbPtrs W, int t) {
+// ---- adjoint of observation q of step t for a chunk of 64 columns (s = Sb M is in W.SV) ----------------------
+// grid (ceil(m/64), B).  abf_in / abf_out: adjoint of a^{q+1} / a^q (ping-pong: other workgroups
+// still read abf_in).
+__global__ __launch_bounds__(NT) void bb_adj_update_kernel(const KfBwdArgs A, const BbPtrs W, int t, int q,
+                                                           const double* abf_in, double* abf_out) {
   extern __shared__ double sh[];
   const int m = A.m, p = A.p, n = A.T;
-  double* Ms = sh;         // m
-  double* zs = Ms + m;     // m
-  double* sv = zs + m;     // m  s = Sb M
-  double* uv = sv + m;     // m  u
-  double* af = uv + m;     // m  ab_f
-  double* m1 = af + m;     // m  m1b (exact g_P0 only)
-  double* red = m1 + m;
+  double* Ms = sh;          // m
+  double* zs = Ms + m;      // m
+  double* uv = zs + m;      // m  u = m1b + m2b
+  double* m1 = uv + m;      // m  m1b (exact g_P0 only)
+  double* part = m1 + m;    // RG x CW
+  double* red = part + NT;  // NT/64
   const int tid = threadIdx.x;
-  const long b = blockIdx.x;
+  const long b = blockIdx.y;
   const long mm = (long)m * m;
+  const int col = tid & (CW - 1), rg = tid / CW;
+  const int j = blockIdx.x * CW + col;
   double* Pc = W.Pc + b * mm;
   double* SB = W.SB + b * mm;
+  const double* sv = W.SV + b * (long)m;
+  const double* af = abf_in + b * (long)m;
   const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;
   const double gt = (A.g_logp ? A.g_logp[b] : 0.0) + (A.g_ll_obs ? A.g_ll_obs[b * (long)n + t] : 0.0);
-  for (int j = tid; j < m; j += NT) af[j] = W.abf[b * m + j];
-  __syncthreads();
-  for (int q = p - 1; q >= 0; --q) {
-    for (int j = tid; j < m; j += NT) {
-      Ms[j] = W.MQ[(b * p + q) * (long)m + j];
-      zs[j] = A.Z[(b * p + q) * (long)m + j];
-    }
-    const double v = W.SCq[(b * p + q) * 4 + 1], invF = W.SCq[(b * p + q) * 4 + 2];
-    __syncthreads();
-    // s_j = sum_i Sb[i][j] M_i  (Sb symmetric)
-    for (int j = tid; j < m; j += NT) {
-      double s = 0.0;
-      for (int i = 0; i < m; ++i) s = fma(SB[(long)i * m + j], Ms[i], s);
-      sv[j] = s;
-    }
-    __syncthreads();
-    double bpart = 0.0, gpart = 0.0;
-    for (int j = tid; j < m; j += NT) {
-      bpart = fma(Ms[j], af[j], bpart);
-      gpart = fma(Ms[j], sv[j], gpart);
-    }
-    const double beta = block_sum(bpart, red);
-    const double gamma = block_sum(gpart, red);
-    const double Fb = (gamma - beta * v) * invF * invF - 0.5 * gt * (invF - v * v * invF * invF);
-    const double vb = (beta - gt * v) * invF;
-    for (int j = tid; j < m; j += NT) {
-      uv[j] = (af[j] * v - 2.0 * sv[j]) * invF;
-      m1[j] = (af[j] * v - sv[j]) * invF;
-    }
-    __syncthreads();
-    // P^q = P^{q+1} + M M'/F, and in the same pass  pdot_j = sum_i P^q[i][j] u_i
-    for (int j = tid; j < m; j += NT) {
-      double s = 0.0;
-      const double mj = Ms[j] * invF;
-      for (int i = 0; i < m; ++i) {
-        const double pv = fma(Ms[i], mj, Pc[(long)i * m + j]);
-        Pc[(long)i * m + j] = pv;
-        s = fma(pv, uv[i], s);
-      }
-      const double aq = W.AQ[(b * p + q) * (long)m + j];
-      W.zb[(b * p + q) * (long)m + j] += fma(-aq, vb, fma(2.0 * Fb, Ms[j], s));
-    }
-    // exact entrywise g_P0 (p == 1): Sb + (Fb z + m1b) z' - z s'/F
-    if (p == 1 && t == 0 && A.g_P0) {
-      for (long e = tid; e < mm; e += NT) {
-        const int i = (int)(e / m), j = (int)(e - (long)i * m);
-        double gp = SB[e];
-        gp = fma(fma(Fb, zs[i], m1[i]), zs[j], gp);
-        gp = fma(-zs[i] * invF, sv[j], gp);
-        A.g_P0[b * mm + e] = gp;
-      }
-    }
-    // symmetrised adjoint of P^q ; adjoint of a^q
-    for (long e = tid; e < mm; e += NT) {
-      const int i = (int)(e / m), j = (int)(e - (long)i * m);
-      double sb = SB[e];
-      sb = fma(Fb * zs[i], zs[j], sb);
-      sb = fma(0.5 * uv[i], zs[j], sb);
-      sb = fma(0.5 * zs[i], uv[j], sb);
-      SB[e] = sb;
-    }
-    __syncthreads();
-    for (int j = tid; j < m; j += NT) af[j] = fma(-zs[j], vb, af[j]);
-    if (tid == 0) {
-      W.hb[b * p + q] += Fb;
-      W.db[b * p + q] += dsign * vb;
-    }
-    __syncthreads();
+  const double v = W.SCq[(b * p + q) * 4 + 1], invF = W.SCq[(b * p + q) * 4 + 2];
+  double bpart = 0.0, gpart = 0.0;
+  for (int i = tid; i < m; i += NT) {
+    const double mi = W.MQ[(b * p + q) * (long)m + i];
+    Ms[i] = mi;
+    zs[i] = A.Z[(b * p + q) * (long)m + i];
+    uv[i] = (af[i] * v - 2.0 * sv[i]) * invF;
+    m1[i] = (af[i] * v - sv[i]) * invF;
+    bpart = fma(mi, af[i], bpart);
+    gpart = fma(mi, sv[i], gpart);
   }
-  for (int j = tid; j < m; j += NT) W.abp[b * m + j] = af[j];
+  const double beta = block_sum(bpart, red);
+  const double gamma = block_sum(gpart, red);
+  const double Fb = (gamma - beta * v) * invF * invF - 0.5 * gt * (invF - v * v * invF * invF);
+  const double vb = (beta - gt * v) * invF;
+  // P^q = P^{q+1} + M M'/F for this chunk's columns, and pdot_j = sum_i P^q[i][j] u_i in the same pass
+  double s = 0.0;
+  if (j < m) {
+    const double mj = Ms[j] * invF;
+    for (int i = rg; i < m; i += RG) {
+      const double pv = fma(Ms[i], mj, Pc[(long)i * m + j]);
+      Pc[(long)i * m + j] = pv;
+      s = fma(pv, uv[i], s);
+    }
+  }
+  part[rg * CW + col] = s;
+  __syncthreads();
+  if (rg == 0 && j < m) {
+    const double pdot = (part[col] + part[CW + col]) + (part[2 * CW + col] + part[3 * CW + col]);
+    const double aq = (q == 0) ? A.pred_a[(b * (long)(n + 1) + t) * m + j] : W.AQ[(b * (p + 1) + q) * (long)m + j];
+    W.zb[(b * p + q) * (long)m + j] += fma(-aq, vb, fma(2.0 * Fb, Ms[j], pdot));
+    abf_out[b * (long)m + j] = fma(-zs[j], vb, af[j]);
+  }
+  if (j < m) {
+    const double zj = zs[j], uj = uv[j], sj = sv[j];
+    const bool exact_p0 = (p == 1 && t == 0 && A.g_P0);
+    for (int i = rg; i < m; i += RG) {
+      const double sb0 = SB[(long)i * m + j];
+      if (exact_p0) {  // entrywise g_P0: Sb + (Fb z + m1b) z' - z s'/F
+        double gp = fma(fma(Fb, zs[i], m1[i]), zj, sb0);
+        gp = fma(-zs[i] * invF, sj, gp);
+        A.g_P0[b * mm + (long)i * m + j] = gp;
+      }
+      // symmetrised adjoint of P^q
+      double sb = fma(Fb * zs[i], zj, sb0);
+      sb = fma(0.5 * uv[i], zj, sb);
+      sb = fma(0.5 * zs[i], uj, sb);
+      SB[(long)i * m + j] = sb;
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    W.hb[b * p + q] += Fb;
+    W.db[b * p + q] += dsign * vb;
+  }
 }
 
 __global__ __launch_bounds__(256) void bb_scale_kernel(double* X, long count, double f) {
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void bb_finish_kernel(const KfBwdArgs A, const
 
 inline size_t bb_doubles(long B, int m, int p, int n, int r) {
   const long mm = (long)m * m;
-  return (size_t)B * (size_t)(7 * mm + 2L * m * n + 3L * p * m + 4L * p + 3L * m + 2L * p + (long)m * r);
+  return (size_t)B * (size_t)(7 * mm + 2L * m * n + (3L * p + 1) * m + 4L * p + 5L * m + 2L * p + (long)m * r);
 }
 
 }  // namespace
@@ -321,32 +322,54 @@ int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, si
   W.AbT = q; q += B * (long)m * n;
   W.Af = q; q += B * (long)n * m;
   W.MQ = q; q += B * (long)p * m;
-  W.AQ = q; q += B * (long)p * m;
+  W.AQ = q; q += B * (long)(p + 1) * m;
   W.zb = q; q += B * (long)p * m;
   W.SCq = q; q += B * 4L * p;
+  W.SV = q; q += B * (long)m;
   W.abp = q; q += B * (long)m;
-  W.abf = q; q += B * (long)m;
+  W.abfA = q; q += B * (long)m;
+  W.abfB = q; q += B * (long)m;
   W.cb = q; q += B * (long)m;
   W.hb = q; q += B * (long)p;
   W.db = q; q += B * (long)p;
   W.GR = q; q += B * (long)m * a.r;
 
-  const size_t sh_f = sizeof(double) * (4 * m + NT / KF_WAVE);
-  const size_t sh_a = sizeof(double) * (6 * m + NT / KF_WAVE);
-  const unsigned tb = (unsigned)((m + 31) / 32);
+  const unsigned cc = (unsigned)((m + CW - 1) / CW), rc = (unsigned)((m + RCH - 1) / RCH);
+  const size_t sh_mv = sizeof(double) * (m + NT);
+  const size_t sh_f = sizeof(double) * (m + NT / KF_WAVE);
+  const size_t sh_a = sizeof(double) * (4 * m + NT + NT / KF_WAVE);
+  const long sTape = (long)(n + 1) * mm;
   for (int t = n - 1; t >= 0; --t) {
-    hipLaunchKernelGGL(bb_fwd_step_kernel, dim3((unsigned)B), dim3(NT), sh_f, st, a, W, t);
+    // ab_f = T' ab'
+    hipLaunchKernelGGL(bb_colmatvec_kernel, dim3(cc, (unsigned)B), dim3(NT), sh_mv, st, a.Tm, mm, W.abp, (long)m,
+                       W.abfA, (long)m, m);
+    for (int qq = 0; qq < p; ++qq) {
+      // M_q = P^q z_q  (P symmetric), then the rank-one update
+      const double* src = (qq == 0) ? a.pred_P + (long)t * mm : W.Pc;
+      hipLaunchKernelGGL(bb_colmatvec_kernel, dim3(cc, (unsigned)B), dim3(NT), sh_mv, st, src, (qq == 0) ? sTape : mm,
+                         a.Z + (long)qq * m, (long)p * m, W.MQ + (long)qq * m, (long)p * m, m);
+      hipLaunchKernelGGL(bb_fwd_update_kernel, dim3(rc, (unsigned)B), dim3(NT), sh_f, st, a, W, t, qq);
+    }
     // X1 = Pb T ; Sb = X1' T ; Tb_m += X1 P_f
     kf_sb_gemm(st, B, false, 0, W.PB, mm, m, a.Tm, mm, m, nullptr, 0, 0, X1, mm, m, m, m, m);
     kf_sb_transpose(st, B, X1, mm, X1t, mm, m);
     kf_sb_gemm(st, B, false, 0, X1t, mm, m, a.Tm, mm, m, nullptr, 0, 0, W.SB, mm, m, m, m, m);
     kf_sb_gemm(st, B, false, 1, X1, mm, m, W.Pc, mm, m, TBm, mm, m, TBm, mm, m, m, m, m);
-    hipLaunchKernelGGL(bb_adj_step_kernel, dim3((unsigned)B), dim3(NT), sh_a, st, a, W, t);
+    double* ain = W.abfA;
+    double* aother = W.abfB;
+    for (int qq = p - 1; qq >= 0; --qq) {
+      // s = Sb M_q, then the rank-one adjoint; the adjoint of a^0 is the ab' of the next step
+      hipLaunchKernelGGL(bb_colmatvec_kernel, dim3(cc, (unsigned)B), dim3(NT), sh_mv, st, W.SB, mm,
+                         W.MQ + (long)qq * m, (long)p * m, W.SV, (long)m, m);
+      double* aout = (qq == 0) ? W.abp : aother;
+      hipLaunchKernelGGL(bb_adj_update_kernel, dim3(cc, (unsigned)B), dim3(NT), sh_a, st, a, W, t, qq, ain, aout);
+      aother = ain;
+      ain = aout;
+    }
     double* tmp = W.PB;  // the updated Sb is the adjoint of the predicted covariance of step t
     W.PB = W.SB;
     W.SB = tmp;
   }
-  (void)tb;
   // g_T = 2 Tb_m + sum_t ab'_t a_f,t'
   if (a.g_T) {
     hipLaunchKernelGGL(bb_scale_kernel, dim3((unsigned)((B * mm + 255) / 256)), dim3(256), 0, st, TBm, B * mm, 2.0);
