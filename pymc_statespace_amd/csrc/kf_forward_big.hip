@@ -13,8 +13,8 @@
 //   big_sym      P_hat = (S + S')/2 (:221) through 32x32 LDS transposes; predicted tapes
 //
 // The two m x m x m products are >99% of the flops (m = 367: 2 x 98.9 MFLOP per draw-step) and
-// are real contractions, so they run on the matrix cores: 64x64 output tile per 256-thread
-// workgroup (4 waves, 2x2 MFMA 16x16 tiles each), K staged through LDS in chunks of 32 with the
+// are real contractions, so they run on the matrix cores: 128x64 output tile per 512-thread
+// workgroup (8 waves, 2x2 MFMA 16x16 tiles each), K staged through LDS in chunks of 32 with the
 // next chunk prefetched into registers.
 #include "kf_internal.h"
 
@@ -22,10 +22,11 @@ namespace {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int GTM = 64, GTN = 64;    // output tile; measured at m=367: 64x64 38 TF per GEMM, 128x64 and 128x128 slower
+constexpr int GTM = 128, GTN = 64;   // output tile; measured at m=367 (C5 share, ms per step): 64x64 / 4 waves 0.888,
+                                     // 128x64 / 8 waves 0.825, 128x128 / 16 waves (K chunk 16) 0.835
 constexpr int GK = 32;               // K chunk
-constexpr int GNT = 256;             // threads: 4 waves as 2 x 2, 32 x 32 per wave
-constexpr int GWR = 2, GWC = 2;
+constexpr int GNT = 512;             // threads: 8 waves as 4 x 2, 32 x 32 per wave
+constexpr int GWR = 4, GWC = 2;
 constexpr int GTI = GTM / GWR / 16;  // MFMA tiles per wave, rows (2)
 constexpr int GTJ = GTN / GWC / 16;  // MFMA tiles per wave, cols (4)
 constexpr int GLDA = GTM + 1, GLDB = GTN + 1;  // odd LDS row strides
