@@ -249,15 +249,20 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     for (int s = 0; s < KS; ++s)
       if (on[s]) STG[offb[s] >> 3] = Preg[s];
   };
+  // lane predicates fixed for the whole launch: plain exec-masked stores, no branch chains in the loop
+  const bool st1 = lane < nb128, st1b = (mm & 1) && lane == nb128;
+  const bool st2 = lane + KF_WAVE < nb128, st2b = (mm & 1) && lane + KF_WAVE == nb128;
+  const bool two_rounds = mm > 2 * KF_WAVE;  // m > 11
+  const bool odd_tail = (mm & 1) != 0;
   auto flush_cov = [&](double* dst) {
     wave_lds_fence();
     const double2_t v2 = *reinterpret_cast<const double2_t*>(STG + 2 * lane);
-    if (lane < nb128) st_stream(reinterpret_cast<double2_t*>(dst) + lane, v2);
-    else if ((mm & 1) && lane == nb128) st_stream(dst + mm - 1, v2.x);
-    if (mm > 2 * KF_WAVE) {  // m > 11: a second round of lanes
+    if (st1) st_stream(reinterpret_cast<double2_t*>(dst) + lane, v2);
+    if (odd_tail && st1b) st_stream(dst + mm - 1, v2.x);
+    if (two_rounds) {
       const double2_t w2 = *reinterpret_cast<const double2_t*>(STG + 2 * (lane + KF_WAVE));
-      if (lane + KF_WAVE < nb128) st_stream(reinterpret_cast<double2_t*>(dst) + lane + KF_WAVE, w2);
-      else if ((mm & 1) && lane + KF_WAVE == nb128) st_stream(dst + mm - 1, w2.x);
+      if (st2) st_stream(reinterpret_cast<double2_t*>(dst) + lane + KF_WAVE, w2);
+      if (odd_tail && st2b) st_stream(dst + mm - 1, w2.x);
     }
     wave_lds_fence();
   };
