@@ -7,6 +7,7 @@ device, with the batch-of-draws axis leading (layouts: include/kf.h).
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 from typing import Optional
 
@@ -191,10 +192,13 @@ class KalmanEngine:
             h_diagonal = False
             if p > 1 and m <= 16 and p <= 8 and not tv and filter_type in ("standard", "cholesky"):
                 # the check costs a few small launches and a host sync: remember the answer per tensor
-                key = (H.data_ptr(), H._version, tuple(H.shape))
-                if getattr(self, "_hdiag_key", None) != key:
+                # (keyed on the live tensor OBJECT and its version counter -- not on the address: the
+                # caching allocator hands the same block to the next, different H)
+                ref = getattr(self, "_hdiag_ref", None)
+                if ref is None or ref() is not H or self._hdiag_ver != H._version:
                     off = H - torch.diag_embed(torch.diagonal(H, dim1=-2, dim2=-1))
-                    self._hdiag_key, self._hdiag_val = key, not bool(torch.any(off != 0))
+                    self._hdiag_val = not bool(torch.any(off != 0))
+                    self._hdiag_ref, self._hdiag_ver = weakref.ref(H), H._version
                 h_diagonal = self._hdiag_val
         if h_diagonal:
             dims.flags |= _lib.KF_FLAG_H_DIAGONAL

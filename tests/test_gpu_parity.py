@@ -1170,3 +1170,21 @@ def test_register_tile_kernels_at_block_boundaries(eng, n):
     ra, rP = kn.kalman_smoother(w["T"], w["R"], w["Q"], ref["filtered_states"], ref["filtered_covs"])
     assert_allclose(sa.cpu().numpy(), ra, rtol=1e-8, atol=1e-8)
     assert_allclose(sP.cpu().numpy(), rP, rtol=1e-8, atol=1e-8)
+
+
+def test_diagonal_h_detection_is_not_fooled_by_buffer_reuse(eng):
+    """The cached diagonal-H check is keyed on the tensor object: a dense H that lands on the block a
+    diagonal one just vacated must still go to the joint-update kernel."""
+    import torch
+
+    wd = W.random_dense(6, 25, 3, 8, 3, seed=41)
+    wf = W.random_dense(6, 25, 3, 8, 3, seed=41, h_diag=False)
+    dev = [eng.to_device(x) for x in _args(wd)]
+    eng.forward(*dev)  # caches "diagonal"
+    addr = dev[6].data_ptr()
+    dev[6] = None
+    torch.cuda.empty_cache()
+    Hf = eng.to_device(wf["H"])  # same shape; typically the same address
+    out = eng.forward(dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], Hf, dev[7]).logp.cpu().numpy()
+    ref = kn.kalman_filter(wd["y"], wd["a0"], wd["P0"], wd["T"], wd["Z"], wd["R"], wf["H"], wd["Q"])
+    assert np.max(np.abs(out - ref["logp"])) < 1e-8, (addr, Hf.data_ptr())
