@@ -204,10 +204,13 @@ __global__ __launch_bounds__(256) void sb_potrf_inv_kernel(double* A, long sA, i
     __syncthreads();
     for (int i = j + tid; i < nb; i += 256) L[i][j] = (i == j) ? d : L[i][j] / d;
     __syncthreads();
-    const int rem = nb - j - 1;
-    for (int e = tid; e < rem * rem; e += 256) {
-      const int ii = j + 1 + e / rem, kk = j + 1 + e % rem;
-      if (kk <= ii) L[ii][kk] -= L[ii][j] * L[kk][j];
+    // trailing rank-one update, threads as a 16 x 16 grid over (row, column): no integer division
+    {
+      const int ty = tid >> 4, tx = tid & 15;
+      for (int ii = j + 1 + ty; ii < nb; ii += 16) {
+        const double lij = L[ii][j];
+        for (int kk = j + 1 + tx; kk <= ii; kk += 16) L[ii][kk] -= lij * L[kk][j];
+      }
     }
     __syncthreads();
   }
