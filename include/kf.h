@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define KF_ABI_VERSION 1
+#define KF_ABI_VERSION 2 /* 2: KF_FLAG_H_DIAGONAL, KF_KERNEL_MFMA, kf_dare, kf_simulate_statespace, workspace use by smoother/backward */
 
 typedef struct kf_handle kf_handle;
 
