@@ -1188,3 +1188,19 @@ def test_diagonal_h_detection_is_not_fooled_by_buffer_reuse(eng):
     out = eng.forward(dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], Hf, dev[7]).logp.cpu().numpy()
     ref = kn.kalman_filter(wd["y"], wd["a0"], wd["P0"], wd["T"], wd["Z"], wd["R"], wf["H"], wd["Q"])
     assert np.max(np.abs(out - ref["logp"])) < 1e-8, (addr, Hf.data_ptr())
+
+
+def test_plain_cpp_consumer_of_the_c_abi():
+    """tests/abi_c/abi_consumer.cpp: dlopen + hipMalloc + the extern "C" entry points, no Python or
+    torch in the data path -- known answers, smoother, gradient vs a finite difference."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "abi_c", "abi_consumer")
+    if not os.path.exists(exe):
+        pytest.fail("tests/abi_c/abi_consumer is not built: run __graft_entry__.build()")
+    lib = os.path.join(root, "pymc_statespace_amd", "libkf_hip.so")
+    csv = os.path.join(root, "tests", "golden", "nile.csv")
+    res = subprocess.run([exe, lib, csv], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "ABI_CONSUMER_OK" in res.stdout, res.stdout + res.stderr
