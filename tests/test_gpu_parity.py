@@ -1204,3 +1204,24 @@ def test_plain_cpp_consumer_of_the_c_abi():
     csv = os.path.join(root, "tests", "golden", "nile.csv")
     res = subprocess.run([exe, lib, csv], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "ABI_CONSUMER_OK" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.parametrize("m", [5, 6, 7, 8, 9, 11, 12, 13, 16])
+def test_register_tile_smoother_every_tile_size(eng, m):
+    """kf_smooth_mfma_kernel for every accumulator count (KS = 2, 3, 4), odd and even m x m."""
+    w = W.random_dense(9, 77, 1, m, m, seed=60 + m)  # full-rank R Q R': P_hat safely positive definite
+    flt = kn.kalman_filter(*_args(w))
+    ra, rP = kn.kalman_smoother(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
+    sa, sP = eng.smooth(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
+    assert_allclose(sa.cpu().numpy(), ra, rtol=1e-8, atol=1e-8)
+    assert_allclose(sP.cpu().numpy(), rP, rtol=1e-8, atol=1e-8)
+    # and with a singular prediction covariance (zero state noise, exactly known initial state
+    # components): the flagged draws take the pinv path of the LDS kernel
+    w0 = W.random_dense(4, 30, 1, m, 1, seed=80 + m)
+    P0 = w0["P0"].copy()
+    P0[:, 0, :] = 0.0
+    P0[:, :, 0] = 0.0
+    flt0 = kn.kalman_filter(w0["y"], w0["a0"], P0, w0["T"], w0["Z"], w0["R"], w0["H"], w0["Q"])
+    ra0, rP0 = kn.kalman_smoother(w0["T"], w0["R"], w0["Q"], flt0["filtered_states"], flt0["filtered_covs"])
+    sa0, sP0 = eng.smooth(w0["T"], w0["R"], w0["Q"], flt0["filtered_states"], flt0["filtered_covs"])
+    assert np.isfinite(sa0.cpu().numpy()).all() and np.isfinite(sP0.cpu().numpy()).all()
