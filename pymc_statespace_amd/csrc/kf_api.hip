@@ -91,9 +91,9 @@ static int kf_split_for(const kf_handle* h, int m, long B) {
   return (m % 2 == 0 && have) ? H : 1;
 }
 
-// multivariate row kernel: eligible shapes and the (padded M, lanes per row H) instantiation
+// scalar-observation kernels (multivariate row kernel, MFMA tile kernel): eligible shapes
 static bool kf_mp_ok(const kf_handle* h, int m, int p, int T, int filter, unsigned flags) {
-  if (16.0 * ((double)T + 1.0) * m * m >= 2147483648.0) return false;  // 31-bit tape offsets per block
+  (void)T;
   if (flags & KF_FLAG_TV_ANY) return false;
   if (h->forward_kernel != KF_KERNEL_AUTO && h->forward_kernel != KF_KERNEL_ROW &&
       h->forward_kernel != KF_KERNEL_MFMA)
@@ -101,6 +101,9 @@ static bool kf_mp_ok(const kf_handle* h, int m, int p, int T, int filter, unsign
   if (m > KF_MP_M_MAX || p > KF_MP_P_MAX || p < 1) return false;
   return p == 1 || filter == KF_FILTER_UNIVARIATE || (flags & KF_FLAG_H_DIAGONAL);
 }
+
+// the multivariate row kernel addresses its tapes with 31-bit offsets per block
+static bool kf_mp_offsets_ok(int m, int T) { return 16.0 * ((double)T + 1.0) * m * m < 2147483648.0; }
 
 static void kf_mp_pick(const kf_handle* h, int m, long B, int* Mo, int* Ho) {
   int M = m + (m & 1);
@@ -171,7 +174,7 @@ extern "C" const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims*
     return "kf_fwd_mfma_kernel";
   if (row_ok && h->forward_kernel != KF_KERNEL_LDS && h->forward_kernel != KF_KERNEL_LANE)
     return kf_split_for(h, d->m, d->B) > 1 ? "kf_fwd_rowsplit_kernel" : "kf_fwd_row_kernel";
-  if (mp_ok) return "kf_fwd_rowsplit_mp_kernel";
+  if (mp_ok) return kf_mp_offsets_ok(d->m, d->T) ? "kf_fwd_rowsplit_mp_kernel" : "kf_fwd_mfma_kernel";
   return "kf_fwd_lds_kernel";
 }
 
@@ -245,7 +248,7 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t 
       default: return kf_launch_forward_row_m10(h, a, stream);
     }
   }
-  if (mp_ok) return kf_launch_forward_mp(h, a, stream);
+  if (mp_ok) return kf_mp_offsets_ok(a.m, a.T) ? kf_launch_forward_mp(h, a, stream) : kf_launch_forward_mfma(h, a, stream);
   return kf_launch_forward_lds(h, a, stream);
 }
 
