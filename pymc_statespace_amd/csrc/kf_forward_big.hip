@@ -33,20 +33,28 @@ constexpr int GLDA = GTM + 1, GLDB = GTN + 1;  // odd LDS row strides
 constexpr int GPA = GTM * GK / GNT, GPB = GTN * GK / GNT;  // staged elements per thread
 
 // C[b] (m x m) = A[b] (m x m) * op(B[b])  (+ E[b]);  op = identity or transpose.
-// grid: (tiles_n, tiles_m, draws)  block: 512.  Software pipeline: the next K chunk is fetched
+// grid: 1-D, 8 * tiles * ceil(draws / 8) workgroups (XCD-aware, see below)  block: 512.  Software pipeline: the next K chunk is fetched
 // from HBM/L2 into registers while the MFMAs of the current chunk run out of LDS.
 template <bool TRANS_B, bool ADD_E>
 __global__ __launch_bounds__(GNT) void big_gemm_kernel(const double* __restrict__ A, long strideA,
                                                        const double* __restrict__ Bm, long strideB,
                                                        const double* __restrict__ E, long strideE,
-                                                       double* __restrict__ Cm, long strideC, int m) {
+                                                       double* __restrict__ Cm, long strideC, int m,
+                                                       long B, int tiles_n, int tiles_m) {
   __shared__ double As[GK][GLDA];  // As[k][r]  (A tile, k-major)
   __shared__ double Bs[GK][GLDB];  // Bs[k][c]
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int wr = wave / GWC, wc = wave % GWC;
-  const long b = blockIdx.z;
-  const int r0 = blockIdx.y * GTM, c0 = blockIdx.x * GTN;
+  // XCD-aware mapping: workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD
+  // has its own L2.  All tiles of one draw share the draw's A and B rows, so they must share an
+  // XCD: linear id L -> draw = (L % 8) + 8 * (L / (8 * tiles)), tile = (L / 8) % tiles.
+  const int tiles = tiles_n * tiles_m;
+  const long L = blockIdx.x;
+  const long b = (L & 7) + 8 * (L / (8L * tiles));
+  if (b >= B) return;
+  const int tile = (int)((L >> 3) % tiles);
+  const int r0 = (tile / tiles_n) * GTM, c0 = (tile % tiles_n) * GTN;
   const double* Ab = A + b * strideA;
   const double* Bb = Bm + b * strideB;
 
@@ -718,10 +726,12 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
       hipLaunchKernelGGL(big_pf_kernel, dim3((m + PF_ROWS - 1) / PF_ROWS, (unsigned)a.B), dim3(256), lds_pf,
                          stream, a, t, P_ws, M_ws, K_ws, KF_ws, Pf_ws);
     }
-    hipLaunchKernelGGL((big_gemm_kernel<false, false>), dim3(tgn, tgm, (unsigned)a.B), dim3(GNT), 0, stream,
-                       a.Tm, (long)mm, Pf_ws, (long)mm, nullptr, 0L, W_ws, (long)mm, m);
-    hipLaunchKernelGGL((big_gemm_kernel<true, true>), dim3(tgn, tgm, (unsigned)a.B), dim3(GNT), 0, stream,
-                       W_ws, (long)mm, a.Tm, (long)mm, RQR_ws, (long)mm, Pf_ws, (long)mm, m);
+    // 1-D grid: 8 * tiles * ceil(B / 8) workgroups (see the XCD mapping in the kernel)
+    const unsigned ggrid = (unsigned)(8L * tgn * tgm * ((a.B + 7) / 8));
+    hipLaunchKernelGGL((big_gemm_kernel<false, false>), dim3(ggrid), dim3(GNT), 0, stream,
+                       a.Tm, (long)mm, Pf_ws, (long)mm, nullptr, 0L, W_ws, (long)mm, m, a.B, tgn, tgm);
+    hipLaunchKernelGGL((big_gemm_kernel<true, true>), dim3(ggrid), dim3(GNT), 0, stream,
+                       W_ws, (long)mm, a.Tm, (long)mm, RQR_ws, (long)mm, Pf_ws, (long)mm, m, a.B, tgn, tgm);
     hipLaunchKernelGGL(big_sym_kernel, dim3(ts, ts, (unsigned)a.B), dim3(256), 0, stream, Pf_ws, P_ws,
                        a.pred_P ? a.pred_P + (size_t)(t + 1) * mm : nullptr, (long)(a.T + 1) * (long)mm, m);
   }
