@@ -103,6 +103,14 @@ static bool kf_mp_ok(const kf_handle* h, int m, int p, int T, int filter, unsign
 }
 
 // the multivariate row kernel addresses its tapes with 31-bit offsets per block
+// block-tile MFMA kernel: 16 < m <= 48, static matrices, scalar observations
+static bool kf_nb_ok(const kf_handle* h, int m, int p, int r, int filter, unsigned flags) {
+  if (flags & KF_FLAG_TV_ANY) return false;
+  if (h->forward_kernel != KF_KERNEL_AUTO && h->forward_kernel != KF_KERNEL_MFMA) return false;
+  if (!kf_forward_mfma_nb_ok(m, p, r)) return false;
+  return p == 1 || filter == KF_FILTER_UNIVARIATE || (flags & KF_FLAG_H_DIAGONAL);
+}
+
 static bool kf_mp_offsets_ok(int m, int T) { return 16.0 * ((double)T + 1.0) * m * m < 2147483648.0; }
 
 static void kf_mp_pick(const kf_handle* h, int m, long B, int* Mo, int* Ho) {
@@ -163,6 +171,7 @@ extern "C" const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims*
   if (!h || !d) return "";
   const bool row_ok = d->p == 1 && d->m <= KF_ROW_M_MAX;
   if (d->flags & KF_FLAG_TV_ANY) return "kf_fwd_lds_kernel";
+  if (kf_nb_ok(h, d->m, d->p, d->r, d->filter, d->flags)) return "kf_fwd_mfma_nb_kernel";
   if (!kf_forward_lds_fits(d->m, d->p)) return "big_gemm_kernel";
   if (h->forward_kernel == KF_KERNEL_MFMA)
     return kf_mp_ok(h, d->m, d->p, d->T, d->filter, d->flags) ? "kf_fwd_mfma_kernel" : "";
@@ -191,6 +200,8 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t 
     }
     return kf_launch_forward_lds(h, a, stream);
   }
+  // measured (MI355X, 4096 draws x 1000 steps): m = 17..40 took 25..670 ms on the LDS kernel
+  if (kf_nb_ok(h, a.m, a.p, a.r, a.filter, a.flags)) return kf_launch_forward_mfma_nb(h, a, stream);
   if (!kf_forward_lds_fits(a.m, a.p)) return kf_launch_forward_big(h, a, workspace, workspace_bytes, stream);
   const bool row_ok = a.p == 1 && a.m <= KF_ROW_M_MAX;
   const bool lane_ok = a.p == 1 && a.m <= KF_LANE_M_MAX;

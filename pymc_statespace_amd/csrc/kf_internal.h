@@ -134,6 +134,10 @@ KF_DECL_MP(10, 2) KF_DECL_MP(10, 3) KF_DECL_MP(8, 2) KF_DECL_MP(8, 4) KF_DECL_MP
 KF_DECL_MP(4, 1) KF_DECL_MP(4, 2)
 // accumulator-layout kernel (kf_forward_mfma.hip): one wavefront per draw, m <= 16, p <= 8
 int kf_launch_forward_mfma(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+// block-tile variant (kf_forward_mfma_nb.hip): 16 < m <= 48 as 2 x 2 / 3 x 3 blocks of 16 x 16
+#define KF_NB_M_MAX 48
+bool kf_forward_mfma_nb_ok(int m, int p, int r);
+int kf_launch_forward_mfma_nb(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 // lane-per-draw kernels for tiny m (kf_forward_lane.hip)
 #define KF_LANE_M_MAX 4
 int kf_launch_forward_lane_m1(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);

@@ -1049,7 +1049,11 @@ def test_auto_kernel_selection(eng):
     assert name(4096, 1000, 1, 10, 5) == "kf_fwd_mfma_kernel"       # north star
     assert name(65536, 1000, 1, 10, 5) == "kf_fwd_mfma_kernel"      # C3
     assert name(4096, 1000, 1, 16, 5) == "kf_fwd_mfma_kernel"
-    assert name(4096, 1000, 1, 17, 5) == "kf_fwd_lds_kernel"
+    assert name(4096, 1000, 1, 17, 5) == "kf_fwd_mfma_nb_kernel"
+    assert name(4096, 1000, 1, 48, 5) == "kf_fwd_mfma_nb_kernel"
+    assert name(4096, 1000, 3, 30, 5, "standard", True) == "kf_fwd_mfma_nb_kernel"
+    assert name(4096, 1000, 3, 30, 5, "standard", False) == "kf_fwd_lds_kernel"    # dense H
+    assert name(4096, 1000, 1, 49, 5) == "kf_fwd_lds_kernel"
     assert name(16384, 1000, 5, 15, 5, "standard", True) == "kf_fwd_mfma_kernel"   # C4
     assert name(16384, 1000, 5, 10, 5, "standard", True) == "kf_fwd_rowsplit_mp_kernel"
     assert name(16384, 1000, 5, 15, 5, "standard", False) == "kf_fwd_lds_kernel"   # dense H
@@ -1225,3 +1229,66 @@ def test_register_tile_smoother_every_tile_size(eng, m):
     ra0, rP0 = kn.kalman_smoother(w0["T"], w0["R"], w0["Q"], flt0["filtered_states"], flt0["filtered_covs"])
     sa0, sP0 = eng.smooth(w0["T"], w0["R"], w0["Q"], flt0["filtered_states"], flt0["filtered_covs"])
     assert np.isfinite(sa0.cpu().numpy()).all() and np.isfinite(sP0.cpu().numpy()).all()
+
+
+# ----------------------------------------------------------------------------------------------
+# block-tile kernel (kf_forward_mfma_nb.hip): 16 < m <= 48 as 2 x 2 / 3 x 3 blocks of 16 x 16
+# ----------------------------------------------------------------------------------------------
+NB_SHAPES = [(1, m, max(1, m // 3)) for m in (17, 20, 21, 24, 25, 28, 29, 32, 33, 36, 37, 40, 41, 44, 45, 48)] + \
+            [(3, 18, 4), (5, 27, 9), (8, 32, 32), (2, 35, 3), (4, 43, 20), (8, 48, 7)]
+
+
+@pytest.mark.parametrize("pmr", NB_SHAPES, ids=[f"p{p}m{m}r{r}" for p, m, r in NB_SHAPES])
+@pytest.mark.parametrize("ft", ["standard", "cholesky", "univariate", "single"])
+def test_block_tile_kernel_matches_oracle(eng, pmr, ft):
+    p, m, r = pmr
+    if ft == "single" and p != 1:
+        pytest.skip("single is p == 1 only")
+    mvn = "exact" if (m + p) % 2 else "reference"
+    B, n = 7, 70
+    w = W.random_dense(B, n, p, m, r, seed=900 + 17 * p + m)
+    y = w["y"].copy()
+    y[[3, 17, 64]] = np.nan
+    if p > 1:
+        y[5, 0] = np.nan
+        y[40, 1:] = np.nan
+    rng = np.random.default_rng(m)
+    c = 0.1 * rng.standard_normal((B, m))
+    d = 0.1 * rng.standard_normal((B, p))
+    ref = kn.kalman_filter(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const=mvn,
+                           cholesky_triangle="correct", partial_missing="delete")
+    assert eng.forward_kernel_name(B, n, p, m, r, ft, True) == "kf_fwd_mfma_nb_kernel"
+    out = _np(eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const=mvn))
+    assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8
+    for k in TAPES:
+        assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=k)
+    assert not out["info"].any()
+    assert np.all(out["ll_obs"][:, [3, 17, 64]] == 0.0)
+    assert np.array_equal(out["predicted_covs"][:, 1:], np.swapaxes(out["predicted_covs"][:, 1:], -1, -2))
+    assert np.array_equal(out["filtered_covs"], np.swapaxes(out["filtered_covs"], -1, -2))
+
+
+def test_block_tile_kernel_agrees_with_lds_kernel_per_draw_data_and_partial_outputs(eng):
+    B, n, p, m, r = 40, 130, 2, 30, 6
+    w = W.random_dense(B, n, p, m, r, seed=77)
+    rng = np.random.default_rng(5)
+    yb = w["y"][None] + 0.1 * rng.standard_normal((B,) + w["y"].shape)
+    H = w["H"].copy()
+    H[7, 1, 1] = -500.0
+    args = (yb, w["a0"], w["P0"], w["T"], w["Z"], w["R"], H, w["Q"])
+    res = eng.forward(*args, store_filtered=False, store_ll_obs=False, h_diagonal=True)
+    assert res.filtered_covs is None and res.ll_obs is None
+    info = res.info.cpu().numpy()
+    good = np.arange(B) != 7
+    assert info[7] == ((0 + 1) << 8) | 2 and not info[good].any()
+    eng.set_forward_kernel("lds")
+    try:
+        ref = eng.forward(*args, h_diagonal=True)
+    finally:
+        eng.set_forward_kernel("auto")
+    lp, lr = res.logp.cpu().numpy(), ref.logp.cpu().numpy()
+    assert np.isnan(lp[7]) and np.max(np.abs(lp[good] - lr[good])) < 1e-8
+    assert_allclose(res.predicted_covs.cpu().numpy()[good], ref.predicted_covs.cpu().numpy()[good],
+                    rtol=1e-9, atol=1e-9)
+    assert_allclose(res.predicted_states.cpu().numpy()[good], ref.predicted_states.cpu().numpy()[good],
+                    rtol=1e-9, atol=1e-9)
