@@ -14,7 +14,8 @@
 // With P bitwise symmetric, register P[I][ks] is at once the A operand "rows 16 I + c, k = 4 ks + g"
 // and the B operand "k = 4 ks + g, columns 16 I + c", so
 //     W2 = P_f T'        : W2(I, J) += mfma(A = P[I][ks],  B = T[J][ks])      NB^2 KSR MFMAs
-//     S  = T W2 + R Q R' : S(I, J)  += mfma(A = T[I][ks],  B = W2[J][ks])     NB^2 KSR MFMAs
+//     S  = T W2 + R Q R' : S(I, J)  += mfma(A = T[I][ks],  B = W2[J][ks])     NB (NB + 1) / 2 KSR MFMAs
+//                          (blocks I <= J only; the blocks below the diagonal are mirrored)
 // take their operands straight from registers (T[J][s] = T[16 J + c][4 s + g] is static).  One LDS
 // transpose gives P_hat = (S + S') / 2 (:221).  Update, likelihood bookkeeping and the tape
 // stores follow kf_forward_mfma.hip (non-augmented variant), with vectors held per column block.
@@ -319,11 +320,13 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB == 2
       flush_cov(o_fP);
       o_fP += mm;
     }
+    // S = T W2 + R Q R' is symmetric up to rounding: only the blocks on and above the block diagonal
+    // are computed; the blocks below are their mirror images (through the LDS transpose)
     double4_t S[NB][NB];
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
-      for (int J = 0; J < NB; ++J)
+      for (int J = I; J < NB; ++J)
 #pragma unroll
         for (int u = 0; u < 4; ++u) S[I][J][u] = (4 * I + u < KSR) ? RQR[J][(4 * I + u < KSR) ? 4 * I + u : 0] : 0.0;
 #pragma unroll
@@ -331,16 +334,15 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB == 2
 #pragma unroll
       for (int I = 0; I < NB; ++I)
 #pragma unroll
-        for (int J = 0; J < NB; ++J)
-          if (4 * I < KSR)
-            S[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(TA[I][ks], W2[ks >> 2][J][ks & 3], S[I][J], 0, 0, 0);
-    // transpose S through LDS: element (i, j) at TR[i * LD + pos(j)]
+        for (int J = I; J < NB; ++J)
+          S[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(TA[I][ks], W2[ks >> 2][J][ks & 3], S[I][J], 0, 0, 0);
+    // transpose through LDS: element (i, j) at TR[i * LD + pos(j)]
 #pragma unroll
     for (int J = 0; J < NB; ++J) {
       const int j = 16 * J + c;
 #pragma unroll
       for (int s = 0; s < KSR; ++s)
-        if (j < 4 * KSR) TR[(4 * s + g) * LD + pos(j)] = S[s >> 2][J][s & 3];
+        if ((s >> 2) <= J && j < 4 * KSR) TR[(4 * s + g) * LD + pos(j)] = S[s >> 2][J][s & 3];
     }
     wave_lds_fence();
 #pragma unroll
@@ -348,10 +350,17 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB == 2
       const int j = 16 * J + c;
       const double* row = TR + (j < 4 * KSR ? j : 4 * KSR - 1) * LD + g * KSRP;
 #pragma unroll
-      for (int s = 0; s < KSRP; s += 2) {
+      for (int s = 0; s < 4 * J && s < KSR; ++s) P[J][s] = S[s >> 2][J][s & 3];  // above the diagonal: as computed
+#pragma unroll
+      for (int s = 4 * J; s < KSRP; s += 2) {
         const double2_t t2 = *reinterpret_cast<const double2_t*>(row + s);
-        P[J][s] = cok[J] ? 0.5 * (S[s >> 2][J][s & 3] + t2.x) : 0.0;
-        if (s + 1 < KSR) P[J][s + 1 < KSR ? s + 1 : 0] = cok[J] ? 0.5 * (S[(s + 1) >> 2][J][(s + 1) & 3] + t2.y) : 0.0;
+        const bool dg0 = (s >> 2) == J, dg1 = ((s + 1) >> 2) == J;  // diagonal block: (S + S') / 2 (:221)
+        const double v0 = dg0 ? 0.5 * (S[dg0 ? J : 0][J][s & 3] + t2.x) : t2.x;
+        P[J][s] = cok[J] ? v0 : 0.0;
+        if (s + 1 < KSR) {
+          const double v1 = dg1 ? 0.5 * (S[dg1 ? J : 0][J][(s + 1) & 3] + t2.y) : t2.y;
+          P[J][s + 1 < KSR ? s + 1 : 0] = cok[J] ? v1 : 0.0;
+        }
       }
     }
     wave_lds_fence();

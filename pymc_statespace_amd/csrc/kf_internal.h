@@ -138,6 +138,9 @@ int kf_launch_forward_mfma(kf_handle* h, const KfFwdArgs& a, hipStream_t stream)
 #define KF_NB_M_MAX 48
 bool kf_forward_mfma_nb_ok(int m, int p, int r);
 int kf_launch_forward_mfma_nb(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+struct KfBwdArgs;
+bool kf_backward_mfma_nb_ok(int m, int p, int r);
+int kf_launch_backward_mfma_nb(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 // lane-per-draw kernels for tiny m (kf_forward_lane.hip)
 #define KF_LANE_M_MAX 4
 int kf_launch_forward_lane_m1(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
