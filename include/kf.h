@@ -82,8 +82,8 @@ enum {
   KF_FLAG_TV_D = 1u << 10,
   KF_FLAG_TV_ANY = 0x7f0u,
   /* The caller asserts that every draw's H is diagonal (e.g. VARMAX measurement error,
-   * models/VARMAX.py:80-83).  Standard/CholeskyFilter with p > 1 and m <= 16 may then process the
-   * p observations of a step one at a time in the register-resident row kernel -- algebraically
+   * models/VARMAX.py:80-83).  Standard/CholeskyFilter with p > 1 and m <= 48 may then process the
+   * p observations of a step one at a time in the register-resident kernels -- algebraically
    * the same filter (results agree to rounding).  Off-diagonal entries are ignored when set. */
   KF_FLAG_H_DIAGONAL = 1u << 11
 };
@@ -124,8 +124,11 @@ int kf_set_lanes_per_draw(kf_handle* h, int lanes);
  * ("lane"); p == 1, m <= 6 (m <= 9 for large batches) -> register-resident row-owner kernels
  * ("row"); m <= 16, p <= 8 with p == 1 / UnivariateFilter / KF_FLAG_H_DIAGONAL -> covariance in
  * MFMA accumulator layout, one wavefront per draw ("mfma": m >= 10, or m >= 11 for p > 1) or the
- * multivariate row kernel ("row"); other tiles that fit LDS -> generic LDS-resident kernel
- * ("lds", also all time-varying models); else the workspace + MFMA GEMM path.  Results agree to
+ * multivariate row kernel ("row"); 16 < m <= 48 with the same eligibility -> covariance as 2 x 2 /
+ * 3 x 3 blocks of 16 x 16 in accumulator layout ("mfma" as well); other tiles that fit LDS ->
+ * generic LDS-resident kernel ("lds", also all time-varying models); else the workspace + MFMA
+ * GEMM path.  The gradient and the smoother follow the same ranges (block-tile kernels for
+ * 16 < m <= 48 / 47).  Results agree to
  * rounding. */
 enum { KF_KERNEL_AUTO = 0, KF_KERNEL_LDS = 1, KF_KERNEL_ROW = 2, KF_KERNEL_LANE = 3, KF_KERNEL_MFMA = 4 };
 int kf_set_forward_kernel(kf_handle* h, int kernel);
@@ -135,7 +138,8 @@ const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* dims);
 /* Scratch the three entry points need for `dims` (max over them); may be 0.  Non-zero for
  * k_states too large for on-chip tiles (forward: m^2-sized covariance workspace; smoother for
  * m > ~47: 6 B m^2 doubles; gradient for m > ~45: 7 B m^2 + 2 B m T doubles) and, a few bytes per draw, for the register-tile smoother
- * (5 <= m <= 16: per-draw flags; without them kf_smoother uses the slower LDS kernel). */
+ * smoothers
+ * (5 <= m <= 47: per-draw flags; without them kf_smoother uses the slower LDS kernel). */
 int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes);
 
 /* Forward filter for B draws.  c, d may be NULL (= 0: initialize_intercepts,

@@ -203,6 +203,10 @@ int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, si
 size_t kf_smoother_mfma_workspace_bytes(long B);
 int kf_launch_smoother_mfma(kf_handle* h, const KfSmoothArgs& a, void* workspace, size_t workspace_bytes,
                             hipStream_t stream);
+// block-tile smoother (kf_smoother_mfma_nb.hip): 16 < m <= 47, same flag workspace
+bool kf_smoother_mfma_nb_ok(int m, int r);
+int kf_launch_smoother_mfma_nb(kf_handle* h, const KfSmoothArgs& a, void* workspace, size_t workspace_bytes,
+                               hipStream_t stream);
 // large-m smoother (kf_smoother_big.hip): HBM workspace, blocked Cholesky, fp64-MFMA GEMMs
 size_t kf_smoother_big_workspace_bytes(long B, int m);
 int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace, size_t workspace_bytes,

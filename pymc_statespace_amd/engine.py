@@ -78,7 +78,8 @@ class KalmanEngine:
         """'auto' | 'lds' (generic LDS-resident) | 'row' (register-resident: p == 1, m <= 10; or
         m <= 16, p <= 8 with the Univariate filter / diagonal H) | 'lane' (one lane per draw,
         p == 1, m <= 4) | 'mfma' (covariance in MFMA accumulator layout, one wavefront per draw:
-        m <= 16, p <= 8, same eligibility as the multivariate row kernel)."""
+        m <= 16, p <= 8, same eligibility as the multivariate row kernel; 16 < m <= 48 as blocks of
+        16 x 16)."""
         code = {"auto": 0, "lds": 1, "row": 2, "lane": 3, "mfma": 4}[kernel]
         self._check(self.lib.kf_set_forward_kernel(self._h, code), "kf_set_forward_kernel")
 
@@ -139,7 +140,7 @@ class KalmanEngine:
         (subset of T,Z,R,H,Q,c,d) carry an extra time axis after the draw axis: (B,n,...).
 
         ``h_diagonal``: True asserts every draw's H is diagonal (KF_FLAG_H_DIAGONAL: lets the
-        Standard/Cholesky filters with p > 1, m <= 16 use the register-resident row kernel);
+        Standard/Cholesky filters with p > 1, m <= 48 use the register-resident kernels);
         None checks H on the device (one small reduction + host sync) when it matters."""
         tv = set(time_varying)
         if not tv <= set(_lib.KF_FLAG_TV):
@@ -228,7 +229,7 @@ class KalmanEngine:
                  mvn_const="reference", want_cd=False, h_diagonal=False):
         """kf_filter_backward -> dict of per-draw gradients (a0,P0,T,Z,R,H,Q[,c,d]).
 
-        ``h_diagonal=True`` (KF_FLAG_H_DIAGONAL) lets Standard/Cholesky with p > 1, m <= 16 use the
+        ``h_diagonal=True`` (KF_FLAG_H_DIAGONAL) lets Standard/Cholesky with p > 1, m <= 48 use the
         scalar-observation adjoint kernel: g["H"] then carries the diagonal only and g["P0"] the
         symmetric part of the entrywise gradient (all a symmetric / diagonal parameterisation sees).
         Unlike ``forward`` this is never auto-detected: a dense-H model that happens to be diagonal

@@ -1334,3 +1334,31 @@ def test_block_tile_gradient_kernel_matches_autograd(eng, pmr, ft):
         elif k in ("P0", "Q") and (p > 1 or ft == "univariate"):
             a, b = a + np.swapaxes(a, -1, -2), b + np.swapaxes(b, -1, -2)
         assert np.max(np.abs(a - b)) / (1.0 + np.max(np.abs(b))) < 1e-10, k
+
+
+@pytest.mark.parametrize("m", [17, 20, 22, 24, 27, 28, 32, 33, 36, 39, 40, 44, 47])
+def test_block_tile_smoother_matches_oracle(eng, m):
+    """kf_smooth_mfma_nb_kernel for every (blocks, slices) instantiation, odd and even m."""
+    w = W.random_dense(5, 40, 1, m, m, seed=160 + m)  # full-rank R Q R': P_hat safely positive definite
+    flt = kn.kalman_filter(*_args(w))
+    ra, rP = kn.kalman_smoother(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
+    sa, sP = eng.smooth(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
+    assert_allclose(sa.cpu().numpy(), ra, rtol=1e-8, atol=1e-8)
+    assert_allclose(sP.cpu().numpy(), rP, rtol=1e-8, atol=1e-8)
+    # agrees with the LDS-resident smoother (Cholesky path) it replaces
+    eng.set_forward_kernel("lds")
+    try:
+        la, lP = eng.smooth(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
+    finally:
+        eng.set_forward_kernel("auto")
+    assert_allclose(sa.cpu().numpy(), la.cpu().numpy(), rtol=1e-8, atol=1e-8)
+    assert_allclose(sP.cpu().numpy(), lP.cpu().numpy(), rtol=1e-8, atol=1e-8)
+    # singular prediction covariance: flagged draws take the pinv path of the LDS kernel
+    w0 = W.random_dense(3, 20, 1, m, 1, seed=180 + m)
+    P0 = w0["P0"].copy()
+    P0[:, 0, :] = 0.0
+    P0[:, :, 0] = 0.0
+    flt0 = kn.kalman_filter(w0["y"], w0["a0"], P0, w0["T"], w0["Z"], w0["R"], w0["H"], w0["Q"])
+    sa0, sP0 = eng.smooth(w0["T"], w0["R"], w0["Q"], flt0["filtered_states"], flt0["filtered_covs"])
+    # (cond(P_hat) ~ 1e9 .. 1e11 here: every solver, the oracle's pinv included, returns noise)
+    assert np.isfinite(sa0.cpu().numpy()).all() and np.isfinite(sP0.cpu().numpy()).all()
