@@ -111,6 +111,14 @@ static bool kf_nb_ok(const kf_handle* h, int m, int p, int r, int filter, unsign
   return p == 1 || filter == KF_FILTER_UNIVARIATE || (flags & KF_FLAG_H_DIAGONAL);
 }
 
+// workgroup-per-draw MFMA kernel: 48 < m <= 64, same eligibility
+static bool kf_wg_ok(const kf_handle* h, int m, int p, int r, int filter, unsigned flags) {
+  if (flags & KF_FLAG_TV_ANY) return false;
+  if (h->forward_kernel != KF_KERNEL_AUTO && h->forward_kernel != KF_KERNEL_MFMA) return false;
+  if (!kf_forward_mfma_wg_ok(m, p, r)) return false;
+  return p == 1 || filter == KF_FILTER_UNIVARIATE || (flags & KF_FLAG_H_DIAGONAL);
+}
+
 static bool kf_mp_offsets_ok(int m, int T) { return 16.0 * ((double)T + 1.0) * m * m < 2147483648.0; }
 
 static void kf_mp_pick(const kf_handle* h, int m, long B, int* Mo, int* Ho) {
@@ -172,7 +180,10 @@ extern "C" const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims*
   const bool row_ok = d->p == 1 && d->m <= KF_ROW_M_MAX;
   if (d->flags & KF_FLAG_TV_ANY) return "kf_fwd_lds_kernel";
   if (kf_nb_ok(h, d->m, d->p, d->r, d->filter, d->flags)) return "kf_fwd_mfma_nb_kernel";
-  if (!kf_forward_lds_fits(d->m, d->p)) return "big_gemm_kernel";
+  if (kf_wg_ok(h, d->m, d->p, d->r, d->filter, d->flags)) return "kf_fwd_mfma_wg_kernel";
+  // (48 < m that still fits LDS: the workspace path is 5x faster, kf_launch_forward takes it when
+  // the caller passed the workspace kf_workspace_bytes asks for)
+  if (!kf_forward_lds_fits(d->m, d->p) || (d->m > KF_NB_M_MAX && d->B <= 65535)) return "big_gemm_kernel";
   if (h->forward_kernel == KF_KERNEL_MFMA)
     return kf_mp_ok(h, d->m, d->p, d->T, d->filter, d->flags) ? "kf_fwd_mfma_kernel" : "";
   if (d->p == 1 && d->m <= KF_LANE_M_MAX &&
@@ -202,7 +213,14 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t 
   }
   // measured (MI355X, 4096 draws x 1000 steps): m = 17..40 took 25..670 ms on the LDS kernel
   if (kf_nb_ok(h, a.m, a.p, a.r, a.filter, a.flags)) return kf_launch_forward_mfma_nb(h, a, stream);
+  if (kf_wg_ok(h, a.m, a.p, a.r, a.filter, a.flags)) return kf_launch_forward_mfma_wg(h, a, stream);
   if (!kf_forward_lds_fits(a.m, a.p)) return kf_launch_forward_big(h, a, workspace, workspace_bytes, stream);
+  // 48 < m <= ~60 still fits LDS, but one workgroup per CU at m^3 LDS reads per step: measured
+  // (4096 draws x 1000 steps) 2.2 s at m = 49, 3.9 s at m = 60 against 0.62 s at m = 64 on the
+  // workspace path -- taken whenever the caller provided the workspace
+  if (a.m > KF_NB_M_MAX && a.B <= 65535 && workspace &&
+      workspace_bytes >= kf_forward_big_workspace_bytes(a.B, a.m, a.p))
+    return kf_launch_forward_big(h, a, workspace, workspace_bytes, stream);
   const bool row_ok = a.p == 1 && a.m <= KF_ROW_M_MAX;
   const bool lane_ok = a.p == 1 && a.m <= KF_LANE_M_MAX;
   const bool mp_ok = kf_mp_ok(h, a.m, a.p, a.T, a.filter, a.flags);
@@ -377,7 +395,8 @@ static int check_dims(kf_handle* h, const kf_dims* d, bool need_p) {
 extern "C" int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes) {
   if (!h || !dims || !bytes) return KF_ERR_ARG;
   *bytes = 0;  // the LDS- and register-resident kernels keep all scratch on chip
-  if (dims->m >= 1 && dims->p >= 1 && !kf_forward_lds_fits(dims->m, dims->p))
+  if (dims->m >= 1 && dims->p >= 1 && !(dims->flags & KF_FLAG_TV_ANY) &&
+      (!kf_forward_lds_fits(dims->m, dims->p) || dims->m > KF_NB_M_MAX))
     *bytes = kf_forward_big_workspace_bytes(dims->B, dims->m, dims->p);
   if (dims->m >= 1 && dims->m <= KF_NB_M_MAX) {  // flags of the register-tile smoothers
     const size_t sm = kf_smoother_mfma_workspace_bytes(dims->B);

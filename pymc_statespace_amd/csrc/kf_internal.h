@@ -138,6 +138,10 @@ int kf_launch_forward_mfma(kf_handle* h, const KfFwdArgs& a, hipStream_t stream)
 #define KF_NB_M_MAX 48
 bool kf_forward_mfma_nb_ok(int m, int p, int r);
 int kf_launch_forward_mfma_nb(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+// workgroup-per-draw variant (kf_forward_mfma_wg.hip): 48 < m <= 64, four wavefronts per draw
+#define KF_WG_M_MAX 64
+bool kf_forward_mfma_wg_ok(int m, int p, int r);
+int kf_launch_forward_mfma_wg(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 struct KfBwdArgs;
 bool kf_backward_mfma_nb_ok(int m, int p, int r);
 int kf_launch_backward_mfma_nb(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);

@@ -191,7 +191,7 @@ class KalmanEngine:
             dims.flags |= _lib.KF_FLAG_TV[name]
         if h_diagonal is None:
             h_diagonal = False
-            if p > 1 and m <= 48 and p <= 8 and not tv and filter_type in ("standard", "cholesky"):
+            if p > 1 and m <= 64 and p <= 8 and not tv and filter_type in ("standard", "cholesky"):
                 # the check costs a few small launches and a host sync: remember the answer per tensor
                 # (keyed on the live tensor OBJECT and its version counter -- not on the address: the
                 # caching allocator hands the same block to the next, different H)

@@ -1053,7 +1053,10 @@ def test_auto_kernel_selection(eng):
     assert name(4096, 1000, 1, 48, 5) == "kf_fwd_mfma_nb_kernel"
     assert name(4096, 1000, 3, 30, 5, "standard", True) == "kf_fwd_mfma_nb_kernel"
     assert name(4096, 1000, 3, 30, 5, "standard", False) == "kf_fwd_lds_kernel"    # dense H
-    assert name(4096, 1000, 1, 49, 5) == "kf_fwd_lds_kernel"
+    assert name(4096, 1000, 1, 49, 5) == "kf_fwd_mfma_wg_kernel"
+    assert name(4096, 1000, 1, 64, 5) == "kf_fwd_mfma_wg_kernel"
+    assert name(4096, 1000, 3, 60, 5, "standard", False) == "big_gemm_kernel"      # dense H
+    assert name(4096, 1000, 1, 65, 5) == "big_gemm_kernel"
     assert name(16384, 1000, 5, 15, 5, "standard", True) == "kf_fwd_mfma_kernel"   # C4
     assert name(16384, 1000, 5, 10, 5, "standard", True) == "kf_fwd_rowsplit_mp_kernel"
     assert name(16384, 1000, 5, 15, 5, "standard", False) == "kf_fwd_lds_kernel"   # dense H
@@ -1362,3 +1365,62 @@ def test_block_tile_smoother_matches_oracle(eng, m):
     sa0, sP0 = eng.smooth(w0["T"], w0["R"], w0["Q"], flt0["filtered_states"], flt0["filtered_covs"])
     # (cond(P_hat) ~ 1e9 .. 1e11 here: every solver, the oracle's pinv included, returns noise)
     assert np.isfinite(sa0.cpu().numpy()).all() and np.isfinite(sP0.cpu().numpy()).all()
+
+
+# ----------------------------------------------------------------------------------------------
+# workgroup-per-draw kernel (kf_forward_mfma_wg.hip): 48 < m <= 64, four wavefronts per draw
+# ----------------------------------------------------------------------------------------------
+WG_SHAPES = [(1, m, max(1, m // 4)) for m in (49, 50, 52, 53, 56, 57, 60, 61, 63, 64)] + \
+            [(3, 51, 4), (5, 55, 9), (8, 64, 20), (2, 59, 3)]
+
+
+@pytest.mark.parametrize("pmr", WG_SHAPES, ids=[f"p{p}m{m}r{r}" for p, m, r in WG_SHAPES])
+@pytest.mark.parametrize("ft", ["standard", "cholesky", "univariate", "single"])
+def test_workgroup_kernel_matches_oracle(eng, pmr, ft):
+    p, m, r = pmr
+    if ft == "single" and p != 1:
+        pytest.skip("single is p == 1 only")
+    if ft in ("cholesky", "single") and m % 4 not in (0, 1):
+        pytest.skip("covered by the standard filter at this shape")
+    mvn = "exact" if (m + p) % 2 else "reference"
+    B, n = 5, 70
+    w = W.random_dense(B, n, p, m, r, seed=2900 + 17 * p + m)
+    y = w["y"].copy()
+    y[[3, 17, 64]] = np.nan
+    if p > 1:
+        y[5, 0] = np.nan
+        y[40, 1:] = np.nan
+    rng = np.random.default_rng(m)
+    c = 0.1 * rng.standard_normal((B, m))
+    d = 0.1 * rng.standard_normal((B, p))
+    ref = kn.kalman_filter(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const=mvn,
+                           cholesky_triangle="correct", partial_missing="delete")
+    assert eng.forward_kernel_name(B, n, p, m, r, ft, True) == "kf_fwd_mfma_wg_kernel"
+    out = _np(eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const=mvn))
+    assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8
+    for k in TAPES:
+        assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=k)
+    assert not out["info"].any()
+    assert np.all(out["ll_obs"][:, [3, 17, 64]] == 0.0)
+    assert np.array_equal(out["predicted_covs"][:, 1:], np.swapaxes(out["predicted_covs"][:, 1:], -1, -2))
+    assert np.array_equal(out["filtered_covs"], np.swapaxes(out["filtered_covs"], -1, -2))
+
+
+def test_workgroup_kernel_per_draw_data_not_pd_and_partial_outputs(eng):
+    B, n, p, m, r = 24, 130, 2, 58, 6
+    w = W.random_dense(B, n, p, m, r, seed=78)
+    rng = np.random.default_rng(5)
+    yb = w["y"][None] + 0.1 * rng.standard_normal((B,) + w["y"].shape)
+    H = w["H"].copy()
+    H[7, 1, 1] = -500.0
+    args = (yb, w["a0"], w["P0"], w["T"], w["Z"], w["R"], H, w["Q"])
+    res = eng.forward(*args, store_filtered=False, store_ll_obs=False, h_diagonal=True)
+    assert res.filtered_covs is None and res.ll_obs is None
+    info = res.info.cpu().numpy()
+    good = np.arange(B) != 7
+    assert info[7] == ((0 + 1) << 8) | 2 and not info[good].any()
+    ref = kn.kalman_filter(yb, w["a0"], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"])
+    lp = res.logp.cpu().numpy()
+    assert np.isnan(lp[7]) and np.max(np.abs(lp[good] - ref["logp"][good])) < 1e-8
+    assert_allclose(res.predicted_covs.cpu().numpy()[good], ref["predicted_covs"][good], rtol=1e-9, atol=1e-9)
+    assert_allclose(res.predicted_states.cpu().numpy()[good], ref["predicted_states"][good], rtol=1e-9, atol=1e-9)
