@@ -125,10 +125,11 @@ int kf_set_lanes_per_draw(kf_handle* h, int lanes);
  * ("row"); m <= 16, p <= 8 with p == 1 / UnivariateFilter / KF_FLAG_H_DIAGONAL -> covariance in
  * MFMA accumulator layout, one wavefront per draw ("mfma": m >= 10, or m >= 11 for p > 1) or the
  * multivariate row kernel ("row"); 16 < m <= 48 with the same eligibility -> covariance as 2 x 2 /
- * 3 x 3 blocks of 16 x 16 in accumulator layout ("mfma" as well); other tiles that fit LDS ->
+ * 3 x 3 blocks of 16 x 16 in accumulator layout ("mfma" as well); 48 < m <= 64 -> one workgroup of
+ * four wavefronts per draw, one column block each ("mfma"); other tiles that fit LDS ->
  * generic LDS-resident kernel ("lds", also all time-varying models); else the workspace + MFMA
  * GEMM path.  The gradient and the smoother follow the same ranges (block-tile kernels for
- * 16 < m <= 48 / 47).  Results agree to
+ * 16 < m <= 48 / 47, workgroup kernels for the gradient up to m = 64).  Results agree to
  * rounding. */
 enum { KF_KERNEL_AUTO = 0, KF_KERNEL_LDS = 1, KF_KERNEL_ROW = 2, KF_KERNEL_LANE = 3, KF_KERNEL_MFMA = 4 };
 int kf_set_forward_kernel(kf_handle* h, int kernel);

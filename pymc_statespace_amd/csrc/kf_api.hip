@@ -318,6 +318,11 @@ int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t
       kf_backward_mfma_nb_ok(a.m, a.p, a.r) &&
       (a.p == 1 || a.filter == KF_FILTER_UNIVARIATE || (a.flags & KF_FLAG_H_DIAGONAL)))
     return kf_launch_backward_mfma_nb(h, a, stream);
+  // 48 < m <= 64: four wavefronts per draw (kf_backward_mfma_wg.hip)
+  if ((h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_MFMA) &&
+      kf_backward_mfma_wg_ok(a.m, a.p, a.r) &&
+      (a.p == 1 || a.filter == KF_FILTER_UNIVARIATE || (a.flags & KF_FLAG_H_DIAGONAL)))
+    return kf_launch_backward_mfma_wg(h, a, stream);
   // tiles too large for LDS (m > ~45): workspace + MFMA-GEMM adjoint, scalar observations only
   if (!kf_backward_lds_fits(a.m, a.p)) return kf_launch_backward_big(h, a, workspace, workspace_bytes, stream);
   // accumulator-layout adjoint (kf_backward_mfma.hip): scalar observations only, i.e. p == 1, the

@@ -143,6 +143,8 @@ int kf_launch_forward_mfma_nb(kf_handle* h, const KfFwdArgs& a, hipStream_t stre
 bool kf_forward_mfma_wg_ok(int m, int p, int r);
 int kf_launch_forward_mfma_wg(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 struct KfBwdArgs;
+bool kf_backward_mfma_wg_ok(int m, int p, int r);
+int kf_launch_backward_mfma_wg(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 bool kf_backward_mfma_nb_ok(int m, int p, int r);
 int kf_launch_backward_mfma_nb(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 // lane-per-draw kernels for tiny m (kf_forward_lane.hip)

@@ -1424,3 +1424,45 @@ def test_workgroup_kernel_per_draw_data_not_pd_and_partial_outputs(eng):
     assert np.isnan(lp[7]) and np.max(np.abs(lp[good] - ref["logp"][good])) < 1e-8
     assert_allclose(res.predicted_covs.cpu().numpy()[good], ref["predicted_covs"][good], rtol=1e-9, atol=1e-9)
     assert_allclose(res.predicted_states.cpu().numpy()[good], ref["predicted_states"][good], rtol=1e-9, atol=1e-9)
+
+
+BWD_WG_SHAPES = [(1, m, max(1, m // 4)) for m in (49, 52, 53, 56, 57, 60, 61, 64)] + \
+                [(3, 51, 4), (5, 55, 9), (8, 64, 12), (2, 59, 3)]
+
+
+@pytest.mark.parametrize("pmr", BWD_WG_SHAPES, ids=[f"p{p}m{m}r{r}" for p, m, r in BWD_WG_SHAPES])
+@pytest.mark.parametrize("ft", ["standard", "univariate", "single"])
+def test_workgroup_gradient_kernel_matches_autograd(eng, pmr, ft):
+    from oracle import kalman_torch as kt
+
+    p, m, r = pmr
+    if ft == "single" and p != 1:
+        pytest.skip("single is p == 1 only")
+    if ft != "standard" and p == 1 and m % 4 not in (0, 1):
+        pytest.skip("covered by the standard filter at this shape")
+    B, n = 3, 67  # 67: crosses a 64-step staging block
+    w = W.random_dense(B, n, p, m, r, seed=2700 + 17 * p + m)
+    y = w["y"].copy()
+    y[2] = np.nan
+    y[-1] = np.nan
+    if p > 1:
+        y[5, 0] = np.nan
+        y[65, 1:] = np.nan
+    rng = np.random.default_rng(m * 10 + p)
+    g_logp = rng.standard_normal(B)
+    g_ll = rng.standard_normal((B, n))
+    c = 0.1 * rng.standard_normal((B, m))
+    d = 0.1 * rng.standard_normal((B, p))
+    _, _, gt = kt.logp_and_grads(*_args(w, y), c=c, d=d, g_logp=g_logp, g_ll_obs=g_ll, filter_type=ft)
+    res = eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, h_diagonal=True)
+    g = eng.backward(*_args(w, y), c=c, d=d, predicted_states=res.predicted_states,
+                     predicted_covs=res.predicted_covs, g_logp=g_logp, g_ll_obs=g_ll,
+                     filter_type=ft, want_cd=True, h_diagonal=True)
+    for k in kt.NAMES:
+        a, b = g[k].cpu().numpy(), gt[k]
+        if k == "H" and p > 1:
+            assert np.all(a[:, ~np.eye(p, dtype=bool)] == 0.0)
+            a, b = np.diagonal(a, axis1=-2, axis2=-1), np.diagonal(b, axis1=-2, axis2=-1)
+        elif k in ("P0", "Q") and (p > 1 or ft == "univariate"):
+            a, b = a + np.swapaxes(a, -1, -2), b + np.swapaxes(b, -1, -2)
+        assert np.max(np.abs(a - b)) / (1.0 + np.max(np.abs(b))) < 1e-10, k
