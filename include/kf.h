@@ -129,7 +129,7 @@ int kf_set_lanes_per_draw(kf_handle* h, int lanes);
  * four wavefronts per draw, one column block each ("mfma"); other tiles that fit LDS ->
  * generic LDS-resident kernel ("lds", also all time-varying models); else the workspace + MFMA
  * GEMM path.  The gradient and the smoother follow the same ranges (block-tile kernels for
- * 16 < m <= 48 / 47, workgroup kernels for the gradient up to m = 64).  Results agree to
+ * 16 < m <= 48 / 47, workgroup kernels up to m = 64).  Results agree to
  * rounding. */
 enum { KF_KERNEL_AUTO = 0, KF_KERNEL_LDS = 1, KF_KERNEL_ROW = 2, KF_KERNEL_LANE = 3, KF_KERNEL_MFMA = 4 };
 int kf_set_forward_kernel(kf_handle* h, int kernel);
@@ -177,8 +177,9 @@ int kf_filter_backward(kf_handle* h, const kf_dims* dims,
  * Only dims->B, T, m, r are used.  The gain uses the Moore-Penrose pseudo-inverse of
  * the one-step prediction covariance with numpy's default cutoff 1e-15 * sigma_max
  * (kalman_smoother.py:92): a Cholesky / Gauss-Jordan solve whenever that covariance is safely
- * positive definite, a Jacobi eigen-decomposition otherwise (m <= ~47; beyond that the
- * workspace path requires positive definiteness).  `workspace`: see kf_workspace_bytes. */
+ * positive definite, a Jacobi eigen-decomposition otherwise (m <= 47; beyond that
+ * positive definiteness is required: the workgroup kernel, 47 < m <= 64, returns NaN for a draw
+ * that fails the test, the workspace path's Cholesky likewise).  `workspace`: see kf_workspace_bytes. */
 int kf_smoother(kf_handle* h, const kf_dims* dims,
                 const double* T, const double* R, const double* Q,
                 const double* filt_a, const double* filt_P,

@@ -40,7 +40,7 @@ struct WgLayout {
   static constexpr int OFF_YB = OFF_DL + PMAXQ;
   static int loop_doubles(int p) { return OFF_YB + 64 * p + p * 4 * KSRP; }
   // setup scratch (R, Q, R Q) aliases PL + TR
-  static bool setup_fits(int m, int r) { return 2 * m * r + r * r <= NBW * KSR * KF_WAVE + 4 * KSR * LD; }
+  static bool setup_fits(int m, int r) { return 2 * m * r <= NBW * KSR * KF_WAVE + 4 * KSR * LD; }
 };
 
 template <int KSR>
@@ -82,18 +82,16 @@ __global__ __launch_bounds__(NBW* KF_WAVE) void kf_fwd_mfma_wg_kernel(const KfFw
   double TA[KSR], RQR[KSR], P[KSR];
   {
     // ---- R Q R' through an LDS scratch that aliases PL / TR ------------------------------------------
-    double* sR = PL;                // R     m x r
-    double* sQ = sR + m * r_;       // Q     r x r
-    double* sRQ = sQ + r_ * r_;     // R Q   m x r
+    double* sR = PL;                // R     m x r   (Q is read from global memory: R and R Q of an
+    double* sRQ = sR + m * r_;      // R Q   m x r    m = r = 64 model fill PL + TR exactly)
     const double* gR = A.R + b * (long)m * r_;
     const double* gQ = A.Q + b * (long)r_ * r_;
     for (int e = threadIdx.x; e < m * r_; e += NBW * KF_WAVE) sR[e] = gR[e];
-    for (int e = threadIdx.x; e < r_ * r_; e += NBW * KF_WAVE) sQ[e] = gQ[e];
     __syncthreads();
     for (int e = threadIdx.x; e < m * r_; e += NBW * KF_WAVE) {
       const int i = e / r_, l = e - i * r_;
       double v = 0.0;
-      for (int kk = 0; kk < r_; ++kk) v += sR[i * r_ + kk] * sQ[kk * r_ + l];
+      for (int kk = 0; kk < r_; ++kk) v += sR[i * r_ + kk] * gQ[kk * r_ + l];
       sRQ[e] = v;
     }
     __syncthreads();

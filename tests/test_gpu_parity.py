@@ -1371,7 +1371,7 @@ def test_block_tile_smoother_matches_oracle(eng, m):
 # workgroup-per-draw kernel (kf_forward_mfma_wg.hip): 48 < m <= 64, four wavefronts per draw
 # ----------------------------------------------------------------------------------------------
 WG_SHAPES = [(1, m, max(1, m // 4)) for m in (49, 50, 52, 53, 56, 57, 60, 61, 63, 64)] + \
-            [(3, 51, 4), (5, 55, 9), (8, 64, 20), (2, 59, 3)]
+            [(3, 51, 4), (5, 55, 9), (8, 64, 20), (2, 59, 3), (1, 64, 64), (1, 50, 50)]
 
 
 @pytest.mark.parametrize("pmr", WG_SHAPES, ids=[f"p{p}m{m}r{r}" for p, m, r in WG_SHAPES])
@@ -1427,7 +1427,7 @@ def test_workgroup_kernel_per_draw_data_not_pd_and_partial_outputs(eng):
 
 
 BWD_WG_SHAPES = [(1, m, max(1, m // 4)) for m in (49, 52, 53, 56, 57, 60, 61, 64)] + \
-                [(3, 51, 4), (5, 55, 9), (8, 64, 12), (2, 59, 3)]
+                [(3, 51, 4), (5, 55, 9), (8, 64, 12), (2, 59, 3), (1, 64, 64)]
 
 
 @pytest.mark.parametrize("pmr", BWD_WG_SHAPES, ids=[f"p{p}m{m}r{r}" for p, m, r in BWD_WG_SHAPES])
@@ -1466,3 +1466,28 @@ def test_workgroup_gradient_kernel_matches_autograd(eng, pmr, ft):
         elif k in ("P0", "Q") and (p > 1 or ft == "univariate"):
             a, b = a + np.swapaxes(a, -1, -2), b + np.swapaxes(b, -1, -2)
         assert np.max(np.abs(a - b)) / (1.0 + np.max(np.abs(b))) < 1e-10, k
+
+
+@pytest.mark.parametrize("m", [48, 49, 52, 53, 56, 57, 60, 61, 64])
+def test_workgroup_smoother_matches_oracle(eng, m):
+    """kf_smooth_mfma_wg_kernel for every slice count, odd and even m."""
+    w = W.random_dense(4, 40, 1, m, m, seed=260 + m)  # full-rank R Q R': P_hat safely positive definite
+    flt = kn.kalman_filter(*_args(w))
+    ra, rP = kn.kalman_smoother(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
+    sa, sP = eng.smooth(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
+    assert_allclose(sa.cpu().numpy(), ra, rtol=1e-8, atol=1e-8)
+    assert_allclose(sP.cpu().numpy(), rP, rtol=1e-8, atol=1e-8)
+    # exactly singular prediction covariance (no state noise, a state known exactly): this range has no
+    # pinv fallback -- the draw comes back as NaN, the other draws are untouched
+    w0 = W.random_dense(3, 12, 1, m, m, seed=280 + m)
+    Q = w0["Q"].copy()
+    Q[1] = 0.0
+    P0 = w0["P0"].copy()
+    P0[1] = 0.0
+    flt0 = kn.kalman_filter(w0["y"], w0["a0"], P0, w0["T"], w0["Z"], w0["R"], w0["H"], Q)
+    ra0, rP0 = kn.kalman_smoother(w0["T"], w0["R"], Q, flt0["filtered_states"], flt0["filtered_covs"])
+    sa0, sP0 = eng.smooth(w0["T"], w0["R"], Q, flt0["filtered_states"], flt0["filtered_covs"])
+    sa0, sP0 = sa0.cpu().numpy(), sP0.cpu().numpy()
+    assert np.isnan(sa0[1]).all() and np.isnan(sP0[1]).all()
+    assert_allclose(sa0[[0, 2]], ra0[[0, 2]], rtol=1e-8, atol=1e-8)
+    assert_allclose(sP0[[0, 2]], rP0[[0, 2]], rtol=1e-8, atol=1e-8)
