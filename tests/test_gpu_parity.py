@@ -1491,3 +1491,47 @@ def test_workgroup_smoother_matches_oracle(eng, m):
     assert np.isnan(sa0[1]).all() and np.isnan(sP0[1]).all()
     assert_allclose(sa0[[0, 2]], ra0[[0, 2]], rtol=1e-8, atol=1e-8)
     assert_allclose(sP0[[0, 2]], rP0[[0, 2]], rtol=1e-8, atol=1e-8)
+
+
+# ----------------------------------------------------------------------------------------------
+# the C-ABI never allocates, synchronises or copies to the host: its launches can be captured
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 10, 5), (1, 3, 2), (1, 24, 6), (1, 52, 6), (2, 15, 4)],
+                         ids=["tile", "lane", "block_tile", "workgroup", "tile_p2"])
+def test_forward_gradient_smoother_replay_from_a_hip_graph(eng, shape):
+    """Capture forward + gradient + smoother into one graph, change the data in place, replay:
+    the replayed outputs equal an eager run on the new data (one NUTS-style step without any
+    per-launch host work)."""
+    import torch
+
+    p, m, r = shape
+    B, n = 48, 40
+    w = W.random_dense(B, n, p, m, r, seed=31 + m)
+    dev = [eng.to_device(x) for x in _args(w)]
+    gl = torch.ones(B, dtype=torch.float64, device=dev[0].device)
+    kw = dict(h_diagonal=True)
+
+    def step():
+        res = eng.forward(*dev, **kw)
+        g = eng.backward(*dev, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
+                         g_logp=gl, h_diagonal=True)
+        sa, sP = eng.smooth(dev[3], dev[5], dev[7], res.filtered_states, res.filtered_covs)
+        return res, g, sa, sP
+
+    step()  # lazy initialisation (workspaces, function attributes) outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        res_c, g_c, sa_c, sP_c = step()
+    y2 = w["y"] + 0.3 * np.random.default_rng(1).standard_normal(w["y"].shape)
+    dev[0].copy_(torch.as_tensor(y2, device=dev[0].device))
+    graph.replay()
+    torch.cuda.synchronize()
+    res_e, g_e, sa_e, sP_e = step()
+    torch.cuda.synchronize()
+    assert torch.equal(res_c.logp, res_e.logp) and torch.equal(res_c.predicted_covs, res_e.predicted_covs)
+    for k in g_e:
+        assert torch.equal(g_c[k], g_e[k]), k
+    assert torch.equal(sa_c, sa_e) and torch.equal(sP_c, sP_e)
+    ref = kn.kalman_filter(y2, *_args(w)[1:])
+    assert np.max(np.abs(res_c.logp.cpu().numpy() - ref["logp"])) < 1e-8
