@@ -9,7 +9,9 @@
 // Products on register blocks:
 //     W2 = P_f T'            NB^2 KSR MFMAs          P_hat = T W2 + RQR'   blocks I <= J, mirrored
 //     E  = D X               NB^2 KSR MFMAs          P_s   = X' E + P_f    blocks I <= J, mirrored
-// (P_hat and P_s are symmetric up to rounding; the reference does not symmetrise them either).
+// (P_hat and P_s are symmetric up to rounding; here they are made exactly symmetric -- mirrored
+// off-diagonal blocks, averaged diagonal blocks -- which differs from the reference's unsymmetrised
+// values at rounding level only).
 // X: Gauss-Jordan on the pair (P_hat | W), W = W2', m pivots without exchanges; per pivot the
 // pivot ROW comes from its lane group by v_permlane swaps, the pivot COLUMN through an LDS exchange;
 // column blocks of P_hat left of the pivot are already identity and are skipped.  A pivot below
@@ -237,12 +239,15 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB == 2
       for (int s = 0; s < KSR; ++s) Wt[J][s] = cok[J] ? tw[s] : 0.0;
     }
     wave_lds_fence();
-    // mirror P_hat below the block diagonal (same transpose tile)
+    // P_hat: blocks above the diagonal as computed, below mirrored, DIAGONAL blocks (S + S') / 2 -- the
+    // tile must be exactly symmetric: every symmetric matrix here doubles as its own transpose (A
+    // operand), and with mirroring an antisymmetric residue in the diagonal blocks is fed back as a
+    // symmetric error each step (measured: errors growing 1.45x per step backwards in time)
 #pragma unroll
-    for (int J = 1; J < NB; ++J) {
+    for (int J = 0; J < NB; ++J) {
       const int j = 16 * J + c;
 #pragma unroll
-      for (int s = 0; s < 4 * J && s < KSR; ++s)
+      for (int s = 0; s < 4 * (J + 1) && s < KSR; ++s)
         if (j < 4 * KSR) TR[(4 * s + g) * LD + pos(j)] = PHv[s >> 2][J][s & 3];
     }
     wave_lds_fence();
@@ -250,11 +255,14 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB == 2
     for (int J = 0; J < NB; ++J) {
       const int j = 16 * J + c;
       double tw[KSRP];
-      if (J + 1 < NB) read_rows(TR + (j < 4 * KSR ? j : 4 * KSR - 1) * LD, tw);
+      read_rows(TR + (j < 4 * KSR ? j : 4 * KSR - 1) * LD, tw);
 #pragma unroll
       for (int s = 0; s < KSR; ++s) {
         const int I = s >> 2;
-        const double ph = (I <= J) ? PHv[I <= J ? I : 0][J][s & 3] : (cok[J] ? tw[s] : 0.0);
+        double ph;
+        if (I < J) ph = PHv[I < J ? I : 0][J][s & 3];
+        else if (I == J) ph = cok[J] ? 0.5 * (PHv[I == J ? I : 0][J][s & 3] + tw[s]) : 0.0;
+        else ph = cok[J] ? tw[s] : 0.0;
         PH[J][s] = ph;
         D[J][s] = PS[J][s] - ph;  // P_s[t+1] - P_hat
       }
@@ -353,7 +361,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB == 2
       if (g == 0 && cok[J]) gsa[(long)t * m + 16 * J + c] = as_c[J];
     }
 
-    // ---- smoothed covariance: blocks on / above the diagonal as computed, below mirrored; image -> HBM ---------
+    // ---- smoothed covariance: blocks above the diagonal as computed, below mirrored, diagonal blocks
+    //      symmetrised (see P_hat above); compact image -> HBM ------------------------------------------------
 #pragma unroll
     for (int J = 0; J < NB; ++J)
 #pragma unroll
@@ -371,9 +380,17 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB == 2
 #pragma unroll
       for (int s = 0; s < KSR; ++s) {
         const int I = s >> 2;
-        if (I <= J) PS[J][s] = (cok[J] && rok(s)) ? PSv[I <= J ? I : 0][J][s & 3] : 0.0;
-        else PS[J][s] = (cok[J] && rok(s)) ? TR[obase + 4 * s * m + 16 * J] : 0.0;
+        const bool on = cok[J] && rok(s);
+        if (I < J) PS[J][s] = on ? PSv[I < J ? I : 0][J][s & 3] : 0.0;
+        else if (I == J) PS[J][s] = on ? 0.5 * (PSv[I == J ? I : 0][J][s & 3] + TR[(16 * J + c) * m + 4 * s + g]) : 0.0;
+        else PS[J][s] = on ? TR[obase + 4 * s * m + 16 * J] : 0.0;
       }
+    wave_lds_fence();
+#pragma unroll
+    for (int J = 0; J < NB; ++J)
+#pragma unroll
+      for (int s = 4 * J; s < 4 * (J + 1) && s < KSR; ++s)
+        if (cok[J] && rok(s)) TR[(4 * s + g) * m + 16 * J + c] = PS[J][s];
     flush_image(gsP + (long)t * mm);
   }
   if (lane == 0) flags[b] = bad ? 1 : 0;
