@@ -1593,3 +1593,27 @@ def test_smoother_errors_do_not_grow_over_long_series(eng, m):
     assert err.max() < 1e-9, (err[:5], err[-5:])
     assert err[:20].max() < 50 * max(err[-40:-1].max(), 1e-14), "error grows backwards in time"
     assert_allclose(sa.cpu().numpy(), ra, rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("m", [10, 21, 37, 50], ids=["tile", "block_tile_2x2", "block_tile_3x3", "workgroup"])
+def test_forward_and_gradient_over_a_long_series(eng, m):
+    """400 steps: the recursions of the register-tile families neither drift nor lose symmetry."""
+    from oracle import kalman_torch as kt
+
+    n, B = 400, 2
+    w = W.random_dense(B, n, 1, m, max(2, m // 3), seed=3300 + m)
+    ref = kn.kalman_filter(*_args(w))
+    res = eng.forward(*_args(w))
+    out = _np(res)
+    assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8
+    for k in TAPES:
+        assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=k)
+    pc = out["predicted_covs"][:, 1:]
+    assert np.array_equal(pc, np.swapaxes(pc, -1, -2))
+    g_logp = np.array([1.0, -0.5])
+    _, _, gt = kt.logp_and_grads(*_args(w), g_logp=g_logp)
+    g = eng.backward(*_args(w), predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
+                     g_logp=g_logp)
+    for k in ("a0", "P0", "T", "Z", "R", "H", "Q"):
+        a, b = g[k].cpu().numpy(), gt[k]
+        assert np.max(np.abs(a - b)) / (1.0 + np.max(np.abs(b))) < 1e-9, k
