@@ -1617,3 +1617,34 @@ def test_forward_and_gradient_over_a_long_series(eng, m):
     for k in ("a0", "P0", "T", "Z", "R", "H", "Q"):
         a, b = g[k].cpu().numpy(), gt[k]
         assert np.max(np.abs(a - b)) / (1.0 + np.max(np.abs(b))) < 1e-9, k
+
+
+@pytest.mark.parametrize("s", [24, 40, 52, 63], ids=["m25", "m41", "m53_weekly", "m64"])
+def test_seasonal_structural_models_on_the_mid_size_kernels(eng, s):
+    """Level + trend + s-period dummy seasonal (unit roots, sparse T, r = 3): the model family that
+    lands in the 16 < m <= 64 range in practice (weekly data: m = 53)."""
+    from oracle import kalman_torch as kt
+
+    B, n = 3, 150
+    w = W.daily_seasonal(B=B, n=n, s=s)
+    m = s + 1
+    y = w["y"].copy()
+    y[[7, 77]] = np.nan
+    assert eng.forward_kernel_name(B, n, 1, m, 3) in ("kf_fwd_mfma_nb_kernel", "kf_fwd_mfma_wg_kernel")
+    ref = kn.kalman_filter(*_args(w, y))
+    res = eng.forward(*_args(w, y))
+    out = _np(res)
+    assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8
+    for k in TAPES:
+        assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=k)
+    g_logp = np.array([1.0, -0.5, 2.0])
+    _, _, gt = kt.logp_and_grads(*_args(w, y), g_logp=g_logp)
+    g = eng.backward(*_args(w, y), predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
+                     g_logp=g_logp)
+    for k in ("a0", "P0", "T", "Z", "R", "H", "Q"):
+        a, b = g[k].cpu().numpy(), gt[k]
+        assert np.max(np.abs(a - b)) / (1.0 + np.max(np.abs(b))) < 1e-9, k
+    ra, rP = kn.kalman_smoother(w["T"], w["R"], w["Q"], ref["filtered_states"], ref["filtered_covs"])
+    sa, sP = eng.smooth(w["T"], w["R"], w["Q"], ref["filtered_states"], ref["filtered_covs"])
+    assert_allclose(sa.cpu().numpy(), ra, rtol=1e-7, atol=1e-7)
+    assert_allclose(sP.cpu().numpy(), rP, rtol=1e-7, atol=1e-7)
