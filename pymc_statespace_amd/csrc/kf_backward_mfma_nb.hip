@@ -49,7 +49,7 @@ struct NbBwdLayout {
 };
 
 template <int NB, int KSR>
-__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB == 2 ? 2 : 1))) void kf_bwd_mfma_nb_kernel(
+__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((NB == 2 && KSR <= 6) ? 2 : 1))) void kf_bwd_mfma_nb_kernel(
     const KfBwdArgs A) {
   using L = NbBwdLayout<NB, KSR>;
   constexpr int KSRP = L::KSRP, LD = L::LD, NCOL = L::NCOL;
