@@ -136,9 +136,10 @@ int kf_set_forward_kernel(kf_handle* h, int kernel);
 /* Name of the kernel kf_filter_forward would launch for `dims` (for profiles / bench logs). */
 const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* dims);
 
-/* Scratch the three entry points need for `dims` (max over them); may be 0.  Non-zero for
- * k_states too large for on-chip tiles (forward: m^2-sized covariance workspace; smoother for
- * m > ~47: 6 B m^2 doubles; gradient for m > ~45: 7 B m^2 + 2 B m T doubles) and, a few bytes per draw, for the register-tile smoother
+/* Scratch the three entry points need for `dims` (max over them, for the kernel selection in force
+ * on `h`); may be 0.  Non-zero for k_states too large for the on-chip kernels (m > 64, or m > ~45
+ * with a dense H: forward 4 B m^2 doubles; smoother 6 B m^2 doubles; gradient 7 B m^2 + 2 B m T
+ * doubles) and, a few bytes per draw, for the register-tile smoother
  * smoothers
  * (5 <= m <= 47: per-draw flags; without them kf_smoother uses the slower LDS kernel). */
 int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes);

@@ -400,19 +400,26 @@ static int check_dims(kf_handle* h, const kf_dims* d, bool need_p) {
 extern "C" int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes) {
   if (!h || !dims || !bytes) return KF_ERR_ARG;
   *bytes = 0;  // the LDS- and register-resident kernels keep all scratch on chip
-  if (dims->m >= 1 && dims->p >= 1 && !(dims->flags & KF_FLAG_TV_ANY) &&
-      (!kf_forward_lds_fits(dims->m, dims->p) || dims->m > KF_NB_M_MAX))
-    *bytes = kf_forward_big_workspace_bytes(dims->B, dims->m, dims->p);
-  if (dims->m >= 1 && dims->m <= KF_NB_M_MAX) {  // flags of the register-tile smoothers
+  const int m = dims->m, p = dims->p, r = dims->r;
+  const bool tile_kernels = h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_MFMA;
+  const bool scalar_obs = p == 1 || dims->filter == KF_FILTER_UNIVARIATE || (dims->flags & KF_FLAG_H_DIAGONAL);
+  // forward: HBM-workspace path for tiles beyond LDS and, when no on-chip kernel takes the shape, for m > 48
+  if (m >= 1 && p >= 1 && !(dims->flags & KF_FLAG_TV_ANY) &&
+      (!kf_forward_lds_fits(m, p) || m > KF_NB_M_MAX) &&
+      !kf_nb_ok(h, m, p, r, dims->filter, dims->flags) && !kf_wg_ok(h, m, p, r, dims->filter, dims->flags))
+    *bytes = kf_forward_big_workspace_bytes(dims->B, m, p);
+  if (m >= 1 && m <= KF_NB_M_MAX) {  // flags of the register-tile smoothers
     const size_t sm = kf_smoother_mfma_workspace_bytes(dims->B);
     if (sm > *bytes) *bytes = sm;
   }
-  if (dims->m >= 1 && dims->p >= 1 && dims->T >= 1 && !kf_backward_lds_fits(dims->m, dims->p)) {
-    const size_t bw = kf_backward_big_workspace_bytes(dims->B, dims->m, dims->p, dims->T, dims->r);
+  if (m >= 1 && p >= 1 && dims->T >= 1 && !kf_backward_lds_fits(m, p) &&
+      !(tile_kernels && scalar_obs && (kf_backward_mfma_nb_ok(m, p, r) || kf_backward_mfma_wg_ok(m, p, r)))) {
+    const size_t bw = kf_backward_big_workspace_bytes(dims->B, m, p, dims->T, r);
     if (bw > *bytes) *bytes = bw;
   }
-  if (dims->m >= 1 && !kf_smoother_lds_fits(dims->m)) {
-    const size_t sm = kf_smoother_big_workspace_bytes(dims->B, dims->m);
+  if (m >= 1 && !kf_smoother_lds_fits(m) &&
+      !(kf_smoother_mfma_wg_ok(m, r) && h->forward_kernel != KF_KERNEL_LDS)) {
+    const size_t sm = kf_smoother_big_workspace_bytes(dims->B, m);
     if (sm > *bytes) *bytes = sm;
   }
   return KF_OK;

@@ -1648,3 +1648,25 @@ def test_seasonal_structural_models_on_the_mid_size_kernels(eng, s):
     sa, sP = eng.smooth(w["T"], w["R"], w["Q"], ref["filtered_states"], ref["filtered_covs"])
     assert_allclose(sa.cpu().numpy(), ra, rtol=1e-7, atol=1e-7)
     assert_allclose(sP.cpu().numpy(), rP, rtol=1e-7, atol=1e-7)
+
+
+def test_workspace_is_only_requested_where_a_workspace_path_runs(eng):
+    """kf_workspace_bytes follows the kernel selection: nothing (or the per-draw flags of the tile
+    smoothers) while an on-chip kernel takes the shape, m^2-sized scratch only beyond."""
+    import ctypes as C
+    from pymc_statespace_amd import _lib
+
+    def ws(B, n, p, m, r, ft="standard", hdiag=False):
+        dims = eng._dims(B, n, p, m, r, ft)
+        if hdiag:
+            dims.flags |= _lib.KF_FLAG_H_DIAGONAL
+        nb = C.c_size_t(0)
+        assert eng.lib.kf_workspace_bytes(eng._h, C.byref(dims), C.byref(nb)) == 0
+        return nb.value
+
+    assert ws(4096, 1000, 1, 10, 4) == 4 * 4096 + 64           # flags of the tile smoother
+    assert ws(4096, 1000, 1, 40, 4) == 4 * 4096 + 64
+    assert ws(4096, 1000, 1, 64, 8) == 0                        # workgroup kernels: all on chip
+    assert ws(4096, 1000, 3, 60, 8, "standard", True) == 0
+    assert ws(4096, 1000, 3, 60, 8, "standard", False) > 4096 * 60 * 60 * 8   # dense H: workspace paths
+    assert ws(128, 100, 1, 367, 3) >= 7 * 128 * 367 * 367 * 8   # C5
