@@ -1670,3 +1670,35 @@ def test_workspace_is_only_requested_where_a_workspace_path_runs(eng):
     assert ws(4096, 1000, 3, 60, 8, "standard", True) == 0
     assert ws(4096, 1000, 3, 60, 8, "standard", False) > 4096 * 60 * 60 * 8   # dense H: workspace paths
     assert ws(128, 100, 1, 367, 3) >= 7 * 128 * 367 * 367 * 8   # C5
+
+
+@pytest.mark.parametrize("m", [29, 45, 57], ids=["block_tile_2x2", "block_tile_3x3", "workgroup"])
+def test_mid_size_kernels_at_a_full_size_batch(eng, m):
+    """4099 draws (more workgroups than the chip holds at once, odd count): sampled draws against the
+    oracle for forward, gradient and smoother; every draw finite; identical draws give identical bits."""
+    from oracle import kalman_torch as kt
+
+    B, n, p, r = 4099, 30, 1, m  # full-rank state noise: well-conditioned prediction covariances
+    base = W.random_dense(7, n, p, m, r, seed=4100 + m)
+    idx = np.arange(B) % 7
+    w = {k: (v if k == "y" else v[idx]) for k, v in base.items() if isinstance(v, np.ndarray)}
+    res = eng.forward(*_args(w))
+    gl = np.ones(B)
+    g = eng.backward(*_args(w), predicted_states=res.predicted_states, predicted_covs=res.predicted_covs, g_logp=gl)
+    sa, sP = eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
+    lp = res.logp.cpu().numpy()
+    assert np.isfinite(lp).all() and not res.info.cpu().numpy().any()
+    ref = kn.kalman_filter(*_args(base))
+    assert np.max(np.abs(lp - ref["logp"][idx])) < 1e-8
+    # replicas of the same parameters: bitwise equal wherever they ran
+    for k in range(7):
+        sel = np.where(idx == k)[0]
+        assert np.all(lp[sel] == lp[sel[0]])
+        assert bool((g["T"][sel] == g["T"][sel[0]]).all()) and bool((sP[sel] == sP[sel[0]]).all())
+    _, _, gt = kt.logp_and_grads(*_args(base), g_logp=np.ones(7))
+    for k in ("a0", "P0", "T", "Z", "R", "H", "Q"):
+        a, b_ = g[k][-7:].cpu().numpy(), gt[k][idx[-7:]]
+        assert np.max(np.abs(a - b_)) / (1.0 + np.max(np.abs(b_))) < 1e-9, k
+    ra, rP = kn.kalman_smoother(base["T"], base["R"], base["Q"], ref["filtered_states"], ref["filtered_covs"])
+    assert_allclose(sa[-7:].cpu().numpy(), ra[idx[-7:]], rtol=1e-7, atol=1e-8)
+    assert_allclose(sP[-7:].cpu().numpy(), rP[idx[-7:]], rtol=1e-7, atol=1e-8)
