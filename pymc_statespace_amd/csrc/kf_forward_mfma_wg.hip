@@ -15,8 +15,9 @@
 //     W2(:, J) = P_f T'(:, J)   A operand = P_f[I][ks] from an LDS image every wavefront writes its
 //                               column block of (P_f symmetric), B = T[J][ks] (own registers)
 //     S(:, J)  = T W2(:, J) + RQR'(:, J)   A operand = T[I][ks] from its static LDS image
-//     P_hat = (S + S') / 2 (:221) through a 64 x 64 LDS transpose tile (second barrier; third:
-//     the image of P_f).  2 x 4 x KSR MFMAs per wavefront and step, operands never leave the CU.
+//     P_hat = (S + S') / 2 (:221) through a 64 x 64 LDS transpose tile that reuses the image's
+//     buffer (p + 3 barriers per step).  2 x 4 x KSR MFMAs per wavefront and step, operands never
+//     leave the CU; ~70 KB of LDS per draw: two draws per CU hide each other's barrier latency.
 #include "kf_internal.h"
 #include "kf_tile.h"
 
@@ -30,21 +31,27 @@ struct WgLayout {
   static constexpr int KSRP = KSR + (KSR & 1);
   static constexpr int LD = 4 * KSRP + 2;
   static constexpr int NCOL = 16 * NBW;
-  static constexpr int OFF_PL = NBW * KSR * KF_WAVE;           // TL: T operand image
-  static constexpr int OFF_TR = OFF_PL + NBW * KSR * KF_WAVE;  // PL: P_f operand image
-  static constexpr int OFF_EXM = OFF_TR + 4 * KSR * LD;        // TR: transpose tile
+  static constexpr int IMG = NBW * KSR * KF_WAVE;
+  static constexpr int BUF = (4 * KSR * LD > IMG) ? 4 * KSR * LD : IMG;
+  static constexpr int OFF_PL = IMG;                           // TL: T operand image
+  static constexpr int OFF_TR = OFF_PL;                        // PL: P_f operand image, then (one barrier later)
+  static constexpr int OFF_EXM = OFF_PL + BUF;                 // TR: the transpose tile -- ~70 KB: two draws per CU
   static constexpr int OFF_EXA = OFF_EXM + 2 * 4 * KSRP;       // EXM: double buffered
   static constexpr int OFF_RG = OFF_EXA + 4 * KSRP;
   static constexpr int OFF_HD = OFF_RG + 128;
   static constexpr int OFF_DL = OFF_HD + PMAXQ;
   static constexpr int OFF_YB = OFF_DL + PMAXQ;
   static int loop_doubles(int p) { return OFF_YB + 64 * p + p * 4 * KSRP; }
-  // setup scratch (R, Q, R Q) aliases PL + TR
-  static bool setup_fits(int m, int r) { return 2 * m * r <= NBW * KSR * KF_WAVE + 4 * KSR * LD; }
+  // setup scratch (R, R Q) aliases the whole allocation
+  static int doubles(int p, int m, int r) {
+    const int loop = loop_doubles(p), setup = 2 * m * r;
+    return loop > setup ? loop : setup;
+  }
+  static bool setup_fits(int p, int m, int r) { return sizeof(double) * (size_t)doubles(p, m, r) <= 80 * 1024; }
 };
 
 template <int KSR>
-__global__ __launch_bounds__(NBW* KF_WAVE) void kf_fwd_mfma_wg_kernel(const KfFwdArgs A) {
+__global__ __launch_bounds__(NBW* KF_WAVE) __attribute__((amdgpu_waves_per_eu(2))) void kf_fwd_mfma_wg_kernel(const KfFwdArgs A) {
   using L = WgLayout<KSR>;
   constexpr int KSRP = L::KSRP, LD = L::LD;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -81,9 +88,9 @@ __global__ __launch_bounds__(NBW* KF_WAVE) void kf_fwd_mfma_wg_kernel(const KfFw
   const double* gZ = A.Z + b * (long)p * m;
   double TA[KSR], RQR[KSR], P[KSR];
   {
-    // ---- R Q R' through an LDS scratch that aliases PL / TR ------------------------------------------
-    double* sR = PL;                // R     m x r   (Q is read from global memory: R and R Q of an
-    double* sRQ = sR + m * r_;      // R Q   m x r    m = r = 64 model fill PL + TR exactly)
+    // ---- R Q R' through an LDS scratch that aliases the loop buffers (Q is read from global memory) ----
+    double* sR = smem;              // R     m x r
+    double* sRQ = sR + m * r_;      // R Q   m x r
     const double* gR = A.R + b * (long)m * r_;
     const double* gQ = A.Q + b * (long)r_ * r_;
     for (int e = threadIdx.x; e < m * r_; e += NBW * KF_WAVE) sR[e] = gR[e];
@@ -105,11 +112,12 @@ __global__ __launch_bounds__(NBW* KF_WAVE) void kf_fwd_mfma_wg_kernel(const KfFw
         for (int l = 0; l < r_; ++l) acc += sRQ[k * r_ + l] * sR[j * r_ + l];
       RQR[s] = acc;
       TA[s] = on ? gT[j * m + k] : 0.0;
-      TL[(J * KSR + s) * KF_WAVE + lane] = TA[s];
       // P0 as the reference reads it through the symmetric recursion: upper triangle
       P[s] = on ? ((j >= k) ? gP[k * m + j] : gP[j * m + k]) : 0.0;
     }
     __syncthreads();  // scratch is dead
+#pragma unroll
+    for (int s = 0; s < KSR; ++s) TL[(J * KSR + s) * KF_WAVE + lane] = TA[s];
   }
   const double cc = (cok && A.c) ? A.c[b * (long)m + j] : 0.0;
   double ac = cok ? A.a0[b * (long)m + j] : 0.0;
@@ -273,6 +281,7 @@ __global__ __launch_bounds__(NBW* KF_WAVE) void kf_fwd_mfma_wg_kernel(const KfFw
       for (int I = 0; I < NBW; ++I)
         if (4 * I < KSR)
           W2[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(PL[(I * KSR + ks) * KF_WAVE + lane], TA[ks], W2[I], 0, 0, 0);
+    __syncthreads();  // every wavefront has read the image: its buffer becomes the transpose tile
     double4_t S[NBW];
 #pragma unroll
     for (int I = 0; I < NBW; ++I)
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(NBW* KF_WAVE) void kf_fwd_mfma_wg_kernel(const KfFw
 
 template <int KSR>
 int launch_wg(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
-  const size_t lds = sizeof(double) * (size_t)WgLayout<KSR>::loop_doubles(a.p);
+  const size_t lds = sizeof(double) * (size_t)WgLayout<KSR>::doubles(a.p, a.m, a.r);
   static bool attr_set = false;
   if (!attr_set) {
     KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&kf_fwd_mfma_wg_kernel<KSR>),
@@ -338,10 +347,10 @@ int launch_wg(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
 bool kf_forward_mfma_wg_ok(int m, int p, int r) {
   if (!(m > KF_NB_M_MAX && m <= KF_WG_M_MAX && p >= 1 && p <= PMAXQ)) return false;
   switch ((m + 3) / 4) {
-    case 13: return WgLayout<13>::setup_fits(m, r);
-    case 14: return WgLayout<14>::setup_fits(m, r);
-    case 15: return WgLayout<15>::setup_fits(m, r);
-    default: return WgLayout<16>::setup_fits(m, r);
+    case 13: return WgLayout<13>::setup_fits(p, m, r);
+    case 14: return WgLayout<14>::setup_fits(p, m, r);
+    case 15: return WgLayout<15>::setup_fits(p, m, r);
+    default: return WgLayout<16>::setup_fits(p, m, r);
   }
 }
 
