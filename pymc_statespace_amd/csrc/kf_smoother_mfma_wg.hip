@@ -43,18 +43,21 @@ struct WgSmLayout {
   static constexpr int KSRP = KSR + (KSR & 1);
   static constexpr int LD = 4 * KSRP + 2;
   static constexpr int IMG = NBW * KSR * KF_WAVE;
-  static constexpr int OFF_B1 = IMG;                   // TL: static A-operand image of T
-  static constexpr int OFF_B2 = OFF_B1 + IMG;          // B1: image of P_f, later of D
-  static constexpr int B2 = (4 * KSR * LD > IMG) ? 4 * KSR * LD : IMG;  // B2: transpose tile of W2, later image of X
+  // one buffer, four uses in turn (a barrier between each): image of P_f -> transpose tile of W2 -> image
+  // of D -> image of X.  With the static image of T: ~70 KB, two draws per CU.
+  static constexpr int OFF_B1 = IMG;
+  static constexpr int OFF_B2 = OFF_B1;
+  static constexpr int B2 = (4 * KSR * LD > IMG) ? 4 * KSR * LD : IMG;
   static constexpr int OFF_EXK = OFF_B2 + B2;          // pivot column, double buffered
   static constexpr int OFF_EXD = OFF_EXK + 2 * 4 * KSRP;
   static constexpr int OFF_RED = OFF_EXD + 4 * KSRP;
   static constexpr int LOOP = OFF_RED + NBW;
-  static bool setup_fits(int m, int r) { return 2 * m * r <= IMG + B2; }
+  static int doubles(int m, int r) { return LOOP > 2 * m * r ? LOOP : 2 * m * r; }  // setup scratch aliases everything
+  static bool setup_fits(int m, int r) { return sizeof(double) * (size_t)doubles(m, r) <= 80 * 1024; }
 };
 
 template <int KSR>
-__global__ __launch_bounds__(NT) void kf_smooth_mfma_wg_kernel(const KfSmoothArgs A) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void kf_smooth_mfma_wg_kernel(const KfSmoothArgs A) {
   using L = WgSmLayout<KSR>;
   constexpr int KSRP = L::KSRP, LD = L::LD;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -82,10 +85,13 @@ __global__ __launch_bounds__(NT) void kf_smooth_mfma_wg_kernel(const KfSmoothArg
     }
   };
 
-  double TA[KSR], RQ[KSR];  // TA[s] = T[j][4 s + g]; RQ[s] = (R Q R')[4 s + g][j]
+  double RQ[KSR];  // RQ[s] = (R Q R')[4 s + g][j]
+  // TA(s) = T[j][4 s + g], own column block: read back from the image (registers are scarce at two
+  // wavefronts per SIMD)
+  auto TA = [&](int s) { return TL[(J * KSR + s) * KF_WAVE + lane]; };
   {
-    double* sR = B1;               // R     m x r   (Q is read from global memory: R and R Q of an
-    double* sRQ = sR + m * r_;     // R Q   m x r    m = r = 64 model fill B1 + B2 exactly)
+    double* sR = smem;             // R     m x r   (Q is read from global memory)
+    double* sRQ = sR + m * r_;     // R Q   m x r
     const double* gR = A.R + b * (long)m * r_;
     const double* gQ = A.Q + b * (long)r_ * r_;
     const double* gT = A.Tm + b * (long)mm;
@@ -106,9 +112,11 @@ __global__ __launch_bounds__(NT) void kf_smooth_mfma_wg_kernel(const KfSmoothArg
       if (on)
         for (int l = 0; l < r_; ++l) acc += sRQ[k * r_ + l] * sR[j * r_ + l];
       RQ[s] = acc;
-      TA[s] = on ? gT[j * m + k] : 0.0;
-      TL[(J * KSR + s) * KF_WAVE + lane] = TA[s];
     }
+    __syncthreads();  // scratch is dead
+#pragma unroll
+    for (int s = 0; s < KSR; ++s)
+      TL[(J * KSR + s) * KF_WAVE + lane] = (cok && rok(s)) ? gT[j * m + 4 * s + g] : 0.0;
     if (tid < 2 * 4 * KSRP) EXK[tid] = 0.0;
     if (tid < 4 * KSRP) EXD[tid] = 0.0;
     __syncthreads();
@@ -132,15 +140,13 @@ __global__ __launch_bounds__(NT) void kf_smooth_mfma_wg_kernel(const KfSmoothArg
   for (int t = n - 2; t >= 0; --t) {
     // ---- a_f, T a_f ; image of P_f ---------------------------------------------------------------------------
     const double af_c = cok ? gfa[(long)t * m + j] : 0.0;
-    double PF[KSR];
     {
       double part = 0.0;
 #pragma unroll
       for (int s = 0; s < KSR; ++s) {
-        PF[s] = (cok && rok(s)) ? gfP[(long)t * mm + obase + 4 * s * m] : 0.0;
-        B1[(J * KSR + s) * KF_WAVE + lane] = PF[s];
+        B1[(J * KSR + s) * KF_WAVE + lane] = (cok && rok(s)) ? gfP[(long)t * mm + obase + 4 * s * m] : 0.0;
         const double afr = rok(s) ? gfa[(long)t * m + 4 * s + g] : 0.0;
-        part = fma(TA[s], afr, part);
+        part = fma(TA(s), afr, part);
       }
       const double diff_c = as_c - col_allsum(part);  // a_s[t+1] - T a_f,  (T a_f)_j = sum_k T[j][k] a_k
       if (g == 0 && j < 4 * KSR) EXD[pos(j)] = diff_c;
@@ -159,7 +165,8 @@ __global__ __launch_bounds__(NT) void kf_smooth_mfma_wg_kernel(const KfSmoothArg
 #pragma unroll
       for (int I = 0; I < NBW; ++I)
         if (4 * I < KSR)
-          W2[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(B1[(I * KSR + ks) * KF_WAVE + lane], TA[ks], W2[I], 0, 0, 0);
+          W2[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(B1[(I * KSR + ks) * KF_WAVE + lane], TA(ks), W2[I], 0, 0, 0);
+    __syncthreads();  // image of P_f read by every wavefront: the buffer becomes the transpose tile
 #pragma unroll
     for (int ks = 0; ks < KSR; ++ks)
 #pragma unroll
@@ -226,26 +233,30 @@ __global__ __launch_bounds__(NT) void kf_smooth_mfma_wg_kernel(const KfSmoothArg
     }
     // Wt = X(:, J) = (P_hat^-1 T P_f)(:, J)
 
-    // ---- images of D and X ; E(:, J) = D X(:, J) ; P_s(:, J) = P_f(:, J) + X' E(:, J) ---------------------------
+    // ---- image of D ; E(:, J) = D X(:, J) ; image of X ; P_s(:, J) = P_f(:, J) + X' E(:, J) -------------------
 #pragma unroll
-    for (int s = 0; s < KSR; ++s) {
-      B1[(J * KSR + s) * KF_WAVE + lane] = D[s];
-      B2[(J * KSR + s) * KF_WAVE + lane] = Wt[s];
-    }
+    for (int s = 0; s < KSR; ++s) B1[(J * KSR + s) * KF_WAVE + lane] = D[s];
     __syncthreads();
     double4_t E[NBW], PSv[NBW];
 #pragma unroll
-    for (int I = 0; I < NBW; ++I) {
-      E[I] = double4_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) PSv[I][u] = (4 * I + u < KSR) ? PF[(4 * I + u < KSR) ? 4 * I + u : 0] : 0.0;
-    }
+    for (int I = 0; I < NBW; ++I) E[I] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int ks = 0; ks < KSR; ++ks)
 #pragma unroll
       for (int I = 0; I < NBW; ++I)
         if (4 * I < KSR)
           E[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(B1[(I * KSR + ks) * KF_WAVE + lane], Wt[ks], E[I], 0, 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KSR; ++s) B2[(J * KSR + s) * KF_WAVE + lane] = Wt[s];
+#pragma unroll
+    for (int I = 0; I < NBW; ++I)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // seed: P_f, re-read (L2) rather than held through the elimination
+        const int s = (4 * I + u < KSR) ? 4 * I + u : 0;
+        PSv[I][u] = (4 * I + u < KSR && cok && rok(s)) ? gfP[(long)t * mm + obase + 4 * s * m] : 0.0;
+      }
+    __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < KSR; ++ks)
 #pragma unroll
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(NT) void kf_smooth_mfma_wg_kernel(const KfSmoothArg
 
 template <int KSR>
 int launch_sm_wg(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream) {
-  const size_t lds = sizeof(double) * (size_t)WgSmLayout<KSR>::LOOP;
+  const size_t lds = sizeof(double) * (size_t)WgSmLayout<KSR>::doubles(a.m, a.r);
   static bool attr_set = false;
   if (!attr_set) {
     KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&kf_smooth_mfma_wg_kernel<KSR>),
