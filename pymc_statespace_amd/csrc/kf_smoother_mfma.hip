@@ -21,13 +21,6 @@ namespace {
 
 constexpr int TILE = 16;
 
-// all-reduce max over the wavefront
-__device__ __forceinline__ double wave_allmax(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, KF_WAVE));
-  return x;
-}
-
 template <int KS>
 __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) void kf_smooth_mfma_kernel(
     const KfSmoothArgs A, int32_t* flags) {

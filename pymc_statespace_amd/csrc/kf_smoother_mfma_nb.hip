@@ -24,25 +24,6 @@
 
 namespace {
 
-__device__ __forceinline__ double wave_allmax_nb(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, KF_WAVE));
-  return x;
-}
-
-template <int G_SRC>
-__device__ __forceinline__ double gb(double x) {
-  return group_bcast<G_SRC>(x);
-}
-__device__ __forceinline__ double group_bcast_rt(double x, int kg) {  // kg compile-time after unrolling
-  switch (kg) {
-    case 0: return gb<0>(x);
-    case 1: return gb<1>(x);
-    case 2: return gb<2>(x);
-    default: return gb<3>(x);
-  }
-}
-
 template <int NB, int KSR>
 struct NbSmLayout {
   static constexpr int KSRP = KSR + (KSR & 1);
@@ -274,7 +255,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB == 2
     for (int J = 0; J < NB; ++J)
 #pragma unroll
       for (int s = 0; s < KSR; ++s) dg = (16 * J + c == 4 * s + g) ? fmax(dg, PH[J][s]) : dg;
-    const double tol = 1e-9 * wave_allmax_nb(dg);
+    const double tol = 1e-9 * wave_allmax(dg);
 
     // ---- Gauss-Jordan: (P_hat | W) -> (I | X) ------------------------------------------------------------------
 #pragma unroll
@@ -284,8 +265,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB == 2
         double rowA[NB], rowW[NB];
 #pragma unroll
         for (int J = 0; J < NB; ++J) {
-          if (J >= Jk) rowA[J] = group_bcast_rt(PH[J][ks], kg);
-          rowW[J] = group_bcast_rt(Wt[J][ks], kg);
+          if (J >= Jk) rowA[J] = group_bcast_sel(PH[J][ks], kg);
+          rowW[J] = group_bcast_sel(Wt[J][ks], kg);
         }
         const double d = readlane_f64(rowA[Jk], k & 15);
         bad = bad || !(d > tol);

@@ -25,19 +25,6 @@ namespace {
 constexpr int NBW = 4;
 constexpr int NT = NBW * KF_WAVE;
 
-template <int G_SRC>
-__device__ __forceinline__ double gbw(double x) {
-  return group_bcast<G_SRC>(x);
-}
-__device__ __forceinline__ double group_bcast_sel(double x, int kg) {  // kg compile-time after unrolling
-  switch (kg) {
-    case 0: return gbw<0>(x);
-    case 1: return gbw<1>(x);
-    case 2: return gbw<2>(x);
-    default: return gbw<3>(x);
-  }
-}
-
 template <int KSR>
 struct WgSmLayout {
   static constexpr int KSRP = KSR + (KSR & 1);
@@ -192,8 +179,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void kf
       }
       read_rows(EXD, dfr);
       // pivot threshold: 1e-9 x the largest diagonal entry of P_hat (over the four wavefronts)
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) dg = fmax(dg, __shfl_xor(dg, o, KF_WAVE));
+      dg = wave_allmax(dg);
       if (lane == 0) RED[J] = dg;
     }
     __syncthreads();

@@ -71,6 +71,23 @@ __device__ __forceinline__ double group_bcast(double x) {
   return (G_SRC & 2) ? __hiloint2double(d[1], c[1]) : __hiloint2double(d[0], c[0]);
 }
 
+// group_bcast with the source group chosen by a value that is a compile-time constant after unrolling
+__device__ __forceinline__ double group_bcast_sel(double x, int g_src) {
+  switch (g_src) {
+    case 0: return group_bcast<0>(x);
+    case 1: return group_bcast<1>(x);
+    case 2: return group_bcast<2>(x);
+    default: return group_bcast<3>(x);
+  }
+}
+
+// all-reduce max over the wavefront
+__device__ __forceinline__ double wave_allmax(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, KF_WAVE));
+  return x;
+}
+
 // 1/x to rounding accuracy: v_rcp_f64 + two Newton steps (x finite, normal, > 0)
 __device__ __forceinline__ double fast_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
