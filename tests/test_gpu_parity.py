@@ -1702,3 +1702,17 @@ def test_mid_size_kernels_at_a_full_size_batch(eng, m):
     ra, rP = kn.kalman_smoother(base["T"], base["R"], base["Q"], ref["filtered_states"], ref["filtered_covs"])
     assert_allclose(sa[-7:].cpu().numpy(), ra[idx[-7:]], rtol=1e-7, atol=1e-8)
     assert_allclose(sP[-7:].cpu().numpy(), rP[idx[-7:]], rtol=1e-7, atol=1e-8)
+
+
+def test_random_shapes_against_the_oracles(eng):
+    """scripts/gpu_fuzz.py: random (p, m, r, n, filter, constants, missing data, intercepts) up to
+    m = 71 -- whatever kernel AUTO picks must match the CPU oracles (forward tapes, gradient, smoother)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import gpu_fuzz
+
+    flagged, worst, kernels = gpu_fuzz.run(n_cases=60, seed=7, eng=eng, verbose=False)
+    assert flagged == 0, worst
+    assert len(kernels) >= 4  # several kernel families were exercised
