@@ -141,7 +141,8 @@ const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* dims);
  * with a dense H: forward 4 B m^2 doubles; smoother 6 B m^2 doubles; gradient 7 B m^2 + 2 B m T
  * doubles) and, a few bytes per draw, for the register-tile smoother
  * smoothers
- * (5 <= m <= 47: per-draw flags; without them kf_smoother uses the slower LDS kernel). */
+ * (5 <= m <= 64: per-draw flags; without them kf_smoother uses the slower LDS kernel, m <= 47, or
+ * cannot redo singular draws with the pseudo-inverse, 47 < m <= 64). */
 int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes);
 
 /* Forward filter for B draws.  c, d may be NULL (= 0: initialize_intercepts,
@@ -178,9 +179,9 @@ int kf_filter_backward(kf_handle* h, const kf_dims* dims,
  * Only dims->B, T, m, r are used.  The gain uses the Moore-Penrose pseudo-inverse of
  * the one-step prediction covariance with numpy's default cutoff 1e-15 * sigma_max
  * (kalman_smoother.py:92): a Cholesky / Gauss-Jordan solve whenever that covariance is safely
- * positive definite, a Jacobi eigen-decomposition otherwise (m <= 47; beyond that
- * positive definiteness is required: the workgroup kernel, 47 < m <= 64, returns NaN for a draw
- * that fails the test, the workspace path's Cholesky likewise).  `workspace`: see kf_workspace_bytes. */
+ * positive definite, a Jacobi eigen-decomposition otherwise (m <= 64, given the
+ * per-draw flag workspace -- without it the 47 < m <= 64 kernel returns NaN for such a draw;
+ * beyond m = 64 the workspace path's Cholesky requires positive definiteness).  `workspace`: see kf_workspace_bytes. */
 int kf_smoother(kf_handle* h, const kf_dims* dims,
                 const double* T, const double* R, const double* Q,
                 const double* filt_a, const double* filt_P,

@@ -408,7 +408,7 @@ extern "C" int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_
       (!kf_forward_lds_fits(m, p) || m > KF_NB_M_MAX) &&
       !kf_nb_ok(h, m, p, r, dims->filter, dims->flags) && !kf_wg_ok(h, m, p, r, dims->filter, dims->flags))
     *bytes = kf_forward_big_workspace_bytes(dims->B, m, p);
-  if (m >= 1 && m <= KF_NB_M_MAX) {  // flags of the register-tile smoothers
+  if (m >= 1 && m <= KF_WG_M_MAX) {  // flags of the register-tile smoothers
     const size_t sm = kf_smoother_mfma_workspace_bytes(dims->B);
     if (sm > *bytes) *bytes = sm;
   }
@@ -506,7 +506,7 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
   // 47 < m <= 64: four wavefronts per draw (measured: 1.2 - 1.6 s per 1000 steps at 4096 draws on the
   // workspace path)
   if (kf_smoother_mfma_wg_ok(a.m, a.r) && h->forward_kernel != KF_KERNEL_LDS)
-    return kf_launch_smoother_mfma_wg(h, a, (hipStream_t)stream);
+    return kf_launch_smoother_mfma_wg(h, a, workspace, workspace_bytes, (hipStream_t)stream);
   if (!kf_smoother_lds_fits(a.m))
     return kf_launch_smoother_big(h, a, workspace, workspace_bytes, (hipStream_t)stream);
   return kf_launch_smoother_lds(h, a, (hipStream_t)stream);

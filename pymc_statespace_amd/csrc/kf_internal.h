@@ -215,7 +215,9 @@ int kf_launch_smoother_mfma_nb(kf_handle* h, const KfSmoothArgs& a, void* worksp
                                hipStream_t stream);
 // workgroup-per-draw smoother (kf_smoother_mfma_wg.hip): 47 < m <= 64, no workspace
 bool kf_smoother_mfma_wg_ok(int m, int r);
-int kf_launch_smoother_mfma_wg(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream);
+int kf_launch_smoother_mfma_wg(kf_handle* h, const KfSmoothArgs& a, void* workspace, size_t workspace_bytes,
+                               hipStream_t stream);
+int kf_launch_smoother_pinv_wide(kf_handle* h, const KfSmoothArgs& a, const int32_t* flags, hipStream_t stream);
 // large-m smoother (kf_smoother_big.hip): HBM workspace, blocked Cholesky, fp64-MFMA GEMMs
 size_t kf_smoother_big_workspace_bytes(long B, int m);
 int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace, size_t workspace_bytes,

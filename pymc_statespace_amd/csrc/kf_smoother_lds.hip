@@ -351,7 +351,148 @@ int launch_g(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream) {
   return KF_OK;
 }
 
+// Lean pinv smoother for the draws the workgroup kernel (kf_smoother_mfma_wg.hip, 47 < m <= 64)
+// flagged as not safely positive definite: one wavefront per flagged draw, every step with the
+// Moore-Penrose inverse as the reference does (kalman_smoother.py:92).  Four m x m regions in LDS
+// (A: P_hat -> W -> E;  V: Jacobi vectors -> X;  Pi: pinv -> D;  RQR static), everything else
+// streams from the tapes; throughput is irrelevant here (rare draws), ~5 m^3 LDS-fed MACs per step.
+__global__ __launch_bounds__(KF_WAVE) void kf_smooth_pinv_wide_kernel(const KfSmoothArgs A, const int32_t* flags) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const long b = blockIdx.x;
+  if (!flags[b]) return;
+  const int lane = threadIdx.x;
+  const int n = A.T, m = A.m, r_ = A.r, mm = m * m;
+  double* Am = smem;          // P_hat, then W = T P_f, then E
+  double* V = Am + mm;        // Jacobi eigenvectors, then X = pinv(P_hat) W
+  double* Pi = V + mm;        // pinv(P_hat), then D = P_s[t+1] - P_hat
+  double* RQR = Pi + mm;      // R Q R'
+  double* ev = RQR + mm;      // m
+  double* cs = ev + m;        // 4 ceil(m / 2)
+  double* va = cs + 4 * ((m + 1) / 2);  // a_f (m), diff (m)
+  const double* gT = A.Tm + b * (long)mm;
+  const double* gR = A.R + b * (long)m * r_;
+  const double* gQ = A.Q + b * (long)r_ * r_;
+  const double* gfa = A.filt_a + b * (long)n * m;
+  const double* gfP = A.filt_P + b * (long)n * mm;
+  double* gsa = A.smooth_a + b * (long)n * m;
+  double* gsP = A.smooth_P + b * (long)n * mm;
+  // R Q R' (R Q, m x r with r <= 2 m, staged across Am | V | Pi)
+  for (int e = lane; e < m * r_; e += KF_WAVE) {
+    const int i = e / r_, l = e - i * r_;
+    double v = 0.0;
+    for (int k = 0; k < r_; ++k) v += gR[i * r_ + k] * gQ[k * r_ + l];
+    Am[e] = v;
+  }
+  wsync();
+  for (int e = lane; e < mm; e += KF_WAVE) {
+    const int i = e / m, j = e - i * m;
+    double v = 0.0;
+    for (int l = 0; l < r_; ++l) v += Am[i * r_ + l] * gR[j * r_ + l];
+    RQR[e] = v;
+  }
+  for (int e = lane; e < mm; e += KF_WAVE) gsP[(long)(n - 1) * mm + e] = gfP[(long)(n - 1) * mm + e];
+  for (int e = lane; e < m; e += KF_WAVE) gsa[(long)(n - 1) * m + e] = gfa[(long)(n - 1) * m + e];
+  wsync();
+  for (int t = n - 2; t >= 0; --t) {
+    const double* Pf = gfP + (long)t * mm;
+    const double* Psn = gsP + (long)(t + 1) * mm;
+    __threadfence_block();
+    // W = T P_f (in V for now) ; P_hat = W T' + RQR' (in Am)
+    for (int e = lane; e < mm; e += KF_WAVE) {
+      const int i = e / m, j = e - i * m;
+      double v = 0.0;
+      for (int k = 0; k < m; ++k) v = fma(gT[i * m + k], Pf[k * m + j], v);
+      V[e] = v;
+    }
+    wsync();
+    for (int e = lane; e < mm; e += KF_WAVE) {
+      const int i = e / m, j = e - i * m;
+      double v = RQR[e];
+      for (int k = 0; k < m; ++k) v = fma(V[i * m + k], gT[j * m + k], v);
+      Am[e] = v;
+    }
+    wsync();
+    // the Jacobi iteration wants an exactly symmetric matrix
+    for (int e = lane; e < mm; e += KF_WAVE) {
+      const int i = e / m, j = e - i * m;
+      if (i < j) {
+        const double v = 0.5 * (Am[i * m + j] + Am[j * m + i]);
+        Am[i * m + j] = v;
+        Am[j * m + i] = v;
+      }
+    }
+    wsync();
+    pinv_jacobi<KF_WAVE>(Am, V, Pi, ev, cs, m, lane);  // Pi = pinv(P_hat); Am, V destroyed
+    // W again (Am) ; X = Pi W (V)
+    for (int e = lane; e < mm; e += KF_WAVE) {
+      const int i = e / m, j = e - i * m;
+      double v = 0.0;
+      for (int k = 0; k < m; ++k) v = fma(gT[i * m + k], Pf[k * m + j], v);
+      Am[e] = v;
+    }
+    wsync();
+    for (int e = lane; e < mm; e += KF_WAVE) {
+      const int i = e / m, j = e - i * m;
+      double v = 0.0;
+      for (int k = 0; k < m; ++k) v = fma(Pi[i * m + k], Am[k * m + j], v);
+      V[e] = v;
+    }
+    wsync();
+    // D = P_s[t+1] - P_hat (Pi), P_hat = W T' + RQR' recomputed from W
+    for (int e = lane; e < mm; e += KF_WAVE) {
+      const int i = e / m, j = e - i * m;
+      double v = RQR[e];
+      for (int k = 0; k < m; ++k) v = fma(Am[i * m + k], gT[j * m + k], v);
+      Pi[e] = Psn[e] - v;
+    }
+    // a_f, diff = a_s[t+1] - T a_f
+    for (int i = lane; i < m; i += KF_WAVE) va[i] = gfa[(long)t * m + i];
+    wsync();
+    for (int i = lane; i < m; i += KF_WAVE) {
+      double v = 0.0;
+      for (int k = 0; k < m; ++k) v = fma(gT[i * m + k], va[k], v);
+      va[m + i] = gsa[(long)(t + 1) * m + i] - v;
+    }
+    // E = D X (Am)
+    for (int e = lane; e < mm; e += KF_WAVE) {
+      const int i = e / m, j = e - i * m;
+      double v = 0.0;
+      for (int k = 0; k < m; ++k) v = fma(Pi[i * m + k], V[k * m + j], v);
+      Am[e] = v;
+    }
+    wsync();
+    // P_s[t] = P_f + X' E ; a_s[t] = a_f + X' diff
+    for (int e = lane; e < mm; e += KF_WAVE) {
+      const int i = e / m, j = e - i * m;
+      double v = Pf[e];
+      for (int k = 0; k < m; ++k) v = fma(V[k * m + i], Am[k * m + j], v);
+      gsP[(long)t * mm + e] = v;
+    }
+    for (int i = lane; i < m; i += KF_WAVE) {
+      double v = va[i];
+      for (int k = 0; k < m; ++k) v = fma(V[k * m + i], va[m + k], v);
+      gsa[(long)t * m + i] = v;
+    }
+    wsync();
+  }
+}
+
 }  // namespace
+
+// fallback of the workgroup smoother: draws with a non-zero flag, Jacobi pinv at every step
+int kf_launch_smoother_pinv_wide(kf_handle* h, const KfSmoothArgs& a, const int32_t* flags, hipStream_t stream) {
+  const int m = a.m;
+  const size_t lds = sizeof(double) * (size_t)(4 * m * m + 3 * m + 4 * ((m + 1) / 2) + 2);
+  if (lds > KF_LDS_BYTES_MAX || a.r > 3 * m) {
+    KF_SET_ERR(h, "smoother(pinv_wide): m=%d needs %zu B of LDS", m, lds);
+    return KF_ERR_UNSUPPORTED;
+  }
+  KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kf_smooth_pinv_wide_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kf_smooth_pinv_wide_kernel, dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a, flags);
+  KF_HIP_CHECK(h, hipGetLastError());
+  return KF_OK;
+}
 
 int kf_launch_smoother_lds(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream) {
   int G = kf_pick_lanes(h, a.m, a.B);

@@ -13,10 +13,11 @@
 // X: Gauss-Jordan on (P_hat | W) without exchanges, one barrier per pivot: the wavefront that holds
 // pivot column k publishes it (double-buffered), the pivot row is in every wavefront's own
 // registers (lane group k & 3, slice k >> 2).
-// Like the HBM-workspace smoother it replaces in this range (kf_smoother_big.hip: Cholesky, 1.2 -
-// 1.6 s per 1000 steps at 4096 draws), it needs positive definite prediction covariances: a pivot
-// below 1e-9 x the largest diagonal entry turns the draw's outputs into NaN (the LDS-resident
-// pinv fallback of the smaller kernels does not fit m > 47).
+// A pivot below 1e-9 x the largest diagonal entry flags the draw: with the per-draw flag workspace
+// (4 B + 64 bytes) its results are recomputed afterwards by kf_smooth_pinv_wide_kernel
+// (kf_smoother_lds.hip: Jacobi pinv at every step, as the reference), which exits at once for
+// unflagged draws; without the workspace the draw's outputs become NaN.  (The HBM-workspace smoother
+// this kernel replaces in the range, 1.2 - 1.6 s per 1000 steps at 4096 draws, is Cholesky only.)
 #include "kf_internal.h"
 #include "kf_tile.h"
 
@@ -44,7 +45,8 @@ struct WgSmLayout {
 };
 
 template <int KSR>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void kf_smooth_mfma_wg_kernel(const KfSmoothArgs A) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void kf_smooth_mfma_wg_kernel(const KfSmoothArgs A,
+                                                                                                     int32_t* flags) {
   using L = WgSmLayout<KSR>;
   constexpr int KSRP = L::KSRP, LD = L::LD;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -262,7 +264,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void kf
     }
     __syncthreads();  // the images are rewritten by the next step
   }
-  if (bad) {  // not safely positive definite: no pinv fallback in this range -- NaN, loudly
+  if (flags) {  // the pinv kernel launched behind recomputes flagged draws (kf_smooth_pinv_wide_kernel)
+    if (tid == 0) flags[b] = bad ? 1 : 0;
+  } else if (bad) {  // no flag workspace: not safely positive definite -> NaN, loudly
     __threadfence();
     __syncthreads();
     const double qnan = __builtin_nan("");
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void kf
 }
 
 template <int KSR>
-int launch_sm_wg(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream) {
+int launch_sm_wg(kf_handle* h, const KfSmoothArgs& a, int32_t* flags, hipStream_t stream) {
   const size_t lds = sizeof(double) * (size_t)WgSmLayout<KSR>::doubles(a.m, a.r);
   static bool attr_set = false;
   if (!attr_set) {
@@ -280,7 +284,7 @@ int launch_sm_wg(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, KF_LDS_BYTES_MAX));
     attr_set = true;
   }
-  hipLaunchKernelGGL((kf_smooth_mfma_wg_kernel<KSR>), dim3((unsigned)a.B), dim3(NT), lds, stream, a);
+  hipLaunchKernelGGL((kf_smooth_mfma_wg_kernel<KSR>), dim3((unsigned)a.B), dim3(NT), lds, stream, a, flags);
   KF_HIP_CHECK(h, hipGetLastError());
   return KF_OK;
 }
@@ -298,16 +302,25 @@ bool kf_smoother_mfma_wg_ok(int m, int r) {
   }
 }
 
-int kf_launch_smoother_mfma_wg(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream) {
+int kf_launch_smoother_mfma_wg(kf_handle* h, const KfSmoothArgs& a, void* workspace, size_t workspace_bytes,
+                               hipStream_t stream) {
   if (!kf_smoother_mfma_wg_ok(a.m, a.r)) {
     KF_SET_ERR(h, "smoother(mfma_wg): m=%d r=%d out of range (47 < m <= %d)", a.m, a.r, KF_WG_M_MAX);
     return KF_ERR_UNSUPPORTED;
   }
+  // with the per-draw flag workspace (kf_workspace_bytes) flagged draws are redone with the pinv; without
+  // it they come back as NaN
+  int32_t* flags = nullptr;
+  if (workspace && workspace_bytes >= kf_smoother_mfma_workspace_bytes(a.B))
+    flags = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(workspace) + 63) & ~(uintptr_t)63);
+  int rc;
   switch ((a.m + 3) / 4) {
-    case 12: return launch_sm_wg<12>(h, a, stream);
-    case 13: return launch_sm_wg<13>(h, a, stream);
-    case 14: return launch_sm_wg<14>(h, a, stream);
-    case 15: return launch_sm_wg<15>(h, a, stream);
-    default: return launch_sm_wg<16>(h, a, stream);
+    case 12: rc = launch_sm_wg<12>(h, a, flags, stream); break;
+    case 13: rc = launch_sm_wg<13>(h, a, flags, stream); break;
+    case 14: rc = launch_sm_wg<14>(h, a, flags, stream); break;
+    case 15: rc = launch_sm_wg<15>(h, a, flags, stream); break;
+    default: rc = launch_sm_wg<16>(h, a, flags, stream); break;
   }
+  if (rc != KF_OK || !flags) return rc;
+  return kf_launch_smoother_pinv_wide(h, a, flags, stream);
 }

@@ -1477,8 +1477,8 @@ def test_workgroup_smoother_matches_oracle(eng, m):
     sa, sP = eng.smooth(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
     assert_allclose(sa.cpu().numpy(), ra, rtol=1e-8, atol=1e-8)
     assert_allclose(sP.cpu().numpy(), rP, rtol=1e-8, atol=1e-8)
-    # exactly singular prediction covariance (no state noise, a state known exactly): this range has no
-    # pinv fallback -- the draw comes back as NaN, the other draws are untouched
+    # exactly singular prediction covariance (no state noise, initial state known exactly): the draw is
+    # flagged and redone by kf_smooth_pinv_wide_kernel (Jacobi pinv, as the reference); the others stay
     w0 = W.random_dense(3, 12, 1, m, m, seed=280 + m)
     Q = w0["Q"].copy()
     Q[1] = 0.0
@@ -1487,10 +1487,21 @@ def test_workgroup_smoother_matches_oracle(eng, m):
     flt0 = kn.kalman_filter(w0["y"], w0["a0"], P0, w0["T"], w0["Z"], w0["R"], w0["H"], Q)
     ra0, rP0 = kn.kalman_smoother(w0["T"], w0["R"], Q, flt0["filtered_states"], flt0["filtered_covs"])
     sa0, sP0 = eng.smooth(w0["T"], w0["R"], Q, flt0["filtered_states"], flt0["filtered_covs"])
-    sa0, sP0 = sa0.cpu().numpy(), sP0.cpu().numpy()
-    assert np.isnan(sa0[1]).all() and np.isnan(sP0[1]).all()
-    assert_allclose(sa0[[0, 2]], ra0[[0, 2]], rtol=1e-8, atol=1e-8)
-    assert_allclose(sP0[[0, 2]], rP0[[0, 2]], rtol=1e-8, atol=1e-8)
+    assert_allclose(sa0.cpu().numpy(), ra0, rtol=1e-8, atol=1e-8)
+    assert_allclose(sP0.cpu().numpy(), rP0, rtol=1e-8, atol=1e-8)
+    # rank-deficient but not zero: state noise on 5 of m directions, P0 of rank 7
+    w1 = W.random_dense(2, 10, 1, m, 5, seed=290 + m)
+    rng = np.random.default_rng(m)
+    Lr = rng.standard_normal((2, m, 7))
+    P1 = Lr @ np.swapaxes(Lr, -1, -2)
+    flt1 = kn.kalman_filter(w1["y"], w1["a0"], P1, w1["T"], w1["Z"], w1["R"], w1["H"], w1["Q"])
+    ra1, rP1 = kn.kalman_smoother(w1["T"], w1["R"], w1["Q"], flt1["filtered_states"], flt1["filtered_covs"])
+    sa1, sP1 = eng.smooth(w1["T"], w1["R"], w1["Q"], flt1["filtered_states"], flt1["filtered_covs"])
+    # (eigenvalues of P_hat between the 1e-15 cutoff and ~1e-10 are kept by every pinv and amplify
+    # rounding noise by their reciprocal: the answers agree to what such a problem determines)
+    assert np.isfinite(sa1.cpu().numpy()).all() and np.isfinite(sP1.cpu().numpy()).all()
+    assert_allclose(sa1.cpu().numpy(), ra1, rtol=1e-2, atol=1e-3)
+    assert_allclose(sP1.cpu().numpy(), rP1, rtol=1e-2, atol=1e-3)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -1666,8 +1677,8 @@ def test_workspace_is_only_requested_where_a_workspace_path_runs(eng):
 
     assert ws(4096, 1000, 1, 10, 4) == 4 * 4096 + 64           # flags of the tile smoother
     assert ws(4096, 1000, 1, 40, 4) == 4 * 4096 + 64
-    assert ws(4096, 1000, 1, 64, 8) == 0                        # workgroup kernels: all on chip
-    assert ws(4096, 1000, 3, 60, 8, "standard", True) == 0
+    assert ws(4096, 1000, 1, 64, 8) == 4 * 4096 + 64            # workgroup kernels: all on chip (+ flags)
+    assert ws(4096, 1000, 3, 60, 8, "standard", True) == 4 * 4096 + 64
     assert ws(4096, 1000, 3, 60, 8, "standard", False) > 4096 * 60 * 60 * 8   # dense H: workspace paths
     assert ws(128, 100, 1, 367, 3) >= 7 * 128 * 367 * 367 * 8   # C5
 
