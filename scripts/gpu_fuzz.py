@@ -28,18 +28,22 @@ def run(n_cases=120, seed=2026, eng=None, verbose=True):
         ft = str(rng.choice(["standard", "cholesky", "univariate"] + (["single"] if p == 1 else [])))
         mvn = str(rng.choice(["reference", "exact"]))
         B = int(rng.integers(1, 5))
-        w = W.random_dense(B, n, p, m, r, seed=int(rng.integers(1 << 30)))
+        dense_h = p > 1 and m <= 40 and rng.random() < 0.2  # joint update with a full H: generic LDS kernels
+        w = W.random_dense(B, n, p, m, r, seed=int(rng.integers(1 << 30)), h_diag=not dense_h)
         y = w["y"].copy()
         if n == 1:
             y[:] = 0.2
         if n > 4:
             y[rng.integers(0, n)] = np.nan
-            if p > 1:
+            if p > 1 and not dense_h:
                 y[rng.integers(0, n), rng.integers(0, p)] = np.nan
+        per_draw = n > 1 and rng.random() < 0.25
+        if per_draw:
+            y = y[None] + 0.1 * rng.standard_normal((B,) + y.shape)
         c = 0.1 * rng.standard_normal((B, m)) if rng.random() < 0.5 else None
         d = 0.1 * rng.standard_normal((B, p)) if rng.random() < 0.5 else None
         args = (y, w["a0"], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"])
-        name = eng.forward_kernel_name(B, n, p, m, r, ft, True)
+        name = eng.forward_kernel_name(B, n, p, m, r, ft, not dense_h)
         kernels[name] = kernels.get(name, 0) + 1
         ref = kn.kalman_filter(*args, c=c, d=d, filter_type=ft, mvn_const=mvn, cholesky_triangle="correct",
                                partial_missing="delete")
@@ -52,13 +56,26 @@ def run(n_cases=120, seed=2026, eng=None, verbose=True):
         e_g = 0.0
         if n <= 40 and m <= 64:
             g_logp = rng.standard_normal(B)
+            g_ll = rng.standard_normal((B, n)) if rng.random() < 0.3 else None
             fto = "standard" if ft == "cholesky" else ft
-            _, _, gt = kt.logp_and_grads(*args, c=c, d=d, g_logp=g_logp, filter_type=fto, mvn_const=mvn)
+            if per_draw:
+                gts = [kt.logp_and_grads(y[i], *[x[i:i + 1] for x in args[1:]], c=None if c is None else c[i:i + 1],
+                                         d=None if d is None else d[i:i + 1], g_logp=g_logp[i:i + 1],
+                                         g_ll_obs=None if g_ll is None else g_ll[i:i + 1], filter_type=fto,
+                                         mvn_const=mvn)[2] for i in range(B)]
+                gt = {k: np.concatenate([gi[k] for gi in gts], axis=0) for k in kt.NAMES}
+            else:
+                _, _, gt = kt.logp_and_grads(*args, c=c, d=d, g_logp=g_logp, g_ll_obs=g_ll, filter_type=fto,
+                                             mvn_const=mvn)
             g = eng.backward(*args, c=c, d=d, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
-                             g_logp=g_logp, filter_type=ft, mvn_const=mvn, want_cd=True, h_diagonal=True)
+                             g_logp=g_logp, g_ll_obs=g_ll, filter_type=ft, mvn_const=mvn, want_cd=True,
+                             h_diagonal=not dense_h)
             for k in kt.NAMES:
                 a, b_ = g[k].cpu().numpy(), gt[k]
-                if k == "H" and p > 1:
+                if dense_h and ft != "univariate":
+                    if k in ("P0", "Q", "H"):  # entrywise partials of symmetric inputs: compare symmetric parts
+                        a, b_ = a + np.swapaxes(a, -1, -2), b_ + np.swapaxes(b_, -1, -2)
+                elif k == "H" and p > 1:
                     a, b_ = np.diagonal(a, axis1=-2, axis2=-1), np.diagonal(b_, axis1=-2, axis2=-1)
                 elif k in ("P0", "Q") and (p > 1 or ft == "univariate"):
                     a, b_ = a + np.swapaxes(a, -1, -2), b_ + np.swapaxes(b_, -1, -2)
@@ -84,7 +101,7 @@ def run(n_cases=120, seed=2026, eng=None, verbose=True):
         flagged += 0 if ok else 1
         flag = "" if ok else "   <-- CHECK"
         if verbose or not ok:
-            print(f"{case:3d} p={p} m={m:2d} r={r:2d} n={n:2d} B={B} {ft:10s} {mvn:9s} {name:26s} "
+            print(f"{case:3d} p={p} m={m:2d} r={r:2d} n={n:2d} B={B} {ft:10s} {mvn:9s} {'H' if dense_h else '-'}{'y' if per_draw else '-'} {name:26s} "
                   f"dlogp {e_lp:.1e} tapes {e_tp:.1e} grad {e_g:.1e} smooth {e_s:.1e}{flag}", flush=True)
     print("kernels:", kernels)
     print("worst:", {k: f"{v:.2e}" for k, v in worst.items()}, f"flagged: {flagged}", f"({time.time() - t0:.0f} s)")
