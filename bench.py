@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- Kalman log-likelihood throughput on MI355X (contract: see the round brief).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c2|c3|c4|c4_m10]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c2|c3|c4|c4_m10|weekly|hourly]
 
 A "step" is ONE pass of the hot path over one batch of synthetic draws already resident in
 HBM: the fused forward filter (reference pymc_statespace/filters/kalman_filter.py:126-252)

@@ -320,4 +320,8 @@ WORKLOADS = {
     "c4": lambda **kw: varmax(**{**dict(B=16384, n=1000, order=(2, 1)), **kw}),
     "c4_m10": lambda **kw: varmax(**{**dict(B=16384, n=1000, order=(2, 0)), **kw}),
     "c5": lambda **kw: daily_seasonal(**{**dict(B=1024, n=730), **kw}),
+    # not a BASELINE config: level + trend + 52-week seasonal (m = 53), the shape of the workgroup kernels
+    "weekly": lambda **kw: daily_seasonal(**{**dict(B=4096, n=520, s=52), **kw}),
+    # level + trend + 24-period seasonal (m = 25): block-tile kernels
+    "hourly": lambda **kw: daily_seasonal(**{**dict(B=4096, n=1000, s=24), **kw}),
 }
