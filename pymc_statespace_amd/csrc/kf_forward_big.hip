@@ -35,7 +35,9 @@ constexpr int GPA = GTM * GK / GNT, GPB = GTN * GK / GNT;  // staged elements pe
 // C[b] (m x m) = A[b] (m x m) * op(B[b])  (+ E[b]);  op = identity or transpose.
 // grid: 1-D, 8 * tiles * ceil(draws / 8) workgroups (XCD-aware, see below)  block: 512.  Software pipeline: the next K chunk is fetched
 // from HBM/L2 into registers while the MFMAs of the current chunk run out of LDS.
-template <bool TRANS_B, bool ADD_E>
+// UPPER: the result is symmetric up to rounding and only its upper triangle is consumed (big_sym_kernel
+// mirrors it): tiles entirely below the diagonal are skipped -- a third of them at m = 367
+template <bool TRANS_B, bool ADD_E, bool UPPER = false>
 __global__ __launch_bounds__(GNT) void big_gemm_kernel(const double* __restrict__ A, long strideA,
                                                        const double* __restrict__ Bm, long strideB,
                                                        const double* __restrict__ E, long strideE,
@@ -55,6 +57,7 @@ __global__ __launch_bounds__(GNT) void big_gemm_kernel(const double* __restrict_
   if (b >= B) return;
   const int tile = (int)((L >> 3) % tiles);
   const int r0 = (tile / tiles_n) * GTM, c0 = (tile % tiles_n) * GTN;
+  if (UPPER && r0 > c0 + GTN - 1) return;
   const double* Ab = A + b * strideA;
   const double* Bb = Bm + b * strideB;
 
@@ -619,36 +622,36 @@ __global__ __launch_bounds__(256) void big_pf_kernel(const KfFwdArgs A, int t, c
   }
 }
 
-// P = (S + S')/2 via 32 x 32 LDS transposes; predicted covariance tape
+// P = upper triangle of S mirrored (S = T P_f T' + RQR' is symmetric up to rounding; the reference's
+// (S + S') / 2, :221, differs from this at rounding level only) via 32 x 32 LDS transposes;
+// predicted covariance tape.  Reads the upper half of S only: the GEMM skipped the tiles below.
 __global__ __launch_bounds__(256) void big_sym_kernel(const double* __restrict__ S, double* __restrict__ P,
                                                       double* pred_P, long tape_stride, int m) {
-  __shared__ double t1[32][33], t2[32][33];
+  __shared__ double t1[32][33];
   const long b = blockIdx.z;
   const long mm = (long)m * m;
   const int bi = blockIdx.y, bj = blockIdx.x;
-  if (bj < bi) return;  // tile pair (bi,bj) also writes (bj,bi)
+  if (bj < bi) return;  // tile (bi, bj), bi <= bj, also writes (bj, bi)
   const double* Sb = S + b * mm;
   double* Pb = P + b * mm;
   double* Tb = pred_P ? pred_P + b * tape_stride : nullptr;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   for (int rr = ty; rr < 32; rr += 8) {
-    int r1 = bi * 32 + rr, c1 = bj * 32 + tx;
+    const int r1 = bi * 32 + rr, c1 = bj * 32 + tx;
     t1[rr][tx] = (r1 < m && c1 < m) ? Sb[(long)r1 * m + c1] : 0.0;
-    int r2 = bj * 32 + rr, c2 = bi * 32 + tx;
-    t2[rr][tx] = (r2 < m && c2 < m) ? Sb[(long)r2 * m + c2] : 0.0;
   }
   __syncthreads();
   for (int rr = ty; rr < 32; rr += 8) {
-    int r1 = bi * 32 + rr, c1 = bj * 32 + tx;
+    const int r1 = bi * 32 + rr, c1 = bj * 32 + tx;
     if (r1 < m && c1 < m) {
-      double v = 0.5 * (t1[rr][tx] + t2[tx][rr]);
+      const double v = (bi != bj || rr <= tx) ? t1[rr][tx] : t1[tx][rr];
       Pb[(long)r1 * m + c1] = v;
       if (Tb) __builtin_nontemporal_store(v, Tb + (long)r1 * m + c1);
     }
     if (bi != bj) {
-      int r2 = bj * 32 + rr, c2 = bi * 32 + tx;
+      const int r2 = bj * 32 + rr, c2 = bi * 32 + tx;
       if (r2 < m && c2 < m) {
-        double v = 0.5 * (t2[rr][tx] + t1[tx][rr]);
+        const double v = t1[tx][rr];
         Pb[(long)r2 * m + c2] = v;
         if (Tb) __builtin_nontemporal_store(v, Tb + (long)r2 * m + c2);
       }
@@ -730,7 +733,7 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
     const unsigned ggrid = (unsigned)(8L * tgn * tgm * ((a.B + 7) / 8));
     hipLaunchKernelGGL((big_gemm_kernel<false, false>), dim3(ggrid), dim3(GNT), 0, stream,
                        a.Tm, (long)mm, Pf_ws, (long)mm, nullptr, 0L, W_ws, (long)mm, m, a.B, tgn, tgm);
-    hipLaunchKernelGGL((big_gemm_kernel<true, true>), dim3(ggrid), dim3(GNT), 0, stream,
+    hipLaunchKernelGGL((big_gemm_kernel<true, true, true>), dim3(ggrid), dim3(GNT), 0, stream,
                        W_ws, (long)mm, a.Tm, (long)mm, RQR_ws, (long)mm, Pf_ws, (long)mm, m, a.B, tgn, tgm);
     hipLaunchKernelGGL(big_sym_kernel, dim3(ts, ts, (unsigned)a.B), dim3(256), 0, stream, Pf_ws, P_ws,
                        a.pred_P ? a.pred_P + (size_t)(t + 1) * mm : nullptr, (long)(a.T + 1) * (long)mm, m);
