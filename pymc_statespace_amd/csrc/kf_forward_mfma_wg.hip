@@ -16,7 +16,8 @@
 //                               column block of (P_f symmetric), B = T[J][ks] (own registers)
 //     S(:, J)  = T W2(:, J) + RQR'(:, J)   A operand = T[I][ks] from its static LDS image
 //     P_hat = (S + S') / 2 (:221) through a 64 x 64 LDS transpose tile that reuses the image's
-//     buffer (p + 3 barriers per step).  2 x 4 x KSR MFMAs per wavefront and step, operands never
+//     buffer (p + 3 barriers per step).  (4 + 3) x KSR MFMAs per wavefront and step (S is symmetric:
+//     one block of every mirrored pair), operands never
 //     leave the CU; ~70 KB of LDS per draw: two draws per CU hide each other's barrier latency.
 #include "kf_internal.h"
 #include "kf_tile.h"
@@ -73,6 +74,8 @@ __global__ __launch_bounds__(NBW* KF_WAVE) __attribute__((amdgpu_waves_per_eu(2)
 
   const int j = 16 * J + c;  // this lane's column
   const bool cok = j < m;
+  // row blocks of S this wavefront computes (bit I): {0,1,2}, {1,2,3}, {2,3}, {3,0} -- see the predict step
+  const unsigned mine = (J == 0) ? 0x7u : (J == 1) ? 0xEu : (J == 2) ? 0xCu : 0x9u;
   auto rok = [&](int s) { return 4 * s + g < m; };
   auto pos = [&](int jj) { return (jj & 3) * KSRP + (jj >> 2); };
   auto read_rows = [&](const double* src, double (&x)[KSRP]) {
@@ -282,6 +285,9 @@ __global__ __launch_bounds__(NBW* KF_WAVE) __attribute__((amdgpu_waves_per_eu(2)
         if (4 * I < KSR)
           W2[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(PL[(I * KSR + ks) * KF_WAVE + lane], TA[ks], W2[I], 0, 0, 0);
     __syncthreads();  // every wavefront has read the image: its buffer becomes the transpose tile
+    // S is symmetric up to rounding: of every block pair {(I, J), (J, I)} only one is computed, the other
+    // is its mirror image through the transpose tile; diagonal blocks are averaged (:221).  `mine`:
+    // the row blocks I of column block J this wavefront computes -- 3, 3, 2, 2 blocks instead of 4 each
     double4_t S[NBW];
 #pragma unroll
     for (int I = 0; I < NBW; ++I)
@@ -291,20 +297,29 @@ __global__ __launch_bounds__(NBW* KF_WAVE) __attribute__((amdgpu_waves_per_eu(2)
     for (int ks = 0; ks < KSR; ++ks)
 #pragma unroll
       for (int I = 0; I < NBW; ++I)
-        if (4 * I < KSR)
+        if (4 * I < KSR && ((mine >> I) & 1))
           S[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(TL[(I * KSR + ks) * KF_WAVE + lane], W2[ks >> 2][ks & 3], S[I], 0, 0, 0);
     // transpose through LDS: element (i, j) at TR[i * LD + pos(j)]
 #pragma unroll
     for (int s = 0; s < KSR; ++s)
-      if (j < 4 * KSR) TR[(4 * s + g) * LD + pos(j)] = S[s >> 2][s & 3];
+      if (((mine >> (s >> 2)) & 1) && j < 4 * KSR) TR[(4 * s + g) * LD + pos(j)] = S[s >> 2][s & 3];
     __syncthreads();
     {
       const double* row = TR + (j < 4 * KSR ? j : 4 * KSR - 1) * LD + g * KSRP;
+      double tw[KSRP];
 #pragma unroll
       for (int s = 0; s < KSRP; s += 2) {
         const double2_t t2 = *reinterpret_cast<const double2_t*>(row + s);
-        P[s] = cok ? 0.5 * (S[s >> 2][s & 3] + t2.x) : 0.0;
-        if (s + 1 < KSR) P[s + 1 < KSR ? s + 1 : 0] = cok ? 0.5 * (S[(s + 1) >> 2][(s + 1) & 3] + t2.y) : 0.0;
+        tw[s] = t2.x;
+        tw[s + 1] = t2.y;
+      }
+#pragma unroll
+      for (int s = 0; s < KSR; ++s) {
+        const int I = s >> 2;
+        const double sv = S[I][s & 3];
+        // own diagonal block: average; computed here: as is; computed by the other wavefront: its mirror
+        const double v = (I == J) ? 0.5 * (sv + tw[s]) : (((mine >> I) & 1) ? sv : tw[s]);
+        P[s] = cok ? v : 0.0;
       }
     }
     read_rows(EXA, ar);
