@@ -10,8 +10,11 @@ from pymc_statespace_amd import KalmanEngine
 eng = KalmanEngine()
 print("| workload | B | T | p,m,r | forward (predicted tapes only) ms | gradient ms | logp + gradient ms | evaluations/s |")
 print("|---|---|---|---|---|---|---|---|")
-for name, kw, ft in (("headline", {}, "standard"), ("c3", {}, "cholesky"), ("c4", dict(B=16384), "standard"),
-                     ("hourly", {}, "standard"), ("weekly", {}, "standard")):
+CASES = (("headline", {}, "standard"), ("c3", {}, "cholesky"), ("c4", dict(B=16384), "standard"),
+         ("hourly", {}, "standard"), ("weekly", {}, "standard"))
+if len(sys.argv) > 1:  # few draws: the latency of one draw's T sequential steps (a few NUTS chains)
+    CASES = tuple((n_, dict(B=int(sys.argv[1])), f_) for n_, _, f_ in CASES)
+for name, kw, ft in CASES:
     w = W.WORKLOADS[name](**kw)
     d = [eng.to_device(w[k]) for k in ("y", "a0", "P0", "T", "Z", "R", "H", "Q")]
     B = w["B"]
