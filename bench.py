@@ -1,16 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- Kalman log-likelihood throughput on MI355X (contract: see the round brief).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|c2|c3|c4|c4_m10|weekly|hourly]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
+                    [--workload headline|c2|c3|c4|c4_m10|c5|weekly|hourly]
 
 A "step" is ONE pass of the hot path over one batch of synthetic draws already resident in
 HBM: the fused forward filter (reference pymc_statespace/filters/kalman_filter.py:126-252)
 for every draw, writing the same six outputs the reference graph registers
 (filtered/predicted states + covariances, logp, ll_obs -- core/statespace.py:164-174), i.e.
-the "reference-equivalent op" of SURVEY.md section 8(d), which is HBM-write bound.
-With N > 1 GPUs (one process per GPU, torch.distributed over RCCL) the draw axis is sharded
--- each rank filters its own B draws (weak scaling) -- and the per-draw log-likelihoods are
-all-gathered (the only exchange step of the path) inside the timed region.
+the "reference-equivalent op" of SURVEY.md section 8(d), which is HBM-write bound
+(workload c5, m = 367: logp only -- its tapes are 0.8 GB per draw -- and MFMA bound).
+
+Multi-GPU (`--gpus N`, N > 1): one process per GPU over RCCL.  Started without a launcher
+(no WORLD_SIZE in the environment) this script spawns `python -m torch.distributed.run
+--nproc-per-node N` on itself BEFORE anything touches the GPU and exits with its code; under
+a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE.  The draw axis is sharded through
+`pymc_statespace_amd.distributed.ShardedKalman` (contiguous shards, no data-path exchange)
+and the per-draw log-likelihoods are all-gathered inside the timed region -- the loop this
+axis replaces is the per-draw Python loop of reference core/statespace.py:230-236.
+  --scaling weak   (default) every GPU filters the workload's B draws: global batch N x B
+  --scaling strong the workload's B draws in total, B / N per GPU
+A weak run on N > 1 GPUs also reports a `strong_scaling` object: the same global batch as
+the 1-GPU run, sharded over the N GPUs, next to rank 0 filtering all of it alone.
 
 Prints ONE JSON line on rank 0.  `value` = draws filtered per second over all ranks
 ("evals/s": one evaluation = one draw's full T-step filter).
@@ -20,18 +31,24 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 measured copy)
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 measured copy)
+FP64_MFMA_PEAK_TF = 78.6  # dense fp64 matrix peak; v_mfma_f64_16x16x4_f64 measured at 45.2 TF with
+#                           register operands only (profiles/r01/fp64_issue_rates.txt)
 
 DEFAULT_FILTER = {"headline": "standard", "c2": "standard", "c3": "cholesky", "c4": "standard",
                   "c4_m10": "standard", "c1": "standard", "c5": "standard"}
+# draws per GPU when --batch is not given: the workload's own B, except C5 whose BASELINE batch
+# (1024) is quoted over 8 GPUs -- one GPU's share is 128 draws (0.28 GB of inputs)
+DEFAULT_BATCH = {"c5": 128}
+KEYS = ("a0", "P0", "T", "Z", "R", "H", "Q")
 
 
 def algorithmic_bytes(B, n, p, m, r, full_tape=True):
@@ -41,170 +58,333 @@ def algorithmic_bytes(B, n, p, m, r, full_tape=True):
     return B * (inp + out) + 8 * n * p
 
 
-def cpu_baseline(w, filter_type, full_tape=True, target_s=15.0, n_sample=None):
+def algorithmic_flops(B, n, p, m, r):
+    """dense flop count of the reference's own operation sequence
+    (Standard filter, Joseph form), per draw-step, times draws x steps."""
+    per_step = (8 * m ** 3 + m * m * (6 * p + 2 * r + 7) + m * (6 * p * p + 2 * r * r + 4 * p + 2)
+                + 3 * p ** 3 + 3 * p * p + 4 * p)
+    return float(per_step) * B * n
+
+
+def executed_flops_big(B, n, m):
+    """What the workspace path actually issues on the matrix cores per launch: two m^3 products per
+    draw-step (W = P_f T', S = T W; the second on the upper-triangle tiles only -- counted in full)."""
+    return 4.0 * m ** 3 * B * n
+
+
+def cpu_baseline(w, filter_type, full_tape=True, target_s=12.0, n_sample=None):
     """The C restatement of the reference algorithm (oracle/kf_oracle.c, kind "port") on the
     host cores, on the leading draws of the SAME workload, computing the same outputs.
+    Built here, on the box that times it, with -O3 -march=native (oracle/Makefile `native`).
 
     The sample is processed in chunks whose output tapes reuse one pre-touched host buffer
     (first-touch page faults of multi-GB fresh arrays would otherwise dominate the CPU time;
     recycling the buffer only favours the CPU)."""
+    import numpy as np
+
     from oracle import c_oracle as co
 
+    flavour = co.use_native()
     cores = os.cpu_count() or 1
-    chunk = max(8, 4 * cores)
     B = w["B"]
+    chunk = min(max(8, 4 * cores), B)
 
-    def run(lo, hi, out=None):
+    def run(lo, hi, out=None, full=full_tape):
         sl = slice(lo, hi)
         return co.kalman_filter(w["y"], w["a0"][sl], w["P0"][sl], w["T"][sl], w["Z"][sl],
                                 w["R"][sl], w["H"][sl], w["Q"][sl], filter_type=filter_type,
-                                full=full_tape, nthreads=cores, out=out)
+                                full=full, nthreads=cores, out=out)
 
-    chunk = min(chunk, B)
     buf = run(0, chunk)          # untimed: loads the library, touches the tape buffer
     t0 = time.perf_counter()
     run(0, chunk, out=buf)       # calibration pass
     rate = chunk / (time.perf_counter() - t0)
     if n_sample is None:
         n_sample = int(min(B, max(chunk, rate * target_s)))
-    n_sample = max(chunk, (n_sample // chunk) * chunk)
+    n_sample = min(B, max(chunk, (n_sample // chunk) * chunk))
     logp = np.empty(n_sample)
     t0 = time.perf_counter()
     for lo in range(0, n_sample, chunk):
-        run(lo, lo + chunk, out=buf)
-        logp[lo:lo + chunk] = buf["logp"]
+        hi = min(lo + chunk, n_sample)
+        if hi - lo == chunk:
+            run(lo, hi, out=buf)
+            logp[lo:hi] = buf["logp"]
+        else:
+            logp[lo:hi] = run(lo, hi)["logp"]
     dt = time.perf_counter() - t0
-    return logp, dict(value=n_sample / dt, unit="evals/s", cores=cores, kind="port",
-                      sample=f"first {n_sample} draws x all {w['n']} steps of the same workload, "
-                             f"{'full tapes' if full_tape else 'logp only'}, {dt:.2f} s wall, "
-                             f"oracle/kf_oracle.c, OpenMP over draws on {cores} threads")
+    out = dict(value=n_sample / dt, unit="evals/s", cores=cores, kind="port",
+               sample=f"first {n_sample} draws x all {w['n']} steps of the same workload, "
+                      f"{'full tapes' if full_tape else 'logp only'}, {dt:.2f} s wall, "
+                      f"oracle/kf_oracle.c ({flavour}), OpenMP over draws on {cores} threads")
+    if full_tape:
+        # the same sample with logp as the only output (what a sampler consumes): no tape stores
+        n2 = min(n_sample, 4 * chunk)
+        t0 = time.perf_counter()
+        for lo in range(0, n2, chunk):
+            run(lo, min(lo + chunk, n2), full=False)
+        out["value_logp_only"] = n2 / (time.perf_counter() - t0)
+    return logp, out
 
 
-def main():
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n):
+    """--gpus N without a launcher: start N ranks of this script (one per GPU).  Runs in a parent
+    that has imported neither torch nor HIP: a process that has touched the GPU must not spawn or
+    exec GPU children on this pool."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="headline")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--filter", default=None)
-    ap.add_argument("--batch", type=int, default=None, help="draws per GPU (default: workload's B)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="draws per GPU (weak) / in total (strong); default: the workload's B")
     ap.add_argument("--logp-only", action="store_true", help="skip the tapes (what NUTS consumes)")
     ap.add_argument("--cpu-sample", type=int, default=None)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-strong-probe", action="store_true",
+                    help="N > 1, weak: skip the extra strong-scaling measurement")
     ap.add_argument("--lanes", type=int, default=0)
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     import workloads as W
     from pymc_statespace_amd import KalmanEngine
+    from pymc_statespace_amd.distributed import ShardedKalman, shard_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("KF_BENCH_SHARE_GPU") == "1":
+            # test mode for 1-GPU boxes: every rank on cuda:0, exchange over gloo (RCCL refuses two
+            # ranks on one device).  Exercises the N > 1 control flow, not xGMI; never a bench number.
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            if local_rank >= torch.cuda.device_count():
+                sys.exit(f"bench.py: rank {rank} wants cuda:{local_rank} but only "
+                         f"{torch.cuda.device_count()} GPUs are visible")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
     ft = args.filter or DEFAULT_FILTER.get(args.workload, "standard")
-    kw = {} if args.batch is None else {"B": args.batch}
-    w = W.WORKLOADS[args.workload](**kw)  # same seeded draws on every rank (weak scaling)
-    B, n, p, m, r = w["B"], w["n"], w["p"], w["m"], w["r"]
-    full = not args.logp_only
+    B0 = args.batch or DEFAULT_BATCH.get(args.workload)
+    kw = {} if B0 is None else {"B": B0}
+    base = W.WORKLOADS[args.workload](**kw)   # the 1-GPU workload (seeded)
+    B0, n, p, m, r = base["B"], base["n"], base["p"], base["m"], base["r"]
+    big = m > 64                               # HBM-workspace path (C5): logp only, MFMA bound
+    full = not (args.logp_only or big)
+    strong = args.scaling == "strong"
 
     eng = KalmanEngine(dev, lanes_per_draw=args.lanes)
-    keys = ("y", "a0", "P0", "T", "Z", "R", "H", "Q")
-    d = [eng.to_device(w[k]) for k in keys]
+    sk = ShardedKalman(eng)
     fkw = dict(filter_type=ft, mvn_const="exact", store_ll_obs=full, store_filtered=full,
                store_predicted=full)
-    res = eng.forward(*d, **fkw)  # allocates the output tapes once; reused by every step
-    gathered = torch.empty(world * B, device=dev, dtype=torch.float64) if world > 1 else None
+
+    def shard_of(w, lo, hi):
+        return [eng.to_device(w["y"])] + [eng.to_device(w[k][lo:hi]) for k in KEYS]
+
+    # ---- the timed configuration -------------------------------------------------------------------
+    if strong or world == 1:
+        B_global = B0
+        lo, hi = shard_bounds(B_global, rank, world)
+        d = shard_of(base, lo, hi)
+        w_mine, lo_mine = base, lo
+    else:
+        # weak: rank k holds draws [k B0, (k+1) B0) of a global batch of world x B0 draws; the shard is
+        # generated from its own seed so that no rank materialises the whole batch on the host
+        B_global = world * B0
+        w_mine = W.WORKLOADS[args.workload](**{**kw, "seed": W.SEED_DRAWS + 1000 + rank}) if rank else base
+        lo, hi = rank * B0, (rank + 1) * B0
+        d = shard_of(w_mine, 0, B0)
+        lo_mine = 0
+    B_local = hi - lo
+    res_holder = {}
+
+    def one_step(inputs, Bg, out=None):
+        g, res = sk.forward(*inputs, B_global=Bg, out=out, **fkw)
+        return g, res
+
+    gathered, res = one_step(d, B_global)   # allocates the output tapes once; reused by every step
     torch.cuda.synchronize()
 
-    def step():
-        eng.forward(*d, out=res, **fkw)
+    def timed(inputs, Bg, out, steps, warmup):
+        for _ in range(warmup):
+            one_step(inputs, Bg, out)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(steps)]
+        torch.cuda.synchronize()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, res.logp)
+            dist.barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            # the events bracket the filter launch only; the all-gather of the per-draw
+            # log-likelihoods is outside them but inside the wall time
+            ev[k][0].record()
+            sk.forward_local(*inputs, out=out, **fkw)
+            ev[k][1].record()
+            res_holder["g"] = sk.gather_logp(out.logp, Bg)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64,
+                                device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if steps else float("nan")
+        return elapsed, kern_ms
 
-    for _ in range(args.warmup):
-        step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    if world > 1:
+    elapsed, kern_ms = timed(d, B_global, res, args.steps, args.warmup)
+    gathered = res_holder["g"]
+
+    # ---- N > 1, weak: the extra strong-scaling measurement (global batch = the 1-GPU run's) -----------
+    strong_obj = None
+    if world > 1 and not strong and not args.no_strong_probe:
+        slo, shi = shard_bounds(B0, rank, world)
+        ds = shard_of(base, slo, shi)
+        _, rs = one_step(ds, B0)
+        ks, kws = max(5, args.steps), 2
+        el_s, kern_s = timed(ds, B0, rs, ks, kws)
+        g_strong = res_holder["g"]
+        del rs, ds
+        # rank 0 alone on the full batch (the other ranks wait at the barrier)
+        el_1 = None
+        if rank == 0:
+            d1 = shard_of(base, 0, B0)
+            r1 = sk.forward_local(*d1, out=res if B_local == B0 else None, **fkw)
+            for _ in range(kws):
+                sk.forward_local(*d1, out=r1, **fkw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(ks):
+                sk.forward_local(*d1, out=r1, **fkw)
+            torch.cuda.synchronize()
+            el_1 = time.perf_counter() - t0
+            dmax = float((g_strong - r1.logp).abs().max().item())
+            strong_obj = {
+                "global_draws": B0, "draws_per_gpu": shi - slo, "steps": ks,
+                "ms_per_step": el_s / ks * 1e3, "value": B0 * ks / el_s, "unit": "evals/s",
+                "single_gpu_ms_per_step": el_1 / ks * 1e3,
+                "speedup_vs_single_gpu": el_1 / el_s,
+                "max_abs_dlogp_sharded_vs_single_gpu": dmax,
+            }
         dist.barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        eng.forward(*d, out=res, **fkw)
-        ev[k][1].record()
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, res.logp)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     if rank == 0:
-        abytes = algorithmic_bytes(B, n, p, m, r, full)
-        achieved = abytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(f"{args.workload}:{'full' if full else 'logp'}")
-            except Exception:  # noqa: BLE001
-                traffic = None
         out = {
             "metric": "Kalman logp evals/sec (batch x T x m)",
-            "value": world * B * args.steps / elapsed,
+            "value": B_global * args.steps / elapsed,
             "unit": "evals/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if os.environ.get("KF_BENCH_SHARE_GPU") != "1"
+            else "synthetic; TEST MODE: all ranks share cuda:0 over gloo -- not a measurement",
             "config": {
-                "workload": f"{args.workload}: {w['name']} B={B} draws/GPU x T={n} x m={m} "
+                "workload": f"{args.workload}: {base['name']} B={B_local} draws/GPU x T={n} x m={m} "
                             f"(p={p}, r={r}), {ft} filter, "
                             f"{'all six reference outputs written to HBM' if full else 'logp only'}",
-                "draws_per_gpu": B, "T": n, "k_states": m, "k_endog": p, "k_posdef": r,
+                "draws_per_gpu": B_local, "T": n, "k_states": m, "k_endog": p, "k_posdef": r,
                 "filter": ft, "outputs": "full_tape" if full else "logp_only",
-                "global_draws": world * B, "parallelism": f"draws sharded x{world}",
-                "draw_steps_per_s": world * B * n * args.steps / elapsed,
-            },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": eng.forward_kernel_name(B, n, p, m, r), "kernel_ms": kern_ms,
-                "algorithmic_bytes_per_launch": abytes,
+                "global_draws": B_global, "parallelism": f"draws sharded x{world}",
+                "draw_steps_per_s": B_global * n * args.steps / elapsed,
             },
         }
+        diag = bool(p > 1 and np.all(base["H"] == base["H"] * np.eye(p)))
+        kname = eng.forward_kernel_name(B_local, n, p, m, r, filter_type=ft, h_diagonal=diag)
+        if big:
+            aflops = algorithmic_flops(B_local, n, p, m, r)
+            ach = aflops / (kern_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": ach / FP64_MFMA_PEAK_TF, "traffic": None,
+                "kernel": kname, "kernel_ms": kern_ms, "launches_per_step": 7 * n,
+                "algorithmic_flops_per_launch": aflops,
+                "executed_tflops": executed_flops_big(B_local, n, m) / (kern_ms * 1e-3) / 1e12,
+                "note": "kernel_ms = the whole forward pass (7 launches per time step); achieved = "
+                        "SURVEY 8(d) dense flop count of the reference sequence / that time; "
+                        "executed_tflops counts the two m^3 MFMA products actually issued; the "
+                        "instruction's measured ceiling is 45.2 TF (profiles/r01/fp64_issue_rates.txt)",
+            }
+        else:
+            abytes = algorithmic_bytes(B_local, n, p, m, r, full)
+            achieved = abytes / (kern_ms * 1e-3) / 1e9
+            traffic, tsrc = None, None
+            tfile = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tfile):
+                try:
+                    ent = json.load(open(tfile)).get(f"{args.workload}:{'full' if full else 'logp'}:B{B_local}")
+                    if ent and ent.get("kernel", "").startswith(kname):
+                        traffic, tsrc = ent["bytes"], ent.get("source")
+                except Exception:  # noqa: BLE001
+                    traffic = None
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                "kernel": kname, "kernel_ms": kern_ms,
+                "algorithmic_bytes_per_launch": abytes,
+            }
+        if strong_obj is not None:
+            out["strong_scaling"] = strong_obj
         if not args.no_cpu:
-            # bounded sample (~15 s of host work); doubles as the in-bench parity check
-            cpu_logp, cb = cpu_baseline(w, ft, full, n_sample=args.cpu_sample)
-            ns = cpu_logp.shape[0]
+            # bounded sample (~12 s of host work); doubles as the in-bench parity check of the
+            # GATHERED log-likelihoods (rank 0's own draws lead the gathered vector)
+            cpu_logp, cb = cpu_baseline(w_mine if not strong else base, ft, full,
+                                        n_sample=args.cpu_sample,
+                                        target_s=12.0 if not big else 20.0)
+            ns = min(cpu_logp.shape[0], B_local)
             out["cpu_baseline"] = cb
-            dl = np.abs(res.logp[:ns].cpu().numpy() - cpu_logp)
+            dl = np.abs(gathered[lo_mine:lo_mine + ns].cpu().numpy() - cpu_logp[:ns])
             out["parity"] = {"max_abs_dlogp_vs_oracle": float(dl.max()), "draws_checked": int(ns),
                              "max_abs_logp": float(np.abs(cpu_logp).max())}
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -38,6 +38,9 @@
  *   - Return value: 0 ok; < 0 argument / HIP error (text via kf_last_error).
  *     Numerical failures are reported per draw through `info`, like LAPACK.
  *   - Threading: re-entrant per handle; one handle per (host thread, device).
+ *   - Devices: every entry point makes the handle's device current for the duration of the
+ *     call and restores the caller's current device on return; buffers and `stream` must
+ *     belong to the handle's device (NULL = that device's null stream).
  */
 #ifndef KF_H_
 #define KF_H_
@@ -49,7 +52,8 @@
 extern "C" {
 #endif
 
-#define KF_ABI_VERSION 2 /* 2: KF_FLAG_H_DIAGONAL, KF_KERNEL_MFMA, kf_dare, kf_simulate_statespace, workspace use by smoother/backward */
+#define KF_ABI_VERSION 3 /* 2: KF_FLAG_H_DIAGONAL, KF_KERNEL_MFMA, kf_dare, kf_simulate_statespace, workspace use by smoother/backward; \
+                            3: kf_workspace_bytes_for, kf_forward_kernel_name_ws; every entry point runs on the handle's device */
 
 typedef struct kf_handle kf_handle;
 
@@ -133,8 +137,11 @@ int kf_set_lanes_per_draw(kf_handle* h, int lanes);
  * rounding. */
 enum { KF_KERNEL_AUTO = 0, KF_KERNEL_LDS = 1, KF_KERNEL_ROW = 2, KF_KERNEL_LANE = 3, KF_KERNEL_MFMA = 4 };
 int kf_set_forward_kernel(kf_handle* h, int kernel);
-/* Name of the kernel kf_filter_forward would launch for `dims` (for profiles / bench logs). */
+/* Name of the kernel kf_filter_forward would launch for `dims` (for profiles / bench logs), assuming
+ * the caller passes the workspace kf_workspace_bytes asks for; the _ws form takes the size of the
+ * workspace the caller will actually pass (0 = none). */
 const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* dims);
+const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_dims* dims, size_t workspace_bytes);
 
 /* Scratch the three entry points need for `dims` (max over them, for the kernel selection in force
  * on `h`); may be 0.  Non-zero for k_states too large for the on-chip kernels (m > 64, or m > ~45
@@ -144,6 +151,11 @@ const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* dims);
  * (5 <= m <= 64: per-draw flags; without them kf_smoother uses the slower LDS kernel, m <= 47, or
  * cannot redo singular draws with the pseudo-inverse, 47 < m <= 64). */
 int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes);
+/* The same per entry point (`which`: OR of KF_WS_*), so that a forward-only or smoother-only caller
+ * does not hold the gradient's scratch.  The HBM-workspace kernels (m > 64) put the draw axis in
+ * gridDim.y/z: B <= 65535 there (KF_ERR_UNSUPPORTED beyond; chunk the batch). */
+enum { KF_WS_FORWARD = 1, KF_WS_BACKWARD = 2, KF_WS_SMOOTHER = 4, KF_WS_ALL = 7 };
+int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, int which, size_t* bytes);
 
 /* Forward filter for B draws.  c, d may be NULL (= 0: initialize_intercepts,
  * kalman_filter.py:36-51).  ll_obs / filt_* / pred_* / info may be NULL. */

@@ -9,6 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(_HERE, "_build", "libkf_oracle.so")
+LIB_NATIVE = os.path.join(_HERE, "_build", "libkf_oracle_native.so")
 FILTERS = {"standard": 0, "cholesky": 1, "univariate": 2, "single": 3}
 _lib = None
 
@@ -17,12 +18,29 @@ def build():
     subprocess.check_call(["make", "-C", _HERE, "-s"])
 
 
-def load():
+def use_native():
+    """bench.py's cpu_baseline leg: (re)build with -O3 -march=native ON THIS HOST and load that
+    library from now on.  Returns a label of the flavour in use; falls back to the portable build
+    when the host has no compiler."""
+    global _lib
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"])
+    except Exception:  # noqa: BLE001
+        load()
+        return "-O2 portable build"
+    _lib = None
+    load(LIB_NATIVE)
+    return "-O3 -march=native, built on this host"
+
+
+def load(path=None):
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
-            build()
-        _lib = C.CDLL(LIB)
+        if path is None:
+            path = LIB
+            if not os.path.exists(LIB):
+                build()
+        _lib = C.CDLL(path)
         dp = C.c_void_p
         _lib.kf_oracle_filter.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_uint] + [dp] * 17 + [C.c_int]

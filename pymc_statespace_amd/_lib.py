@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkf_hip.so")
 
-KF_ABI_VERSION = 2
+KF_ABI_VERSION = 3
 
 KF_FILTER = {"standard": 0, "cholesky": 1, "univariate": 2, "single": 3}
 KF_FLAG_MVN_CONST_EXACT = 1 << 0
@@ -19,13 +19,14 @@ KF_FLAG_Y_PER_DRAW = 1 << 1
 KF_FLAG_H_DIAGONAL = 1 << 11
 KF_FLAG_TV = {"T": 1 << 4, "Z": 1 << 5, "R": 1 << 6, "H": 1 << 7, "Q": 1 << 8, "c": 1 << 9, "d": 1 << 10}
 
+KF_WS_FORWARD, KF_WS_BACKWARD, KF_WS_SMOOTHER, KF_WS_ALL = 1, 2, 4, 7
 KF_OK, KF_ERR_ARG, KF_ERR_HIP, KF_ERR_WORKSPACE, KF_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 
 # every symbol include/kf.h declares (tests check the built library exports them all)
 EXPORTS = (
     "kf_abi_version", "kf_create", "kf_destroy", "kf_last_error", "kf_set_lanes_per_draw",
-    "kf_set_forward_kernel", "kf_forward_kernel_name",
-    "kf_workspace_bytes", "kf_filter_forward", "kf_filter_backward", "kf_smoother",
+    "kf_set_forward_kernel", "kf_forward_kernel_name", "kf_forward_kernel_name_ws",
+    "kf_workspace_bytes", "kf_workspace_bytes_for", "kf_filter_forward", "kf_filter_backward", "kf_smoother",
     "kf_assemble", "kf_lyapunov", "kf_conditional_simulation", "kf_dare", "kf_simulate_statespace",
 )
 
@@ -76,6 +77,10 @@ def load():
     lib.kf_forward_kernel_name.restype = C.c_char_p
     lib.kf_workspace_bytes.argtypes = [C.c_void_p, C.POINTER(KfDims), C.POINTER(C.c_size_t)]
     lib.kf_workspace_bytes.restype = C.c_int
+    lib.kf_forward_kernel_name_ws.argtypes = [C.c_void_p, C.POINTER(KfDims), C.c_size_t]
+    lib.kf_forward_kernel_name_ws.restype = C.c_char_p
+    lib.kf_workspace_bytes_for.argtypes = [C.c_void_p, C.POINTER(KfDims), C.c_int, C.POINTER(C.c_size_t)]
+    lib.kf_workspace_bytes_for.restype = C.c_int
     lib.kf_filter_forward.argtypes = [vp, C.POINTER(KfDims)] + [dp] * 10 + [dp] * 6 + [ip, vp,
                                                                                      C.c_size_t, vp]
     lib.kf_filter_forward.restype = C.c_int

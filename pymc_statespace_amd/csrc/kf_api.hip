@@ -28,7 +28,18 @@ extern "C" int kf_create(kf_handle** out, int device) {
   h->lanes_per_draw = 0;
   h->forward_kernel = KF_KERNEL_AUTO;
   const char* envk = getenv("KF_FORWARD_KERNEL");
-  if (envk) h->forward_kernel = !strcmp(envk, "lds") ? KF_KERNEL_LDS : !strcmp(envk, "row") ? KF_KERNEL_ROW : !strcmp(envk, "lane") ? KF_KERNEL_LANE : KF_KERNEL_AUTO;
+  if (envk && *envk) {
+    if (!strcmp(envk, "auto")) h->forward_kernel = KF_KERNEL_AUTO;
+    else if (!strcmp(envk, "lds")) h->forward_kernel = KF_KERNEL_LDS;
+    else if (!strcmp(envk, "row")) h->forward_kernel = KF_KERNEL_ROW;
+    else if (!strcmp(envk, "lane")) h->forward_kernel = KF_KERNEL_LANE;
+    else if (!strcmp(envk, "mfma")) h->forward_kernel = KF_KERNEL_MFMA;
+    else {
+      snprintf(g_err, sizeof(g_err), "kf_create: KF_FORWARD_KERNEL=%s is not one of auto|lds|row|lane|mfma", envk);
+      free(h);
+      return KF_ERR_ARG;
+    }
+  }
   const char* env = getenv("KF_LANES_PER_DRAW");
   if (env) h->lanes_per_draw = atoi(env);
   hipDeviceProp_t prop;
@@ -176,6 +187,10 @@ static int kf_launch_forward_mp(kf_handle* h, const KfFwdArgs& a, hipStream_t st
 }
 
 extern "C" const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* d) {
+  return kf_forward_kernel_name_ws(h, d, (size_t)-1);
+}
+
+extern "C" const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_dims* d, size_t workspace_bytes) {
   if (!h || !d) return "";
   const bool row_ok = d->p == 1 && d->m <= KF_ROW_M_MAX;
   if (d->flags & KF_FLAG_TV_ANY) return "kf_fwd_lds_kernel";
@@ -183,7 +198,10 @@ extern "C" const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims*
   if (kf_wg_ok(h, d->m, d->p, d->r, d->filter, d->flags)) return "kf_fwd_mfma_wg_kernel";
   // (48 < m that still fits LDS: the workspace path is 5x faster, kf_launch_forward takes it when
   // the caller passed the workspace kf_workspace_bytes asks for)
-  if (!kf_forward_lds_fits(d->m, d->p) || (d->m > KF_NB_M_MAX && d->B <= 65535)) return "big_gemm_kernel";
+  // (mirrors kf_launch_forward: without the workspace the launcher stays on the LDS kernel while it fits)
+  if (!kf_forward_lds_fits(d->m, d->p) ||
+      (d->m > KF_NB_M_MAX && d->B <= 65535 && workspace_bytes >= kf_forward_big_workspace_bytes(d->B, d->m, d->p)))
+    return "big_gemm_kernel";
   if (h->forward_kernel == KF_KERNEL_MFMA)
     return kf_mp_ok(h, d->m, d->p, d->T, d->filter, d->flags) ? "kf_fwd_mfma_kernel" : "";
   if (d->p == 1 && d->m <= KF_LANE_M_MAX &&
@@ -397,32 +415,36 @@ static int check_dims(kf_handle* h, const kf_dims* d, bool need_p) {
   return KF_OK;
 }
 
-extern "C" int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes) {
+extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, int which, size_t* bytes) {
   if (!h || !dims || !bytes) return KF_ERR_ARG;
   *bytes = 0;  // the LDS- and register-resident kernels keep all scratch on chip
   const int m = dims->m, p = dims->p, r = dims->r;
   const bool tile_kernels = h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_MFMA;
   const bool scalar_obs = p == 1 || dims->filter == KF_FILTER_UNIVARIATE || (dims->flags & KF_FLAG_H_DIAGONAL);
   // forward: HBM-workspace path for tiles beyond LDS and, when no on-chip kernel takes the shape, for m > 48
-  if (m >= 1 && p >= 1 && !(dims->flags & KF_FLAG_TV_ANY) &&
+  if ((which & KF_WS_FORWARD) && m >= 1 && p >= 1 && !(dims->flags & KF_FLAG_TV_ANY) &&
       (!kf_forward_lds_fits(m, p) || m > KF_NB_M_MAX) &&
       !kf_nb_ok(h, m, p, r, dims->filter, dims->flags) && !kf_wg_ok(h, m, p, r, dims->filter, dims->flags))
     *bytes = kf_forward_big_workspace_bytes(dims->B, m, p);
-  if (m >= 1 && m <= KF_WG_M_MAX) {  // flags of the register-tile smoothers
+  if ((which & KF_WS_SMOOTHER) && m >= 1 && m <= KF_WG_M_MAX) {  // flags of the register-tile smoothers
     const size_t sm = kf_smoother_mfma_workspace_bytes(dims->B);
     if (sm > *bytes) *bytes = sm;
   }
-  if (m >= 1 && p >= 1 && dims->T >= 1 && !kf_backward_lds_fits(m, p) &&
+  if ((which & KF_WS_BACKWARD) && m >= 1 && p >= 1 && dims->T >= 1 && !kf_backward_lds_fits(m, p) &&
       !(tile_kernels && scalar_obs && (kf_backward_mfma_nb_ok(m, p, r) || kf_backward_mfma_wg_ok(m, p, r)))) {
     const size_t bw = kf_backward_big_workspace_bytes(dims->B, m, p, dims->T, r);
     if (bw > *bytes) *bytes = bw;
   }
-  if (m >= 1 && !kf_smoother_lds_fits(m) &&
+  if ((which & KF_WS_SMOOTHER) && m >= 1 && !kf_smoother_lds_fits(m) &&
       !(kf_smoother_mfma_wg_ok(m, r) && h->forward_kernel != KF_KERNEL_LDS)) {
     const size_t sm = kf_smoother_big_workspace_bytes(dims->B, m);
     if (sm > *bytes) *bytes = sm;
   }
   return KF_OK;
+}
+
+extern "C" int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes) {
+  return kf_workspace_bytes_for(h, dims, KF_WS_ALL, bytes);
 }
 
 extern "C" int kf_filter_forward(kf_handle* h, const kf_dims* dims, const double* y, const double* a0,
@@ -437,6 +459,7 @@ extern "C" int kf_filter_forward(kf_handle* h, const kf_dims* dims, const double
     KF_SET_ERR(h, "kf_filter_forward: y, a0, P0, T, Z, R, H, Q and logp must be non-NULL");
     return KF_ERR_ARG;
   }
+  KF_ON_DEVICE(h);
   KfFwdArgs a;
   a.B = dims->B; a.T = dims->T; a.p = dims->p; a.m = dims->m; a.r = dims->r;
   a.filter = dims->filter; a.flags = dims->flags;
@@ -467,6 +490,7 @@ extern "C" int kf_filter_backward(kf_handle* h, const kf_dims* dims, const doubl
     KF_SET_ERR(h, "kf_filter_backward: g_logp and g_ll_obs are both NULL");
     return KF_ERR_ARG;
   }
+  KF_ON_DEVICE(h);
   KfBwdArgs a;
   a.B = dims->B; a.T = dims->T; a.p = dims->p; a.m = dims->m; a.r = dims->r;
   a.filter = dims->filter; a.flags = dims->flags;
@@ -487,6 +511,7 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
     KF_SET_ERR(h, "kf_smoother: all pointers must be non-NULL");
     return KF_ERR_ARG;
   }
+  KF_ON_DEVICE(h);
   KfSmoothArgs a;
   a.B = dims->B; a.T = dims->T; a.m = dims->m; a.r = dims->r;
   a.Tm = T; a.R = R; a.Q = Q; a.filt_a = filt_a; a.filt_P = filt_P;
@@ -521,6 +546,7 @@ extern "C" int kf_assemble(kf_handle* h, int64_t B, int32_t n_theta, const doubl
                (long)total, n_map);
     return KF_ERR_ARG;
   }
+  KF_ON_DEVICE(h);
   return kf_launch_assemble(h, B, n_theta, theta, total, tmpl, n_map, dst, src, out, (hipStream_t)stream);
 }
 
@@ -531,6 +557,7 @@ extern "C" int kf_lyapunov(kf_handle* h, int64_t B, int32_t m, int32_t r, const 
     KF_SET_ERR(h, "kf_lyapunov: need T, P and either S or (R, Q, r >= 1)");
     return KF_ERR_ARG;
   }
+  KF_ON_DEVICE(h);
   return kf_launch_lyapunov(h, B, m, r, T, R, Q, S, P, info, (hipStream_t)stream);
 }
 
@@ -543,6 +570,7 @@ extern "C" int kf_conditional_simulation(kf_handle* h, int64_t B, int32_t n, int
                n_sims);
     return KF_ERR_ARG;
   }
+  KF_ON_DEVICE(h);
   return kf_launch_simulate(h, B, n, k, n_sims, mu, cov, z, jitter, out, info, (hipStream_t)stream);
 }
 
@@ -554,6 +582,7 @@ extern "C" int kf_dare(kf_handle* h, int64_t B, int32_t m, int32_t p, int32_t r,
     KF_SET_ERR(h, "kf_dare: bad arguments (B=%ld m=%d p=%d r=%d max_iter=%d)", (long)B, m, p, r, max_iter);
     return KF_ERR_ARG;
   }
+  KF_ON_DEVICE(h);
   return kf_launch_dare(h, B, m, p, r, T, Z, R, H, Q, P_init, P, info, max_iter, tol, (hipStream_t)stream);
 }
 
@@ -568,6 +597,7 @@ extern "C" int kf_simulate_statespace(kf_handle* h, int64_t B, int32_t n_sims, i
                p, m, r);
     return KF_ERR_ARG;
   }
+  KF_ON_DEVICE(h);
   return kf_launch_simulate_statespace(h, B, n_sims, n, p, m, r, T, Z, R, H, Q, x0, z_state, z_obs, states, obs, info,
                                        (hipStream_t)stream);
 }

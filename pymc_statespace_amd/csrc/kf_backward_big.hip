@@ -294,6 +294,10 @@ int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, si
   const int m = a.m, p = a.p, n = a.T;
   const long mm = (long)m * m;
   const size_t need = kf_backward_big_workspace_bytes(B, m, p, n, a.r);
+  if (B > 65535) {  // the draw axis sits in gridDim.y/z of every per-step launch
+    KF_SET_ERR(h, "backward(big): B=%ld > 65535 draws per call (chunk the batch)", B);
+    return KF_ERR_UNSUPPORTED;
+  }
   if (!workspace || workspace_bytes < need) {
     KF_SET_ERR(h, "backward(big): m=%d needs a workspace of %zu bytes (kf_workspace_bytes), got %zu", m, need,
                workspace_bytes);

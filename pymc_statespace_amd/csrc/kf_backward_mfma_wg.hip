@@ -400,11 +400,11 @@ __global__ __launch_bounds__(NT) void kf_bwd_mfma_wg_kernel(const KfBwdArgs A) {
 template <int KSR>
 int launch_bwd_wg(kf_handle* h, const KfBwdArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(double) * (size_t)WgBwdLayout<KSR>::doubles(a.p);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static KfAttrOnce attr_set;  // the attribute is per device
+  if (attr_set.need(h->device)) {
     KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&kf_bwd_mfma_wg_kernel<KSR>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, KF_LDS_BYTES_MAX));
-    attr_set = true;
+    attr_set.mark(h->device);
   }
   hipLaunchKernelGGL((kf_bwd_mfma_wg_kernel<KSR>), dim3((unsigned)a.B), dim3(NT), lds, stream, a);
   KF_HIP_CHECK(h, hipGetLastError());

@@ -309,6 +309,10 @@ int kf_launch_simulate_statespace(kf_handle* h, long B, int n_sims, int n, int p
     KF_SET_ERR(h, "simulate_statespace: matrices need %zu B of LDS", lds);
     return KF_ERR_UNSUPPORTED;
   }
+  if (B > 65535) {  // the draw axis sits in gridDim.y
+    KF_SET_ERR(h, "simulate_statespace: B=%ld > 65535 draws per call (chunk the batch)", B);
+    return KF_ERR_UNSUPPORTED;
+  }
   dim3 grid((unsigned)((n_sims + KF_WAVE - 1) / KF_WAVE), (unsigned)B);
   hipLaunchKernelGGL(kf_simulate_ss_kernel, grid, dim3(KF_WAVE), lds, stream, B, n_sims, n, p, m, r, T, Z, R, H, Q, x0,
                      zs, zo, states, obs, info);

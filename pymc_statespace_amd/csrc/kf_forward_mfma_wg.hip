@@ -346,11 +346,11 @@ __global__ __launch_bounds__(NBW* KF_WAVE) __attribute__((amdgpu_waves_per_eu(2)
 template <int KSR>
 int launch_wg(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(double) * (size_t)WgLayout<KSR>::doubles(a.p, a.m, a.r);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static KfAttrOnce attr_set;  // the attribute is per device
+  if (attr_set.need(h->device)) {
     KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&kf_fwd_mfma_wg_kernel<KSR>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, KF_LDS_BYTES_MAX));
-    attr_set = true;
+    attr_set.mark(h->device);
   }
   hipLaunchKernelGGL((kf_fwd_mfma_wg_kernel<KSR>), dim3((unsigned)a.B), dim3(NBW * KF_WAVE), lds, stream, a);
   KF_HIP_CHECK(h, hipGetLastError());

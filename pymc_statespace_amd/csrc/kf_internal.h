@@ -13,6 +13,15 @@
 #define KF_LDS_BYTES_MAX (160 * 1024)
 #define KF_LOG_2PI 1.8378770664093454835606594728112  // log(2*pi), MVN_CONST kalman_filter.py:16
 
+// hipFuncSetAttribute is per device: remember it per (kernel instantiation, device), not per process
+struct KfAttrOnce {
+  unsigned long long done = 0;
+  bool need(int dev) const { return dev < 0 || dev >= 64 || !((done >> dev) & 1ull); }
+  void mark(int dev) {
+    if (dev >= 0 && dev < 64) done |= 1ull << dev;
+  }
+};
+
 struct kf_handle {
   int device;
   int lanes_per_draw;  // 0 = auto
@@ -238,6 +247,34 @@ int kf_launch_simulate_statespace(kf_handle* h, long B, int n_sims, int n, int p
 int kf_launch_assemble(kf_handle* h, long B, int n_theta, const double* theta, long total,
                        const double* tmpl, int n_map, const int32_t* dst, const int32_t* src,
                        double* out, hipStream_t stream);
+
+// Every extern "C" entry point runs on the handle's device whatever device is current in the calling
+// thread (launches and hipFuncSetAttribute act on the CURRENT device; a NULL stream is the current
+// device's default stream), and restores the caller's device on return.
+struct KfDeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit KfDeviceGuard(const kf_handle* h) {
+    if (!h) return;
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != h->device) {
+      err = hipSetDevice(h->device);
+      switched = err == hipSuccess;
+    }
+  }
+  ~KfDeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  KfDeviceGuard(const KfDeviceGuard&) = delete;
+  KfDeviceGuard& operator=(const KfDeviceGuard&) = delete;
+};
+#define KF_ON_DEVICE(h)                                                                        \
+  KfDeviceGuard kf_dev_guard_(h);                                                              \
+  if (kf_dev_guard_.err != hipSuccess) {                                                       \
+    KF_SET_ERR(h, "cannot make device %d current: %s", (h)->device, hipGetErrorString(kf_dev_guard_.err)); \
+    return KF_ERR_HIP;                                                                         \
+  }
 
 #define KF_SET_ERR(h, ...)                                 \
   do {                                                     \

@@ -312,6 +312,10 @@ int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace,
   const int m = a.m, n = a.T, r = a.r;
   const long mm = (long)m * m;
   const size_t need = kf_smoother_big_workspace_bytes(B, m);
+  if (B > 65535) {  // the draw axis sits in gridDim.y/z of every per-step launch
+    KF_SET_ERR(h, "smoother(big): B=%ld > 65535 draws per call (chunk the batch)", B);
+    return KF_ERR_UNSUPPORTED;
+  }
   if (!workspace || workspace_bytes < need) {
     KF_SET_ERR(h, "smoother(big): m=%d needs a workspace of %zu bytes (kf_workspace_bytes), got %zu", m, need,
                workspace_bytes);

@@ -278,11 +278,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void kf
 template <int KSR>
 int launch_sm_wg(kf_handle* h, const KfSmoothArgs& a, int32_t* flags, hipStream_t stream) {
   const size_t lds = sizeof(double) * (size_t)WgSmLayout<KSR>::doubles(a.m, a.r);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static KfAttrOnce attr_set;  // the attribute is per device
+  if (attr_set.need(h->device)) {
     KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&kf_smooth_mfma_wg_kernel<KSR>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, KF_LDS_BYTES_MAX));
-    attr_set = true;
+    attr_set.mark(h->device);
   }
   hipLaunchKernelGGL((kf_smooth_mfma_wg_kernel<KSR>), dim3((unsigned)a.B), dim3(NT), lds, stream, a, flags);
   KF_HIP_CHECK(h, hipGetLastError());

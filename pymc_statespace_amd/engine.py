@@ -84,22 +84,33 @@ class KalmanEngine:
         self._check(self.lib.kf_set_forward_kernel(self._h, code), "kf_set_forward_kernel")
 
     def forward_kernel_name(self, B, n, p, m, r, filter_type="standard", h_diagonal=False) -> str:
+        """Kernel ``forward`` launches for this shape (``forward`` always passes the workspace)."""
         dims = self._dims(B, n, p, m, r, filter_type)
         if h_diagonal:
             dims.flags |= _lib.KF_FLAG_H_DIAGONAL
         return self.lib.kf_forward_kernel_name(self._h, C.byref(dims)).decode()
 
-    def _workspace(self, dims):
-        """Scratch for the large-m path (kf_workspace_bytes); cached, grown on demand."""
+    def _workspace(self, dims, which=_lib.KF_WS_ALL):
+        """Scratch for the entry point about to be called (kf_workspace_bytes_for): only what THAT
+        call needs, cached per (entry point, stream) and grown on demand -- a forward-only caller at
+        m = 367 never holds the gradient's 7 B m^2 + 2 B m T doubles, and calls on different streams
+        never share scratch.  ``release_workspace()`` drops the cache."""
         nbytes = C.c_size_t(0)
-        self._check(self.lib.kf_workspace_bytes(self._h, C.byref(dims), C.byref(nbytes)),
-                    "kf_workspace_bytes")
+        self._check(self.lib.kf_workspace_bytes_for(self._h, C.byref(dims), which, C.byref(nbytes)),
+                    "kf_workspace_bytes_for")
         if nbytes.value == 0:
             return None, 0
-        ws = getattr(self, "_ws", None)
+        cache = self.__dict__.setdefault("_ws", {})
+        key = (which, torch.cuda.current_stream(self.device).cuda_stream)
+        ws = cache.get(key)
         if ws is None or ws.numel() < nbytes.value:
-            self._ws = ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+            cache.pop(key, None)
+            ws = None  # free the old block before asking for the larger one
+            cache[key] = ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
         return ws, ws.numel()
+
+    def release_workspace(self):
+        self.__dict__.pop("_ws", None)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -214,7 +225,7 @@ class KalmanEngine:
                 predicted_covs=torch.empty(B, n + 1, m, m, device=dev, dtype=f64) if store_predicted else None,
                 info=torch.empty(B, device=dev, dtype=torch.int32),
             )
-        ws, ws_bytes = self._workspace(dims)
+        ws, ws_bytes = self._workspace(dims, _lib.KF_WS_FORWARD)
         rc = self.lib.kf_filter_forward(
             self._h, C.byref(dims), _ptr(y), _ptr(a0), _ptr(P0), _ptr(T), _ptr(Z), _ptr(R), _ptr(H),
             _ptr(Q), _ptr(c), _ptr(d), _ptr(out.logp), _ptr(out.ll_obs), _ptr(out.filtered_states),
@@ -266,7 +277,7 @@ class KalmanEngine:
         if want_cd:
             g["c"] = torch.empty(B, m, device=dev, dtype=f64)
             g["d"] = torch.empty(B, p, device=dev, dtype=f64)
-        ws, ws_bytes = self._workspace(dims)  # large m only (kf_backward_big.hip)
+        ws, ws_bytes = self._workspace(dims, _lib.KF_WS_BACKWARD)  # large m only (kf_backward_big.hip)
         rc = self.lib.kf_filter_backward(
             self._h, C.byref(dims), _ptr(y), _ptr(a0), _ptr(P0), _ptr(T), _ptr(Z), _ptr(R), _ptr(H),
             _ptr(Q), _ptr(c), _ptr(d), _ptr(pa), _ptr(pP), _ptr(g_logp), _ptr(g_ll),
@@ -290,7 +301,7 @@ class KalmanEngine:
         dims = self._dims(B, n, 1, m, r)
         sa = torch.empty_like(fa)
         sP = torch.empty_like(fP)
-        ws, ws_bytes = self._workspace(dims)  # large m only (kf_smoother_big.hip)
+        ws, ws_bytes = self._workspace(dims, _lib.KF_WS_SMOOTHER)  # large m only (kf_smoother_big.hip)
         rc = self.lib.kf_smoother(self._h, C.byref(dims), _ptr(T), _ptr(R), _ptr(Q), _ptr(fa),
                                   _ptr(fP), _ptr(sa), _ptr(sP), _ptr(ws), ws_bytes, self._stream())
         self._check(rc, "kf_smoother")

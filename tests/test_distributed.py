@@ -75,3 +75,87 @@ def test_two_rank_gloo_allgather_matches_single_process(B):
     ref = kn.kalman_filter(w["y"], w["a0"], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"])["logp"]
     for r in range(world):
         assert np.array_equal(ret[r], ref), f"rank {r}"
+
+
+class _OracleEngine:
+    """Stands in for KalmanEngine on CPU: rejects B == 0 exactly as kf_filter_forward does."""
+
+    device = torch.device("cpu")
+
+    def forward(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, out=None, **kw):
+        from oracle import kalman_numpy as kn
+        from pymc_statespace_amd.engine import FilterResult
+
+        if T.shape[0] < 1:
+            raise RuntimeError("kf_filter_forward failed (-1): bad dims: B=0")
+        o = kn.kalman_filter(y.numpy(), *[x.numpy() for x in (a0, P0, T, Z, R, H, Q)],
+                             mvn_const=kw.get("mvn_const", "reference"))
+        return FilterResult(logp=torch.from_numpy(o["logp"]), ll_obs=None, filtered_states=None,
+                            predicted_states=None, filtered_covs=None, predicted_covs=None,
+                            info=torch.zeros(T.shape[0], dtype=torch.int32))
+
+
+def _worker_sharded_kalman(rank, world, port, B, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pymc_statespace_amd.distributed import ShardedKalman
+
+        w = W.structural(B=B, n=15)
+        sk = ShardedKalman(_OracleEngine())
+        y = torch.from_numpy(w["y"])
+        mats = [torch.from_numpy(w[k]) for k in ("a0", "P0", "T", "Z", "R", "H", "Q")]
+        full, local = sk.logp(y, *mats, return_local=True)       # global arrays in, sharded inside
+        lo, hi = shard_bounds(B, rank, world)
+        assert local.logp.shape[0] == hi - lo
+        g2, res = sk.forward(y, *[x[lo:hi] for x in mats], B_global=B)   # this rank's shard in
+        assert torch.equal(g2, full)
+        ret[rank] = full.numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [1, 5])
+def test_sharded_kalman_gloo_with_an_empty_shard(B):
+    """B < world leaves a rank without draws: it must skip the launch (the C-ABI rejects B = 0)
+    and still join the all-gather -- before, the other ranks hung in the collective."""
+    from oracle import kalman_numpy as kn
+
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_sharded_kalman, args=(world, _free_port(), B, ret), nprocs=world, join=True)
+    w = W.structural(B=B, n=15)
+    ref = kn.kalman_filter(w["y"], w["a0"], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"])["logp"]
+    for r in range(world):
+        assert np.array_equal(ret[r], ref), f"rank {r}"
+
+
+def test_bench_launcher_builds_a_torchrun_command(monkeypatch):
+    """`bench.py --gpus N` without a launcher must start N ranks itself, from a parent that has not
+    touched the GPU (the driver invokes it exactly like this)."""
+    import importlib
+    import sys
+
+    import bench
+
+    importlib.reload(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert "torch" not in bench.__dict__          # the parent never imported torch

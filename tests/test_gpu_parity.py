@@ -229,6 +229,9 @@ FULL = {
     "c2": dict(ft="standard", sample=256),
     "headline": dict(ft="standard", sample=96),
     "c4_m10": dict(ft="univariate", sample=48),
+    # BASELINE configs 3 and 4 at their full sizes (B = 8192 x T = 2000 Cholesky; B = 16384, m = 15, p = 5)
+    "c3": dict(ft="cholesky", sample=64),
+    "c4": dict(ft="standard", sample=48),
 }
 
 
