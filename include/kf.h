@@ -135,7 +135,7 @@ int kf_set_lanes_per_draw(kf_handle* h, int lanes);
  * GEMM path.  The gradient and the smoother follow the same ranges (block-tile kernels for
  * 16 < m <= 48 / 47, workgroup kernels up to m = 64).  Results agree to
  * rounding. */
-enum { KF_KERNEL_AUTO = 0, KF_KERNEL_LDS = 1, KF_KERNEL_ROW = 2, KF_KERNEL_LANE = 3, KF_KERNEL_MFMA = 4 };
+enum { KF_KERNEL_AUTO = 0, KF_KERNEL_LDS = 1, KF_KERNEL_ROW = 2, KF_KERNEL_LANE = 3, KF_KERNEL_MFMA = 4, KF_KERNEL_B4 = 5 };
 int kf_set_forward_kernel(kf_handle* h, int kernel);
 /* Name of the kernel kf_filter_forward would launch for `dims` (for profiles / bench logs), assuming
  * the caller passes the workspace kf_workspace_bytes asks for; the _ws form takes the size of the

@@ -34,8 +34,9 @@ extern "C" int kf_create(kf_handle** out, int device) {
     else if (!strcmp(envk, "row")) h->forward_kernel = KF_KERNEL_ROW;
     else if (!strcmp(envk, "lane")) h->forward_kernel = KF_KERNEL_LANE;
     else if (!strcmp(envk, "mfma")) h->forward_kernel = KF_KERNEL_MFMA;
+    else if (!strcmp(envk, "b4")) h->forward_kernel = KF_KERNEL_B4;
     else {
-      snprintf(g_err, sizeof(g_err), "kf_create: KF_FORWARD_KERNEL=%s is not one of auto|lds|row|lane|mfma", envk);
+      snprintf(g_err, sizeof(g_err), "kf_create: KF_FORWARD_KERNEL=%s is not one of auto|lds|row|lane|mfma|b4", envk);
       free(h);
       return KF_ERR_ARG;
     }
@@ -67,7 +68,7 @@ extern "C" int kf_set_lanes_per_draw(kf_handle* h, int lanes) {
 extern "C" int kf_set_forward_kernel(kf_handle* h, int kernel) {
   if (!h) return KF_ERR_ARG;
   if (kernel != KF_KERNEL_AUTO && kernel != KF_KERNEL_LDS && kernel != KF_KERNEL_ROW &&
-      kernel != KF_KERNEL_LANE && kernel != KF_KERNEL_MFMA) {
+      kernel != KF_KERNEL_LANE && kernel != KF_KERNEL_MFMA && kernel != KF_KERNEL_B4) {
     KF_SET_ERR(h, "unknown forward kernel %d", kernel);
     return KF_ERR_ARG;
   }
@@ -128,6 +129,17 @@ static bool kf_wg_ok(const kf_handle* h, int m, int p, int r, int filter, unsign
   if (h->forward_kernel != KF_KERNEL_AUTO && h->forward_kernel != KF_KERNEL_MFMA) return false;
   if (!kf_forward_mfma_wg_ok(m, p, r)) return false;
   return p == 1 || filter == KF_FILTER_UNIVARIATE || (flags & KF_FLAG_H_DIAGONAL);
+}
+
+// 4x4x4-block kernel (kf_forward_b4.hip): forced by KF_KERNEL_B4; AUTO: see kf_b4_auto
+static bool kf_b4_auto(const kf_handle* h, int m, long B) {
+  (void)h; (void)m; (void)B;
+  return false;
+}
+static bool kf_b4_selected(const kf_handle* h, int m, int p, int r, long B) {
+  if (!kf_forward_b4_ok(m, p, r)) return false;
+  if (h->forward_kernel == KF_KERNEL_B4) return true;
+  return h->forward_kernel == KF_KERNEL_AUTO && kf_b4_auto(h, m, B);
 }
 
 static bool kf_mp_offsets_ok(int m, int T) { return 16.0 * ((double)T + 1.0) * m * m < 2147483648.0; }
@@ -194,6 +206,7 @@ extern "C" const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_di
   if (!h || !d) return "";
   const bool row_ok = d->p == 1 && d->m <= KF_ROW_M_MAX;
   if (d->flags & KF_FLAG_TV_ANY) return "kf_fwd_lds_kernel";
+  if (kf_b4_selected(h, d->m, d->p, d->r, d->B)) return "kf_fwd_b4_kernel";
   if (kf_nb_ok(h, d->m, d->p, d->r, d->filter, d->flags)) return "kf_fwd_mfma_nb_kernel";
   if (kf_wg_ok(h, d->m, d->p, d->r, d->filter, d->flags)) return "kf_fwd_mfma_wg_kernel";
   // (48 < m that still fits LDS: the workspace path is 5x faster, kf_launch_forward takes it when
@@ -228,6 +241,11 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t 
       return KF_ERR_UNSUPPORTED;
     }
     return kf_launch_forward_lds(h, a, stream);
+  }
+  if (kf_b4_selected(h, a.m, a.p, a.r, a.B)) return kf_launch_forward_b4(h, a, stream);
+  if (h->forward_kernel == KF_KERNEL_B4) {
+    KF_SET_ERR(h, "forward(b4): needs p == 1, m <= 14, static matrices (got p=%d m=%d)", a.p, a.m);
+    return KF_ERR_UNSUPPORTED;
   }
   // measured (MI355X, 4096 draws x 1000 steps): m = 17..40 took 25..670 ms on the LDS kernel
   if (kf_nb_ok(h, a.m, a.p, a.r, a.filter, a.flags)) return kf_launch_forward_mfma_nb(h, a, stream);

@@ -79,8 +79,8 @@ class KalmanEngine:
         m <= 16, p <= 8 with the Univariate filter / diagonal H) | 'lane' (one lane per draw,
         p == 1, m <= 4) | 'mfma' (covariance in MFMA accumulator layout, one wavefront per draw:
         m <= 16, p <= 8, same eligibility as the multivariate row kernel; 16 < m <= 48 as blocks of
-        16 x 16)."""
-        code = {"auto": 0, "lds": 1, "row": 2, "lane": 3, "mfma": 4}[kernel]
+        16 x 16) | 'b4' (v_mfma_f64_4x4x4_4b_f64 blocks, mean carried in the tile: p == 1, m <= 14)."""
+        code = {"auto": 0, "lds": 1, "row": 2, "lane": 3, "mfma": 4, "b4": 5}[kernel]
         self._check(self.lib.kf_set_forward_kernel(self._h, code), "kf_set_forward_kernel")
 
     def forward_kernel_name(self, B, n, p, m, r, filter_type="standard", h_diagonal=False) -> str:
