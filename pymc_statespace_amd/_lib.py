@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkf_hip.so")
+# KF_LIB_PATH: developer override for A/B experiments with instrumented builds of the same ABI
+LIB_PATH = os.environ.get("KF_LIB_PATH") or os.path.join(_HERE, "libkf_hip.so")
 
 KF_ABI_VERSION = 3
 

@@ -21,7 +21,18 @@ for m in (1, 2, 3, 5, 6, 7, 9, 10, 11, 13, 14):
             d = 0.05 * np.ones((7, 1))
             ref = co.kalman_filter(y, *[w[k] for k in KEYS], c=c, d=d, filter_type=ft, mvn_const="exact")
             eng.set_forward_kernel("b4")
-            res = eng.forward(y, *[w[k] for k in KEYS], c, d, filter_type=ft, mvn_const="exact")
+            out = None
+            if missing:  # tapes that start 8 bytes off a 16-byte boundary: the streams' odd-parity path
+                from pymc_statespace_amd.engine import FilterResult
+                B_, n_ = 7, 70
+                def odd(*shape):
+                    flat = torch.full((int(np.prod(shape)) + 3,), float("nan"), device="cuda", dtype=torch.float64)
+                    return flat[1:1 + int(np.prod(shape))].view(*shape)
+                out = FilterResult(logp=odd(B_), ll_obs=odd(B_, n_), filtered_states=odd(B_, n_, m),
+                                   predicted_states=odd(B_, n_ + 1, m), filtered_covs=odd(B_, n_, m, m),
+                                   predicted_covs=odd(B_, n_ + 1, m, m),
+                                   info=torch.empty(B_, device="cuda", dtype=torch.int32))
+            res = eng.forward(y, *[w[k] for k in KEYS], c, d, filter_type=ft, mvn_const="exact", out=out)
             eng.set_forward_kernel("auto")
             e = np.abs(res.logp.cpu().numpy() - ref["logp"]).max()
             et = max(np.abs(getattr(res, k).cpu().numpy() - ref[k]).max() for k in TAPES)
