@@ -131,10 +131,20 @@ static bool kf_wg_ok(const kf_handle* h, int m, int p, int r, int filter, unsign
   return p == 1 || filter == KF_FILTER_UNIVARIATE || (flags & KF_FLAG_H_DIAGONAL);
 }
 
-// 4x4x4-block kernel (kf_forward_b4.hip): forced by KF_KERNEL_B4; AUTO: see kf_b4_auto
+// 4x4x4-block kernel (kf_forward_b4.hip): forced by KF_KERNEL_B4.  AUTO, measured on MI355X with 1000 steps
+// (scripts/r02/kern_sweep.py; full tapes ; logp only, ms):
+//   4096 draws  m = 10: 1.94 ; 1.12 against 2.10 ; 1.53 (16 x 16 tile kernel)   m = 14: 3.05 ; 1.68 against 3.29 ; 1.78
+//               m = 6: 1.13 ; 0.75 against 1.26 ; 1.04 (row-split)   m = 4: 1.08 ; 0.76 against 1.62 ; 0.95 (lane)
+//               m = 2: 0.77 ; 0.57 against 0.87 ; 0.50   m = 1: 0.76 ; 0.57 against 0.67 ; 0.36
+//   512 draws   m <= 6: 0.43 - 0.64 ; 0.36 - 0.42 against 0.66 - 1.60 ; 0.36 - 1.15
+//   32768 draws x 200 steps, m <= 8: the lane / row kernels win (64 / m draws per wavefront)
+// -> one wavefront per draw pays as soon as the batch cannot fill the chip with packed wavefronts
 static bool kf_b4_auto(const kf_handle* h, int m, long B) {
-  (void)h; (void)m; (void)B;
-  return false;
+  if (m >= 10) return true;
+  const long n_simd = (h ? h->n_cu : 256) * 4L;
+  if (m >= 7) return (B * m + KF_WAVE - 1) / KF_WAVE < 2 * n_simd;  // else the row kernel (as before)
+  if (m >= 4) return B < 16384;
+  return B <= 2048;
 }
 static bool kf_b4_selected(const kf_handle* h, int m, int p, int r, long B) {
   if (!kf_forward_b4_ok(m, p, r)) return false;

@@ -1,0 +1,178 @@
+// kf_b4.h -- shared pieces of the 4x4x4-block forward kernels (kf_forward_b4.hip, kf_forward_b4s.hip):
+// the MFMA wrappers, the per-draw constants of the augmented tile and the LDS transpose tile geometry.
+// Layout and algebra: see the header of kf_forward_b4.hip.
+#pragma once
+#include "kf_internal.h"
+#include "kf_tile.h"
+
+namespace {
+
+constexpr int TRS = 18;  // transpose tile row stride (doubles): conflict-free 16-byte reads
+// setup scratch (aliases the loop buffers): T, P0, R, Q, Z, a0, c, R_ext, R_ext Q, Z T, P0 Z', 3 scalars
+inline int b4_setup_doubles(int m, int r) { return 2 * m * m + m * r + r * r + 5 * m + 32 * r + 4; }
+
+__device__ __forceinline__ double mfma4(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ double mfma4_nega(double a, double b, double c) {  // c - a b   (neg:[1,0,0])
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 1);
+}
+
+// rows {2, 3} of the wavefront (lanes 32..63) copied over rows {0, 1}: v_permlane32_swap
+__device__ __forceinline__ double high_half_everywhere(double x) {
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[1], a[1]);
+}
+
+// 1/sqrt(x) to rounding accuracy: v_rsq_f64 + two Newton steps (x finite, normal, > 0)
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  r = fma(r, fma(-hx * r, r, 0.5), r);
+  r = fma(r, fma(-hx * r, r, 0.5), r);
+  return r;
+}
+
+// Per-draw constants in register layout (lane = 16 g + 4 b + q):
+//   Ta[I][K]  left-factor block T_ext(I, K) replicated over the four slots: lane (g = k, any b, q = i) holds T_ext[4I+q][4K+g]
+//   Tha       = Ta / 2 (kept as registers for NB <= 3; else the 1/2 is applied after the symmetrisation)
+//   Ch[I]     row-block register I of C_ext / 2 (C_ext itself when !HALF), bitwise symmetric
+//   P[I]      row-block register I of the initial tile P0_ext
+template <int NB, bool HALF_ = (NB <= 3)>
+struct B4Const {
+  static constexpr bool HALF = HALF_;
+  double Ta[NB][NB];
+  double Tha[HALF ? NB : 1][HALF ? NB : 1];
+  double Ch[NB];
+  double P[NB];
+};
+
+// `scratch`: LDS private to this wavefront, >= max(b4_setup_doubles(m, r), 16 * TRS) doubles.  All
+// synchronisation is wave-local (LDS executes a wavefront's instructions in order).  On return
+// scratch[0 .. 16 TRS) is a zeroed transpose tile except for the entries the registers wrote.
+template <int NB, bool HALF_>
+__device__ __forceinline__ void b4_setup(const KfFwdArgs& A, long b, double* scratch, int lane, B4Const<NB, HALF_>& K) {
+  constexpr int N4 = 4 * NB, JA = N4 - 2, JC = N4 - 1;
+  constexpr bool HALF_STATIC = HALF_;
+  const int g = lane >> 4, bq = lane & 15;
+  const int fb = (lane & 3) * 4 + ((lane >> 2) & 3);
+  const int r_ = A.r, m = A.m, mm = m * m;
+  const double* gP = A.P0 + b * (long)mm;
+  {
+    double* sT = scratch;              // T    m x m
+    double* sP = sT + mm;              // P0   m x m (as given; the upper triangle is used)
+    double* sR = sP + mm;              // R    m x r
+    double* sQ = sR + m * r_;          // Q    r x r
+    double* sZ = sQ + r_ * r_;         // Z    m
+    double* sa = sZ + m;               // a0
+    double* sc = sa + m;               // c
+    double* sZT = sc + m;              // Z T
+    double* sPZ = sZT + m;             // P0 Z'
+    double* sS = sPZ + m;              // [0] Z P0 Z'   [1] Z a0   [2] Z c
+    double* sRe = sS + 4;              // R_ext   16 x r  rows: R | 0 | Z R (row JA)
+    double* sRQ = sRe + 16 * r_;       // R_ext Q
+    {
+      const double* gT = A.Tm + b * (long)mm;
+      const double* gR = A.R + b * (long)m * r_;
+      const double* gQ = A.Q + b * (long)r_ * r_;
+      const double* gZ = A.Z + b * (long)m;
+      for (int e = lane; e < mm; e += KF_WAVE) {
+        sT[e] = gT[e];
+        sP[e] = gP[e];
+      }
+      for (int e = lane; e < m * r_; e += KF_WAVE) sR[e] = gR[e];
+      for (int e = lane; e < r_ * r_; e += KF_WAVE) sQ[e] = gQ[e];
+      if (lane < m) {
+        sZ[lane] = gZ[lane];
+        sa[lane] = A.a0[b * (long)m + lane];
+        sc[lane] = A.c ? A.c[b * (long)m + lane] : 0.0;
+      }
+    }
+    wave_lds_fence();
+    auto P0s = [&](int i, int j) { return (j >= i) ? sP[i * m + j] : sP[j * m + i]; };
+    for (int e = lane; e < 16 * r_; e += KF_WAVE) {
+      const int i = e / r_, l = e - i * r_;
+      double v = 0.0;
+      if (i < m) {
+        v = sR[e];
+      } else if (i == JA) {
+        for (int j = 0; j < m; ++j) v += sZ[j] * sR[j * r_ + l];
+      }
+      sRe[e] = v;
+    }
+    if (lane < m) {
+      double tz = 0.0, pz = 0.0;
+      for (int l = 0; l < m; ++l) {
+        tz += sZ[l] * sT[l * m + lane];
+        pz += P0s(lane, l) * sZ[l];
+      }
+      sZT[lane] = tz;
+      sPZ[lane] = pz;
+    }
+    wave_lds_fence();
+    for (int e = lane; e < 16 * r_; e += KF_WAVE) {
+      const int i = e / r_, l = e - i * r_;
+      double v = 0.0;
+      for (int kk = 0; kk < r_; ++kk) v += sRe[i * r_ + kk] * sQ[kk * r_ + l];
+      sRQ[e] = v;
+    }
+    if (lane < 3) {
+      double v = 0.0;
+      for (int l = 0; l < m; ++l) v += sZ[l] * (lane == 0 ? sPZ[l] : lane == 1 ? sa[l] : sc[l]);
+      sS[lane] = v;
+    }
+    wave_lds_fence();
+    const int cc = bq;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      const int rr = 4 * I + g;
+      // replicated left-factor blocks: Ta[I][K] at lane (g = k, any b, q = i) = T_ext[4I+q][4K+g]
+#pragma unroll
+      for (int Kk = 0; Kk < NB; ++Kk) {
+        const int ti = 4 * I + (lane & 3), tk = 4 * Kk + g;
+        double tv = 0.0;
+        if (tk < m) tv = (ti < m) ? sT[ti * m + tk] : (ti == JA ? sZT[tk] : 0.0);
+        else if (ti == JC && tk == JC) tv = 1.0;
+        K.Ta[I][Kk] = tv;
+        if (HALF_STATIC) {
+          double th = 0.5 * tv;
+          asm volatile("" : "+v"(th));  // keep T/2 in registers: the compiler otherwise re-multiplies NB^2 times per step
+          K.Tha[HALF_STATIC ? I : 0][HALF_STATIC ? Kk : 0] = th;
+        }
+      }
+      // P0_ext[rr][cc]
+      double pv = 0.0;
+      if (rr < m) pv = (cc < m) ? P0s(rr, cc) : (cc == JA ? sPZ[rr] : (cc == JC ? 2.0 * sa[rr] : 0.0));
+      else if (rr == JA) pv = (cc < m) ? sPZ[cc] : (cc == JA ? sS[0] : (cc == JC ? 2.0 * sS[1] : 0.0));
+      else if (rr == JC) pv = (cc < m) ? 2.0 * sa[cc] : (cc == JA ? 2.0 * sS[1] : 0.0);
+      K.P[I] = pv;
+      // C_ext[rr][cc] / 2: R_ext Q R_ext' on states + JA, the intercept 2 c on the carrier row / column
+      double cv = 0.0;
+      const bool r_cov = rr < m || rr == JA, c_cov = cc < m || cc == JA;
+      if (r_cov && c_cov) {
+        for (int l = 0; l < r_; ++l) cv += sRQ[rr * r_ + l] * sRe[cc * r_ + l];
+      } else if (rr == JC && cc != JC && c_cov) {
+        cv = 2.0 * (cc < m ? sc[cc] : sS[2]);
+      } else if (cc == JC && rr != JC && r_cov) {
+        cv = 2.0 * (rr < m ? sc[rr] : sS[2]);
+      }
+      K.Ch[I] = HALF_STATIC ? 0.5 * cv : cv;
+    }
+    wave_lds_fence();  // scratch is dead: the loop buffers may be written
+  }
+  // C_ext must be bitwise symmetric (both mirrored entries are the same sum in a different order otherwise):
+  // transpose once through the tile and average -- also zeroes the tile rows no register ever writes
+  double* TR = scratch;
+  for (int e = lane; e < 16 * TRS; e += KF_WAVE) TR[e] = 0.0;
+  wave_lds_fence();
+#pragma unroll
+  for (int I = 0; I < NB; ++I) TR[(4 * I + g) * TRS + fb] = K.Ch[I];
+  wave_lds_fence();
+#pragma unroll
+  for (int I = 0; I < NB; ++I) K.Ch[I] = 0.5 * (K.Ch[I] + TR[bq * TRS + 4 * g + I]);
+  wave_lds_fence();
+}
+
+}  // namespace

@@ -33,12 +33,10 @@
 // agree to rounding (tests: 1e-8 on logp, 1e-9 on tapes).
 #include <type_traits>
 
-#include "kf_internal.h"
-#include "kf_tile.h"
+#include "kf_b4.h"
 
 namespace {
 
-constexpr int TRS = 18;                 // transpose tile row stride (doubles): conflict-free 16-byte reads
 constexpr int LB = 32;                  // steps per y block / likelihood ring
 // loop-time LDS (doubles); 16 wavefronts per CU must fit 160 KiB: <= 1280 doubles each
 constexpr int B4_OFF_UX = 16 * TRS;               // u by column index (16) | zeros (4)
@@ -50,39 +48,14 @@ constexpr int B4_OFF_RP = B4_OFF_RA + 2 * RING_A; // covariance tapes: 2 rings o
 constexpr int RING_P = 256, GRAN_P = 128;
 constexpr int B4_LOOP_DOUBLES = B4_OFF_RP + 2 * RING_P;
 static_assert(B4_LOOP_DOUBLES <= 1280, "four wavefronts per SIMD need <= 10 KiB of LDS per wavefront");
-constexpr int B4_STREAM_MM_MAX = RING_P - GRAN_P + 1;  // largest m*m the covariance rings can stream (m <= 11)
-// setup scratch (aliases the loop buffers): T, P0, R, Q, Z, a0, c, R_ext, R_ext Q, Z T, P0 Z', 3 scalars
-inline int b4_setup_doubles(int m, int r) { return 2 * m * m + m * r + r * r + 5 * m + 32 * r + 4; }
+// (the covariance rings hold GRAN_P - 1 left-over doubles + one step: m * m <= RING_P - GRAN_P + 1, i.e. m <= 11; used for NB <= 3)
 
-__device__ __forceinline__ double mfma4(double a, double b, double c) {
-  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ double mfma4_nega(double a, double b, double c) {  // c - a b   (neg:[1,0,0])
-  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 1);
-}
 template <int I, int N, typename F>
 __device__ __forceinline__ void sfor(F&& f) {
   if constexpr (I < N) {
     f(std::integral_constant<int, I>{});
     sfor<I + 1, N>(f);
   }
-}
-
-// rows {2, 3} of the wavefront (lanes 32..63) copied over rows {0, 1}: v_permlane32_swap
-__device__ __forceinline__ double high_half_everywhere(double x) {
-  const int lo = __double2loint(x), hi = __double2hiint(x);
-  auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return __hiloint2double(b[1], a[1]);
-}
-
-// 1/sqrt(x) to rounding accuracy: v_rsq_f64 + two Newton steps (x finite, normal, > 0)
-__device__ __forceinline__ double fast_rsqrt(double x) {
-  double r = __builtin_amdgcn_rsq(x);
-  const double hx = 0.5 * x;
-  r = fma(r, fma(-hx * r, r, 0.5), r);
-  r = fma(r, fma(-hx * r, r, 0.5), r);
-  return r;
 }
 
 // One output tape of one draw, streamed through an LDS ring.  Why: measured on MI355X (scripts/r02, headline
@@ -118,10 +91,6 @@ struct TapeStream {
     v.y *= scale;
     char* dst = reinterpret_cast<char*>(tape + (w0 - e0));  // (may point below the tape: only lanes >= lo store)
     const unsigned off = 16u * (unsigned)lane;
-#ifdef B4_NO_GSTORE  // experiment builds (scripts/r02/b4_variants.sh): ring traffic only
-    if (v.x == 1.2345e300) *reinterpret_cast<double2_t*>(dst + off) = v;
-    return;
-#endif
     if (lo <= w0 && hi >= w0 + GRAN) {  // wave-uniform: the whole window, every lane
       if (GRAN == 128 || lane < GRAN / 2) *reinterpret_cast<double2_t*>(dst + off) = v;
     } else if (lane < GRAN / 2) {
@@ -131,28 +100,19 @@ struct TapeStream {
       else if (k1) *reinterpret_cast<double*>(dst + off + 8) = v.y;
     }
   }
-  // after the lanes wrote `cnt` more elements into the ring: at most one window becomes complete per append
-  __device__ __forceinline__ void bump(int cnt) { E += cnt; }
-  __device__ __forceinline__ bool ready() const { return (E & ~(GRAN - 1)) > Ef; }
-  // read / store halves of flushing the complete window, so that a caller with several streams can issue all
-  // LDS reads first and pay ONE round trip before the stores
-  __device__ __forceinline__ double2_t read_window(int lane) const {
-    const int w0 = (E & ~(GRAN - 1)) - GRAN;
-    return *reinterpret_cast<const double2_t*>(ring + ((w0 + 2 * lane) & (RING - 1)));
-  }
-  __device__ __forceinline__ void store_window(int lane, double2_t v) {
-    const int bound = E & ~(GRAN - 1), w0 = bound - GRAN;
-    char* dst = reinterpret_cast<char*>(tape + (w0 - e0));
-    const unsigned off = 16u * (unsigned)lane;
-    if (Ef <= w0) {  // wave-uniform: the whole window (always, except the first window of a tape)
-      if (GRAN == 128 || lane < GRAN / 2) *reinterpret_cast<double2_t*>(dst + off) = v;
-    } else if (lane < GRAN / 2) {
-      const int e = w0 + 2 * lane;
-      const bool k0 = e >= Ef, k1 = e + 1 >= Ef;
-      if (k0 && k1) *reinterpret_cast<double2_t*>(dst + off) = v;
-      else if (k1) *reinterpret_cast<double*>(dst + off + 8) = v.y;
+  // after the lanes wrote `cnt` more elements into the ring: at most one window becomes complete per append.
+  // (Tried and dropped, both slower at the headline shape: reading the window right after the ring writes and
+  // storing it later in the step -- 2.05 vs 1.84 ms, register pressure; collecting the windows of all four tapes
+  // once per step, reads first -- 1.89 ms.)
+  __device__ __forceinline__ void appended(int cnt, int lane, double scale) {
+    E += cnt;
+    const int bound = E & ~(GRAN - 1);
+    if (bound > Ef) {
+      wave_lds_fence();
+      window(bound - GRAN, Ef, bound, lane, scale);
+      wave_lds_fence();
+      Ef = bound;
     }
-    Ef = bound;
   }
   __device__ __forceinline__ void finish(int lane, double scale) {
     if (E > Ef) {
@@ -163,7 +123,7 @@ struct TapeStream {
   }
 };
 
-// STREAM: covariance tapes through TapeStream rings (m * m <= B4_STREAM_MM_MAX), else one compact image per step
+// STREAM: covariance tapes through TapeStream rings (m <= 10), else one compact image per step
 template <int NB, bool STREAM>
 __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) void kf_fwd_b4_kernel(const KfFwdArgs A) {
   // (waves_per_eu(4): <= 128 registers, and the compiler then keeps MFMA results in VGPRs -- no v_accvgpr moves)
@@ -173,7 +133,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   const int g = lane >> 4, bq = lane & 15;       // bq = 4 b + q: column index of the lane
   const int fb = (lane & 3) * 4 + ((lane >> 2) & 3);  // 4 q + b: position of column bq in a transpose-tile row
   const long b = blockIdx.x;
-  const int n = A.T, r_ = A.r, m = A.m, mm = m * m;
+  const int n = A.T, m = A.m, mm = m * m;
 
   double* TR = smem;
   double* STG = smem + B4_OFF_RP;  // !STREAM: compact m x m image (<= 196 doubles) + 64 dump slots at 256
@@ -181,125 +141,23 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   double* RG = smem + B4_OFF_RG;
   double* YB = smem + B4_OFF_YB;
 
-  // ---- per-draw constants through an LDS scratch that aliases the loop buffers ----------------------------
-  constexpr bool HALF_STATIC = NB <= 3;  // keep T/2 as a second set of replicated blocks (else scale at the end)
-  double Ta[NB][NB], Tha[HALF_STATIC ? NB : 1][HALF_STATIC ? NB : 1], Ch[NB], P[NB];
-  unsigned stg_off[NB];  // LDS byte offset of this lane's element in the compact tape image (dummy slot if none)
+  // ---- per-draw constants through an LDS scratch that aliases the loop buffers (kf_b4.h) ------------------------
+  constexpr bool HALF_STATIC = B4Const<NB>::HALF;
+  B4Const<NB> KC;
+  b4_setup(A, b, smem, lane, KC);
+  double (&Ta)[NB][NB] = KC.Ta;
+  double (&Tha)[HALF_STATIC ? NB : 1][HALF_STATIC ? NB : 1] = KC.Tha;
+  double (&Ch)[NB] = KC.Ch;
+  double (&P)[NB] = KC.P;
   const double* gP = A.P0 + b * (long)mm;
-  {
-    double* sT = smem;                 // T    m x m
-    double* sP = sT + mm;              // P0   m x m (as given; the upper triangle is used)
-    double* sR = sP + mm;              // R    m x r
-    double* sQ = sR + m * r_;          // Q    r x r
-    double* sZ = sQ + r_ * r_;         // Z    m
-    double* sa = sZ + m;               // a0
-    double* sc = sa + m;               // c
-    double* sZT = sc + m;              // Z T
-    double* sPZ = sZT + m;             // P0 Z'
-    double* sS = sPZ + m;              // [0] Z P0 Z'   [1] Z a0   [2] Z c
-    double* sRe = sS + 4;              // R_ext   16 x r  rows: R | 0 | Z R (row JA)
-    double* sRQ = sRe + 16 * r_;       // R_ext Q
-    {
-      const double* gT = A.Tm + b * (long)mm;
-      const double* gR = A.R + b * (long)m * r_;
-      const double* gQ = A.Q + b * (long)r_ * r_;
-      const double* gZ = A.Z + b * (long)m;
-      for (int e = lane; e < mm; e += KF_WAVE) {
-        sT[e] = gT[e];
-        sP[e] = gP[e];
-      }
-      for (int e = lane; e < m * r_; e += KF_WAVE) sR[e] = gR[e];
-      for (int e = lane; e < r_ * r_; e += KF_WAVE) sQ[e] = gQ[e];
-      if (lane < m) {
-        sZ[lane] = gZ[lane];
-        sa[lane] = A.a0[b * (long)m + lane];
-        sc[lane] = A.c ? A.c[b * (long)m + lane] : 0.0;
-      }
-    }
-    __syncthreads();
-    auto P0s = [&](int i, int j) { return (j >= i) ? sP[i * m + j] : sP[j * m + i]; };
-    for (int e = lane; e < 16 * r_; e += KF_WAVE) {
-      const int i = e / r_, l = e - i * r_;
-      double v = 0.0;
-      if (i < m) {
-        v = sR[e];
-      } else if (i == JA) {
-        for (int j = 0; j < m; ++j) v += sZ[j] * sR[j * r_ + l];
-      }
-      sRe[e] = v;
-    }
-    if (lane < m) {
-      double tz = 0.0, pz = 0.0;
-      for (int l = 0; l < m; ++l) {
-        tz += sZ[l] * sT[l * m + lane];
-        pz += P0s(lane, l) * sZ[l];
-      }
-      sZT[lane] = tz;
-      sPZ[lane] = pz;
-    }
-    __syncthreads();
-    for (int e = lane; e < 16 * r_; e += KF_WAVE) {
-      const int i = e / r_, l = e - i * r_;
-      double v = 0.0;
-      for (int kk = 0; kk < r_; ++kk) v += sRe[i * r_ + kk] * sQ[kk * r_ + l];
-      sRQ[e] = v;
-    }
-    if (lane < 3) {
-      double v = 0.0;
-      for (int l = 0; l < m; ++l) v += sZ[l] * (lane == 0 ? sPZ[l] : lane == 1 ? sa[l] : sc[l]);
-      sS[lane] = v;
-    }
-    __syncthreads();
-    const int cc = bq;
+  unsigned stg_off[NB];  // (!STREAM) LDS byte offset of this lane's element in the compact tape image (dump slot if none)
 #pragma unroll
-    for (int I = 0; I < NB; ++I) {
-      const int rr = 4 * I + g;
-      // replicated left-factor blocks: Ta[I][K] at lane (g = k, any b, q = i) = T_ext[4I+q][4K+g]
-#pragma unroll
-      for (int K = 0; K < NB; ++K) {
-        const int ti = 4 * I + (lane & 3), tk = 4 * K + g;
-        double tv = 0.0;
-        if (tk < m) tv = (ti < m) ? sT[ti * m + tk] : (ti == JA ? sZT[tk] : 0.0);
-        else if (ti == JC && tk == JC) tv = 1.0;
-        Ta[I][K] = tv;
-        if (HALF_STATIC) {
-          double th = 0.5 * tv;
-          asm volatile("" : "+v"(th));  // keep T/2 in registers: the compiler otherwise re-multiplies NB^2 times per step
-          Tha[HALF_STATIC ? I : 0][HALF_STATIC ? K : 0] = th;
-        }
-      }
-      // P0_ext[rr][cc]
-      double pv = 0.0;
-      if (rr < m) pv = (cc < m) ? P0s(rr, cc) : (cc == JA ? sPZ[rr] : (cc == JC ? 2.0 * sa[rr] : 0.0));
-      else if (rr == JA) pv = (cc < m) ? sPZ[cc] : (cc == JA ? sS[0] : (cc == JC ? 2.0 * sS[1] : 0.0));
-      else if (rr == JC) pv = (cc < m) ? 2.0 * sa[cc] : (cc == JA ? 2.0 * sS[1] : 0.0);
-      P[I] = pv;
-      // C_ext[rr][cc] / 2: R_ext Q R_ext' on states + JA, the intercept 2 c on the carrier row / column
-      double cv = 0.0;
-      const bool r_cov = rr < m || rr == JA, c_cov = cc < m || cc == JA;
-      if (r_cov && c_cov) {
-        for (int l = 0; l < r_; ++l) cv += sRQ[rr * r_ + l] * sRe[cc * r_ + l];
-      } else if (rr == JC && cc != JC && c_cov) {
-        cv = 2.0 * (cc < m ? sc[cc] : sS[2]);
-      } else if (cc == JC && rr != JC && r_cov) {
-        cv = 2.0 * (rr < m ? sc[rr] : sS[2]);
-      }
-      Ch[I] = HALF_STATIC ? 0.5 * cv : cv;
-      stg_off[I] = (unsigned)(((rr < m && cc < m) ? rr * m + cc : 256 + lane) * 8);  // (!STREAM only)
-    }
-    __syncthreads();  // scratch is dead: the loop buffers may be written
+  for (int I = 0; I < NB; ++I) {
+    const int rr = 4 * I + g;
+    stg_off[I] = (unsigned)(((rr < m && bq < m) ? rr * m + bq : 256 + lane) * 8);
   }
-  // C_ext must be bitwise symmetric (both mirrored entries are the same sum in a different order otherwise):
-  // transpose once through the tile and average -- also zeroes the tile rows no register ever writes
-  for (int e = lane; e < 16 * TRS; e += KF_WAVE) TR[e] = 0.0;
   if (lane < 20) UX[lane] = 0.0;
-  __syncthreads();
-#pragma unroll
-  for (int I = 0; I < NB; ++I) TR[(4 * I + g) * TRS + fb] = Ch[I];
-  __syncthreads();
-#pragma unroll
-  for (int I = 0; I < NB; ++I) Ch[I] = 0.5 * (Ch[I] + TR[bq * TRS + 4 * g + I]);
-  __syncthreads();
+  wave_lds_fence();
 
   double H1 = A.H[b];
   asm volatile("" : "+v"(H1));  // VGPR: F = H + readlane(...) then is one instruction (one SGPR operand per VALU op)
@@ -319,12 +177,6 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   double* t_pa = A.pred_a ? A.pred_a + b * (long)(n + 1) * m : nullptr;
   double* t_fP = A.filt_P ? A.filt_P + b * (long)n * mm : nullptr;
   double* t_pP = A.pred_P ? A.pred_P + b * (long)(n + 1) * mm : nullptr;
-#ifdef B4_NO_PTAPE
-  t_fP = t_pP = nullptr;
-#endif
-#ifdef B4_NO_ATAPE
-  t_fa = t_pa = nullptr;
-#endif
   const bool w_fa = t_fa != nullptr, w_pa = t_pa != nullptr, w_fP = t_fP != nullptr, w_pP = t_pP != nullptr;
 
   // state tapes: row JC of the tile (2 a') appended to a ring, scaled by 1/2 on the way out
@@ -335,7 +187,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   auto put_a = [&](TapeStream<RING_A, GRAN_A>& st, unsigned& off, double twice_a) {
     if (vec_on) *reinterpret_cast<double*>(reinterpret_cast<char*>(st.ring) + off) = twice_a;
     off = TapeStream<RING_A, GRAN_A>::next(off, m);
-    st.bump(m);
+    st.appended(m, lane, 0.5);
   };
   // covariance tapes
   TapeStream<RING_P, GRAN_P> s_fP, s_pP;
@@ -356,24 +208,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       if (on[I]) *reinterpret_cast<double*>(reinterpret_cast<char*>(st.ring) + off[I]) = Preg[I];
       off[I] = TapeStream<RING_P, GRAN_P>::next(off[I], mm);
     }
-    st.bump(mm);
-  };
-  // complete windows of all four tapes -> HBM: every LDS read first, then the stores (one round trip)
-  auto flush_tapes = [&]() {
-    const bool r1 = w_fa && s_fa.ready(), r2 = w_pa && s_pa.ready();
-    const bool r3 = STREAM && w_fP && s_fP.ready(), r4 = STREAM && w_pP && s_pP.ready();
-    if (!(r1 || r2 || r3 || r4)) return;
-    wave_lds_fence();
-    double2_t v1 = {0.0, 0.0}, v2 = v1, v3 = v1, v4 = v1;
-    if (r3) v3 = s_fP.read_window(lane);
-    if (r4) v4 = s_pP.read_window(lane);
-    if (r1) v1 = s_fa.read_window(lane);
-    if (r2) v2 = s_pa.read_window(lane);
-    wave_lds_fence();
-    if (r3) s_fP.store_window(lane, v3);
-    if (r4) s_pP.store_window(lane, v4);
-    if (r1) s_fa.store_window(lane, 0.5 * v1);
-    if (r2) s_pa.store_window(lane, 0.5 * v2);
+    st.appended(mm, lane, 1.0);
   };
   // !STREAM (m * m too large for the rings): compact m x m image in LDS -> 16 bytes per lane, one step at a time
   const int nb128 = mm >> 1;
@@ -400,30 +235,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   };
   bool pred_pending = false;
 
-#ifdef B4_DIRECT
-  // tapes straight from the registers: register I covers rows 4I..4I+3 = 4 m contiguous doubles (8 B per lane)
-  unsigned d_off[NB];
-#pragma unroll
-  for (int I = 0; I < NB; ++I) d_off[I] = (unsigned)(((4 * I + g) * m + bq) * 8);
-  auto direct_P = [&](double*& dst, const double (&Preg)[NB]) {
-#pragma unroll
-    for (int I = 0; I < NB; ++I)
-      if (on[I]) *reinterpret_cast<double*>(reinterpret_cast<char*>(dst) + d_off[I]) = Preg[I];
-    dst += mm;
-  };
-  auto direct_a = [&](double*& dst, double twice_a) {
-    if (vec_on) *reinterpret_cast<double*>(reinterpret_cast<char*>(dst) + 8u * (unsigned)bq) = 0.5 * twice_a;
-    dst += m;
-  };
-#endif
   // predicted tape slot 0 = (a0, P0 as given: the caller's P0, not its symmetrised upper triangle)
-#ifdef B4_DIRECT
-  if (w_pa) direct_a(t_pa, P[NB - 1]);
-  if (w_pP) {
-    for (int e = lane; e < mm; e += KF_WAVE) t_pP[e] = gP[e];
-    t_pP += mm;
-  }
-#else
   if (w_pa) put_a(s_pa, o_pa, P[NB - 1]);
   if (w_pP) {
     if (STREAM) {
@@ -436,8 +248,6 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       t_pP += mm;
     }
   }
-  flush_tapes();
-#endif
 
   // row-block layout of X -> row-block layout of X' through the LDS tile (wave-local: LDS is in order)
   auto transpose_tile = [&](const double (&X)[NB], double (&Xt)[NB]) {
@@ -524,16 +334,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       pred_pending = false;
     }
     // ---- filtered tapes -----------------------------------------------------------------------------------------------
-#ifdef B4_DIRECT
-    if (w_fa) direct_a(t_fa, P[NB - 1]);
-    if (w_fP) direct_P(t_fP, P);
-#else
     if (w_fa) put_a(s_fa, o_fa, P[NB - 1]);
     if (w_fP) {
       if (STREAM) put_P(s_fP, o_fP, P);
       else stage_cov(P);  // flushed below, behind the MFMAs
     }
-#endif
     // ---- predict: tile <- sym(T_ext tile T_ext' + C_ext) ---------------------------------------------------------------------
     double U[NB], Y[NB];
 #pragma unroll
@@ -542,13 +347,10 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     for (int K = 0; K < NB; ++K)
 #pragma unroll
       for (int I = 0; I < NB; ++I) U[I] = mfma4(Ta[I][K], P[K], U[I]);
-#ifndef B4_DIRECT
-    flush_tapes();  // windows completed by this step's filtered and the previous step's predicted moments
     if (!STREAM && w_fP) {
       flush_cov(t_fP);
       t_fP += mm;
     }
-#endif
     // pass 1: U' through the tile -- element (i, j) at TR[i * TRS + 4 (j & 3) + (j >> 2)]
     transpose_tile(U, U);
 #pragma unroll
@@ -565,10 +367,6 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
 #pragma unroll
       for (int I = 0; I < NB; ++I) P[I] = HALF_STATIC ? Y[I] + Yt[I] : 0.5 * (Y[I] + Yt[I]);
     }
-#ifdef B4_DIRECT
-    if (w_pa) direct_a(t_pa, P[NB - 1]);
-    if (w_pP) direct_P(t_pP, P);
-#else
     if (w_pa) put_a(s_pa, o_pa, P[NB - 1]);
     if (w_pP) {
       if (STREAM) {
@@ -578,19 +376,15 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
         pred_pending = true;
       }
     }
-#endif
     if ((t & (LB - 1)) == LB - 1) flush_ring(t - (LB - 1), LB);
   }
-#ifndef B4_DIRECT
   if (!STREAM && pred_pending) flush_cov(t_pP);
-  flush_tapes();
   s_fa.finish(lane, 0.5);
   s_pa.finish(lane, 0.5);
   if (STREAM) {
     s_fP.finish(lane, 1.0);
     s_pP.finish(lane, 1.0);
   }
-#endif
   if (n & (LB - 1)) flush_ring(n & ~(LB - 1), n & (LB - 1));
   if (lane == 0) {
     A.logp[b] = logp;
@@ -612,15 +406,11 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
   const int nb = (a.m + 2 + 3) / 4;
 #define KF_B4_LAUNCH(NB_, ST_) \
   hipLaunchKernelGGL((kf_fwd_b4_kernel<NB_, ST_>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a)
-  const bool stream_p = a.m * a.m <= B4_STREAM_MM_MAX;
   switch (nb) {
     case 1: KF_B4_LAUNCH(1, true); break;
     case 2: KF_B4_LAUNCH(2, true); break;
     case 3: KF_B4_LAUNCH(3, true); break;
-    default:
-      if (stream_p) KF_B4_LAUNCH(4, true);
-      else KF_B4_LAUNCH(4, false);
-      break;
+    default: KF_B4_LAUNCH(4, false); break;  // m = 11 would fit the rings, but measured 2.48 vs 2.40 ms
   }
 #undef KF_B4_LAUNCH
   KF_HIP_CHECK(h, hipGetLastError());

@@ -538,7 +538,7 @@ def test_kernel_families_agree_at_headline_size(eng):
     dev = [eng.to_device(x) for x in _args(w)]
     res = {}
     try:
-        for kern, lanes in (("lds", 0), ("row", 10), ("row", 30), ("mfma", 0), ("auto", 0)):
+        for kern, lanes in (("lds", 0), ("row", 10), ("row", 30), ("mfma", 0), ("b4", 0), ("auto", 0)):
             eng.set_forward_kernel(kern)
             eng.set_lanes_per_draw(lanes)
             r = eng.forward(*dev, mvn_const="exact", store_filtered=False, store_predicted=True)
@@ -726,7 +726,7 @@ def test_lane_kernels_match_oracle(eng, m, ft):
     c = 0.1 * rng.standard_normal((B, m))
     d = 0.1 * rng.standard_normal((B, 1))
     ref = kn.kalman_filter(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact")
-    assert eng.forward_kernel_name(B, 70, 1, m, w["r"]) == "kf_fwd_lane_kernel"
+    assert eng.forward_kernel_name(32768, 70, 1, m, w["r"]) == "kf_fwd_lane_kernel"  # AUTO: large batches
     eng.set_forward_kernel("lane")
     try:
         out = _np(eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact"))
@@ -1044,13 +1044,18 @@ def test_mfma_kernel_per_draw_data_not_pd_and_partial_outputs(eng):
 def test_auto_kernel_selection(eng):
     """The documented AUTO rules (include/kf.h) -- names only, no launch."""
     name = eng.forward_kernel_name
-    assert name(4096, 1000, 1, 2, 1) == "kf_fwd_lane_kernel"
-    assert name(4096, 1000, 1, 6, 3) == "kf_fwd_rowsplit_kernel"
+    assert name(4096, 1000, 1, 2, 1) == "kf_fwd_lane_kernel"        # C2
+    assert name(512, 1000, 1, 2, 1) == "kf_fwd_b4_kernel"           # C2, one of 8 GPUs' share: too few draws to pack
+    assert name(4096, 1000, 1, 6, 3) == "kf_fwd_b4_kernel"
+    assert name(16384, 1000, 1, 6, 3) == "kf_fwd_rowsplit_kernel"
     assert name(65536, 1000, 1, 6, 3) == "kf_fwd_row_kernel"
-    assert name(4096, 1000, 1, 8, 3) == "kf_fwd_mfma_kernel"
+    assert name(4096, 1000, 1, 8, 3) == "kf_fwd_b4_kernel"
     assert name(65536, 1000, 1, 8, 3) == "kf_fwd_row_kernel"
-    assert name(4096, 1000, 1, 10, 5) == "kf_fwd_mfma_kernel"       # north star
-    assert name(65536, 1000, 1, 10, 5) == "kf_fwd_mfma_kernel"      # C3
+    assert name(4096, 1000, 1, 10, 5) == "kf_fwd_b4_kernel"         # north star
+    assert name(8192, 2000, 1, 10, 4, "cholesky") == "kf_fwd_b4_kernel"  # C3
+    assert name(65536, 1000, 1, 10, 5) == "kf_fwd_b4_kernel"
+    assert name(4096, 1000, 1, 14, 5) == "kf_fwd_b4_kernel"
+    assert name(4096, 1000, 1, 15, 5) == "kf_fwd_mfma_kernel"       # m + 2 > 16: no room for the mean carrier
     assert name(4096, 1000, 1, 16, 5) == "kf_fwd_mfma_kernel"
     assert name(4096, 1000, 1, 17, 5) == "kf_fwd_mfma_nb_kernel"
     assert name(4096, 1000, 1, 48, 5) == "kf_fwd_mfma_nb_kernel"
@@ -1065,6 +1070,109 @@ def test_auto_kernel_selection(eng):
     assert name(16384, 1000, 5, 15, 5, "standard", False) == "kf_fwd_lds_kernel"   # dense H
     assert name(16384, 1000, 5, 15, 5, "univariate", False) == "kf_fwd_mfma_kernel"
     assert name(128, 1000, 1, 367, 3) == "big_gemm_kernel"          # C5
+
+
+# ----------------------------------------------------------------------------------------------
+# 4x4x4-block kernel (kf_forward_b4.hip): v_mfma_f64_4x4x4_4b_f64, mean carried in the tile
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m", list(range(1, 15)))
+@pytest.mark.parametrize("ft", FILTERS)
+def test_b4_kernel_matches_oracle(eng, m, ft):
+    """Every block count (NB = 1..4), streamed (m <= 10) and per-step (m >= 11) covariance tapes, intercepts,
+    missing rows, both log(2 pi) conventions, a batch that is not a multiple of anything."""
+    B = 19
+    w = W.random_dense(B, 77, 1, m, max(1, min(m, 3)), seed=300 + m)
+    y = w["y"].copy()
+    y[[0, 3, 31, 32, 64, 76]] = np.nan
+    rng = np.random.default_rng(m)
+    c = 0.1 * rng.standard_normal((B, m))
+    d = 0.1 * rng.standard_normal((B, 1))
+    eng.set_forward_kernel("b4")
+    try:
+        for mvn in ("reference", "exact"):
+            ref = kn.kalman_filter(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const=mvn)
+            out = _np(eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const=mvn))
+            assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8, (m, mvn)
+            for k in TAPES:
+                assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=f"m={m} {mvn} {k}")
+            assert not out["info"].any()
+        lp_only = eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact", store_ll_obs=False,
+                              store_filtered=False, store_predicted=False).logp.cpu().numpy()
+        assert np.max(np.abs(lp_only - ref["logp"])) < 1e-8
+    finally:
+        eng.set_forward_kernel("auto")
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 64, 65, 129])
+@pytest.mark.parametrize("m", [2, 7, 10, 12])
+def test_b4_kernel_block_boundaries_and_partial_outputs(eng, n, m):
+    """Series lengths around the 32-step y block / likelihood ring and the 128-double tape windows; every subset of
+    tapes; tapes that start 8 bytes off a 16-byte boundary (the streams' single-element head / tail path)."""
+    import torch
+
+    from pymc_statespace_amd.engine import FilterResult
+
+    B = 6
+    w = W.random_dense(B, n, 1, m, 2, seed=17 * n + m)
+    ref = kn.kalman_filter(*_args(w), mvn_const="exact")
+    eng.set_forward_kernel("b4")
+    try:
+        for sel in ((True, True, True), (False, True, False), (False, False, True), (True, False, False)):
+            r = eng.forward(*_args(w), mvn_const="exact", store_ll_obs=sel[0], store_filtered=sel[1],
+                            store_predicted=sel[2])
+            assert np.max(np.abs(r.logp.cpu().numpy() - ref["logp"])) < 1e-8
+            for k in TAPES:
+                v = getattr(r, k)
+                if v is not None:
+                    assert_allclose(v.cpu().numpy(), ref[k], rtol=1e-9, atol=1e-9, err_msg=f"{sel} {k}")
+
+        def odd(*shape):  # 8-byte aligned only, guard words around
+            flat = torch.full((int(np.prod(shape)) + 4,), float("nan"), device="cuda", dtype=torch.float64)
+            return flat, flat[1:1 + int(np.prod(shape))].view(*shape)
+
+        bufs = {k: odd(*s) for k, s in dict(ll_obs=(B, n), filtered_states=(B, n, m), predicted_states=(B, n + 1, m),
+                                            filtered_covs=(B, n, m, m), predicted_covs=(B, n + 1, m, m)).items()}
+        out = FilterResult(logp=torch.empty(B, device="cuda", dtype=torch.float64),
+                           info=torch.empty(B, device="cuda", dtype=torch.int32), **{k: v[1] for k, v in bufs.items()})
+        eng.forward(*_args(w), mvn_const="exact", out=out)
+        for k, (flat, view) in bufs.items():
+            assert_allclose(view.cpu().numpy(), ref[k], rtol=1e-9, atol=1e-9, err_msg=k)
+            g = flat.cpu().numpy()
+            assert np.isnan(g[0]) and np.isnan(g[-3:]).all(), f"{k}: wrote outside the tape"
+    finally:
+        eng.set_forward_kernel("auto")
+
+
+def test_b4_kernel_per_draw_data_not_pd_and_univariate_skip(eng):
+    """y per draw; a draw whose F turns non-positive reports info = (t + 1) << 8 | 1 and NaN; the Univariate filter
+    skips F == 0 (:468-471) where Standard flags it."""
+    B, n, m = 9, 40, 5
+    w = W.random_dense(B, n, 1, m, 2, seed=77)
+    yb = np.repeat(w["y"][None], B, 0) + 0.01 * np.arange(B)[:, None, None]
+    H = w["H"].copy()
+    H[4] = -50.0
+    eng.set_forward_kernel("b4")
+    try:
+        res = eng.forward(yb, *_args(w)[1:6], H, w["Q"], mvn_const="exact")
+        info = res.info.cpu().numpy()
+        assert info[4] == ((0 + 1) << 8 | 1) and not np.delete(info, 4).any()
+        good = np.arange(B) != 4
+        ref = kn.kalman_filter(yb, w["a0"], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"], mvn_const="exact")
+        lp = res.logp.cpu().numpy()
+        assert np.isnan(lp[4]) and np.max(np.abs(lp[good] - ref["logp"][good])) < 1e-8
+        # exactly known state and no noise: F == 0 at every step
+        z = W.reference_test_inputs(1, 3, 1, 12)
+        P0 = np.zeros_like(z["P0"])
+        Hz, Qz = np.zeros((1, 1, 1)), np.zeros((1, 1, 1))
+        ru = eng.forward(z["y"], z["a0"], P0, z["T"], z["Z"], z["R"], Hz, Qz, filter_type="univariate")
+        rf = kn.kalman_filter(z["y"], z["a0"], P0, z["T"], z["Z"], z["R"], Hz, Qz, filter_type="univariate")
+        assert not ru.info.cpu().numpy().any()
+        assert_allclose(ru.logp.cpu().numpy(), rf["logp"], atol=1e-12)
+        assert_allclose(ru.filtered_states.cpu().numpy(), rf["filtered_states"], atol=1e-12)
+        rs = eng.forward(z["y"], z["a0"], P0, z["T"], z["Z"], z["R"], Hz, Qz, filter_type="standard")
+        assert rs.info.cpu().numpy()[0] == ((0 + 1) << 8 | 1)
+    finally:
+        eng.set_forward_kernel("auto")
 
 
 # ----------------------------------------------------------------------------------------------
