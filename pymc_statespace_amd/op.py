@@ -8,8 +8,21 @@ gradient is a second Op whose ``perform`` calls ``kf_filter_backward``.
 
 PyTensor / PyMC are not installed in the build image, so the Op classes are created lazily and
 everything numeric lives in the plain functions ``perform_filter`` / ``perform_filter_grad`` /
-``perform_smoother`` (exercised by the GPU tests); the Op methods only move arrays in and out
-of them.
+``perform_logp_and_grad`` / ``perform_filter_batched`` / ``perform_smoother`` (exercised by the GPU
+tests); the Op methods only move arrays in and out of them.  ``tests/test_pytensor_op.py`` is the
+executable contract for an environment that has PyTensor (it skips here).
+
+What crosses PCIe.  ``perform`` receives host numpy arrays and must return host numpy arrays, so every
+output the graph consumes is copied back; the covariance tapes are (2n + 1) m^2 doubles per draw.
+  * ``KalmanFilterOp.perform`` asks its FunctionGraph which outputs have clients and computes / copies
+    ONLY those (``store_*`` flags of ``kf_filter_forward``); without that information it computes all six.
+  * ``KalmanLogpOp`` -- one output, ``logp``, plus the gradients as extra outputs of the SAME node --
+    is what ``build_graph(..., outputs="logp")`` returns: forward (predicted tapes stay in HBM) and
+    adjoint run back to back on the device, 8 + (2 m^2 + ...) * 8 bytes come back, and ``L_op`` reuses
+    the node's own gradient outputs, so NUTS evaluates value and gradient with one ``perform``.
+  * ``KalmanFilterBatchedOp`` takes a leading draw axis B on every system matrix (data shared) and is
+    what ``pytensor.graph.replace.vectorize_graph`` maps ``KalmanFilterOp`` to: posterior-predictive
+    style evaluation over draws reaches the batched kernels through ``build_statespace_graph()``.
 """
 from __future__ import annotations
 
@@ -29,10 +42,11 @@ def _col(x):
 
 
 def perform_filter(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standard",
-                   mvn_const="reference", h_diagonal=False, engine=None):
+                   mvn_const="reference", h_diagonal=False, engine=None, want=(True,) * 6):
     """One draw, reference layouts in (data (n,p,1), a0 (m,1), c (m,1), d (p,1)) -> the six
     reference outputs [filtered_states (n,m,1), predicted_states (n+1,m,1), filtered_covs,
-    predicted_covs, logp (), ll_obs (n,)] as numpy arrays."""
+    predicted_covs, logp (), ll_obs (n,)] as numpy arrays.  ``want[i]`` False: output i is neither
+    computed nor copied back (None in its place); a tape pair is produced when either half is wanted."""
     eng = engine or get_engine()
     data = np.asarray(data, dtype=np.float64)
     if data.ndim == 3:
@@ -41,19 +55,80 @@ def perform_filter(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standard",
                       np.asarray(Z)[None], np.asarray(R)[None], np.asarray(H)[None],
                       np.asarray(Q)[None], _col(c)[None], _col(d)[None],
                       filter_type=filter_type, mvn_const=mvn_const,
-                      h_diagonal=True if h_diagonal else None)
-    info = int(res.info[0].item())
-    if info != 0:
-        raise np.linalg.LinAlgError(
-            f"{info & 0xff}-th leading minor of the innovation covariance not positive definite "
-            f"at time step {(info >> 8) - 1}")
+                      h_diagonal=bool(h_diagonal),  # never auto-detected here: that costs a host sync per call
+                      store_filtered=bool(want[0] or want[2]), store_predicted=bool(want[1] or want[3]),
+                      store_ll_obs=bool(want[5]))
+    _raise_if_not_pd(res.info)
     return [
-        res.filtered_states[0].cpu().numpy()[..., None],
-        res.predicted_states[0].cpu().numpy()[..., None],
-        res.filtered_covs[0].cpu().numpy(),
-        res.predicted_covs[0].cpu().numpy(),
+        res.filtered_states[0].cpu().numpy()[..., None] if want[0] else None,
+        res.predicted_states[0].cpu().numpy()[..., None] if want[1] else None,
+        res.filtered_covs[0].cpu().numpy() if want[2] else None,
+        res.predicted_covs[0].cpu().numpy() if want[3] else None,
         np.asarray(res.logp[0].item(), dtype=np.float64),
-        res.ll_obs[0].cpu().numpy(),
+        res.ll_obs[0].cpu().numpy() if want[5] else None,
+    ]
+
+
+def _raise_if_not_pd(info):
+    bad = info.nonzero()
+    if bad.numel():
+        b = int(bad[0].item())
+        code = int(info[b].item())
+        raise np.linalg.LinAlgError(
+            f"{code & 0xff}-th leading minor of the innovation covariance not positive definite "
+            f"at time step {(code >> 8) - 1}" + (f" (draw {b})" if info.numel() > 1 else ""))
+
+
+def perform_logp_and_grad(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standard",
+                          mvn_const="reference", h_diagonal=False, engine=None):
+    """logp () and d logp / d (a0, P0, T, Z, R, H, Q, c, d) of one draw in ONE device round trip: the forward
+    filter keeps its predicted tapes in HBM, the adjoint kernel consumes them there; only the scalar and
+    the nine small gradient arrays are copied back (what a NUTS leapfrog step needs)."""
+    eng = engine or get_engine()
+    data = np.asarray(data, dtype=np.float64)
+    if data.ndim == 3:
+        data = data[..., 0]
+    args = (data, _col(a0)[None], np.asarray(P0)[None], np.asarray(T)[None], np.asarray(Z)[None],
+            np.asarray(R)[None], np.asarray(H)[None], np.asarray(Q)[None], _col(c)[None], _col(d)[None])
+    dev = [eng.to_device(x) for x in args]
+    res = eng.forward(*dev, filter_type=filter_type, mvn_const=mvn_const, h_diagonal=bool(h_diagonal),
+                      store_filtered=False, store_ll_obs=False)
+    g = eng.backward(*dev, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
+                     g_logp=np.ones(1), filter_type=filter_type, mvn_const=mvn_const, want_cd=True,
+                     h_diagonal=bool(h_diagonal))
+    _raise_if_not_pd(res.info)
+    out = {k: g[k][0].cpu().numpy() for k in GRAD_INPUT_NAMES}
+    for k in ("a0", "c", "d"):
+        out[k] = out[k][:, None]
+    return [np.asarray(res.logp[0].item(), dtype=np.float64)] + [out[k] for k in GRAD_INPUT_NAMES]
+
+
+def perform_filter_batched(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standard",
+                           mvn_const="reference", h_diagonal=False, engine=None, want=(True,) * 6):
+    """B draws at once: data (n,p,1) shared, every other input with a leading axis B in the reference
+    layouts (a0 (B,m,1), ...) -> the six reference outputs with a leading B (logp (B,), ll_obs (B,n))."""
+    eng = engine or get_engine()
+    data = np.asarray(data, dtype=np.float64)
+    if data.ndim == 3:
+        data = data[..., 0]
+
+    def vec(x):
+        x = np.asarray(x, dtype=np.float64)
+        return x[..., 0] if x.ndim == 3 and x.shape[-1] == 1 else x
+
+    res = eng.forward(data, vec(a0), np.asarray(P0), np.asarray(T), np.asarray(Z), np.asarray(R),
+                      np.asarray(H), np.asarray(Q), vec(c), vec(d), filter_type=filter_type,
+                      mvn_const=mvn_const, h_diagonal=bool(h_diagonal),
+                      store_filtered=bool(want[0] or want[2]), store_predicted=bool(want[1] or want[3]),
+                      store_ll_obs=bool(want[5]))
+    _raise_if_not_pd(res.info)
+    return [
+        res.filtered_states.cpu().numpy()[..., None] if want[0] else None,
+        res.predicted_states.cpu().numpy()[..., None] if want[1] else None,
+        res.filtered_covs.cpu().numpy() if want[2] else None,
+        res.predicted_covs.cpu().numpy() if want[3] else None,
+        res.logp.cpu().numpy(),
+        res.ll_obs.cpu().numpy() if want[5] else None,
     ]
 
 
@@ -66,6 +141,8 @@ def perform_filter_grad(data, a0, P0, T, Z, R, H, Q, c, d, predicted_states, pre
     data = np.asarray(data, dtype=np.float64)
     if data.ndim == 3:
         data = data[..., 0]
+    # (host arrays here: PyTensor hands the forward node's outputs back through the graph; the fused
+    # KalmanLogpOp exists so that the sampler's value-and-gradient path never does this)
     pa = np.asarray(predicted_states, dtype=np.float64)
     if pa.ndim == 3:
         pa = pa[..., 0]
@@ -97,6 +174,16 @@ def perform_smoother(T, R, Q, filtered_states, filtered_covs, engine=None):
 # PyTensor Ops (built on first use)
 # --------------------------------------------------------------------------------------------
 _OPS = None
+
+
+def _outputs_with_clients(node):
+    """Which outputs of ``node`` does its FunctionGraph consume (another node, or a function output)?
+    All of them when the node is not in a graph (eager ``Op.perform`` calls, old PyTensor)."""
+    fg = getattr(node, "fgraph", None)
+    clients = getattr(fg, "clients", None)
+    if clients is None:
+        return tuple(True for _ in node.outputs)
+    return tuple(bool(clients.get(o)) for o in node.outputs)
 
 
 def _build_ops():
@@ -152,10 +239,13 @@ def _build_ops():
             return Apply(self, ins, outs)
 
         def perform(self, node, inputs, output_storage):
+            want = _outputs_with_clients(node)
             outs = perform_filter(*inputs, filter_type=self.filter_type, mvn_const=self.mvn_const,
-                                  h_diagonal=self.h_diagonal)
-            for storage, o in zip(output_storage, outs):
-                storage[0] = np.ascontiguousarray(o, dtype=np.float64)
+                                  h_diagonal=self.h_diagonal, want=want)
+            for storage, o, var in zip(output_storage, outs, node.outputs):
+                # an output nothing consumes still needs a correctly typed placeholder
+                storage[0] = (np.ascontiguousarray(o, dtype=np.float64) if o is not None
+                              else np.zeros((0,) * var.type.ndim, dtype=np.float64))
 
         def infer_shape(self, fgraph, node, shapes):
             n = shapes[0][0]
@@ -184,6 +274,86 @@ def _build_ops():
                 *inputs, outputs[1], outputs[3], g_logp, g_ll)
             return [DisconnectedType()()] + list(grads)
 
+    class KalmanLogpOp(Op):
+        """[logp, g_a0, g_P0, g_T, g_Z, g_R, g_H, g_Q, g_c, g_d] = Op(data, a0, P0, T, Z, R, H, Q, c, d):
+        value and gradient from one perform (perform_logp_and_grad); L_op hands out the node's own
+        gradient outputs scaled by the incoming cotangent."""
+        __props__ = ("filter_type", "mvn_const", "h_diagonal")
+
+        def __init__(self, filter_type="standard", mvn_const="reference", h_diagonal=False):
+            self.filter_type, self.mvn_const, self.h_diagonal = filter_type, mvn_const, bool(h_diagonal)
+
+        def make_node(self, data, a0, P0, T, Z, R, H, Q, c, d):
+            ins = [pt.as_tensor_variable(x) for x in (data, a0, P0, T, Z, R, H, Q, c, d)]
+            return Apply(self, ins, [pt.scalar(dtype=f64)] + [ins[i].type() for i in range(1, 10)])
+
+        def perform(self, node, inputs, output_storage):
+            outs = perform_logp_and_grad(*inputs, filter_type=self.filter_type, mvn_const=self.mvn_const,
+                                         h_diagonal=self.h_diagonal)
+            for storage, o in zip(output_storage, outs):
+                storage[0] = np.ascontiguousarray(o, dtype=np.float64)
+
+        def infer_shape(self, fgraph, node, shapes):
+            return [()] + [shapes[i] for i in range(1, 10)]
+
+        def connection_pattern(self, node):
+            # only logp (output 0) is differentiable, and not with respect to the data
+            return [[False] * 10] + [[True] + [False] * 9 for _ in range(9)]
+
+        def L_op(self, inputs, outputs, output_grads):
+            g = output_grads[0]
+            return [DisconnectedType()()] + [g * outputs[1 + k] for k in range(9)]
+
+    class KalmanFilterBatchedOp(Op):
+        """KalmanFilterOp with a leading draw axis B on a0 .. d (data shared): outputs B-leading."""
+        __props__ = ("filter_type", "mvn_const", "h_diagonal")
+
+        def __init__(self, filter_type="standard", mvn_const="reference", h_diagonal=False):
+            self.filter_type, self.mvn_const, self.h_diagonal = filter_type, mvn_const, bool(h_diagonal)
+
+        def make_node(self, data, a0, P0, T, Z, R, H, Q, c, d):
+            ins = [pt.as_tensor_variable(x) for x in (data, a0, P0, T, Z, R, H, Q, c, d)]
+            t4 = pt.tensor4(dtype=f64)
+            outs = [t4.type(), t4.type(), t4.type(), t4.type(), pt.vector(dtype=f64), pt.matrix(dtype=f64)]
+            return Apply(self, ins, outs)
+
+        def perform(self, node, inputs, output_storage):
+            want = _outputs_with_clients(node)
+            outs = perform_filter_batched(*inputs, filter_type=self.filter_type, mvn_const=self.mvn_const,
+                                          h_diagonal=self.h_diagonal, want=want)
+            for storage, o, var in zip(output_storage, outs, node.outputs):
+                storage[0] = (np.ascontiguousarray(o, dtype=np.float64) if o is not None
+                              else np.zeros((0,) * var.type.ndim, dtype=np.float64))
+
+        def infer_shape(self, fgraph, node, shapes):
+            n, B, m = shapes[0][0], shapes[3][0], shapes[3][1]
+            return [(B, n, m, 1), (B, n + 1, m, 1), (B, n, m, m), (B, n + 1, m, m), (B,), (B, n)]
+
+        def L_op(self, inputs, outputs, output_grads):
+            return [grad_not_implemented(self, k, inputs[k], "use KalmanLogpOp per draw for gradients")
+                    for k in range(10)]
+
+    try:  # vectorize_graph (PyMC's draw-vectorised predictive sampling) -> the batched kernels
+        from pytensor.graph.replace import _vectorize_node
+
+        @_vectorize_node.register(KalmanFilterOp)
+        def _vectorize_kalman_filter(op, node, data, *mats):
+            core = [2] * 9  # a0, c, d are (m,1) / (p,1) columns: every per-draw input is 2-D
+            if data.type.ndim != node.inputs[0].type.ndim or not any(
+                    x.type.ndim > nd for x, nd in zip(mats, core)):
+                return op.make_node(data, *mats)
+            B = None
+            for x, nd in zip(mats, core):
+                if x.type.ndim == nd + 1:
+                    B = x.shape[0]
+                elif x.type.ndim != nd:
+                    raise NotImplementedError("one leading batch axis only")
+            mats = [x if x.type.ndim == nd + 1 else pt.broadcast_to(x, (B,) + tuple(x.shape))
+                    for x, nd in zip(mats, core)]
+            return KalmanFilterBatchedOp(op.filter_type, op.mvn_const, op.h_diagonal).make_node(data, *mats)
+    except ImportError:  # pragma: no cover - older PyTensor
+        pass
+
     class KalmanSmootherOp(Op):
         """(smoothed_states, smoothed_covs) = Op(T, R, Q, filtered_states, filtered_covs)
         -- reference kalman_smoother.py:56-85."""
@@ -206,17 +376,19 @@ def _build_ops():
                     for k in range(5)]
 
     _OPS = dict(pt=pt, pytensor=pytensor, KalmanFilterOp=KalmanFilterOp,
-                KalmanFilterGradOp=KalmanFilterGradOp, KalmanSmootherOp=KalmanSmootherOp)
+                KalmanFilterGradOp=KalmanFilterGradOp, KalmanSmootherOp=KalmanSmootherOp,
+                KalmanLogpOp=KalmanLogpOp, KalmanFilterBatchedOp=KalmanFilterBatchedOp)
     return _OPS
 
 
 def kalman_filter_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type="standard",
-                        mvn_const="reference", h_diagonal=False):
+                        mvn_const="reference", h_diagonal=False, outputs="all"):
     """Symbolic equivalent of BaseFilter.build_graph (reference kalman_filter.py:126-163).
     Static (2-D) system matrices only; c, d default to zeros (initialize_intercepts :36-51).
     ``h_diagonal=True``: the model's H is diagonal by construction (e.g. VARMAX measurement
     error, reference models/VARMAX.py:80-83) -- the gradient then runs on the scalar-observation
-    adjoint kernel and is returned for diag(H) only (KF_FLAG_H_DIAGONAL, include/kf.h)."""
+    adjoint kernel and is returned for diag(H) only (KF_FLAG_H_DIAGONAL, include/kf.h).
+    ``outputs="logp"`` returns the log-likelihood alone, from ``KalmanLogpOp``."""
     ops = _build_ops()
     pt = ops["pt"]
     T, Z, R, H, Q = (pt.as_tensor_variable(x) for x in (T, Z, R, H, Q))
@@ -233,6 +405,8 @@ def kalman_filter_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type
         c = pt.zeros((T.shape[0], 1))
     if d is None:
         d = pt.zeros((Z.shape[0], 1))
+    if outputs == "logp":  # the sampler's path: value and gradient from one node, no tapes over PCIe
+        return ops["KalmanLogpOp"](filter_type, mvn_const, h_diagonal)(data, a0, P0, T, Z, R, H, Q, c, d)[0]
     return list(ops["KalmanFilterOp"](filter_type, mvn_const, h_diagonal)(
         data, a0, P0, T, Z, R, H, Q, c, d))
 

@@ -1,0 +1,136 @@
+"""BASELINE config 5 (daily seasonality, m = 367, T = 730) and the HBM-workspace path (m > 64) at REAL length.
+
+Round 1 checked this path on 5 - 8 time steps only; the long-series guards of the register-tile kernels exist
+because a smoother there amplified rounding 1.45x per step.  Here: forward, gradient and smoother of
+kf_forward_big.hip / kf_backward_big.hip / kf_smoother_big.hip over 300 steps at m in {70, 130, 367} against the
+numpy / torch oracles (BLAS-backed, so m = 367 finishes in seconds), with the same error-growth assertion, and one
+full T = 730 run of the C5 workload at one GPU's share of the batch (128 draws).
+"""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import workloads as W
+from oracle import kalman_numpy as kn
+
+pytestmark = pytest.mark.gpu
+KEYS = ("a0", "P0", "T", "Z", "R", "H", "Q")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    from pymc_statespace_amd import KalmanEngine
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return KalmanEngine()
+
+
+def _args(w, y=None):
+    return (w["y"] if y is None else y,) + tuple(w[k] for k in KEYS)
+
+
+LONG = {
+    # seasonal structural models (level + trend + dummy seasonal, r = 3: the C5 family) and a dense random model
+    "seasonal_m70": lambda: W.daily_seasonal(B=2, n=300, s=69),
+    "dense_m130": lambda: W.random_dense(2, 300, 1, 130, 40, seed=41),
+    "c5_seasonal_m367": lambda: W.daily_seasonal(B=2, n=300),
+}
+
+
+@pytest.mark.parametrize("case", sorted(LONG))
+def test_workspace_forward_over_300_steps(eng, case):
+    w = LONG[case]()
+    assert eng.forward_kernel_name(w["B"], w["n"], 1, w["m"], w["r"]) == "big_gemm_kernel"
+    y = w["y"].copy()
+    y[[7, 150, 299]] = np.nan
+    ref = kn.kalman_filter(*_args(w, y), mvn_const="exact")
+    res = eng.forward(*_args(w, y), mvn_const="exact")
+    assert not res.info.cpu().numpy().any()
+    assert np.max(np.abs(res.logp.cpu().numpy() - ref["logp"])) < 1e-8 * max(1.0, np.abs(ref["logp"]).max() / 1e4)
+    for k in ("ll_obs", "filtered_states", "predicted_states", "filtered_covs", "predicted_covs"):
+        got = getattr(res, k).cpu().numpy()
+        assert_allclose(got, ref[k], rtol=1e-9, atol=1e-9, err_msg=f"{case} {k}")
+    # the per-step error of the covariance tape must not grow along the series
+    err = np.abs(res.predicted_covs.cpu().numpy() - ref["predicted_covs"]).reshape(w["B"], w["n"] + 1, -1).max(2).max(0)
+    assert err[-30:].max() < 50 * max(err[1:40].max(), 1e-14), (err[:5], err[-5:])
+    pc = res.predicted_covs[:, 1:]
+    assert bool((pc == pc.transpose(-1, -2)).all())
+
+
+@pytest.mark.parametrize("case", sorted(LONG))
+def test_workspace_smoother_over_300_steps(eng, case):
+    w = LONG[case]()
+    flt = kn.kalman_filter(*_args(w))
+    sel = slice(0, 1)  # one draw: the oracle takes an SVD per step
+    ra, rP = kn.kalman_smoother(w["T"][sel], w["R"][sel], w["Q"][sel], flt["filtered_states"][sel],
+                                flt["filtered_covs"][sel])
+    sa, sP = eng.smooth(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
+    sa, sP = sa.cpu().numpy(), sP.cpu().numpy()
+    n = w["n"]
+    err = np.abs(sP[sel] - rP).reshape(1, n, -1).max(axis=2).max(axis=0)
+    scale = max(1.0, np.abs(rP).max())
+    assert err.max() < 1e-8 * scale, (err[:5], err[-5:])
+    assert err[:20].max() < 50 * max(err[-40:-1].max(), 1e-14 * scale), "error grows backwards in time"
+    assert_allclose(sa[sel], ra, rtol=1e-8, atol=1e-8 * max(1.0, np.abs(ra).max()))
+    assert np.array_equal(sa[:, -1], flt["filtered_states"][:, -1])
+    assert np.array_equal(sP[:, -1], flt["filtered_covs"][:, -1])
+    # smoothing never increases a variance
+    d_s = np.diagonal(sP, axis1=-2, axis2=-1)
+    d_f = np.diagonal(flt["filtered_covs"], axis1=-2, axis2=-1)
+    assert (d_s <= d_f + 1e-9 * scale).all()
+
+
+@pytest.mark.parametrize("case", sorted(LONG))
+def test_workspace_gradient_over_300_steps(eng, case):
+    from oracle import kalman_torch as kt
+
+    w = LONG[case]()
+    one = {k: w[k][:1] for k in KEYS}
+    args = (w["y"],) + tuple(one[k] for k in KEYS)
+    g_logp = np.array([1.0])
+    _, _, gt = kt.logp_and_grads(*args, g_logp=g_logp)
+    res = eng.forward(*args)
+    g = eng.backward(*args, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs, g_logp=g_logp)
+    for k in KEYS:
+        a, b = g[k].cpu().numpy(), gt[k]
+        assert np.max(np.abs(a - b)) / (1.0 + np.max(np.abs(b))) < 1e-9, (case, k)
+
+
+def test_c5_full_length_one_gpu_share(eng):
+    """BASELINE config 5 as configured: daily seasonality, m = 367, T = 730, 128 draws (1024 over 8 GPUs)."""
+    import torch
+
+    w = W.WORKLOADS["c5"](B=128)
+    B, n, m = w["B"], w["n"], w["m"]
+    assert (n, m) == (730, 367)
+    dev = [eng.to_device(x) for x in _args(w)]
+    res = eng.forward(*dev, mvn_const="exact", store_filtered=False, store_predicted=False)
+    torch.cuda.synchronize()
+    logp = res.logp.cpu().numpy()
+    assert np.isfinite(logp).all() and not res.info.cpu().numpy().any()
+    assert_allclose(logp, res.ll_obs.sum(-1).cpu().numpy(), rtol=1e-12, atol=1e-9)
+    idx = np.array([0, 77, 127])
+    ref = kn.kalman_filter(w["y"], *[w[k][idx] for k in KEYS], mvn_const="exact")
+    assert np.max(np.abs(logp[idx] - ref["logp"])) < 1e-8 * max(1.0, np.abs(ref["logp"]).max() / 1e4)
+    # filtered tapes + RTS smoother, 64 draws at a time (101 GB of filtered + smoothed covariances per chunk)
+    ra, rP = kn.kalman_smoother(w["T"][idx[:1]], w["R"][idx[:1]], w["Q"][idx[:1]], ref["filtered_states"][:1],
+                                ref["filtered_covs"][:1])
+    for lo in (0, 64):
+        sl = slice(lo, lo + 64)
+        part = [dev[0]] + [x[sl] for x in dev[1:]]
+        flt = eng.forward(*part, mvn_const="exact", store_ll_obs=False, store_predicted=False)
+        assert torch.equal(flt.logp, res.logp[sl])
+        sa, sP = eng.smooth(part[3], part[5], part[7], flt.filtered_states, flt.filtered_covs)
+        torch.cuda.synchronize()
+        assert torch.equal(sa[:, -1], flt.filtered_states[:, -1]) and torch.equal(sP[:, -1], flt.filtered_covs[:, -1])
+        assert bool(torch.isfinite(sa).all()) and bool(torch.isfinite(sP[:, ::73]).all())
+        if lo == 0:
+            assert_allclose(flt.filtered_states[0].cpu().numpy(), ref["filtered_states"][0], rtol=1e-9, atol=1e-9)
+            assert_allclose(flt.filtered_covs[0, -1].cpu().numpy(), ref["filtered_covs"][0, -1], rtol=1e-9, atol=1e-9)
+            assert_allclose(sa[0].cpu().numpy(), ra[0], rtol=1e-8, atol=1e-8)
+            for t in (0, 1, 365, 728):
+                assert_allclose(sP[0, t].cpu().numpy(), rP[0, t], rtol=1e-8, atol=1e-8, err_msg=f"t={t}")
+        del flt, sa, sP
+        torch.cuda.empty_cache()

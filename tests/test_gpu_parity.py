@@ -494,6 +494,51 @@ def test_op_perform_bodies_match_oracle():
                         err_msg=name)
 
 
+def test_op_fused_logp_and_grad_batched_and_partial_outputs():
+    """The bodies behind KalmanLogpOp (value + gradient in one device round trip), KalmanFilterBatchedOp (leading
+    draw axis) and the `want` mask KalmanFilterOp.perform derives from its graph's clients."""
+    from oracle import kalman_torch as kt
+    from pymc_statespace_amd import op
+
+    w = W.structural(B=5, n=40)
+    y = w["y"].copy()
+    y[[3, 17]] = np.nan
+    c = 0.05 * np.arange(10.0)[:, None]
+    d = np.array([[0.1]])
+    one = [y[..., None], w["a0"][0][:, None], w["P0"][0], w["T"][0], w["Z"][0], w["R"][0], w["H"][0], w["Q"][0], c, d]
+    outs = op.perform_logp_and_grad(*one)
+    lp, _, gt = kt.logp_and_grads(y, w["a0"][:1], w["P0"][:1], w["T"][:1], w["Z"][:1], w["R"][:1], w["H"][:1],
+                                  w["Q"][:1], c=c[None, :, 0], d=d[None, :, 0], g_logp=np.ones(1))
+    assert np.shape(outs[0]) == () and abs(float(outs[0]) - float(lp[0])) < 1e-8
+    for name, gr, x in zip(op.GRAD_INPUT_NAMES, outs[1:], one[1:]):
+        assert gr.shape == x.shape, name
+        assert_allclose(gr.reshape(gt[name][0].shape), gt[name][0], rtol=1e-9, atol=1e-10, err_msg=name)
+    # only what is wanted is computed and copied
+    full = op.perform_filter(*one)
+    part = op.perform_filter(*one, want=(False, False, False, False, True, False))
+    assert [o is None for o in part] == [True, True, True, True, False, True]
+    assert float(part[4]) == float(full[4])
+    part = op.perform_filter(*one, want=(False, True, False, True, True, False))
+    assert part[0] is None and part[2] is None and part[5] is None
+    assert np.array_equal(part[1], full[1]) and np.array_equal(part[3], full[3])
+    # leading draw axis
+    cB, dB = np.repeat(c[None], 5, 0), np.repeat(d[None], 5, 0)
+    bat = op.perform_filter_batched(y[..., None], w["a0"][..., None], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"],
+                                    cB, dB)
+    ref = kn.kalman_filter(y, w["a0"], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"], c=cB[..., 0], d=dB[..., 0])
+    shapes = [(5, 40, 10, 1), (5, 41, 10, 1), (5, 40, 10, 10), (5, 41, 10, 10), (5,), (5, 40)]
+    assert [np.shape(o) for o in bat] == shapes
+    assert_allclose(bat[4], ref["logp"], rtol=0, atol=1e-8)
+    assert_allclose(bat[2], ref["filtered_covs"], rtol=1e-9, atol=1e-9)
+    assert_allclose(bat[1][..., 0], ref["predicted_states"], rtol=1e-9, atol=1e-9)
+    assert np.array_equal(bat[0][0], full[0]) and np.array_equal(bat[3][0], full[3])
+    # a draw that is not positive definite raises LinAlgError like LAPACK inside the reference graph
+    Hb = w["H"].copy()
+    Hb[3] = -100.0
+    with pytest.raises(np.linalg.LinAlgError, match="draw 3"):
+        op.perform_filter_batched(y[..., None], w["a0"][..., None], w["P0"], w["T"], w["Z"], w["R"], Hb, w["Q"], cB, dB)
+
+
 # ----------------------------------------------------------------------------------------------
 # forward kernel families: LDS-resident generic vs register-resident row / row-split (p == 1)
 # ----------------------------------------------------------------------------------------------
@@ -1047,7 +1092,7 @@ def test_auto_kernel_selection(eng):
     assert name(4096, 1000, 1, 2, 1) == "kf_fwd_lane_kernel"        # C2
     assert name(512, 1000, 1, 2, 1) == "kf_fwd_b4_kernel"           # C2, one of 8 GPUs' share: too few draws to pack
     assert name(4096, 1000, 1, 6, 3) == "kf_fwd_b4_kernel"
-    assert name(16384, 1000, 1, 6, 3) == "kf_fwd_rowsplit_kernel"
+    assert name(16384, 1000, 1, 6, 3) == "kf_fwd_row_kernel"
     assert name(65536, 1000, 1, 6, 3) == "kf_fwd_row_kernel"
     assert name(4096, 1000, 1, 8, 3) == "kf_fwd_b4_kernel"
     assert name(65536, 1000, 1, 8, 3) == "kf_fwd_row_kernel"
