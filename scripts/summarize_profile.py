@@ -35,6 +35,7 @@ def pmc(d, counter):
 
 def main():
     out = sys.argv[1]
+    bench = None
     print(f"# profile summary: {out}")
     for tag in ("kt", "fetch", "write"):
         f = os.path.join(out, f"bench_{tag}.json")
@@ -45,13 +46,15 @@ def main():
                     print(f"bench[{tag}]: value={j['value']:.4g} {j['unit']} ms_per_step={j['ms_per_step']:.4f} "
                           f"kernel_ms={j['roofline']['kernel_ms']:.4f} achieved={j['roofline']['achieved']:.1f} GB/s "
                           f"frac={j['roofline']['frac']:.4f}  [{j['config']['workload']}]")
-                    abytes = j["roofline"]["algorithmic_bytes_per_launch"]
+                    abytes = j["roofline"].get("algorithmic_bytes_per_launch")
+                    bench = j
     print("\n## rocprofv3 --kernel-trace --stats (kernel_stats.csv)")
     print(f"{'kernel':60s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}")
     for r in sorted(kernel_stats(os.path.join(out, "kt")), key=lambda r: -float(r["TotalDurationNs"])):
         print(f"{r['Name'][:60]:60s} {r['Calls']:>6s} {float(r['TotalDurationNs']) / 1e6:10.3f} "
               f"{float(r['AverageNs']) / 1e3:10.2f} {float(r['Percentage']):6.2f}")
     print("\n## HBM traffic per launch (separate --pmc passes)")
+    entries = []
     fetch = pmc(os.path.join(out, "pmc_fetch"), "FETCH_SIZE")
     write = pmc(os.path.join(out, "pmc_write"), "WRITE_SIZE")
     for k in sorted(set(fetch) | set(write)):
@@ -70,6 +73,20 @@ def main():
                   f"{(wmean + 2 * fmean) / 1e9:.4f} GB ; traffic(write + fetch raw) = {(wmean + fmean) / 1e9:.4f} GB")
         except NameError:
             pass
+        if fk and wk:
+            entries.append(dict(kernel=k.split("<")[0].split("::")[-1].strip(), bytes=int(wmean + 2 * fmean),
+                                write_bytes=int(wmean), fetch_bytes_raw=int(fmean)))
+    # machine-readable: merged into profiles/traffic.json by scripts/merge_traffic.py (bench.py reads that file and
+    # labels roofline.traffic with its source)
+    if entries and bench is not None:
+        cfg = bench["config"]
+        key = f"{bench['config']['workload'].split(':')[0]}:{'full' if cfg['outputs'] == 'full_tape' else 'logp'}:B{cfg['draws_per_gpu']}"
+        top = max(entries, key=lambda e: e["bytes"])
+        top.update(key=key, commit=os.environ.get("KF_COMMIT", "unknown"),
+                   source=f"{os.path.basename(out.rstrip('/'))}: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, "
+                          "write + 2 x fetch (gfx950 wide-read correction)")
+        json.dump(top, open(os.path.join(out, "traffic_entry.json"), "w"), indent=1)
+        print(f"\ntraffic entry: {json.dumps(top)}")
 
 
 if __name__ == "__main__":
