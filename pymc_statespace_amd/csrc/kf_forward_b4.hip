@@ -92,6 +92,7 @@ struct TapeStream {
     char* dst = reinterpret_cast<char*>(tape + (w0 - e0));  // (may point below the tape: only lanes >= lo store)
     const unsigned off = 16u * (unsigned)lane;
     if (lo <= w0 && hi >= w0 + GRAN) {  // wave-uniform: the whole window, every lane
+      // (write-back; non-temporal window stores measured the same: 1.755 vs 1.783 ms)
       if (GRAN == 128 || lane < GRAN / 2) *reinterpret_cast<double2_t*>(dst + off) = v;
     } else if (lane < GRAN / 2) {
       const bool k0 = e >= lo && e < hi, k1 = e + 1 >= lo && e + 1 < hi;
