@@ -6,8 +6,11 @@
 //     a_hat = T a_f[t]                       P_hat = T P_f[t] T' + R Q R'   (no c, not symmetrised)
 //     G     = (pinv(P_hat) T P_f[t])'
 //     a_s[t] = a_f[t] + G (a_s[t+1] - a_hat)  P_s[t] = P_f[t] + G (P_s[t+1] - P_hat) G'
-// P_hat is symmetric positive definite here (P_f >= 0, and the tiles that reach this path carry a
-// full-rank P0), so pinv is a Cholesky solve:  X = P_hat^-1 (T P_f),  G = X'.
+// While P_hat is safely positive definite pinv is a Cholesky solve:  X = P_hat^-1 (T P_f),  G = X'.
+// A Cholesky pivot below 1e-12 x max diag(P_hat) (or NaN) flags the draw; flagged draws are redone after
+// the main pass, the whole series, by sb_pinv_redo_kernel: one 1024-thread workgroup per draw, every step
+// with the Moore-Penrose inverse from a parallel-ordered Jacobi eigen-decomposition in the draw's workspace
+// (numpy's cutoff 1e-15 x max |eigenvalue|, kalman_smoother.py:92) -- tens of ms per step at m = 367, rare.
 //
 // Everything is batched over draws in a caller-provided HBM workspace (6 B m^2 doubles + the
 // inverses of the diagonal Cholesky blocks) and every m x m x m piece is an fp64-MFMA GEMM
@@ -185,9 +188,10 @@ __global__ __launch_bounds__(256) void sb_transpose_kernel(const double* src, lo
 
 // Cholesky of the nb x nb diagonal block at (k1, k1) of A (in place, lower) and the inverse of its
 // factor: LINV[b][blk] = inv(L_kk), LINVT = its transpose (64 x 64, zero padded).  One workgroup
-// per draw.  A non-positive pivot leaves NaNs (the smoother has no info output).
+// per draw.  A pivot below 1e-12 x scale[b] (or NaN) flags the draw for the pseudo-inverse pass.
 __global__ __launch_bounds__(256) void sb_potrf_inv_kernel(double* A, long sA, int m, int k1, int nb, double* LINV,
-                                                           double* LINVT, long sL) {
+                                                           double* LINVT, long sL, const double* scale,
+                                                           int32_t* flags) {
   __shared__ double L[NB][NB + 1];
   __shared__ double I[NB][NB + 1];
   const int tid = threadIdx.x;
@@ -199,8 +203,11 @@ __global__ __launch_bounds__(256) void sb_potrf_inv_kernel(double* A, long sA, i
     I[i][j] = 0.0;
   }
   __syncthreads();
+  const double tol = 1e-12 * scale[b];
   for (int j = 0; j < nb; ++j) {
-    const double d = sqrt(L[j][j]);  // NaN for a negative pivot
+    const double piv = L[j][j];
+    if (tid == 0 && !(piv > tol)) flags[b] = 1;
+    const double d = sqrt(piv);  // NaN for a negative pivot (the flagged draw is redone anyway)
     __syncthreads();
     for (int i = j + tid; i < nb; i += 256) L[i][j] = (i == j) ? d : L[i][j] / d;
     __syncthreads();
@@ -259,6 +266,227 @@ __global__ __launch_bounds__(256) void sb_avec_kernel(const double* Tm, const do
   }
 }
 
+// scale[b] = max diag(P_hat[b]) (P_hat is PSD: its largest entry is on the diagonal)
+__global__ __launch_bounds__(256) void sb_scale_kernel(const double* PH, long sP, int m, double* scale) {
+  __shared__ double red[256];
+  const long b = blockIdx.x;
+  double v = 0.0;
+  for (int i = threadIdx.x; i < m; i += 256) v = fmax(v, fabs(PH[b * sP + (long)i * m + i]));
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scale[b] = red[0];
+}
+
+constexpr int PNT = 1024;  // threads of the pseudo-inverse workgroup
+
+__device__ __forceinline__ double pinv_block_sum(double v, double* red) {
+  __syncthreads();
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = PNT / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  return red[0];
+}
+
+// Moore-Penrose inverse of the symmetric m x m matrix D (global memory, destroyed) -> Pi; V, ev (m), cs (4 ceil(m/2))
+// are scratch.  Round-robin (parallel-ordered) cyclic Jacobi as pinv_jacobi of kf_smoother_lds.hip, one workgroup.
+__device__ void pinv_jacobi_wg(double* D, double* V, double* Pi, double* ev, double* cs, int m, double* red) {
+  const int tid = threadIdx.x;
+  const long mm = (long)m * m;
+  const int M = (m + 1) & ~1, half = M / 2;
+  for (long e = tid; e < mm; e += PNT) V[e] = (e / m == e % m) ? 1.0 : 0.0;
+  __syncthreads();
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    double off = 0.0, dg = 0.0;
+    for (long e = tid; e < mm; e += PNT) {
+      const double x = D[e];
+      if (e / m == e % m) dg += x * x; else off += x * x;
+    }
+    off = pinv_block_sum(off, red);
+    dg = pinv_block_sum(dg, red);
+    if (!(off > 1e-30 * dg && off > 0.0)) break;  // block-uniform
+    for (int rd = 0; rd < M - 1; ++rd) {
+      for (int pr = tid; pr < half; pr += PNT) {
+        int p_, q_;
+        if (pr == 0) { p_ = M - 1; q_ = rd; }
+        else { p_ = (rd + pr) % (M - 1); q_ = (rd - pr + (M - 1)) % (M - 1); }
+        if (p_ > q_) { const int t_ = p_; p_ = q_; q_ = t_; }
+        double c = 1.0, s_ = 0.0;
+        if (q_ < m) {
+          const double apq = D[(long)p_ * m + q_];
+          if (apq != 0.0) {
+            const double app = D[(long)p_ * m + p_], aqq = D[(long)q_ * m + q_];
+            const double tau = (aqq - app) / (2.0 * apq);
+            const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+            c = 1.0 / sqrt(1.0 + t * t);
+            s_ = t * c;
+          }
+        } else {
+          p_ = q_ = -1;
+        }
+        cs[4 * pr + 0] = c;
+        cs[4 * pr + 1] = s_;
+        cs[4 * pr + 2] = (double)p_;
+        cs[4 * pr + 3] = (double)q_;
+      }
+      __threadfence_block();
+      __syncthreads();
+      for (long idx = tid; idx < (long)half * m; idx += PNT) {  // columns of D and V
+        const int pr = (int)(idx / m), k = (int)(idx - (long)pr * m);
+        const int p_ = (int)cs[4 * pr + 2], q_ = (int)cs[4 * pr + 3];
+        if (p_ < 0) continue;
+        const double c = cs[4 * pr + 0], s_ = cs[4 * pr + 1];
+        const double dkp = D[(long)k * m + p_], dkq = D[(long)k * m + q_];
+        D[(long)k * m + p_] = c * dkp - s_ * dkq;
+        D[(long)k * m + q_] = s_ * dkp + c * dkq;
+        const double vkp = V[(long)k * m + p_], vkq = V[(long)k * m + q_];
+        V[(long)k * m + p_] = c * vkp - s_ * vkq;
+        V[(long)k * m + q_] = s_ * vkp + c * vkq;
+      }
+      __threadfence_block();
+      __syncthreads();
+      for (long idx = tid; idx < (long)half * m; idx += PNT) {  // rows of D
+        const int pr = (int)(idx / m), k = (int)(idx - (long)pr * m);
+        const int p_ = (int)cs[4 * pr + 2], q_ = (int)cs[4 * pr + 3];
+        if (p_ < 0) continue;
+        const double c = cs[4 * pr + 0], s_ = cs[4 * pr + 1];
+        const double dpk = D[(long)p_ * m + k], dqk = D[(long)q_ * m + k];
+        D[(long)p_ * m + k] = c * dpk - s_ * dqk;
+        D[(long)q_ * m + k] = s_ * dpk + c * dqk;
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+  }
+  double smax = 0.0;
+  for (int k = 0; k < m; ++k) smax = fmax(smax, fabs(D[(long)k * m + k]));
+  for (int k = tid; k < m; k += PNT) {
+    const double lam = D[(long)k * m + k];
+    ev[k] = (fabs(lam) > 1e-15 * smax) ? 1.0 / lam : 0.0;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (long e = tid; e < mm; e += PNT) {
+    const int i = (int)(e / m), j = (int)(e - (long)i * m);
+    double s_ = 0.0;
+    for (int k = 0; k < m; ++k) s_ += V[(long)i * m + k] * V[(long)j * m + k] * ev[k];
+    Pi[e] = s_;
+  }
+  __threadfence_block();
+  __syncthreads();
+}
+
+// The whole series again for the draws the Cholesky pass flagged, with pinv at every step (the reference's
+// smoother_step, kalman_smoother.py:87-97).  Scratch: the draw's own slices of the workspace arrays.
+__global__ __launch_bounds__(PNT) void sb_pinv_redo_kernel(const KfSmoothArgs A, const int32_t* flags, const double* RQRw,
+                                                           double* Aw, double* Vw, double* Pw, double* Sw) {
+  __shared__ double red[PNT];
+  const long b = blockIdx.x;
+  if (!flags[b]) return;
+  const int tid = threadIdx.x;
+  const int n = A.T, m = A.m;
+  const long mm = (long)m * m;
+  double* Am = Aw + b * mm;   // P_hat, then W = T P_f, then E
+  double* V = Vw + b * mm;    // Jacobi vectors, then X = pinv(P_hat) W
+  double* Pi = Pw + b * mm;   // pinv, then D = P_s[t+1] - P_hat
+  const double* RQR = RQRw + b * mm;
+  double* ev = Sw + b * mm;   // m
+  double* cs = ev + m;        // 4 ceil(m / 2)
+  double* va = cs + 4 * ((m + 1) / 2);  // a_f (m), diff (m)     (m^2 >= 5 m + 4 for m >= 7)
+  const double* gT = A.Tm + b * mm;
+  const double* gfa = A.filt_a + b * (long)n * m;
+  const double* gfP = A.filt_P + b * (long)n * mm;
+  double* gsa = A.smooth_a + b * (long)n * m;
+  double* gsP = A.smooth_P + b * (long)n * mm;
+  for (long e = tid; e < mm; e += PNT) gsP[(long)(n - 1) * mm + e] = gfP[(long)(n - 1) * mm + e];
+  for (int e = tid; e < m; e += PNT) gsa[(long)(n - 1) * m + e] = gfa[(long)(n - 1) * m + e];
+  auto sync = [&]() {
+    __threadfence_block();
+    __syncthreads();
+  };
+  sync();
+  for (int t = n - 2; t >= 0; --t) {
+    const double* Pf = gfP + (long)t * mm;
+    const double* Psn = gsP + (long)(t + 1) * mm;
+    for (long e = tid; e < mm; e += PNT) {  // W = T P_f (in V for now)
+      const int i = (int)(e / m), j = (int)(e - (long)i * m);
+      double v = 0.0;
+      for (int k = 0; k < m; ++k) v = fma(gT[(long)i * m + k], Pf[(long)k * m + j], v);
+      V[e] = v;
+    }
+    sync();
+    for (long e = tid; e < mm; e += PNT) {  // P_hat = W T' + RQR'
+      const int i = (int)(e / m), j = (int)(e - (long)i * m);
+      double v = RQR[e];
+      for (int k = 0; k < m; ++k) v = fma(V[(long)i * m + k], gT[(long)j * m + k], v);
+      Am[e] = v;
+    }
+    sync();
+    for (long e = tid; e < mm; e += PNT) {  // the Jacobi iteration wants an exactly symmetric matrix
+      const int i = (int)(e / m), j = (int)(e - (long)i * m);
+      if (i < j) {
+        const double v = 0.5 * (Am[(long)i * m + j] + Am[(long)j * m + i]);
+        Am[(long)i * m + j] = v;
+        Am[(long)j * m + i] = v;
+      }
+    }
+    sync();
+    pinv_jacobi_wg(Am, V, Pi, ev, cs, m, red);  // Pi = pinv(P_hat); Am, V destroyed
+    for (long e = tid; e < mm; e += PNT) {      // W again (Am)
+      const int i = (int)(e / m), j = (int)(e - (long)i * m);
+      double v = 0.0;
+      for (int k = 0; k < m; ++k) v = fma(gT[(long)i * m + k], Pf[(long)k * m + j], v);
+      Am[e] = v;
+    }
+    sync();
+    for (long e = tid; e < mm; e += PNT) {      // X = Pi W (V)
+      const int i = (int)(e / m), j = (int)(e - (long)i * m);
+      double v = 0.0;
+      for (int k = 0; k < m; ++k) v = fma(Pi[(long)i * m + k], Am[(long)k * m + j], v);
+      V[e] = v;
+    }
+    sync();
+    for (long e = tid; e < mm; e += PNT) {      // D = P_s[t+1] - P_hat (Pi), P_hat recomputed from W
+      const int i = (int)(e / m), j = (int)(e - (long)i * m);
+      double v = RQR[e];
+      for (int k = 0; k < m; ++k) v = fma(Am[(long)i * m + k], gT[(long)j * m + k], v);
+      Pi[e] = Psn[e] - v;
+    }
+    for (int i = tid; i < m; i += PNT) va[i] = gfa[(long)t * m + i];
+    sync();
+    for (int i = tid; i < m; i += PNT) {        // diff = a_s[t+1] - T a_f
+      double v = 0.0;
+      for (int k = 0; k < m; ++k) v = fma(gT[(long)i * m + k], va[k], v);
+      va[m + i] = gsa[(long)(t + 1) * m + i] - v;
+    }
+    for (long e = tid; e < mm; e += PNT) {      // E = D X (Am)
+      const int i = (int)(e / m), j = (int)(e - (long)i * m);
+      double v = 0.0;
+      for (int k = 0; k < m; ++k) v = fma(Pi[(long)i * m + k], V[(long)k * m + j], v);
+      Am[e] = v;
+    }
+    sync();
+    for (long e = tid; e < mm; e += PNT) {      // P_s[t] = P_f + X' E
+      const int i = (int)(e / m), j = (int)(e - (long)i * m);
+      double v = Pf[e];
+      for (int k = 0; k < m; ++k) v = fma(V[(long)k * m + i], Am[(long)k * m + j], v);
+      gsP[(long)t * mm + e] = v;
+    }
+    for (int i = tid; i < m; i += PNT) {        // a_s[t] = a_f + X' diff
+      double v = va[i];
+      for (int k = 0; k < m; ++k) v = fma(V[(long)k * m + i], va[m + k], v);
+      gsa[(long)t * m + i] = v;
+    }
+    sync();
+  }
+}
+
 // smooth[n-1] = filt[n-1]
 __global__ __launch_bounds__(256) void sb_last_kernel(const double* filt_a, const double* filt_P, double* smooth_a,
                                                       double* smooth_P, int n, int m) {
@@ -303,7 +531,7 @@ void kf_sb_transpose(hipStream_t st, long B, const double* src, long sS, double*
 size_t kf_smoother_big_workspace_bytes(long B, int m) {
   const long mm = (long)m * m;
   const int nblk = (m + NB - 1) / NB;
-  return sizeof(double) * (size_t)B * (size_t)(6 * mm + 2L * nblk * NB * NB) + 256;
+  return sizeof(double) * (size_t)B * (size_t)(6 * mm + 2L * nblk * NB * NB + 2) + 256;  // + scale, flags per draw
 }
 
 int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace, size_t workspace_bytes,
@@ -336,6 +564,9 @@ int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace,
   double* Em = U + B * mm;     // D X
   double* LINV = Em + B * mm;
   double* LINVT = LINV + B * sL;
+  double* scale = LINVT + B * sL;                       // max diag(P_hat) of the current step
+  int32_t* flags = reinterpret_cast<int32_t*>(scale + B);  // draw needs the pseudo-inverse pass
+  KF_HIP_CHECK(h, hipMemsetAsync(flags, 0, sizeof(int32_t) * (size_t)B, st));
 
   const unsigned eb = (unsigned)((mm + 255) / 256);
   hipLaunchKernelGGL(sb_rqr_kernel, dim3(eb, (unsigned)B), dim3(256), 0, st, a.R, a.Q, RQR, m, r);
@@ -351,11 +582,12 @@ int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace,
     gemm<false, EPI_STORE>(st, B, a.Tm, mm, m, Pf, sTape, m, nullptr, 0, 0, W, mm, m, m, m, m);
     gemm<true, EPI_ADD>(st, B, W, mm, m, a.Tm, mm, m, RQR, mm, m, PH, mm, m, m, m, m);
     hipLaunchKernelGGL(sb_sub_kernel, dim3(eb, (unsigned)B), dim3(256), 0, st, Psn, sTape, PH, mm, Dm, mm, mm);
+    hipLaunchKernelGGL(sb_scale_kernel, dim3((unsigned)B), dim3(256), 0, st, PH, mm, m, scale);
     // blocked Cholesky of P_hat (lower, in place)
     for (int k = 0; k < nblk; ++k) {
       const int k1 = k * NB, nb = (m - k1 < NB) ? m - k1 : NB, k2 = k1 + nb, rem = m - k2;
       hipLaunchKernelGGL(sb_potrf_inv_kernel, dim3((unsigned)B), dim3(256), 0, st, PH, mm, m, k1, nb,
-                         LINV + (long)k * NB * NB, LINVT + (long)k * NB * NB, sL);
+                         LINV + (long)k * NB * NB, LINVT + (long)k * NB * NB, sL, scale, flags);
       if (rem > 0) {
         double* panel = PH + (long)k2 * m + k1;
         // L21 = A21 inv(L11)'   (in place: every workgroup reads exactly the rows it writes)
@@ -391,6 +623,8 @@ int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace,
     hipLaunchKernelGGL(sb_avec_kernel, dim3((unsigned)B), dim3(256), sizeof(double) * 2 * m, st, a.Tm, U, mm,
                        a.filt_a, a.smooth_a, n, m, t);
   }
+  // draws whose P_hat was not safely positive definite at some step: the whole series again with pinv
+  hipLaunchKernelGGL(sb_pinv_redo_kernel, dim3((unsigned)B), dim3(PNT), 0, st, a, flags, RQR, W, PH, Dm, U);
   KF_HIP_CHECK(h, hipGetLastError());
   return KF_OK;
 }

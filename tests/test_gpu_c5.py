@@ -134,3 +134,28 @@ def test_c5_full_length_one_gpu_share(eng):
                 assert_allclose(sP[0, t].cpu().numpy(), rP[0, t], rtol=1e-8, atol=1e-8, err_msg=f"t={t}")
         del flt, sa, sP
         torch.cuda.empty_cache()
+
+
+def test_workspace_smoother_pinv_for_singular_prediction_covariance(eng):
+    """kalman_smoother.py:91-92 uses pinv(P_hat).  m = 70 on the workspace path with two perfectly correlated states
+    (exactly singular P_hat at every step) in one draw and a regular draw next to it: the Cholesky pass flags the
+    first, sb_pinv_redo_kernel redoes it with the Moore-Penrose inverse; the second keeps its Cholesky result."""
+    n, m = 25, 70
+    w = W.random_dense(2, n, 1, m, 35, seed=90)
+    T, R, P0 = w["T"].copy(), w["R"].copy(), w["P0"].copy()
+    T[0, 1, :] = T[0, 0, :]          # states 0 and 1 of draw 0 move together ...
+    R[0, 1, :] = R[0, 0, :]
+    P0[0, 1, :] = P0[0, 0, :]
+    P0[0, :, 1] = P0[0, :, 0]        # ... and start perfectly correlated
+    P0[0, 1, 1] = P0[0, 0, 0]
+    flt = kn.kalman_filter(w["y"], w["a0"], P0, T, w["Z"], R, w["H"], w["Q"])
+    ra, rP = kn.kalman_smoother(T, R, w["Q"], flt["filtered_states"], flt["filtered_covs"])
+    sa, sP = eng.smooth(T, R, w["Q"], flt["filtered_states"], flt["filtered_covs"])
+    sa, sP = sa.cpu().numpy(), sP.cpu().numpy()
+    assert np.isfinite(sa).all() and np.isfinite(sP).all()
+    # regular draw: as before (Cholesky).  Singular draw: rank decisions sit at rounding level in both codes
+    assert_allclose(sa[1], ra[1], rtol=1e-8, atol=1e-8)
+    assert_allclose(sP[1], rP[1], rtol=1e-8, atol=1e-8)
+    assert_allclose(sa[0], ra[0], rtol=1e-6, atol=1e-6)
+    assert_allclose(sP[0], rP[0], rtol=1e-6, atol=1e-6)
+    assert_allclose(sP[0, :, 0, :], sP[0, :, 1, :], rtol=0, atol=1e-7)   # the two states stay perfectly correlated
