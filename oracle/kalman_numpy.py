@@ -438,13 +438,23 @@ def kalman_filter(data, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type="stan
                 logp=ll_obs.sum(axis=-1), ll_obs=ll_obs, batched=s["batched"])
 
 
-def kalman_smoother(T, R, Q, filtered_states, filtered_covs):
+def kalman_smoother(T, R, Q, filtered_states, filtered_covs, time_varying=()):
     """KalmanSmoother.build_graph, kalman_smoother.py:56-104, batched.
 
     filtered_states (B,n,m) | (n,m) | (n,m,1); filtered_covs (B,n,m,m) | (n,m,m).
     predict here has NO intercept and NO symmetrisation (:99-104); the gain uses
     ``pinv`` (numpy default rcond=1e-15, SVD based), :92.
+
+    ``time_varying`` (subset of T, R, Q): that matrix is (B,n,.,.) and the step that smooths t predicts from t with
+    slice t -- the pairing of the forward filter (kalman_filter.py:231-252).  QUIRK, not reproduced: the reference's
+    own scan (kalman_smoother.py:62-77) hands the n-long matrix sequences reversed next to the (n-1)-long reversed
+    filtered tapes, so its step for t receives slice t + 1; with that pairing the smoother is not the adjoint of the
+    filter that produced the tapes (and nothing in the reference's tests exercises it numerically: they are shape
+    tests, tests/test_kalman_filter.py:143-156).
     """
+    tv = set(time_varying)
+    if tv:
+        return _kalman_smoother_tv(T, R, Q, filtered_states, filtered_covs, tv)
     T_b, _ = _as_batch(T, 2)
     R_b, _ = _as_batch(R, 2)
     Q_b, _ = _as_batch(Q, 2)
@@ -474,6 +484,30 @@ def kalman_smoother(T, R, Q, filtered_states, filtered_covs):
         sa[:, t], sP[:, t] = a_s, P_s
     if not batched:
         return sa[0], sP[0]
+    return sa, sP
+
+
+def _kalman_smoother_tv(T, R, Q, filtered_states, filtered_covs, tv):
+    fa = np.asarray(filtered_states, dtype=np.float64)
+    fP = np.asarray(filtered_covs, dtype=np.float64)
+    B, n, m = fa.shape
+    T, R, Q = (np.asarray(x, dtype=np.float64) for x in (T, R, Q))
+
+    def at(x, name, t):
+        return x[:, t] if name in tv else x
+
+    sa, sP = np.empty_like(fa), np.empty_like(fP)
+    sa[:, -1], sP[:, -1] = fa[:, -1], fP[:, -1]
+    a_s, P_s = fa[:, -1], fP[:, -1]
+    for t in range(n - 2, -1, -1):
+        Tt, Rt, Qt = at(T, "T", t), at(R, "R", t), at(Q, "Q", t)
+        a, P = fa[:, t], fP[:, t]
+        a_hat = np.einsum("bij,bj->bi", Tt, a)
+        P_hat = Tt @ P @ _T(Tt) + Rt @ Qt @ _T(Rt)
+        gain = _T(np.linalg.pinv(P_hat) @ Tt @ P)
+        a_s = a + np.einsum("bij,bj->bi", gain, a_s - a_hat)
+        P_s = P + gain @ (P_s - P_hat) @ _T(gain)
+        sa[:, t], sP[:, t] = a_s, P_s
     return sa, sP
 
 

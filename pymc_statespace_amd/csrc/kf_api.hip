@@ -542,9 +542,18 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
   KF_ON_DEVICE(h);
   KfSmoothArgs a;
   a.B = dims->B; a.T = dims->T; a.m = dims->m; a.r = dims->r;
+  a.flags = dims->flags & (KF_FLAG_TV_T | KF_FLAG_TV_R | KF_FLAG_TV_Q);
   a.Tm = T; a.R = R; a.Q = Q; a.filt_a = filt_a; a.filt_P = filt_P;
   a.smooth_a = smooth_a; a.smooth_P = smooth_P;
   a.only_flagged = nullptr;
+  if (a.flags) {
+    // time-varying T / R / Q (kalman_smoother.py:17-54,62-77): the LDS-resident kernel reloads the slices per step
+    if (!kf_smoother_lds_fits(a.m)) {
+      KF_SET_ERR(h, "kf_smoother: time-varying system matrices need the LDS-resident kernel (m=%d too large)", a.m);
+      return KF_ERR_UNSUPPORTED;
+    }
+    return kf_launch_smoother_lds(h, a, (hipStream_t)stream);
+  }
   // 5 <= m <= 16: register-tile smoother when the caller provided the (tiny) flag workspace
   // (measured: m = 10, B = 4096: 6.5 vs 17.1 ms; C4 shard m = 15: 6.1 vs 25.7 ms; m = 2 stays on the
   // LDS kernel, 3.4 ms)

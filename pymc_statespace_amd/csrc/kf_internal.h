@@ -88,6 +88,7 @@ struct KfBwdArgs {
 struct KfSmoothArgs {
   long B;
   int T, m, r;
+  unsigned flags;  // KF_FLAG_TV_T / _R / _Q: that matrix is [B][T][.][.], step t uses slice t (LDS kernel only)
   const double* Tm;
   const double* R;
   const double* Q;

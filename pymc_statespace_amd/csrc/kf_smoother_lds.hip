@@ -166,15 +166,16 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lds_kernel(const KfSmoothAr
   double* gsa = A.smooth_a + b * (long)n * m;
   double* gsP = A.smooth_P + b * (long)n * mm;
 
-  {
-    const double* gT = A.Tm + b * mm;
-    for (int e = lig; e < mm; e += G) {
-      Tl[e] = gT[e];
-      Ps[e] = gfP[(long)(n - 1) * mm + e];
-    }
-    for (int e = lig; e < m; e += G) as[e] = gfa[(long)(n - 1) * m + e];
-    const double* gR = A.R + b * (long)m * r;
-    const double* gQ = A.Q + b * (long)r * r;
+  // time-varying matrices (KF_FLAG_TV_*): [B][n][.][.]; the step that smooths t predicts from t with slice t, the
+  // pairing of the forward filter (kalman_filter.py:231-252: step t predicts with T[t], R[t], Q[t])
+  const bool tvT = (A.flags & KF_FLAG_TV_T) != 0, tvR = (A.flags & KF_FLAG_TV_R) != 0, tvQ = (A.flags & KF_FLAG_TV_Q) != 0;
+  auto load_T = [&](int t) {
+    const double* gT = A.Tm + (tvT ? b * (long)n + t : b) * mm;
+    for (int e = lig; e < mm; e += G) Tl[e] = gT[e];
+  };
+  auto load_RQR = [&](int t) {
+    const double* gR = A.R + (tvR ? b * (long)n + t : b) * (long)m * r;
+    const double* gQ = A.Q + (tvQ ? b * (long)n + t : b) * (long)r * r;
     for (int e = lig; e < mm; e += G) {
       int i = e / m, j = e - i * m;
       double s = 0.0;
@@ -185,6 +186,12 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lds_kernel(const KfSmoothAr
       }
       RQR[e] = s;
     }
+  };
+  {
+    for (int e = lig; e < mm; e += G) Ps[e] = gfP[(long)(n - 1) * mm + e];
+    for (int e = lig; e < m; e += G) as[e] = gfa[(long)(n - 1) * m + e];
+    if (!tvT) load_T(0);
+    if (!(tvR || tvQ)) load_RQR(0);
   }
   wsync();
   if (live) {  // smoothed[-1] = filtered[-1]  (:79-85)
@@ -195,6 +202,8 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lds_kernel(const KfSmoothAr
   for (int t = n - 2; t >= 0; --t) {
     for (int e = lig; e < m; e += G) al[e] = gfa[(long)t * m + e];
     for (int e = lig; e < mm; e += G) P[e] = gfP[(long)t * mm + e];
+    if (tvT) load_T(t);
+    if (tvR || tvQ) load_RQR(t);
     wsync();
     // a_hat = T a ; W = T P
     for (int i = lig; i < m; i += G) {

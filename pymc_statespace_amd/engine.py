@@ -287,18 +287,26 @@ class KalmanEngine:
         return g
 
     # --------------------------------------------------------------- smoother
-    def smooth(self, T, R, Q, filtered_states, filtered_covs):
-        """kf_smoother -> (smoothed_states (B,n,m), smoothed_covs (B,n,m,m))."""
+    def smooth(self, T, R, Q, filtered_states, filtered_covs, time_varying=()):
+        """kf_smoother -> (smoothed_states (B,n,m), smoothed_covs (B,n,m,m)).  Names in ``time_varying`` (subset of
+        T, R, Q) carry a time axis after the draw axis, (B,n,.,.): the step that smooths t uses slice t."""
+        tv = set(time_varying)
+        if not tv <= {"T", "R", "Q"}:
+            raise ValueError("time_varying must be a subset of {'T', 'R', 'Q'}")
         T = self.to_device(T)
-        B, m = T.shape[0], T.shape[1]
+        B, m = T.shape[0], T.shape[-1]
         R = self.to_device(R)
-        r = R.shape[2]
-        Q = self.to_device(Q, (B, r, r))
+        r = R.shape[-1]
         fa = self.to_device(filtered_states)
         n = fa.shape[1]
         fa = self.to_device(fa, (B, n, m))
         fP = self.to_device(filtered_covs, (B, n, m, m))
+        T = self.to_device(T, (B, n, m, m) if "T" in tv else (B, m, m))
+        R = self.to_device(R, (B, n, m, r) if "R" in tv else (B, m, r))
+        Q = self.to_device(Q, (B, n, r, r) if "Q" in tv else (B, r, r))
         dims = self._dims(B, n, 1, m, r)
+        for name in tv:
+            dims.flags |= _lib.KF_FLAG_TV[name]
         sa = torch.empty_like(fa)
         sP = torch.empty_like(fP)
         ws, ws_bytes = self._workspace(dims, _lib.KF_WS_SMOOTHER)  # large m only (kf_smoother_big.hip)

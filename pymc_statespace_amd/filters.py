@@ -255,15 +255,16 @@ class KalmanSmoother:
         fP = _np_or_t(filtered_covariances)
         fa = _np_or_t(filtered_states)
         batched = fP.ndim == 4
-        if _check_ndim([T_, R_, Q_], ["T", "R", "Q"], batched):
-            raise NotImplementedError(
-                "the MI355X smoother supports static T, R, Q only (time-varying: forward filter)")
+        # per draw a 3-D matrix is time varying, time on axis 0 (filters/utilities.py:1-20); the step that smooths t
+        # uses slice t, the forward filter's pairing (the reference's scan pairs it with t + 1: see oracle/kalman_numpy.py)
+        self.seq_names = _check_ndim([T_, R_, Q_], ["T", "R", "Q"], batched)
+        self.non_seq_names = [nm for nm in ("T", "R", "Q") if nm not in self.seq_names]
         m = T_.shape[-1]
         if fa.shape[-1] == 1 and fa.ndim >= 2 and fa.shape[-2] == m:
             fa = fa[..., 0]
         if not batched:
             T_, R_, Q_, fa, fP = T_[None], R_[None], Q_[None], fa[None], fP[None]
-        sa, sP = self.engine.smooth(T_, R_, Q_, fa, fP)
+        sa, sP = self.engine.smooth(T_, R_, Q_, fa, fP, time_varying=tuple(self.seq_names))
         sa = sa[..., None]
         if not batched:
             sa, sP = sa[0], sP[0]

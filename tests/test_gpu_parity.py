@@ -840,6 +840,60 @@ def test_time_varying_matches_oracle(eng, ft, tv):
         assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=f"{ft} {tv} {k}")
 
 
+@pytest.mark.parametrize("tv", [("T",), ("R", "Q"), ("T", "R", "Q")])
+@pytest.mark.parametrize("m", [3, 10, 21])
+def test_time_varying_smoother_matches_oracle(eng, tv, m):
+    """time-varying T / R / Q in the RTS smoother (kalman_smoother.py:17-54, 62-77): the step that
+    smooths t predicts from t with slice t.  Fed with the tapes of the time-varying forward filter."""
+    from pymc_statespace_amd.filters import KalmanSmoother, StandardFilter
+
+    B, n, r = 5, 40, max(1, m // 2)
+    w = W.random_dense(B, n, 1, m, r, seed=500 + m)
+    mats = dict(T=w["T"], R=w["R"], Q=w["Q"])
+    for name in tv:
+        wob = (0.8 + 0.2 * np.cos(0.7 * np.arange(n) + len(name)))[None, :, None, None]
+        mats[name] = np.repeat(mats[name][:, None], n, axis=1) * wob
+    fwd_tv = tuple(tv)
+    ref_f = kn.kalman_filter_time_varying(w["y"], w["a0"], w["P0"], mats["T"], w["Z"], mats["R"], w["H"], mats["Q"],
+                                          time_varying=fwd_tv)
+    res = eng.forward(w["y"], w["a0"], w["P0"], mats["T"], w["Z"], mats["R"], w["H"], mats["Q"], time_varying=fwd_tv)
+    assert_allclose(res.filtered_covs.cpu().numpy(), ref_f["filtered_covs"], rtol=1e-9, atol=1e-9)
+    ra, rP = kn.kalman_smoother(mats["T"], mats["R"], mats["Q"], ref_f["filtered_states"], ref_f["filtered_covs"],
+                                time_varying=tv)
+    sa, sP = eng.smooth(mats["T"], mats["R"], mats["Q"], res.filtered_states, res.filtered_covs, time_varying=tv)
+    assert_allclose(sa.cpu().numpy(), ra, rtol=1e-8, atol=1e-8)
+    assert_allclose(sP.cpu().numpy(), rP, rtol=1e-8, atol=1e-8)
+    # constant "time-varying" matrices reproduce the static smoother bit for bit
+    const = {k: np.repeat(w[k][:, None], n, axis=1) for k in ("T", "R", "Q")}
+    flt = kn.kalman_filter(*_args(w))
+    s1 = eng.smooth(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
+    eng.set_forward_kernel("lds")
+    try:
+        s0 = eng.smooth(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
+    finally:
+        eng.set_forward_kernel("auto")
+    s2 = eng.smooth(const["T"], const["R"], const["Q"], flt["filtered_states"], flt["filtered_covs"],
+                    time_varying=("T", "R", "Q"))
+    assert np.array_equal(s2[1].cpu().numpy(), s0[1].cpu().numpy())
+    assert_allclose(s2[1].cpu().numpy(), s1[1].cpu().numpy(), rtol=1e-8, atol=1e-9)
+    # the reference-shaped eager class: a per-draw 3-D matrix is a sequence (filters/utilities.py:1-20)
+    ks = KalmanSmoother()
+    a1, P1 = ks(mats["T"][0], mats["R"][0], mats["Q"][0], ref_f["filtered_states"][0][..., None], ref_f["filtered_covs"][0])
+    assert sorted(ks.seq_names) == sorted(tv)
+    assert_allclose(P1, rP[0], rtol=1e-8, atol=1e-8)
+    assert a1.shape == (n, m, 1) and StandardFilter is not None
+
+
+def test_time_varying_smoother_needs_the_lds_kernel(eng):
+    from pymc_statespace_amd import KalmanError
+
+    w = W.random_dense(1, 4, 1, 70, 2, seed=5)
+    flt = kn.kalman_filter(*_args(w))
+    Tt = np.repeat(w["T"][:, None], 4, axis=1)
+    with pytest.raises(KalmanError, match="time-varying"):
+        eng.smooth(Tt, w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"], time_varying=("T",))
+
+
 def test_time_varying_gradient_is_declared_unsupported(eng):
     from pymc_statespace_amd import KalmanError, _lib
 
