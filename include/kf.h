@@ -76,7 +76,9 @@ enum {
   KF_FLAG_Y_PER_DRAW = 1u << 1,
   /* Time-varying system matrices: the flagged matrix is [B][T][rows][cols] (per draw: time on
    * axis 0, the reference's 3-D convention, filters/utilities.py:1-20) and step t uses slice t
-   * for both its update and its predict (kalman_filter.py:231-252).  Forward filter only. */
+   * for both its update and its predict (kalman_filter.py:231-252).  kf_filter_forward (all seven)
+   * and kf_smoother (T, R, Q: the step that smooths t predicts from t with slice t); LDS-resident
+   * kernels only (m <~ 47).  kf_filter_backward: KF_ERR_UNSUPPORTED. */
   KF_FLAG_TV_T = 1u << 4,
   KF_FLAG_TV_Z = 1u << 5,
   KF_FLAG_TV_R = 1u << 6,
@@ -124,11 +126,13 @@ const char* kf_last_error(const kf_handle* h);
  * row of P) for the compiled H; other values fall back to the automatic choice. */
 int kf_set_lanes_per_draw(kf_handle* h, int lanes);
 
-/* Forward-kernel selection.  AUTO (static matrices): p == 1 and m <= 4 -> one lane per draw
- * ("lane"); p == 1, m <= 6 (m <= 9 for large batches) -> register-resident row-owner kernels
- * ("row"); m <= 16, p <= 8 with p == 1 / UnivariateFilter / KF_FLAG_H_DIAGONAL -> covariance in
- * MFMA accumulator layout, one wavefront per draw ("mfma": m >= 10, or m >= 11 for p > 1) or the
- * multivariate row kernel ("row"); 16 < m <= 48 with the same eligibility -> covariance as 2 x 2 /
+/* Forward-kernel selection.  AUTO (static matrices): p == 1, m <= 14 -> 4x4x4-block MFMA kernel with
+ * the state vector carried in the covariance tile, one wavefront per draw ("b4": always for m >= 10;
+ * for m = 7..9 and m = 4..6 while the batch cannot fill the chip with packed wavefronts, for m <= 3
+ * up to 2048 draws), else one lane per draw ("lane", m <= 4) / register-resident row-owner kernels
+ * ("row", m <= 9); m <= 16, p <= 8 with p == 1 / UnivariateFilter / KF_FLAG_H_DIAGONAL -> covariance
+ * in the 16 x 16 MFMA accumulator layout, one wavefront per draw ("mfma": p == 1 with m = 15, 16;
+ * m >= 11 for p > 1) or the multivariate row kernel ("row"); 16 < m <= 48 with the same eligibility -> covariance as 2 x 2 /
  * 3 x 3 blocks of 16 x 16 in accumulator layout ("mfma" as well); 48 < m <= 64 -> one workgroup of
  * four wavefronts per draw, one column block each ("mfma"); other tiles that fit LDS ->
  * generic LDS-resident kernel ("lds", also all time-varying models); else the workspace + MFMA
@@ -188,12 +192,12 @@ int kf_filter_backward(kf_handle* h, const kf_dims* dims,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* RTS smoother over the filtered tapes: smooth_a [B][T][m], smooth_P [B][T][m][m].
- * Only dims->B, T, m, r are used.  The gain uses the Moore-Penrose pseudo-inverse of
- * the one-step prediction covariance with numpy's default cutoff 1e-15 * sigma_max
+ * Only dims->B, T, m, r and the KF_FLAG_TV_T / _R / _Q flags are used.  The gain uses the Moore-Penrose
+ * pseudo-inverse of the one-step prediction covariance with numpy's default cutoff 1e-15 * sigma_max
  * (kalman_smoother.py:92): a Cholesky / Gauss-Jordan solve whenever that covariance is safely
- * positive definite, a Jacobi eigen-decomposition otherwise (m <= 64, given the
- * per-draw flag workspace -- without it the 47 < m <= 64 kernel returns NaN for such a draw;
- * beyond m = 64 the workspace path's Cholesky requires positive definiteness).  `workspace`: see kf_workspace_bytes. */
+ * positive definite, a Jacobi eigen-decomposition otherwise (m <= 64: given the per-draw flag
+ * workspace -- without it the 47 < m <= 64 kernel returns NaN for such a draw; m > 64: flagged draws
+ * are redone, the whole series, by one workgroup each).  `workspace`: see kf_workspace_bytes. */
 int kf_smoother(kf_handle* h, const kf_dims* dims,
                 const double* T, const double* R, const double* Q,
                 const double* filt_a, const double* filt_P,
