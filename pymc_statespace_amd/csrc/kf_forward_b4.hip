@@ -31,6 +31,8 @@
 // step  tile -= (u / sqrt F)(u / sqrt F)',  issued as NB more MFMAs (A = -u_hat, B = u_hat, k = 0 only);
 // u / sqrt F keeps the tile bitwise symmetric.  Reference operation order differs (Joseph form); results
 // agree to rounding (tests: 1e-8 on logp, 1e-9 on tapes).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "kf_b4.h"
