@@ -78,7 +78,8 @@ enum {
    * axis 0, the reference's 3-D convention, filters/utilities.py:1-20) and step t uses slice t
    * for both its update and its predict (kalman_filter.py:231-252).  kf_filter_forward (all seven)
    * and kf_smoother (T, R, Q: the step that smooths t predicts from t with slice t); LDS-resident
-   * kernels only (m <~ 47).  kf_filter_backward: KF_ERR_UNSUPPORTED. */
+   * kernels only (m <~ 47).  kf_filter_backward: all seven as well; the gradient of a flagged matrix is a tape of
+   * the same [B][T][rows][cols] shape. */
   KF_FLAG_TV_T = 1u << 4,
   KF_FLAG_TV_Z = 1u << 5,
   KF_FLAG_TV_R = 1u << 6,
@@ -179,7 +180,10 @@ int kf_filter_forward(kf_handle* h, const kf_dims* dims,
  * matrix entry as an independent variable (what autodiff of the reference graph
  * returns).  With KF_FLAG_H_DIAGONAL and p > 1 (Standard/Cholesky on the scalar-observation
  * kernels) g_H carries the diagonal only (off-diagonal entries 0) and g_P0 the symmetric part
- * of the entrywise gradient -- all a diagonal-H / symmetric-P0 parameterisation can see. */
+ * of the entrywise gradient -- all a diagonal-H / symmetric-P0 parameterisation can see.
+ * Time-varying matrices (KF_FLAG_TV_*): the gradient of a flagged matrix has that matrix's shape, [B][T][rows][cols]
+ * (slice t = the partial w.r.t. the slice step t used); unflagged ones stay per draw.  Served by the LDS-resident adjoint
+ * (KF_ERR_UNSUPPORTED when m, p do not fit 160 KiB). */
 int kf_filter_backward(kf_handle* h, const kf_dims* dims,
                        const double* y, const double* a0, const double* P0,
                        const double* T, const double* Z, const double* R,

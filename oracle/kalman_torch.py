@@ -28,20 +28,25 @@ def _t(x):
 
 
 def kalman_logp(y, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type="standard",
-                mvn_const="reference"):
-    """Batched (leading B) torch tensors -> (logp (B,), ll_obs (B,n)). y: (n,p) numpy/tensor."""
+                mvn_const="reference", time_varying=()):
+    """Batched (leading B) torch tensors -> (logp (B,), ll_obs (B,n)). y: (n,p) numpy/tensor.
+    Names in ``time_varying`` (subset of T,Z,R,H,Q,c,d) carry a time axis after the draw axis and step t uses slice t
+    for its update and its predict (reference filters/kalman_filter.py:231-252)."""
     y = torch.as_tensor(np.asarray(y), dtype=torch.float64)
     B, m = a0.shape
-    p = Z.shape[1]
+    tv = set(time_varying)
+    p = Z.shape[-2]
     n = y.shape[0]
     eye_m = torch.eye(m, dtype=torch.float64)
     eye_p = torch.eye(p, dtype=torch.float64)
-    RQR = R @ Q @ _t(R)
     a, P = a0, P0
-    cz = torch.zeros(B, m, dtype=torch.float64) if c is None else c
-    dz = torch.zeros(B, p, dtype=torch.float64) if d is None else d
+    c = torch.zeros(B, m, dtype=torch.float64) if c is None else c
+    d = torch.zeros(B, p, dtype=torch.float64) if d is None else d
+    full = dict(T=T, Z=Z, R=R, H=H, Q=Q, c=c, d=d)
     lls = []
     for t in range(n):
+        T, Z, R, H, Q, cz, dz = (full[k][:, t] if k in tv else full[k] for k in ("T", "Z", "R", "H", "Q", "c", "d"))
+        RQR = R @ Q @ _t(R)
         yt = y[t]
         miss = torch.isnan(yt)
         obs = (~miss).to(torch.float64)
@@ -97,16 +102,20 @@ NAMES = ("a0", "P0", "T", "Z", "R", "H", "Q", "c", "d")
 
 
 def logp_and_grads(y, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type="standard",
-                   mvn_const="reference", g_logp=None, g_ll_obs=None):
+                   mvn_const="reference", g_logp=None, g_ll_obs=None, time_varying=()):
     """Returns (logp, ll_obs, grads dict) with numpy arrays; grads of
-    sum_b g_logp[b] logp[b] + sum_{b,t} g_ll_obs[b,t] ll_obs[b,t]."""
+    sum_b g_logp[b] logp[b] + sum_{b,t} g_ll_obs[b,t] ll_obs[b,t].  The gradient of a matrix named in
+    ``time_varying`` has that matrix's (B,n,.,.) shape."""
     B, m = np.asarray(a0).shape
-    p = np.asarray(Z).shape[1]
+    p = np.asarray(Z).shape[-2]
+    n = np.asarray(y).shape[0]
+    tv = set(time_varying)
     vals = dict(a0=a0, P0=P0, T=T, Z=Z, R=R, H=H, Q=Q,
-                c=np.zeros((B, m)) if c is None else c, d=np.zeros((B, p)) if d is None else d)
+                c=np.zeros((B, n, m) if "c" in tv else (B, m)) if c is None else c,
+                d=np.zeros((B, n, p) if "d" in tv else (B, p)) if d is None else d)
     ts = {k: torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True) for k, v in vals.items()}
     logp, ll_obs = kalman_logp(y, ts["a0"], ts["P0"], ts["T"], ts["Z"], ts["R"], ts["H"], ts["Q"],
-                               ts["c"], ts["d"], filter_type=filter_type, mvn_const=mvn_const)
+                               ts["c"], ts["d"], filter_type=filter_type, mvn_const=mvn_const, time_varying=tv)
     gl = torch.ones(B, dtype=torch.float64) if g_logp is None else torch.as_tensor(g_logp)
     obj = (gl * logp).sum()
     if g_ll_obs is not None:

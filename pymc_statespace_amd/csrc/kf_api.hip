@@ -358,6 +358,15 @@ int kf_launch_backward_lds(kf_handle* h, const KfBwdArgs& a, hipStream_t stream)
 
 int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t workspace_bytes,
                        hipStream_t stream) {
+  // time-varying system matrices: the LDS-resident adjoint reloads slice t per step and writes gradient tapes
+  if (a.flags & KF_FLAG_TV_ANY) {
+    if (!kf_backward_lds_fits(a.m, a.p)) {
+      KF_SET_ERR(h, "kf_filter_backward: time-varying system matrices need the LDS-resident adjoint (m=%d p=%d does "
+                 "not fit %d B of LDS)", a.m, a.p, KF_LDS_BYTES_MAX);
+      return KF_ERR_UNSUPPORTED;
+    }
+    return kf_launch_backward_lds(h, a, stream);
+  }
   // 16 < m <= 48, scalar observations: block-tile adjoint (kf_backward_mfma_nb.hip); measured at
   // 4096 draws x 1000 steps the LDS adjoint took 144 ms (m = 20) .. 2.6 s (m = 40)
   if ((h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_MFMA) &&
@@ -509,10 +518,6 @@ extern "C" int kf_filter_backward(kf_handle* h, const kf_dims* dims, const doubl
   if (!y || !a0 || !P0 || !T || !Z || !R || !H || !Q || !pred_a || !pred_P) {
     KF_SET_ERR(h, "kf_filter_backward: inputs and the predicted tapes must be non-NULL");
     return KF_ERR_ARG;
-  }
-  if (dims->flags & KF_FLAG_TV_ANY) {
-    KF_SET_ERR(h, "kf_filter_backward: time-varying system matrices are not supported yet");
-    return KF_ERR_UNSUPPORTED;
   }
   if (!g_logp && !g_ll_obs) {
     KF_SET_ERR(h, "kf_filter_backward: g_logp and g_ll_obs are both NULL");

@@ -17,6 +17,10 @@
 // m x m x m products:  T P_f,  Gm (T P_f),  Gm T,  T' (Gm T).
 //
 // Every filter type shares this adjoint: for diagonal H the Univariate/Cholesky/Single
+// Time-varying system matrices (KF_FLAG_TV_*, [B][T][.][.]): step t loads slice t of each flagged matrix, and the
+// gradient of a flagged matrix is a tape of the same shape -- its accumulator is written to slice t and cleared at the
+// end of step t (R and Q: from the step's own Gm, since R_t Q_t R_t' enters P_pred[t+1] only).
+//
 // filters evaluate the same function as the Standard one (tests/test_oracle_torch.py);
 // Univariate reads diag(H) only (:493), so off-diagonal H is dropped on load and its gradient
 // is zero; Single flips the sign of d (:335).
@@ -232,9 +236,28 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_lds_kernel(const KfBwdArgs A) 
   const double* gpa = A.pred_a + b * (long)(n + 1) * m;
   const double* gpP = A.pred_P + b * (long)(n + 1) * mm;
   const double g_all = A.g_logp ? A.g_logp[b] : 0.0;
+  const unsigned tv = A.flags & KF_FLAG_TV_ANY;
+  const bool tv_rq = (tv & (KF_FLAG_TV_R | KF_FLAG_TV_Q)) != 0;
+  const int mr = m * r, rr = r * r;
+  if (tv_rq && live) {
+    // R Q R' differs per step: g_R / g_Q come from each step's Gm.  The one that is NOT time-varying is summed in place in
+    // global memory (lane e owns element e at every step)
+    if (!(tv & KF_FLAG_TV_R) && A.g_R) for (int e = lig; e < mr; e += G) A.g_R[b * (long)mr + e] = 0.0;
+    if (!(tv & KF_FLAG_TV_Q) && A.g_Q) for (int e = lig; e < rr; e += G) A.g_Q[b * (long)rr + e] = 0.0;
+  }
 
   for (int t = n - 1; t >= 0; --t) {
     const double g = g_all + (A.g_ll_obs ? A.g_ll_obs[b * (long)n + t] : 0.0);
+    if (tv) {  // slice t of the flagged matrices
+      const long bt = b * (long)n + t;
+      if (tv & KF_FLAG_TV_T) for (int e = lig; e < mm; e += G) Tl[e] = A.Tm[bt * mm + e];
+      if (tv & KF_FLAG_TV_Z) for (int e = lig; e < pm; e += G) Zl[e] = A.Z[bt * pm + e];
+      if (tv & KF_FLAG_TV_H) for (int e = lig; e < pp; e += G) {
+        int q1 = e / p, q2 = e - q1 * p;
+        Hl[e] = (univariate && q1 != q2) ? 0.0 : A.H[bt * pp + e];
+      }
+      if ((tv & KF_FLAG_TV_D) && A.d) for (int e = lig; e < p; e += G) dl[e] = A.d[bt * p + e];
+    }
     // ---- (1) tape + observation ---------------------------------------------------------------
     for (int e = lig; e < m; e += G) al[e] = gpa[(long)t * m + e];
     for (int e = lig; e < mm; e += G) P[e] = gpP[(long)t * mm + e];
@@ -490,6 +513,62 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_lds_kernel(const KfBwdArgs A) 
     for (int q = lig; q < p; q += G)
       if (ob[q] != 0.0) db[q] += dsign * vb[q];
     wsync();
+    if (tv) {  // gradients of the flagged matrices: this step's terms go to slice t, the accumulators restart
+      const long bt = b * (long)n + t;
+      if (tv_rq) {
+        const double* gR = A.R + ((tv & KF_FLAG_TV_R) ? bt : b) * (long)mr;
+        const double* gQ = A.Q + ((tv & KF_FLAG_TV_Q) ? bt : b) * (long)rr;
+        double* GR = AP;  // AP .. Gm (4 m^2 doubles) are dead until the next step
+        for (int e = lig; e < mr; e += G) {
+          int i = e / r, l = e - i * r;
+          double s = 0.0;
+          for (int j = 0; j < m; ++j) s += Gs[i * m + j] * gR[j * r + l];
+          GR[e] = s;
+        }
+        wsync();
+        if (live && A.g_R) {
+          double* o = A.g_R + ((tv & KF_FLAG_TV_R) ? bt : b) * (long)mr;
+          for (int e = lig; e < mr; e += G) {
+            int i = e / r, l = e - i * r;
+            double s = 0.0;
+            for (int k = 0; k < r; ++k) s += GR[i * r + k] * (gQ[k * r + l] + gQ[l * r + k]);
+            o[e] = (tv & KF_FLAG_TV_R) ? s : o[e] + s;
+          }
+        }
+        if (live && A.g_Q) {
+          double* o = A.g_Q + ((tv & KF_FLAG_TV_Q) ? bt : b) * (long)rr;
+          for (int e = lig; e < rr; e += G) {
+            int k = e / r, l = e - k * r;
+            double s = 0.0;
+            for (int i = 0; i < m; ++i) s += gR[i * r + k] * GR[i * r + l];
+            o[e] = (tv & KF_FLAG_TV_Q) ? s : o[e] + s;
+          }
+        }
+        for (int e = lig; e < mm; e += G) Gs[e] = 0.0;
+      }
+      if (tv & KF_FLAG_TV_T) for (int e = lig; e < mm; e += G) {
+        if (live && A.g_T) A.g_T[bt * mm + e] = Tb[e];
+        Tb[e] = 0.0;
+      }
+      if (tv & KF_FLAG_TV_Z) for (int e = lig; e < pm; e += G) {
+        if (live && A.g_Z) A.g_Z[bt * pm + e] = Zb[e];
+        Zb[e] = 0.0;
+      }
+      if (tv & KF_FLAG_TV_H) for (int e = lig; e < pp; e += G) {
+        int q1 = e / p, q2 = e - q1 * p;
+        if (live && A.g_H) A.g_H[bt * pp + e] = (univariate && q1 != q2) ? 0.0 : Hb[e];
+        Hb[e] = 0.0;
+      }
+      if (tv & KF_FLAG_TV_C) for (int e = lig; e < m; e += G) {
+        if (live && A.g_c) A.g_c[bt * m + e] = cb[e];
+        cb[e] = 0.0;
+      }
+      if (tv & KF_FLAG_TV_D) for (int e = lig; e < p; e += G) {
+        if (live && A.g_d) A.g_d[bt * p + e] = db[e];
+        db[e] = 0.0;
+      }
+      wsync();
+    }
   }
 
   // ---- gradients out ------------------------------------------------------------------------------------
@@ -497,7 +576,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_lds_kernel(const KfBwdArgs A) 
   const double* gR = A.R + b * (long)m * r;
   const double* gQ = A.Q + b * (long)r * r;
   double* GR = AP;  // m x r scratch (r <= m is not required: AP..Gm are contiguous 4 m^2)
-  if ((long)m * r <= 4L * mm) {
+  if (!tv_rq && (long)m * r <= 4L * mm) {
     for (int e = lig; e < m * r; e += G) {
       int i = e / r, l = e - i * r;
       double s = 0.0;
@@ -509,21 +588,21 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_lds_kernel(const KfBwdArgs A) 
   if (live) {
     if (A.g_a0) for (int e = lig; e < m; e += G) A.g_a0[b * m + e] = ab[e];
     if (A.g_P0) for (int e = lig; e < mm; e += G) A.g_P0[b * mm + e] = Pb[e];
-    if (A.g_T) for (int e = lig; e < mm; e += G) A.g_T[b * mm + e] = Tb[e];
-    if (A.g_Z) for (int e = lig; e < pm; e += G) A.g_Z[b * pm + e] = Zb[e];
-    if (A.g_H) for (int e = lig; e < pp; e += G) {
+    if (A.g_T && !(tv & KF_FLAG_TV_T)) for (int e = lig; e < mm; e += G) A.g_T[b * mm + e] = Tb[e];
+    if (A.g_Z && !(tv & KF_FLAG_TV_Z)) for (int e = lig; e < pm; e += G) A.g_Z[b * pm + e] = Zb[e];
+    if (A.g_H && !(tv & KF_FLAG_TV_H)) for (int e = lig; e < pp; e += G) {
       int q1 = e / p, q2 = e - q1 * p;
       A.g_H[b * pp + e] = (univariate && q1 != q2) ? 0.0 : Hb[e];
     }
-    if (A.g_c) for (int e = lig; e < m; e += G) A.g_c[b * m + e] = cb[e];
-    if (A.g_d) for (int e = lig; e < p; e += G) A.g_d[b * p + e] = db[e];
-    if (A.g_R) for (int e = lig; e < m * r; e += G) {
+    if (A.g_c && !(tv & KF_FLAG_TV_C)) for (int e = lig; e < m; e += G) A.g_c[b * m + e] = cb[e];
+    if (A.g_d && !(tv & KF_FLAG_TV_D)) for (int e = lig; e < p; e += G) A.g_d[b * p + e] = db[e];
+    if (A.g_R && !tv_rq) for (int e = lig; e < m * r; e += G) {
       int i = e / r, l = e - i * r;
       double s = 0.0;
       for (int k = 0; k < r; ++k) s += GR[i * r + k] * (gQ[k * r + l] + gQ[l * r + k]);
       A.g_R[b * (long)m * r + e] = s;
     }
-    if (A.g_Q) for (int e = lig; e < r * r; e += G) {
+    if (A.g_Q && !tv_rq) for (int e = lig; e < r * r; e += G) {
       int k = e / r, l = e - k * r;
       double s = 0.0;
       for (int i = 0; i < m; ++i) s += gR[i * r + k] * GR[i * r + l];

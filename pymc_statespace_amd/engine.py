@@ -237,46 +237,61 @@ class KalmanEngine:
     # --------------------------------------------------------------- backward
     def backward(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, predicted_states,
                  predicted_covs, g_logp=None, g_ll_obs=None, filter_type="standard",
-                 mvn_const="reference", want_cd=False, h_diagonal=False):
+                 mvn_const="reference", want_cd=False, h_diagonal=False, time_varying=()):
         """kf_filter_backward -> dict of per-draw gradients (a0,P0,T,Z,R,H,Q[,c,d]).
 
         ``h_diagonal=True`` (KF_FLAG_H_DIAGONAL) lets Standard/Cholesky with p > 1, m <= 48 use the
         scalar-observation adjoint kernel: g["H"] then carries the diagonal only and g["P0"] the
         symmetric part of the entrywise gradient (all a symmetric / diagonal parameterisation sees).
         Unlike ``forward`` this is never auto-detected: a dense-H model that happens to be diagonal
-        at the current point still needs its off-diagonal partials."""
-        T = self.to_device(T)
-        B, m = T.shape[0], T.shape[1]
+        at the current point still needs its off-diagonal partials.
+
+        ``time_varying`` as in ``forward``; the gradient of a matrix named there has its (B,n,.,.) shape."""
+        tv = set(time_varying)
+        if not tv <= set(_lib.KF_FLAG_TV):
+            raise ValueError(f"time_varying must be a subset of {sorted(_lib.KF_FLAG_TV)}")
+        P0 = self.to_device(P0)
+        B, m = P0.shape[0], P0.shape[1]
         Z = self.to_device(Z)
-        p = Z.shape[1]
+        p = Z.shape[-2]
         R = self.to_device(R)
-        r = R.shape[2]
+        r = R.shape[-1]
         y = self.to_device(y)
         y_per_draw = y.ndim == 3
         n = y.shape[-2]
+
+        def shp(name, *core):
+            return (B, n) + core if name in tv else (B,) + core
+
         a0 = self.to_device(a0, (B, m))
-        P0 = self.to_device(P0, (B, m, m))
-        H = self.to_device(H, (B, p, p))
-        Q = self.to_device(Q, (B, r, r))
-        c = self.to_device(c, (B, m)) if c is not None else None
-        d = self.to_device(d, (B, p)) if d is not None else None
+        T = self.to_device(T, shp("T", m, m))
+        Z = self.to_device(Z, shp("Z", p, m))
+        R = self.to_device(R, shp("R", m, r))
+        H = self.to_device(H, shp("H", p, p))
+        Q = self.to_device(Q, shp("Q", r, r))
+        c = self.to_device(c, shp("c", m)) if c is not None else None
+        d = self.to_device(d, shp("d", p)) if d is not None else None
         pa = self.to_device(predicted_states, (B, n + 1, m))
         pP = self.to_device(predicted_covs, (B, n + 1, m, m))
         g_logp = self.to_device(g_logp, (B,)) if g_logp is not None else None
         g_ll = self.to_device(g_ll_obs, (B, n)) if g_ll_obs is not None else None
         dims = self._dims(B, n, p, m, r, filter_type, mvn_const, y_per_draw)
+        for name in tv:
+            dims.flags |= _lib.KF_FLAG_TV[name]
         if h_diagonal:
             dims.flags |= _lib.KF_FLAG_H_DIAGONAL
         dev, f64 = self.device, torch.float64
+
+        def empty(name, *core):
+            return torch.empty(shp(name, *core), device=dev, dtype=f64)
+
         g = dict(
             a0=torch.empty(B, m, device=dev, dtype=f64), P0=torch.empty(B, m, m, device=dev, dtype=f64),
-            T=torch.empty(B, m, m, device=dev, dtype=f64), Z=torch.empty(B, p, m, device=dev, dtype=f64),
-            R=torch.empty(B, m, r, device=dev, dtype=f64), H=torch.empty(B, p, p, device=dev, dtype=f64),
-            Q=torch.empty(B, r, r, device=dev, dtype=f64),
+            T=empty("T", m, m), Z=empty("Z", p, m), R=empty("R", m, r), H=empty("H", p, p), Q=empty("Q", r, r),
         )
         if want_cd:
-            g["c"] = torch.empty(B, m, device=dev, dtype=f64)
-            g["d"] = torch.empty(B, p, device=dev, dtype=f64)
+            g["c"] = empty("c", m)
+            g["d"] = empty("d", p)
         ws, ws_bytes = self._workspace(dims, _lib.KF_WS_BACKWARD)  # large m only (kf_backward_big.hip)
         rc = self.lib.kf_filter_backward(
             self._h, C.byref(dims), _ptr(y), _ptr(a0), _ptr(P0), _ptr(T), _ptr(Z), _ptr(R), _ptr(H),

@@ -41,6 +41,28 @@ def _col(x):
     return x[:, 0] if x.ndim == 2 and x.shape[1] == 1 else x
 
 
+_TV_ORDER = ("T", "Z", "R", "H", "Q", "c", "d")
+
+
+def _lead_system(T, Z, R, H, Q, c, d):
+    """One draw's system matrices in the reference layouts -> (arrays with a leading draw axis, time_varying names).
+    A matrix with one more axis than its static form (T (n,m,m); c (n,m,1)) is time-varying: slice t at step t
+    (reference filters/utilities.py:1-20, kalman_filter.py:231-252)."""
+    out, tv = [], []
+    for name, x in zip(_TV_ORDER, (T, Z, R, H, Q, c, d)):
+        x = np.asarray(x, dtype=np.float64)
+        if name in ("c", "d"):
+            if x.ndim == 3 or (x.ndim == 2 and x.shape[-1] != 1):
+                tv.append(name)
+                x = x[..., 0] if x.ndim == 3 else x
+            else:
+                x = _col(x)
+        elif x.ndim == 3:
+            tv.append(name)
+        out.append(x[None])
+    return out, tuple(tv)
+
+
 def perform_filter(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standard",
                    mvn_const="reference", h_diagonal=False, engine=None, want=(True,) * 6):
     """One draw, reference layouts in (data (n,p,1), a0 (m,1), c (m,1), d (p,1)) -> the six
@@ -51,10 +73,9 @@ def perform_filter(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standard",
     data = np.asarray(data, dtype=np.float64)
     if data.ndim == 3:
         data = data[..., 0]
-    res = eng.forward(data, _col(a0)[None], np.asarray(P0)[None], np.asarray(T)[None],
-                      np.asarray(Z)[None], np.asarray(R)[None], np.asarray(H)[None],
-                      np.asarray(Q)[None], _col(c)[None], _col(d)[None],
-                      filter_type=filter_type, mvn_const=mvn_const,
+    sysm, tv = _lead_system(T, Z, R, H, Q, c, d)
+    res = eng.forward(data, _col(a0)[None], np.asarray(P0)[None], *sysm,
+                      filter_type=filter_type, mvn_const=mvn_const, time_varying=tv,
                       h_diagonal=bool(h_diagonal),  # never auto-detected here: that costs a host sync per call
                       store_filtered=bool(want[0] or want[2]), store_predicted=bool(want[1] or want[3]),
                       store_ll_obs=bool(want[5]))
@@ -88,18 +109,18 @@ def perform_logp_and_grad(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standa
     data = np.asarray(data, dtype=np.float64)
     if data.ndim == 3:
         data = data[..., 0]
-    args = (data, _col(a0)[None], np.asarray(P0)[None], np.asarray(T)[None], np.asarray(Z)[None],
-            np.asarray(R)[None], np.asarray(H)[None], np.asarray(Q)[None], _col(c)[None], _col(d)[None])
+    sysm, tv = _lead_system(T, Z, R, H, Q, c, d)
+    args = (data, _col(a0)[None], np.asarray(P0)[None], *sysm)
     dev = [eng.to_device(x) for x in args]
     res = eng.forward(*dev, filter_type=filter_type, mvn_const=mvn_const, h_diagonal=bool(h_diagonal),
-                      store_filtered=False, store_ll_obs=False)
+                      store_filtered=False, store_ll_obs=False, time_varying=tv)
     g = eng.backward(*dev, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
                      g_logp=np.ones(1), filter_type=filter_type, mvn_const=mvn_const, want_cd=True,
-                     h_diagonal=bool(h_diagonal))
+                     h_diagonal=bool(h_diagonal), time_varying=tv)
     _raise_if_not_pd(res.info)
     out = {k: g[k][0].cpu().numpy() for k in GRAD_INPUT_NAMES}
     for k in ("a0", "c", "d"):
-        out[k] = out[k][:, None]
+        out[k] = out[k][..., None]  # columns, as the inputs ((m,1); time-varying (n,m,1))
     return [np.asarray(res.logp[0].item(), dtype=np.float64)] + [out[k] for k in GRAD_INPUT_NAMES]
 
 
@@ -146,17 +167,16 @@ def perform_filter_grad(data, a0, P0, T, Z, R, H, Q, c, d, predicted_states, pre
     pa = np.asarray(predicted_states, dtype=np.float64)
     if pa.ndim == 3:
         pa = pa[..., 0]
-    g = eng.backward(data, _col(a0)[None], np.asarray(P0)[None], np.asarray(T)[None],
-                     np.asarray(Z)[None], np.asarray(R)[None], np.asarray(H)[None],
-                     np.asarray(Q)[None], _col(c)[None], _col(d)[None],
+    sysm, tv = _lead_system(T, Z, R, H, Q, c, d)
+    g = eng.backward(data, _col(a0)[None], np.asarray(P0)[None], *sysm,
                      predicted_states=pa[None], predicted_covs=np.asarray(predicted_covs)[None],
                      g_logp=np.atleast_1d(np.asarray(g_logp, dtype=np.float64)),
                      g_ll_obs=np.asarray(g_ll_obs, dtype=np.float64)[None],
                      filter_type=filter_type, mvn_const=mvn_const, want_cd=True,
-                     h_diagonal=h_diagonal)
+                     h_diagonal=h_diagonal, time_varying=tv)
     out = {k: g[k][0].cpu().numpy() for k in GRAD_INPUT_NAMES}
     for k in ("a0", "c", "d"):
-        out[k] = out[k][:, None]
+        out[k] = out[k][..., None]
     return [out[k] for k in GRAD_INPUT_NAMES]
 
 
@@ -165,8 +185,9 @@ def perform_smoother(T, R, Q, filtered_states, filtered_covs, engine=None):
     fa = np.asarray(filtered_states, dtype=np.float64)
     if fa.ndim == 3:
         fa = fa[..., 0]
+    tv = tuple(nm for nm, x in zip(("T", "R", "Q"), (T, R, Q)) if np.asarray(x).ndim == 3)
     sa, sP = eng.smooth(np.asarray(T)[None], np.asarray(R)[None], np.asarray(Q)[None], fa[None],
-                        np.asarray(filtered_covs)[None])
+                        np.asarray(filtered_covs)[None], time_varying=tv)
     return [sa[0].cpu().numpy()[..., None], sP[0].cpu().numpy()]
 
 
@@ -249,7 +270,7 @@ def _build_ops():
 
         def infer_shape(self, fgraph, node, shapes):
             n = shapes[0][0]
-            m = shapes[3][0]
+            m = shapes[3][-1]  # T is (m,m), or (n,m,m) when time-varying
             return [(n, m, 1), (n + 1, m, 1), (n, m, m), (n + 1, m, m), (), (n,)]
 
         def connection_pattern(self, node):
@@ -338,7 +359,9 @@ def _build_ops():
 
         @_vectorize_node.register(KalmanFilterOp)
         def _vectorize_kalman_filter(op, node, data, *mats):
-            core = [2] * 9  # a0, c, d are (m,1) / (p,1) columns: every per-draw input is 2-D
+            core = [v.type.ndim for v in node.inputs[1:]]  # a0, c, d are (m,1) / (p,1) columns: 2-D per draw
+            if any(nd != 2 for nd in core):
+                raise NotImplementedError("vectorize_graph over a time-varying Kalman filter node")
             if data.type.ndim != node.inputs[0].type.ndim or not any(
                     x.type.ndim > nd for x, nd in zip(mats, core)):
                 return op.make_node(data, *mats)
@@ -384,7 +407,8 @@ def _build_ops():
 def kalman_filter_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type="standard",
                         mvn_const="reference", h_diagonal=False, outputs="all"):
     """Symbolic equivalent of BaseFilter.build_graph (reference kalman_filter.py:126-163).
-    Static (2-D) system matrices only; c, d default to zeros (initialize_intercepts :36-51).
+    System matrices are 2-D (static) or 3-D (time-varying, time on axis 0: step t uses slice t, and the gradient
+    of such a matrix has its 3-D shape); c, d default to zeros (initialize_intercepts :36-51).
     ``h_diagonal=True``: the model's H is diagonal by construction (e.g. VARMAX measurement
     error, reference models/VARMAX.py:80-83) -- the gradient then runs on the scalar-observation
     adjoint kernel and is returned for diag(H) only (KF_FLAG_H_DIAGONAL, include/kf.h).
@@ -393,18 +417,14 @@ def kalman_filter_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type
     pt = ops["pt"]
     T, Z, R, H, Q = (pt.as_tensor_variable(x) for x in (T, Z, R, H, Q))
     for prm, name in zip((T, Z, R, H, Q), ("T", "Z", "R", "H", "Q")):
-        if prm.ndim == 3:
-            raise NotImplementedError(
-                f"Matrix {name} is time varying (3-D); the MI355X path supports static system "
-                "matrices only")
-        if prm.ndim != 2:
+        if prm.ndim not in (2, 3):
             # reference filters/utilities.py:16-18
             raise ValueError(
                 f"Matrix {name} has {prm.ndim}, it should either 2 (static) or 3 (time varying).")
     if c is None:
-        c = pt.zeros((T.shape[0], 1))
+        c = pt.zeros((T.shape[-1], 1))
     if d is None:
-        d = pt.zeros((Z.shape[0], 1))
+        d = pt.zeros((Z.shape[-2], 1))
     if outputs == "logp":  # the sampler's path: value and gradient from one node, no tapes over PCIe
         return ops["KalmanLogpOp"](filter_type, mvn_const, h_diagonal)(data, a0, P0, T, Z, R, H, Q, c, d)[0]
     return list(ops["KalmanFilterOp"](filter_type, mvn_const, h_diagonal)(

@@ -539,6 +539,41 @@ def test_op_fused_logp_and_grad_batched_and_partial_outputs():
         op.perform_filter_batched(y[..., None], w["a0"][..., None], w["P0"], w["T"], w["Z"], w["R"], Hb, w["Q"], cB, dB)
 
 
+def test_op_bodies_with_time_varying_matrices():
+    """Reference layouts with time on axis 0 (T (n,m,m), c (n,m,1)): the Op bodies pass the flags on and the gradient
+    of a time-varying input has that input's shape."""
+    from oracle import kalman_torch as kt
+    from pymc_statespace_amd import op
+
+    n, m, p, r = 15, 4, 1, 2
+    w = W.random_dense(1, n, p, m, r, seed=3)
+    wave = 0.8 + 0.2 * np.cos(np.arange(n))
+    Tt = w["T"][0][None] * wave[:, None, None]
+    Qt = w["Q"][0][None] * (1.5 - wave)[:, None, None]
+    ct = 0.1 * np.sin(np.arange(n))[:, None, None] * np.ones((n, m, 1))
+    d = np.array([[0.2]])
+    one = [w["y"][..., None], w["a0"][0][:, None], w["P0"][0], Tt, w["Z"][0], w["R"][0], w["H"][0], Qt, ct, d]
+    tv = ("T", "Q", "c")
+    lp, ll, gt = kt.logp_and_grads(w["y"], w["a0"], w["P0"], Tt[None], w["Z"], w["R"], w["H"], Qt[None],
+                                   c=ct[None, ..., 0], d=d[None, :, 0], g_logp=np.ones(1), time_varying=tv)
+    outs = op.perform_logp_and_grad(*one)
+    assert abs(float(outs[0]) - float(lp[0])) < 1e-8
+    for name, gr, x in zip(op.GRAD_INPUT_NAMES, outs[1:], one[1:]):
+        assert gr.shape == x.shape, name
+        assert_allclose(gr.reshape(gt[name][0].shape), gt[name][0], rtol=1e-9, atol=1e-10, err_msg=name)
+    full = op.perform_filter(*one)
+    assert abs(float(full[4]) - float(lp[0])) < 1e-8 and full[0].shape == (n, m, 1)
+    assert_allclose(full[5], ll[0], rtol=0, atol=1e-9)
+    grads = op.perform_filter_grad(*one, full[1], full[3], np.asarray(1.0), np.zeros(n))
+    for name, gr, g2 in zip(op.GRAD_INPUT_NAMES, grads, outs[1:]):
+        assert_allclose(gr, g2, rtol=1e-12, atol=1e-12, err_msg=name)
+    ss, sc = op.perform_smoother(Tt, w["R"][0], Qt, full[0], full[2])
+    ra, rP = kn.kalman_smoother(Tt[None], w["R"], Qt[None], full[0][None, ..., 0], full[2][None],
+                                time_varying=("T", "Q"))
+    assert_allclose(ss[..., 0], ra[0], rtol=1e-8, atol=1e-8)
+    assert_allclose(sc, rP[0], rtol=1e-8, atol=1e-8)
+
+
 # ----------------------------------------------------------------------------------------------
 # forward kernel families: LDS-resident generic vs register-resident row / row-split (p == 1)
 # ----------------------------------------------------------------------------------------------
@@ -894,18 +929,88 @@ def test_time_varying_smoother_needs_the_lds_kernel(eng):
         eng.smooth(Tt, w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"], time_varying=("T",))
 
 
-def test_time_varying_gradient_is_declared_unsupported(eng):
-    from pymc_statespace_amd import KalmanError, _lib
+def _tv_mats(w, tv, n, rng):
+    B, m, p = w["B"], w["m"], w["p"]
+    mats = dict(T=w["T"], Z=w["Z"], R=w["R"], H=w["H"], Q=w["Q"],
+                c=0.1 * rng.standard_normal((B, m)), d=0.1 * rng.standard_normal((B, p)))
+    for k, name in enumerate(tv):
+        x = np.repeat(mats[name][:, None], n, axis=1)
+        wave = (0.8 + 0.2 * np.cos(np.arange(n) + k))[None, :]
+        mats[name] = x * wave.reshape(wave.shape + (1,) * (x.ndim - 2))
+    return mats
 
-    w = W.random_dense(2, 5, 1, 3, 1, seed=1)
-    res = eng.forward(*_args(w))
-    import ctypes as C
 
-    dims = _lib.KfDims(2, 5, 1, 3, 1, 0, _lib.KF_FLAG_TV["T"])
-    rc = eng.lib.kf_filter_backward(eng._h, C.byref(dims), *([C.c_void_p(res.logp.data_ptr())] * 10),
-                                    *([C.c_void_p(res.logp.data_ptr())] * 4), *([None] * 9), None, 0, None)
-    assert rc == _lib.KF_ERR_UNSUPPORTED
-    assert KalmanError is not None
+TVG = [("T",), ("Z", "d"), ("R",), ("Q",), ("H", "c"), ("R", "Q"), ("T", "Z", "R", "H", "Q", "c", "d")]
+
+
+@pytest.mark.parametrize("ft", ["standard", "univariate"])
+@pytest.mark.parametrize("tv", TVG, ids=["".join(t) for t in TVG])
+@pytest.mark.parametrize("pm", [(1, 4), (2, 5), (1, 10)], ids=lambda x: f"p{x[0]}m{x[1]}")
+def test_time_varying_gradient_matches_autograd(eng, ft, tv, pm):
+    """reverse-mode gradient with time-varying system matrices (LDS-resident adjoint).  The gradient
+    of a flagged matrix is a (B,n,.,.) tape; unflagged ones are per draw.  Oracle: torch autograd through the same
+    recursion with slice t at step t (kalman_filter.py:231-252)."""
+    from oracle import kalman_torch as kt
+
+    p, m = pm
+    B, n, r = 3, 12, 2
+    w = W.random_dense(B, n, p, m, r, seed=31 + m)
+    rng = np.random.default_rng(17)
+    mats = _tv_mats(w, tv, n, rng)
+    y = w["y"].copy()
+    y[5] = np.nan
+    g_logp = rng.standard_normal(B)
+    g_ll = 0.3 * rng.standard_normal((B, n))
+    args = (y, w["a0"], w["P0"], mats["T"], mats["Z"], mats["R"], mats["H"], mats["Q"], mats["c"], mats["d"])
+    _, _, gt = kt.logp_and_grads(*args, filter_type=ft, mvn_const="exact", g_logp=g_logp, g_ll_obs=g_ll,
+                                 time_varying=tv)
+    res = eng.forward(*args, filter_type=ft, mvn_const="exact", time_varying=tv)
+    g = eng.backward(*args, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
+                     g_logp=g_logp, g_ll_obs=g_ll, filter_type=ft, mvn_const="exact", want_cd=True, time_varying=tv)
+    for k in ("a0", "P0", "T", "Z", "R", "H", "Q", "c", "d"):
+        a, b = g[k].cpu().numpy(), gt[k]
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        if ft == "univariate" and k in ("P0", "Q", "H"):
+            # entrywise partials w.r.t. symmetric inputs differ between the recursions; their symmetric parts agree
+            a, b = a + np.swapaxes(a, -1, -2), b + np.swapaxes(b, -1, -2)
+            if k == "H":
+                a, b = np.diagonal(a, axis1=-2, axis2=-1), np.diagonal(b, axis1=-2, axis2=-1)
+        assert np.max(np.abs(a - b)) / (1.0 + np.max(np.abs(b))) < 1e-9, (ft, tv, k)
+
+
+def test_time_varying_gradient_of_repeated_matrices_sums_to_the_static_one(eng):
+    """Every matrix repeated n times: the time-summed gradient tapes are the static gradients."""
+    B, n, p, m, r = 4, 20, 1, 6, 2
+    w = W.random_dense(B, n, p, m, r, seed=8)
+    args = _args(w)
+    res = eng.forward(*args)
+    g0 = eng.backward(*args, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
+                      g_logp=np.ones(B))
+    tv = ("T", "Z", "R", "H", "Q")
+    rep = {k: np.repeat(w[k][:, None], n, axis=1) for k in tv}
+    args_tv = (w["y"], w["a0"], w["P0"], rep["T"], rep["Z"], rep["R"], rep["H"], rep["Q"])
+    res_tv = eng.forward(*args_tv, time_varying=tv)
+    assert_allclose(res_tv.logp.cpu().numpy(), res.logp.cpu().numpy(), rtol=1e-12)
+    g1 = eng.backward(*args_tv, predicted_states=res_tv.predicted_states, predicted_covs=res_tv.predicted_covs,
+                      g_logp=np.ones(B), time_varying=tv)
+    for k in ("a0", "P0"):
+        assert_allclose(g1[k].cpu().numpy(), g0[k].cpu().numpy(), rtol=1e-9, atol=1e-9)
+    for k in tv:
+        assert g1[k].shape[:2] == (B, n)
+        assert_allclose(g1[k].sum(1).cpu().numpy(), g0[k].cpu().numpy(), rtol=1e-8, atol=1e-9, err_msg=k)
+
+
+def test_time_varying_gradient_needs_the_lds_kernel(eng):
+    from pymc_statespace_amd import KalmanError
+
+    n = 4
+    w = W.random_dense(1, n, 1, 70, 2, seed=5)
+    Tt = np.repeat(w["T"][:, None], n, axis=1)
+    flt = kn.kalman_filter(*_args(w))
+    with pytest.raises(KalmanError, match="time-varying"):
+        eng.backward(w["y"], w["a0"], w["P0"], Tt, w["Z"], w["R"], w["H"], w["Q"],
+                     predicted_states=flt["predicted_states"], predicted_covs=flt["predicted_covs"],
+                     g_logp=np.ones(1), time_varying=("T",))
 
 
 BWD_SPLITS = [(10, 1), (10, 2), (10, 3), (10, 5), (8, 1), (8, 2), (8, 4), (6, 1), (6, 3), (4, 1), (4, 2), (2, 1)]
