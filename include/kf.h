@@ -52,8 +52,9 @@
 extern "C" {
 #endif
 
-#define KF_ABI_VERSION 3 /* 2: KF_FLAG_H_DIAGONAL, KF_KERNEL_MFMA, kf_dare, kf_simulate_statespace, workspace use by smoother/backward; \
-                            3: kf_workspace_bytes_for, kf_forward_kernel_name_ws; every entry point runs on the handle's device */
+#define KF_ABI_VERSION 4 /* 2: KF_FLAG_H_DIAGONAL, KF_KERNEL_MFMA, kf_dare, kf_simulate_statespace, workspace use by smoother/backward; \
+                            3: kf_workspace_bytes_for, kf_forward_kernel_name_ws; every entry point runs on the handle's device; \
+                            4: kf_dare_backward, time-varying matrices in kf_filter_backward */
 
 typedef struct kf_handle kf_handle;
 
@@ -250,6 +251,18 @@ int kf_dare(kf_handle* h, int64_t B, int32_t m, int32_t p, int32_t r, const doub
             const double* Z, const double* R, const double* H, const double* Q,
             const double* P_init, double* P, int32_t* info, int32_t max_iter, double tol,
             void* stream);
+
+/* Reverse mode through kf_dare: given P ([B][m][m], the fixed point kf_dare returned) and g_P = d objective / d P,
+ * the gradient with respect to the filter's own matrices, every entry independent.  Replaces SolveDiscreteARE.grad
+ * (pymc_statespace/utils/pytensor_scipy.py:33-60, Kao & Hennequin 2020: one discrete Lyapunov solve with the
+ * closed-loop matrix T' - Z' K) composed with A = T', B = Z', Q_d = R Q R', R_d = H of
+ * SteadyStateFilter.build_graph (filters/kalman_filter.py:388).  Any output may be NULL; accumulate != 0 adds to what
+ * the outputs hold -- the direct gradient kf_filter_backward wrote for the filter started from P, with g_P = its g_P0.
+ * info[b] (may be NULL): 0 ok, 1 = the Lyapunov iteration did not converge, 2 = Z P Z' + H not positive definite. */
+int kf_dare_backward(kf_handle* h, int64_t B, int32_t m, int32_t p, int32_t r, const double* T,
+                     const double* Z, const double* R, const double* H, const double* Q,
+                     const double* P, const double* g_P, double* g_T, double* g_Z, double* g_R,
+                     double* g_H, double* g_Q, int32_t accumulate, int32_t* info, void* stream);
 
 /* Batched unconditional simulation of the state space model, n_sims trajectories per draw:
  * simulate_statespace / unconditional_simulations (pymc_statespace/utils/simulation.py:29-79)

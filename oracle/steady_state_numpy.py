@@ -75,3 +75,47 @@ def simulate_statespace(T, Z, R, H, Q, state_noise, obs_noise, x0=None):
         states[t] = T @ states[t - 1] + R @ state_innovations[t]
         obs[t] = Z @ states[t - 1] + (obs_innovations[t] if k_obs_noise != 0 else 0.0)
     return states, obs
+
+
+def dare_grad(A, B, Q, R, dX):
+    """Reverse-mode gradient of X = solve_discrete_are(A, B, Q, R): the reference's SolveDiscreteARE.grad
+    (utils/pytensor_scipy.py:33-60, Kao & Hennequin 2020), line by line.  Returns (A_bar, B_bar, Q_bar, R_bar)."""
+    from scipy.linalg import solve_discrete_lyapunov
+
+    X = solve_discrete_are(A, B, Q, R)
+    K_inner = R + B.T @ X @ B                                   # :41
+    K_inner_inv = np.linalg.solve(K_inner, np.eye(R.shape[0]))  # :42
+    K = K_inner_inv @ B.T @ X @ A                               # :43
+    A_tilde = A - B @ K                                         # :45
+    dX_symm = 0.5 * (dX + dX.T)                                 # :47
+    S = solve_discrete_lyapunov(A_tilde, dX_symm)               # :48   S = A~ S A~' + dX_symm
+    A_bar = 2.0 * X @ A_tilde @ S                               # :50
+    B_bar = -2.0 * X @ A_tilde @ S @ K.T                        # :51
+    Q_bar = S                                                   # :52
+    R_bar = K @ S @ K.T                                         # :53
+    return A_bar, B_bar, Q_bar, R_bar
+
+
+def steady_state_grad(T, Z, R, H, Q, g_P):
+    """Gradient of <g_P, P_steady> with P_steady = solve_discrete_are(T', Z', R Q R', H) (kalman_filter.py:388) w.r.t.
+    the filter's own matrices, every entry independent: the chain rule through A = T', B = Z', Q_d = R Q R', R_d = H."""
+    A_bar, B_bar, Q_bar, R_bar = dare_grad(T.T, Z.T, R @ Q @ R.T, H, g_P)
+    return dict(T=A_bar.T, Z=B_bar.T, H=R_bar, R=Q_bar @ R @ Q.T + Q_bar.T @ R @ Q, Q=R.T @ Q_bar @ R)
+
+
+def steady_state_logp_and_grad(y, a0, P0, T, Z, R, H, Q, c=None):
+    """(logp, gradients) of the SteadyStateFilter's log-likelihood, every matrix entry independent: torch autograd of
+    the Standard recursion started from P_steady (oracle/kalman_torch.py; complete data: the same function as the
+    frozen-F_inv recursion above) plus the Riccati adjoint of its g_P0 (steady_state_grad)."""
+    from . import kalman_torch as kt
+
+    y = np.asarray(y, dtype=np.float64)
+    m = T.shape[0]
+    Ps = solve_discrete_are(T.T, Z.T, R @ Q @ R.T, H)
+    cc = np.zeros(m) if c is None else np.asarray(c, dtype=np.float64).reshape(m)
+    lp, _, g = kt.logp_and_grads(y, np.asarray(a0, dtype=np.float64).reshape(1, m), Ps[None], T[None], Z[None], R[None],
+                                 H[None], Q[None], c=cc[None], g_logp=np.ones(1))
+    out = {k: g[k][0] for k in ("a0", "T", "Z", "R", "H", "Q", "c")}
+    for k, v in steady_state_grad(T, Z, R, H, Q, g["P0"][0]).items():
+        out[k] = out[k] + v
+    return float(lp[0]), out

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # KF_LIB_PATH: developer override for A/B experiments with instrumented builds of the same ABI
 LIB_PATH = os.environ.get("KF_LIB_PATH") or os.path.join(_HERE, "libkf_hip.so")
 
-KF_ABI_VERSION = 3
+KF_ABI_VERSION = 4
 
 KF_FILTER = {"standard": 0, "cholesky": 1, "univariate": 2, "single": 3}
 KF_FLAG_MVN_CONST_EXACT = 1 << 0
@@ -28,7 +28,7 @@ EXPORTS = (
     "kf_abi_version", "kf_create", "kf_destroy", "kf_last_error", "kf_set_lanes_per_draw",
     "kf_set_forward_kernel", "kf_forward_kernel_name", "kf_forward_kernel_name_ws",
     "kf_workspace_bytes", "kf_workspace_bytes_for", "kf_filter_forward", "kf_filter_backward", "kf_smoother",
-    "kf_assemble", "kf_lyapunov", "kf_conditional_simulation", "kf_dare", "kf_simulate_statespace",
+    "kf_assemble", "kf_lyapunov", "kf_conditional_simulation", "kf_dare", "kf_dare_backward", "kf_simulate_statespace",
 )
 
 
@@ -100,6 +100,9 @@ def load():
     lib.kf_dare.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp, dp, dp, dp, dp, ip,
                             C.c_int32, C.c_double, vp]
     lib.kf_dare.restype = C.c_int
+    lib.kf_dare_backward.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp, dp, dp, dp, dp,
+                                     dp, dp, dp, dp, dp, C.c_int32, ip, vp]
+    lib.kf_dare_backward.restype = C.c_int
     lib.kf_simulate_statespace.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, ip, vp]
     lib.kf_simulate_statespace.restype = C.c_int

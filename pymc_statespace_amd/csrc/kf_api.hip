@@ -628,6 +628,20 @@ extern "C" int kf_dare(kf_handle* h, int64_t B, int32_t m, int32_t p, int32_t r,
   return kf_launch_dare(h, B, m, p, r, T, Z, R, H, Q, P_init, P, info, max_iter, tol, (hipStream_t)stream);
 }
 
+extern "C" int kf_dare_backward(kf_handle* h, int64_t B, int32_t m, int32_t p, int32_t r, const double* T,
+                                const double* Z, const double* R, const double* H, const double* Q, const double* P,
+                                const double* g_P, double* g_T, double* g_Z, double* g_R, double* g_H, double* g_Q,
+                                int32_t accumulate, int32_t* info, void* stream) {
+  if (!h) return KF_ERR_ARG;
+  if (B < 1 || m < 1 || p < 1 || r < 1 || !T || !Z || !R || !H || !Q || !P || !g_P) {
+    KF_SET_ERR(h, "kf_dare_backward: bad arguments (B=%ld m=%d p=%d r=%d)", (long)B, m, p, r);
+    return KF_ERR_ARG;
+  }
+  KF_ON_DEVICE(h);
+  return kf_launch_dare_backward(h, B, m, p, r, T, Z, R, H, Q, P, g_P, g_T, g_Z, g_R, g_H, g_Q, accumulate, info,
+                                 (hipStream_t)stream);
+}
+
 extern "C" int kf_simulate_statespace(kf_handle* h, int64_t B, int32_t n_sims, int32_t n, int32_t p, int32_t m,
                                       int32_t r, const double* T, const double* Z, const double* R, const double* H,
                                       const double* Q, const double* x0, const double* z_state, const double* z_obs,

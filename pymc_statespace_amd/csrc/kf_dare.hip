@@ -278,6 +278,235 @@ __global__ __launch_bounds__(KF_WAVE) void kf_simulate_ss_kernel(long B, int n_s
   }
 }
 
+// ---- reverse mode through the Riccati fixed point ---------------------------------------------------------------------
+// Reference: SolveDiscreteARE.grad (utils/pytensor_scipy.py:33-60, Kao & Hennequin 2020) applied to
+// X = solve_discrete_are(A = T', B = Z', Q_d = R Q R', R_d = H) (kalman_filter.py:388).  Per draw, in LDS:
+//     F = Z X Z' + H            K = F^-1 Z X T'  (p x m)            A~ = T' - Z' K
+//     S = A~ S A~' + sym(g_X)   (Smith doubling, as kf_lyap_lds_kernel)
+//     W = X A~ S                A_bar = 2 W      B_bar = -2 W K'    Q_bar = S      R_bar = K S K'
+// and the chain rule back to the filter's matrices:  g_T = A_bar', g_Z = B_bar', g_H = R_bar,
+// g_R = S R (Q + Q'), g_Q = R' S R.  accumulate != 0: added to what the outputs hold (the direct gradient of the
+// filter started from X).  info[b] = 1: the Lyapunov iteration did not converge, 2: F not positive definite.
+__host__ __device__ inline int dare_bwd_region_doubles(int m, int p, int r) {
+  const int mr = m * r > m * p ? m * r : m * p;
+  return 7 * m * m + 3 * m * p + 3 * p * p + mr + 8;  // T, X, At, S, W, A2, V | Z, ZX, K | F, L, Fi | SR/KS
+}
+
+__global__ __launch_bounds__(KF_WAVE) void kf_dare_bwd_kernel(long B, int m, int p, int r, const double* Tm,
+                                                              const double* Zm, const double* Rm, const double* Hm,
+                                                              const double* Qm, const double* Xm, const double* gX,
+                                                              double* g_T, double* g_Z, double* g_R, double* g_H,
+                                                              double* g_Q, int accumulate, int32_t* info) {
+  extern __shared__ double smem[];
+  const int lane = threadIdx.x;
+  const long b = blockIdx.x;
+  const int mm = m * m, mp = m * p, pp = p * p, mr = m * r;
+  double* Tl = smem;
+  double* X = Tl + mm;
+  double* At = X + mm;
+  double* S = At + mm;
+  double* W = S + mm;
+  double* A2 = W + mm;
+  double* V = A2 + mm;
+  double* Zl = V + mm;
+  double* ZX = Zl + mp;
+  double* K = ZX + mp;
+  double* F = K + mp;
+  double* L = F + pp;
+  double* Fi = L + pp;
+  double* SR = Fi + pp;  // m x max(r, p)
+  int status = 0;
+
+  for (int e = lane; e < mm; e += KF_WAVE) {
+    const int i = e / m, j = e - i * m;
+    Tl[e] = Tm[b * mm + e];
+    X[e] = Xm[b * mm + e];
+    S[e] = 0.5 * (gX[b * mm + e] + gX[b * mm + j * m + i]);
+  }
+  for (int e = lane; e < mp; e += KF_WAVE) Zl[e] = Zm[b * mp + e];
+  __syncthreads();
+  // ZX = Z X
+  for (int e = lane; e < mp; e += KF_WAVE) {
+    const int q = e / m, j = e - q * m;
+    double s = 0.0;
+    for (int k = 0; k < m; ++k) s += Zl[q * m + k] * X[k * m + j];
+    ZX[e] = s;
+  }
+  __syncthreads();
+  // F = sym(ZX Z' + H) ; K <- ZX T' (before the solve)
+  for (int e = lane; e < pp; e += KF_WAVE) {
+    const int q1 = e / p, q2 = e - q1 * p;
+    double s = 0.5 * (Hm[b * pp + e] + Hm[b * pp + q2 * p + q1]);
+    for (int j = 0; j < m; ++j) s += 0.5 * (ZX[q1 * m + j] * Zl[q2 * m + j] + ZX[q2 * m + j] * Zl[q1 * m + j]);
+    F[e] = s;
+  }
+  for (int e = lane; e < mp; e += KF_WAVE) {
+    const int q = e / m, j = e - q * m;
+    double s = 0.0;
+    for (int k = 0; k < m; ++k) s += ZX[q * m + k] * Tl[j * m + k];
+    K[e] = s;
+  }
+  __syncthreads();
+  // Cholesky of F by lane 0, then K <- F^-1 K column by column (lane j owns column j of the p x m right-hand side)
+  if (lane == 0) {
+    for (int j = 0; j < p; ++j) {
+      double s = F[j * p + j];
+      for (int k = 0; k < j; ++k) s -= L[j * p + k] * L[j * p + k];
+      if (!(s > 0.0)) status = 2;
+      const double dj = sqrt(s);
+      L[j * p + j] = dj;
+      for (int i = j + 1; i < p; ++i) {
+        double t = F[i * p + j];
+        for (int k = 0; k < j; ++k) t -= L[i * p + k] * L[j * p + k];
+        L[i * p + j] = t / dj;
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = lane; j < m; j += KF_WAVE) {
+    for (int i = 0; i < p; ++i) {
+      double t = K[i * m + j];
+      for (int k = 0; k < i; ++k) t -= L[i * p + k] * K[k * m + j];
+      K[i * m + j] = t / L[i * p + i];
+    }
+    for (int i = p - 1; i >= 0; --i) {
+      double t = K[i * m + j];
+      for (int k = i + 1; k < p; ++k) t -= L[k * p + i] * K[k * m + j];
+      K[i * m + j] = t / L[i * p + i];
+    }
+  }
+  __syncthreads();
+  // At = T' - Z' K ; V = X At (needs the original At: the doubling below overwrites its working copy A2)
+  for (int e = lane; e < mm; e += KF_WAVE) {
+    const int i = e / m, j = e - i * m;
+    double s = Tl[j * m + i];
+    for (int q = 0; q < p; ++q) s -= Zl[q * m + i] * K[q * m + j];
+    At[e] = s;
+  }
+  __syncthreads();
+  for (int e = lane; e < mm; e += KF_WAVE) {
+    const int i = e / m, j = e - i * m;
+    double s = 0.0;
+    for (int k = 0; k < m; ++k) s += X[i * m + k] * At[k * m + j];
+    V[e] = s;
+  }
+  __syncthreads();
+  // S = sum_j At^j D At'^j by doubling: S <- S + A S A', A <- A A  (Tl is free from here on: it holds A A)
+  {
+    int st = 1;
+    for (int it = 0; it < 48; ++it) {
+      for (int e = lane; e < mm; e += KF_WAVE) {
+        const int i = e / m, j = e - i * m;
+        double s = 0.0, s2 = 0.0;
+        for (int k = 0; k < m; ++k) {
+          const double aik = At[i * m + k];
+          s += aik * S[k * m + j];
+          s2 += aik * At[k * m + j];
+        }
+        W[e] = s;
+        A2[e] = s2;
+      }
+      __syncthreads();
+      double dmax = 0.0, pmax = 0.0;
+      for (int e = lane; e < mm; e += KF_WAVE) {
+        const int i = e / m, j = e - i * m;
+        double sij = 0.0, sji = 0.0;
+        for (int k = 0; k < m; ++k) {
+          sij += W[i * m + k] * At[j * m + k];
+          sji += W[j * m + k] * At[i * m + k];
+        }
+        const double inc = 0.5 * (sij + sji);
+        const double pn = S[e] + inc;
+        dmax = fmax(dmax, fabs(inc));
+        pmax = fmax(pmax, fabs(pn));
+        S[e] = pn;
+      }
+      dmax = wave_max(dmax);
+      pmax = wave_max(pmax);
+      __syncthreads();
+      for (int e = lane; e < mm; e += KF_WAVE) At[e] = A2[e];
+      __syncthreads();
+      if (!(dmax > 1e-17 * pmax)) {
+        if (pmax < 1.0e300 && dmax == dmax) st = 0;
+        break;
+      }
+    }
+    if (st && !status) status = 1;
+  }
+  // W = V S  (= X At S)
+  for (int e = lane; e < mm; e += KF_WAVE) {
+    const int i = e / m, j = e - i * m;
+    double s = 0.0;
+    for (int k = 0; k < m; ++k) s += V[i * m + k] * S[k * m + j];
+    W[e] = s;
+  }
+  __syncthreads();
+  const double keep = accumulate ? 1.0 : 0.0;
+  if (g_T)
+    for (int e = lane; e < mm; e += KF_WAVE) {
+      const int i = e / m, j = e - i * m;
+      double* o = g_T + b * mm + e;
+      *o = (accumulate ? *o : 0.0) + 2.0 * W[j * m + i];
+    }
+  if (g_Z)
+    for (int e = lane; e < mp; e += KF_WAVE) {
+      const int q = e / m, j = e - q * m;
+      double s = 0.0;
+      for (int i = 0; i < m; ++i) s += K[q * m + i] * W[j * m + i];
+      double* o = g_Z + b * mp + e;
+      *o = (accumulate ? *o : 0.0) - 2.0 * s;
+    }
+  if (g_H) {
+    for (int e = lane; e < mp; e += KF_WAVE) {  // KS = K S  (p x m)
+      const int q = e / m, j = e - q * m;
+      double s = 0.0;
+      for (int i = 0; i < m; ++i) s += K[q * m + i] * S[i * m + j];
+      SR[e] = s;
+    }
+    __syncthreads();
+    for (int e = lane; e < pp; e += KF_WAVE) {
+      const int q1 = e / p, q2 = e - q1 * p;
+      double s = 0.0;
+      for (int j = 0; j < m; ++j) s += SR[q1 * m + j] * K[q2 * m + j];
+      double* o = g_H + b * pp + e;
+      *o = (accumulate ? *o : 0.0) + s;
+    }
+    __syncthreads();
+  }
+  if (g_R || g_Q) {
+    const double* gR = Rm + b * (long)mr;
+    const double* gQ = Qm + b * (long)r * r;
+    for (int e = lane; e < mr; e += KF_WAVE) {  // SR = S R  (m x r)
+      const int i = e / r, l = e - i * r;
+      double s = 0.0;
+      for (int j = 0; j < m; ++j) s += S[i * m + j] * gR[j * r + l];
+      SR[e] = s;
+    }
+    __syncthreads();
+    if (g_R)
+      for (int e = lane; e < mr; e += KF_WAVE) {
+        const int i = e / r, l = e - i * r;
+        double s = 0.0;
+        for (int k = 0; k < r; ++k) s += SR[i * r + k] * (gQ[k * r + l] + gQ[l * r + k]);
+        double* o = g_R + b * (long)mr + e;
+        *o = (accumulate ? *o : 0.0) + s;
+      }
+    if (g_Q)
+      for (int e = lane; e < r * r; e += KF_WAVE) {
+        const int k = e / r, l = e - k * r;
+        double s = 0.0;
+        for (int i = 0; i < m; ++i) s += gR[i * r + k] * SR[i * r + l];
+        double* o = g_Q + b * (long)r * r + e;
+        *o = (accumulate ? *o : 0.0) + s;
+      }
+  }
+  (void)keep;
+  if (info) {
+    status = __shfl(status, 0, KF_WAVE);  // the Cholesky verdict lives in lane 0
+    if (lane == 0) info[b] = status;
+  }
+}
+
 }  // namespace
 
 int kf_launch_dare(kf_handle* h, long B, int m, int p, int r, const double* T, const double* Z, const double* R,
@@ -292,6 +521,24 @@ int kf_launch_dare(kf_handle* h, long B, int m, int p, int r, const double* T, c
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kf_dare_kernel, dim3((unsigned)B), dim3(KF_WAVE), lds, stream, B, m, p, r, T, Z, R, H, Q, Pinit,
                      P, info, max_iter, tol);
+  KF_HIP_CHECK(h, hipGetLastError());
+  return KF_OK;
+}
+
+int kf_launch_dare_backward(kf_handle* h, long B, int m, int p, int r, const double* T, const double* Z, const double* R,
+                            const double* H, const double* Q, const double* P, const double* g_P, double* g_T,
+                            double* g_Z, double* g_R, double* g_H, double* g_Q, int accumulate, int32_t* info,
+                            hipStream_t stream) {
+  const size_t lds = sizeof(double) * (size_t)dare_bwd_region_doubles(m, p, r);
+  if (lds > KF_LDS_BYTES_MAX) {
+    KF_SET_ERR(h, "dare_backward: m=%d p=%d r=%d needs %zu B of LDS per workgroup (> %d)", m, p, r, lds,
+               KF_LDS_BYTES_MAX);
+    return KF_ERR_UNSUPPORTED;
+  }
+  KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kf_dare_bwd_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kf_dare_bwd_kernel, dim3((unsigned)B), dim3(KF_WAVE), lds, stream, B, m, p, r, T, Z, R, H, Q, P,
+                     g_P, g_T, g_Z, g_R, g_H, g_Q, accumulate, info);
   KF_HIP_CHECK(h, hipGetLastError());
   return KF_OK;
 }

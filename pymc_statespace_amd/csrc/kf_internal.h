@@ -244,6 +244,10 @@ int kf_launch_simulate(kf_handle* h, long B, int n, int k, int n_sims, const dou
 int kf_launch_dare(kf_handle* h, long B, int m, int p, int r, const double* T, const double* Z, const double* R,
                    const double* H, const double* Q, const double* Pinit, double* P, int32_t* info, int max_iter,
                    double tol, hipStream_t stream);
+int kf_launch_dare_backward(kf_handle* h, long B, int m, int p, int r, const double* T, const double* Z, const double* R,
+                            const double* H, const double* Q, const double* P, const double* g_P, double* g_T,
+                            double* g_Z, double* g_R, double* g_H, double* g_Q, int accumulate, int32_t* info,
+                            hipStream_t stream);
 int kf_launch_simulate_statespace(kf_handle* h, long B, int n_sims, int n, int p, int m, int r, const double* T,
                                   const double* Z, const double* R, const double* H, const double* Q,
                                   const double* x0, const double* zs, const double* zo, double* states, double* obs,

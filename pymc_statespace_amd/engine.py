@@ -406,6 +406,36 @@ class KalmanEngine:
         self._check(rc, "kf_dare")
         return P, info
 
+    def dare_backward(self, T, Z, R, H, Q, P, g_P, into=None):
+        """kf_dare_backward: gradient of <g_P, P_steady> w.r.t. (T, Z, R, H, Q) per draw -> (dict, info).
+        ``into``: a dict of gradient tensors (as ``backward`` returns) to ADD the result to, in place."""
+        T = self.to_device(T)
+        B, m = T.shape[0], T.shape[1]
+        Z = self.to_device(Z)
+        p = Z.shape[1]
+        R = self.to_device(R)
+        r = R.shape[2]
+        H = self.to_device(H, (B, p, p))
+        Q = self.to_device(Q, (B, r, r))
+        P = self.to_device(P, (B, m, m))
+        g_P = self.to_device(g_P, (B, m, m))
+        dev, f64 = self.device, torch.float64
+        if into is None:
+            g = dict(T=torch.empty(B, m, m, device=dev, dtype=f64), Z=torch.empty(B, p, m, device=dev, dtype=f64),
+                     R=torch.empty(B, m, r, device=dev, dtype=f64), H=torch.empty(B, p, p, device=dev, dtype=f64),
+                     Q=torch.empty(B, r, r, device=dev, dtype=f64))
+        else:
+            g = into
+            for k, shape in (("T", (B, m, m)), ("Z", (B, p, m)), ("R", (B, m, r)), ("H", (B, p, p)), ("Q", (B, r, r))):
+                if tuple(g[k].shape) != shape or not g[k].is_contiguous():
+                    raise ValueError(f"into[{k!r}] must be a contiguous {shape} tensor")
+        info = torch.empty(B, device=dev, dtype=torch.int32)
+        rc = self.lib.kf_dare_backward(self._h, B, m, p, r, _ptr(T), _ptr(Z), _ptr(R), _ptr(H), _ptr(Q), _ptr(P),
+                                       _ptr(g_P), _ptr(g["T"]), _ptr(g["Z"]), _ptr(g["R"]), _ptr(g["H"]), _ptr(g["Q"]),
+                                       1 if into is not None else 0, _ptr(info), self._stream())
+        self._check(rc, "kf_dare_backward")
+        return g, info
+
     def simulate_statespace(self, T, Z, R, H, Q, n_steps, n_simulations=1, x0=None, generator=None,
                             z_state=None, z_obs=None):
         """kf_simulate_statespace: (states (B*n_simulations, n_steps, m), obs (B*n_simulations, n_steps, p),

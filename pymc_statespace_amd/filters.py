@@ -177,14 +177,29 @@ class SteadyStateFilter(BaseFilter):
     ``_postprocess_scan_results(results, a0, P0)``), and the innovation ignores ``d`` (:400).
     With missing observations the reference keeps the frozen gain although P has left the fixed
     point (its recursion can then diverge); this filter uses the exact gain of the current P there.
-    Static system matrices only (:380-383).  Eager evaluation only: the symbolic ``build_graph``
-    raises (the gradient through the Riccati solve is not provided)."""
+    Static system matrices only (:380-383).  ``build_graph`` returns the same six outputs from one PyTensor node
+    whose gradient includes the Riccati solve (``kf_dare_backward``: utils/pytensor_scipy.py:33-60);
+    ``logp_and_grad`` is the eager form of that value-and-gradient."""
     filter_type = "standard"
 
-    def build_graph(self, *args, **kwargs):
-        raise NotImplementedError(
-            "SteadyStateFilter: eager evaluation only on the MI355X path "
-            "(flt(data, a0, P0, T, Z, R, H, Q)); use StandardFilter inside a PyMC graph")
+    def build_graph(self, data, a0, P0, T, Z, R, H, Q, c=None, d=None, mode=None, outputs="all"):
+        """Reference signature (kalman_filter.py:364)."""
+        from .op import steady_state_filter_graph  # imports pytensor; fails loudly without it
+
+        self.mode = mode
+        return steady_state_filter_graph(data, a0, P0, T, Z, R, H, Q, c=c, d=d, mvn_const=self.mvn_const,
+                                         outputs=outputs)
+
+    def logp_and_grad(self, data, a0, P0, T, Z, R, H, Q, c=None, d=None):
+        """(logp, dict of gradients w.r.t. a0, P0, T, Z, R, H, Q, c, d) for one draw in the reference layouts --
+        what the compiled graph's value-and-gradient evaluates."""
+        from .op import GRAD_INPUT_NAMES, perform_steady_state_grad
+
+        m, p = np.asarray(T).shape[-1], np.asarray(Z).shape[-2]
+        outs = perform_steady_state_grad(data, a0, P0, T, Z, R, H, Q, np.zeros((m, 1)) if c is None else c,
+                                         np.zeros((p, 1)) if d is None else d, mvn_const=self.mvn_const,
+                                         engine=self.engine)
+        return float(outs[0]), dict(zip(GRAD_INPUT_NAMES, outs[1:]))
 
     def __call__(self, data, a0, P0, T, Z, R, H, Q, c=None, d=None, *, outputs="all",
                  max_iter=100000, tol=1e-14):

@@ -180,6 +180,80 @@ def perform_filter_grad(data, a0, P0, T, Z, R, H, Q, c, d, predicted_states, pre
     return [out[k] for k in GRAD_INPUT_NAMES]
 
 
+def _steady_inputs(data, a0, P0, T, Z, R, H, Q, c):
+    data = np.asarray(data, dtype=np.float64)
+    if data.ndim == 3:
+        data = data[..., 0]
+    mats = [np.asarray(x, dtype=np.float64) for x in (T, Z, R, H, Q)]
+    if any(x.ndim != 2 for x in mats):
+        raise ValueError("All system matrices must be time-invariant to use the SteadyStateFilter")
+    return data, _col(a0)[None], np.asarray(P0, dtype=np.float64), [x[None] for x in mats], _col(c)[None]
+
+
+def _steady_covariance(eng, mats, max_iter=100000, tol=1e-14):
+    P, info = eng.dare(*mats, max_iter=max_iter, tol=tol)
+    code = int(info[0].item())
+    if code:
+        raise np.linalg.LinAlgError("discrete Riccati iteration " + (
+            "did not converge" if code == 1 else "met a non positive definite Z P Z' + H"))
+    return P
+
+
+def perform_steady_state(data, a0, P0, T, Z, R, H, Q, c, d, mvn_const="reference", engine=None,
+                         want=(True,) * 6):
+    """SteadyStateFilter (reference kalman_filter.py:354-441) for one draw: kf_dare, then the Standard recursion
+    started from P_steady.  Kept quirks: slot 0 of predicted_covs is the caller's P0 (:397), d is ignored (:400)."""
+    eng = engine or get_engine()
+    data, a0_, P0_, mats, c_ = _steady_inputs(data, a0, P0, T, Z, R, H, Q, c)
+    Ps = _steady_covariance(eng, mats)
+    res = eng.forward(data, a0_, Ps, *mats, c_, None, filter_type="standard", mvn_const=mvn_const,
+                      store_filtered=bool(want[0] or want[2]), store_predicted=bool(want[1] or want[3]),
+                      store_ll_obs=bool(want[5]))
+    _raise_if_not_pd(res.info)
+    pc = None
+    if want[3]:
+        pc = res.predicted_covs[0].cpu().numpy()
+        pc[0] = P0_
+    return [
+        res.filtered_states[0].cpu().numpy()[..., None] if want[0] else None,
+        res.predicted_states[0].cpu().numpy()[..., None] if want[1] else None,
+        res.filtered_covs[0].cpu().numpy() if want[2] else None,
+        pc,
+        np.asarray(res.logp[0].item(), dtype=np.float64),
+        res.ll_obs[0].cpu().numpy() if want[5] else None,
+    ]
+
+
+def perform_steady_state_grad(data, a0, P0, T, Z, R, H, Q, c, d, g_logp=None, g_ll_obs=None,
+                              mvn_const="reference", engine=None):
+    """(logp, gradients of g_logp*logp + <g_ll_obs, ll_obs> w.r.t. (a0,P0,T,Z,R,H,Q,c,d)) of the SteadyStateFilter, all
+    on the device: kf_dare -> kf_filter_forward from P_steady -> kf_filter_backward -> kf_dare_backward, which adds the
+    path through the Riccati solve (g_P0 of the filter is the cotangent of P_steady; reference
+    utils/pytensor_scipy.py:33-60).  P0 and d do not enter the likelihood: their gradients are zero."""
+    eng = engine or get_engine()
+    data, a0_, P0_, mats, c_ = _steady_inputs(data, a0, P0, T, Z, R, H, Q, c)
+    dev = [eng.to_device(x) for x in mats]
+    Ps = _steady_covariance(eng, dev)
+    y, a0d, cd = eng.to_device(data), eng.to_device(a0_), eng.to_device(c_)
+    res = eng.forward(y, a0d, Ps, *dev, cd, None, filter_type="standard", mvn_const=mvn_const,
+                      store_filtered=False, store_ll_obs=False)
+    _raise_if_not_pd(res.info)
+    g = eng.backward(y, a0d, Ps, *dev, cd, None, predicted_states=res.predicted_states,
+                     predicted_covs=res.predicted_covs,
+                     g_logp=np.ones(1) if g_logp is None else np.atleast_1d(np.asarray(g_logp, dtype=np.float64)),
+                     g_ll_obs=None if g_ll_obs is None else np.asarray(g_ll_obs, dtype=np.float64)[None],
+                     filter_type="standard", mvn_const=mvn_const, want_cd=True)
+    _, info = eng.dare_backward(*dev, Ps, g["P0"], into=g)
+    if int(info[0].item()):
+        raise np.linalg.LinAlgError("the Lyapunov solve of the Riccati gradient did not converge")
+    out = {k: g[k][0].cpu().numpy() for k in GRAD_INPUT_NAMES}
+    out["P0"] = np.zeros_like(P0_)
+    out["d"] = np.zeros_like(_col(d))
+    for k in ("a0", "c", "d"):
+        out[k] = out[k][..., None]
+    return [np.asarray(res.logp[0].item(), dtype=np.float64)] + [out[k] for k in GRAD_INPUT_NAMES]
+
+
 def perform_smoother(T, R, Q, filtered_states, filtered_covs, engine=None):
     eng = engine or get_engine()
     fa = np.asarray(filtered_states, dtype=np.float64)
@@ -354,6 +428,94 @@ def _build_ops():
             return [grad_not_implemented(self, k, inputs[k], "use KalmanLogpOp per draw for gradients")
                     for k in range(10)]
 
+    class SteadyStateGradOp(Op):
+        """gradients = Op(data, a0, P0, T, Z, R, H, Q, c, d, g_logp, g_ll_obs) -- perform_steady_state_grad."""
+        __props__ = ("mvn_const",)
+
+        def __init__(self, mvn_const="reference"):
+            self.mvn_const = mvn_const
+
+        def make_node(self, *args):
+            args = [pt.as_tensor_variable(a) for a in args]
+            return Apply(self, args, [args[i].type() for i in range(1, 10)])
+
+        def perform(self, node, inputs, output_storage):
+            outs = perform_steady_state_grad(*inputs[:10], g_logp=inputs[10], g_ll_obs=inputs[11],
+                                             mvn_const=self.mvn_const)
+            for storage, g in zip(output_storage, outs[1:]):
+                storage[0] = np.ascontiguousarray(g, dtype=np.float64)
+
+        def infer_shape(self, fgraph, node, shapes):
+            return [shapes[i] for i in range(1, 10)]
+
+    class SteadyStateFilterOp(Op):
+        """The six reference outputs of SteadyStateFilter.build_graph (kalman_filter.py:364-397) from one node:
+        kf_dare + the Standard recursion from P_steady; gradients (through logp / ll_obs) include the Riccati solve."""
+        __props__ = ("mvn_const",)
+
+        def __init__(self, mvn_const="reference"):
+            self.mvn_const = mvn_const
+
+        def make_node(self, data, a0, P0, T, Z, R, H, Q, c, d):
+            ins = [pt.as_tensor_variable(x) for x in (data, a0, P0, T, Z, R, H, Q, c, d)]
+            outs = [pt.tensor3(dtype=f64), pt.tensor3(dtype=f64), pt.tensor3(dtype=f64),
+                    pt.tensor3(dtype=f64), pt.scalar(dtype=f64), pt.vector(dtype=f64)]
+            return Apply(self, ins, outs)
+
+        def perform(self, node, inputs, output_storage):
+            want = _outputs_with_clients(node)
+            outs = perform_steady_state(*inputs, mvn_const=self.mvn_const, want=want)
+            for storage, o, var in zip(output_storage, outs, node.outputs):
+                storage[0] = (np.ascontiguousarray(o, dtype=np.float64) if o is not None
+                              else np.zeros((0,) * var.type.ndim, dtype=np.float64))
+
+        def infer_shape(self, fgraph, node, shapes):
+            n, m = shapes[0][0], shapes[3][0]
+            return [(n, m, 1), (n + 1, m, 1), (n, m, m), (n + 1, m, m), (), (n,)]
+
+        def connection_pattern(self, node):
+            return [[False] * 6] + [[True] * 6 for _ in range(9)]
+
+        def L_op(self, inputs, outputs, output_grads):
+            for i in range(4):
+                if not isinstance(output_grads[i].type, DisconnectedType):
+                    return [DisconnectedType()()] + [
+                        grad_not_implemented(self, k, inputs[k], "gradients flow through log_likelihood / ll_obs only")
+                        for k in range(1, 10)]
+            g_logp, g_ll = output_grads[4], output_grads[5]
+            if isinstance(g_logp.type, DisconnectedType):
+                g_logp = pt.zeros_like(outputs[4])
+            if isinstance(g_ll.type, DisconnectedType):
+                g_ll = pt.zeros_like(outputs[5])
+            return [DisconnectedType()()] + list(SteadyStateGradOp(self.mvn_const)(*inputs, g_logp, g_ll))
+
+    class SteadyStateLogpOp(Op):
+        """[logp, g_a0 .. g_d] = Op(data, a0, P0, T, Z, R, H, Q, c, d): value and gradient of the SteadyStateFilter's
+        log-likelihood from one perform (KalmanLogpOp's pattern)."""
+        __props__ = ("mvn_const",)
+
+        def __init__(self, mvn_const="reference"):
+            self.mvn_const = mvn_const
+
+        def make_node(self, data, a0, P0, T, Z, R, H, Q, c, d):
+            ins = [pt.as_tensor_variable(x) for x in (data, a0, P0, T, Z, R, H, Q, c, d)]
+            return Apply(self, ins, [pt.scalar(dtype=f64)] + [ins[i].type() for i in range(1, 10)])
+
+        def perform(self, node, inputs, output_storage):
+            outs = perform_steady_state_grad(*inputs, mvn_const=self.mvn_const)
+            for storage, o in zip(output_storage, outs):
+                storage[0] = np.ascontiguousarray(o, dtype=np.float64)
+
+        def infer_shape(self, fgraph, node, shapes):
+            return [()] + [shapes[i] for i in range(1, 10)]
+
+        def connection_pattern(self, node):
+            return [[False] * 10] + [[True] + [False] * 9 for _ in range(9)]
+
+        def L_op(self, inputs, outputs, output_grads):
+            g = output_grads[0]
+            return [DisconnectedType()()] + [g * outputs[1 + k] for k in range(9)]
+
     try:  # vectorize_graph (PyMC's draw-vectorised predictive sampling) -> the batched kernels
         from pytensor.graph.replace import _vectorize_node
 
@@ -400,7 +562,9 @@ def _build_ops():
 
     _OPS = dict(pt=pt, pytensor=pytensor, KalmanFilterOp=KalmanFilterOp,
                 KalmanFilterGradOp=KalmanFilterGradOp, KalmanSmootherOp=KalmanSmootherOp,
-                KalmanLogpOp=KalmanLogpOp, KalmanFilterBatchedOp=KalmanFilterBatchedOp)
+                KalmanLogpOp=KalmanLogpOp, KalmanFilterBatchedOp=KalmanFilterBatchedOp,
+                SteadyStateFilterOp=SteadyStateFilterOp, SteadyStateGradOp=SteadyStateGradOp,
+                SteadyStateLogpOp=SteadyStateLogpOp)
     return _OPS
 
 
@@ -429,6 +593,23 @@ def kalman_filter_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type
         return ops["KalmanLogpOp"](filter_type, mvn_const, h_diagonal)(data, a0, P0, T, Z, R, H, Q, c, d)[0]
     return list(ops["KalmanFilterOp"](filter_type, mvn_const, h_diagonal)(
         data, a0, P0, T, Z, R, H, Q, c, d))
+
+
+def steady_state_filter_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, mvn_const="reference", outputs="all"):
+    """Symbolic SteadyStateFilter.build_graph (reference kalman_filter.py:364-397): static matrices only (:380-383)."""
+    ops = _build_ops()
+    pt = ops["pt"]
+    T, Z, R, H, Q = (pt.as_tensor_variable(x) for x in (T, Z, R, H, Q))
+    for prm in (T, Z, R, H, Q):
+        if prm.ndim != 2:
+            raise ValueError("All system matrices must be time-invariant to use the SteadyStateFilter")
+    if c is None:
+        c = pt.zeros((T.shape[0], 1))
+    if d is None:
+        d = pt.zeros((Z.shape[0], 1))
+    if outputs == "logp":
+        return ops["SteadyStateLogpOp"](mvn_const)(data, a0, P0, T, Z, R, H, Q, c, d)[0]
+    return list(ops["SteadyStateFilterOp"](mvn_const)(data, a0, P0, T, Z, R, H, Q, c, d))
 
 
 def kalman_smoother_graph(T, R, Q, filtered_states, filtered_covariances):

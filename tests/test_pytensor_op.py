@@ -109,3 +109,47 @@ def test_vectorize_graph_reaches_the_batched_kernels(nile):
     got = f(*(vals[:6] + vals[7:]), Hs)
     assert got.shape == (3,)
     assert_allclose(got[0], g["llf_obs"].sum(), rtol=2e-9)
+
+
+def test_steady_state_build_graph_value_and_gradient(nile):
+    """SteadyStateFilter.build_graph (reference kalman_filter.py:364-397): the gradient includes the Riccati solve
+    (utils/pytensor_scipy.py:33-60 -> kf_dare_backward)."""
+    import pytensor.tensor as pt
+
+    from oracle import steady_state_numpy as so
+    from pymc_statespace_amd.filters import SteadyStateFilter
+
+    g, vals, m, p = nile
+    sym = _symbols()
+    outs = SteadyStateFilter().build_graph(*sym)
+    assert len(outs) == 6
+    logp = SteadyStateFilter().build_graph(*sym, outputs="logp")
+    grads = pt.grad(logp, [sym[3], sym[7]])          # T, Q
+    grads6 = pt.grad(outs[4], [sym[3], sym[7]])
+    f = pytensor.function(sym, [logp, outs[4], outs[3]] + grads + grads6, on_unused_input="ignore")
+    res = f(*vals)
+    y = vals[0][..., 0]
+    rlp, rg = so.steady_state_logp_and_grad(y, vals[1][:, 0], *vals[2:])
+    assert_allclose(res[0], rlp, rtol=1e-8)
+    assert_allclose(res[1], rlp, rtol=1e-8)
+    assert np.array_equal(res[2][0], vals[2])        # slot 0 of predicted_covs is the caller's P0 (:397)
+    for got, got6, k in zip(res[3:5], res[5:7], ("T", "Q")):
+        assert_allclose(got, rg[k], rtol=1e-6, atol=1e-7)
+        assert_allclose(got6, rg[k], rtol=1e-6, atol=1e-7)
+
+
+def test_time_varying_inputs_keep_their_shape_in_the_gradient(nile):
+    import pytensor.tensor as pt
+
+    from pymc_statespace_amd.filters import StandardFilter
+
+    g, vals, m, p = nile
+    n = vals[0].shape[0]
+    sym = _symbols()
+    Tt = pt.tensor3("Tt")
+    logp = StandardFilter().build_graph(sym[0], sym[1], sym[2], Tt, *sym[4:], outputs="logp")
+    f = pytensor.function([sym[0], sym[1], sym[2], Tt] + sym[4:], [logp, pt.grad(logp, Tt)], on_unused_input="ignore")
+    Tv = np.repeat(vals[3][None], n, axis=0)
+    lp, gT = f(vals[0], vals[1], vals[2], Tv, *vals[4:])
+    assert gT.shape == (n, m, m)
+    assert_allclose(lp, g["llf_obs"].sum(), rtol=2e-9)

@@ -40,6 +40,68 @@ def test_oracle_simulation_matches_definition():
     assert_allclose(ob[7], d["Z"] @ st[6] + zo[7] @ LH)
 
 
+def _fd(f, x, eps=1e-6, symmetric=False):
+    num = np.zeros_like(x)
+    for idx in np.ndindex(x.shape):
+        e = np.zeros_like(x)
+        e[idx] = eps
+        if symmetric:
+            e = e + e.T
+        num[idx] = (f(x + e) - f(x - e)) / (2 * eps)
+    return num
+
+
+def _dense_model(seed, m=4, p=2, r=3):
+    rng = np.random.default_rng(seed)
+    T = rng.standard_normal((m, m))
+    T *= 0.8 / np.abs(np.linalg.eigvals(T)).max()
+    Q = rng.standard_normal((r, r))
+    H = rng.standard_normal((p, p))
+    return dict(T=T, Z=rng.standard_normal((p, m)), R=rng.standard_normal((m, r)), H=H @ H.T + 0.5 * np.eye(p),
+                Q=Q @ Q.T + np.eye(r))
+
+
+def test_oracle_dare_gradient_matches_finite_differences():
+    """dare_grad restates SolveDiscreteARE.grad (utils/pytensor_scipy.py:33-60); the reference has no test of it, so it
+    is pinned here by central differences of SciPy's solve_discrete_are."""
+    from scipy.linalg import solve_discrete_are
+
+    mdl = _dense_model(0)
+    gP = np.random.default_rng(1).standard_normal((4, 4))
+
+    def obj(**kw):
+        a = dict(mdl, **kw)
+        return float(np.sum(gP * solve_discrete_are(a["T"].T, a["Z"].T, a["R"] @ a["Q"] @ a["R"].T, a["H"])))
+
+    g = so.steady_state_grad(mdl["T"], mdl["Z"], mdl["R"], mdl["H"], mdl["Q"], gP)
+    for k in ("T", "Z", "R"):
+        num = _fd(lambda x: obj(**{k: x}), mdl[k])
+        assert_allclose(g[k], num, rtol=1e-6, atol=1e-6, err_msg=k)
+    for k in ("H", "Q"):  # symmetric arguments: only the symmetric part of the entrywise gradient is observable
+        num = _fd(lambda x: obj(**{k: x}), mdl[k], symmetric=True)
+        assert_allclose(g[k] + g[k].T, num, rtol=1e-6, atol=1e-6, err_msg=k)
+
+
+def test_oracle_steady_state_logp_gradient_matches_finite_differences_of_the_frozen_gain_filter():
+    """The filter started from P_steady and the reference's frozen-F_inv recursion are the same function of the
+    parameters (complete data), so the gradient `Kalman adjoint + Riccati adjoint` must match central differences of
+    the line-by-line restatement of SteadyStateFilter (kalman_filter.py:354-441)."""
+    mdl = _dense_model(3, m=3, p=1, r=2)
+    rng = np.random.default_rng(5)
+    y = rng.standard_normal((12, 1))
+    a0, P0 = rng.standard_normal(3), np.eye(3)
+    lp, g = so.steady_state_logp_and_grad(y, a0, P0, **mdl)
+    assert abs(lp - so.steady_state_filter(y, a0, P0, **mdl)["logp"]) < 1e-9
+    for k in ("T", "Z", "R"):
+        num = _fd(lambda x: so.steady_state_filter(y, a0, P0, **dict(mdl, **{k: x}))["logp"], mdl[k])
+        assert_allclose(g[k], num, rtol=2e-6, atol=2e-6, err_msg=k)
+    for k in ("H", "Q"):
+        num = _fd(lambda x: so.steady_state_filter(y, a0, P0, **dict(mdl, **{k: x}))["logp"], mdl[k], symmetric=True)
+        assert_allclose(g[k] + g[k].T, num, rtol=2e-6, atol=2e-6, err_msg=k)
+    num = _fd(lambda x: so.steady_state_filter(y, x, P0, **mdl)["logp"], a0)
+    assert_allclose(g["a0"], num, rtol=1e-6, atol=1e-6)
+
+
 @pytest.fixture(scope="module")
 def eng():
     import torch
@@ -98,6 +160,53 @@ def test_hip_steady_state_filter_matches_oracle(eng, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(STEADY_CASES))
+def test_hip_dare_backward_matches_oracle(eng, case):
+    w = STEADY_CASES[case]()
+    P, info = eng.dare(w["T"], w["Z"], w["R"], w["H"], w["Q"])
+    gP = np.random.default_rng(2).standard_normal(P.shape)
+    g, info = eng.dare_backward(w["T"], w["Z"], w["R"], w["H"], w["Q"], P, gP)
+    assert not info.cpu().numpy().any()
+    for b in range(w["B"]):
+        ref = so.steady_state_grad(w["T"][b], w["Z"][b], w["R"][b], w["H"][b], w["Q"][b], gP[b])
+        for k in ("T", "Z", "R", "H", "Q"):
+            got = g[k][b].cpu().numpy()
+            assert np.max(np.abs(got - ref[k])) / (1.0 + np.max(np.abs(ref[k]))) < 1e-8, (case, b, k)
+    # accumulate: the result is added to what the buffers hold
+    g2 = {k: v.clone() for k, v in g.items()}
+    eng.dare_backward(w["T"], w["Z"], w["R"], w["H"], w["Q"], P, gP, into=g2)
+    for k in g:
+        assert_allclose(g2[k].cpu().numpy(), 2.0 * g[k].cpu().numpy(), rtol=1e-12, atol=1e-300)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["structural_m10", "varmax_k3", "local_level"])
+def test_hip_steady_state_logp_and_grad_matches_oracle(eng, case):
+    """SteadyStateFilter.logp_and_grad (what build_graph's value-and-gradient node evaluates): kf_dare ->
+    kf_filter_forward -> kf_filter_backward -> kf_dare_backward, against the oracle's Kalman + Riccati adjoints."""
+    from pymc_statespace_amd import SteadyStateFilter
+    from pymc_statespace_amd import op
+
+    w = STEADY_CASES[case]()
+    d = _one(w, 1)
+    flt = SteadyStateFilter(engine=eng)
+    lp, g = flt.logp_and_grad(w["y"][..., None], d["a0"][:, None], d["P0"], d["T"], d["Z"], d["R"], d["H"], d["Q"])
+    rlp, rg = so.steady_state_logp_and_grad(w["y"], **d)
+    assert abs(lp - rlp) < 1e-8 * max(1.0, abs(rlp))
+    for k in ("a0", "T", "Z", "R", "H", "Q", "c"):
+        a, b = np.asarray(g[k]), rg[k]
+        assert a.reshape(b.shape).shape == b.shape
+        assert np.max(np.abs(a.reshape(b.shape) - b)) / (1.0 + np.max(np.abs(b))) < 1e-7, (case, k)
+    assert not np.any(g["P0"]) and not np.any(g["d"])
+    # the six-output body: slot 0 of predicted_covs is the caller's P0 (:397)
+    outs = op.perform_steady_state(w["y"][..., None], d["a0"][:, None], d["P0"], d["T"], d["Z"], d["R"], d["H"], d["Q"],
+                                   np.zeros((w["m"], 1)), np.zeros((w["p"], 1)))
+    ref = so.steady_state_filter(w["y"], **d)
+    assert np.array_equal(outs[3][0], d["P0"]) and abs(float(outs[4]) - ref["logp"]) < 1e-8 * max(1.0, abs(ref["logp"]))
+    assert_allclose(outs[0][..., 0], ref["filtered_states"], rtol=1e-7, atol=1e-8)
+
+
+@pytest.mark.gpu
 def test_hip_steady_state_filter_errors(eng):
     from pymc_statespace_amd import SteadyStateFilter
 
@@ -109,8 +218,6 @@ def test_hip_steady_state_filter_errors(eng):
     T[1] *= 50.0  # explosive transition: the Riccati iteration cannot settle in 200 steps
     with pytest.raises(np.linalg.LinAlgError, match="Riccati"):
         SteadyStateFilter(engine=eng)(w["y"], w["a0"], w["P0"], T, w["Z"], w["R"], w["H"], w["Q"], max_iter=200)
-    with pytest.raises(NotImplementedError):
-        SteadyStateFilter(engine=eng).build_graph(None, None, None, None, None, None, None, None)
 
 
 @pytest.mark.gpu
