@@ -144,7 +144,10 @@ static bool kf_b4_auto(const kf_handle* h, int m, long B) {
   const long n_simd = (h ? h->n_cu : 256) * 4L;
   if (m >= 7) return (B * m + KF_WAVE - 1) / KF_WAVE < 2 * n_simd;  // else the row kernel (as before)
   if (m >= 4) return B < 16384;
-  return B <= 2048;
+  // m <= 3: the lane kernel (4 .. 64 draws per wavefront, LDS-staged tapes; scripts/r02/lane_time.py, full ; logp ms):
+  //   m = 2: 0.46 / 0.51 / 0.52 ; 0.33 - 0.35 at 512 / 2048 / 4096 draws against 0.47 / 0.54 / 0.71 ; 0.32 - 0.50 here
+  //   m = 3: 0.76 / 0.84 / 0.92 against 0.58 / 0.69 / 0.98
+  return m == 3 && B <= 2048;
 }
 static bool kf_b4_selected(const kf_handle* h, int m, int p, int r, long B) {
   if (!kf_forward_b4_ok(m, p, r)) return false;

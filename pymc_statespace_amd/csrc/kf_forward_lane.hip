@@ -3,14 +3,25 @@
 // For tiny state dimension (BASELINE config C2: ARMA(1,1), m = 2; C1: m = 1) the row-owner
 // kernels are bound by their per-step LDS exchanges (~2000 cycles of latency per time step
 // whatever m is).  With m <= 4 a whole draw fits one lane's registers (P, T, RQR': 3 m^2
-// doubles), so a time step is a short straight-line block of FMAs with NO exchange and NO sync:
-// 64 draws per wavefront, step latency = its own issue time.
+// doubles), so a time step is a short straight-line block of FMAs with NO exchange and NO sync.
+//
+// Round 2 (C2 ran on 64 wavefronts, each lane storing 13 scattered doubles per step):
+//   * DPW draws per wavefront, DPW in {4, 16, 64} chosen from the batch so that the launch covers the
+//     chip's 1024 SIMDs (4096 draws: 1024 wavefronts of 4 draws).  All 64 lanes run the recursion --
+//     lane l that of draw slot l % DPW, replicas are free -- and lanes < DPW own the results.
+//   * Tapes leave through LDS: the owners append each step's rows to per-draw chunks, and every S steps
+//     the whole wavefront copies the chunks out, 8 contiguous bytes per lane: a draw's S rows are adjacent
+//     in the draw-major tapes, so the stores are whole 128-byte lines instead of 64 scattered 8-byte pieces.
+//   * The logarithm is off the recursion: (F, v^2/F, observed) go to the LDS block and the S x DPW
+//     log-likelihood terms are evaluated side by side at the flush, one per lane; ll_obs is stored
+//     coalesced from there and logp is the sum of the lanes' partial sums (a different summation order
+//     than the sequential kernels: differences at rounding level, tests: 1e-8).
 //
 // Same contract and arithmetic as the other forward kernels (reference
 // pymc_statespace/filters/kalman_filter.py:126-252, 255-351, 444-505): expanded Joseph form,
-// P_hat = (S + S')/2 computed pairwise.  Tapes: each lane writes its draw's rows directly
-// (m <= 4: 8..128 contiguous bytes per draw-step; consecutive time steps are adjacent in the
-// draw-major tapes, so plain write-back stores let L2 assemble full lines).
+// P_hat = (S + S')/2 computed pairwise.
+#include <type_traits>
+
 #include "kf_internal.h"
 #include "kf_tile.h"
 
@@ -20,10 +31,46 @@
 
 namespace {
 
-template <int M>
+// steps per LDS block: the largest power of two <= 16 that keeps a wavefront's block under 40 KiB
+constexpr int lane_block_steps(int M, int DPW) {
+  int s = 16;
+  while (s > 2 && DPW * ((2 * M + 2 * M * M + 4) * s + 8) * 8 > 40 * 1024) s >>= 1;
+  return s;
+}
+
+template <int M, int DPW>
+struct LaneLds {
+  static constexpr int MM = M * M;
+  static constexpr int S = lane_block_steps(M, DPW);
+  static constexpr int W_A = S * M + 1;   // chunk strides are odd: the DPW owners hit different banks
+  static constexpr int W_P = S * MM + 1;
+  static constexpr int W_L = S + 1;
+  static constexpr int OFF_FA = 0;
+  static constexpr int OFF_PA = OFF_FA + DPW * W_A;
+  static constexpr int OFF_FP = OFF_PA + DPW * W_A;
+  static constexpr int OFF_PP = OFF_FP + DPW * W_P;
+  static constexpr int OFF_LF = OFF_PP + DPW * W_P;
+  static constexpr int OFF_LQ = OFF_LF + DPW * W_L;
+  static constexpr int OFF_LO = OFF_LQ + DPW * W_L;
+  static constexpr int OFF_YB = OFF_LO + DPW * W_L;   // y of the block, per draw slot (shared y: replicated)
+  static constexpr int OFF_ACC = OFF_YB + DPW * W_L;
+  static constexpr int TOTAL = OFF_ACC + DPW;
+};
+
+// TM: which tapes are written, known at compile time (bit 0 filtered states, 1 predicted states, 2 filtered
+// covariances, 3 predicted covariances) -- a taken scalar branch costs about as much as four dependent FMAs and the
+// step had a dozen of them; TM < 0: decided at run time (the uncommon combinations)
+template <int M, int DPW, int TM>
 __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A) {
-  constexpr int MM = M * M;
-  long b = (long)blockIdx.x * KF_WAVE + threadIdx.x;
+  using L = LaneLds<M, DPW>;
+  constexpr int MM = M * M, S = L::S;
+  constexpr int NK = (DPW * S + KF_WAVE - 1) / KF_WAVE;  // log-likelihood terms per lane and block
+  __shared__ double smem[L::TOTAL];
+  const int lane = threadIdx.x;
+  const int d = lane % DPW;
+  const bool owner = lane < DPW;
+  const long b0 = (long)blockIdx.x * DPW;
+  long b = b0 + d;
   const bool live = b < A.B;
   if (!live) b = A.B - 1;
   const int n = A.T, r = A.r;
@@ -56,80 +103,143 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
   const double Hs = A.H[b];
   const double ds = A.d ? A.d[b] : 0.0;
   const bool univariate = A.filter == KF_FILTER_UNIVARIATE;
+  const bool exact_const = (A.flags & KF_FLAG_MVN_CONST_EXACT) != 0;
   const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;
-  const double* ybase = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n : 0L);
+  const bool w_fa = TM < 0 ? A.filt_a != nullptr : (TM & 1) != 0, w_pa = TM < 0 ? A.pred_a != nullptr : (TM & 2) != 0,
+             w_fP = TM < 0 ? A.filt_P != nullptr : (TM & 4) != 0, w_pP = TM < 0 ? A.pred_P != nullptr : (TM & 8) != 0;
 
-  double* o_fa = (A.filt_a && live) ? A.filt_a + b * (long)n * M : nullptr;
-  double* o_pa = (A.pred_a && live) ? A.pred_a + b * (long)(n + 1) * M : nullptr;
-  double* o_fP = (A.filt_P && live) ? A.filt_P + b * (long)n * MM : nullptr;
-  double* o_pP = (A.pred_P && live) ? A.pred_P + b * (long)(n + 1) * MM : nullptr;
-  double* o_ll = (A.ll_obs && live) ? A.ll_obs + b * (long)n : nullptr;
-  if (o_pa) {
+  // predicted slot 0 = (a0, P0 as given)
+  if (owner && live) {
+    if (w_pa) {
 #pragma unroll
-    for (int i = 0; i < M; ++i) o_pa[i] = a[i];
-    o_pa += M;
-  }
-  if (o_pP) {
-    const double* gP = A.P0 + b * MM;
+      for (int i = 0; i < M; ++i) A.pred_a[b * (long)(n + 1) * M + i] = a[i];
+    }
+    if (w_pP) {
+      const double* gP = A.P0 + b * MM;
 #pragma unroll
-    for (int e = 0; e < MM; ++e) o_pP[e] = gP[e];
-    o_pP += MM;
+      for (int e = 0; e < MM; ++e) A.pred_P[b * (long)(n + 1) * MM + e] = gP[e];
+    }
   }
+  if (owner) smem[L::OFF_ACC + d] = 0.0;
 
-  double logp = 0.0;
+  double* s_fa = smem + L::OFF_FA + d * L::W_A;
+  double* s_pa = smem + L::OFF_PA + d * L::W_A;
+  double* s_fP = smem + L::OFF_FP + d * L::W_P;
+  double* s_pP = smem + L::OFF_PP + d * L::W_P;
+  double* s_lf = smem + L::OFF_LF + d * L::W_L;
+  double* s_lq = smem + L::OFF_LQ + d * L::W_L;
+  double* s_lo = smem + L::OFF_LO + d * L::W_L;
+
+  // chunk [draw slot][cnt rows of W doubles] in LDS -> rows [row0, row0 + cnt) of a draw-major tape with `rows`
+  // rows per draw: 8 contiguous bytes per lane
+  auto copy_out = [&](double* tape, const double* lds, int stride, auto wtag, int rows, int row0, int cnt) {
+    constexpr int W = decltype(wtag)::value;
+    if (cnt == S) {
+      constexpr int CW = S * W;
+#pragma unroll
+      for (int e0 = 0; e0 < DPW * CW; e0 += KF_WAVE) {
+        const int e = e0 + lane;
+        const int dd = e / CW, off = e - dd * CW;
+        if ((DPW * CW) % KF_WAVE == 0 || e < DPW * CW)
+          if (b0 + dd < A.B) tape[((b0 + dd) * (long)rows + row0) * W + off] = lds[dd * stride + off];
+      }
+    } else {
+      const int cw = cnt * W;
+      for (int e = lane; e < DPW * cw; e += KF_WAVE) {
+        const int dd = e / cw, off = e - dd * cw;
+        if (b0 + dd < A.B) tape[((b0 + dd) * (long)rows + row0) * W + off] = lds[dd * stride + off];
+      }
+    }
+  };
+
+  // y reaches the recursion through LDS, a block of S steps at a time: the loads of block k + 1 are issued when block k
+  // is flushed and land in LDS after its copy-out (a per-step global load would put L2 latency on every step)
+  const bool y_per_draw = (A.flags & KF_FLAG_Y_PER_DRAW) != 0;
+  double ynx[NK];
+  auto y_fetch = [&](int t0) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int e = lane + KF_WAVE * k;
+      const int dd = e / S, ss = e - dd * S;
+      long bb = b0 + dd;
+      if (bb >= A.B) bb = A.B - 1;
+      const int tt = (t0 + ss < n) ? t0 + ss : n - 1;
+      ynx[k] = ((DPW * S) % KF_WAVE == 0 || e < DPW * S) ? A.y[(y_per_draw ? bb * (long)n : 0L) + tt] : 0.0;
+    }
+  };
+  auto y_commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int e = lane + KF_WAVE * k;
+      const int dd = e / S, ss = e - dd * S;
+      if ((DPW * S) % KF_WAVE == 0 || e < DPW * S) smem[L::OFF_YB + dd * L::W_L + ss] = ynx[k];
+    }
+    wave_lds_fence();
+  };
+  const double* s_yb = smem + L::OFF_YB + d * L::W_L;
+  double lsum[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) lsum[k] = 0.0;
+  auto flush = [&](int t0, int cnt) {
+    wave_lds_fence();
+    if (t0 + cnt < n) y_fetch(t0 + cnt);
+    if (w_fa) copy_out(A.filt_a, smem + L::OFF_FA, L::W_A, std::integral_constant<int, M>{}, n, t0, cnt);
+    if (w_pa) copy_out(A.pred_a, smem + L::OFF_PA, L::W_A, std::integral_constant<int, M>{}, n + 1, t0 + 1, cnt);
+    if (w_fP) copy_out(A.filt_P, smem + L::OFF_FP, L::W_P, std::integral_constant<int, MM>{}, n, t0, cnt);
+    if (w_pP) copy_out(A.pred_P, smem + L::OFF_PP, L::W_P, std::integral_constant<int, MM>{}, n + 1, t0 + 1, cnt);
+    // the block's log-likelihood terms, one (draw slot, step) pair per lane and round
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int e = lane + KF_WAVE * k;
+      const int dd = e / S, ss = e - dd * S;
+      if (((DPW * S) % KF_WAVE == 0 || e < DPW * S) && ss < cnt) {
+        const double Fv = smem[L::OFF_LF + dd * L::W_L + ss];
+        const double quad = smem[L::OFF_LQ + dd * L::W_L + ss];
+        const bool observed = smem[L::OFF_LO + dd * L::W_L + ss] != 0.0;
+        const bool skipped = observed && univariate && Fv == 0.0;  // :468-471
+        double llv;
+        if (!observed) llv = 0.0;
+        else if (skipped) llv = exact_const ? -0.5 * KF_LOG_2PI : 0.0;
+        else if (univariate && !exact_const && Fv == 1.0 && quad == 0.0) llv = 0.0;  // :497-500
+        else llv = -0.5 * (KF_LOG_2PI + log(Fv) + quad);
+        if (A.ll_obs && b0 + dd < A.B) A.ll_obs[(b0 + dd) * (long)n + t0 + ss] = llv;
+        lsum[k] += llv;
+      }
+    }
+    wave_lds_fence();
+    if (t0 + cnt < n) y_commit();
+  };
+
+  y_fetch(0);
+  y_commit();
+
   int info = 0;
-  double ynext = ybase[0];
-  // without the per-step tape the log is taken once per 16 steps: mantissa product, exponent sum
-  const bool want_ll = A.ll_obs != nullptr;  // wave-uniform
-  double mant = 1.0, qsum = 0.0;
-  int ex = 0, cnt = 0;
+  double ycur = s_yb[0];
   for (int t = 0; t < n; ++t) {
-    const double yv = ynext;
-    if (t + 1 < n) ynext = ybase[t + 1];
+    const int s = t & (S - 1);
+    const double yv = ycur;
+    ycur = s_yb[s + 1];  // next step's y (slot S is the chunk's pad: re-read after the flush at a block boundary)
     const bool obs = !(yv != yv);
     double Mv[M];
     double F = Hs, za = 0.0;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
-      double s = 0.0;
+      double sm = 0.0;
 #pragma unroll
-      for (int k = 0; k < M; ++k) s = fma(P[i][k], Z[k], s);
-      Mv[i] = s;
-      F = fma(Z[i], s, F);
+      for (int k = 0; k < M; ++k) sm = fma(P[i][k], Z[k], sm);
+      Mv[i] = sm;
+      F = fma(Z[i], sm, F);
       za = fma(Z[i], a[i], za);
     }
+    const double Fraw = F;
     double v = (yv + dsign * ds) - za;
-    bool degenerate = !obs;
-    if (univariate) {
-      degenerate = degenerate || (F == 0.0);
-      if (degenerate) F += 1e-8;
-    } else if (!obs) {
-      F = 1.0;
-    }
+    // Univariate: a zero F skips the step (:468-471); the others process a missing step with F = 1, K = 0
+    const bool degenerate = !obs || (univariate && F == 0.0);
+    F = degenerate ? (univariate ? F + 1e-8 : 1.0) : F;
     if (!(F > 0.0) && info == 0 && !degenerate) info = ((t + 1) << 8) | 1;
     const double invF = degenerate ? 0.0 : fast_rcp(F);
     if (degenerate) v = 0.0;
-    double ll = 0.0;
-    if (want_ll) {
-      ll = degenerate ? 0.0 : -0.5 * (KF_LOG_2PI + log(F) + v * v * invF);
-      logp += ll;
-    } else {
-      if (!degenerate) {
-        int e2;
-        const double fm = frexp(F, &e2);
-        mant *= (F > 0.0) ? fm : __builtin_nan("");  // not PD: NaN, as log(F) would give
-        ex += e2;
-        qsum = fma(v * v, invF, qsum);
-        ++cnt;
-      }
-      if ((t & 15) == 15 || t == n - 1) {
-        logp += -0.5 * ((double)cnt * KF_LOG_2PI + log(mant) + 0.69314718055994530942 * (double)ex + qsum);
-        mant = 1.0;
-        qsum = 0.0;
-        ex = 0;
-        cnt = 0;
-      }
-    }
+    const double quad = v * v * invF;
     double K[M], af[M], Pf[M][M];
 #pragma unroll
     for (int i = 0; i < M; ++i) {
@@ -140,38 +250,25 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
     for (int i = 0; i < M; ++i)
 #pragma unroll
       for (int j = i; j < M; ++j) {
-        double s;
+        double sm;
         if (univariate) {
-          s = P[i][j] - K[i] * K[j] * F;
+          sm = P[i][j] - K[i] * K[j] * F;
         } else {
-          s = P[i][j] - K[i] * Mv[j];
-          s = fma(-Mv[i], K[j], s);
-          s = fma(F * K[i], K[j], s);
+          sm = P[i][j] - K[i] * Mv[j];
+          sm = fma(-Mv[i], K[j], sm);
+          sm = fma(F * K[i], K[j], sm);
         }
-        Pf[i][j] = s;
-        Pf[j][i] = s;
+        Pf[i][j] = sm;
+        Pf[j][i] = sm;
       }
-    if (o_fa) {
-#pragma unroll
-      for (int i = 0; i < M; ++i) o_fa[i] = af[i];
-      o_fa += M;
-    }
-    if (o_fP) {
-#pragma unroll
-      for (int i = 0; i < M; ++i)
-#pragma unroll
-        for (int j = 0; j < M; ++j) o_fP[i * M + j] = Pf[i][j];
-      o_fP += MM;
-    }
-    if (o_ll) o_ll[t] = ll;
     // predict
     double W[M][M];
 #pragma unroll
     for (int i = 0; i < M; ++i) {
-      double s = c[i];
+      double sm = c[i];
 #pragma unroll
-      for (int k = 0; k < M; ++k) s = fma(T[i][k], af[k], s);
-      a[i] = s;
+      for (int k = 0; k < M; ++k) sm = fma(T[i][k], af[k], sm);
+      a[i] = sm;
 #pragma unroll
       for (int j = 0; j < M; ++j) {
         double w = 0.0;
@@ -190,25 +287,53 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
           sij = fma(W[i][k], T[j][k], sij);
           sji = fma(W[j][k], T[i][k], sji);
         }
-        const double s = 0.5 * (sij + sji);
-        P[i][j] = s;
-        P[j][i] = s;
+        const double sm = 0.5 * (sij + sji);
+        P[i][j] = sm;
+        P[j][i] = sm;
       }
-    if (o_pa) {
+    // the step's rows and likelihood terms -> the LDS block (replicas write what the owner writes, to the same address)
+    s_lf[s] = Fraw;
+    s_lq[s] = quad;
+    s_lo[s] = obs ? 1.0 : 0.0;
+    if (w_fa) {
 #pragma unroll
-      for (int i = 0; i < M; ++i) o_pa[i] = a[i];
-      o_pa += M;
+      for (int i = 0; i < M; ++i) s_fa[s * M + i] = af[i];
     }
-    if (o_pP) {
+    if (w_fP) {
 #pragma unroll
       for (int i = 0; i < M; ++i)
 #pragma unroll
-        for (int j = 0; j < M; ++j) o_pP[i * M + j] = P[i][j];
-      o_pP += MM;
+        for (int j = 0; j < M; ++j) s_fP[s * MM + i * M + j] = Pf[i][j];
+    }
+    if (w_pa) {
+#pragma unroll
+      for (int i = 0; i < M; ++i) s_pa[s * M + i] = a[i];
+    }
+    if (w_pP) {
+#pragma unroll
+      for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) s_pP[s * MM + i * M + j] = P[i][j];
+    }
+    if (s == S - 1) {
+      flush(t - (S - 1), S);
+      ycur = s_yb[0];
     }
   }
-  if (live) {
-    A.logp[b] = logp;
+  if (n % S) flush(n - n % S, n % S);
+
+  // logp: the lanes' partial sums, S consecutive lanes per draw slot and round
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    double v = lsum[k];
+#pragma unroll
+    for (int off = S / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, KF_WAVE);
+    const int e = lane + KF_WAVE * k;
+    if ((lane % S) == 0 && ((DPW * S) % KF_WAVE == 0 || e < DPW * S)) smem[L::OFF_ACC + e / S] += v;
+    wave_lds_fence();
+  }
+  if (owner && live) {
+    A.logp[b] = smem[L::OFF_ACC + d];
     if (A.info) A.info[b] = info;
   }
 }
@@ -219,8 +344,26 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
 #define KF_CAT(a, b) KF_CAT2(a, b)
 int KF_CAT(kf_launch_forward_lane_m, KF_LANE_M)(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
   constexpr int M = KF_LANE_M;
-  long blocks = (a.B + KF_WAVE - 1) / KF_WAVE;
-  hipLaunchKernelGGL(kf_fwd_lane_kernel<M>, dim3((unsigned)blocks), dim3(KF_WAVE), 0, stream, a);
+  // draws per wavefront: enough wavefronts for every SIMD of the device first (the recursion is one
+  // dependency chain per wavefront, replicas cost nothing), then wider wavefronts
+  const long simds = (h && h->n_cu > 0 ? h->n_cu : 256) * 4L;
+  const int dpw = a.B <= 4 * simds ? 4 : (a.B <= 16 * simds ? 16 : 64);
+  const int mask = (a.filt_a ? 1 : 0) | (a.pred_a ? 2 : 0) | (a.filt_P ? 4 : 0) | (a.pred_P ? 8 : 0);
+#define KF_LANE_LAUNCH2(D_, TM_)                                                                              \
+  hipLaunchKernelGGL((kf_fwd_lane_kernel<M, D_, TM_>), dim3((unsigned)((a.B + D_ - 1) / D_)), dim3(KF_WAVE), \
+                     0, stream, a)
+#define KF_LANE_LAUNCH(D_)                                \
+  do {                                                    \
+    if (mask == 0) KF_LANE_LAUNCH2(D_, 0);                \
+    else if (mask == 15) KF_LANE_LAUNCH2(D_, 15);         \
+    else if (mask == 10) KF_LANE_LAUNCH2(D_, 10);         \
+    else KF_LANE_LAUNCH2(D_, -1);                         \
+  } while (0)
+  if (dpw == 4) KF_LANE_LAUNCH(4);
+  else if (dpw == 16) KF_LANE_LAUNCH(16);
+  else KF_LANE_LAUNCH(64);
+#undef KF_LANE_LAUNCH2
+#undef KF_LANE_LAUNCH
   KF_HIP_CHECK(h, hipGetLastError());
   return KF_OK;
 }

@@ -822,6 +822,46 @@ def test_lane_kernels_match_oracle(eng, m, ft):
     assert not out["info"].any()
 
 
+@pytest.mark.parametrize("B", [5000, 17000], ids=["dpw16", "dpw64"])
+@pytest.mark.parametrize("m", [1, 2, 3, 4])
+def test_lane_kernel_wide_wavefronts_per_draw_y_and_tape_subsets(eng, B, m):
+    """The lane kernel packs 4 / 16 / 64 draws per wavefront depending on the batch (B = 130 above: 4) and stages tapes
+    and y through LDS blocks of 4 .. 16 steps: the wider packings, y per draw, a series length that is not a multiple
+    of the block, the compile-time tape subsets (none / predicted only / all) and a run-time one (filtered only), and
+    the not-positive-definite report."""
+    n = 37
+    w = W.random_dense(B, n, 1, m, 1, seed=300 + m)
+    rng = np.random.default_rng(B + m)
+    y = w["y"][None, :, :] + 0.1 * rng.standard_normal((B, n, 1))
+    y[:, 5] = np.nan
+    y[7, 11:14] = np.nan
+    H = w["H"].copy()
+    H[B - 3] = -50.0  # F < 0 at the first step of that draw
+    args = (y, w["a0"], w["P0"], w["T"], w["Z"], w["R"], H, w["Q"])
+    ref = kn.kalman_filter(*args, mvn_const="exact")
+    eng.set_forward_kernel("lane")
+    try:
+        full = _np(eng.forward(*args, mvn_const="exact"))
+        lo = eng.forward(*args, mvn_const="exact", store_ll_obs=False, store_filtered=False, store_predicted=False)
+        pr = eng.forward(*args, mvn_const="exact", store_ll_obs=False, store_filtered=False)
+        fo = eng.forward(*args, mvn_const="exact", store_predicted=False)
+    finally:
+        eng.set_forward_kernel("auto")
+    ok = np.ones(B, bool)
+    ok[B - 3] = False
+    assert full["info"][B - 3] == ((1 << 8) | 1) and not full["info"][ok].any()
+    assert np.max(np.abs(full["logp"][ok] - ref["logp"][ok])) < 1e-8
+    for k in TAPES:
+        assert_allclose(full[k][ok], ref[k][ok], rtol=1e-9, atol=1e-9, err_msg=f"m={m} {k}")
+    assert np.array_equal(lo.logp.cpu().numpy()[ok], full["logp"][ok])
+    assert np.array_equal(pr.logp.cpu().numpy()[ok], full["logp"][ok])
+    assert np.array_equal(pr.predicted_covs.cpu().numpy()[ok], full["predicted_covs"][ok])
+    assert np.array_equal(pr.predicted_states.cpu().numpy()[ok], full["predicted_states"][ok])
+    assert np.array_equal(fo.filtered_covs.cpu().numpy()[ok], full["filtered_covs"][ok])
+    assert np.array_equal(fo.filtered_states.cpu().numpy()[ok], full["filtered_states"][ok])
+    assert np.array_equal(fo.ll_obs.cpu().numpy()[ok], full["ll_obs"][ok])
+
+
 # ----------------------------------------------------------------------------------------------
 # time-varying system matrices (SURVEY 8f row 3; reference tests/test_kalman_filter.py:102-156)
 # ----------------------------------------------------------------------------------------------
@@ -1249,7 +1289,8 @@ def test_auto_kernel_selection(eng):
     """The documented AUTO rules (include/kf.h) -- names only, no launch."""
     name = eng.forward_kernel_name
     assert name(4096, 1000, 1, 2, 1) == "kf_fwd_lane_kernel"        # C2
-    assert name(512, 1000, 1, 2, 1) == "kf_fwd_b4_kernel"           # C2, one of 8 GPUs' share: too few draws to pack
+    assert name(512, 1000, 1, 2, 1) == "kf_fwd_lane_kernel"         # C2, one of 8 GPUs' share: 4 draws per wavefront
+    assert name(512, 1000, 1, 3, 1) == "kf_fwd_b4_kernel"
     assert name(4096, 1000, 1, 6, 3) == "kf_fwd_b4_kernel"
     assert name(16384, 1000, 1, 6, 3) == "kf_fwd_row_kernel"
     assert name(65536, 1000, 1, 6, 3) == "kf_fwd_row_kernel"
