@@ -34,8 +34,8 @@ CASES = [("c1", {}, "standard"), ("c2", {}, "standard"), ("headline", {}, "stand
          ("c3", {}, "cholesky"), ("c4_m10", {"B": 2048}, "standard"), ("c4", {"B": 2048}, "standard"),
          ("c4", {"B": 2048}, "univariate"), ("c4_m10", {"B": 16384}, "standard"),
          ("c4", {"B": 16384}, "standard"), ("c4", {"B": 16384}, "univariate")]
-print("| workload | B | T | p,m,r | filter | kernel | fwd logp-only ms | fwd full-tape ms | evals/s (full) | HBM GB/s (full) | frac of 8 TB/s | bwd ms | smoother ms |")
-print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+print("| workload | B | T | p,m,r | filter | kernel | fwd logp-only ms | fwd full-tape ms | evals/s (full) | HBM GB/s (full) | frac of 8 TB/s | fwd predicted-tape-only ms | bwd ms | logp + gradient ms | smoother ms |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 for name, kw, ft in CASES:
     w = W.WORKLOADS[name](**kw)
     B, n, p, m, r = w["B"], w["n"], w["p"], w["m"], w["r"]
@@ -49,6 +49,9 @@ for name, kw, ft in CASES:
     res = eng.forward(*d, filter_type=ft)
     t_full = timeit(lambda: eng.forward(*d, filter_type=ft, out=res))
     gl = torch.ones(B, device="cuda", dtype=torch.float64)
+    res_p = eng.forward(*d, filter_type=ft, store_ll_obs=False, store_filtered=False)
+    t_pred = timeit(lambda: eng.forward(*d, filter_type=ft, out=res_p, store_ll_obs=False, store_filtered=False))
+    del res_p
     try:
         t_bwd = timeit(lambda: eng.backward(*d, predicted_states=res.predicted_states,
                                             predicted_covs=res.predicted_covs, g_logp=gl, filter_type=ft,
@@ -63,6 +66,6 @@ for name, kw, ft in CASES:
     gbs = ab / t_full / 1e9
     print(f"| {name} | {B} | {n} | {p},{m},{r} | {ft} | {eng.forward_kernel_name(B, n, p, m, r, ft, True)} | "
           f"{t_logp * 1e3:.3f} | {t_full * 1e3:.3f} | {B / t_full:.3e} | {gbs:.0f} | {gbs / 8000:.3f} | "
-          f"{t_bwd * 1e3:.2f} | {t_sm * 1e3:.2f} |", flush=True)
+          f"{t_pred * 1e3:.3f} | {t_bwd * 1e3:.2f} | {(t_pred + t_bwd) * 1e3:.2f} | {t_sm * 1e3:.2f} |", flush=True)
     del d, res, res_l
     torch.cuda.empty_cache()
