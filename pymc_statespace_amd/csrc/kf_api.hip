@@ -155,6 +155,19 @@ static bool kf_b4_selected(const kf_handle* h, int m, int p, int r, long B) {
   return h->forward_kernel == KF_KERNEL_AUTO && kf_b4_auto(h, m, B);
 }
 
+// KF_BACKWARD_B4=0 / 1 in the environment forces the choice (A/B measurements)
+static bool kf_backward_b4_selected(const kf_handle* h, int m, int p, int r, long B) {
+  if (!kf_backward_b4_ok(m, p, r)) return false;
+  if (h->forward_kernel != KF_KERNEL_AUTO && h->forward_kernel != KF_KERNEL_B4 && h->forward_kernel != KF_KERNEL_MFMA)
+    return false;
+  const char* e = getenv("KF_BACKWARD_B4");  // (read per call: tests switch it)
+  if (e && e[0]) return e[0] != '0';
+  // measured (scripts/r02/bwd_sweep.py, 1000 steps, ms): 4096 draws m = 5 / 6 / 8 / 10 / 14: 1.72 / 1.78 / 2.46 / 2.56 / 3.69 against
+  // 2.54 / 2.30 / 2.63 / 3.20 / 4.15 (round-1 choice); m = 2 / 4: 1.22 / 1.71 against 0.89 / 1.53, but 0.60 / 0.69 against
+  // 0.70 / 1.32 at 512 draws (one wavefront per draw fills the chip sooner)
+  return m >= 5 || B <= 1024;
+}
+
 static bool kf_mp_offsets_ok(int m, int T) { return 16.0 * ((double)T + 1.0) * m * m < 2147483648.0; }
 
 static void kf_mp_pick(const kf_handle* h, int m, long B, int* Mo, int* Ho) {
@@ -370,6 +383,11 @@ int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t
     }
     return kf_launch_backward_lds(h, a, stream);
   }
+  // scalar observation, m <= 14: adjoint of the augmented recursion on 4x4x4 block MFMAs (kf_backward_b4.hip); needs
+  // B (m + m^2) doubles of workspace for the hand-over of its last step (else the 16x16 tile adjoint below)
+  if (kf_backward_b4_selected(h, a.m, a.p, a.r, a.B) && workspace &&
+      workspace_bytes >= kf_backward_b4_workspace_bytes(a.B, a.m))
+    return kf_launch_backward_b4(h, a, workspace, workspace_bytes, stream);
   // 16 < m <= 48, scalar observations: block-tile adjoint (kf_backward_mfma_nb.hip); measured at
   // 4096 draws x 1000 steps the LDS adjoint took 144 ms (m = 20) .. 2.6 s (m = 40)
   if ((h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_MFMA) &&
@@ -475,6 +493,10 @@ extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, i
     const size_t bw = kf_backward_big_workspace_bytes(dims->B, m, p, dims->T, r);
     if (bw > *bytes) *bytes = bw;
   }
+  if ((which & KF_WS_BACKWARD) && dims->T >= 2 && !(dims->flags & KF_FLAG_TV_ANY) && kf_backward_b4_selected(h, m, p, r, dims->B)) {
+    const size_t bw = kf_backward_b4_workspace_bytes(dims->B, m);
+    if (bw > *bytes) *bytes = bw;
+  }
   if ((which & KF_WS_SMOOTHER) && m >= 1 && !kf_smoother_lds_fits(m) &&
       !(kf_smoother_mfma_wg_ok(m, r) && h->forward_kernel != KF_KERNEL_LDS)) {
     const size_t sm = kf_smoother_big_workspace_bytes(dims->B, m);
@@ -534,6 +556,7 @@ extern "C" int kf_filter_backward(kf_handle* h, const kf_dims* dims, const doubl
   a.pred_a = pred_a; a.pred_P = pred_P; a.g_logp = g_logp; a.g_ll_obs = g_ll_obs;
   a.g_a0 = g_a0; a.g_P0 = g_P0; a.g_T = g_T; a.g_Z = g_Z; a.g_R = g_R; a.g_H = g_H; a.g_Q = g_Q;
   a.g_c = g_c; a.g_d = g_d;
+  a.tape_T = dims->T; a.init_ab = nullptr; a.init_Pb = nullptr; a.accumulate = 0;
   return kf_launch_backward(h, a, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
   const int c = lane & 15, g = lane >> 4;
   const int permc = (c & 3) * 4 + (c >> 2);
   const long b = blockIdx.x;
-  const int n = A.T, r_ = A.r, m = A.m, p = P1 ? 1 : A.p, mm = m * m;
+  const int n = A.T, nt = A.tape_T, r_ = A.r, m = A.m, p = P1 ? 1 : A.p, mm = m * m;  // nt: tape stride (>= n)
 
   double* EX = smem;                 // exchange: permuted write, two b128 reads give the row-indexed view
   double* HD = EX + 16;
@@ -99,11 +99,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
   const bool univariate = A.filter == KF_FILTER_UNIVARIATE;
   const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;
   const bool y_per_draw = (A.flags & KF_FLAG_Y_PER_DRAW) != 0;
-  const double* ybase = A.y + (y_per_draw ? b * (long)n * p : 0L);
-  const double* gpa = A.pred_a + b * (long)(n + 1) * m;
-  const double* gpP = A.pred_P + b * (long)(n + 1) * mm;
+  const double* ybase = A.y + (y_per_draw ? b * (long)nt * p : 0L);
+  const double* gpa = A.pred_a + b * (long)(nt + 1) * m;
+  const double* gpP = A.pred_P + b * (long)(nt + 1) * mm;
   const double g_all = A.g_logp ? A.g_logp[b] : 0.0;
-  const double* gll = A.g_ll_obs ? A.g_ll_obs + b * (long)n : nullptr;
+  const double* gll = A.g_ll_obs ? A.g_ll_obs + b * (long)nt : nullptr;
 
   double zc1 = 0.0, zr1[4] = {0.0, 0.0, 0.0, 0.0}, H1 = 0.0, d1 = 0.0;
   if (P1) {
@@ -118,12 +118,14 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
   double PB[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
-    PB[s] = 0.0;
+    PB[s] = (A.init_Pb && on[s]) ? A.init_Pb[b * (long)mm + off[s]] : 0.0;
     ACC[s * KF_WAVE + lane] = 0.0;
     ACC[(4 + s) * KF_WAVE + lane] = 0.0;
   }
   double4_t TBm = {0.0, 0.0, 0.0, 0.0};
-  double abp = 0.0, cb = 0.0, hbv = 0.0, dbv = 0.0;
+  double abp = (A.init_ab && c_ok) ? A.init_ab[b * (long)m + c] : 0.0, cb = 0.0, hbv = 0.0, dbv = 0.0;
+  const bool acc_out = A.accumulate != 0;
+  auto put = [&](double* dst, double v) { *dst = acc_out ? *dst + v : v; };
 
   double PN[KS], an;
   auto prefetch = [&](int t) {
@@ -334,23 +336,23 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
   __syncthreads();
   if (g == 0 && c_ok) {
     if (A.g_a0) A.g_a0[b * (long)m + c] = abp;
-    if (A.g_c) A.g_c[b * (long)m + c] = cb;
+    if (A.g_c) put(A.g_c + b * (long)m + c, cb);
   }
   if (A.g_Z)
     for (int e = lane; e < p * m; e += KF_WAVE) {
       const int q = e / m, k = e - q * m;
-      A.g_Z[b * (long)p * m + e] = ZB[q * TILE + k];
+      put(A.g_Z + b * (long)p * m + e, ZB[q * TILE + k]);
     }
   if (A.g_H)
     for (int e = lane; e < p * p; e += KF_WAVE) {
       const int q1 = e / p, q2 = e - q1 * p;
-      A.g_H[b * (long)p * p + e] = (q1 == q2) ? HB[q1] : 0.0;
+      put(A.g_H + b * (long)p * p + e, (q1 == q2) ? HB[q1] : 0.0);
     }
-  if (A.g_d && lane < p) A.g_d[b * (long)p + lane] = DB[lane];
+  if (A.g_d && lane < p) put(A.g_d + b * (long)p + lane, DB[lane]);
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     if (!on[s]) continue;
-    if (A.g_T) A.g_T[b * (long)mm + off[s]] = fma(2.0, TBm[s], ACC[(4 + s) * KF_WAVE + lane]);
+    if (A.g_T) put(A.g_T + b * (long)mm + off[s], fma(2.0, TBm[s], ACC[(4 + s) * KF_WAVE + lane]));
     if (A.g_P0 && p > 1) A.g_P0[b * (long)mm + off[s]] = PB[s];
   }
   // R_b = Gs R (Q + Q') ;  Q_b = R' Gs R   (Gs in tile FT)
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
         for (int j = 0; j < m; ++j) grk = fma(FT[i * TILE + j], gR[j * r_ + k], grk);
         sacc = fma(grk, gQ[k * r_ + l] + gQ[l * r_ + k], sacc);
       }
-      A.g_R[b * (long)m * r_ + e] = sacc;
+      put(A.g_R + b * (long)m * r_ + e, sacc);
     }
   if (A.g_Q)
     for (int e = lane; e < r_ * r_; e += KF_WAVE) {
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
         for (int j = 0; j < m; ++j) grl = fma(FT[i * TILE + j], gR[j * r_ + l], grl);
         sacc = fma(gR[i * r_ + k], grl, sacc);
       }
-      A.g_Q[b * (long)r_ * r_ + e] = sacc;
+      put(A.g_Q + b * (long)r_ * r_ + e, sacc);
     }
 }
 

@@ -83,6 +83,14 @@ struct KfBwdArgs {
   double* g_Q;
   double* g_c;
   double* g_d;
+  // continuation of a reverse sweep another kernel started (kf_backward_b4.hip hands its last step to
+  // kf_backward_mfma.hip): T counts the steps to run, tape_T is the series length the tapes / y / g_ll_obs are strided by,
+  // (init_ab, init_Pb) [B][m], [B][m][m] are the adjoints of the predicted moments after those steps (NULL = 0), and
+  // accumulate != 0 adds to g_T, g_Z, g_R, g_H, g_Q, g_c, g_d instead of overwriting them
+  int tape_T;
+  const double* init_ab;
+  const double* init_Pb;
+  int accumulate;
 };
 
 struct KfSmoothArgs {
@@ -160,6 +168,11 @@ bool kf_backward_mfma_wg_ok(int m, int p, int r);
 int kf_launch_backward_mfma_wg(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 bool kf_backward_mfma_nb_ok(int m, int p, int r);
 int kf_launch_backward_mfma_nb(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+// adjoint of the augmented recursion on 4x4x4 block MFMAs (kf_backward_b4.hip): p == 1, m + 2 <= 16
+bool kf_backward_b4_ok(int m, int p, int r);
+size_t kf_backward_b4_workspace_bytes(long B, int m);
+int kf_launch_backward_b4(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream);
+int kf_launch_backward_mfma(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 // lane-per-draw kernels for tiny m (kf_forward_lane.hip)
 #define KF_LANE_M_MAX 4
 int kf_launch_forward_lane_m1(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);

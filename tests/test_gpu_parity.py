@@ -1053,6 +1053,61 @@ def test_time_varying_gradient_needs_the_lds_kernel(eng):
                      g_logp=np.ones(1), time_varying=("T",))
 
 
+@pytest.mark.parametrize("ft", ["standard", "univariate", "single"])
+@pytest.mark.parametrize("m", list(range(1, 15)))
+def test_b4_adjoint_matches_autograd(eng, m, ft, monkeypatch):
+    """kf_backward_b4.hip: the adjoint of the augmented recursion (p = 1, m <= 14) -- sweep down to step 1 on block MFMAs,
+    step 0 handed to kf_backward_mfma.hip for the exact entrywise gradient of P0.  Oracle: torch autograd of the
+    reference recursion.  Missing observations (first, last, block boundary), y per draw, c / d, a cotangent on every
+    ll_obs term, and series of 1, 2, 3 and 70 steps."""
+    from oracle import kalman_torch as kt
+
+    monkeypatch.setenv("KF_BACKWARD_B4", "1")  # (also below the batch / m thresholds of the AUTO choice)
+    for n in (70, 3, 2, 1):
+        B, r = 3, max(1, m // 2)
+        w = W.random_dense(B, n, 1, m, r, seed=50 + m)
+        rng = np.random.default_rng(m + n)
+        y = rng.standard_normal((B, n, 1))  # (the workload standardises its y: undefined for n = 1)
+        if n == 70:
+            y[:, [0, 5, 63, 64, 69]] = np.nan
+            y[1, 20:23] = np.nan
+        c = 0.1 * rng.standard_normal((B, m))
+        d = 0.1 * rng.standard_normal((B, 1))
+        gl = rng.standard_normal(B)
+        gll = 0.3 * rng.standard_normal((B, n))
+        args = (y,) + tuple(w[k] for k in ("a0", "P0", "T", "Z", "R", "H", "Q")) + (c, d)
+        grads = []
+        for b in range(B):  # the torch oracle shares y between draws
+            one = (y[b],) + tuple(x[b:b + 1] for x in args[1:])
+            grads.append(kt.logp_and_grads(*one, filter_type=ft, g_logp=gl[b:b + 1], g_ll_obs=gll[b:b + 1])[2])
+        res = eng.forward(*args, filter_type=ft)
+        g = eng.backward(*args, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs, g_logp=gl,
+                         g_ll_obs=gll, filter_type=ft, want_cd=True)
+        for k in ("a0", "P0", "T", "Z", "R", "H", "Q", "c", "d"):
+            a_ = g[k].cpu().numpy()
+            b_ = np.concatenate([gr[k] for gr in grads], axis=0)
+            if ft == "univariate" and k in ("P0", "Q", "H"):
+                a_, b_ = a_ + np.swapaxes(a_, -1, -2), b_ + np.swapaxes(b_, -1, -2)
+            assert np.max(np.abs(a_ - b_)) / (1.0 + np.max(np.abs(b_))) < 1e-10, (m, ft, n, k)
+
+
+def test_b4_adjoint_equals_the_tile_adjoint_at_the_headline_shape(eng, monkeypatch):
+    """4096 draws x 1000 steps x m = 10 (north star): both adjoint kernels on the same tapes."""
+    w = W.WORKLOADS["headline"]()
+    dev = [eng.to_device(w[k]) for k in ("y", "a0", "P0", "T", "Z", "R", "H", "Q")]
+    res = eng.forward(*dev, store_ll_obs=False, store_filtered=False)
+    ones = np.ones(w["B"])
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("KF_BACKWARD_B4", flag)
+        out[flag] = eng.backward(*dev, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
+                                 g_logp=ones, want_cd=True)
+    for k in out["1"]:
+        a_, b_ = out["1"][k].cpu().numpy(), out["0"][k].cpu().numpy()
+        assert np.isfinite(a_).all()
+        assert np.max(np.abs(a_ - b_)) / (1.0 + np.max(np.abs(b_))) < 1e-9, k
+
+
 BWD_SPLITS = [(10, 1), (10, 2), (10, 3), (10, 5), (8, 1), (8, 2), (8, 4), (6, 1), (6, 3), (4, 1), (4, 2), (2, 1)]
 
 
