@@ -54,7 +54,7 @@ extern "C" {
 
 #define KF_ABI_VERSION 4 /* 2: KF_FLAG_H_DIAGONAL, KF_KERNEL_MFMA, kf_dare, kf_simulate_statespace, workspace use by smoother/backward; \
                             3: kf_workspace_bytes_for, kf_forward_kernel_name_ws; every entry point runs on the handle's device; \
-                            4: kf_dare_backward, time-varying matrices in kf_filter_backward */
+                            4: kf_dare_backward, time-varying matrices in kf_filter_backward, kf_filter_value_and_grad */
 
 typedef struct kf_handle kf_handle;
 
@@ -160,7 +160,8 @@ int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes);
 /* The same per entry point (`which`: OR of KF_WS_*), so that a forward-only or smoother-only caller
  * does not hold the gradient's scratch.  The HBM-workspace kernels (m > 64) put the draw axis in
  * gridDim.y/z: B <= 65535 there (KF_ERR_UNSUPPORTED beyond; chunk the batch). */
-enum { KF_WS_FORWARD = 1, KF_WS_BACKWARD = 2, KF_WS_SMOOTHER = 4, KF_WS_ALL = 7 };
+enum { KF_WS_FORWARD = 1, KF_WS_BACKWARD = 2, KF_WS_SMOOTHER = 4, KF_WS_ALL = 7,
+       KF_WS_VALUE_AND_GRAD = 8 /* kf_filter_value_and_grad: tapes + both passes (not part of KF_WS_ALL) */ };
 int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, int which, size_t* bytes);
 
 /* Forward filter for B draws.  c, d may be NULL (= 0: initialize_intercepts,
@@ -173,6 +174,22 @@ int kf_filter_forward(kf_handle* h, const kf_dims* dims,
                       double* logp, double* ll_obs,
                       double* filt_a, double* pred_a, double* filt_P, double* pred_P,
                       int32_t* info, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Log-likelihood per draw AND the gradient of  sum_b g_logp[b]*logp[b]  (g_logp NULL = all ones) with respect to every
+ * input, in one call -- what a NUTS leapfrog step evaluates (the reference: pytensor.grad through the filter's scan,
+ * core/statespace.py:174).  The forward filter keeps its predicted tapes inside the workspace and the adjoint sweep
+ * consumes them there: nothing but logp, info and the nine gradient arrays is written for the caller.  Gradient
+ * conventions as kf_filter_backward.  workspace: kf_workspace_bytes_for(h, dims, KF_WS_VALUE_AND_GRAD, &bytes) --
+ * B (T + 1)(m + m^2) doubles of tape plus what the two passes need themselves. */
+int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims,
+                             const double* y, const double* a0, const double* P0,
+                             const double* T, const double* Z, const double* R,
+                             const double* H, const double* Q,
+                             const double* c, const double* d, const double* g_logp,
+                             double* logp, int32_t* info,
+                             double* g_a0, double* g_P0, double* g_T, double* g_Z,
+                             double* g_R, double* g_H, double* g_Q, double* g_c, double* g_d,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* Reverse-mode gradient of  sum_b g_logp[b]*logp[b] + sum_{b,t} g_ll_obs[b][t]*ll_obs[b][t]
  * with respect to every input, per draw.  Needs the predicted tapes of a forward

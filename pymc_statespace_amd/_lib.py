@@ -21,13 +21,14 @@ KF_FLAG_H_DIAGONAL = 1 << 11
 KF_FLAG_TV = {"T": 1 << 4, "Z": 1 << 5, "R": 1 << 6, "H": 1 << 7, "Q": 1 << 8, "c": 1 << 9, "d": 1 << 10}
 
 KF_WS_FORWARD, KF_WS_BACKWARD, KF_WS_SMOOTHER, KF_WS_ALL = 1, 2, 4, 7
+KF_WS_VALUE_AND_GRAD = 8
 KF_OK, KF_ERR_ARG, KF_ERR_HIP, KF_ERR_WORKSPACE, KF_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 
 # every symbol include/kf.h declares (tests check the built library exports them all)
 EXPORTS = (
     "kf_abi_version", "kf_create", "kf_destroy", "kf_last_error", "kf_set_lanes_per_draw",
     "kf_set_forward_kernel", "kf_forward_kernel_name", "kf_forward_kernel_name_ws",
-    "kf_workspace_bytes", "kf_workspace_bytes_for", "kf_filter_forward", "kf_filter_backward", "kf_smoother",
+    "kf_workspace_bytes", "kf_workspace_bytes_for", "kf_filter_forward", "kf_filter_backward", "kf_filter_value_and_grad", "kf_smoother",
     "kf_assemble", "kf_lyapunov", "kf_conditional_simulation", "kf_dare", "kf_dare_backward", "kf_simulate_statespace",
 )
 
@@ -88,6 +89,9 @@ def load():
     lib.kf_filter_backward.argtypes = [vp, C.POINTER(KfDims)] + [dp] * 10 + [dp] * 4 + [dp] * 9 + [
         vp, C.c_size_t, vp]
     lib.kf_filter_backward.restype = C.c_int
+    lib.kf_filter_value_and_grad.argtypes = [vp, C.POINTER(KfDims)] + [dp] * 10 + [dp, dp, ip] + [dp] * 9 + [
+        vp, C.c_size_t, vp]
+    lib.kf_filter_value_and_grad.restype = C.c_int
     lib.kf_smoother.argtypes = [vp, C.POINTER(KfDims)] + [dp] * 5 + [dp] * 2 + [vp, C.c_size_t, vp]
     lib.kf_smoother.restype = C.c_int
     lib.kf_assemble.argtypes = [vp, C.c_int64, C.c_int32, dp, C.c_int64, dp, C.c_int32, dp, dp, dp, vp]

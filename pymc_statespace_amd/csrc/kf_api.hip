@@ -473,8 +473,22 @@ static int check_dims(kf_handle* h, const kf_dims* d, bool need_p) {
   return KF_OK;
 }
 
+// kf_filter_value_and_grad's workspace: [ones B | pred_a B (T+1) m | pred_P B (T+1) m^2 | what the passes need], 64-byte pieces
+static size_t kf_vg_round(size_t x) { return (x + 63) & ~(size_t)63; }
+static size_t kf_vg_tape_bytes(const kf_dims* d) {
+  const size_t B = (size_t)d->B, n1 = (size_t)d->T + 1, m = (size_t)d->m;
+  return kf_vg_round(8 * B) + kf_vg_round(8 * B * n1 * m) + kf_vg_round(8 * B * n1 * m * m) + 64;
+}
+
 extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, int which, size_t* bytes) {
   if (!h || !dims || !bytes) return KF_ERR_ARG;
+  if (which & KF_WS_VALUE_AND_GRAD) {
+    size_t inner = 0;
+    const int rc = kf_workspace_bytes_for(h, dims, KF_WS_FORWARD | KF_WS_BACKWARD, &inner);
+    if (rc) return rc;
+    *bytes = kf_vg_tape_bytes(dims) + inner;
+    return KF_OK;
+  }
   *bytes = 0;  // the LDS- and register-resident kernels keep all scratch on chip
   const int m = dims->m, p = dims->p, r = dims->r;
   const bool tile_kernels = h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_MFMA;
@@ -558,6 +572,51 @@ extern "C" int kf_filter_backward(kf_handle* h, const kf_dims* dims, const doubl
   a.g_c = g_c; a.g_d = g_d;
   a.tape_T = dims->T; a.init_ab = nullptr; a.init_Pb = nullptr; a.accumulate = 0;
   return kf_launch_backward(h, a, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+namespace {
+__global__ void kf_fill_kernel(double* x, long n, double v) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = v;
+}
+}  // namespace
+
+extern "C" int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims, const double* y, const double* a0,
+                                        const double* P0, const double* T, const double* Z, const double* R,
+                                        const double* H, const double* Q, const double* c, const double* d,
+                                        const double* g_logp, double* logp, int32_t* info, double* g_a0, double* g_P0,
+                                        double* g_T, double* g_Z, double* g_R, double* g_H, double* g_Q, double* g_c,
+                                        double* g_d, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_dims(h, dims, true);
+  if (rc) return rc;
+  size_t need = 0;
+  rc = kf_workspace_bytes_for(h, dims, KF_WS_VALUE_AND_GRAD, &need);
+  if (rc) return rc;
+  if (!workspace || workspace_bytes < need) {
+    KF_SET_ERR(h, "kf_filter_value_and_grad: needs %zu bytes of workspace (got %zu)", need, workspace_bytes);
+    return KF_ERR_ARG;
+  }
+  const size_t B = (size_t)dims->B, n1 = (size_t)dims->T + 1, m = (size_t)dims->m;
+  char* w = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 63) & ~(uintptr_t)63);
+  double* ones = reinterpret_cast<double*>(w);
+  w += kf_vg_round(8 * B);
+  double* pred_a = reinterpret_cast<double*>(w);
+  w += kf_vg_round(8 * B * n1 * m);
+  double* pred_P = reinterpret_cast<double*>(w);
+  w += kf_vg_round(8 * B * n1 * m * m);
+  const size_t inner = workspace_bytes - (size_t)(w - reinterpret_cast<char*>(workspace));
+  rc = kf_filter_forward(h, dims, y, a0, P0, T, Z, R, H, Q, c, d, logp, nullptr, nullptr, pred_a, nullptr, pred_P, info,
+                         w, inner, stream);
+  if (rc) return rc;
+  if (!g_logp) {
+    KF_ON_DEVICE(h);
+    hipLaunchKernelGGL(kf_fill_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ones,
+                       (long)B, 1.0);
+    KF_HIP_CHECK(h, hipGetLastError());
+    g_logp = ones;
+  }
+  return kf_filter_backward(h, dims, y, a0, P0, T, Z, R, H, Q, c, d, pred_a, pred_P, g_logp, nullptr, g_a0, g_P0, g_T,
+                            g_Z, g_R, g_H, g_Q, g_c, g_d, w, inner, stream);
 }
 
 extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, const double* R,

@@ -301,6 +301,47 @@ class KalmanEngine:
         self._check(rc, "kf_filter_backward")
         return g
 
+    def value_and_grad(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, g_logp=None, filter_type="standard",
+                       mvn_const="reference", h_diagonal=False):
+        """kf_filter_value_and_grad -> (logp (B,), info (B,) int32, dict of gradients a0,P0,T,Z,R,H,Q,c,d) of
+        sum_b g_logp[b] logp[b] (default: ones) in ONE call: the predicted tapes live in the workspace only."""
+        P0 = self.to_device(P0)
+        B, m = P0.shape[0], P0.shape[1]
+        Z = self.to_device(Z, None)
+        p = Z.shape[-2]
+        R = self.to_device(R)
+        r = R.shape[-1]
+        y = self.to_device(y)
+        y_per_draw = y.ndim == 3
+        n = y.shape[-2]
+        a0 = self.to_device(a0, (B, m))
+        T = self.to_device(T, (B, m, m))
+        Z = self.to_device(Z, (B, p, m))
+        R = self.to_device(R, (B, m, r))
+        H = self.to_device(H, (B, p, p))
+        Q = self.to_device(Q, (B, r, r))
+        c = self.to_device(c, (B, m)) if c is not None else None
+        d = self.to_device(d, (B, p)) if d is not None else None
+        g_logp = self.to_device(g_logp, (B,)) if g_logp is not None else None
+        dims = self._dims(B, n, p, m, r, filter_type, mvn_const, y_per_draw)
+        if h_diagonal:
+            dims.flags |= _lib.KF_FLAG_H_DIAGONAL
+        dev, f64 = self.device, torch.float64
+        logp = torch.empty(B, device=dev, dtype=f64)
+        info = torch.empty(B, device=dev, dtype=torch.int32)
+        g = dict(a0=torch.empty(B, m, device=dev, dtype=f64), P0=torch.empty(B, m, m, device=dev, dtype=f64),
+                 T=torch.empty(B, m, m, device=dev, dtype=f64), Z=torch.empty(B, p, m, device=dev, dtype=f64),
+                 R=torch.empty(B, m, r, device=dev, dtype=f64), H=torch.empty(B, p, p, device=dev, dtype=f64),
+                 Q=torch.empty(B, r, r, device=dev, dtype=f64), c=torch.empty(B, m, device=dev, dtype=f64),
+                 d=torch.empty(B, p, device=dev, dtype=f64))
+        ws, ws_bytes = self._workspace(dims, _lib.KF_WS_VALUE_AND_GRAD)
+        rc = self.lib.kf_filter_value_and_grad(
+            self._h, C.byref(dims), _ptr(y), _ptr(a0), _ptr(P0), _ptr(T), _ptr(Z), _ptr(R), _ptr(H), _ptr(Q), _ptr(c),
+            _ptr(d), _ptr(g_logp), _ptr(logp), _ptr(info), _ptr(g["a0"]), _ptr(g["P0"]), _ptr(g["T"]), _ptr(g["Z"]),
+            _ptr(g["R"]), _ptr(g["H"]), _ptr(g["Q"]), _ptr(g["c"]), _ptr(g["d"]), _ptr(ws), ws_bytes, self._stream())
+        self._check(rc, "kf_filter_value_and_grad")
+        return logp, info, g
+
     # --------------------------------------------------------------- smoother
     def smooth(self, T, R, Q, filtered_states, filtered_covs, time_varying=()):
         """kf_smoother -> (smoothed_states (B,n,m), smoothed_covs (B,n,m,m)).  Names in ``time_varying`` (subset of

@@ -28,7 +28,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .engine import get_engine
+from .engine import FilterResult, get_engine
 
 GRAD_INPUT_NAMES = ("a0", "P0", "T", "Z", "R", "H", "Q", "c", "d")
 
@@ -112,11 +112,17 @@ def perform_logp_and_grad(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standa
     sysm, tv = _lead_system(T, Z, R, H, Q, c, d)
     args = (data, _col(a0)[None], np.asarray(P0)[None], *sysm)
     dev = [eng.to_device(x) for x in args]
-    res = eng.forward(*dev, filter_type=filter_type, mvn_const=mvn_const, h_diagonal=bool(h_diagonal),
-                      store_filtered=False, store_ll_obs=False, time_varying=tv)
-    g = eng.backward(*dev, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
-                     g_logp=np.ones(1), filter_type=filter_type, mvn_const=mvn_const, want_cd=True,
-                     h_diagonal=bool(h_diagonal), time_varying=tv)
+    if not tv:  # one C-ABI call: the predicted tapes never leave the workspace (kf_filter_value_and_grad)
+        logp, info, g = eng.value_and_grad(*dev, filter_type=filter_type, mvn_const=mvn_const,
+                                           h_diagonal=bool(h_diagonal))
+        res = FilterResult(logp=logp, ll_obs=None, filtered_states=None, predicted_states=None, filtered_covs=None,
+                           predicted_covs=None, info=info)
+    else:
+        res = eng.forward(*dev, filter_type=filter_type, mvn_const=mvn_const, h_diagonal=bool(h_diagonal),
+                          store_filtered=False, store_ll_obs=False, time_varying=tv)
+        g = eng.backward(*dev, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
+                         g_logp=np.ones(1), filter_type=filter_type, mvn_const=mvn_const, want_cd=True,
+                         h_diagonal=bool(h_diagonal), time_varying=tv)
     _raise_if_not_pd(res.info)
     out = {k: g[k][0].cpu().numpy() for k in GRAD_INPUT_NAMES}
     for k in ("a0", "c", "d"):

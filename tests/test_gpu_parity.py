@@ -1108,6 +1108,53 @@ def test_b4_adjoint_equals_the_tile_adjoint_at_the_headline_shape(eng, monkeypat
         assert np.max(np.abs(a_ - b_)) / (1.0 + np.max(np.abs(b_))) < 1e-9, k
 
 
+@pytest.mark.parametrize("case", ["headline_m10", "c2_m2", "varmax_p2_m6", "dense_m20"])
+def test_value_and_grad_single_call(eng, case):
+    """kf_filter_value_and_grad: logp, info and the nine gradients from one C-ABI call with the tapes inside the
+    workspace -- bit for bit what kf_filter_forward + kf_filter_backward give, and the oracle's numbers."""
+    from oracle import kalman_torch as kt
+
+    w = {"headline_m10": lambda: W.structural(B=37, n=80), "c2_m2": lambda: W.arma11(B=70, n=50),
+         "varmax_p2_m6": lambda: W.random_dense(9, 40, 2, 6, 3, seed=2),
+         "dense_m20": lambda: W.random_dense(5, 30, 1, 20, 4, seed=3)}[case]()
+    B = w["B"]
+    rng = np.random.default_rng(1)
+    y = w["y"].copy()
+    y[3] = np.nan
+    c, d = 0.1 * rng.standard_normal((B, w["m"])), 0.1 * rng.standard_normal((B, w["p"]))
+    gl = rng.standard_normal(B)
+    args = (y,) + tuple(w[k] for k in ("a0", "P0", "T", "Z", "R", "H", "Q")) + (c, d)
+    logp, info, g = eng.value_and_grad(*args, g_logp=gl, mvn_const="exact")
+    res = eng.forward(*args, mvn_const="exact")
+    g2 = eng.backward(*args, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs, g_logp=gl,
+                      mvn_const="exact", want_cd=True)
+    # (without the ll_obs tape some kernels sum the log terms in another order: last-bit differences in logp)
+    assert_allclose(logp.cpu().numpy(), res.logp.cpu().numpy(), rtol=1e-13, atol=0)
+    assert not info.cpu().numpy().any()
+    for k in g:  # (p > 1: forward() detects a diagonal H and may take another kernel than the one-call path)
+        if w["p"] == 1:
+            assert torch_equal(g[k], g2[k]), k
+        else:
+            assert_allclose(g[k].cpu().numpy(), g2[k].cpu().numpy(), rtol=1e-9, atol=1e-12, err_msg=k)
+    rl, _, gt = kt.logp_and_grads(*args, mvn_const="exact", g_logp=gl)
+    assert np.max(np.abs(logp.cpu().numpy() - rl)) < 1e-8
+    for k in g:
+        a_, b_ = g[k].cpu().numpy(), gt[k]
+        assert np.max(np.abs(a_ - b_)) / (1.0 + np.max(np.abs(b_))) < 1e-9, k
+    # default cotangent: ones
+    _, _, g1 = eng.value_and_grad(*args, mvn_const="exact")
+    g3 = eng.backward(*args, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
+                      g_logp=np.ones(B), mvn_const="exact", want_cd=True)
+    assert_allclose(g1["T"].cpu().numpy(), g3["T"].cpu().numpy(), rtol=1e-9, atol=1e-12)
+    assert_allclose(g1["Q"].cpu().numpy(), g3["Q"].cpu().numpy(), rtol=1e-9, atol=1e-12)
+
+
+def torch_equal(a, b):
+    import torch
+
+    return bool(torch.equal(a, b))
+
+
 BWD_SPLITS = [(10, 1), (10, 2), (10, 3), (10, 5), (8, 1), (8, 2), (8, 4), (6, 1), (6, 3), (4, 1), (4, 2), (2, 1)]
 
 
