@@ -477,7 +477,17 @@ static int check_dims(kf_handle* h, const kf_dims* d, bool need_p) {
 static size_t kf_vg_round(size_t x) { return (x + 63) & ~(size_t)63; }
 static size_t kf_vg_tape_bytes(const kf_dims* d) {
   const size_t B = (size_t)d->B, n1 = (size_t)d->T + 1, m = (size_t)d->m;
-  return kf_vg_round(8 * B) + kf_vg_round(8 * B * n1 * m) + kf_vg_round(8 * B * n1 * m * m) + 64;
+  const size_t compact = kf_vg_round(8 * B * n1 * m) + kf_vg_round(8 * B * n1 * m * m);
+  const size_t n4 = 4 * ((m + 2 + 3) / 4);
+  const size_t tile = kf_vg_round(8 * B * n1 * n4 * n4);  // the block kernels' own tape (p = 1, m <= 14)
+  return kf_vg_round(8 * B) + (m + 2 <= 16 && tile > compact ? tile : compact) + 64;
+}
+// value-and-gradient through the 4x4x4-block kernels' tile tape: both kernels selected, static, a series to sweep
+static bool kf_vg_tile_path(const kf_handle* h, const kf_dims* d) {
+  if ((d->flags & KF_FLAG_TV_ANY) || d->T < 2) return false;
+  const char* e = getenv("KF_VG_TILE_TAPE");  // =0: compact tapes (A/B measurements)
+  if (e && e[0] == '0') return false;
+  return kf_b4_selected(h, d->m, d->p, d->r, d->B) && kf_backward_b4_selected(h, d->m, d->p, d->r, d->B);
 }
 
 extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, int which, size_t* bytes) {
@@ -541,7 +551,7 @@ extern "C" int kf_filter_forward(kf_handle* h, const kf_dims* dims, const double
   a.filter = dims->filter; a.flags = dims->flags;
   a.y = y; a.a0 = a0; a.P0 = P0; a.Tm = T; a.Z = Z; a.R = R; a.H = H; a.Q = Q; a.c = c; a.d = d;
   a.logp = logp; a.ll_obs = ll_obs; a.filt_a = filt_a; a.pred_a = pred_a; a.filt_P = filt_P;
-  a.pred_P = pred_P; a.info = info;
+  a.pred_P = pred_P; a.info = info; a.tile_tape = nullptr;
   return kf_launch_forward(h, a, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -570,7 +580,7 @@ extern "C" int kf_filter_backward(kf_handle* h, const kf_dims* dims, const doubl
   a.pred_a = pred_a; a.pred_P = pred_P; a.g_logp = g_logp; a.g_ll_obs = g_ll_obs;
   a.g_a0 = g_a0; a.g_P0 = g_P0; a.g_T = g_T; a.g_Z = g_Z; a.g_R = g_R; a.g_H = g_H; a.g_Q = g_Q;
   a.g_c = g_c; a.g_d = g_d;
-  a.tape_T = dims->T; a.init_ab = nullptr; a.init_Pb = nullptr; a.accumulate = 0;
+  a.tape_T = dims->T; a.y_T = dims->T; a.tile_tape = nullptr; a.init_ab = nullptr; a.init_Pb = nullptr; a.accumulate = 0;
   return kf_launch_backward(h, a, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -605,6 +615,40 @@ extern "C" int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims, const
   double* pred_P = reinterpret_cast<double*>(w);
   w += kf_vg_round(8 * B * n1 * m * m);
   const size_t inner = workspace_bytes - (size_t)(w - reinterpret_cast<char*>(workspace));
+  const bool tile = kf_vg_tile_path(h, dims);
+  if (!y || !a0 || !P0 || !T || !Z || !R || !H || !Q || !logp) {
+    KF_SET_ERR(h, "kf_filter_value_and_grad: y, a0, P0, T, Z, R, H, Q and logp must be non-NULL");
+    return KF_ERR_ARG;
+  }
+  if (tile) {
+    // [ones | tile tape | inner]: the forward kernel leaves the predicted tile of every step, the adjoint reads it back
+    w = reinterpret_cast<char*>(pred_a);
+    double* tape = reinterpret_cast<double*>(w);
+    const size_t n4 = 4 * ((m + 2 + 3) / 4);
+    w += kf_vg_round(8 * B * n1 * n4 * n4);
+    const size_t inner_t = workspace_bytes - (size_t)(w - reinterpret_cast<char*>(workspace));
+    KF_ON_DEVICE(h);
+    KfFwdArgs f;
+    f.B = dims->B; f.T = dims->T; f.p = dims->p; f.m = dims->m; f.r = dims->r; f.filter = dims->filter; f.flags = dims->flags;
+    f.y = y; f.a0 = a0; f.P0 = P0; f.Tm = T; f.Z = Z; f.R = R; f.H = H; f.Q = Q; f.c = c; f.d = d;
+    f.logp = logp; f.ll_obs = nullptr; f.filt_a = nullptr; f.pred_a = nullptr; f.filt_P = nullptr; f.pred_P = nullptr;
+    f.info = info; f.tile_tape = tape;
+    rc = kf_launch_forward_b4(h, f, (hipStream_t)stream);
+    if (rc) return rc;
+    if (!g_logp) {
+      hipLaunchKernelGGL(kf_fill_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ones,
+                         (long)B, 1.0);
+      KF_HIP_CHECK(h, hipGetLastError());
+      g_logp = ones;
+    }
+    KfBwdArgs a;
+    a.B = dims->B; a.T = dims->T; a.p = dims->p; a.m = dims->m; a.r = dims->r; a.filter = dims->filter; a.flags = dims->flags;
+    a.y = y; a.a0 = a0; a.P0 = P0; a.Tm = T; a.Z = Z; a.R = R; a.H = H; a.Q = Q; a.c = c; a.d = d;
+    a.pred_a = nullptr; a.pred_P = nullptr; a.g_logp = g_logp; a.g_ll_obs = nullptr;
+    a.g_a0 = g_a0; a.g_P0 = g_P0; a.g_T = g_T; a.g_Z = g_Z; a.g_R = g_R; a.g_H = g_H; a.g_Q = g_Q; a.g_c = g_c; a.g_d = g_d;
+    a.tape_T = dims->T; a.y_T = dims->T; a.tile_tape = tape; a.init_ab = nullptr; a.init_Pb = nullptr; a.accumulate = 0;
+    return kf_launch_backward_b4(h, a, w, inner_t, (hipStream_t)stream);
+  }
   rc = kf_filter_forward(h, dims, y, a0, P0, T, Z, R, H, Q, c, d, logp, nullptr, nullptr, pred_a, nullptr, pred_P, info,
                          w, inner, stream);
   if (rc) return rc;

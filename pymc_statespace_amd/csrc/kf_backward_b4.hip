@@ -39,7 +39,9 @@ __host__ __device__ inline int bb_epilogue_doubles(int n4, int m, int r) {
   return 3 * n4 * n4 + 2 * m * m + m * r + 8 * m + 8;  // EB, EC, EG | RQR, Ms | Ms R | vectors
 }
 
-template <int NB>
+// TILE: the tape is kf_forward_b4.hip's own tile tape (KfBwdArgs::tile_tape, kf_filter_value_and_grad): the predicted
+// augmented tile of every step in the layout the registers want it -- u is a row of it, no matrix-vector product
+template <int NB, bool TILE>
 __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3 ? 4 : 3))) void kf_bwd_b4_kernel(
     const KfBwdArgs A, double* __restrict__ scratch) {
   constexpr int N4 = 4 * NB, JA = N4 - 2, JC = N4 - 1;
@@ -93,16 +95,18 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   const double mAA = (g == (JA & 3) && bq == JA) ? 1.0 : 0.0;                       // tile entry (JA, JA), register NB-1
 
   // tape image: lane (register I) reads P[rr][cc], or 2 a[rr] in column JC, or 2 a[cc] in row JC
-  const long nt1 = (long)A.tape_T + 1;
-  const double* gpa = A.pred_a + b * nt1 * m;
-  const double* gpP = A.pred_P + b * nt1 * mm;
   // (every other lane reads some finite tape value: those tile entries only ever meet exact zeros of T_e / z, see below)
+  const long nt1 = (long)A.tape_T + 1;
+  const double* gpa = TILE ? nullptr : A.pred_a + b * nt1 * m;
+  const double* gpP = TILE ? nullptr : A.pred_P + b * nt1 * mm;
+  const double* gtl = TILE ? A.tile_tape + b * nt1 * (N4 * N4) : nullptr;  // [T+1][N4][N4]
   const double* src[NB];
   int stp[NB], sh[NB];
 #pragma unroll
   for (int I = 0; I < NB; ++I) {
     const int rr = 4 * I + g;
-    if (rr < m && bq < m) { src[I] = gpP + rr * m + bq; stp[I] = mm; sh[I] = 0; }
+    if (TILE) { src[I] = gtl + (bq < N4 ? rr * N4 + bq : 0); stp[I] = N4 * N4; sh[I] = 0; }
+    else if (rr < m && bq < m) { src[I] = gpP + rr * m + bq; stp[I] = mm; sh[I] = 0; }
     else if (rr < m && bq == JC) { src[I] = gpa + rr; stp[I] = m; sh[I] = 1; }
     else if (rr == JC && bq < m) { src[I] = gpa + bq; stp[I] = m; sh[I] = 1; }
     else { src[I] = gpa; stp[I] = 0; sh[I] = 0; }
@@ -116,8 +120,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
       src[I] -= stp[I];
     }
   };
-  const double* ybase = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)A.tape_T : 0L);
-  const double* gll = A.g_ll_obs ? A.g_ll_obs + b * (long)A.tape_T : nullptr;
+  const double* ybase = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)A.y_T : 0L);
+  const double* gll = A.g_ll_obs ? A.g_ll_obs + b * (long)A.y_T : nullptr;
   const double g_all = A.g_logp ? A.g_logp[b] : 0.0;
   auto stage_block = [&](int t) {  // y and g_ll_obs of the 64-step block that holds t
     const int t0 = t & ~63;
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   for (int t = n - 1; t >= 1; --t) {
     double Sx[NB];
 #pragma unroll
-    for (int I = 0; I < NB; ++I) Sx[I] = ldexp(PN[I], sh[I]);
+    for (int I = 0; I < NB; ++I) Sx[I] = TILE ? PN[I] : ldexp(PN[I], sh[I]);
     if ((t & 63) == 63 && t != n - 1) stage_block(t);
     const double yv = YB[t & 63];
     const double gl = g_all + GL[t & 63];
@@ -159,11 +163,19 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     const double yo = ob ? -2.0 * (yv + dsign * d1) : 0.0;
 #pragma unroll
     for (int I = 0; I < NB; ++I) CB[I * KF_WAVE + lane] += G[I];
-    // ---- u = S e_A + yo e_C from the tape image: r = z S (row-0 layout), u_A = r . z ------------------------------------
-    double r = 0.0;
+    // ---- u = S e_A + yo e_C: a row of the tile (TILE), or from the tape image: r = z S (row-0 layout), u_A = r . z ----------
+    double r, uA;
+    if (TILE) {
+      // row JA = DPP row 2 of the last register (the lane swap must run in EVERY lane: not inside the select)
+      const double hh = high_half_everywhere(Sx[NB - 1]);
+      r = (g == 0 && bq < N4) ? hh : 0.0;
+      uA = readlane_f64(r, JA);
+    } else {
+      r = 0.0;
 #pragma unroll
-    for (int K = 0; K < NB; ++K) r = mfma4(zArow[K], Sx[K], r);
-    const double uA = readlane_f64(row_allsum(r * zc), 0);
+      for (int K = 0; K < NB; ++K) r = mfma4(zArow[K], Sx[K], r);
+      uA = readlane_f64(row_allsum(r * zc), 0);
+    }
     const double F = H1 + uA;
     const bool obe = ob && !(univariate && F == 0.0);  // Univariate skips a zero F (:468-471)
     const double rs = obe ? fast_rsqrt(fmax(F, 1e-300)) : 0.0;
@@ -285,8 +297,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   }
   const double* gR = A.R + b * (long)m * r_;
   const double* gQ = A.Q + b * (long)r_ * r_;
-  const double* P1 = gpP + mm;  // predicted moments of step 1
-  const double* a1 = gpa + m;
+  // predicted moments of step 1: compact tape rows, or tile row 1 (S_1[i][j] = P_1, S_1[i][JC] = 2 a_1)
+  const double* P1 = TILE ? gtl + N4 * N4 : gpP + mm;
+  const double* a1 = TILE ? gtl + N4 * N4 + JC : gpa + m;
+  const int p1s = TILE ? N4 : m, a1s = TILE ? N4 : 1;
+  const double a1f = TILE ? 0.5 : 1.0;
   for (int e = lane; e < mm; e += KF_WAVE) {
     const int i = e / m, j = e - i * m;
     double s = 0.0;
@@ -303,7 +318,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     double sq = 0.0, sp = 0.0;
     for (int j = 0; j < m; ++j) {
       sq += RQR[lane * m + j] * vz[j];
-      sp += 0.5 * (P1[lane * m + j] + P1[j * m + lane]) * vz[j];
+      sp += 0.5 * (P1[lane * p1s + j] + P1[j * p1s + lane]) * vz[j];
     }
     vq[lane] = sq;
     vp[lane] = sp;
@@ -329,9 +344,9 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     for (int j = 0; j < m; ++j) {
       s += gT[i * m + j] * vt[j];                                                   // T_e row JA = z T
       s += 2.0 * RQR[i * m + j] * vA[j];                                            // C_e column JA = R Q R' z'
-      s += 2.0 * 0.5 * (P1[i * m + j] + P1[j * m + i]) * v1[j];                     // S_1 column JA = P_1 z'
+      s += 2.0 * 0.5 * (P1[i * p1s + j] + P1[j * p1s + i]) * v1[j];                 // S_1 column JA = P_1 z'
     }
-    s += 2.0 * CAA * vq[i] + 4.0 * CAC * ci + 2.0 * GAA * vp[i] + 4.0 * GAC * a1[i];
+    s += 2.0 * CAA * vq[i] + 4.0 * CAC * ci + 2.0 * GAA * vp[i] + 4.0 * GAC * a1f * a1[i * a1s];
     if (A.g_Z) A.g_Z[b * (long)m + i] = s;
     if (A.g_c) A.g_c[b * (long)m + i] = 4.0 * EC[i * N4 + JC] + 4.0 * CAC * vz[i];
     scratch[b * (long)m + i] = 4.0 * EG[i * N4 + JC] + 4.0 * GAC * vz[i];   // adjoint of a_pred[1]
@@ -378,7 +393,14 @@ int kf_launch_backward_b4(kf_handle* h, const KfBwdArgs& a, void* workspace, siz
                kf_backward_b4_workspace_bytes(a.B, a.m), a.p, a.m, workspace_bytes);
     return KF_ERR_UNSUPPORTED;
   }
-  if (a.T < 2) return kf_launch_backward_mfma(h, a, stream);
+  if (a.T < 2) {
+    if (a.tile_tape) {
+      KfBwdArgs one = a;
+      one.tile_tape = nullptr; one.pred_a = a.a0; one.pred_P = a.P0; one.tape_T = 0;
+      return kf_launch_backward_mfma(h, one, stream);
+    }
+    return kf_launch_backward_mfma(h, a, stream);
+  }
   double* scratch = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 63) & ~(uintptr_t)63);
   const int nb = (a.m + 2 + 3) / 4;
   const int epi = bb_epilogue_doubles(4 * nb, a.m, a.r);
@@ -387,8 +409,11 @@ int kf_launch_backward_b4(kf_handle* h, const KfBwdArgs& a, void* workspace, siz
     KF_SET_ERR(h, "backward(b4): r=%d needs %zu B of LDS", a.r, lds);
     return KF_ERR_UNSUPPORTED;
   }
-#define KF_BB_LAUNCH(NB_) \
-  hipLaunchKernelGGL((kf_bwd_b4_kernel<NB_>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a, scratch)
+#define KF_BB_LAUNCH(NB_)                                                                                              \
+  if (a.tile_tape)                                                                                                     \
+    hipLaunchKernelGGL((kf_bwd_b4_kernel<NB_, true>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a, scratch);   \
+  else                                                                                                                 \
+    hipLaunchKernelGGL((kf_bwd_b4_kernel<NB_, false>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a, scratch)
   switch (nb) {
     case 1: KF_BB_LAUNCH(1); break;
     case 2: KF_BB_LAUNCH(2); break;
@@ -403,5 +428,11 @@ int kf_launch_backward_b4(kf_handle* h, const KfBwdArgs& a, void* workspace, siz
   tail.init_ab = scratch;               // [B][m]
   tail.init_Pb = scratch + a.B * a.m;   // [B][m][m]
   tail.accumulate = 1;
+  if (a.tile_tape) {  // the tail's one tape row is the caller's (a0, P0) itself
+    tail.tile_tape = nullptr;
+    tail.pred_a = a.a0;
+    tail.pred_P = a.P0;
+    tail.tape_T = 0;
+  }
   return kf_launch_backward_mfma(h, tail, stream);
 }

@@ -99,11 +99,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
   const bool univariate = A.filter == KF_FILTER_UNIVARIATE;
   const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;
   const bool y_per_draw = (A.flags & KF_FLAG_Y_PER_DRAW) != 0;
-  const double* ybase = A.y + (y_per_draw ? b * (long)nt * p : 0L);
+  const double* ybase = A.y + (y_per_draw ? b * (long)A.y_T * p : 0L);
   const double* gpa = A.pred_a + b * (long)(nt + 1) * m;
   const double* gpP = A.pred_P + b * (long)(nt + 1) * mm;
   const double g_all = A.g_logp ? A.g_logp[b] : 0.0;
-  const double* gll = A.g_ll_obs ? A.g_ll_obs + b * (long)nt : nullptr;
+  const double* gll = A.g_ll_obs ? A.g_ll_obs + b * (long)A.y_T : nullptr;
 
   double zc1 = 0.0, zr1[4] = {0.0, 0.0, 0.0, 0.0}, H1 = 0.0, d1 = 0.0;
   if (P1) {

@@ -238,6 +238,17 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   };
   bool pred_pending = false;
 
+  // internal tile tape (kf_filter_value_and_grad): the predicted tile itself, N4 x N4 row-major per step -- NB stores of
+  // N4-double rows straight from the registers, no staging (read back in the same layout by kf_backward_b4.hip)
+  double* t_tile = A.tile_tape ? A.tile_tape + b * (long)(n + 1) * (N4 * N4) + g * N4 + bq : nullptr;
+  auto put_tile = [&]() {
+    if (bq < N4) {
+#pragma unroll
+      for (int I = 0; I < NB; ++I) t_tile[I * 4 * N4] = P[I];
+    }
+    t_tile += N4 * N4;
+  };
+  if (t_tile) put_tile();
   // predicted tape slot 0 = (a0, P0 as given: the caller's P0, not its symmetrised upper triangle)
   if (w_pa) put_a(s_pa, o_pa, P[NB - 1]);
   if (w_pP) {
@@ -370,6 +381,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
 #pragma unroll
       for (int I = 0; I < NB; ++I) P[I] = HALF_STATIC ? Y[I] + Yt[I] : 0.5 * (Y[I] + Yt[I]);
     }
+    if (t_tile) put_tile();
     if (w_pa) put_a(s_pa, o_pa, P[NB - 1]);
     if (w_pP) {
       if (STREAM) {

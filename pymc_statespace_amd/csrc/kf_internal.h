@@ -53,6 +53,9 @@ struct KfFwdArgs {
   double* filt_P;
   double* pred_P;
   int32_t* info;
+  // internal (kf_filter_value_and_grad): the 4x4x4-block kernel's own tape -- the predicted augmented tile of every step,
+  // [B][T+1][N4][N4] row-major (N4 = 4 ceil((m + 2) / 4)), read back by kf_backward_b4.hip.  NULL for every public call
+  double* tile_tape;
 };
 
 struct KfBwdArgs {
@@ -88,6 +91,8 @@ struct KfBwdArgs {
   // (init_ab, init_Pb) [B][m], [B][m][m] are the adjoints of the predicted moments after those steps (NULL = 0), and
   // accumulate != 0 adds to g_T, g_Z, g_R, g_H, g_Q, g_c, g_d instead of overwriting them
   int tape_T;
+  int y_T;  // series length y / g_ll_obs are strided by (= tape_T except in the tile-tape hand-over)
+  const double* tile_tape;  // internal: kf_forward_b4.hip's tile tape instead of (pred_a, pred_P), see KfFwdArgs
   const double* init_ab;
   const double* init_Pb;
   int accumulate;

@@ -1131,11 +1131,11 @@ def test_value_and_grad_single_call(eng, case):
     # (without the ll_obs tape some kernels sum the log terms in another order: last-bit differences in logp)
     assert_allclose(logp.cpu().numpy(), res.logp.cpu().numpy(), rtol=1e-13, atol=0)
     assert not info.cpu().numpy().any()
-    for k in g:  # (p > 1: forward() detects a diagonal H and may take another kernel than the one-call path)
-        if w["p"] == 1:
-            assert torch_equal(g[k], g2[k]), k
-        else:
-            assert_allclose(g[k].cpu().numpy(), g2[k].cpu().numpy(), rtol=1e-9, atol=1e-12, err_msg=k)
+    # (same numbers up to rounding, not bit for bit: the one-call path hands the block kernels' own tile tape from the
+    #  forward to the adjoint, and for p > 1 forward() may pick another kernel after detecting a diagonal H)
+    for k in g:
+        a_, b_ = g[k].cpu().numpy(), g2[k].cpu().numpy()
+        assert np.max(np.abs(a_ - b_)) / (1.0 + np.max(np.abs(b_))) < 1e-10, k
     rl, _, gt = kt.logp_and_grads(*args, mvn_const="exact", g_logp=gl)
     assert np.max(np.abs(logp.cpu().numpy() - rl)) < 1e-8
     for k in g:
@@ -1147,6 +1147,39 @@ def test_value_and_grad_single_call(eng, case):
                       g_logp=np.ones(B), mvn_const="exact", want_cd=True)
     assert_allclose(g1["T"].cpu().numpy(), g3["T"].cpu().numpy(), rtol=1e-9, atol=1e-12)
     assert_allclose(g1["Q"].cpu().numpy(), g3["Q"].cpu().numpy(), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("ft", ["standard", "univariate", "single"])
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 7, 8, 10, 11, 12, 14])
+def test_value_and_grad_through_the_tile_tape(eng, m, ft):
+    """One call, p = 1, m <= 14: where AUTO puts both passes on the 4x4x4-block kernels the forward leaves its own tile
+    tape in the workspace and the adjoint reads it back (m <= 3 at this batch size: lane kernel + compact tapes -- the
+    same entry point).  Oracle: torch autograd.  y per draw, missing steps, c / d, series of 70, 2 and 1 steps."""
+    from oracle import kalman_torch as kt
+
+    for n in (70, 2, 1):
+        B, r = 5, max(1, m // 2)
+        w = W.random_dense(B, n, 1, m, r, seed=70 + m)
+        rng = np.random.default_rng(m + n)
+        y = rng.standard_normal((B, n, 1))
+        if n == 70:
+            y[:, [0, 31, 32, 69]] = np.nan
+            y[2, 40:43] = np.nan
+        c = 0.1 * rng.standard_normal((B, m))
+        d = 0.1 * rng.standard_normal((B, 1))
+        gl = rng.standard_normal(B)
+        args = (y,) + tuple(w[k] for k in ("a0", "P0", "T", "Z", "R", "H", "Q")) + (c, d)
+        logp, info, g = eng.value_and_grad(*args, g_logp=gl, filter_type=ft, mvn_const="exact")
+        assert not info.cpu().numpy().any()
+        for b in range(B):
+            one = (y[b],) + tuple(x[b:b + 1] for x in args[1:])
+            rl, _, gt = kt.logp_and_grads(*one, filter_type=ft, mvn_const="exact", g_logp=gl[b:b + 1])
+            assert abs(float(logp[b]) - float(rl[0])) < 1e-8
+            for k in g:
+                a_, b_ = g[k][b:b + 1].cpu().numpy(), gt[k]
+                if ft == "univariate" and k in ("P0", "Q", "H"):
+                    a_, b_ = a_ + np.swapaxes(a_, -1, -2), b_ + np.swapaxes(b_, -1, -2)
+                assert np.max(np.abs(a_ - b_)) / (1.0 + np.max(np.abs(b_))) < 1e-10, (m, ft, n, b, k)
 
 
 def torch_equal(a, b):
@@ -2133,7 +2166,9 @@ def test_workspace_is_only_requested_where_a_workspace_path_runs(eng):
         assert eng.lib.kf_workspace_bytes(eng._h, C.byref(dims), C.byref(nb)) == 0
         return nb.value
 
-    assert ws(4096, 1000, 1, 10, 4) == 4 * 4096 + 64           # flags of the tile smoother
+    # (p = 1, m <= 14: the block adjoint hands its last step over through B (m + m^2) doubles; else the tile smoother's flags)
+    assert ws(4096, 1000, 1, 10, 4) == 8 * 4096 * (10 + 100) + 64
+    assert ws(4096, 1000, 1, 16, 4) == 4 * 4096 + 64
     assert ws(4096, 1000, 1, 40, 4) == 4 * 4096 + 64
     assert ws(4096, 1000, 1, 64, 8) == 4 * 4096 + 64            # workgroup kernels: all on chip (+ flags)
     assert ws(4096, 1000, 3, 60, 8, "standard", True) == 4 * 4096 + 64
