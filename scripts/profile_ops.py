@@ -18,5 +18,6 @@ for _ in range(5):
     g = eng.backward(*d, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs, g_logp=ones,
                      h_diagonal=True)
     sa, sP = eng.smooth(d[3], d[5], d[7], res.filtered_states, res.filtered_covs)
+    vg = eng.value_and_grad(*d, h_diagonal=True)
 torch.cuda.synchronize()
 print("done", name)
