@@ -26,6 +26,14 @@ __device__ __forceinline__ double high_half_everywhere(double x) {
   return __hiloint2double(b[1], a[1]);
 }
 
+// rows {0, 1} (lanes 0..31) copied over rows {2, 3}
+__device__ __forceinline__ double low_half_everywhere(double x) {
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]);
+}
+
 // 1/sqrt(x) to rounding accuracy: v_rsq_f64 + two Newton steps (x finite, normal, > 0)
 __device__ __forceinline__ double fast_rsqrt(double x) {
   double r = __builtin_amdgcn_rsq(x);

@@ -39,8 +39,9 @@ __host__ __device__ inline int bb_epilogue_doubles(int n4, int m, int r) {
   return 3 * n4 * n4 + 2 * m * m + m * r + 8 * m + 8;  // EB, EC, EG | RQR, Ms | Ms R | vectors
 }
 
-// TILE: the tape is kf_forward_b4.hip's own tile tape (KfBwdArgs::tile_tape, kf_filter_value_and_grad): the predicted
-// augmented tile of every step in the layout the registers want it -- u is a row of it, no matrix-vector product
+// TILE: the tape is kf_forward_b4.hip's own tile tape (KfBwdArgs::tile_tape, kf_filter_value_and_grad): slot t holds S_f of
+// step t in the layout the registers want it, with u_hat in its (otherwise unused) row JA and 1 / sqrt(F) at [JA][JA] --
+// no tape image to assemble, no matrix-vector product, no rsqrt, no rank-one MFMAs; slot T holds the predicted tile S_1
 template <int NB, bool TILE>
 __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3 ? 4 : 3))) void kf_bwd_b4_kernel(
     const KfBwdArgs A, double* __restrict__ scratch) {
@@ -159,29 +160,34 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     if ((t & 63) == 63 && t != n - 1) stage_block(t);
     const double yv = YB[t & 63];
     const double gl = g_all + GL[t & 63];
-    const bool ob = !(yv != yv);
-    const double yo = ob ? -2.0 * (yv + dsign * d1) : 0.0;
 #pragma unroll
     for (int I = 0; I < NB; ++I) CB[I * KF_WAVE + lane] += G[I];
-    // ---- u = S e_A + yo e_C: a row of the tile (TILE), or from the tape image: r = z S (row-0 layout), u_A = r . z ----------
-    double r, uA;
+    double u, ut, rs, invF;   // u: what goes through the exchange (u itself, or u_hat with TILE); ut = u_hat
+    bool obe;
     if (TILE) {
-      // row JA = DPP row 2 of the last register (the lane swap must run in EVERY lane: not inside the select)
+      // row JA of the taped tile = (u_hat, rs at JA) in DPP row 2 of the last register (the lane swap must run in EVERY lane:
+      // not inside a select).  Entry JA of the vector only ever meets exact zeros (row / column JA of G_f)
       const double hh = high_half_everywhere(Sx[NB - 1]);
-      r = (g == 0 && bq < N4) ? hh : 0.0;
-      uA = readlane_f64(r, JA);
+      ut = (g == 0 && bq < N4) ? hh : 0.0;
+      rs = readlane_f64(ut, JA);
+      invF = rs * rs;
+      obe = true;  // (a missing / skipped step has rs = 0 and u_hat = 0 on the tape: every term vanishes by itself)
+      u = ut;
     } else {
-      r = 0.0;
+      const bool ob = !(yv != yv);
+      const double yo = ob ? -2.0 * (yv + dsign * d1) : 0.0;
+      // ---- u = S e_A + yo e_C from the tape image: r = z S (row-0 layout), u_A = r . z -----------------------------------
+      double r = 0.0;
 #pragma unroll
       for (int K = 0; K < NB; ++K) r = mfma4(zArow[K], Sx[K], r);
-      uA = readlane_f64(row_allsum(r * zc), 0);
+      const double uA = readlane_f64(row_allsum(r * zc), 0);
+      const double F = H1 + uA;
+      obe = ob && !(univariate && F == 0.0);  // Univariate skips a zero F (:468-471)
+      rs = obe ? fast_rsqrt(fmax(F, 1e-300)) : 0.0;
+      invF = rs * rs;
+      u = fma(selC, yo, (lane == JA) ? uA : r);
+      ut = u * rs;
     }
-    const double F = H1 + uA;
-    const bool obe = ob && !(univariate && F == 0.0);  // Univariate skips a zero F (:468-471)
-    const double rs = obe ? fast_rsqrt(fmax(F, 1e-300)) : 0.0;
-    const double invF = rs * rs;
-    const double u = fma(selC, yo, (lane == JA) ? uA : r);
-    const double ut = u * rs;
     if (g == 0) UX[fb] = u;
     // ---- Y = T_e' G ------------------------------------------------------------------------------------------------------
     double Y[NB];
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     // ---- S_f = S - ut ut' (rows < m and JC, columns < m are what T_b needs) --------------------------------------------------
     double Sf[NB];
 #pragma unroll
-    for (int I = 0; I < NB; ++I) Sf[I] = mfma4_nega(urep[I] * rs, ut, Sx[I]);
+    for (int I = 0; I < NB; ++I) Sf[I] = TILE ? Sx[I] : mfma4_nega(urep[I] * rs, ut, Sx[I]);
     // ---- G_f = T_e' Y' ;  T_b += Y' S_f   (left factor (Y')(I, K): lane (g = k, any b, q = i) holds Y[4K+g][4I+q]) -------------------
     double Gf[NB];
 #pragma unroll
@@ -241,13 +247,14 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     if (t > 1) prefetch();
     // ---- g = -2 G_f ut - (gl / 4) ut_C e_C (row-0 layout) -------------------------------------------------------------------------
     double gv = 0.0;
-    const double m2rs = -2.0 * rs;
+    const double m2rs = TILE ? -2.0 : -2.0 * rs;  // (TILE: u_hat itself went through the exchange)
 #pragma unroll
     for (int K = 0; K < NB; ++K) gv = mfma4(urow[K] * m2rs, Gf[K], gv);
     const double utC = readlane_f64(ut, JC);
     const double gut = fma(selC, obe ? -0.25 * gl * utC : 0.0, gv);
-    const double rsb = readlane_f64(row_allsum(gut * u), 0);
-    const double Fb = obe ? -0.5 * invF * (gl + rsb * rs) : 0.0;
+    // rs_b rs = (g . u) rs = g . u_hat
+    const double rsbrs = TILE ? readlane_f64(row_allsum(gut * ut), 0) : readlane_f64(row_allsum(gut * u), 0) * rs;
+    const double Fb = obe ? -0.5 * invF * (gl + rsbrs) : 0.0;
     Hb += Fb;
     const double ub = rs * gut;
     dacc += ub;
@@ -297,9 +304,9 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   }
   const double* gR = A.R + b * (long)m * r_;
   const double* gQ = A.Q + b * (long)r_ * r_;
-  // predicted moments of step 1: compact tape rows, or tile row 1 (S_1[i][j] = P_1, S_1[i][JC] = 2 a_1)
-  const double* P1 = TILE ? gtl + N4 * N4 : gpP + mm;
-  const double* a1 = TILE ? gtl + N4 * N4 + JC : gpa + m;
+  // predicted moments of step 1: compact tape rows, or the tile tape's last slot (S_1[i][j] = P_1, S_1[i][JC] = 2 a_1)
+  const double* P1 = TILE ? gtl + (long)A.tape_T * (N4 * N4) : gpP + mm;
+  const double* a1 = TILE ? gtl + (long)A.tape_T * (N4 * N4) + JC : gpa + m;
   const int p1s = TILE ? N4 : m, a1s = TILE ? N4 : 1;
   const double a1f = TILE ? 0.5 : 1.0;
   for (int e = lane; e < mm; e += KF_WAVE) {

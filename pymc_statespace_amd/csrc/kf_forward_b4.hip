@@ -238,17 +238,18 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   };
   bool pred_pending = false;
 
-  // internal tile tape (kf_filter_value_and_grad): the predicted tile itself, N4 x N4 row-major per step -- NB stores of
-  // N4-double rows straight from the registers, no staging (read back in the same layout by kf_backward_b4.hip)
+  // internal tile tape (kf_filter_value_and_grad; read back by kf_backward_b4.hip in the same register layout): per draw
+  // T + 1 slots of N4 x N4 doubles, row-major, stored straight from the registers (no staging).  Slot t < T = what the
+  // adjoint of step t needs: the FILTERED tile, its row JA (never used there) replaced by u_hat with 1 / sqrt(F) at
+  // [JA][JA] (0 on a missing / skipped step); slot T = the predicted tile of step 1 (the de-augmentation at the hand-over)
   double* t_tile = A.tile_tape ? A.tile_tape + b * (long)(n + 1) * (N4 * N4) + g * N4 + bq : nullptr;
-  auto put_tile = [&]() {
+  auto put_tile = [&](double* dst, const double (&X)[NB], double last) {
     if (bq < N4) {
 #pragma unroll
-      for (int I = 0; I < NB; ++I) t_tile[I * 4 * N4] = P[I];
+      for (int I = 0; I < NB - 1; ++I) dst[I * 4 * N4] = X[I];
+      dst[(NB - 1) * 4 * N4] = last;
     }
-    t_tile += N4 * N4;
   };
-  if (t_tile) put_tile();
   // predicted tape slot 0 = (a0, P0 as given: the caller's P0, not its symmetrised upper triangle)
   if (w_pa) put_a(s_pa, o_pa, P[NB - 1]);
   if (w_pP) {
@@ -342,6 +343,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     // tile -= u_hat u_hat'
 #pragma unroll
     for (int I = 0; I < NB; ++I) P[I] = mfma4_nega(urep[I] * rs, uh, P[I]);
+    if (t_tile) {
+      const double rs_t = (univariate && F == 0.0) ? 0.0 : rs;  // a skipped step has no adjoint terms (:468-471)
+      const double rowv = low_half_everywhere((lane == JA) ? rs_t : uh);  // DPP row 0 -> row 2 (= row JA of the last register)
+      put_tile(t_tile + (long)t * (N4 * N4), P, (g == (JA & 3)) ? rowv : P[NB - 1]);
+    }
     if (!STREAM && pred_pending) {  // (image mode) predicted covariance of the previous step: tile image -> HBM
       flush_cov(t_pP);
       t_pP += mm;
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
 #pragma unroll
       for (int I = 0; I < NB; ++I) P[I] = HALF_STATIC ? Y[I] + Yt[I] : 0.5 * (Y[I] + Yt[I]);
     }
-    if (t_tile) put_tile();
+    if (t_tile && t == 0) put_tile(t_tile + (long)n * (N4 * N4), P, P[NB - 1]);
     if (w_pa) put_a(s_pa, o_pa, P[NB - 1]);
     if (w_pP) {
       if (STREAM) {

@@ -53,8 +53,9 @@ struct KfFwdArgs {
   double* filt_P;
   double* pred_P;
   int32_t* info;
-  // internal (kf_filter_value_and_grad): the 4x4x4-block kernel's own tape -- the predicted augmented tile of every step,
-  // [B][T+1][N4][N4] row-major (N4 = 4 ceil((m + 2) / 4)), read back by kf_backward_b4.hip.  NULL for every public call
+  // internal (kf_filter_value_and_grad): the 4x4x4-block kernel's own tape, [B][T+1][N4][N4] row-major (N4 = 4 ceil((m + 2) / 4)):
+  // slot t < T the filtered augmented tile of step t with u_hat in row JA and 1 / sqrt(F) at [JA][JA], slot T the predicted
+  // tile of step 1; read back by kf_backward_b4.hip.  NULL for every public call
   double* tile_tape;
 };
 
