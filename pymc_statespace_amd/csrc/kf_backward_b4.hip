@@ -138,11 +138,14 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   for (int e = lane; e < 16 * TRS; e += KF_WAVE) TR[e] = 0.0;
   wave_lds_fence();
 
-  double G[NB], Tb[NB];
+  // (the tile-tape sweep has registers to spare at NB <= 3: its C_e accumulators stay in VGPRs)
+  constexpr bool CB_REG = TILE && NB <= 3;
+  double G[NB], Tb[NB], Cbr[CB_REG ? NB : 1];
 #pragma unroll
   for (int I = 0; I < NB; ++I) {
     G[I] = Tb[I] = 0.0;
-    CB[I * KF_WAVE + lane] = 0.0;
+    if (CB_REG) Cbr[CB_REG ? I : 0] = 0.0;
+    else CB[I * KF_WAVE + lane] = 0.0;
   }
   double Hb = 0.0, dacc = 0.0;
 
@@ -161,7 +164,10 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     const double yv = YB[t & 63];
     const double gl = g_all + GL[t & 63];
 #pragma unroll
-    for (int I = 0; I < NB; ++I) CB[I * KF_WAVE + lane] += G[I];
+    for (int I = 0; I < NB; ++I) {
+      if (CB_REG) Cbr[CB_REG ? I : 0] += G[I];
+      else CB[I * KF_WAVE + lane] += G[I];
+    }
     double u, ut, rs, invF;   // u: what goes through the exchange (u itself, or u_hat with TILE); ut = u_hat
     bool obe;
     if (TILE) {
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   // ---- after the sweep: G = d L / d S_1.  Chain rule to (T, Z, R, Q, H, c, d), de-augmentation to (a_b, P_b) ------------------
   double cb_fin[NB];
 #pragma unroll
-  for (int I = 0; I < NB; ++I) cb_fin[I] = CB[I * KF_WAVE + lane];
+  for (int I = 0; I < NB; ++I) cb_fin[I] = CB_REG ? Cbr[CB_REG ? I : 0] : CB[I * KF_WAVE + lane];
   wave_lds_fence();
   double* EB = smem;             // T_e adjoint (2 T_b), N4 x N4 row-major
   double* EC = EB + N4 * N4;     // C_e adjoint
