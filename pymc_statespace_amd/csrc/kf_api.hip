@@ -688,6 +688,18 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
     }
     return kf_launch_smoother_lds(h, a, (hipStream_t)stream);
   }
+  // 5 <= m <= 15: block-MFMA smoother with warm-started Newton-Schulz inverses (kf_smoother_b4.hip); KF_SMOOTHER_B4=0
+  // in the environment keeps the elimination kernel below (A/B measurements)
+  if (kf_smoother_b4_ok(a.m, a.r) && h->forward_kernel != KF_KERNEL_LDS && workspace &&
+      workspace_bytes >= kf_smoother_mfma_workspace_bytes(a.B)) {
+    // measured (scripts/r02/smooth_sweep.py, 1000 steps, ms, against the elimination kernel): 4096 draws m = 5 / 7 / 8 / 10 / 11:
+    // 2.3 / 2.5 / 4.1 / 4.8 / 5.1 against 3.8 / 4.5 / 5.3 / 6.6 / 7.1; m = 12 .. 15 (4 x 4 blocks: three wavefronts per SIMD,
+    // two rounds at 4096 draws) 9.3 - 10.3 against 7.4 - 10.3, but 3.0 - 3.2 against 3.6 - 4.6 at 512 draws and 4.0 against 7.1
+    // on the C4 shard (m = 15, 2048 draws)
+    const char* e = getenv("KF_SMOOTHER_B4");
+    const bool pick = (e && e[0]) ? e[0] != '0' : (a.m <= 11 || a.B <= 3L * 4 * (h->n_cu > 0 ? h->n_cu : 256));
+    if (pick) return kf_launch_smoother_b4(h, a, workspace, workspace_bytes, (hipStream_t)stream);
+  }
   // 5 <= m <= 16: register-tile smoother when the caller provided the (tiny) flag workspace
   // (measured: m = 10, B = 4096: 6.5 vs 17.1 ms; C4 shard m = 15: 6.1 vs 25.7 ms; m = 2 stays on the
   // LDS kernel, 3.4 ms)

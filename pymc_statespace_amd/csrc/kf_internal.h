@@ -174,6 +174,9 @@ bool kf_backward_mfma_wg_ok(int m, int p, int r);
 int kf_launch_backward_mfma_wg(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 bool kf_backward_mfma_nb_ok(int m, int p, int r);
 int kf_launch_backward_mfma_nb(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+// block-MFMA smoother, Newton-Schulz inverses (kf_smoother_b4.hip): 5 <= m <= 15
+bool kf_smoother_b4_ok(int m, int r);
+int kf_launch_smoother_b4(kf_handle* h, const KfSmoothArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream);
 // adjoint of the augmented recursion on 4x4x4 block MFMAs (kf_backward_b4.hip): p == 1, m + 2 <= 16
 bool kf_backward_b4_ok(int m, int p, int r);
 size_t kf_backward_b4_workspace_bytes(long B, int m);

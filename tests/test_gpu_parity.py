@@ -1704,6 +1704,42 @@ def test_plain_cpp_consumer_of_the_c_abi():
     assert res.returncode == 0 and "ABI_CONSUMER_OK" in res.stdout, res.stdout + res.stderr
 
 
+@pytest.mark.parametrize("m", [5, 6, 7, 8, 9, 10, 11, 12, 13, 15])
+def test_newton_schulz_block_smoother(eng, m, monkeypatch):
+    """kf_smoother_b4.hip (5 <= m <= 15): P_hat^-1 by warm-started Newton-Schulz iterations on block MFMAs, the state
+    vector carried in the tile.  Against the pinv oracle on a full-rank model, on one with a diffuse start (a cold
+    restart per step near t = 0), and -- singular P_hat: the iteration cannot settle -- through the flagged-draw
+    fallback; and against the elimination kernel it replaces."""
+    monkeypatch.setenv("KF_SMOOTHER_B4", "1")
+    w = W.random_dense(9, 120, 1, m, m, seed=60 + m)
+    for scale, tol in ((1.0, 1e-10), (1e6, 1e-7)):
+        # (x 1e6: a diffuse start -- P_hat changes by orders of magnitude over the first steps and has a condition number of
+        #  ~1e6 there: cold restarts, and a residual floor of cond x eps, which the tolerance allows for)
+        P0 = w["P0"] * scale
+        flt = kn.kalman_filter(w["y"], w["a0"], P0, w["T"], w["Z"], w["R"], w["H"], w["Q"])
+        ra, rP = kn.kalman_smoother(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
+        sa, sP = eng.smooth(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
+        scale_a, scale_P = 1.0 + np.abs(ra).max(), 1.0 + np.abs(rP).max()
+        assert np.isfinite(sP.cpu().numpy()).all()
+        assert np.abs(sa.cpu().numpy() - ra).max() / scale_a < tol
+        assert np.abs(sP.cpu().numpy() - rP).max() / scale_P < tol
+        assert np.array_equal(sa[:, -1].cpu().numpy(), flt["filtered_states"][:, -1])
+        monkeypatch.setenv("KF_SMOOTHER_B4", "0")
+        ea, eP = eng.smooth(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
+        monkeypatch.setenv("KF_SMOOTHER_B4", "1")
+        assert np.abs((sa - ea).cpu().numpy()).max() / scale_a < tol and np.abs((sP - eP).cpu().numpy()).max() / scale_P < tol
+    # singular prediction covariance (no state noise on an exactly known component): flagged, redone with the pinv
+    w0 = W.random_dense(4, 30, 1, m, 1, seed=80 + m)
+    P00 = w0["P0"].copy()
+    P00[:, 0, :] = 0.0
+    P00[:, :, 0] = 0.0
+    flt0 = kn.kalman_filter(w0["y"], w0["a0"], P00, w0["T"], w0["Z"], w0["R"], w0["H"], w0["Q"])
+    sa0, sP0 = eng.smooth(w0["T"], w0["R"], w0["Q"], flt0["filtered_states"], flt0["filtered_covs"])
+    # (values: rank decisions of a pseudo-inverse sit at rounding level in every implementation, the reference's included)
+    assert np.isfinite(sa0.cpu().numpy()).all() and np.isfinite(sP0.cpu().numpy()).all()
+    assert np.array_equal(sa0[:, -1].cpu().numpy(), flt0["filtered_states"][:, -1])
+
+
 @pytest.mark.parametrize("m", [5, 6, 7, 8, 9, 11, 12, 13, 16])
 def test_register_tile_smoother_every_tile_size(eng, m):
     """kf_smooth_mfma_kernel for every accumulator count (KS = 2, 3, 4), odd and even m x m."""
