@@ -29,12 +29,13 @@
 
 namespace {
 
-// LDS (doubles): three N4-row transpose tiles -- TA (scratch: U', A^, D, X_e in turn), TX (the inverse, kept across steps,
-// rewritten only when it changes), TU (U, parked while the inverse is iterated) -- and the compact output image
+// LDS (doubles): four N4-row transpose tiles -- TA (scratch: A^, then X_e), TX (the inverse, kept across steps, rewritten
+// only when it changes), TU (U, parked while the inverse is iterated), TD (D, written in the same pass as A^) -- and the
+// compact output image
 template <int NB>
 struct Sb4Lds {
   static constexpr int TILE_D = 4 * NB * TRS;
-  static constexpr int OFF_TX = TILE_D, OFF_TU = 2 * TILE_D, OFF_IMG = 3 * TILE_D, OFF_IMA = OFF_IMG + 240;
+  static constexpr int OFF_TX = TILE_D, OFF_TU = 2 * TILE_D, OFF_TD = 3 * TILE_D, OFF_IMG = 4 * TILE_D, OFF_IMA = OFF_IMG + 240;
   static constexpr int TOTAL = OFF_IMA + 16 + 4 * TRS;  // (+ slack: lanes of unused columns read up to 4 rows past a tile)
 };
 static_assert(Sb4Lds<3>::TOTAL <= 1280, "four wavefronts per SIMD need <= 10 KiB of LDS per wavefront");
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   double* TA = smem;
   double* TX = smem + L::OFF_TX;
   double* TU = smem + L::OFF_TU;
+  double* TD = smem + L::OFF_TD;
   double* IMG = smem + L::OFF_IMG;
   double* IMA = smem + L::OFF_IMA;
 
@@ -197,6 +199,9 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
 #pragma unroll
         for (int I = 0; I < NB; ++I) Ah[I] = mfma4(Ta[I][K], ut[K], Ah[I]);
     }
+    // D = S_s[t+1] - A goes to its tile now: it rides along with the pass that replicates A^ (no round trip of its own later)
+#pragma unroll
+    for (int I = 0; I < NB; ++I) TD[(4 * I + g) * TRS + fb] = Ps[I] - Ah[I];
     // ---- X = A^^-1, A^ = blockdiag(P_hat, s I): residual of the previous inverse, Newton-Schulz where needed -------------------------
     double Rm[NB];
     double rnorm = 0.0;
@@ -299,25 +304,19 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
         Xe[I] = acc;
       }
     }
-    {
-      double Dm[NB];
 #pragma unroll
-      for (int I = 0; I < NB; ++I) Dm[I] = Ps[I] - Ah[I];
-      to_tile(TA, Dm);
+    for (int I = 0; I < NB; ++I) {
+      const double* ls = TD + (4 * I + q) * TRS + 4 * g;
+      const double2_t d01 = *reinterpret_cast<const double2_t*>(ls);
+      double2_t d23 = {0.0, 0.0};
+      if (NB > 2) d23 = *reinterpret_cast<const double2_t*>(ls + 2);
+      const double dr[4] = {d01.x, d01.y, d23.x, d23.y};
+      double acc = 0.0;
 #pragma unroll
-      for (int I = 0; I < NB; ++I) {
-        const double* ls = TA + (4 * I + q) * TRS + 4 * g;
-        const double2_t d01 = *reinterpret_cast<const double2_t*>(ls);
-        double2_t d23 = {0.0, 0.0};
-        if (NB > 2) d23 = *reinterpret_cast<const double2_t*>(ls + 2);
-        const double dr[4] = {d01.x, d01.y, d23.x, d23.y};
-        double acc = 0.0;
-#pragma unroll
-        for (int K = 0; K < NB; ++K) acc = mfma4(dr[K], Xe[K], acc);
-        E[I] = acc;
-      }
-      wave_lds_fence();
+      for (int K = 0; K < NB; ++K) acc = mfma4(dr[K], Xe[K], acc);
+      E[I] = acc;
     }
+    wave_lds_fence();
     to_tile(TA, Xe);
 #pragma unroll
     for (int I = 0; I < NB; ++I) Ps[I] = Sf[I];
