@@ -216,7 +216,8 @@ int kf_filter_backward(kf_handle* h, const kf_dims* dims,
 /* RTS smoother over the filtered tapes: smooth_a [B][T][m], smooth_P [B][T][m][m].
  * Only dims->B, T, m, r and the KF_FLAG_TV_T / _R / _Q flags are used.  The gain uses the Moore-Penrose
  * pseudo-inverse of the one-step prediction covariance with numpy's default cutoff 1e-15 * sigma_max
- * (kalman_smoother.py:92): a Cholesky / Gauss-Jordan solve whenever that covariance is safely
+ * (kalman_smoother.py:92): a Cholesky / Gauss-Jordan solve -- for 5 <= m <= 15 a Newton-Schulz iteration warm-started
+ * from the previous step's inverse (kf_smoother_b4.hip) -- whenever that covariance is safely
  * positive definite, a Jacobi eigen-decomposition otherwise (m <= 64: given the per-draw flag
  * workspace -- without it the 47 < m <= 64 kernel returns NaN for such a draw; m > 64: flagged draws
  * are redone, the whole series, by one workgroup each).  `workspace`: see kf_workspace_bytes. */
