@@ -130,8 +130,9 @@ int kf_set_lanes_per_draw(kf_handle* h, int lanes);
 
 /* Forward-kernel selection.  AUTO (static matrices): p == 1, m <= 14 -> 4x4x4-block MFMA kernel with
  * the state vector carried in the covariance tile, one wavefront per draw ("b4": always for m >= 10;
- * for m = 7..9 and m = 4..6 while the batch cannot fill the chip with packed wavefronts, for m <= 3
- * up to 2048 draws), else one lane per draw ("lane", m <= 4) / register-resident row-owner kernels
+ * for m = 7..9 and m = 4..6 while the batch cannot fill the chip with packed wavefronts, for m = 3
+ * up to 2048 draws), else one lane per draw, 4 / 16 / 64 draws per wavefront by batch size ("lane", m <= 4: always for
+ * m <= 2) / register-resident row-owner kernels
  * ("row", m <= 9); m <= 16, p <= 8 with p == 1 / UnivariateFilter / KF_FLAG_H_DIAGONAL -> covariance
  * in the 16 x 16 MFMA accumulator layout, one wavefront per draw ("mfma": p == 1 with m = 15, 16;
  * m >= 11 for p > 1) or the multivariate row kernel ("row"); 16 < m <= 48 with the same eligibility -> covariance as 2 x 2 /
