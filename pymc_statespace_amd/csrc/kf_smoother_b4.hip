@@ -272,6 +272,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
       }
       wave_lds_fence();
       to_tile(TX, X);
+      if (rnorm <= 1e-7) break;  // quadratic convergence: the new residual is rnorm^2 (+ the rounding floor) -- not worth a product
       const double rprev = rnorm;
       residual();
       // the rounding floor of I - A^ X (~ cond(P_hat) eps) is reached: accepted up to cond ~ 1e8 -- where the elimination
