@@ -2054,23 +2054,30 @@ def test_forward_gradient_smoother_replay_from_a_hip_graph(eng, shape):
         g = eng.backward(*dev, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
                          g_logp=gl, h_diagonal=True)
         sa, sP = eng.smooth(dev[3], dev[5], dev[7], res.filtered_states, res.filtered_covs)
-        return res, g, sa, sP
+        vg = eng.value_and_grad(*dev, h_diagonal=True)  # the one-call entry point (its own tapes in the workspace)
+        return res, g, sa, sP, vg
 
     step()  # lazy initialisation (workspaces, function attributes) outside the capture
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        res_c, g_c, sa_c, sP_c = step()
+        res_c, g_c, sa_c, sP_c, vg_c = step()
     y2 = w["y"] + 0.3 * np.random.default_rng(1).standard_normal(w["y"].shape)
     dev[0].copy_(torch.as_tensor(y2, device=dev[0].device))
     graph.replay()
     torch.cuda.synchronize()
-    res_e, g_e, sa_e, sP_e = step()
+    res_e, g_e, sa_e, sP_e, vg_e = step()
     torch.cuda.synchronize()
     assert torch.equal(res_c.logp, res_e.logp) and torch.equal(res_c.predicted_covs, res_e.predicted_covs)
     for k in g_e:
         assert torch.equal(g_c[k], g_e[k]), k
     assert torch.equal(sa_c, sa_e) and torch.equal(sP_c, sP_e)
+    assert torch.equal(vg_c[0], vg_e[0])
+    for k in vg_e[2]:
+        assert torch.equal(vg_c[2][k], vg_e[2][k]), k
+        a_, b_ = vg_c[2][k].cpu().numpy(), g_e[k].cpu().numpy() if k in g_e else None
+        if b_ is not None:
+            assert np.max(np.abs(a_ - b_)) / (1.0 + np.max(np.abs(b_))) < 1e-9, k
     ref = kn.kalman_filter(y2, *_args(w)[1:])
     assert np.max(np.abs(res_c.logp.cpu().numpy() - ref["logp"])) < 1e-8
 
