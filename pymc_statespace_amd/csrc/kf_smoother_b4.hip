@@ -29,14 +29,17 @@
 
 namespace {
 
-// LDS (doubles): four N4-row transpose tiles -- TA (scratch: A^, then X_e), TX (the inverse, kept across steps, rewritten
-// only when it changes), TU (U, parked while the inverse is iterated), TD (D, written in the same pass as A^) -- and the
-// compact output image
+// LDS (doubles): five N4-row transpose tiles -- TH (A^: only its state block is rewritten per step, the padding at a cold
+// start), TA (X_e), TX (the inverse, kept across steps, rewritten only when it changes), TU (U, parked while the inverse is
+// iterated), TD (D, written in the same pass as A^) -- and the compact output image
 template <int NB>
 struct Sb4Lds {
   static constexpr int TILE_D = 4 * NB * TRS;
-  static constexpr int OFF_TX = TILE_D, OFF_TU = 2 * TILE_D, OFF_TD = 3 * TILE_D, OFF_IMG = 4 * TILE_D, OFF_IMA = OFF_IMG + 240;
-  static constexpr int TOTAL = OFF_IMA + 16 + 4 * TRS;  // (+ slack: lanes of unused columns read up to 4 rows past a tile)
+  static constexpr int IMG_D = NB <= 3 ? 128 : 240;  // m <= 11: 121 doubles; m <= 15: 225
+  static constexpr int OFF_TX = TILE_D, OFF_TU = 2 * TILE_D, OFF_TD = 3 * TILE_D, OFF_TH = 4 * TILE_D, OFF_IMG = 5 * TILE_D,
+                       OFF_IMA = OFF_IMG + IMG_D;
+  static constexpr int TOTAL = OFF_IMA + 16 + (NB <= 3 ? 0 : 4 * TRS);  // (lanes of unused columns read up to 4 rows past a tile:
+                                                                        //  into the next tile / the image, never used)
 };
 static_assert(Sb4Lds<3>::TOTAL <= 1280, "four wavefronts per SIMD need <= 10 KiB of LDS per wavefront");
 constexpr int SB4_MAXIT = 64;
@@ -57,6 +60,22 @@ __device__ __forceinline__ double wave_allmax_dpp(double x) {
   auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
   return fmax(__hiloint2double(d[0], c[0]), __hiloint2double(d[1], c[1]));
 }
+// The same for a convergence test, on the HIGH DWORDS of |x| only: sign cleared, the exponent and 20 mantissa bits of a
+// double order like unsigned integers -- a norm to 1e-6 relative is all a threshold needs -- so each level is one
+// v_max_u32 (DPP folded in) instead of two moves and a canonicalising v_max_f64, and Inf / NaN come out as the largest
+// values (no separate NaN test).  Returns a wave-uniform lower bound of max |x| within 2^-20.
+__device__ __forceinline__ unsigned abs_hi(double x) { return (unsigned)__double2hiint(x) & 0x7fffffffu; }
+__device__ __forceinline__ double wave_absmax_hi(unsigned h) {
+  h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x128, 0xf, 0xf, false));
+  h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x124, 0xf, 0xf, false));
+  h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x122, 0xf, 0xf, false));
+  h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x121, 0xf, 0xf, false));
+  auto a = __builtin_amdgcn_permlane16_swap((int)h, (int)h, false, false);
+  h = max((unsigned)a[0], (unsigned)a[1]);
+  auto c = __builtin_amdgcn_permlane32_swap((int)h, (int)h, false, false);
+  h = max((unsigned)c[0], (unsigned)c[1]);
+  return __hiloint2double(__builtin_amdgcn_readfirstlane((int)h), 0);
+}
 __device__ __forceinline__ double uniform_f64(double x) {  // lane 0's value as a wave-uniform scalar
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
@@ -76,6 +95,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   double* TX = smem + L::OFF_TX;
   double* TU = smem + L::OFF_TU;
   double* TD = smem + L::OFF_TD;
+  double* TH = smem + L::OFF_TH;
   double* IMG = smem + L::OFF_IMG;
   double* IMA = smem + L::OFF_IMA;
 
@@ -115,7 +135,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     if (on) { src[I] = gfP + rr * m + bq; stp[I] = mm; on_tp[I] = true; }
     else if (rr < m && bq == JC) { src[I] = gfa + rr; stp[I] = m; on_tp[I] = true; }
     else if (rr == JC && bq < m) { src[I] = gfa + bq; stp[I] = m; on_tp[I] = true; }
-    else { src[I] = gfa; stp[I] = 0; on_tp[I] = false; }
+    else { src[I] = gfa; stp[I] = 0; on_tp[I] = false; }  // (a finite value: such tile entries never reach an output, see below)
     src[I] += (long)(n - 1) * stp[I];
   }
   const bool on_jc = g == 3 && bq == JC;  // tile entry (JC, JC): DPP row 3 of the last register
@@ -175,7 +195,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   for (int t = n - 2; t >= 0 && !bad; --t) {
     double Sf[NB];
 #pragma unroll
-    for (int I = 0; I < NB; ++I) Sf[I] = on_tp[I] ? PN[I] : 0.0;
+    for (int I = 0; I < NB; ++I) Sf[I] = PN[I];  // (entries outside the tape image stay confined to unused rows / columns and (JC, JC))
     // ---- U = T_e S_f (parked in TU) ;  A = T_e U' + C_e ----------------------------------------------------------------------------
     double Ah[NB];
     {
@@ -205,17 +225,17 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     // ---- X = A^^-1, A^ = blockdiag(P_hat, s I): residual of the previous inverse, Newton-Schulz where needed -------------------------
     double Rm[NB];
     double rnorm = 0.0;
-    auto a_hat_tile = [&]() {  // A^ -> TA
-      double Ahat[NB];
+    auto a_hat_tile = [&]() {  // the state block of A^ -> TH (its padding is written at a cold start, the rest stays zero)
 #pragma unroll
-      for (int I = 0; I < NB; ++I) Ahat[I] = on_mm[I] ? Ah[I] : (on_dg[I] ? s_pad : 0.0);
-      to_tile(TA, Ahat);
+      for (int I = 0; I < NB; ++I)
+        if (on_mm[I]) TH[(4 * I + g) * TRS + fb] = Ah[I];
+      wave_lds_fence();
     };
     auto residual = [&]() {  // R = I - A^ X (A^ as a left factor from TA, block row by block row); rnorm = max |R|
-      double mx = 0.0, chk = 0.0;
+      unsigned mx = 0u;
 #pragma unroll
       for (int I = 0; I < NB; ++I) {
-        const double* ls = TA + (4 * I + q) * TRS + 4 * g;
+        const double* ls = TH + (4 * I + q) * TRS + 4 * g;
         const double2_t d01 = *reinterpret_cast<const double2_t*>(ls);
         double2_t d23 = {0.0, 0.0};
         if (NB > 2) d23 = *reinterpret_cast<const double2_t*>(ls + 2);
@@ -224,11 +244,9 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
 #pragma unroll
         for (int K = 0; K < NB; ++K) rr_ = mfma4_nega(ar[K], X[K], rr_);
         Rm[I] = rr_;
-        mx = fmax(mx, fabs(rr_));
-        chk += rr_;
+        mx = max(mx, abs_hi(rr_));
       }
-      rnorm = uniform_f64(wave_allmax_dpp(mx));
-      if (__any(chk != chk)) rnorm = __builtin_nan("");  // (fmax drops NaNs: a diverged iteration must not look converged)
+      rnorm = wave_absmax_hi(mx);  // (a NaN / Inf entry comes out as NaN / Inf: a diverged iteration cannot look converged)
     };
     auto rnorm_inf = [&]() {  // max absolute row sum of R: < 1 guarantees convergence (max |R_ij| does not)
       double rs_ = 0.0;
@@ -251,6 +269,9 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
       const double n1 = uniform_f64(wave_allmax_dpp(rs_));
       if (!(n1 > 0.0) || !(n1 < 1e300)) bad = true;
       s_pad = n1;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+        if (on_dg[I]) TH[(4 * I + g) * TRS + fb] = s_pad;
       a_hat_tile();
       const double inv1 = 1.0 / n1;
 #pragma unroll
