@@ -196,11 +196,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     }
     if (g == 0) UX[fb] = u;
     // ---- Y = T_e' G ------------------------------------------------------------------------------------------------------
-    double Y[NB];
+    double Y[NB];  // (the first product of each chain takes the literal 0 as its C operand: an inline constant, no v_mov)
 #pragma unroll
-    for (int I = 0; I < NB; ++I) Y[I] = 0.0;
+    for (int I = 0; I < NB; ++I) Y[I] = mfma4(TtA[I][0], G[0], 0.0);
 #pragma unroll
-    for (int K = 0; K < NB; ++K)
+    for (int K = 1; K < NB; ++K)
 #pragma unroll
       for (int I = 0; I < NB; ++I) Y[I] = mfma4(TtA[I][K], G[K], Y[I]);
 #pragma unroll
@@ -235,8 +235,6 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     // ---- G_f = T_e' Y' ;  T_b += Y' S_f   (left factor (Y')(I, K): lane (g = k, any b, q = i) holds Y[4K+g][4I+q]) -------------------
     double Gf[NB];
 #pragma unroll
-    for (int I = 0; I < NB; ++I) Gf[I] = 0.0;
-#pragma unroll
     for (int K = 0; K < NB; ++K) {
       const double* ls = TR + (4 * K + g) * TRS + 4 * q;
       const double2_t d01 = *reinterpret_cast<const double2_t*>(ls);
@@ -245,17 +243,17 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
       const double LK[4] = {d01.x, d01.y, d23.x, d23.y};
 #pragma unroll
       for (int I = 0; I < NB; ++I) {
-        Gf[I] = mfma4(TtA[I][K], Yt[K], Gf[I]);
+        Gf[I] = mfma4(TtA[I][K], Yt[K], K == 0 ? 0.0 : Gf[I]);
         Tb[I] = mfma4(LK[I], Sf[K], Tb[I]);
       }
     }
     wave_lds_fence();
     if (t > 1) prefetch();
     // ---- g = -2 G_f ut - (gl / 4) ut_C e_C (row-0 layout) -------------------------------------------------------------------------
-    double gv = 0.0;
     const double m2rs = TILE ? -2.0 : -2.0 * rs;  // (TILE: u_hat itself went through the exchange)
+    double gv = mfma4(urow[0] * m2rs, Gf[0], 0.0);
 #pragma unroll
-    for (int K = 0; K < NB; ++K) gv = mfma4(urow[K] * m2rs, Gf[K], gv);
+    for (int K = 1; K < NB; ++K) gv = mfma4(urow[K] * m2rs, Gf[K], gv);
     const double utC = readlane_f64(ut, JC);
     const double gut = fma(selC, obe ? -0.25 * gl * utC : 0.0, gv);
     // rs_b rs = (g . u) rs = g . u_hat

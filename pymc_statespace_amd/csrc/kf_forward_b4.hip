@@ -360,11 +360,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       else stage_cov(P);  // flushed below, behind the MFMAs
     }
     // ---- predict: tile <- sym(T_ext tile T_ext' + C_ext) ---------------------------------------------------------------------
-    double U[NB], Y[NB];
+    double U[NB], Y[NB];  // (first product of each chain: the literal 0 as C operand is an inline constant -- no v_mov per step)
 #pragma unroll
-    for (int I = 0; I < NB; ++I) U[I] = 0.0;
+    for (int I = 0; I < NB; ++I) U[I] = mfma4(Ta[I][0], P[0], 0.0);
 #pragma unroll
-    for (int K = 0; K < NB; ++K)
+    for (int K = 1; K < NB; ++K)
 #pragma unroll
       for (int I = 0; I < NB; ++I) U[I] = mfma4(Ta[I][K], P[K], U[I]);
     if (!STREAM && w_fP) {

@@ -199,11 +199,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     // ---- U = T_e S_f (parked in TU) ;  A = T_e U' + C_e ----------------------------------------------------------------------------
     double Ah[NB];
     {
-      double U[NB];
+      double U[NB];  // (first product of each chain: the literal 0 as C operand is an inline constant)
 #pragma unroll
-      for (int I = 0; I < NB; ++I) U[I] = 0.0;
+      for (int I = 0; I < NB; ++I) U[I] = mfma4(Ta[I][0], Sf[0], 0.0);
 #pragma unroll
-      for (int K = 0; K < NB; ++K)
+      for (int K = 1; K < NB; ++K)
 #pragma unroll
         for (int I = 0; I < NB; ++I) U[I] = mfma4(Ta[I][K], Sf[K], U[I]);
       to_tile(TU, U);
@@ -320,9 +320,9 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
         double2_t d23 = {0.0, 0.0};
         if (NB > 2) d23 = *reinterpret_cast<const double2_t*>(ls + 2);
         const double xr[4] = {d01.x, d01.y, d23.x, d23.y};
-        double acc = 0.0;
+        double acc = mfma4(xr[0], uh[0], 0.0);
 #pragma unroll
-        for (int K = 0; K < NB; ++K) acc = mfma4(xr[K], uh[K], acc);
+        for (int K = 1; K < NB; ++K) acc = mfma4(xr[K], uh[K], acc);
         Xe[I] = acc;
       }
     }
@@ -333,9 +333,9 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
       double2_t d23 = {0.0, 0.0};
       if (NB > 2) d23 = *reinterpret_cast<const double2_t*>(ls + 2);
       const double dr[4] = {d01.x, d01.y, d23.x, d23.y};
-      double acc = 0.0;
+      double acc = mfma4(dr[0], Xe[0], 0.0);
 #pragma unroll
-      for (int K = 0; K < NB; ++K) acc = mfma4(dr[K], Xe[K], acc);
+      for (int K = 1; K < NB; ++K) acc = mfma4(dr[K], Xe[K], acc);
       E[I] = acc;
     }
     wave_lds_fence();
