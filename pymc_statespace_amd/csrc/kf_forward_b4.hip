@@ -126,8 +126,12 @@ struct TapeStream {
   }
 };
 
-// STREAM: covariance tapes through TapeStream rings (m <= 10), else one compact image per step
-template <int NB, bool STREAM>
+// STREAM: covariance tapes through TapeStream rings (m <= 10), else one compact image per step.
+// TM: which tapes are written, known at compile time -- bit 0 filtered states, 1 predicted states, 2 filtered covariances,
+// 3 predicted covariances, 4 the internal tile tape; TM < 0: decided at run time (the uncommon combinations).  Measured
+// (SQ counters, profiles/r02/ops_headline_sq_counters.txt): at four wavefronts per SIMD a wavefront's step costs ~4 cycles
+// per instruction of ANY kind; the run-time tape switches alone were a dozen scalar instructions per step.
+template <int NB, bool STREAM, int TM>
 __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) void kf_fwd_b4_kernel(const KfFwdArgs A) {
   // (waves_per_eu(4): <= 128 registers, and the compiler then keeps MFMA results in VGPRs -- no v_accvgpr moves)
   constexpr int N4 = 4 * NB, JA = N4 - 2, JC = N4 - 1;
@@ -180,7 +184,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   double* t_pa = A.pred_a ? A.pred_a + b * (long)(n + 1) * m : nullptr;
   double* t_fP = A.filt_P ? A.filt_P + b * (long)n * mm : nullptr;
   double* t_pP = A.pred_P ? A.pred_P + b * (long)(n + 1) * mm : nullptr;
-  const bool w_fa = t_fa != nullptr, w_pa = t_pa != nullptr, w_fP = t_fP != nullptr, w_pP = t_pP != nullptr;
+  const bool w_fa = TM < 0 ? t_fa != nullptr : (TM & 1) != 0, w_pa = TM < 0 ? t_pa != nullptr : (TM & 2) != 0,
+             w_fP = TM < 0 ? t_fP != nullptr : (TM & 4) != 0, w_pP = TM < 0 ? t_pP != nullptr : (TM & 8) != 0;
 
   // state tapes: row JC of the tile (2 a') appended to a ring, scaled by 1/2 on the way out
   TapeStream<RING_A, GRAN_A> s_fa, s_pa;
@@ -242,7 +247,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   // T + 1 slots of N4 x N4 doubles, row-major, stored straight from the registers (no staging).  Slot t < T = what the
   // adjoint of step t needs: the FILTERED tile, its row JA (never used there) replaced by u_hat with 1 / sqrt(F) at
   // [JA][JA] (0 on a missing / skipped step); slot T = the predicted tile of step 1 (the de-augmentation at the hand-over)
-  double* t_tile = A.tile_tape ? A.tile_tape + b * (long)(n + 1) * (N4 * N4) + g * N4 + bq : nullptr;
+  const bool w_tile = TM < 0 ? A.tile_tape != nullptr : (TM & 16) != 0;
+  double* t_tile = w_tile ? A.tile_tape + b * (long)(n + 1) * (N4 * N4) + g * N4 + bq : nullptr;
   auto put_tile = [&](double* dst, const double (&X)[NB], double last) {
     if (bq < N4) {
 #pragma unroll
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     // tile -= u_hat u_hat'
 #pragma unroll
     for (int I = 0; I < NB; ++I) P[I] = mfma4_nega(urep[I] * rs, uh, P[I]);
-    if (t_tile) {
+    if (w_tile) {
       const double rs_t = (univariate && F == 0.0) ? 0.0 : rs;  // a skipped step has no adjoint terms (:468-471)
       const double rowv = low_half_everywhere((lane == JA) ? rs_t : uh);  // DPP row 0 -> row 2 (= row JA of the last register)
       put_tile(t_tile + (long)t * (N4 * N4), P, (g == (JA & 3)) ? rowv : P[NB - 1]);
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
 #pragma unroll
       for (int I = 0; I < NB; ++I) P[I] = HALF_STATIC ? Y[I] + Yt[I] : 0.5 * (Y[I] + Yt[I]);
     }
-    if (t_tile && t == 0) put_tile(t_tile + (long)n * (N4 * N4), P, P[NB - 1]);
+    if (w_tile && t == 0) put_tile(t_tile + (long)n * (N4 * N4), P, P[NB - 1]);
     if (w_pa) put_a(s_pa, o_pa, P[NB - 1]);
     if (w_pP) {
       if (STREAM) {
@@ -425,14 +431,24 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
   const int lds_setup = b4_setup_doubles(a.m, a.r);
   const size_t lds = sizeof(double) * (size_t)(B4_LOOP_DOUBLES > lds_setup ? B4_LOOP_DOUBLES : lds_setup);
   const int nb = (a.m + 2 + 3) / 4;
-#define KF_B4_LAUNCH(NB_, ST_) \
-  hipLaunchKernelGGL((kf_fwd_b4_kernel<NB_, ST_>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a)
+  const int mask = (a.filt_a ? 1 : 0) | (a.pred_a ? 2 : 0) | (a.filt_P ? 4 : 0) | (a.pred_P ? 8 : 0) | (a.tile_tape ? 16 : 0);
+#define KF_B4_LAUNCH2(NB_, ST_, TM_) \
+  hipLaunchKernelGGL((kf_fwd_b4_kernel<NB_, ST_, TM_>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a)
+#define KF_B4_LAUNCH(NB_, ST_)                           \
+  do {                                                   \
+    if (mask == 15) KF_B4_LAUNCH2(NB_, ST_, 15);         \
+    else if (mask == 0) KF_B4_LAUNCH2(NB_, ST_, 0);      \
+    else if (mask == 10) KF_B4_LAUNCH2(NB_, ST_, 10);    \
+    else if (mask == 16) KF_B4_LAUNCH2(NB_, ST_, 16);    \
+    else KF_B4_LAUNCH2(NB_, ST_, -1);                    \
+  } while (0)
   switch (nb) {
     case 1: KF_B4_LAUNCH(1, true); break;
     case 2: KF_B4_LAUNCH(2, true); break;
     case 3: KF_B4_LAUNCH(3, true); break;
     default: KF_B4_LAUNCH(4, false); break;  // m = 11 would fit the rings, but measured 2.48 vs 2.40 ms
   }
+#undef KF_B4_LAUNCH2
 #undef KF_B4_LAUNCH
   KF_HIP_CHECK(h, hipGetLastError());
   return KF_OK;
