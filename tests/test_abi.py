@@ -91,3 +91,35 @@ def test_filter_factory_keys_match_reference():
     assert set(FILTER_FACTORY) == {"standard", "univariate", "single", "cholesky", "steady_state"}
     for cls in FILTER_FACTORY.values():
         assert hasattr(cls, "build_graph") and callable(cls)
+
+
+def test_op_layer_detects_time_varying_inputs_by_shape():
+    """op._lead_system: a system matrix with one more axis than its static form is time-varying (reference
+    filters/utilities.py:1-20); c / d are (m,1) columns when static and (n,m,1) when time-varying."""
+    import numpy as np
+
+    from pymc_statespace_amd import op
+
+    n, m, p, r = 7, 3, 2, 2
+    T, Z, R, H, Q = np.eye(m), np.ones((p, m)), np.ones((m, r)), np.eye(p), np.eye(r)
+    c, d = np.zeros((m, 1)), np.zeros((p, 1))
+    arrs, tv = op._lead_system(T, Z, R, H, Q, c, d)
+    assert tv == () and [a.shape for a in arrs] == [(1, m, m), (1, p, m), (1, m, r), (1, p, p), (1, r, r), (1, m), (1, p)]
+    Tt, Qt, ct = np.repeat(T[None], n, 0), np.repeat(Q[None], n, 0), np.zeros((n, m, 1))
+    arrs, tv = op._lead_system(Tt, Z, R, H, Qt, ct, d)
+    assert tv == ("T", "Q", "c")
+    assert arrs[0].shape == (1, n, m, m) and arrs[4].shape == (1, n, r, r) and arrs[5].shape == (1, n, m) and arrs[6].shape == (1, p)
+
+
+def test_steady_state_filter_has_a_symbolic_entry_and_a_gradient():
+    """f4: SteadyStateFilter.build_graph exists again (PyTensor needed to call it) and the eager value-and-gradient is there."""
+    from pymc_statespace_amd import filters
+
+    assert callable(filters.SteadyStateFilter.build_graph) and callable(filters.SteadyStateFilter.logp_and_grad)
+    with pytest.raises(ImportError):
+        try:
+            import pytensor  # noqa: F401
+        except ImportError:
+            filters.SteadyStateFilter(engine=object()).build_graph(None, None, None, None, None, None, None, None)
+        else:
+            raise ImportError("pytensor present: nothing to check here")

@@ -85,3 +85,26 @@ def test_autograd_matches_finite_difference():
         Tm[0, i, j] -= h
         fd = (f(Tp) - f(Tm)) / (2 * h)
         assert_allclose(g["T"][0, i, j], fd, rtol=1e-5, atol=1e-6)
+
+
+def test_time_varying_oracle_reduces_to_the_static_one():
+    """kalman_torch with time_varying: matrices repeated along time give the static log-likelihood, and their gradient
+    tapes sum to the static gradients (the oracle of tests/test_gpu_parity.py::test_time_varying_gradient_*)."""
+    import numpy as np
+
+    import workloads as W
+    from oracle import kalman_torch as kt
+
+    B, n, p, m, r = 2, 9, 2, 3, 2
+    w = W.random_dense(B, n, p, m, r, seed=5)
+    a = (w["y"], w["a0"], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"])
+    l0, _, g0 = kt.logp_and_grads(*a)
+    rep = lambda x: np.repeat(x[:, None], n, axis=1)  # noqa: E731
+    l1, _, g1 = kt.logp_and_grads(w["y"], w["a0"], w["P0"], rep(w["T"]), rep(w["Z"]), w["R"], rep(w["H"]), w["Q"],
+                                  time_varying=("T", "Z", "H"))
+    assert np.allclose(l0, l1, rtol=1e-13)
+    for k in ("T", "Z", "H"):
+        assert g1[k].shape == (B, n) + g0[k].shape[1:]
+        assert np.allclose(g1[k].sum(1), g0[k], rtol=1e-10, atol=1e-12)
+    for k in ("a0", "P0", "R", "Q"):
+        assert np.allclose(g1[k], g0[k], rtol=1e-10, atol=1e-12)
