@@ -213,9 +213,9 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
       if (NB > 2) c23 = *reinterpret_cast<const double2_t*>(ys + 2);
       const double ut[4] = {c01.x, c01.y, c23.x, c23.y};
 #pragma unroll
-      for (int I = 0; I < NB; ++I) Ah[I] = Ce[I];
+      for (int I = 0; I < NB; ++I) Ah[I] = mfma4(Ta[I][0], ut[0], Ce[I]);  // (C operand = C_e itself: no copy into the accumulator)
 #pragma unroll
-      for (int K = 0; K < NB; ++K)
+      for (int K = 1; K < NB; ++K)
 #pragma unroll
         for (int I = 0; I < NB; ++I) Ah[I] = mfma4(Ta[I][K], ut[K], Ah[I]);
     }
@@ -341,8 +341,6 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     wave_lds_fence();
     to_tile(TA, Xe);
 #pragma unroll
-    for (int I = 0; I < NB; ++I) Ps[I] = Sf[I];
-#pragma unroll
     for (int K = 0; K < NB; ++K) {  // left factor (X_e')(I, K): lane (g = k, any b, q = i) holds X_e[4K+g][4I+q]
       const double* ls = TA + (4 * K + g) * TRS + 4 * q;
       const double2_t d01 = *reinterpret_cast<const double2_t*>(ls);
@@ -350,7 +348,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
       if (NB > 2) d23 = *reinterpret_cast<const double2_t*>(ls + 2);
       const double LK[4] = {d01.x, d01.y, d23.x, d23.y};
 #pragma unroll
-      for (int I = 0; I < NB; ++I) Ps[I] = mfma4(LK[I], E[K], Ps[I]);
+      for (int I = 0; I < NB; ++I) Ps[I] = mfma4(LK[I], E[K], K == 0 ? Sf[I] : Ps[I]);  // (S_f as the first C operand)
     }
     wave_lds_fence();
     store_moments(t, Ps);
