@@ -168,6 +168,7 @@ def parse_args():
                     help="draws per GPU (weak) / in total (strong); default: the workload's B")
     ap.add_argument("--logp-only", action="store_true", help="skip the tapes (what NUTS consumes)")
     ap.add_argument("--cpu-sample", type=int, default=None)
+    ap.add_argument("--no-ops", action="store_true", help="skip the untimed extras (logp only, logp + gradient, smoother)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-strong-probe", action="store_true",
                     help="N > 1, weak: skip the extra strong-scaling measurement")
@@ -380,6 +381,31 @@ def main():
             }
         if strong_obj is not None:
             out["strong_scaling"] = strong_obj
+        if world == 1 and not big and not args.no_ops:
+            # the other entry points on the same resident inputs, AFTER and outside the timed region (not part of `value`):
+            # log-likelihood only, logp + gradient in one call (kf_filter_value_and_grad), RTS smoother over the filtered tapes
+            def _ms(fn, reps=5):
+                fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / reps * 1e3
+            ops = {}
+            try:
+                lo_res = eng.forward(*d, filter_type=ft, mvn_const="exact", store_ll_obs=False, store_filtered=False,
+                                     store_predicted=False)
+                ops["logp_only_ms"] = _ms(lambda: eng.forward(*d, filter_type=ft, mvn_const="exact", store_ll_obs=False,
+                                                              store_filtered=False, store_predicted=False, out=lo_res))
+                ops["logp_and_gradient_one_call_ms"] = _ms(lambda: eng.value_and_grad(*d, filter_type=ft, mvn_const="exact",
+                                                                                      h_diagonal=True))
+                if full:
+                    ops["rts_smoother_ms"] = _ms(lambda: eng.smooth(d[3], d[5], d[7], res.filtered_states,
+                                                                     res.filtered_covs), reps=3)
+            except Exception as e:  # noqa: BLE001 -- an extra must never break the contract line
+                ops["error"] = str(e)[:200]
+            out["other_entry_points"] = ops
         if not args.no_cpu:
             # bounded sample (~12 s of host work); doubles as the in-bench parity check of the
             # GATHERED log-likelihoods (rank 0's own draws lead the gathered vector)
