@@ -155,6 +155,23 @@ static bool kf_b4_selected(const kf_handle* h, int m, int p, int r, long B) {
   return h->forward_kernel == KF_KERNEL_AUTO && kf_b4_auto(h, m, B);
 }
 
+// p > 1 scalar observations (the Univariate filter, or a diagonal H) on the block tiles: kf_forward_b4q.hip.
+// Measured (scripts/r02/b4q_sweep.py, 500 steps, full tapes ; logp only, ms) against what AUTO picked before:
+//   (p, m) = (5, 15)  512 / 4096 / 16384 draws: 1.04 ; 0.81 / 2.69 ; 2.25 / 10.0 ; 7.9 against 1.44 ; 1.25 / 3.19 ; 2.60 / 11.2 ; 9.1 (16 x 16 tile)
+//   (8, 12): 1.37 ; 1.16 / 3.33 ; 3.08 / 12.0 ; 11.4 against 1.98 ; 1.83 / 5.19 ; 4.65 / 15.6 ; 14.8      (2, 11): 1.3x at every batch
+//   (5, 10): 0.95 ; 0.80 / 1.97 ; 1.80 / 7.27 ; 6.59 against 1.75 ; 1.63 / 2.68 ; 2.31 / 8.72 ; 7.49 (multivariate row kernel)
+//   m <= 8: 1.3 - 2.0x at 512 draws, a tie at 4096, 0.35 - 0.85x at 16384 (the row kernel packs 64 / m draws per wavefront)
+// KF_FORWARD_B4Q=0 / 1 in the environment forces the choice (A/B measurements)
+static bool kf_b4q_selected(const kf_handle* h, int m, int p, int r, int filter, unsigned flags, long B) {
+  if (!kf_forward_b4q_ok(m, p, r) || (flags & KF_FLAG_TV_ANY)) return false;
+  if (!(filter == KF_FILTER_UNIVARIATE || (flags & KF_FLAG_H_DIAGONAL))) return false;
+  if (h->forward_kernel == KF_KERNEL_B4) return true;
+  if (h->forward_kernel != KF_KERNEL_AUTO) return false;
+  const char* e = getenv("KF_FORWARD_B4Q");
+  if (e && *e) return atoi(e) != 0;
+  return m >= 9 || B <= 2L * 4 * h->n_cu;
+}
+
 // KF_BACKWARD_B4=0 / 1 in the environment forces the choice (A/B measurements)
 static bool kf_backward_b4_selected(const kf_handle* h, int m, int p, int r, long B) {
   if (!kf_backward_b4_ok(m, p, r)) return false;
@@ -233,6 +250,7 @@ extern "C" const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_di
   const bool row_ok = d->p == 1 && d->m <= KF_ROW_M_MAX;
   if (d->flags & KF_FLAG_TV_ANY) return "kf_fwd_lds_kernel";
   if (kf_b4_selected(h, d->m, d->p, d->r, d->B)) return "kf_fwd_b4_kernel";
+  if (kf_b4q_selected(h, d->m, d->p, d->r, d->filter, d->flags, d->B)) return "kf_fwd_b4q_kernel";
   if (kf_nb_ok(h, d->m, d->p, d->r, d->filter, d->flags)) return "kf_fwd_mfma_nb_kernel";
   if (kf_wg_ok(h, d->m, d->p, d->r, d->filter, d->flags)) return "kf_fwd_mfma_wg_kernel";
   // (48 < m that still fits LDS: the workspace path is 5x faster, kf_launch_forward takes it when
@@ -269,6 +287,7 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t 
     return kf_launch_forward_lds(h, a, stream);
   }
   if (kf_b4_selected(h, a.m, a.p, a.r, a.B)) return kf_launch_forward_b4(h, a, stream);
+  if (kf_b4q_selected(h, a.m, a.p, a.r, a.filter, a.flags, a.B)) return kf_launch_forward_b4q(h, a, stream);
   if (h->forward_kernel == KF_KERNEL_B4) {
     KF_SET_ERR(h, "forward(b4): needs p == 1, m <= 14, static matrices (got p=%d m=%d)", a.p, a.m);
     return KF_ERR_UNSUPPORTED;

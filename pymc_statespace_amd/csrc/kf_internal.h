@@ -161,6 +161,9 @@ int kf_launch_forward_mfma(kf_handle* h, const KfFwdArgs& a, hipStream_t stream)
 // 4x4x4-block kernel (kf_forward_b4.hip): v_mfma_f64_4x4x4_4b_f64, p == 1, m <= 14, mean carried in the tile
 bool kf_forward_b4_ok(int m, int p, int r);
 int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+// several scalar observations per step on the same 4x4x4 block tiles (kf_forward_b4q.hip)
+bool kf_forward_b4q_ok(int m, int p, int r);
+int kf_launch_forward_b4q(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 // block-tile variant (kf_forward_mfma_nb.hip): 16 < m <= 48 as 2 x 2 / 3 x 3 blocks of 16 x 16
 #define KF_NB_M_MAX 48
 bool kf_forward_mfma_nb_ok(int m, int p, int r);

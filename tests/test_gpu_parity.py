@@ -1301,7 +1301,8 @@ def test_multivariate_row_kernel_needs_diagonal_h(eng):
     """Joint filters with a dense H stay on the LDS kernel (auto) / are refused (forced row)."""
     w = W.random_dense(5, 20, 3, 8, 3, seed=5, h_diag=False)
     assert eng.forward_kernel_name(5, 20, 3, 8, 3, "standard", False) == "kf_fwd_lds_kernel"
-    assert eng.forward_kernel_name(5, 20, 3, 8, 3, "univariate", False) == "kf_fwd_rowsplit_mp_kernel"
+    assert eng.forward_kernel_name(5, 20, 3, 8, 3, "univariate", False) == "kf_fwd_b4q_kernel"
+    assert eng.forward_kernel_name(16384, 20, 3, 8, 3, "univariate", False) == "kf_fwd_rowsplit_mp_kernel"
     out = _np(eng.forward(*_args(w)))  # auto-detects the dense H
     ref = kn.kalman_filter(*_args(w))
     assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8
@@ -1317,9 +1318,13 @@ def test_multivariate_row_kernel_per_draw_data_and_partial_outputs(eng):
     w = W.varmax(B=37, n=130, k=3, order=(1, 1))
     rng = np.random.default_rng(3)
     yb = w["y"][None] + 0.1 * rng.standard_normal((37,) + w["y"].shape)
-    name = eng.forward_kernel_name(37, 130, w["p"], w["m"], w["r"], "standard", True)
-    assert name == "kf_fwd_rowsplit_mp_kernel"
-    res = eng.forward(*_args(w, yb), store_filtered=False, store_ll_obs=False)
+    eng.set_forward_kernel("row")
+    try:
+        name = eng.forward_kernel_name(37, 130, w["p"], w["m"], w["r"], "standard", True)
+        assert name == "kf_fwd_rowsplit_mp_kernel"
+        res = eng.forward(*_args(w, yb), store_filtered=False, store_ll_obs=False)
+    finally:
+        eng.set_forward_kernel("auto")
     assert res.filtered_covs is None and res.ll_obs is None
     ref = kn.kalman_filter(*_args(w, yb))
     assert np.max(np.abs(res.logp.cpu().numpy() - ref["logp"])) < 1e-8
@@ -1445,10 +1450,14 @@ def test_auto_kernel_selection(eng):
     assert name(4096, 1000, 1, 64, 5) == "kf_fwd_mfma_wg_kernel"
     assert name(4096, 1000, 3, 60, 5, "standard", False) == "big_gemm_kernel"      # dense H
     assert name(4096, 1000, 1, 65, 5) == "big_gemm_kernel"
-    assert name(16384, 1000, 5, 15, 5, "standard", True) == "kf_fwd_mfma_kernel"   # C4
-    assert name(16384, 1000, 5, 10, 5, "standard", True) == "kf_fwd_rowsplit_mp_kernel"
+    assert name(16384, 1000, 5, 15, 5, "standard", True) == "kf_fwd_b4q_kernel"    # C4
+    assert name(16384, 1000, 5, 10, 5, "standard", True) == "kf_fwd_b4q_kernel"
     assert name(16384, 1000, 5, 15, 5, "standard", False) == "kf_fwd_lds_kernel"   # dense H
-    assert name(16384, 1000, 5, 15, 5, "univariate", False) == "kf_fwd_mfma_kernel"
+    assert name(16384, 1000, 5, 15, 5, "univariate", False) == "kf_fwd_b4q_kernel"
+    assert name(16384, 1000, 3, 8, 3, "standard", True) == "kf_fwd_rowsplit_mp_kernel"  # m <= 8: packed rows once the batch fills the chip
+    assert name(1024, 1000, 3, 8, 3, "standard", True) == "kf_fwd_b4q_kernel"
+    assert name(4096, 1000, 2, 16, 3, "standard", True) == "kf_fwd_mfma_kernel"    # m + 1 > 16
+    assert name(4096, 1000, 9, 12, 3, "standard", True) == "kf_fwd_lds_kernel"     # p > 8
     assert name(128, 1000, 1, 367, 3) == "big_gemm_kernel"          # C5
 
 
@@ -1553,6 +1562,151 @@ def test_b4_kernel_per_draw_data_not_pd_and_univariate_skip(eng):
         assert rs.info.cpu().numpy()[0] == ((0 + 1) << 8 | 1)
     finally:
         eng.set_forward_kernel("auto")
+
+
+# ----------------------------------------------------------------------------------------------
+# multi-observation block kernel (kf_forward_b4q.hip): p scalar observations per step on the 4x4x4 block tiles
+# ----------------------------------------------------------------------------------------------
+B4Q_SHAPES = [(5, 15, 5), (5, 10, 5), (2, 15, 3), (3, 13, 4), (8, 12, 6), (4, 7, 3), (3, 3, 2), (2, 1, 1), (2, 11, 4), (6, 2, 2)]
+
+
+@pytest.mark.parametrize("pmr", B4Q_SHAPES, ids=[f"p{p}m{m}r{r}" for p, m, r in B4Q_SHAPES])
+@pytest.mark.parametrize("ft", ["standard", "cholesky", "univariate"])
+@pytest.mark.parametrize("mvn", ["reference", "exact"])
+def test_b4q_kernel_matches_oracle(eng, pmr, ft, mvn):
+    """Every block count, whole missing rows and single missing cells (row deletion), intercepts, both log(2 pi)
+    conventions of every filter."""
+    p, m, r = pmr
+    B = 19
+    w = W.random_dense(B, 139, p, m, r, seed=500 + 17 * p + m)
+    y = w["y"].copy()
+    y[[3, 17, 64, 138]] = np.nan
+    y[5, 0] = np.nan
+    y[70, 1:] = np.nan
+    rng = np.random.default_rng(m)
+    c = 0.1 * rng.standard_normal((B, m))
+    d = 0.1 * rng.standard_normal((B, p))
+    ref = kn.kalman_filter(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const=mvn,
+                           cholesky_triangle="correct", partial_missing="delete")
+    eng.set_forward_kernel("b4")
+    try:
+        assert eng.forward_kernel_name(B, 139, p, m, r, ft, True) == "kf_fwd_b4q_kernel"
+        out = _np(eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const=mvn))
+    finally:
+        eng.set_forward_kernel("auto")
+    assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8
+    for k in TAPES:
+        assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=k)
+    assert not out["info"].any()
+    assert np.all(out["ll_obs"][:, [3, 17, 64, 138]] == 0.0)
+    assert np.array_equal(out["predicted_covs"][:, 1:], np.swapaxes(out["predicted_covs"][:, 1:], -1, -2))
+    assert np.array_equal(out["filtered_covs"], np.swapaxes(out["filtered_covs"], -1, -2))
+
+
+@pytest.mark.parametrize("n", [2, 15, 16, 17, 33])
+def test_b4q_kernel_block_boundaries_and_partial_outputs(eng, n):
+    """Series lengths around the 16-step y block / likelihood ring; every subset of tapes; guard words around the tapes."""
+    import torch
+
+    from pymc_statespace_amd.engine import FilterResult
+
+    B, p, m = 6, 3, 11
+    w = W.random_dense(B, n, p, m, 2, seed=17 * n + m)
+    ref = kn.kalman_filter(*_args(w), mvn_const="exact")
+    eng.set_forward_kernel("b4")
+    try:
+        for sel in ((True, True, True), (False, True, False), (False, False, True), (True, False, False)):
+            r = eng.forward(*_args(w), mvn_const="exact", store_ll_obs=sel[0], store_filtered=sel[1],
+                            store_predicted=sel[2])
+            assert np.max(np.abs(r.logp.cpu().numpy() - ref["logp"])) < 1e-8
+            for k in TAPES:
+                v = getattr(r, k)
+                if v is not None:
+                    assert_allclose(v.cpu().numpy(), ref[k], rtol=1e-9, atol=1e-9, err_msg=f"{sel} {k}")
+
+        def guarded(*shape):
+            flat = torch.full((int(np.prod(shape)) + 4,), float("nan"), device="cuda", dtype=torch.float64)
+            return flat, flat[2:2 + int(np.prod(shape))].view(*shape)
+
+        bufs = {k: guarded(*s) for k, s in dict(ll_obs=(B, n), filtered_states=(B, n, m), predicted_states=(B, n + 1, m),
+                                                filtered_covs=(B, n, m, m), predicted_covs=(B, n + 1, m, m)).items()}
+        out = FilterResult(logp=torch.empty(B, device="cuda", dtype=torch.float64),
+                           info=torch.empty(B, device="cuda", dtype=torch.int32), **{k: v[1] for k, v in bufs.items()})
+        eng.forward(*_args(w), mvn_const="exact", out=out)
+        for k, (flat, view) in bufs.items():
+            assert_allclose(view.cpu().numpy(), ref[k], rtol=1e-9, atol=1e-9, err_msg=k)
+            g = flat.cpu().numpy()
+            assert np.isnan(g[:2]).all() and np.isnan(g[-2:]).all(), f"{k}: wrote outside the tape"
+    finally:
+        eng.set_forward_kernel("auto")
+
+
+def test_b4q_kernel_per_draw_data_not_pd_and_univariate_skip(eng):
+    """y per draw; a draw whose F turns non-positive reports info = (t + 1) << 8 | (q + 1) and NaN; the Univariate filter
+    skips F == 0 (:468-471) where Standard flags it; AUTO picks the kernel for the C4 shape."""
+    w = W.varmax(B=21, n=130, k=3, order=(1, 1))
+    rng = np.random.default_rng(3)
+    yb = w["y"][None] + 0.1 * rng.standard_normal((21,) + w["y"].shape)
+    H = w["H"].copy()
+    H[7, 1, 1] = -50.0
+    assert eng.forward_kernel_name(21, 130, w["p"], w["m"], w["r"], "standard", True) == "kf_fwd_b4q_kernel"
+    res = eng.forward(yb, w["a0"], w["P0"], w["T"], w["Z"], w["R"], H, w["Q"],
+                      store_filtered=False, store_ll_obs=False, h_diagonal=True)
+    assert res.filtered_covs is None and res.ll_obs is None
+    info = res.info.cpu().numpy()
+    good = np.arange(21) != 7
+    assert info[7] == ((0 + 1) << 8) | 2 and not info[good].any()
+    ref = kn.kalman_filter(yb, w["a0"], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"])
+    lp = res.logp.cpu().numpy()
+    assert np.isnan(lp[7]) and np.max(np.abs(lp[good] - ref["logp"][good])) < 1e-8
+    assert_allclose(res.predicted_covs.cpu().numpy()[good], ref["predicted_covs"][good], rtol=1e-9, atol=1e-9)
+    # exactly known state and no noise: F == 0 for every observation of every step
+    z = W.reference_test_inputs(2, 3, 1, 12)
+    P0 = np.zeros_like(z["P0"])
+    Hz, Qz = np.zeros((1, 2, 2)), np.zeros((1, 1, 1))
+    for mvn in ("reference", "exact"):
+        ru = eng.forward(z["y"], z["a0"], P0, z["T"], z["Z"], z["R"], Hz, Qz, filter_type="univariate", mvn_const=mvn)
+        rf = kn.kalman_filter(z["y"], z["a0"], P0, z["T"], z["Z"], z["R"], Hz, Qz, filter_type="univariate", mvn_const=mvn)
+        assert not ru.info.cpu().numpy().any()
+        assert_allclose(ru.logp.cpu().numpy(), rf["logp"], atol=1e-12)
+        assert_allclose(ru.filtered_states.cpu().numpy(), rf["filtered_states"], atol=1e-12)
+        assert_allclose(ru.filtered_covs.cpu().numpy(), rf["filtered_covs"], atol=1e-12)
+    rs = eng.forward(z["y"], z["a0"], P0, z["T"], z["Z"], z["R"], Hz, Qz, filter_type="standard", h_diagonal=True)
+    assert rs.info.cpu().numpy()[0] == ((0 + 1) << 8 | 1)
+
+
+def test_b4q_kernel_agrees_with_tile_kernel_at_c4_size(eng):
+    import torch
+
+    w = W.varmax(B=512, n=1000)
+    dev = [eng.to_device(x) for x in _args(w)]
+    res = {}
+    try:
+        for kern in ("mfma", "b4"):
+            eng.set_forward_kernel(kern)
+            r = eng.forward(*dev, mvn_const="exact", h_diagonal=True)
+            torch.cuda.synchronize()
+            res[kern] = (r.logp.clone(), r.predicted_covs[::64, -1].clone(), r.ll_obs[::64].clone(), r.filtered_states[::64].clone())
+    finally:
+        eng.set_forward_kernel("auto")
+    # (observations four at a time -- the default for p >= 3, m >= 8 -- against one at a time)
+    import os
+
+    os.environ["KF_B4Q_GROUP"] = "0"
+    try:
+        eng.set_forward_kernel("b4")
+        r = eng.forward(*dev, mvn_const="exact", h_diagonal=True)
+        torch.cuda.synchronize()
+        res["seq"] = (r.logp.clone(), r.predicted_covs[::64, -1].clone(), r.ll_obs[::64].clone(), r.filtered_states[::64].clone())
+    finally:
+        os.environ.pop("KF_B4Q_GROUP")
+        eng.set_forward_kernel("auto")
+    for other in ("mfma", "seq"):
+        assert (res["b4"][0] - res[other][0]).abs().max().item() < 1e-8
+        assert torch.allclose(res["b4"][1], res[other][1], rtol=1e-9, atol=1e-11)
+        assert torch.allclose(res["b4"][2], res[other][2], rtol=1e-9, atol=1e-10)
+        assert torch.allclose(res["b4"][3], res[other][3], rtol=1e-9, atol=1e-10)
+    assert not torch.equal(res["b4"][0], res["seq"][0])  # (different arithmetic: the switch did switch)
 
 
 # ----------------------------------------------------------------------------------------------
