@@ -93,7 +93,12 @@ enum {
    * models/VARMAX.py:80-83).  Standard/CholeskyFilter with p > 1 and m <= 48 may then process the
    * p observations of a step one at a time in the register-resident kernels -- algebraically
    * the same filter (results agree to rounding).  Off-diagonal entries are ignored when set. */
-  KF_FLAG_H_DIAGONAL = 1u << 11
+  KF_FLAG_H_DIAGONAL = 1u << 11,
+  /* Forward filter: never switch to the steady-state recursion.  By default the block kernels (p == 1, m <= 10, static
+   * matrices) test every 8 steps whether the predicted covariance has stopped moving (max change <= 1e-15 of its largest
+   * entry, no missing observation ahead) and from then on advance only the mean with the converged gain -- what
+   * statsmodels' filter does by default; results agree with the step-by-step recursion to ~1e-13 relative. */
+  KF_FLAG_EXACT_RECURSION = 1u << 12
 };
 
 /* error codes */
@@ -133,9 +138,11 @@ int kf_set_lanes_per_draw(kf_handle* h, int lanes);
  * for m = 7..9 and m = 4..6 while the batch cannot fill the chip with packed wavefronts, for m = 3
  * up to 2048 draws), else one lane per draw, 4 / 16 / 64 draws per wavefront by batch size ("lane", m <= 4: always for
  * m <= 2) / register-resident row-owner kernels
- * ("row", m <= 9); m <= 16, p <= 8 with p == 1 / UnivariateFilter / KF_FLAG_H_DIAGONAL -> covariance
- * in the 16 x 16 MFMA accumulator layout, one wavefront per draw ("mfma": p == 1 with m = 15, 16;
- * m >= 11 for p > 1) or the multivariate row kernel ("row"); 16 < m <= 48 with the same eligibility -> covariance as 2 x 2 /
+ * ("row", m <= 9); 2 <= p <= 8 scalar observations (UnivariateFilter / KF_FLAG_H_DIAGONAL), m <= 15 -> the same block
+ * tiles with the observations taken four at a time, a 4 x 4 LDL' on the wavefront ("b4" as well: always for m >= 9, below
+ * that up to 2048 draws); m <= 16, p <= 8 with p == 1 / UnivariateFilter / KF_FLAG_H_DIAGONAL otherwise -> covariance
+ * in the 16 x 16 MFMA accumulator layout, one wavefront per draw ("mfma": p == 1 with m = 15, 16; p > 1 with m = 16)
+ * or the multivariate row kernel ("row": p > 1, m <= 8, large batches); 16 < m <= 48 with the same eligibility -> covariance as 2 x 2 /
  * 3 x 3 blocks of 16 x 16 in accumulator layout ("mfma" as well); 48 < m <= 64 -> one workgroup of
  * four wavefronts per draw, one column block each ("mfma"); other tiles that fit LDS ->
  * generic LDS-resident kernel ("lds", also all time-varying models); else the workspace + MFMA

@@ -43,6 +43,24 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
   return r;
 }
 
+// wave-wide max |x| on the high dwords (integer max orders non-negative doubles; Inf / NaN come out largest): a wave-uniform
+// lower bound of max |x| within 2^-20
+__device__ __forceinline__ unsigned abs_hi(double x) { return (unsigned)__double2hiint(x) & 0x7fffffffu; }
+__device__ __forceinline__ double wave_absmax_hi(unsigned h) {
+  h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x128, 0xf, 0xf, false));
+  h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x124, 0xf, 0xf, false));
+  h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x122, 0xf, 0xf, false));
+  h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x121, 0xf, 0xf, false));
+  auto a = __builtin_amdgcn_permlane16_swap((int)h, (int)h, false, false);
+  h = max((unsigned)a[0], (unsigned)a[1]);
+  auto c = __builtin_amdgcn_permlane32_swap((int)h, (int)h, false, false);
+  h = max((unsigned)c[0], (unsigned)c[1]);
+  return __hiloint2double(__builtin_amdgcn_readfirstlane((int)h), 0);
+}
+__device__ __forceinline__ double uniform_f64(double x) {  // lane 0's value as a wave-uniform scalar
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+
 // Per-draw constants in register layout (lane = 16 g + 4 b + q):
 //   Ta[I][K]  left-factor block T_ext(I, K) replicated over the four slots: lane (g = k, any b, q = i) holds T_ext[4I+q][4K+g]
 //   Tha       = Ta / 2 (kept as registers for NB <= 3; else the 1/2 is applied after the symmetrisation)

@@ -131,7 +131,7 @@ struct TapeStream {
 // 3 predicted covariances, 4 the internal tile tape; TM < 0: decided at run time (the uncommon combinations).  Measured
 // (SQ counters, profiles/r02/ops_headline_sq_counters.txt): at four wavefronts per SIMD a wavefront's step costs ~4 cycles
 // per instruction of ANY kind; the run-time tape switches alone were a dozen scalar instructions per step.
-template <int NB, bool STREAM, int TM>
+template <int NB, bool STREAM, int TM, bool SS>
 __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) void kf_fwd_b4_kernel(const KfFwdArgs A) {
   // (waves_per_eu(4): <= 128 registers, and the compiler then keeps MFMA results in VGPRs -- no v_accvgpr moves)
   constexpr int N4 = 4 * NB, JA = N4 - 2, JC = N4 - 1;
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   s_fa.init(t_fa, smem + B4_OFF_RA);
   s_pa.init(t_pa, smem + B4_OFF_RA + RING_A);
   unsigned o_fa = s_fa.slot(bq), o_pa = s_pa.slot(bq);
-  auto put_a = [&](TapeStream<RING_A, GRAN_A>& st, unsigned& off, double twice_a) {
-    if (vec_on) *reinterpret_cast<double*>(reinterpret_cast<char*>(st.ring) + off) = twice_a;
+  auto put_a = [&](TapeStream<RING_A, GRAN_A>& st, unsigned& off, double twice_a, bool lanes_on) {
+    if (lanes_on) *reinterpret_cast<double*>(reinterpret_cast<char*>(st.ring) + off) = twice_a;
     off = TapeStream<RING_A, GRAN_A>::next(off, m);
     st.appended(m, lane, 0.5);
   };
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     }
   };
   // predicted tape slot 0 = (a0, P0 as given: the caller's P0, not its symmetrised upper triangle)
-  if (w_pa) put_a(s_pa, o_pa, P[NB - 1]);
+  if (w_pa) put_a(s_pa, o_pa, P[NB - 1], vec_on);
   if (w_pP) {
     if (STREAM) {
       double P0g[NB];
@@ -313,16 +313,44 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
 
   const double* ybase = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n : 0L);
 
-  for (int t = 0; t < n; ++t) {
-    if ((t & (LB - 1)) == 0) {
-      const int cnt = (n - t) < LB ? (n - t) : LB;
-      if (lane < cnt) {
-        const double yv = ybase[(long)t + lane];
-        const bool ob = !(yv != yv);
-        double2_t e = {ob ? -2.0 * (yv + dsign * d1) : 0.0, ob ? 1.0 : 0.0};
-        *reinterpret_cast<double2_t*>(YB + 2 * lane) = e;
-      }
-      wave_lds_fence();
+  auto load_y_block = [&](int t) {
+    const int cnt = (n - t) < LB ? (n - t) : LB;
+    if (lane < cnt) {
+      const double yv = ybase[(long)t + lane];
+      const bool ob = !(yv != yv);
+      double2_t e = {ob ? -2.0 * (yv + dsign * d1) : 0.0, ob ? 1.0 : 0.0};
+      *reinterpret_cast<double2_t*>(YB + 2 * lane) = e;
+    }
+    wave_lds_fence();
+  };
+
+  // ---- steady state ------------------------------------------------------------------------------------------------------------
+  // With static matrices and no missing observation ahead, the covariance recursion is a Riccati iteration that converges
+  // geometrically; once the predicted covariance has stopped moving (to 1e-15 of its largest entry, tested every 8 steps)
+  // the gain, F and both covariances are constants and only the mean is left: a_{t+1} = (T - T K Z) a_t + T K (y_t -+ d) + c
+  // -- the loop at the end of this kernel.  (statsmodels' Kalman filter does the same by default, `tolerance`; the
+  // reference recomputes everything every step, results agree to ~1e-13 relative.  KF_FLAG_EXACT_RECURSION switches it off.)
+  const bool steady_en = SS && STREAM && !w_tile && n >= 64;
+  int t_free = 0;  // first step after the last missing observation
+  if (steady_en) {
+    int tn = -1;
+    for (int e = lane; e < n; e += KF_WAVE) {
+      const double yv = ybase[e];
+      if (yv != yv) tn = e;
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) tn = max(tn, __shfl_xor(tn, off));
+    t_free = tn + 1;
+  }
+
+  int t = 0;
+  for (; t < n; ++t) {
+    if ((t & (LB - 1)) == 0) load_y_block(t);
+    const bool chk = steady_en && (t & 7) == 7 && t >= t_free && t + 16 < n;  // wave-uniform
+    if (chk && !w_pP) {  // the predicted covariance this step starts from, parked in the (unused) tape ring
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+        if (on[I]) *reinterpret_cast<double*>(reinterpret_cast<char*>(s_pP.ring) + o_pP[I]) = P[I];
     }
     const double2_t yo = *reinterpret_cast<const double2_t*>(YB + 2 * (t & (LB - 1)));  // {-2 (y -+ d), observed}
     // ---- update: u = row JA of the tile (DPP row 2 of the last register) brought to DPP row 0 ---------------
@@ -360,7 +388,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       pred_pending = false;
     }
     // ---- filtered tapes -----------------------------------------------------------------------------------------------
-    if (w_fa) put_a(s_fa, o_fa, P[NB - 1]);
+    if (w_fa) put_a(s_fa, o_fa, P[NB - 1], vec_on);
     if (w_fP) {
       if (STREAM) put_P(s_fP, o_fP, P);
       else stage_cov(P);  // flushed below, behind the MFMAs
@@ -393,8 +421,25 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
 #pragma unroll
       for (int I = 0; I < NB; ++I) P[I] = HALF_STATIC ? Y[I] + Yt[I] : 0.5 * (Y[I] + Yt[I]);
     }
+    bool conv = false;
+    if (chk) {
+      // (with the predicted-covariance tape on, the previous step's append still sits in the ring, mm doubles back)
+      unsigned dm = 0, pm = 0;
+      wave_lds_fence();
+#pragma unroll
+      for (int I = 0; I < NB; ++I) {
+        const unsigned oo = w_pP ? ((o_pP[I] + 8u * (unsigned)(RING_P - mm)) & (unsigned)(8 * RING_P - 1)) : o_pP[I];
+        const double old = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_pP.ring) + oo);
+        if (on[I]) {
+          dm = max(dm, abs_hi(P[I] - old));
+          pm = max(pm, abs_hi(P[I]));
+        }
+      }
+      wave_lds_fence();
+      conv = wave_absmax_hi(dm) <= 1e-15 * wave_absmax_hi(pm);
+    }
     if (w_tile && t == 0) put_tile(t_tile + (long)n * (N4 * N4), P, P[NB - 1]);
-    if (w_pa) put_a(s_pa, o_pa, P[NB - 1]);
+    if (w_pa) put_a(s_pa, o_pa, P[NB - 1], vec_on);
     if (w_pP) {
       if (STREAM) {
         put_P(s_pP, o_pP, P);
@@ -404,6 +449,101 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       }
     }
     if ((t & (LB - 1)) == LB - 1) flush_ring(t - (LB - 1), LB);
+    if (conv) {
+      ++t;
+      break;
+    }
+  }
+  if constexpr (SS && STREAM) if (t < n) {
+    // ---- steady-state steps t .. n-1 (see above); P is the converged predicted tile of step t -------------------------------
+    const double us = high_half_everywhere(P[NB - 1]) * mask0;  // row JA: (P Z')' with Z P Z' at JA (DPP row 0)
+    const double F = H1 + readlane_f64(us, JA);
+    const double rs = fast_rsqrt(fmax(F, 1e-300));
+    const double uh = us * rs;
+    // filtered covariance: one more rank-one step (its mean row / column is not used)
+    if (g == 0) *ux_w = us;
+    wave_lds_fence();
+    double Pf[NB];
+    {
+      const double2_t ur01 = *reinterpret_cast<const double2_t*>(ux_r);
+      double2_t ur23 = {0.0, 0.0};
+      if (NB > 2) ur23 = *reinterpret_cast<const double2_t*>(ux_r + 2);
+      wave_lds_fence();
+      const double urep[4] = {ur01.x, ur01.y, ur23.x, ur23.y};
+#pragma unroll
+      for (int I = 0; I < NB; ++I) Pf[I] = mfma4_nega(urep[I] * rs, uh, P[I]);
+    }
+    // gain K = P Z' / F by column index, through the (idle) transpose tile; T K per lane
+    if (g == 0) TR[bq] = (bq < m) ? uh * rs : 0.0;
+    wave_lds_fence();
+    const double* gT = A.Tm + b * (long)mm;
+    const double* gZ = A.Z + b * (long)m;
+    const bool jst = bq < m;
+    const double Kj = TR[bq];
+    double tkj = 0.0;
+    if (jst)
+      for (int l = 0; l < m; ++l) tkj = fma(gT[bq * m + l], TR[l], tkj);
+    const double cj = (jst && A.c) ? A.c[b * (long)m + bq] : 0.0;
+    // the two maps of the extended mean (a, y~ at JA, 1 at JC), rows = input index, columns = output index:
+    //   M1: a_{t+1} = (T - T K Z) a + T K y~ + c, and column JA = Z a (the innovation's prediction)
+    //   M2: a_f     = (I - K Z) a + K y~
+    double M1[NB], M2[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      const int i = 4 * I + g;
+      const double zi = (i < m) ? gZ[i] : 0.0;
+      double v1 = 0.0, v2 = 0.0;
+      if (i < m && jst) {
+        v1 = gT[bq * m + i] - tkj * zi;
+        v2 = ((i == bq) ? 1.0 : 0.0) - Kj * zi;
+      } else if (i < m && bq == JA) {
+        v1 = zi;
+      } else if (i == JA && jst) {
+        v1 = tkj;
+        v2 = Kj;
+      } else if (i == JC && jst) {
+        v1 = cj;
+      }
+      M1[I] = v1;
+      M2[I] = v2;
+    }
+    wave_lds_fence();
+    // the mean as a one-row left factor: element j at UX[4 (j & 3) + (j >> 2)], lane (g = k, q = 0) reads {a[k], a[4 + k], ..}
+    constexpr int PJA = 4 * (JA & 3) + (JA >> 2), PJC = 4 * (JC & 3) + (JC >> 2);
+    if (g == 3) UX[fb] = 0.5 * P[NB - 1];  // row JC of the tile = 2 a_t
+    const double* lq_r = ((lane & 3) == 0) ? UX + 4 * g : UX + 16;
+    const bool row0 = g == 0 && jst;
+    for (; t < n; ++t) {
+      if ((t & (LB - 1)) == 0) load_y_block(t);
+      const double2_t yo = *reinterpret_cast<const double2_t*>(YB + 2 * (t & (LB - 1)));
+      const double yt = -0.5 * yo.x;  // y -+ d
+      if (lane == 0) {
+        UX[PJA] = yt;
+        UX[PJC] = 1.0;
+      }
+      wave_lds_fence();
+      const double2_t l01 = *reinterpret_cast<const double2_t*>(lq_r);
+      double2_t l23 = {0.0, 0.0};
+      if (NB > 2) l23 = *reinterpret_cast<const double2_t*>(lq_r + 2);
+      wave_lds_fence();
+      const double lf[4] = {l01.x, l01.y, l23.x, l23.y};
+      double o1 = mfma4(lf[0], M1[0], 0.0), o2 = mfma4(lf[0], M2[0], 0.0);
+#pragma unroll
+      for (int K = 1; K < NB; ++K) {
+        o1 = mfma4(lf[K], M1[K], o1);
+        o2 = mfma4(lf[K], M2[K], o2);
+      }
+      if (lane == JA) {  // o1 = Z a_t here
+        double2_t fq = {F, -2.0 * (yt - o1) * rs};
+        *reinterpret_cast<double2_t*>(RG + 2 * (t & (LB - 1))) = fq;
+      }
+      if (g == 0) *ux_w = o1;  // a_{t+1} (its JA / JC slots are rewritten at the top of the next step)
+      if (w_fa) put_a(s_fa, o_fa, o2 + o2, row0);
+      if (w_fP) put_P(s_fP, o_fP, Pf);
+      if (w_pa) put_a(s_pa, o_pa, o1 + o1, row0);
+      if (w_pP) put_P(s_pP, o_pP, P);
+      if ((t & (LB - 1)) == LB - 1) flush_ring(t - (LB - 1), LB);
+    }
   }
   if (!STREAM && pred_pending) flush_cov(t_pP);
   s_fa.finish(lane, 0.5);
@@ -432,8 +572,19 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
   const size_t lds = sizeof(double) * (size_t)(B4_LOOP_DOUBLES > lds_setup ? B4_LOOP_DOUBLES : lds_setup);
   const int nb = (a.m + 2 + 3) / 4;
   const int mask = (a.filt_a ? 1 : 0) | (a.pred_a ? 2 : 0) | (a.filt_P ? 4 : 0) | (a.pred_P ? 8 : 0) | (a.tile_tape ? 16 : 0);
-#define KF_B4_LAUNCH2(NB_, ST_, TM_) \
-  hipLaunchKernelGGL((kf_fwd_b4_kernel<NB_, ST_, TM_>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a)
+  // steady-state phase (kernel header): a second instantiation, so that KF_FLAG_EXACT_RECURSION runs the very kernel it ran before
+  // (KF_STEADY_STATE=0 in the environment: the same switch for A/B measurements)
+  const char* sse = getenv("KF_STEADY_STATE");
+  const bool ss = !(a.flags & KF_FLAG_EXACT_RECURSION) && !a.tile_tape && a.T >= 64 && !(sse && *sse && atoi(sse) == 0);
+  // (tried: capping the residency of this instantiation at 3 / 2 wavefronts per SIMD so that the dispatcher hands queued draws to the
+  // SIMDs whose draws converged early -- headline 2.29 / 2.44 ms against 1.63: the queued wavefronts run as a second round)
+#define KF_B4_LAUNCH2(NB_, ST_, TM_)                                                                                       \
+  do {                                                                                                                     \
+    if (ss && ST_ && TM_ != 16)                                                                                            \
+      hipLaunchKernelGGL((kf_fwd_b4_kernel<NB_, ST_, TM_, (ST_ && TM_ != 16)>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((kf_fwd_b4_kernel<NB_, ST_, TM_, false>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);    \
+  } while (0)
 #define KF_B4_LAUNCH(NB_, ST_)                           \
   do {                                                   \
     if (mask == 15) KF_B4_LAUNCH2(NB_, ST_, 15);         \

@@ -21,7 +21,7 @@
 namespace {
 
 #ifndef KF_B4Q_GRP_WAVES
-#define KF_B4Q_GRP_WAVES 3
+#define KF_B4Q_GRP_WAVES 4
 #endif
 constexpr int QLB = 16;  // steps per y block / likelihood ring
 constexpr int QPMAX = 8;
@@ -222,21 +222,25 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
   //   Uh = W R                                                                        1 MFMA
   //   tile -= Uh' Uh                                                                  NB MFMAs (Uh' replicated through LDS)
   // d_i = L_ii^2 is observation i's F and Uh[i][JC] its -2 v / sqrt F, exactly the quantities of the one-at-a-time loop.
-  double* RX = TR;         // R by (column & 3, observation, column >> 2): 64
-  double* FX = TR + 64;    // F row-major: 16
-  double* WX = TR + 80;    // W lower triangle, packed: 10 (+ 2)
-  double* UB = TR + 96;    // Uh rows: 4 x 20
+  double* RX = TR;         // R rows: observation i at 16 i, column c at position 4 (c & 3) + (c >> 2): 64
+  double* UB = TR + 64;    // Uh rows, same layout: 64
+  double* FX = TR + 128;   // F row-major: 16
+  double* WX = TR + 144;   // W lower triangle, packed: 10
   const int qq = lane & 3;
-  double* rx_w = RX + (bq & 3) * 16 + g * 4 + (bq >> 2);
-  const double* rx_r = RX + (g * 4 + qq) * 4;
-  double* fx_w = (bq < 4) ? FX + g * 4 + qq : STG + 256 + lane;
-  const double* wx_r = WX + (qq * (qq + 1)) / 2 + (g <= qq ? g : 0);
-  const double wmask = (g <= qq) ? 1.0 : 0.0;
-  double* ub_w = UB + g * 20 + fb;
-  const double* ub_r = UB + g * 20 + 4 * qq;
-  const double colJC = (bq == JC) ? 1.0 : 0.0;
-  const double dgi = (qq == g) ? 1.0 : 0.0;
-  auto rs_of = [&](double dv) { return fast_rsqrt(fmax(dv, 1e-300)) * ((dv > 0.0) ? 1.0 : 0.0); };
+  double* rw = RX + g * 16 + fb;                  // this lane's element of a 4 x 16 matrix in D layout (UB: + 64)
+  const double* rx_r = RX + qq * 16 + 4 * g;      // lane (g = k, q = j): R[j][4 K + k], K = 0..3
+  const double* ub_r = UB + g * 16 + 4 * qq;      // lane (g = k, q = i): Uh[k][4 I + i], I = 0..3
+  const bool fx_on = bq < 4;                      // one copy of F (the MFMA result is the same in every block slot)
+  const double* wx_r = (g <= qq) ? WX + (qq * (qq + 1)) / 2 + g : UX + 16;  // lane (g = k, q = i): W[i][k] (0 above the diagonal)
+  const bool isJC = bq == JC, isdg = qq == g;
+  // 1 / sqrt(d) for a pivot, 0 for a non-positive one: v_rsq_f64 + ONE third-order correction (e = 1 - d r^2;
+  // r <- r + r e (1/2 + 3/8 e): relative error e^3 -- five instructions where two Newton steps take seven)
+  auto rs_of = [&](double dv) {
+    const double r0 = __builtin_amdgcn_rsq(fmax(dv, 1e-300));
+    const double e = fma(-dv * r0, r0, 1.0);
+    const double r1 = fma(r0 * e, fma(0.375, e, 0.5), r0);
+    return (dv > 0.0) ? r1 : 0.0;
+  };
   auto group_update = [&](int q0, int e0) {
     const int ob = q0 + g;
     const bool valid = ob < p;
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
     const double* za = ZQ + (q0 + qq) * 16 + 4 * g;
     const double2_t z01 = *reinterpret_cast<const double2_t*>(za);
     const double2_t z23 = *reinterpret_cast<const double2_t*>(za + 2);
-    const double hm1 = HD[ob & (QPMAX - 1)] - 1.0;
+    const double hq = HD[ob & (QPMAX - 1)];
     const double zA[4] = {z01.x, z01.y, z23.x, z23.y};
     double R = mfma4(zA[0], P[0], 0.0);
     {
@@ -254,12 +258,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
       R += R2;
     }
     const double flag = yo.y;
-    const double Rm = fma(colJC, yo.x, R) * flag;
-    *rx_w = Rm;
+    const double Rm = (R + (isJC ? yo.x : 0.0)) * flag;
+    *rw = Rm;
     wave_lds_fence();
     const double2_t t01 = *reinterpret_cast<const double2_t*>(rx_r);
     const double2_t t23 = *reinterpret_cast<const double2_t*>(rx_r + 2);
-    wave_lds_fence();
     double G = mfma4(zA[0], t01.x, 0.0);
     {
       double G2 = mfma4(zA[1], t01.y, 0.0);
@@ -267,8 +270,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
       if (NB > 3) G2 = mfma4(zA[3], t23.y, G2);
       G += G2;
     }
-    // F = flag (G + dgi H) + (1 - flag) dgi
-    *fx_w = fma(flag, fma(dgi, hm1, G), dgi);
+    // F = flag (G + [i == j] H) + (1 - flag) [i == j]
+    {
+      const double Fv = isdg ? fma(flag, (G + hq) - 1.0, 1.0) : flag * G;
+      if (fx_on) FX[g * 4 + qq] = Fv;
+    }
     wave_lds_fence();
     const double2_t f0 = *reinterpret_cast<const double2_t*>(FX);
     const double2_t f1 = *reinterpret_cast<const double2_t*>(FX + 4);
@@ -276,7 +282,6 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
     const double2_t f2b = *reinterpret_cast<const double2_t*>(FX + 10);
     const double2_t f3a = *reinterpret_cast<const double2_t*>(FX + 12);
     const double2_t f3b = *reinterpret_cast<const double2_t*>(FX + 14);
-    wave_lds_fence();
     // L L' = F, skipping a non-positive pivot (rs = 0: that observation updates nothing, as in the one-at-a-time loop)
     const double d0 = f0.x, rs0 = rs_of(d0);
     const double l10 = f1.x * rs0, l20 = f2a.x * rs0, l30 = f3a.x * rs0;
@@ -301,19 +306,16 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
       *reinterpret_cast<double2_t*>(WX + 8) = a4;
     }
     wave_lds_fence();
-    const double wv = *wx_r * wmask;  // lane (g = k, q = i): W[i][k]
-    wave_lds_fence();
+    const double wv = *wx_r;
     const double Uh = mfma4(wv, Rm, 0.0);
-    *ub_w = Uh;
+    rw[64] = Uh;
     wave_lds_fence();
     const double2_t u01 = *reinterpret_cast<const double2_t*>(ub_r);
     const double2_t u23 = *reinterpret_cast<const double2_t*>(ub_r + 2);
-    wave_lds_fence();
     {
       const double dsel = (g == 0) ? d0 : (g == 1) ? d1 : (g == 2) ? d2 : d3;
       double2_t fq = {dsel, Uh};
-      double* dst = (valid && bq == JC) ? RG + 2 * (e0 + ob) : STG + 256 + 2 * (lane & 31);
-      *reinterpret_cast<double2_t*>(dst) = fq;
+      if (valid && isJC) *reinterpret_cast<double2_t*>(RG + 2 * (e0 + ob)) = fq;
     }
     const double uT[4] = {u01.x, u01.y, u23.x, u23.y};
 #pragma unroll
@@ -417,12 +419,22 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
         if (NB > 3) r2 = mfma4(zA[3], P[NB > 3 ? 3 : 0], r2);
         r += r2;
       }
-      const double u = fma(adjm, yo.x, r);  // u_JC = 2 z a - 2 (y -+ d) = -2 v
-      *ux_w = u;  // (rows 1..3 write zeros into a dump slot: no exec-mask switch)
-      wave_lds_fence();
-      const double2_t ur01 = *reinterpret_cast<const double2_t*>(ux_r);
-      double2_t ur23 = {0.0, 0.0};
-      if (NB > 2) ur23 = *reinterpret_cast<const double2_t*>(ux_r + 2);
+      double u;
+      double2_t ur01, ur23 = {0.0, 0.0};
+      if constexpr (GRP && NB >= 3) {
+        // (shares the group path's exchange rows: r is zero outside DPP row 0, so rows 1..3 of the buffer hold zeros)
+        u = r + ((lane == JC) ? yo.x : 0.0);
+        rw[64] = u;
+        wave_lds_fence();
+        ur01 = *reinterpret_cast<const double2_t*>(ub_r);
+        ur23 = *reinterpret_cast<const double2_t*>(ub_r + 2);
+      } else {
+        u = fma(adjm, yo.x, r);  // u_JC = 2 z a - 2 (y -+ d) = -2 v
+        *ux_w = u;  // (rows 1..3 write zeros into a dump slot: no exec-mask switch)
+        wave_lds_fence();
+        ur01 = *reinterpret_cast<const double2_t*>(ux_r);
+        if (NB > 2) ur23 = *reinterpret_cast<const double2_t*>(ux_r + 2);
+      }
       wave_lds_fence();
       const double urep[4] = {ur01.x, ur01.y, ur23.x, ur23.y};
       const double F = Hq + readlane_f64(row_allsum(r * zcol), 0);
@@ -432,8 +444,12 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
       const double uh = u * rs;
       {
         double2_t fq = {F, uh};
-        *reinterpret_cast<double2_t*>(rgw) = fq;  // lane JC: the ring; the others: their dump slot
-        rgw += rg_s;
+        if constexpr (GRP && NB >= 3) {
+          if (lane == JC) *reinterpret_cast<double2_t*>(RG + 2 * (e0 + q)) = fq;
+        } else {
+          *reinterpret_cast<double2_t*>(rgw) = fq;  // lane JC: the ring; the others: their dump slot
+          rgw += rg_s;
+        }
       }
 #pragma unroll
       for (int I = 0; I < NB; ++I) P[I] = mfma4_nega(urep[I] * rs, uh, P[I]);

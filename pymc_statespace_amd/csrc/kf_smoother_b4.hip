@@ -64,22 +64,6 @@ __device__ __forceinline__ double wave_allmax_dpp(double x) {
 // double order like unsigned integers -- a norm to 1e-6 relative is all a threshold needs -- so each level is one
 // v_max_u32 (DPP folded in) instead of two moves and a canonicalising v_max_f64, and Inf / NaN come out as the largest
 // values (no separate NaN test).  Returns a wave-uniform lower bound of max |x| within 2^-20.
-__device__ __forceinline__ unsigned abs_hi(double x) { return (unsigned)__double2hiint(x) & 0x7fffffffu; }
-__device__ __forceinline__ double wave_absmax_hi(unsigned h) {
-  h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x128, 0xf, 0xf, false));
-  h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x124, 0xf, 0xf, false));
-  h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x122, 0xf, 0xf, false));
-  h = max(h, (unsigned)__builtin_amdgcn_update_dpp(0, (int)h, 0x121, 0xf, 0xf, false));
-  auto a = __builtin_amdgcn_permlane16_swap((int)h, (int)h, false, false);
-  h = max((unsigned)a[0], (unsigned)a[1]);
-  auto c = __builtin_amdgcn_permlane32_swap((int)h, (int)h, false, false);
-  h = max((unsigned)c[0], (unsigned)c[1]);
-  return __hiloint2double(__builtin_amdgcn_readfirstlane((int)h), 0);
-}
-__device__ __forceinline__ double uniform_f64(double x) {  // lane 0's value as a wave-uniform scalar
-  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
-}
-
 template <int NB>
 __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3 ? 4 : 3))) void kf_smooth_b4_kernel(
     const KfSmoothArgs A, int32_t* flags) {

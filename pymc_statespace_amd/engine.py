@@ -145,6 +145,7 @@ class KalmanEngine:
     def forward(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, filter_type="standard",
                 mvn_const="reference", store_ll_obs=True, store_filtered=True,
                 store_predicted=True, time_varying=(), h_diagonal: Optional[bool] = None,
+                exact_recursion: bool = False,
                 out: Optional[FilterResult] = None) -> FilterResult:
         """kf_filter_forward.  y (n,p) shared or (B,n,p); a0 (B,m); P0,T (B,m,m); Z (B,p,m);
         R (B,m,r); H (B,p,p); Q (B,r,r); c (B,m); d (B,p).  Names listed in ``time_varying``
@@ -214,6 +215,8 @@ class KalmanEngine:
                 h_diagonal = self._hdiag_val
         if h_diagonal:
             dims.flags |= _lib.KF_FLAG_H_DIAGONAL
+        if exact_recursion:
+            dims.flags |= _lib.KF_FLAG_EXACT_RECURSION
         dev, f64 = self.device, torch.float64
         if out is None:
             out = FilterResult(

@@ -1564,6 +1564,43 @@ def test_b4_kernel_per_draw_data_not_pd_and_univariate_skip(eng):
         eng.set_forward_kernel("auto")
 
 
+def test_b4_kernel_steady_state_phase_matches_exact_recursion(eng):
+    """Default: once the predicted covariance has stopped moving (and no observation is missing ahead) the block kernel
+    advances only the mean with the converged gain; KF_FLAG_EXACT_RECURSION keeps the step-by-step recursion.  Both against
+    the oracle; a series with a late missing row (steady state entered only behind it) and intercepts."""
+    w = W.structural(B=24, n=600)
+    B, m = 24, w["m"]
+    rng = np.random.default_rng(1)
+    c = 0.05 * rng.standard_normal((B, m))
+    d = 0.1 * rng.standard_normal((B, 1))
+    for missing in ((), (5, 100, 250)):
+        y = w["y"].copy()
+        y[list(missing)] = np.nan
+        for ft in ("standard", "univariate", "single"):
+            ref = kn.kalman_filter(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact")
+            outs = {}
+            for exact in (True, False):
+                out = _np(eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact", exact_recursion=exact))
+                assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8
+                for k in TAPES:
+                    assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=f"{ft} exact={exact} {k}")
+                assert not out["info"].any()
+                outs[exact] = out
+            # the switch did switch (some draw of this workload converges within 600 steps), and changes nothing beyond rounding
+            assert not np.array_equal(outs[True]["predicted_states"], outs[False]["predicted_states"])
+            assert_allclose(outs[True]["filtered_covs"], outs[False]["filtered_covs"], rtol=1e-11, atol=1e-12)
+            assert_allclose(outs[True]["logp"], outs[False]["logp"], rtol=1e-12)
+    # partial outputs in the steady phase: every tape subset, against the full run
+    full = _np(eng.forward(*_args(w), mvn_const="exact"))
+    for sel in ((False, True, False), (False, False, True), (True, False, False), (False, False, False)):
+        r = eng.forward(*_args(w), mvn_const="exact", store_ll_obs=sel[0], store_filtered=sel[1], store_predicted=sel[2])
+        assert_allclose(r.logp.cpu().numpy(), full["logp"], rtol=1e-13)
+        for k in TAPES:
+            v = getattr(r, k)
+            if v is not None:
+                assert_allclose(v.cpu().numpy(), full[k], rtol=1e-12, atol=1e-13, err_msg=f"{sel} {k}")
+
+
 # ----------------------------------------------------------------------------------------------
 # multi-observation block kernel (kf_forward_b4q.hip): p scalar observations per step on the 4x4x4 block tiles
 # ----------------------------------------------------------------------------------------------
