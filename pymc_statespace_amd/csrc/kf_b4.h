@@ -61,6 +61,72 @@ __device__ __forceinline__ double uniform_f64(double x) {  // lane 0's value as 
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
 
+// One output tape of one draw, streamed through an LDS ring.  Why: measured on MI355X (scripts/r02, headline
+// shape) the per-step stores of kf_forward_mfma.hip -- 800-byte covariance pieces that start and end in the middle
+// of 128-byte lines, 80-byte state vectors -- cost 0.75 ms on top of 1.09 ms of arithmetic: partially written
+// lines are expensive at the memory side (a tape written with 224-byte holes per KiB ran at HALF the speed of one
+// written in full KiB), and an 80-byte store costs a whole wave-instruction.  Here elements are appended to a ring
+// indexed by their ABSOLUTE element number (address / 8 relative to a GRAN-aligned base) and leave for HBM only as
+// windows of GRAN doubles that start on GRAN * 8-byte boundaries: 16 bytes per lane, whole lines, every lane busy.
+template <int RING, int GRAN>
+struct TapeStream {
+  double* ring;
+  double* tape;  // the draw's tape (kept as the kernel argument's pointer: global_store, not flat_store)
+  int e0;        // absolute element number of tape[0]: (address / 8) mod GRAN
+  int E;         // absolute element number of the next append (wave-uniform)
+  int Ef;        // elements below Ef have been stored
+
+  __device__ __forceinline__ void init(double* tape_, double* lds_ring) {
+    ring = lds_ring;
+    tape = tape_;
+    e0 = tape_ ? (int)((reinterpret_cast<unsigned long long>(tape_) >> 3) & (unsigned long long)(GRAN - 1)) : 0;
+    E = Ef = e0;
+  }
+  // LDS byte offset of the element `o` doubles past the next append position
+  __device__ __forceinline__ unsigned slot(int o) const { return (unsigned)(((E + o) & (RING - 1)) * 8); }
+  __device__ __forceinline__ static unsigned next(unsigned byte_off, int cnt) {
+    return (byte_off + 8u * (unsigned)cnt) & (unsigned)(8 * RING - 1);
+  }
+  __device__ __forceinline__ void window(int w0, int lo, int hi, int lane, double scale) {
+    const int e = w0 + 2 * lane;
+    double2_t v = *reinterpret_cast<const double2_t*>(ring + (e & (RING - 1)));
+    v.x *= scale;
+    v.y *= scale;
+    char* dst = reinterpret_cast<char*>(tape + (w0 - e0));  // (may point below the tape: only lanes >= lo store)
+    const unsigned off = 16u * (unsigned)lane;
+    if (lo <= w0 && hi >= w0 + GRAN) {  // wave-uniform: the whole window, every lane
+      // (write-back; non-temporal window stores measured the same: 1.755 vs 1.783 ms)
+      if (GRAN == 128 || lane < GRAN / 2) *reinterpret_cast<double2_t*>(dst + off) = v;
+    } else if (lane < GRAN / 2) {
+      const bool k0 = e >= lo && e < hi, k1 = e + 1 >= lo && e + 1 < hi;
+      if (k0 && k1) *reinterpret_cast<double2_t*>(dst + off) = v;
+      else if (k0) *reinterpret_cast<double*>(dst + off) = v.x;
+      else if (k1) *reinterpret_cast<double*>(dst + off + 8) = v.y;
+    }
+  }
+  // after the lanes wrote `cnt` more elements into the ring: at most one window becomes complete per append.
+  // (Tried and dropped, both slower at the headline shape: reading the window right after the ring writes and
+  // storing it later in the step -- 2.05 vs 1.84 ms, register pressure; collecting the windows of all four tapes
+  // once per step, reads first -- 1.89 ms.)
+  __device__ __forceinline__ void appended(int cnt, int lane, double scale) {
+    E += cnt;
+    const int bound = E & ~(GRAN - 1);
+    if (bound > Ef) {
+      wave_lds_fence();
+      window(bound - GRAN, Ef, bound, lane, scale);
+      wave_lds_fence();
+      Ef = bound;
+    }
+  }
+  __device__ __forceinline__ void finish(int lane, double scale) {
+    if (E > Ef) {
+      wave_lds_fence();
+      window(Ef & ~(GRAN - 1), Ef, E, lane, scale);
+      Ef = E;
+    }
+  }
+};
+
 // Per-draw constants in register layout (lane = 16 g + 4 b + q):
 //   Ta[I][K]  left-factor block T_ext(I, K) replicated over the four slots: lane (g = k, any b, q = i) holds T_ext[4I+q][4K+g]
 //   Tha       = Ta / 2 (kept as registers for NB <= 3; else the 1/2 is applied after the symmetrisation)

@@ -23,7 +23,7 @@ namespace {
 #ifndef KF_B4Q_GRP_WAVES
 #define KF_B4Q_GRP_WAVES 4
 #endif
-constexpr int QLB = 16;  // steps per y block / likelihood ring
+constexpr int QLB = 8;   // steps per y block / likelihood ring
 constexpr int QPMAX = 8;
 // loop-time LDS (doubles): 16 wavefronts per CU need <= 1280 each
 constexpr int Q_OFF_UX = 16 * TRS;                      // u by column index (16) | zeros (4)
@@ -32,7 +32,8 @@ constexpr int Q_OFF_HD = Q_OFF_ZQ + 16 * QPMAX;         // diag(H)
 constexpr int Q_OFF_RG = Q_OFF_HD + QPMAX;              // likelihood ring: QLB x p x {F, u_hat_JC}
 constexpr int Q_OFF_YB = Q_OFF_RG + 2 * QLB * QPMAX;    // y block: QLB x p x {-2 (y -+ d) or 0, observed ? 1 : 0}
 constexpr int Q_OFF_STG = Q_OFF_YB + 2 * QLB * QPMAX;   // covariance tape image: m x m compact + 64 dump slots at 256
-constexpr int Q_LOOP_DOUBLES = Q_OFF_STG + 256 + 64;
+constexpr int Q_OFF_PO = Q_OFF_STG + 256 + 64;          // steady-state test: the predicted covariance a checked step started from (m x m compact)
+constexpr int Q_LOOP_DOUBLES = Q_OFF_PO + 256;
 static_assert(Q_LOOP_DOUBLES <= 1280, "four wavefronts per SIMD need <= 10 KiB of LDS per wavefront");
 inline int b4q_setup_doubles(int m, int r) { return 2 * m * r + r * r; }
 
@@ -43,7 +44,8 @@ __device__ __forceinline__ void st_off(double* base, unsigned byte_off, double v
 }
 
 // GRP: observations are taken FOUR at a time while at least three are left (see group_update below)
-template <int NB, int TM, bool GRP>
+// SS: steady-state phase (3 <= p <= 5 with GRP: one group and at most one single observation) -- see the end of the kernel
+template <int NB, int TM, bool GRP, bool SS>
 __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? KF_B4Q_GRP_WAVES : 4))) void kf_fwd_b4q_kernel(const KfFwdArgs A) {
   constexpr int N4 = 4 * NB, JC = N4 - 1;
   constexpr bool HALF = NB <= 3;  // T / 2 kept as registers; else the 1/2 is applied at the symmetrisation
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
   double* RG = smem + Q_OFF_RG;
   double* YB = smem + Q_OFF_YB;
   double* STG = smem + Q_OFF_STG;
+  double* PO = smem + Q_OFF_PO;
 
   // ---- per-draw constants ---------------------------------------------------------------------------------------------------
   double Ta[NB][NB], Tha[HALF ? NB : 1][HALF ? NB : 1], Ch[NB], P[NB];
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
     const double r1 = fma(r0 * e, fma(0.375, e, 0.5), r0);
     return (dv > 0.0) ? r1 : 0.0;
   };
-  auto group_update = [&](int q0, int e0) {
+  auto group_update = [&](int q0, int e0, double* d_keep) {
     const int ob = q0 + g;
     const bool valid = ob < p;
     const double2_t yo = *reinterpret_cast<const double2_t*>(valid ? YB + 2 * (e0 + ob) : UX + 16);
@@ -314,12 +317,69 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
     const double2_t u23 = *reinterpret_cast<const double2_t*>(ub_r + 2);
     {
       const double dsel = (g == 0) ? d0 : (g == 1) ? d1 : (g == 2) ? d2 : d3;
+      if (d_keep) *d_keep = dsel;
       double2_t fq = {dsel, Uh};
       if (valid && isJC) *reinterpret_cast<double2_t*>(RG + 2 * (e0 + ob)) = fq;
     }
     const double uT[4] = {u01.x, u01.y, u23.x, u23.y};
 #pragma unroll
     for (int I = 0; I < NB; ++I) P[I] = mfma4_nega(uT[I], Uh, P[I]);
+  };
+
+  // one observation at a time (all of them when !GRP; the one or two left over behind the groups otherwise)
+  auto single_update = [&](int q, int e0, const double* zq, const double* zc, char* rgw, double* f_keep, double* rs_keep) {
+      const double2_t yo = *reinterpret_cast<const double2_t*>(YB + 2 * (e0 + q));  // {-2 (y -+ d), observed}
+      const double2_t z01 = *reinterpret_cast<const double2_t*>(zq);
+      double2_t z23 = {0.0, 0.0};
+      if (NB > 2) z23 = *reinterpret_cast<const double2_t*>(zq + 2);
+      const double zcol = *zc;
+      const double Hq = HD[q];
+      const double zA[4] = {z01.x, z01.y, z23.x, z23.y};
+      // two accumulation chains: a dependent 4x4x4 MFMA waits for its predecessor's four passes
+      double r = mfma4(zA[0], P[0], 0.0);
+      if (NB > 1) {
+        double r2 = mfma4(zA[1], P[NB > 1 ? 1 : 0], 0.0);
+        if (NB > 2) r = mfma4(zA[2], P[NB > 2 ? 2 : 0], r);
+        if (NB > 3) r2 = mfma4(zA[3], P[NB > 3 ? 3 : 0], r2);
+        r += r2;
+      }
+      double u;
+      double2_t ur01, ur23 = {0.0, 0.0};
+      if constexpr (GRP && NB >= 3) {
+        // (an exchange slot of the group path's shape at TR + 160: r is zero outside DPP row 0, so rows 1..3 receive zeros)
+        u = r + ((lane == JC) ? yo.x : 0.0);
+        rw[160] = u;
+        wave_lds_fence();
+        ur01 = *reinterpret_cast<const double2_t*>(ub_r + 96);
+        ur23 = *reinterpret_cast<const double2_t*>(ub_r + 98);
+      } else {
+        u = fma(adjm, yo.x, r);  // u_JC = 2 z a - 2 (y -+ d) = -2 v
+        *ux_w = u;  // (rows 1..3 write zeros into a dump slot: no exec-mask switch)
+        wave_lds_fence();
+        ur01 = *reinterpret_cast<const double2_t*>(ux_r);
+        if (NB > 2) ur23 = *reinterpret_cast<const double2_t*>(ux_r + 2);
+      }
+      wave_lds_fence();
+      const double urep[4] = {ur01.x, ur01.y, ur23.x, ur23.y};
+      const double F = Hq + readlane_f64(row_allsum(r * zcol), 0);
+      // missing -> no update; F == 0 (Univariate: skipped, :468-471) and F < 0 / NaN (flagged when the ring is evaluated): no update
+      // either.  (A select, not a branch: F is wave-uniform, but a taken branch costs more than the nine instructions.)
+      const double rs = fast_rsqrt(fmax(F, 1e-300)) * ((F > 0.0) ? yo.y : 0.0);
+      const double uh = u * rs;
+      if (f_keep) {
+        *f_keep = F;
+        *rs_keep = rs;
+      }
+      {
+        double2_t fq = {F, uh};
+        if constexpr (GRP && NB >= 3) {
+          if (lane == JC) *reinterpret_cast<double2_t*>(RG + 2 * (e0 + q)) = fq;
+        } else {
+          *reinterpret_cast<double2_t*>(rgw) = fq;  // lane JC: the ring; the others: their dump slot
+        }
+      }
+#pragma unroll
+      for (int I = 0; I < NB; ++I) P[I] = mfma4_nega(urep[I] * rs, uh, P[I]);
   };
 
   double logp = 0.0;
@@ -372,17 +432,42 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
   const double* ybase = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n * p : 0L);
   const double* gd = A.d ? A.d + b * (long)p : nullptr;
 
-  for (int t = 0; t < n; ++t) {
-    if ((t & (QLB - 1)) == 0) {
-      const int cnt = ((n - t) < QLB ? (n - t) : QLB) * p;
-      for (int e = lane; e < cnt; e += KF_WAVE) {
-        const double yv = ybase[(long)t * p + e];
-        const bool ob = !(yv != yv);
-        const double dq = gd ? gd[e % p] : 0.0;
-        double2_t ye = {ob ? -2.0 * (yv + dsign * dq) : 0.0, ob ? 1.0 : 0.0};
-        *reinterpret_cast<double2_t*>(YB + 2 * e) = ye;
-      }
-      wave_lds_fence();
+  auto load_y_block = [&](int t) {
+    const int cnt = ((n - t) < QLB ? (n - t) : QLB) * p;
+    for (int e = lane; e < cnt; e += KF_WAVE) {
+      const double yv = ybase[(long)t * p + e];
+      const bool ob = !(yv != yv);
+      const double dq = gd ? gd[e % p] : 0.0;
+      double2_t ye = {ob ? -2.0 * (yv + dsign * dq) : 0.0, ob ? 1.0 : 0.0};
+      *reinterpret_cast<double2_t*>(YB + 2 * e) = ye;
+    }
+    wave_lds_fence();
+  };
+
+  // ---- steady state (SS; see kf_forward_b4.hip): every 8 steps, behind the last missing observation, the predicted covariance is
+  // compared with the one the step started from (parked in LDS); once it has stopped moving the loop at the end takes over
+  constexpr bool SSK = SS && GRP && NB >= 3;
+  const bool steady_en = SSK && p >= 3 && p <= 5 && n >= 64;
+  int t_free = 0;
+  if (steady_en) {
+    int tn = -1;
+    for (int e = lane; e < n * p; e += KF_WAVE) {
+      const double yv = ybase[e];
+      if (yv != yv) tn = e;
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) tn = max(tn, __shfl_xor(tn, off));
+    t_free = tn < 0 ? 0 : tn / p + 1;
+  }
+
+  int t = 0;
+  for (; t < n; ++t) {
+    if ((t & (QLB - 1)) == 0) load_y_block(t);
+    const bool chk = steady_en && (t & 7) == 7 && t >= t_free && t + 16 < n;  // wave-uniform
+    if (chk) {
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+        if (stg_off[I] < 256u * 8u) *reinterpret_cast<double*>(reinterpret_cast<char*>(PO) + stg_off[I]) = P[I];
     }
     if (pred_pending) {  // predicted covariance of the previous step: tile image -> HBM
       flush_cov(t_pP);
@@ -394,7 +479,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
     int qs0 = 0;
     if (GRP && NB >= 3) {
 #pragma unroll 1
-      for (; p - qs0 >= 3; qs0 += 4) group_update(qs0, e0);
+      for (; p - qs0 >= 3; qs0 += 4) group_update(qs0, e0, nullptr);
       if (qs0 > p) qs0 = p;
     }
     const double* zq = zq_r + qs0 * zq_s;
@@ -402,57 +487,10 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
     char* rgw = rg_w + (e0 + qs0) * rg_s;
 #pragma unroll 1
     for (int q = qs0; q < p; ++q) {
-      const double2_t yo = *reinterpret_cast<const double2_t*>(YB + 2 * (e0 + q));  // {-2 (y -+ d), observed}
-      const double2_t z01 = *reinterpret_cast<const double2_t*>(zq);
-      double2_t z23 = {0.0, 0.0};
-      if (NB > 2) z23 = *reinterpret_cast<const double2_t*>(zq + 2);
-      const double zcol = *zc;
-      const double Hq = HD[q];
+      single_update(q, e0, zq, zc, rgw, nullptr, nullptr);
       zq += zq_s;
       zc += 16;
-      const double zA[4] = {z01.x, z01.y, z23.x, z23.y};
-      // two accumulation chains: a dependent 4x4x4 MFMA waits for its predecessor's four passes
-      double r = mfma4(zA[0], P[0], 0.0);
-      if (NB > 1) {
-        double r2 = mfma4(zA[1], P[NB > 1 ? 1 : 0], 0.0);
-        if (NB > 2) r = mfma4(zA[2], P[NB > 2 ? 2 : 0], r);
-        if (NB > 3) r2 = mfma4(zA[3], P[NB > 3 ? 3 : 0], r2);
-        r += r2;
-      }
-      double u;
-      double2_t ur01, ur23 = {0.0, 0.0};
-      if constexpr (GRP && NB >= 3) {
-        // (shares the group path's exchange rows: r is zero outside DPP row 0, so rows 1..3 of the buffer hold zeros)
-        u = r + ((lane == JC) ? yo.x : 0.0);
-        rw[64] = u;
-        wave_lds_fence();
-        ur01 = *reinterpret_cast<const double2_t*>(ub_r);
-        ur23 = *reinterpret_cast<const double2_t*>(ub_r + 2);
-      } else {
-        u = fma(adjm, yo.x, r);  // u_JC = 2 z a - 2 (y -+ d) = -2 v
-        *ux_w = u;  // (rows 1..3 write zeros into a dump slot: no exec-mask switch)
-        wave_lds_fence();
-        ur01 = *reinterpret_cast<const double2_t*>(ux_r);
-        if (NB > 2) ur23 = *reinterpret_cast<const double2_t*>(ux_r + 2);
-      }
-      wave_lds_fence();
-      const double urep[4] = {ur01.x, ur01.y, ur23.x, ur23.y};
-      const double F = Hq + readlane_f64(row_allsum(r * zcol), 0);
-      // missing -> no update; F == 0 (Univariate: skipped, :468-471) and F < 0 / NaN (flagged when the ring is evaluated): no update
-      // either.  (A select, not a branch: F is wave-uniform, but a taken branch costs more than the nine instructions.)
-      const double rs = fast_rsqrt(fmax(F, 1e-300)) * ((F > 0.0) ? yo.y : 0.0);
-      const double uh = u * rs;
-      {
-        double2_t fq = {F, uh};
-        if constexpr (GRP && NB >= 3) {
-          if (lane == JC) *reinterpret_cast<double2_t*>(RG + 2 * (e0 + q)) = fq;
-        } else {
-          *reinterpret_cast<double2_t*>(rgw) = fq;  // lane JC: the ring; the others: their dump slot
-          rgw += rg_s;
-        }
-      }
-#pragma unroll
-      for (int I = 0; I < NB; ++I) P[I] = mfma4_nega(urep[I] * rs, uh, P[I]);
+      rgw += rg_s;
     }
     // ---- filtered tapes -------------------------------------------------------------------------------------------------------
     if (w_fa) {
@@ -485,6 +523,21 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
 #pragma unroll
       for (int I = 0; I < NB; ++I) P[I] = HALF ? Y[I] + Yt[I] : 0.5 * (Y[I] + Yt[I]);
     }
+    bool conv = false;
+    if (chk) {
+      unsigned dm = 0, pm = 0;
+      wave_lds_fence();
+#pragma unroll
+      for (int I = 0; I < NB; ++I) {
+        const bool on = stg_off[I] < 256u * 8u;
+        const double old = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(PO) + (on ? stg_off[I] : 0u));
+        if (on) {
+          dm = max(dm, abs_hi(P[I] - old));
+          pm = max(pm, abs_hi(P[I]));
+        }
+      }
+      conv = wave_absmax_hi(dm) <= 1e-15 * wave_absmax_hi(pm);
+    }
     if (w_pa) {
       if (vec_on) st_off(t_pa, voff, 0.5 * P[NB - 1]);
       t_pa += m;
@@ -494,6 +547,193 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
       pred_pending = true;
     }
     if ((t & (QLB - 1)) == QLB - 1) flush_ring(t - (QLB - 1), QLB);
+    if (conv) {
+      ++t;
+      break;
+    }
+  }
+  if constexpr (SSK) if (t < n) {
+    // ---- steady-state steps t .. n-1: P is the converged predicted tile of step t.  The first of them runs the ordinary
+    // update once more and leaves its constants where the update put them -- W and the rows of Uh (the group), u (the single
+    // observation) in their LDS exchange slots, which nothing overwrites from here on (no more transposes) -- then only a MEAN
+    // tile Sm (column JC = 2 a, zero elsewhere) goes through the same MFMAs: R = Z_g Sm, Uh = W R, Sm -= Uh_const' Uh,
+    // and Sm <- T_e Sm + (column JC of C_e) for the predict.
+    double Sm[NB], Cc[NB];
+    double d_c = 1.0, f_c = 1.0, rs_c = 0.0;
+    constexpr int qs1 = 4;  // observations 0..3 are the group; at most one more behind it (3 <= p <= 5)
+    // The covariance tapes of ALL remaining steps are two constants: written here in one go, as whole aligned KiB straight
+    // from a compact image in LDS (element i of the tape = image[i mod m^2]) -- 16 bytes per lane, every lane busy.  (Per-step
+    // image flushes, 14 partly filled vector-memory instructions per wavefront and step, held the steady C4 steps at the
+    // address-processing rate of the CU: 16.3 ms with full tapes against 6.3 ms without.)
+    auto bulk_fill = [&](double* tp, int cnt) {
+      const int a0 = (int)((reinterpret_cast<unsigned long long>(tp) >> 3) & 127ull);
+      const int Aend = a0 + cnt, r128 = 128 % mm;
+      int idx = (2 * lane - a0) % mm;
+      if (idx < 0) idx += mm;
+      for (int Aw = 0; Aw < Aend; Aw += 128) {
+        const int i = Aw + 2 * lane - a0;
+        const int idx1 = (idx + 1 == mm) ? 0 : idx + 1;
+        const double2_t v = {STG[idx], STG[idx1]};
+        double* dst = tp + i;
+        if (Aw >= a0 && Aw + 128 <= Aend) {  // wave-uniform: a whole window
+          *reinterpret_cast<double2_t*>(dst) = v;
+        } else {
+          const bool k0 = i >= 0 && i < cnt, k1 = i + 1 >= 0 && i + 1 < cnt;
+          if (k0 && k1) *reinterpret_cast<double2_t*>(dst) = v;
+          else if (k0) dst[0] = v.x;
+          else if (k1) dst[1] = v.y;
+        }
+        idx += r128;
+        if (idx >= mm) idx -= mm;
+      }
+    };
+    // (tried: odd draws fill behind the mean loop instead of before it, so that the wavefronts of a SIMD stream and compute at the
+    // same time -- 14.9 ms against 13.0 at 16384 draws, 2.29 against 2.39 at 2048; not kept)
+    constexpr bool fill_first = true;
+    if (w_pP && pred_pending) {  // the slot of step t is still pending
+      flush_cov(t_pP);
+      t_pP += mm;
+      pred_pending = false;
+    }
+    double Pp[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) Pp[I] = P[I];
+    const int n_fill = (n - t) * mm;
+    if (w_pP && fill_first) {  // predicted covariances of steps t+1 .. n: the converged tile
+      stage_cov(Pp);
+      wave_lds_fence();
+      bulk_fill(t_pP, n_fill);
+      wave_lds_fence();
+    }
+    // step t: the ordinary update once more; it leaves W / Uh / u in their exchange slots
+    if ((t & (QLB - 1)) == 0) load_y_block(t);
+    {
+      const int e0 = (t & (QLB - 1)) * p;
+      group_update(0, e0, &d_c);
+      if (qs1 < p) single_update(qs1, e0, zq_r + qs1 * zq_s, zc_r + qs1 * 16, nullptr, &f_c, &rs_c);
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      Sm[I] = isJC ? P[I] : 0.0;
+      Cc[I] = isJC ? (HALF ? 2.0 * Ch[I] : Ch[I]) : 0.0;
+    }
+    if (isJC) {  // the constants' own mean entries (column JC of Uh / u) take no part in the mean tile's updates
+      rw[64] = 0.0;
+      rw[160] = 0.0;
+    }
+    wave_lds_fence();
+    if (w_fP && fill_first) {  // filtered covariances of steps t .. n-1
+      stage_cov(P);
+      wave_lds_fence();
+      bulk_fill(t_fP, n_fill);
+      wave_lds_fence();
+    }
+    // state tapes: column JC of the mean tile (lane (g, JC) of register I: 2 a[4 I + g]) through two LDS rings, out as aligned windows
+    TapeStream<128, 64> s_fa, s_pa;
+    s_fa.init(t_fa, PO);
+    s_pa.init(t_pa, PO + 128);
+    unsigned o_fa[NB], o_pa[NB];
+    bool a_on[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      a_on[I] = isJC && 4 * I + g < m;
+      o_fa[I] = s_fa.slot(a_on[I] ? 4 * I + g : 0);
+      o_pa[I] = s_pa.slot(a_on[I] ? 4 * I + g : 0);
+    }
+    auto put_state = [&](TapeStream<128, 64>& st, unsigned (&off)[NB]) {
+#pragma unroll
+      for (int I = 0; I < NB; ++I) {
+        if (a_on[I]) *reinterpret_cast<double*>(reinterpret_cast<char*>(st.ring) + off[I]) = Sm[I];
+        off[I] = TapeStream<128, 64>::next(off[I], m);
+      }
+      st.appended(m, lane, 0.5);
+    };
+    bool first = true;
+    for (; t < n; ++t) {
+      const int e0 = (t & (QLB - 1)) * p;
+      if (!first) {
+        if ((t & (QLB - 1)) == 0) load_y_block(t);
+        {
+          const int ob = g;
+          const bool valid = ob < p;
+          const double2_t yo = *reinterpret_cast<const double2_t*>(valid ? YB + 2 * (e0 + ob) : UX + 16);
+          const double* za = ZQ + qq * 16 + 4 * g;
+          const double2_t z01 = *reinterpret_cast<const double2_t*>(za);
+          const double2_t z23 = *reinterpret_cast<const double2_t*>(za + 2);
+          const double wv = *wx_r;
+          const double2_t u01 = *reinterpret_cast<const double2_t*>(ub_r);
+          const double2_t u23 = *reinterpret_cast<const double2_t*>(ub_r + 2);
+          double R = mfma4(z01.x, Sm[0], 0.0);
+          {
+            double R2 = mfma4(z01.y, Sm[1], 0.0);
+            R = mfma4(z23.x, Sm[2], R);
+            if (NB > 3) R2 = mfma4(z23.y, Sm[NB > 3 ? 3 : 0], R2);
+            R += R2;
+          }
+          const double Rm = R + (isJC ? yo.x : 0.0);
+          const double Uh = mfma4(wv, Rm, 0.0);
+          {
+            double2_t fq = {d_c, Uh};
+            if (valid && isJC) *reinterpret_cast<double2_t*>(RG + 2 * (e0 + ob)) = fq;
+          }
+          const double uT[4] = {u01.x, u01.y, u23.x, u23.y};
+#pragma unroll
+          for (int I = 0; I < NB; ++I) Sm[I] = mfma4_nega(uT[I], Uh, Sm[I]);
+        }
+        if (qs1 < p) {
+          const double2_t yo = *reinterpret_cast<const double2_t*>(YB + 2 * (e0 + qs1));
+          const double* zq = zq_r + qs1 * zq_s;
+          const double2_t z01 = *reinterpret_cast<const double2_t*>(zq);
+          const double2_t z23 = *reinterpret_cast<const double2_t*>(zq + 2);
+          const double2_t ur01 = *reinterpret_cast<const double2_t*>(ub_r + 96);
+          const double2_t ur23 = *reinterpret_cast<const double2_t*>(ub_r + 98);
+          double r = mfma4(z01.x, Sm[0], 0.0);
+          {
+            double r2 = mfma4(z01.y, Sm[1], 0.0);
+            r = mfma4(z23.x, Sm[2], r);
+            if (NB > 3) r2 = mfma4(z23.y, Sm[NB > 3 ? 3 : 0], r2);
+            r += r2;
+          }
+          const double uh = (r + ((lane == JC) ? yo.x : 0.0)) * rs_c;
+          {
+            double2_t fq = {f_c, uh};
+            if (lane == JC) *reinterpret_cast<double2_t*>(RG + 2 * (e0 + qs1)) = fq;
+          }
+          const double urep[4] = {ur01.x, ur01.y, ur23.x, ur23.y};
+#pragma unroll
+          for (int I = 0; I < NB; ++I) Sm[I] = mfma4_nega(urep[I] * rs_c, uh, Sm[I]);
+        }
+      }
+      first = false;
+      if (w_fa) put_state(s_fa, o_fa);
+      // predict: column JC of T_e Sm + C_e
+      double Sn[NB];
+#pragma unroll
+      for (int I = 0; I < NB; ++I) Sn[I] = mfma4(Ta[I][0], Sm[0], Cc[I]);
+#pragma unroll
+      for (int K = 1; K < NB; ++K)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) Sn[I] = mfma4(Ta[I][K], Sm[K], Sn[I]);
+#pragma unroll
+      for (int I = 0; I < NB; ++I) Sm[I] = Sn[I];
+      if (w_pa) put_state(s_pa, o_pa);
+      if ((t & (QLB - 1)) == QLB - 1) flush_ring(t - (QLB - 1), QLB);
+    }
+    s_fa.finish(lane, 0.5);
+    s_pa.finish(lane, 0.5);
+    if (!fill_first) {
+      if (w_pP) {
+        stage_cov(Pp);
+        wave_lds_fence();
+        bulk_fill(t_pP, n_fill);
+        wave_lds_fence();
+      }
+      if (w_fP) {
+        stage_cov(P);
+        wave_lds_fence();
+        bulk_fill(t_fP, n_fill);
+      }
+    }
   }
   if (pred_pending) flush_cov(t_pP);
   if (n & (QLB - 1)) flush_ring(n & ~(QLB - 1), n & (QLB - 1));
@@ -522,12 +762,17 @@ int kf_launch_forward_b4q(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) 
   // KF_B4Q_GROUP=0 in the environment: every observation one at a time (A/B measurements)
   const char* ge = getenv("KF_B4Q_GROUP");
   const bool grp = nb >= 3 && a.p >= 3 && !(ge && *ge && atoi(ge) == 0);
-#define KF_B4Q_LAUNCH2(NB_, TM_)                                                                                        \
-  do {                                                                                                                  \
-    if (grp && NB_ >= 3)                                                                                                \
-      hipLaunchKernelGGL((kf_fwd_b4q_kernel<NB_, TM_, (NB_ >= 3)>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); \
-    else                                                                                                                \
-      hipLaunchKernelGGL((kf_fwd_b4q_kernel<NB_, TM_, false>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);      \
+  // steady-state phase: its own instantiation (KF_FLAG_EXACT_RECURSION / KF_STEADY_STATE=0 run the kernel without it)
+  const char* sse = getenv("KF_STEADY_STATE");
+  const bool ss = grp && a.p <= 5 && a.T >= 64 && !(a.flags & KF_FLAG_EXACT_RECURSION) && !(sse && *sse && atoi(sse) == 0);
+#define KF_B4Q_LAUNCH2(NB_, TM_)                                                                                              \
+  do {                                                                                                                        \
+    if (ss && NB_ >= 3)                                                                                                       \
+      hipLaunchKernelGGL((kf_fwd_b4q_kernel<NB_, TM_, (NB_ >= 3), (NB_ >= 3)>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); \
+    else if (grp && NB_ >= 3)                                                                                                 \
+      hipLaunchKernelGGL((kf_fwd_b4q_kernel<NB_, TM_, (NB_ >= 3), false>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((kf_fwd_b4q_kernel<NB_, TM_, false, false>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);     \
   } while (0)
 #define KF_B4Q_LAUNCH(NB_)                           \
   do {                                               \

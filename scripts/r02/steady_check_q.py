@@ -1,0 +1,59 @@
+"""Steady-state phase of kf_forward_b4q.hip (C4) against the step-by-step recursion and the oracle."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+import workloads as W
+from oracle import kalman_numpy as kn
+from pymc_statespace_amd import KalmanEngine
+
+eng = KalmanEngine()
+TAPES = ["ll_obs", "filtered_states", "predicted_states", "filtered_covs", "predicted_covs"]
+def args(w, y=None):
+    return (w["y"] if y is None else y, w["a0"], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"])
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+for kw in (dict(B=12, n=400), dict(B=12, n=400, k=3, order=(1, 1)), dict(B=12, n=400, k=4, order=(2, 0)), dict(B=12, n=300, k=5, order=(2, 0))):
+    w = W.varmax(**kw)
+    B, m, p = w["T"].shape[0], w["m"], w["p"]
+    for missing in (False, True):
+        for ft in ("standard", "univariate", "cholesky"):
+            y = w["y"].copy()
+            if missing:
+                y[[5, 100]] = np.nan
+                y[150, 1] = np.nan
+            rng = np.random.default_rng(1)
+            c = 0.05 * rng.standard_normal((B, m)); d = 0.1 * rng.standard_normal((B, p))
+            ref = kn.kalman_filter(*args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact", cholesky_triangle="correct", partial_missing="delete")
+            for exact in (True, False):
+                res = eng.forward(*args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact", exact_recursion=exact, h_diagonal=True)
+                e = np.abs(res.logp.cpu().numpy() - ref["logp"]).max()
+                et = max(np.abs(getattr(res, k).cpu().numpy() - ref[k]).max() for k in TAPES)
+                print(f"p={p} m={m:2d} {eng.forward_kernel_name(B, y.shape[0], p, m, w['r'], ft, True):18s} missing={missing!s:5s} {ft:10s} exact={exact!s:5s} dlogp={e:.2e} dtape={et:.2e} info={int(res.info.abs().sum())}"
+                      + ("" if e < 1e-8 and et < 1e-9 else "   <<<<<< FAIL"), flush=True)
+
+for B in (16384, 2048):
+    w = W.varmax(B=B, n=1000)
+    dev = [eng.to_device(x) for x in args(w)]
+    out = {}
+    for exact in (True, False):
+        kw = dict(mvn_const="exact", h_diagonal=True, exact_recursion=exact)
+        full = eng.forward(*dev, **kw)
+        t_full = timeit(lambda: eng.forward(*dev, out=full, **kw))
+        lo = eng.forward(*dev, store_ll_obs=False, store_filtered=False, store_predicted=False, **kw)
+        t_lo = timeit(lambda: eng.forward(*dev, store_ll_obs=False, store_filtered=False, store_predicted=False, out=lo, **kw))
+        po = eng.forward(*dev, store_ll_obs=False, store_filtered=False, **kw)
+        t_po = timeit(lambda: eng.forward(*dev, store_ll_obs=False, store_filtered=False, out=po, **kw))
+        out[exact] = (full, lo)
+        print(f"C4 B={B} exact={exact!s:5s} full {t_full:6.2f} ms  logp-only {t_lo:6.2f} ms  pred-only {t_po:6.2f} ms", flush=True)
+    a, b_ = out[True][0], out[False][0]
+    print("   max |dlogp| %.2e (rel %.1e)  |dll_obs| %.1e  |dfa| %.1e  |dpa| %.1e  |dfP| %.1e  |dpP| %.1e   logp-only vs full: %.1e" % (
+        (a.logp - b_.logp).abs().max().item(), ((a.logp - b_.logp).abs() / a.logp.abs()).max().item(),
+        (a.ll_obs - b_.ll_obs).abs().max().item(), (a.filtered_states - b_.filtered_states).abs().max().item(),
+        (a.predicted_states - b_.predicted_states).abs().max().item(), (a.filtered_covs - b_.filtered_covs).abs().max().item(),
+        (a.predicted_covs - b_.predicted_covs).abs().max().item(), (out[False][1].logp - b_.logp).abs().max().item()))
+    del out, full, lo, po

@@ -1746,6 +1746,74 @@ def test_b4q_kernel_agrees_with_tile_kernel_at_c4_size(eng):
     assert not torch.equal(res["b4"][0], res["seq"][0])  # (different arithmetic: the switch did switch)
 
 
+@pytest.mark.parametrize("korder", [(5, (2, 1)), (3, (1, 1)), (4, (2, 0)), (5, (2, 0))], ids=["p5m15", "p3m6", "p4m8", "p5m10"])
+def test_b4q_kernel_steady_state_phase_matches_exact_recursion(eng, korder):
+    """VARMAX shapes (3 <= p <= 5): the steady-state phase (mean tile through the frozen update's MFMAs, covariance tapes
+    filled in bulk, state tapes through rings) against the step-by-step kernel and the oracle; missing rows and single
+    missing cells delay it; every tape subset."""
+    k, order = korder
+    w = W.varmax(B=12, n=400, k=k, order=order)
+    B, m, p = 12, w["m"], w["p"]
+    rng = np.random.default_rng(1)
+    c = 0.05 * rng.standard_normal((B, m))
+    d = 0.1 * rng.standard_normal((B, p))
+    for missing in (False, True):
+        y = w["y"].copy()
+        if missing:
+            y[[5, 100]] = np.nan
+            y[150, 1] = np.nan
+        for ft in ("standard", "univariate", "cholesky"):
+            ref = kn.kalman_filter(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact",
+                                   cholesky_triangle="correct", partial_missing="delete")
+            outs = {}
+            for exact in (True, False):
+                out = _np(eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact", exact_recursion=exact,
+                                      h_diagonal=True))
+                assert np.max(np.abs(out["logp"] - ref["logp"])) < 1e-8
+                for kk in TAPES:
+                    assert_allclose(out[kk], ref[kk], rtol=1e-9, atol=1e-9, err_msg=f"{ft} exact={exact} {kk}")
+                assert not out["info"].any()
+                outs[exact] = out
+            if m >= 8:  # (m <= 7 runs without groups and without the steady phase)
+                assert not np.array_equal(outs[True]["predicted_states"], outs[False]["predicted_states"])
+            assert_allclose(outs[True]["filtered_covs"], outs[False]["filtered_covs"], rtol=1e-10, atol=1e-12)
+    full = _np(eng.forward(*_args(w), mvn_const="exact", h_diagonal=True))
+    for sel in ((False, True, False), (False, False, True), (True, False, False), (False, False, False)):
+        r = eng.forward(*_args(w), mvn_const="exact", h_diagonal=True, store_ll_obs=sel[0], store_filtered=sel[1],
+                        store_predicted=sel[2])
+        assert_allclose(r.logp.cpu().numpy(), full["logp"], rtol=1e-13)
+        for kk in TAPES:
+            v = getattr(r, kk)
+            if v is not None:
+                assert_allclose(v.cpu().numpy(), full[kk], rtol=1e-12, atol=1e-13, err_msg=f"{sel} {kk}")
+
+
+def test_steady_state_tapes_do_not_write_outside(eng):
+    """Guard words around every tape of a run that spends most of its steps in the steady phase (bulk fills and ring
+    windows start and end in the middle of their aligned windows)."""
+    import torch
+
+    from pymc_statespace_amd.engine import FilterResult
+
+    for w, kw in ((W.varmax(B=5, n=203), dict(h_diagonal=True)), (W.structural(B=5, n=450), {})):
+        B, n, m = 5, w["y"].shape[0], w["m"]
+        ref = eng.forward(*_args(w), mvn_const="exact", exact_recursion=True, **kw)
+
+        def guarded(*shape):
+            flat = torch.full((int(np.prod(shape)) + 6,), float("nan"), device="cuda", dtype=torch.float64)
+            return flat, flat[3:3 + int(np.prod(shape))].view(*shape)
+
+        bufs = {k: guarded(*s) for k, s in dict(ll_obs=(B, n), filtered_states=(B, n, m), predicted_states=(B, n + 1, m),
+                                                filtered_covs=(B, n, m, m), predicted_covs=(B, n + 1, m, m)).items()}
+        out = FilterResult(logp=torch.empty(B, device="cuda", dtype=torch.float64),
+                           info=torch.empty(B, device="cuda", dtype=torch.int32), **{k: v[1] for k, v in bufs.items()})
+        eng.forward(*_args(w), mvn_const="exact", out=out, **kw)
+        for k, (flat, view) in bufs.items():
+            assert_allclose(view.cpu().numpy(), getattr(ref, k).cpu().numpy(), rtol=1e-9, atol=1e-10, err_msg=k)
+            gd = flat.cpu().numpy()
+            assert np.isnan(gd[:3]).all() and np.isnan(gd[-3:]).all(), f"{k}: wrote outside the tape"
+
+
 # ----------------------------------------------------------------------------------------------
 # accumulator-layout adjoint kernel (kf_backward_mfma.hip)
 # ----------------------------------------------------------------------------------------------
