@@ -169,6 +169,8 @@ def parse_args():
     ap.add_argument("--logp-only", action="store_true", help="skip the tapes (what NUTS consumes)")
     ap.add_argument("--cpu-sample", type=int, default=None)
     ap.add_argument("--no-ops", action="store_true", help="skip the untimed extras (logp only, logp + gradient, smoother)")
+    ap.add_argument("--exact-recursion", action="store_true",
+                    help="KF_FLAG_EXACT_RECURSION: the covariance recursion at every step (no steady-state phase)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-strong-probe", action="store_true",
                     help="N > 1, weak: skip the extra strong-scaling measurement")
@@ -225,6 +227,7 @@ def main():
     strong = args.scaling == "strong"
 
     eng = KalmanEngine(dev, lanes_per_draw=args.lanes)
+    eng.set_exact_recursion(args.exact_recursion)
     sk = ShardedKalman(eng)
     fkw = dict(filter_type=ft, mvn_const="exact", store_ll_obs=full or big, store_filtered=full,
                store_predicted=full)
@@ -343,6 +346,9 @@ def main():
                 "filter": ft, "outputs": "full_tape" if full else "logp_only",
                 "global_draws": B_global, "parallelism": f"draws sharded x{world}",
                 "draw_steps_per_s": B_global * n * args.steps / elapsed,
+                "covariance_recursion": "every step (KF_FLAG_EXACT_RECURSION)" if args.exact_recursion else
+                "until converged to 1e-15, then the mean only with the converged gain (library default; all outputs still "
+                "written; other_entry_points.forward_exact_recursion_ms is the same call with the recursion at every step)",
             },
         }
         diag = bool(p > 1 and np.all(base["H"] == base["H"] * np.eye(p)))
@@ -400,6 +406,11 @@ def main():
                                                               store_filtered=False, store_predicted=False, out=lo_res))
                 ops["logp_and_gradient_one_call_ms"] = _ms(lambda: eng.value_and_grad(*d, filter_type=ft, mvn_const="exact",
                                                                                       h_diagonal=True))
+                if not args.exact_recursion:
+                    ex_res = eng.forward(*d, exact_recursion=True, **fkw)
+                    ops["forward_exact_recursion_ms"] = _ms(lambda: eng.forward(*d, exact_recursion=True, out=ex_res, **fkw))
+                    ops["max_rel_dlogp_exact_vs_default"] = float(((ex_res.logp - res.logp).abs() / ex_res.logp.abs()).max())
+                    del ex_res
                 if full:
                     ops["rts_smoother_ms"] = _ms(lambda: eng.smooth(d[3], d[5], d[7], res.filtered_states,
                                                                      res.filtered_covs), reps=3)

@@ -20,6 +20,8 @@
 // Same contract and arithmetic as the other forward kernels (reference
 // pymc_statespace/filters/kalman_filter.py:126-252, 255-351, 444-505): expanded Joseph form,
 // P_hat = (S + S')/2 computed pairwise.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "kf_internal.h"
@@ -215,8 +217,37 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
 
   int info = 0;
   double ycur = s_yb[0];
-  for (int t = 0; t < n; ++t) {
+  // ---- steady state (kf_forward_b4.hip has the long version): once every draw of the wavefront has a predicted covariance that
+  // stopped moving (3e-16 of its largest entry, tested at the end of each block of S steps, no missing observation ahead) the
+  // gain, F and both covariances are constants and the loop at the end advances only the mean
+  // Each LANE decides for its own draw (and from then on keeps its covariance where it is, so that the results of a draw do not
+  // depend on its neighbours in the wavefront -- permuting a batch permutes its outputs bit for bit); the WAVEFRONT leaves the
+  // full loop when all of its lanes have.
+  const bool steady_en = !(A.flags & KF_FLAG_EXACT_RECURSION) && n >= 64;
+  int t_free = 0;  // first step behind the last missing observation of this lane's draw
+  if (steady_en) {
+    constexpr int LPD = KF_WAVE / DPW;  // lanes that share a draw slot: lane, lane + DPW, ...
+    int tn = -1;
+    const double* yb = A.y + (y_per_draw ? b * (long)n : 0L);
+    for (int tt = lane / DPW; tt < n; tt += LPD) {
+      const double yv = yb[tt];
+      if (yv != yv) tn = tt;
+    }
+#pragma unroll
+    for (int off = DPW; off < KF_WAVE; off <<= 1) tn = max(tn, __shfl_xor(tn, off));
+    t_free = tn + 1;
+  }
+  bool fz = false;
+  double Pold[M][M];
+  int t = 0;
+  for (; t < n; ++t) {
     const int s = t & (S - 1);
+    if (steady_en && s == S - 1) {
+#pragma unroll
+      for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = i; j < M; ++j) Pold[i][j] = P[i][j];
+    }
     const double yv = ycur;
     ycur = s_yb[s + 1];  // next step's y (slot S is the chunk's pad: re-read after the flush at a block boundary)
     const bool obs = !(yv != yv);
@@ -287,7 +318,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
           sij = fma(W[i][k], T[j][k], sij);
           sji = fma(W[j][k], T[i][k], sji);
         }
-        const double sm = 0.5 * (sij + sji);
+        const double sm = fz ? P[i][j] : 0.5 * (sij + sji);
         P[i][j] = sm;
         P[j][i] = sm;
       }
@@ -318,6 +349,107 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
     if (s == S - 1) {
       flush(t - (S - 1), S);
       ycur = s_yb[0];
+      if (steady_en && t + S < n) {
+        double dmax = 0.0, pmax = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int j = i; j < M; ++j) {
+            dmax = fmax(dmax, fabs(P[i][j] - Pold[i][j]));
+            pmax = fmax(pmax, fabs(P[i][j]));
+          }
+        bool still = true;
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int j = i; j < M; ++j) still = still && (P[i][j] == P[i][j]);  // (fmax drops NaNs)
+        fz = fz || (still && t >= t_free && dmax <= 3e-16 * pmax);
+        if (__all(fz)) {
+          ++t;
+          break;
+        }
+      }
+    }
+  }
+  if (t < n) {
+    // ---- steady-state steps t .. n-1 (t is a multiple of S) ------------------------------------------------------------------
+    double Mv[M], K[M], Pf[M][M];
+    double F = Hs;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      double sm = 0.0;
+#pragma unroll
+      for (int k = 0; k < M; ++k) sm = fma(P[i][k], Z[k], sm);
+      Mv[i] = sm;
+      F = fma(Z[i], sm, F);
+    }
+    const double Fraw = F;
+    const bool degenerate = univariate && F == 0.0;  // :468-471
+    F = degenerate ? F + 1e-8 : F;
+    if (!(F > 0.0) && info == 0 && !degenerate) info = ((t + 1) << 8) | 1;
+    const double invF = degenerate ? 0.0 : fast_rcp(F);
+#pragma unroll
+    for (int i = 0; i < M; ++i) K[i] = Mv[i] * invF;
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+      for (int j = i; j < M; ++j) {
+        double sm;
+        if (univariate) {
+          sm = P[i][j] - K[i] * K[j] * F;
+        } else {
+          sm = P[i][j] - K[i] * Mv[j];
+          sm = fma(-Mv[i], K[j], sm);
+          sm = fma(F * K[i], K[j], sm);
+        }
+        Pf[i][j] = sm;
+        Pf[j][i] = sm;
+      }
+    // the covariance rows of a block never change again: written to the LDS chunks once
+    if (w_fP || w_pP) {
+      for (int ss = 0; ss < S; ++ss) {
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            if (w_fP) s_fP[ss * MM + i * M + j] = Pf[i][j];
+            if (w_pP) s_pP[ss * MM + i * M + j] = P[i][j];
+          }
+      }
+    }
+    for (; t < n; ++t) {
+      const int s = t & (S - 1);
+      const double yv = ycur;
+      ycur = s_yb[s + 1];
+      double za = 0.0;
+#pragma unroll
+      for (int i = 0; i < M; ++i) za = fma(Z[i], a[i], za);
+      const double v = degenerate ? 0.0 : (yv + dsign * ds) - za;
+      double af[M];
+#pragma unroll
+      for (int i = 0; i < M; ++i) af[i] = fma(K[i], v, a[i]);
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        double sm = c[i];
+#pragma unroll
+        for (int k = 0; k < M; ++k) sm = fma(T[i][k], af[k], sm);
+        a[i] = sm;
+      }
+      s_lf[s] = Fraw;
+      s_lq[s] = v * v * invF;
+      s_lo[s] = 1.0;
+      if (w_fa) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) s_fa[s * M + i] = af[i];
+      }
+      if (w_pa) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) s_pa[s * M + i] = a[i];
+      }
+      if (s == S - 1) {
+        flush(t - (S - 1), S);
+        ycur = s_yb[0];
+      }
     }
   }
   if (n % S) flush(n - n % S, n % S);
@@ -349,9 +481,14 @@ int KF_CAT(kf_launch_forward_lane_m, KF_LANE_M)(kf_handle* h, const KfFwdArgs& a
   const long simds = (h && h->n_cu > 0 ? h->n_cu : 256) * 4L;
   const int dpw = a.B <= 4 * simds ? 4 : (a.B <= 16 * simds ? 16 : 64);
   const int mask = (a.filt_a ? 1 : 0) | (a.pred_a ? 2 : 0) | (a.filt_P ? 4 : 0) | (a.pred_P ? 8 : 0);
+  KfFwdArgs a_ = a;
+  {
+    const char* sse = getenv("KF_STEADY_STATE");  // =0: step-by-step recursion (A/B measurements), as KF_FLAG_EXACT_RECURSION
+    if (sse && *sse && atoi(sse) == 0) a_.flags |= KF_FLAG_EXACT_RECURSION;
+  }
 #define KF_LANE_LAUNCH2(D_, TM_)                                                                              \
   hipLaunchKernelGGL((kf_fwd_lane_kernel<M, D_, TM_>), dim3((unsigned)((a.B + D_ - 1) / D_)), dim3(KF_WAVE), \
-                     0, stream, a)
+                     0, stream, a_)
 #define KF_LANE_LAUNCH(D_)                                \
   do {                                                    \
     if (mask == 0) KF_LANE_LAUNCH2(D_, 0);                \

@@ -34,8 +34,8 @@ CASES = [("c1", {}, "standard"), ("c2", {}, "standard"), ("headline", {}, "stand
          ("c3", {}, "cholesky"), ("c4_m10", {"B": 2048}, "standard"), ("c4", {"B": 2048}, "standard"),
          ("c4", {"B": 2048}, "univariate"), ("c4_m10", {"B": 16384}, "standard"),
          ("c4", {"B": 16384}, "standard"), ("c4", {"B": 16384}, "univariate")]
-print("| workload | B | T | p,m,r | filter | kernel | fwd logp-only ms | fwd full-tape ms | evals/s (full) | HBM GB/s (full) | frac of 8 TB/s | fwd predicted-tape-only ms | bwd ms | logp + gradient, one call (kf_filter_value_and_grad) ms | smoother ms |")
-print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+print("| workload | B | T | p,m,r | filter | kernel | fwd logp-only ms | fwd full-tape ms | evals/s (full) | HBM GB/s (full) | frac of 8 TB/s | fwd predicted-tape-only ms | KF_FLAG_EXACT_RECURSION: logp-only ; full-tape ms | bwd ms | logp + gradient, one call (kf_filter_value_and_grad) ms | smoother ms |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 for name, kw, ft in CASES:
     w = W.WORKLOADS[name](**kw)
     B, n, p, m, r = w["B"], w["n"], w["p"], w["m"], w["r"]
@@ -52,6 +52,11 @@ for name, kw, ft in CASES:
     res_p = eng.forward(*d, filter_type=ft, store_ll_obs=False, store_filtered=False)
     t_pred = timeit(lambda: eng.forward(*d, filter_type=ft, out=res_p, store_ll_obs=False, store_filtered=False))
     del res_p
+    t_logp_x = timeit(lambda: eng.forward(*d, filter_type=ft, out=res_l, store_ll_obs=False, store_filtered=False,
+                                          store_predicted=False, exact_recursion=True))
+    res_x = eng.forward(*d, filter_type=ft, exact_recursion=True)
+    t_full_x = timeit(lambda: eng.forward(*d, filter_type=ft, out=res_x, exact_recursion=True))
+    del res_x
     try:
         t_bwd = timeit(lambda: eng.backward(*d, predicted_states=res.predicted_states,
                                             predicted_covs=res.predicted_covs, g_logp=gl, filter_type=ft,
@@ -70,6 +75,6 @@ for name, kw, ft in CASES:
     gbs = ab / t_full / 1e9
     print(f"| {name} | {B} | {n} | {p},{m},{r} | {ft} | {eng.forward_kernel_name(B, n, p, m, r, ft, True)} | "
           f"{t_logp * 1e3:.3f} | {t_full * 1e3:.3f} | {B / t_full:.3e} | {gbs:.0f} | {gbs / 8000:.3f} | "
-          f"{t_pred * 1e3:.3f} | {t_bwd * 1e3:.2f} | {t_vg * 1e3:.2f} | {t_sm * 1e3:.2f} |", flush=True)
+          f"{t_pred * 1e3:.3f} | {t_logp_x * 1e3:.3f} ; {t_full_x * 1e3:.3f} | {t_bwd * 1e3:.2f} | {t_vg * 1e3:.2f} | {t_sm * 1e3:.2f} |", flush=True)
     del d, res, res_l
     torch.cuda.empty_cache()

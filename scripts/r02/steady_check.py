@@ -18,7 +18,7 @@ def timeit(fn, n=10):
     return (time.perf_counter() - t0) / n * 1e3
 
 # small cases against the oracle: with / without missing rows, intercepts, every filter
-for name, kw in (("structural", dict(B=24, n=600)), ("arma11", dict(B=24, n=300))):
+for name, kw in (("structural", dict(B=24, n=600)), ("arma11", dict(B=24, n=600))):
     w = getattr(W, name)(**kw)
     B, m, p = w["T"].shape[0], w["m"], w["p"]
     for missing in (False, True):
