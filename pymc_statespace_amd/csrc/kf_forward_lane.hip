@@ -239,6 +239,165 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
   }
   bool fz = false;
   double Pold[M][M];
+  // DPW == 4 (SCAN): a frozen draw slot takes the sixteen steps of a block SIDE BY SIDE on its sixteen lanes.  The steady recursion
+  // is affine,  a_{t+1} = A a_t + w_t,  A = T - (T K) Z,  w_t = (T K)(y_t -+ d) + c,  so  a_{t+j} = A^j a_t + sum_{i<j} A^{j-1-i} w_{t+i}:
+  // a 4-level prefix scan over the lanes (shuffles within the slot; A^1, A^2, A^4, A^8 in registers), then every lane runs its own
+  // step from its own a_{t+j} and writes its row of the LDS block.  (A is the closed-loop matrix of the converged filter: stable.)
+  // A slot changes over at the block boundary behind ITS OWN convergence, whatever the other slots of the wavefront do (they keep
+  // stepping with the frozen slots' lanes idle), so a draw's bits do not depend on its neighbours.
+  constexpr bool SCAN = M <= 2 && DPW == 4 && S == 16;
+  const int jj = lane / DPW;
+  double zK[M], zTK[M], zAp[4][M][M], zAj[M][M], zInvF = 0.0, zFraw = 0.0;
+  bool zDegen = false;
+  auto freeze_consts = [&](int t_at) {
+    double Mv[M], Pf[M][M];
+    double F = Hs;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      double sm = 0.0;
+#pragma unroll
+      for (int k = 0; k < M; ++k) sm = fma(P[i][k], Z[k], sm);
+      Mv[i] = sm;
+      F = fma(Z[i], sm, F);
+    }
+    zFraw = F;
+    zDegen = univariate && F == 0.0;  // :468-471
+    F = zDegen ? F + 1e-8 : F;
+    if (!(F > 0.0) && info == 0 && !zDegen) info = ((t_at + 1) << 8) | 1;
+    zInvF = zDegen ? 0.0 : fast_rcp(F);
+#pragma unroll
+    for (int i = 0; i < M; ++i) zK[i] = Mv[i] * zInvF;
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+      for (int j = i; j < M; ++j) {
+        double sm;
+        if (univariate) {
+          sm = P[i][j] - zK[i] * zK[j] * F;
+        } else {
+          sm = P[i][j] - zK[i] * Mv[j];
+          sm = fma(-Mv[i], zK[j], sm);
+          sm = fma(F * zK[i], zK[j], sm);
+        }
+        Pf[i][j] = sm;
+        Pf[j][i] = sm;
+      }
+    // the covariance rows of a block never change again: written to the LDS chunks once
+    if (w_fP || w_pP) {
+      for (int ss = 0; ss < S; ++ss) {
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            if (w_fP) s_fP[ss * MM + i * M + j] = Pf[i][j];
+            if (w_pP) s_pP[ss * MM + i * M + j] = P[i][j];
+          }
+      }
+    }
+    if constexpr (SCAN) {
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        double sm = 0.0;
+#pragma unroll
+        for (int l = 0; l < M; ++l) sm = fma(T[i][l], zK[l], sm);
+        zTK[i] = sm;
+      }
+#pragma unroll
+      for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+          zAp[0][i][k] = fma(-zTK[i], Z[k], T[i][k]);
+          zAj[i][k] = (i == k) ? 1.0 : 0.0;
+        }
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int k = 0; k < M; ++k) {
+            double sm = 0.0;
+#pragma unroll
+            for (int l = 0; l < M; ++l) sm = fma(zAp[q - 1][i][l], zAp[q - 1][l][k], sm);
+            zAp[q][i][k] = sm;
+          }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // A^j by the bits of j
+        double Nx[M][M];
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int k = 0; k < M; ++k) {
+            double sm = 0.0;
+#pragma unroll
+            for (int l = 0; l < M; ++l) sm = fma(zAp[q][i][l], zAj[l][k], sm);
+            Nx[i][k] = sm;
+          }
+        const bool bit = ((jj >> q) & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int k = 0; k < M; ++k) zAj[i][k] = bit ? Nx[i][k] : zAj[i][k];
+      }
+    }
+  };
+  // the `cnt` steps of the current block (its y is in the LDS chunk) for a frozen slot: rows -> LDS, a <- the state behind the block
+  auto scan_block = [&](int cnt) {
+    const double yt = s_yb[jj] + dsign * ds;
+    double Sv[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) Sv[i] = fma(zTK[i], yt, c[i]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double rv[M];
+#pragma unroll
+      for (int i = 0; i < M; ++i) rv[i] = __shfl_up(Sv[i], (1 << q) * DPW, KF_WAVE);
+      const bool has = jj >= (1 << q);
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        double sm = Sv[i];
+#pragma unroll
+        for (int l = 0; l < M; ++l) sm = fma(zAp[q][i][l], rv[l], sm);
+        Sv[i] = has ? sm : Sv[i];
+      }
+    }
+    double x[M], af[M], ap[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const double ev = __shfl_up(Sv[i], DPW, KF_WAVE);
+      double sm = (jj >= 1) ? ev : 0.0;
+#pragma unroll
+      for (int l = 0; l < M; ++l) sm = fma(zAj[i][l], a[l], sm);
+      x[i] = sm;
+    }
+    double za = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) za = fma(Z[i], x[i], za);
+    const double v = zDegen ? 0.0 : yt - za;
+#pragma unroll
+    for (int i = 0; i < M; ++i) af[i] = fma(zK[i], v, x[i]);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      double sm = c[i];
+#pragma unroll
+      for (int k = 0; k < M; ++k) sm = fma(T[i][k], af[k], sm);
+      ap[i] = sm;
+    }
+    if (jj < cnt) {
+      s_lf[jj] = zFraw;
+      s_lq[jj] = v * v * zInvF;
+      s_lo[jj] = 1.0;
+      if (w_fa) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) s_fa[jj * M + i] = af[i];
+      }
+      if (w_pa) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) s_pa[jj * M + i] = ap[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) a[i] = __shfl(ap[i], d + DPW * (S - 1), KF_WAVE);  // the next block starts from the last lane's prediction
+  };
   int t = 0;
   for (; t < n; ++t) {
     const int s = t & (S - 1);
@@ -299,7 +458,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
       double sm = c[i];
 #pragma unroll
       for (int k = 0; k < M; ++k) sm = fma(T[i][k], af[k], sm);
-      a[i] = sm;
+      a[i] = (SCAN && fz) ? a[i] : sm;
 #pragma unroll
       for (int j = 0; j < M; ++j) {
         double w = 0.0;
@@ -323,30 +482,37 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
         P[j][i] = sm;
       }
     // the step's rows and likelihood terms -> the LDS block (replicas write what the owner writes, to the same address)
-    s_lf[s] = Fraw;
-    s_lq[s] = quad;
-    s_lo[s] = obs ? 1.0 : 0.0;
-    if (w_fa) {
+    if (!(SCAN && fz)) {
+      s_lf[s] = Fraw;
+      s_lq[s] = quad;
+      s_lo[s] = obs ? 1.0 : 0.0;
+      if (w_fa) {
 #pragma unroll
-      for (int i = 0; i < M; ++i) s_fa[s * M + i] = af[i];
-    }
-    if (w_fP) {
+        for (int i = 0; i < M; ++i) s_fa[s * M + i] = af[i];
+      }
+      if (w_fP) {
 #pragma unroll
-      for (int i = 0; i < M; ++i)
+        for (int i = 0; i < M; ++i)
 #pragma unroll
-        for (int j = 0; j < M; ++j) s_fP[s * MM + i * M + j] = Pf[i][j];
-    }
-    if (w_pa) {
+          for (int j = 0; j < M; ++j) s_fP[s * MM + i * M + j] = Pf[i][j];
+      }
+      if (w_pa) {
 #pragma unroll
-      for (int i = 0; i < M; ++i) s_pa[s * M + i] = a[i];
-    }
-    if (w_pP) {
+        for (int i = 0; i < M; ++i) s_pa[s * M + i] = a[i];
+      }
+      if (w_pP) {
 #pragma unroll
-      for (int i = 0; i < M; ++i)
+        for (int i = 0; i < M; ++i)
 #pragma unroll
-        for (int j = 0; j < M; ++j) s_pP[s * MM + i * M + j] = P[i][j];
+          for (int j = 0; j < M; ++j) s_pP[s * MM + i * M + j] = P[i][j];
+      }
     }
     if (s == S - 1) {
+      if constexpr (SCAN) {
+        if (__any(fz)) {
+          if (fz) scan_block(S);
+        }
+      }
       flush(t - (S - 1), S);
       ycur = s_yb[0];
       if (steady_en && t + S < n) {
@@ -363,7 +529,11 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
         for (int i = 0; i < M; ++i)
 #pragma unroll
           for (int j = i; j < M; ++j) still = still && (P[i][j] == P[i][j]);  // (fmax drops NaNs)
-        fz = fz || (still && t >= t_free && dmax <= 3e-16 * pmax);
+        const bool newly = !fz && still && t >= t_free && dmax <= 3e-16 * pmax;
+        if constexpr (SCAN) {
+          if (newly) freeze_consts(t + 1);
+        }
+        fz = fz || newly;
         if (__all(fz)) {
           ++t;
           break;
@@ -371,52 +541,24 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
       }
     }
   }
-  if (t < n) {
-    // ---- steady-state steps t .. n-1 (t is a multiple of S) ------------------------------------------------------------------
-    double Mv[M], K[M], Pf[M][M];
-    double F = Hs;
-#pragma unroll
-    for (int i = 0; i < M; ++i) {
-      double sm = 0.0;
-#pragma unroll
-      for (int k = 0; k < M; ++k) sm = fma(P[i][k], Z[k], sm);
-      Mv[i] = sm;
-      F = fma(Z[i], sm, F);
-    }
-    const double Fraw = F;
-    const bool degenerate = univariate && F == 0.0;  // :468-471
-    F = degenerate ? F + 1e-8 : F;
-    if (!(F > 0.0) && info == 0 && !degenerate) info = ((t + 1) << 8) | 1;
-    const double invF = degenerate ? 0.0 : fast_rcp(F);
-#pragma unroll
-    for (int i = 0; i < M; ++i) K[i] = Mv[i] * invF;
-#pragma unroll
-    for (int i = 0; i < M; ++i)
-#pragma unroll
-      for (int j = i; j < M; ++j) {
-        double sm;
-        if (univariate) {
-          sm = P[i][j] - K[i] * K[j] * F;
-        } else {
-          sm = P[i][j] - K[i] * Mv[j];
-          sm = fma(-Mv[i], K[j], sm);
-          sm = fma(F * K[i], K[j], sm);
-        }
-        Pf[i][j] = sm;
-        Pf[j][i] = sm;
+  if constexpr (SCAN) {
+    if (t < n) {  // every slot of the wavefront is frozen (t is a multiple of S)
+      for (; t < n; t += S) {
+        const int cnt = (n - t) < S ? (n - t) : S;
+        scan_block(cnt);
+        if (cnt == S) flush(t, S);
       }
-    // the covariance rows of a block never change again: written to the LDS chunks once
-    if (w_fP || w_pP) {
-      for (int ss = 0; ss < S; ++ss) {
-#pragma unroll
-        for (int i = 0; i < M; ++i)
-#pragma unroll
-          for (int j = 0; j < M; ++j) {
-            if (w_fP) s_fP[ss * MM + i * M + j] = Pf[i][j];
-            if (w_pP) s_pP[ss * MM + i * M + j] = P[i][j];
-          }
-      }
+    } else if ((n % S) != 0 && __any(fz)) {  // the last, partial block of the slots that froze while others kept stepping
+      if (fz) scan_block(n % S);
     }
+  } else if (t < n) {
+    // ---- steady-state steps t .. n-1 (t is a multiple of S), one after the other ----------------------------------------------------
+    freeze_consts(t);
+    const bool degenerate = zDegen;
+    const double Fraw = zFraw, invF = zInvF;
+    double K[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) K[i] = zK[i];
     for (; t < n; ++t) {
       const int s = t & (S - 1);
       const double yv = ycur;
