@@ -1788,6 +1788,50 @@ def test_b4q_kernel_steady_state_phase_matches_exact_recursion(eng, korder):
                 assert_allclose(v.cpu().numpy(), full[kk], rtol=1e-12, atol=1e-13, err_msg=f"{sel} {kk}")
 
 
+@pytest.mark.parametrize("pm", [(1, 3), (1, 9), (3, 9), (5, 12)], ids=["lane", "b4", "b4q_p3", "b4q_p5"])
+def test_steady_state_with_zero_innovation_variance(eng, pm):
+    """Known state, no noise: P = 0 is a fixpoint from the first step on, F == 0 at every step of the steady phase.  The
+    Univariate filter skips such observations (:468-471); the others flag the draw."""
+    p, m = pm
+    z = W.reference_test_inputs(p, m, 1, 120)
+    P0 = np.zeros_like(z["P0"])
+    Hz, Qz = np.zeros((1, p, p)), np.zeros((1, 1, 1))
+    for mvn in ("reference", "exact"):
+        r = eng.forward(z["y"], z["a0"], P0, z["T"], z["Z"], z["R"], Hz, Qz, filter_type="univariate", mvn_const=mvn)
+        f = kn.kalman_filter(z["y"], z["a0"], P0, z["T"], z["Z"], z["R"], Hz, Qz, filter_type="univariate", mvn_const=mvn)
+        assert not r.info.cpu().numpy().any()
+        assert_allclose(r.logp.cpu().numpy(), f["logp"], atol=1e-12)
+        for k in TAPES:
+            assert_allclose(getattr(r, k).cpu().numpy(), f[k], atol=1e-12, err_msg=k)
+    rs = eng.forward(z["y"], z["a0"], P0, z["T"], z["Z"], z["R"], Hz, Qz, filter_type="standard", h_diagonal=True)
+    assert rs.info.cpu().numpy()[0] == ((0 + 1) << 8 | 1) and not np.isfinite(rs.logp.cpu().numpy()).any()
+
+
+@pytest.mark.parametrize("name", ["structural", "varmax", "arma11"])
+def test_steady_state_per_draw_data_not_pd_and_nan_parameters(eng, name):
+    """y per draw with a late NaN in one draw (that draw enters the steady phase behind it), a draw with negative H, a draw
+    with a NaN in T: same flags as the step-by-step kernel, the other draws against the oracle."""
+    w = getattr(W, name)(B=9, n=300)
+    kw = dict(h_diagonal=True) if name == "varmax" else {}
+    yb = np.repeat(w["y"][None], 9, 0).copy()
+    yb[3, 250] = np.nan
+    H = w["H"].copy()
+    H[4] = -np.abs(H[4]) - 50.0 * np.eye(H.shape[-1])
+    T = w["T"].copy()
+    T[6, 0, 0] = np.nan
+    r = eng.forward(yb, w["a0"], w["P0"], T, w["Z"], w["R"], H, w["Q"], mvn_const="exact", **kw)
+    x = eng.forward(yb, w["a0"], w["P0"], T, w["Z"], w["R"], H, w["Q"], mvn_const="exact", exact_recursion=True, **kw)
+    assert np.array_equal(r.info.cpu().numpy(), x.info.cpu().numpy())
+    lp = r.logp.cpu().numpy()
+    assert np.isnan(lp[[4, 6]]).all()
+    good = np.array([0, 1, 2, 3, 5, 7, 8])
+    f = kn.kalman_filter(yb[good], *[w[k][good] for k in ("a0", "P0", "T", "Z", "R", "H", "Q")], mvn_const="exact",
+                         partial_missing="delete")
+    assert np.max(np.abs(lp[good] - f["logp"])) < 1e-8
+    for k in TAPES:
+        assert_allclose(getattr(r, k).cpu().numpy()[good], f[k], rtol=1e-9, atol=1e-9, err_msg=k)
+
+
 def test_steady_state_tapes_do_not_write_outside(eng):
     """Guard words around every tape of a run that spends most of its steps in the steady phase (bulk fills and ring
     windows start and end in the middle of their aligned windows)."""
