@@ -473,6 +473,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       }
       if (g == 0) *ux_w = o1;  // a_{t+1} (its JA / JC slots are rewritten at the top of the next step)
       if (w_fa) put_a(s_fa, o_fa, o2 + o2, row0);
+      // (tried: both constant covariance tapes written in one go at the start of this phase, as kf_forward_b4q.hip does -- headline
+      // 1.81 ms against 1.63, C3 6.7 against 6.2: the burst of stores delays the window flushes of the SIMD's other wavefronts)
       if (w_fP) put_P(s_fP, o_fP, Pf);
       if (w_pa) put_a(s_pa, o_pa, o1 + o1, row0);
       if (w_pP) put_P(s_pP, o_pP, P);
