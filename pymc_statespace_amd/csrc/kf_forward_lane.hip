@@ -62,7 +62,8 @@ struct LaneLds {
 // TM: which tapes are written, known at compile time (bit 0 filtered states, 1 predicted states, 2 filtered
 // covariances, 3 predicted covariances) -- a taken scalar branch costs about as much as four dependent FMAs and the
 // step had a dozen of them; TM < 0: decided at run time (the uncommon combinations)
-template <int M, int DPW, int TM>
+// SS: with the steady-state phase (KF_FLAG_EXACT_RECURSION runs the instantiation without it: the round-2 kernel as it was)
+template <int M, int DPW, int TM, bool SS>
 __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A) {
   using L = LaneLds<M, DPW>;
   constexpr int MM = M * M, S = L::S;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
   // Each LANE decides for its own draw (and from then on keeps its covariance where it is, so that the results of a draw do not
   // depend on its neighbours in the wavefront -- permuting a batch permutes its outputs bit for bit); the WAVEFRONT leaves the
   // full loop when all of its lanes have.
-  const bool steady_en = !(A.flags & KF_FLAG_EXACT_RECURSION) && n >= 64;
+  const bool steady_en = SS && n >= 64;
   int t_free = 0;  // first step behind the last missing observation of this lane's draw
   if (steady_en) {
     constexpr int LPD = KF_WAVE / DPW;  // lanes that share a draw slot: lane, lane + DPW, ...
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
   // step from its own a_{t+j} and writes its row of the LDS block.  (A is the closed-loop matrix of the converged filter: stable.)
   // A slot changes over at the block boundary behind ITS OWN convergence, whatever the other slots of the wavefront do (they keep
   // stepping with the frozen slots' lanes idle), so a draw's bits do not depend on its neighbours.
-  constexpr bool SCAN = M <= 2 && DPW == 4 && S == 16;
+  constexpr bool SCAN = SS && M <= 2 && DPW == 4 && S == 16;
   const int jj = lane / DPW;
   double zK[M], zTK[M], zAp[4][M][M], zAj[M][M], zInvF = 0.0, zFraw = 0.0;
   bool zDegen = false;
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
           sij = fma(W[i][k], T[j][k], sij);
           sji = fma(W[j][k], T[i][k], sji);
         }
-        const double sm = fz ? P[i][j] : 0.5 * (sij + sji);
+        const double sm = (SS && fz) ? P[i][j] : 0.5 * (sij + sji);
         P[i][j] = sm;
         P[j][i] = sm;
       }
@@ -628,9 +629,14 @@ int KF_CAT(kf_launch_forward_lane_m, KF_LANE_M)(kf_handle* h, const KfFwdArgs& a
     const char* sse = getenv("KF_STEADY_STATE");  // =0: step-by-step recursion (A/B measurements), as KF_FLAG_EXACT_RECURSION
     if (sse && *sse && atoi(sse) == 0) a_.flags |= KF_FLAG_EXACT_RECURSION;
   }
-#define KF_LANE_LAUNCH2(D_, TM_)                                                                              \
-  hipLaunchKernelGGL((kf_fwd_lane_kernel<M, D_, TM_>), dim3((unsigned)((a.B + D_ - 1) / D_)), dim3(KF_WAVE), \
-                     0, stream, a_)
+  const bool ss = !(a_.flags & KF_FLAG_EXACT_RECURSION) && a.T >= 64;
+#define KF_LANE_LAUNCH2(D_, TM_)                                                                                             \
+  do {                                                                                                                       \
+    if (ss)                                                                                                                  \
+      hipLaunchKernelGGL((kf_fwd_lane_kernel<M, D_, TM_, true>), dim3((unsigned)((a.B + D_ - 1) / D_)), dim3(KF_WAVE), 0, stream, a_);  \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((kf_fwd_lane_kernel<M, D_, TM_, false>), dim3((unsigned)((a.B + D_ - 1) / D_)), dim3(KF_WAVE), 0, stream, a_); \
+  } while (0)
 #define KF_LANE_LAUNCH(D_)                                \
   do {                                                    \
     if (mask == 0) KF_LANE_LAUNCH2(D_, 0);                \
