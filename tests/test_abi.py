@@ -21,6 +21,20 @@ def test_header_and_binding_agree():
     assert _header_functions() == sorted(_lib.EXPORTS)
 
 
+def test_flag_bits_of_the_binding_match_the_header():
+    from pymc_statespace_amd import _lib
+
+    src = open(os.path.join(ROOT, "include", "kf.h")).read()
+    bits = {name: int(sh) for name, sh in re.findall(r"\b(KF_FLAG_[A-Z_]+)\s*=\s*1u\s*<<\s*(\d+)", src)}
+    assert bits["KF_FLAG_MVN_CONST_EXACT"] == 0 and _lib.KF_FLAG_MVN_CONST_EXACT == 1 << 0
+    assert _lib.KF_FLAG_Y_PER_DRAW == 1 << bits["KF_FLAG_Y_PER_DRAW"]
+    assert _lib.KF_FLAG_H_DIAGONAL == 1 << bits["KF_FLAG_H_DIAGONAL"]
+    assert _lib.KF_FLAG_EXACT_RECURSION == 1 << bits["KF_FLAG_EXACT_RECURSION"]
+    for name, bit in _lib.KF_FLAG_TV.items():
+        assert bit == 1 << bits[f"KF_FLAG_TV_{name.upper()}"]
+    assert len(set(bits.values())) == len(bits)  # no two flags share a bit
+
+
 def test_library_exports_every_declared_symbol():
     from pymc_statespace_amd import _lib
 
