@@ -714,9 +714,14 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
     // measured (scripts/r02/smooth_sweep.py, 1000 steps, ms, against the elimination kernel): 4096 draws m = 5 / 7 / 8 / 10 / 11:
     // 2.3 / 2.5 / 4.1 / 4.8 / 5.1 against 3.8 / 4.5 / 5.3 / 6.6 / 7.1; m = 12 .. 15 (4 x 4 blocks: three wavefronts per SIMD,
     // two rounds at 4096 draws) 9.3 - 10.3 against 7.4 - 10.3, but 3.0 - 3.2 against 3.6 - 4.6 at 512 draws and 4.0 against 7.1
-    // on the C4 shard (m = 15, 2048 draws)
+    // on the C4 shard (m = 15, 2048 draws).  Re-measured at the end of round 2 (scripts/r02/smooth_sweep_m12.py, smooth_c4.py; 500 steps,
+    // dense random models, m = 12 / 13 / 14 / 15): 4096 draws 4.4 / 4.0 / 4.3 / 4.4 against 4.0 / 4.8 / 5.0 / 5.4, 8192 draws 6.5 / 7.2 / 7.3 /
+    // 7.9 against 7.1 / 8.7 / 9.1 / 9.7, 16384 draws 11.9 / 12.5 / 13.3 / 16.5 against 13.3 / 16.5 / 16.9 / 17.9; C4 (VARMA, m = 15, 1000
+    // steps) 16384 / 8192 / 4096 draws: 22.1 / 12.2 / 6.9 against 35.5 / 18.6 / 10.0 -- the one shape left to the elimination kernel is
+    // m = 12 between 3072 and 8192 draws
     const char* e = getenv("KF_SMOOTHER_B4");
-    const bool pick = (e && e[0]) ? e[0] != '0' : (a.m <= 11 || a.B <= 3L * 4 * (h->n_cu > 0 ? h->n_cu : 256));
+    const long wave3 = 3L * 4 * (h->n_cu > 0 ? h->n_cu : 256);
+    const bool pick = (e && e[0]) ? e[0] != '0' : (a.m != 12 || a.B <= wave3 || a.B >= 8192);
     if (pick) return kf_launch_smoother_b4(h, a, workspace, workspace_bytes, (hipStream_t)stream);
   }
   // 5 <= m <= 16: register-tile smoother when the caller provided the (tiny) flag workspace
