@@ -138,8 +138,8 @@ const char* kf_last_error(const kf_handle* h);
 int kf_set_lanes_per_draw(kf_handle* h, int lanes);
 
 /* Forward-kernel selection.  AUTO (static matrices): p == 1, m <= 14 -> 4x4x4-block MFMA kernel with
- * the state vector carried in the covariance tile, one wavefront per draw ("b4": always for m >= 10;
- * for m = 7..9 and m = 4..6 while the batch cannot fill the chip with packed wavefronts, for m = 3
+ * the state vector carried in the covariance tile, one wavefront per draw ("b4": always for m >= 9;
+ * for m = 7, 8 and m = 4..6 while the batch cannot fill the chip with packed wavefronts, for m = 3
  * up to 2048 draws), else one lane per draw, 4 / 16 / 64 draws per wavefront by batch size ("lane", m <= 4: always for
  * m <= 2) / register-resident row-owner kernels
  * ("row", m <= 9); 2 <= p <= 8 scalar observations (UnivariateFilter / KF_FLAG_H_DIAGONAL), m <= 15 -> the same block

@@ -140,7 +140,9 @@ static bool kf_wg_ok(const kf_handle* h, int m, int p, int r, int filter, unsign
 //   32768 draws x 200 steps, m <= 8: the lane / row kernels win (64 / m draws per wavefront)
 // -> one wavefront per draw pays as soon as the batch cannot fill the chip with packed wavefronts
 static bool kf_b4_auto(const kf_handle* h, int m, long B) {
-  if (m >= 10) return true;
+  // (m = 9, re-measured with the row kernel at 16384 / 65536 draws x 500 steps: 3.4 / 12.7 ms against 5.1 / 17.0 with every step,
+  // 2.7 / 9.8 with the steady-state phase; logp only 2.1 / 7.5 against 2.6 / 7.5 -- scripts/r02/b4_auto_sweep.py)
+  if (m >= 9) return true;
   const long n_simd = (h ? h->n_cu : 256) * 4L;
   if (m >= 7) return (B * m + KF_WAVE - 1) / KF_WAVE < 2 * n_simd;  // else the row kernel (as before)
   if (m >= 4) return B < 16384;

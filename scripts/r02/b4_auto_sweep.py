@@ -11,18 +11,20 @@ def timeit(fn, n=3):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 n = 500
-for m in (3, 4, 6, 8, 9):
-    for B in (4096, 16384, 65536):
+import os
+EX = os.environ.get("EXACT") == "1"
+for m in (5, 6, 7, 8, 9):
+    for B in (16384, 65536):
         w = W.random_dense(B, n, 1, m, min(m, 3), seed=m)
         dev = [eng.to_device(x) for x in args(w)]
         row = f"m={m} B={B:6d} T={n}:"
         for kern in ("auto", "b4"):
             eng.set_forward_kernel(kern)
             name = eng.forward_kernel_name(B, n, 1, m, min(m, 3))
-            full = eng.forward(*dev, mvn_const="exact")
-            t_full = timeit(lambda: eng.forward(*dev, mvn_const="exact", out=full))
-            lo = eng.forward(*dev, mvn_const="exact", store_ll_obs=False, store_filtered=False, store_predicted=False)
-            t_lo = timeit(lambda: eng.forward(*dev, mvn_const="exact", store_ll_obs=False, store_filtered=False, store_predicted=False, out=lo))
+            full = eng.forward(*dev, mvn_const="exact", exact_recursion=EX)
+            t_full = timeit(lambda: eng.forward(*dev, mvn_const="exact", exact_recursion=EX, out=full))
+            lo = eng.forward(*dev, mvn_const="exact", exact_recursion=EX, store_ll_obs=False, store_filtered=False, store_predicted=False)
+            t_lo = timeit(lambda: eng.forward(*dev, mvn_const="exact", exact_recursion=EX, store_ll_obs=False, store_filtered=False, store_predicted=False, out=lo))
             row += f"  {name:22s} full {t_full:6.2f} logp {t_lo:6.2f}"
             del full, lo
         eng.set_forward_kernel("auto")
