@@ -40,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 measured copy)
+PARITY_REL_FAIL = 1e-10   # the run exits non-zero when any draw's |dlogp| / max(1, |logp|) exceeds this
 FP64_MFMA_PEAK_TF = 78.6  # dense fp64 matrix peak; v_mfma_f64_16x16x4_f64 measured at 45.2 TF with
 #                           register operands only (profiles/r01/fp64_issue_rates.txt)
 
@@ -72,7 +73,33 @@ def executed_flops_big(B, n, m):
     return 4.0 * m ** 3 * B * n
 
 
-def cpu_baseline(w, filter_type, full_tape=True, target_s=12.0, n_sample=None, n_steps=None):
+def usable_cores():
+    """Cores this process may actually run on: the scheduler affinity mask, capped by the cgroup CPU
+    quota when one is set (os.cpu_count() reports the machine, not the share a container gets)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
+def cpu_baseline(w, filter_type, full_tape=True, target_s=12.0, n_sample=None, n_steps=None, mvn_const="exact"):
     """The C restatement of the reference algorithm (oracle/kf_oracle.c, kind "port") on the
     host cores, on the leading draws of the SAME workload, computing the same outputs.
     Built here, on the box that times it, with -O3 -march=native (oracle/Makefile `native`).
@@ -85,7 +112,7 @@ def cpu_baseline(w, filter_type, full_tape=True, target_s=12.0, n_sample=None, n
     from oracle import c_oracle as co
 
     flavour = co.use_native()
-    cores = os.cpu_count() or 1
+    cores, quota = usable_cores()
     B = w["B"]
     chunk = min(max(8, 4 * cores), B)
     n_all = w["n"]
@@ -99,7 +126,7 @@ def cpu_baseline(w, filter_type, full_tape=True, target_s=12.0, n_sample=None, n
         sl = slice(lo, hi)
         return co.kalman_filter(w["y"], w["a0"][sl], w["P0"][sl], w["T"][sl], w["Z"][sl],
                                 w["R"][sl], w["H"][sl], w["Q"][sl], filter_type=filter_type,
-                                full=full, nthreads=cores, out=out)
+                                mvn_const=mvn_const, full=full, nthreads=cores, out=out)
 
     buf = run(0, chunk)          # untimed: loads the library, touches the tape buffer
     t0 = time.perf_counter()
@@ -120,6 +147,8 @@ def cpu_baseline(w, filter_type, full_tape=True, target_s=12.0, n_sample=None, n
     dt = time.perf_counter() - t0
     frac = w["n"] / n_all
     out = dict(value=n_sample * frac / dt, unit="evals/s", cores=cores, kind="port",
+               cores_note=f"threads used = min(sched_getaffinity = {len(os.sched_getaffinity(0))}, cgroup cpu quota = "
+                          f"{'none' if quota is None else f'{quota:.1f}'}); os.cpu_count() = {os.cpu_count()}",
                sample=f"first {n_sample} draws x {'all' if frac == 1.0 else 'the first'} {w['n']} "
                       f"{'' if frac == 1.0 else f'of {n_all} '}steps of the same workload"
                       f"{'' if frac == 1.0 else ' (scaled to whole evaluations)'}, "
@@ -323,6 +352,7 @@ def main():
             }
         dist.barrier()
 
+    parity_failed = False
     if rank == 0:
         out = {
             "metric": "Kalman logp evals/sec (batch x T x m)",
@@ -422,7 +452,7 @@ def main():
             # GATHERED log-likelihoods (rank 0's own draws lead the gathered vector)
             ns_cpu = 48 if big else None
             cpu_logp, cb = cpu_baseline(w_mine if not strong else base, ft, full,
-                                        n_sample=args.cpu_sample, n_steps=ns_cpu)
+                                        n_sample=args.cpu_sample, n_steps=ns_cpu, mvn_const=fkw["mvn_const"])
             ns = min(cpu_logp.shape[0], B_local)
             out["cpu_baseline"] = cb
             if ns_cpu is None:
@@ -430,12 +460,21 @@ def main():
             else:  # the oracle ran a prefix of the series: compare with the same prefix of ll_obs
                 gpu_lp = res.ll_obs[:ns, :ns_cpu].sum(-1).cpu().numpy()
             dl = np.abs(gpu_lp - cpu_logp[:ns])
-            out["parity"] = {"max_abs_dlogp_vs_oracle": float(dl.max()), "draws_checked": int(ns),
-                             "max_abs_logp": float(np.abs(cpu_logp).max())}
+            rel = dl / np.maximum(1.0, np.abs(cpu_logp[:ns]))
+            # the tolerance of tests/test_gpu_parity.py: 1e-8 absolute on |logp| <= 1e4, relative beyond
+            tol = 1e-8 * np.maximum(1.0, np.abs(cpu_logp[:ns]) / 1e4)
+            ok = bool(np.all(dl <= tol) and rel.max() <= PARITY_REL_FAIL)
+            out["parity"] = {"max_abs_dlogp_vs_oracle": float(dl.max()), "max_rel_dlogp_vs_oracle": float(rel.max()),
+                             "draws_checked": int(ns), "max_abs_logp": float(np.abs(cpu_logp).max()),
+                             "mvn_const": fkw["mvn_const"], "tolerance": "1e-8 * max(1, |logp| / 1e4) per draw",
+                             "pass": ok}
+            parity_failed = not ok
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        sys.exit("bench.py: the in-run parity check against the oracle FAILED (see the parity object)")
 
 
 if __name__ == "__main__":

@@ -13,6 +13,24 @@ import sys
 from collections import defaultdict
 
 
+def _commit():
+    """The commit the measured tree was built from: KF_COMMIT, else the stamp scripts/grun.sh writes before
+    the snapshot leaves for the GPU box (there is no .git there), else git itself."""
+    c = os.environ.get("KF_COMMIT")
+    if c:
+        return c
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        return open(os.path.join(root, ".kf_commit")).read().strip() or "unknown"
+    except OSError:
+        pass
+    try:
+        import subprocess
+        return subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:  # noqa: BLE001
+        return "unknown"
+
+
 def find(d, pat):
     return sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
 
@@ -82,7 +100,7 @@ def main():
         cfg = bench["config"]
         key = f"{bench['config']['workload'].split(':')[0]}:{'full' if cfg['outputs'] == 'full_tape' else 'logp'}:B{cfg['draws_per_gpu']}"
         top = max(entries, key=lambda e: e["bytes"])
-        top.update(key=key, commit=os.environ.get("KF_COMMIT", "unknown"),
+        top.update(key=key, commit=_commit(),
                    source=f"{os.path.basename(out.rstrip('/'))}: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, "
                           "write + 2 x fetch (gfx950 wide-read correction)")
         json.dump(top, open(os.path.join(out, "traffic_entry.json"), "w"), indent=1)
