@@ -14,8 +14,9 @@ executable contract for an environment that has PyTensor (it skips here).
 
 What crosses PCIe.  ``perform`` receives host numpy arrays and must return host numpy arrays, so every
 output the graph consumes is copied back; the covariance tapes are (2n + 1) m^2 doubles per draw.
-  * ``KalmanFilterOp.perform`` asks its FunctionGraph which outputs have clients and computes / copies
-    ONLY those (``store_*`` flags of ``kf_filter_forward``); without that information it computes all six.
+  * ``KalmanFilterOp`` carries a ``want`` mask chosen when the graph is built (``build_graph(..., outputs=(names))``,
+    default all six as the reference returns them) and computes / copies ONLY those (``store_*`` flags of
+    ``kf_filter_forward``); an output that is not wanted is a zero-size placeholder.
   * ``KalmanLogpOp`` -- one output, ``logp``, plus the gradients as extra outputs of the SAME node --
     is what ``build_graph(..., outputs="logp")`` returns: forward (predicted tapes stay in HBM) and
     adjoint run back to back on the device, 8 + (2 m^2 + ...) * 8 bytes come back, and ``L_op`` reuses
@@ -277,14 +278,22 @@ def perform_smoother(T, R, Q, filtered_states, filtered_covs, engine=None):
 _OPS = None
 
 
-def _outputs_with_clients(node):
-    """Which outputs of ``node`` does its FunctionGraph consume (another node, or a function output)?
-    All of them when the node is not in a graph (eager ``Op.perform`` calls, old PyTensor)."""
-    fg = getattr(node, "fgraph", None)
-    clients = getattr(fg, "clients", None)
-    if clients is None:
-        return tuple(True for _ in node.outputs)
-    return tuple(bool(clients.get(o)) for o in node.outputs)
+OUTPUT_NAMES = ("filtered_states", "predicted_states", "filtered_covariances", "predicted_covariances",
+                "log_likelihood", "ll_obs")
+
+
+def want_mask(outputs):
+    """``outputs`` of build_graph -> six booleans in the reference's output order (kalman_filter.py:184-191).
+    "all": every output; otherwise an iterable of names from OUTPUT_NAMES.  The mask is a property of the Op
+    chosen when the graph is BUILT: ``perform`` receives no FunctionGraph in current PyTensor (Apply nodes
+    do not carry one), so which outputs have clients cannot be looked up at run time."""
+    if outputs == "all" or outputs is None:
+        return (True,) * 6
+    names = (outputs,) if isinstance(outputs, str) else tuple(outputs)
+    unknown = [nm for nm in names if nm not in OUTPUT_NAMES]
+    if unknown:
+        raise ValueError(f"unknown filter output(s) {unknown}; choose from {OUTPUT_NAMES}")
+    return tuple(nm in names for nm in OUTPUT_NAMES)
 
 
 def _build_ops():
@@ -328,10 +337,11 @@ def _build_ops():
     class KalmanFilterOp(Op):
         """[filtered_states, predicted_states, filtered_covs, predicted_covs, logp, ll_obs]
         = Op(data, a0, P0, T, Z, R, H, Q, c, d)   -- reference kalman_filter.py:184-191."""
-        __props__ = ("filter_type", "mvn_const", "h_diagonal")
+        __props__ = ("filter_type", "mvn_const", "h_diagonal", "want")
 
-        def __init__(self, filter_type="standard", mvn_const="reference", h_diagonal=False):
+        def __init__(self, filter_type="standard", mvn_const="reference", h_diagonal=False, want=(True,) * 6):
             self.filter_type, self.mvn_const, self.h_diagonal = filter_type, mvn_const, bool(h_diagonal)
+            self.want = tuple(bool(w) for w in want)
 
         def make_node(self, data, a0, P0, T, Z, R, H, Q, c, d):
             ins = [pt.as_tensor_variable(x) for x in (data, a0, P0, T, Z, R, H, Q, c, d)]
@@ -340,7 +350,7 @@ def _build_ops():
             return Apply(self, ins, outs)
 
         def perform(self, node, inputs, output_storage):
-            want = _outputs_with_clients(node)
+            want = self.want
             outs = perform_filter(*inputs, filter_type=self.filter_type, mvn_const=self.mvn_const,
                                   h_diagonal=self.h_diagonal, want=want)
             for storage, o, var in zip(output_storage, outs, node.outputs):
@@ -367,6 +377,16 @@ def _build_ops():
                             "covariance tapes are not differentiated by the HIP backward kernel")
                         for k in range(1, 10)]
             g_logp, g_ll = output_grads[4], output_grads[5]
+            if not (self.want[1] and self.want[3]):
+                # the predicted tapes the adjoint kernel reads were not requested from this node: differentiate logp
+                # through the fused value-and-gradient node instead (ll_obs cotangents need the tapes)
+                if not isinstance(g_ll.type, DisconnectedType):
+                    return [DisconnectedType()()] + [
+                        grad_not_implemented(self, k, inputs[k], "a cotangent on ll_obs needs the predicted tapes: "
+                                             "request predicted_states and predicted_covariances")
+                        for k in range(1, 10)]
+                fused = KalmanLogpOp(self.filter_type, self.mvn_const, self.h_diagonal)(*inputs)
+                return [DisconnectedType()()] + [g_logp * fused[1 + k] for k in range(9)]
             if isinstance(g_logp.type, DisconnectedType):
                 g_logp = pt.zeros_like(outputs[4])
             if isinstance(g_ll.type, DisconnectedType):
@@ -407,10 +427,11 @@ def _build_ops():
 
     class KalmanFilterBatchedOp(Op):
         """KalmanFilterOp with a leading draw axis B on a0 .. d (data shared): outputs B-leading."""
-        __props__ = ("filter_type", "mvn_const", "h_diagonal")
+        __props__ = ("filter_type", "mvn_const", "h_diagonal", "want")
 
-        def __init__(self, filter_type="standard", mvn_const="reference", h_diagonal=False):
+        def __init__(self, filter_type="standard", mvn_const="reference", h_diagonal=False, want=(True,) * 6):
             self.filter_type, self.mvn_const, self.h_diagonal = filter_type, mvn_const, bool(h_diagonal)
+            self.want = tuple(bool(w) for w in want)
 
         def make_node(self, data, a0, P0, T, Z, R, H, Q, c, d):
             ins = [pt.as_tensor_variable(x) for x in (data, a0, P0, T, Z, R, H, Q, c, d)]
@@ -419,7 +440,7 @@ def _build_ops():
             return Apply(self, ins, outs)
 
         def perform(self, node, inputs, output_storage):
-            want = _outputs_with_clients(node)
+            want = self.want
             outs = perform_filter_batched(*inputs, filter_type=self.filter_type, mvn_const=self.mvn_const,
                                           h_diagonal=self.h_diagonal, want=want)
             for storage, o, var in zip(output_storage, outs, node.outputs):
@@ -457,10 +478,11 @@ def _build_ops():
     class SteadyStateFilterOp(Op):
         """The six reference outputs of SteadyStateFilter.build_graph (kalman_filter.py:364-397) from one node:
         kf_dare + the Standard recursion from P_steady; gradients (through logp / ll_obs) include the Riccati solve."""
-        __props__ = ("mvn_const",)
+        __props__ = ("mvn_const", "want")
 
-        def __init__(self, mvn_const="reference"):
+        def __init__(self, mvn_const="reference", want=(True,) * 6):
             self.mvn_const = mvn_const
+            self.want = tuple(bool(w) for w in want)
 
         def make_node(self, data, a0, P0, T, Z, R, H, Q, c, d):
             ins = [pt.as_tensor_variable(x) for x in (data, a0, P0, T, Z, R, H, Q, c, d)]
@@ -469,7 +491,7 @@ def _build_ops():
             return Apply(self, ins, outs)
 
         def perform(self, node, inputs, output_storage):
-            want = _outputs_with_clients(node)
+            want = self.want
             outs = perform_steady_state(*inputs, mvn_const=self.mvn_const, want=want)
             for storage, o, var in zip(output_storage, outs, node.outputs):
                 storage[0] = (np.ascontiguousarray(o, dtype=np.float64) if o is not None
@@ -541,7 +563,7 @@ def _build_ops():
                     raise NotImplementedError("one leading batch axis only")
             mats = [x if x.type.ndim == nd + 1 else pt.broadcast_to(x, (B,) + tuple(x.shape))
                     for x, nd in zip(mats, core)]
-            return KalmanFilterBatchedOp(op.filter_type, op.mvn_const, op.h_diagonal).make_node(data, *mats)
+            return KalmanFilterBatchedOp(op.filter_type, op.mvn_const, op.h_diagonal, op.want).make_node(data, *mats)
     except ImportError:  # pragma: no cover - older PyTensor
         pass
 
@@ -582,7 +604,8 @@ def kalman_filter_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type
     ``h_diagonal=True``: the model's H is diagonal by construction (e.g. VARMAX measurement
     error, reference models/VARMAX.py:80-83) -- the gradient then runs on the scalar-observation
     adjoint kernel and is returned for diag(H) only (KF_FLAG_H_DIAGONAL, include/kf.h).
-    ``outputs="logp"`` returns the log-likelihood alone, from ``KalmanLogpOp``."""
+    ``outputs="logp"`` returns the log-likelihood alone, from ``KalmanLogpOp``; an iterable of names from
+    ``OUTPUT_NAMES`` keeps the six-element return list but computes / copies back only the named outputs."""
     ops = _build_ops()
     pt = ops["pt"]
     T, Z, R, H, Q = (pt.as_tensor_variable(x) for x in (T, Z, R, H, Q))
@@ -597,7 +620,7 @@ def kalman_filter_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type
         d = pt.zeros((Z.shape[-2], 1))
     if outputs == "logp":  # the sampler's path: value and gradient from one node, no tapes over PCIe
         return ops["KalmanLogpOp"](filter_type, mvn_const, h_diagonal)(data, a0, P0, T, Z, R, H, Q, c, d)[0]
-    return list(ops["KalmanFilterOp"](filter_type, mvn_const, h_diagonal)(
+    return list(ops["KalmanFilterOp"](filter_type, mvn_const, h_diagonal, want_mask(outputs))(
         data, a0, P0, T, Z, R, H, Q, c, d))
 
 
@@ -615,7 +638,7 @@ def steady_state_filter_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, mvn_c
         d = pt.zeros((Z.shape[0], 1))
     if outputs == "logp":
         return ops["SteadyStateLogpOp"](mvn_const)(data, a0, P0, T, Z, R, H, Q, c, d)[0]
-    return list(ops["SteadyStateFilterOp"](mvn_const)(data, a0, P0, T, Z, R, H, Q, c, d))
+    return list(ops["SteadyStateFilterOp"](mvn_const, want_mask(outputs))(data, a0, P0, T, Z, R, H, Q, c, d))
 
 
 def kalman_smoother_graph(T, R, Q, filtered_states, filtered_covariances):

@@ -36,6 +36,19 @@ def h_is_diagonal(H):
     return bool(np.all(off == 0))
 
 
+def use_pytensor_or_standin():
+    """The real PyTensor when it is installed, else tests/_pytensor_shim (a TEST-ONLY stand-in for the graph
+    classes pymc_statespace_amd/op.py touches; see its _core.py).  Only tests call this."""
+    try:
+        import pytensor
+    except ImportError:
+        shim = os.path.join(ROOT, "tests", "_pytensor_shim")
+        if shim not in sys.path:
+            sys.path.insert(0, shim)
+        import pytensor
+    return pytensor
+
+
 @pytest.fixture(scope="session")
 def has_gpu():
     import torch

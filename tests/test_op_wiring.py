@@ -1,0 +1,94 @@
+"""Graph-level wiring of the PyTensor Ops (pymc_statespace_amd/op.py) that needs no GPU: arity and types of every
+``make_node``, ``connection_pattern`` shapes, ``__props__`` equality, which nodes ``grad`` / ``vectorize_graph``
+create.  Runs against the real PyTensor when installed, else against the test-only stand-in
+(tests/_pytensor_shim).  The numeric half (perform / L_op values) is tests/test_pytensor_op.py, on the GPU.
+Reference pattern: pymc_statespace/utils/pytensor_scipy.py:11-60; caller core/statespace.py:146-197."""
+import pytest
+
+from conftest import use_pytensor_or_standin
+
+pytensor = use_pytensor_or_standin()
+
+
+def _symbols():
+    import pytensor.tensor as pt
+
+    return [pt.tensor3("data"), pt.matrix("a0")] + [pt.matrix(nm) for nm in ("P0", "T", "Z", "R", "H", "Q")]
+
+
+def _op_names(f):
+    return [type(nd.op).__name__ for nd in f.maker.fgraph.toposort()]
+
+
+def test_every_op_class_builds_a_node_with_the_reference_arity():
+    import pytensor.tensor as pt
+
+    from pymc_statespace_amd import op
+
+    ops = op._build_ops()
+    sym = _symbols()
+    c, d = pt.matrix("c"), pt.matrix("d")
+    ins = sym + [c, d]
+    six = [3, 3, 3, 3, 0, 1]       # kalman_filter.py:184-191: ndim of the six outputs
+    for name in ("KalmanFilterOp", "SteadyStateFilterOp"):
+        node = ops[name]().make_node(*ins)
+        assert len(node.inputs) == 10 and [o.type.ndim for o in node.outputs] == six, name
+        pat = node.op.connection_pattern(node)
+        assert len(pat) == 10 and all(len(row) == 6 for row in pat) and not any(pat[0])
+    for name in ("KalmanLogpOp", "SteadyStateLogpOp"):
+        node = ops[name]().make_node(*ins)
+        assert [o.type.ndim for o in node.outputs] == [0] + [v.type.ndim for v in ins[1:]], name
+        pat = node.op.connection_pattern(node)
+        assert len(pat) == 10 and all(len(row) == 10 for row in pat) and not any(pat[0])
+        assert all(row == [True] + [False] * 9 for row in pat[1:])
+    node = ops["KalmanFilterBatchedOp"]().make_node(sym[0], *[pt.tensor3(f"b{k}") for k in range(9)])
+    assert [o.type.ndim for o in node.outputs] == [4, 4, 4, 4, 1, 2]
+    node = ops["KalmanSmootherOp"]().make_node(sym[3], sym[5], sym[7], pt.tensor3("fs"), pt.tensor3("fP"))
+    assert len(node.inputs) == 5 and [o.type.ndim for o in node.outputs] == [3, 3]
+    node = ops["KalmanFilterGradOp"]().make_node(*ins, pt.tensor3("pa"), pt.tensor3("pP"), pt.scalar("g"), pt.vector("gl"))
+    assert len(node.inputs) == 14 and [o.type.ndim for o in node.outputs] == [v.type.ndim for v in ins[1:]]
+    node = ops["SteadyStateGradOp"]().make_node(*ins, pt.scalar("g"), pt.vector("gl"))
+    assert len(node.inputs) == 12 and len(node.outputs) == 9
+
+
+def test_props_make_equal_ops_equal():
+    from pymc_statespace_amd import op
+
+    ops = op._build_ops()
+    K = ops["KalmanFilterOp"]
+    assert K("cholesky", "exact", True) == K("cholesky", "exact", True)
+    assert hash(K("cholesky", "exact", True)) == hash(K("cholesky", "exact", True))
+    assert K("cholesky") != K("standard")
+    assert K(want=op.want_mask(("log_likelihood",))) != K()
+    assert op.want_mask("all") == (True,) * 6
+    assert op.want_mask(("filtered_states", "ll_obs")) == (True, False, False, False, False, True)
+    with pytest.raises(ValueError):
+        op.want_mask(("smoothed_states",))
+
+
+def test_grad_and_vectorize_create_the_intended_nodes():
+    import pytensor.tensor as pt
+    from pytensor.graph.replace import vectorize_graph
+
+    from pymc_statespace_amd.filters import StandardFilter, SteadyStateFilter
+
+    sym = _symbols()
+    logp = StandardFilter().build_graph(*sym, outputs="logp")
+    f = pytensor.function(sym, [logp] + pytensor.grad(logp, sym[1:]))
+    assert sum("Kalman" in nm for nm in _op_names(f)) == 1          # value and gradient from ONE node
+    outs = StandardFilter().build_graph(*sym)
+    f = pytensor.function(sym, pytensor.grad(outs[4], sym[3]), on_unused_input="ignore")
+    assert "KalmanFilterGradOp" in _op_names(f) and "KalmanFilterOp" in _op_names(f)
+    with pytest.raises(Exception, match="(?i)not implemented|undefined|null"):   # the tapes are not differentiated
+        pytensor.grad(outs[0].sum(), sym[3])
+    few = StandardFilter().build_graph(*sym, outputs=("log_likelihood", "filtered_states"))
+    f = pytensor.function(sym, pytensor.grad(few[4], sym[3]), on_unused_input="ignore")
+    assert "KalmanLogpOp" in _op_names(f) and "KalmanFilterGradOp" not in _op_names(f)
+    bH = pt.tensor3("H_draws")
+    f = pytensor.function([s for s in sym if s is not sym[6]] + [bH], vectorize_graph(outs[4], replace={sym[6]: bH}))
+    assert "KalmanFilterBatchedOp" in _op_names(f) and "KalmanFilterOp" not in _op_names(f)
+    ss = SteadyStateFilter().build_graph(*sym)
+    f = pytensor.function(sym, pytensor.grad(ss[4], [sym[3], sym[7]]), on_unused_input="ignore")
+    assert "SteadyStateGradOp" in _op_names(f)
+    with pytest.raises(ValueError):
+        StandardFilter().build_graph(sym[0], sym[1], sym[2], pt.vector("T1"), *sym[4:])   # filters/utilities.py:16-18

@@ -1,8 +1,13 @@
-"""Executable contract of the PyTensor Ops (pymc_statespace_amd/op.py) for an environment that HAS PyTensor.
+"""Executable contract of the PyTensor Ops (pymc_statespace_amd/op.py).
 
-PyTensor / PyMC are installed neither in the build image nor on the GPU box, so this module skips there
-(``pytest.importorskip``); ``make_node`` / ``perform`` / ``L_op`` / ``infer_shape`` / the vectorize rule are
-otherwise unexecuted -- a maintainer wiring ``FILTER_FACTORY`` runs this file first.
+With PyTensor installed this file runs against the real library -- a maintainer wiring ``FILTER_FACTORY``
+ runs it first.  PyTensor / PyMC are installed neither in the build image nor on the GPU box
+(no network), so there it runs against ``tests/_pytensor_shim`` -- a test-only stand-in for the few graph
+classes the adapter touches (typed variables, ``Apply``, ``Op.__call__``, ``function`` evaluating through
+``Op.perform``, ``grad`` through ``Op.L_op`` with ``DisconnectedType`` placeholders, ``vectorize_graph`` with the
+``_vectorize_node`` hook) -- so that ``make_node`` / ``perform`` / ``infer_shape`` / ``connection_pattern`` /
+``L_op`` / the vectorize rule of every Op class execute on the GPU: arity, output order, shapes, which outputs
+are computed, and the gradients, against the statsmodels golden vectors and the autograd oracle.
 Reference being replaced: pymc_statespace/filters/kalman_filter.py:126-193, utils/pytensor_scipy.py:11-60
 (the Op pattern), tests/test_kalman_filter.py:226-241 (the Nile parity case).
 """
@@ -10,10 +15,11 @@ import numpy as np
 import pytest
 from numpy.testing import assert_allclose
 
-pytensor = pytest.importorskip("pytensor")
-pytestmark = pytest.mark.gpu
+from conftest import load_golden, use_pytensor_or_standin  # noqa: E402
 
-from conftest import load_golden  # noqa: E402
+pytensor = use_pytensor_or_standin()
+pytestmark = pytest.mark.gpu
+STANDIN = bool(getattr(pytensor, "IS_TEST_STANDIN", False))
 
 
 @pytest.fixture(scope="module")
@@ -51,13 +57,15 @@ def test_filter_op_matches_statsmodels_golden(nile):
     assert_allclose(res[6][..., 0], g["smoothed_state"], rtol=1e-7, atol=1e-7)
 
 
-def test_only_consumed_outputs_are_computed(nile, monkeypatch):
+def test_only_requested_outputs_are_computed(nile, monkeypatch):
+    """The ``want`` mask is chosen when the graph is built (perform gets no FunctionGraph in current PyTensor)."""
     from pymc_statespace_amd import op
     from pymc_statespace_amd.filters import StandardFilter
 
     g, vals, m, p = nile
     sym = _symbols()
-    outs = StandardFilter().build_graph(*sym)
+    outs = StandardFilter().build_graph(*sym, outputs=("log_likelihood",))
+    assert len(outs) == 6
     seen = {}
     real = op.perform_filter
 
@@ -66,9 +74,19 @@ def test_only_consumed_outputs_are_computed(nile, monkeypatch):
         return real(*a, **k)
 
     monkeypatch.setattr(op, "perform_filter", spy)
-    f = pytensor.function(sym, outs[4], on_unused_input="ignore")
-    f(*vals)
+    f = pytensor.function(sym, [outs[4], outs[2]], on_unused_input="ignore")
+    lp, fP = f(*vals)
     assert seen["want"] == (False, False, False, False, True, False)
+    assert_allclose(lp, g["llf_obs"].sum(), rtol=2e-9)
+    assert fP.shape == (0, 0, 0)        # an output that was not requested is a zero-size placeholder
+    with pytest.raises(ValueError):
+        StandardFilter().build_graph(*sym, outputs=("no_such_output",))
+    # the gradient of logp does not need the tapes either: it goes through the fused value-and-gradient node
+    gT = pytensor.grad(outs[4], sym[3])
+    f2 = pytensor.function(sym, gT, on_unused_input="ignore")
+    full = StandardFilter().build_graph(*sym)
+    f3 = pytensor.function(sym, pytensor.grad(full[4], sym[3]), on_unused_input="ignore")
+    assert_allclose(f2(*vals), f3(*vals), rtol=1e-9, atol=1e-9)
 
 
 def test_logp_op_value_and_gradient_from_one_node(nile):
