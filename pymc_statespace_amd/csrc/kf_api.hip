@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include "kf_internal.h"
+#include "kf_b4_split.h"
 
 static thread_local char g_err[256] = "";
 
@@ -51,7 +52,25 @@ extern "C" int kf_create(kf_handle** out, int device) {
   return KF_OK;
 }
 
-extern "C" void kf_destroy(kf_handle* h) { free(h); }
+extern "C" void kf_destroy(kf_handle* h) {
+  if (h && h->aux_ready) {
+    KfDeviceGuard guard(h);
+    (void)hipStreamSynchronize(h->aux_stream);
+    for (int i = 0; i < KF_AUX_EVENTS; ++i) (void)hipEventDestroy(h->aux_ev[i]);
+    (void)hipStreamDestroy(h->aux_stream);
+  }
+  free(h);
+}
+
+int kf_handle_aux(kf_handle* h) {
+  if (h->aux_ready) return KF_OK;
+  int lo = 0, hi = 0;
+  KF_HIP_CHECK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = the numerically largest = lowest priority
+  KF_HIP_CHECK(h, hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, lo));
+  for (int i = 0; i < KF_AUX_EVENTS; ++i) KF_HIP_CHECK(h, hipEventCreateWithFlags(&h->aux_ev[i], hipEventDisableTiming));
+  h->aux_ready = 1;
+  return KF_OK;
+}
 
 extern "C" const char* kf_last_error(const kf_handle* h) { return h ? h->err : g_err; }
 
@@ -288,7 +307,7 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t 
     }
     return kf_launch_forward_lds(h, a, stream);
   }
-  if (kf_b4_selected(h, a.m, a.p, a.r, a.B)) return kf_launch_forward_b4(h, a, stream);
+  if (kf_b4_selected(h, a.m, a.p, a.r, a.B)) return kf_launch_forward_b4(h, a, workspace, workspace_bytes, stream);
   if (kf_b4q_selected(h, a.m, a.p, a.r, a.filter, a.flags, a.B)) return kf_launch_forward_b4q(h, a, stream);
   if (h->forward_kernel == KF_KERNEL_B4) {
     KF_SET_ERR(h, "forward(b4): needs p == 1, m <= 14, static matrices (got p=%d m=%d)", a.p, a.m);
@@ -529,6 +548,13 @@ extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, i
       (!kf_forward_lds_fits(m, p) || m > KF_NB_M_MAX) &&
       !kf_nb_ok(h, m, p, r, dims->filter, dims->flags) && !kf_wg_ok(h, m, p, r, dims->filter, dims->flags))
     *bytes = kf_forward_big_workspace_bytes(dims->B, m, p);
+  // forward, block kernel with its steady-state phase: hand-over buffers of the split pipeline (kf_b4_split.h); without them the
+  // launcher keeps the steady-state phase inside the recursion kernel
+  if ((which & KF_WS_FORWARD) && kf_b4_selected(h, m, p, r, dims->B) &&
+      kf_forward_b4_split_ok(h, dims->B, dims->T, p, m, r, dims->flags)) {
+    const size_t sw = kf_b4_split_workspace_bytes(dims->B, m, dims->T);
+    if (sw > *bytes) *bytes = sw;
+  }
   if ((which & KF_WS_SMOOTHER) && m >= 1 && m <= KF_WG_M_MAX) {  // flags of the register-tile smoothers
     const size_t sm = kf_smoother_mfma_workspace_bytes(dims->B);
     if (sm > *bytes) *bytes = sm;
@@ -654,7 +680,7 @@ extern "C" int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims, const
     f.y = y; f.a0 = a0; f.P0 = P0; f.Tm = T; f.Z = Z; f.R = R; f.H = H; f.Q = Q; f.c = c; f.d = d;
     f.logp = logp; f.ll_obs = nullptr; f.filt_a = nullptr; f.pred_a = nullptr; f.filt_P = nullptr; f.pred_P = nullptr;
     f.info = info; f.tile_tape = tape;
-    rc = kf_launch_forward_b4(h, f, (hipStream_t)stream);
+    rc = kf_launch_forward_b4(h, f, nullptr, 0, (hipStream_t)stream);
     if (rc) return rc;
     if (!g_logp) {
       hipLaunchKernelGGL(kf_fill_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ones,

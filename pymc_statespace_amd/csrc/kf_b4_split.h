@@ -1,0 +1,49 @@
+// kf_b4_split.h -- workspace of the split forward pipeline (kf_forward_b4.hip + kf_forward_b4_steady.hip).
+#pragma once
+#include "kf_internal.h"
+
+constexpr int B4_HS_STRIDE = 4 * KF_WAVE;  // doubles per draw in hs_tile: the register image, row-major [16][16]
+constexpr int B4_SPLIT_MAX_CHUNKS = 32;
+
+struct B4SplitWs {
+  double* hs_tile;     // [B][B4_HS_STRIDE]
+  double* hs_logp;     // [B]
+  double* sp;          // [B][sps] steady-phase constants: F, rs, -, - | K | g | Z | c | a | P_filt | P_pred | A^(2^k), k = 0..5
+  int32_t* hs_info;    // [B]
+  int32_t* hs_ts;      // [B]
+  int32_t* hs_tfree;   // [B]
+  int32_t* listR;      // [B] draws whose recursion continues
+  int32_t* listS;      // [B] draws handed to the steady kernels, in hand-over order
+  int32_t* listS_ts;   // [B] their first steady step
+  int32_t* cnt;        // [4] cnt[0] = entries of listR
+  int32_t* offS;       // [B4_SPLIT_MAX_CHUNKS + 1] chunk c handed over listS[offS[c] .. offS[c+1])
+  int sps;
+};
+
+// carve the workspace (base may be NULL: size only); returns the bytes needed
+inline size_t kf_b4_split_carve(void* base, long B, int m, int n, B4SplitWs* W) {
+  (void)n;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  char* p = (char*)base;
+  size_t off = 0;
+  const int sps = (4 + 5 * m + 8 * m * m + 1) & ~1;
+  W->sps = sps;
+  W->hs_tile = (double*)(p + off); off += up(sizeof(double) * (size_t)B * B4_HS_STRIDE);
+  W->hs_logp = (double*)(p + off); off += up(sizeof(double) * (size_t)B);
+  W->sp = (double*)(p + off); off += up(sizeof(double) * (size_t)B * sps);
+  W->hs_info = (int32_t*)(p + off); off += up(4 * (size_t)B);
+  W->hs_ts = (int32_t*)(p + off); off += up(4 * (size_t)B);
+  W->hs_tfree = (int32_t*)(p + off); off += up(4 * (size_t)B);
+  W->listR = (int32_t*)(p + off); off += up(4 * (size_t)B);
+  W->listS = (int32_t*)(p + off); off += up(4 * (size_t)B);
+  W->listS_ts = (int32_t*)(p + off); off += up(4 * (size_t)B);
+  W->cnt = (int32_t*)(p + off); off += up(16);
+  W->offS = (int32_t*)(p + off); off += up(4 * (size_t)(B4_SPLIT_MAX_CHUNKS + 1));
+  return off + 256;  // (+ alignment slack for a base that is not 256-byte aligned)
+}
+
+// the split pipeline serves: p == 1, m <= 10 (covariance tapes through the rings), static matrices, steady-state phase allowed
+bool kf_forward_b4_split_ok(const kf_handle* h, long B, int T, int p, int m, int r, unsigned flags);
+size_t kf_b4_split_workspace_bytes(long B, int m, int n);
+int kf_b4_split_compact(kf_handle* h, const B4SplitWs& W, long B, int chunk, hipStream_t stream);
+int kf_b4_split_steady(kf_handle* h, const KfFwdArgs& a, const B4SplitWs& W, int chunk, hipStream_t stream);

@@ -36,6 +36,7 @@
 #include <type_traits>
 
 #include "kf_b4.h"
+#include "kf_b4_split.h"
 
 namespace {
 
@@ -65,7 +66,10 @@ __device__ __forceinline__ void sfor(F&& f) {
 // 3 predicted covariances, 4 the internal tile tape; TM < 0: decided at run time (the uncommon combinations).  Measured
 // (SQ counters, profiles/r02/ops_headline_sq_counters.txt): at four wavefronts per SIMD a wavefront's step costs ~4 cycles
 // per instruction of ANY kind; the run-time tape switches alone were a dozen scalar instructions per step.
-template <int NB, bool STREAM, int TM, bool SS>
+// SS: 0 the recursion at every step (KF_FLAG_EXACT_RECURSION); 1 the steady-state phase inside this kernel (no workspace); 2 one
+// CHUNK of the split pipeline (kf_forward_b4_steady.hip): steps [A.t_begin, A.t_end) of the draws A.list names, the wavefront
+// leaves as soon as its covariance has converged and hands the draw to the time-parallel steady kernels
+template <int NB, bool STREAM, int TM, int SS>
 __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) void kf_fwd_b4_kernel(const KfFwdArgs A) {
   // (waves_per_eu(4): <= 128 registers, and the compiler then keeps MFMA results in VGPRs -- no v_accvgpr moves)
   constexpr int N4 = 4 * NB, JA = N4 - 2, JC = N4 - 1;
@@ -73,8 +77,17 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   const int lane = threadIdx.x;
   const int g = lane >> 4, bq = lane & 15;       // bq = 4 b + q: column index of the lane
   const int fb = (lane & 3) * 4 + ((lane >> 2) & 3);  // 4 q + b: position of column bq in a transpose-tile row
-  const long b = blockIdx.x;
+  long b = blockIdx.x;
   const int n = A.T, m = A.m, mm = m * m;
+  int t0 = 0, t1 = n;
+  if constexpr (SS == 2) {
+    if (A.list) {
+      if ((int)blockIdx.x >= *A.count) return;
+      b = A.list[blockIdx.x];
+    }
+    t0 = A.t_begin;
+    t1 = A.t_end < n ? A.t_end : n;
+  }
 
   double* TR = smem;
   double* STG = smem + B4_OFF_RP;  // !STREAM: compact m x m image (<= 196 doubles) + 64 dump slots at 256
@@ -114,10 +127,12 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   const double mask0 = (g == 0 && bq < N4) ? 1.0 : 0.0;  // u lives in DPP row 0 (k = 0 of the rank-one MFMA)
   const double adjm = (lane == JC) ? 1.0 : 0.0;
   const bool vec_on = g == 3 && bq < m;                  // row JC of the tile = 2 a'
-  double* t_fa = A.filt_a ? A.filt_a + b * (long)n * m : nullptr;
-  double* t_pa = A.pred_a ? A.pred_a + b * (long)(n + 1) * m : nullptr;
-  double* t_fP = A.filt_P ? A.filt_P + b * (long)n * mm : nullptr;
-  double* t_pP = A.pred_P ? A.pred_P + b * (long)(n + 1) * mm : nullptr;
+  // (a later chunk of the split pipeline continues the tapes at step t0: predicted slot t0 was written by the chunk before)
+  const int ps0 = t0 ? t0 + 1 : 0;
+  double* t_fa = A.filt_a ? A.filt_a + (b * (long)n + t0) * m : nullptr;
+  double* t_pa = A.pred_a ? A.pred_a + (b * (long)(n + 1) + ps0) * m : nullptr;
+  double* t_fP = A.filt_P ? A.filt_P + (b * (long)n + t0) * mm : nullptr;
+  double* t_pP = A.pred_P ? A.pred_P + (b * (long)(n + 1) + ps0) * mm : nullptr;
   const bool w_fa = TM < 0 ? t_fa != nullptr : (TM & 1) != 0, w_pa = TM < 0 ? t_pa != nullptr : (TM & 2) != 0,
              w_fP = TM < 0 ? t_fP != nullptr : (TM & 4) != 0, w_pP = TM < 0 ? t_pP != nullptr : (TM & 8) != 0;
 
@@ -190,9 +205,20 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       dst[(NB - 1) * 4 * N4] = last;
     }
   };
+  double logp = 0.0;
+  int info = 0;
+  if constexpr (SS == 2) {
+    if (t0 > 0) {  // the tile, log-likelihood and flag the previous chunk left
+      const double* ht = A.hs_tile + b * (long)B4_HS_STRIDE + lane;
+#pragma unroll
+      for (int I = 0; I < NB; ++I) P[I] = ht[I * KF_WAVE];
+      logp = A.hs_logp[b];
+      info = A.hs_info[b];
+    }
+  }
   // predicted tape slot 0 = (a0, P0 as given: the caller's P0, not its symmetrised upper triangle)
-  if (w_pa) put_a(s_pa, o_pa, P[NB - 1], vec_on);
-  if (w_pP) {
+  if (w_pa && t0 == 0) put_a(s_pa, o_pa, P[NB - 1], vec_on);
+  if (w_pP && t0 == 0) {
     if (STREAM) {
       double P0g[NB];
 #pragma unroll
@@ -219,8 +245,6 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     if (NB > 2) Xt[NB > 2 ? 2 : 0] = t23.x;
     if (NB > 3) Xt[NB > 3 ? 3 : 0] = t23.y;
   };
-  double logp = 0.0;
-  int info = 0;
   // ll of the steps [tb, tb+cnt) held in the ring, one step per lane: (F, u_hat_JC = -2 v / sqrt F); the flags of
   // these steps are still in the y block.  Everything rare is decided here, LB steps at a time.
   auto flush_ring = [&](int tb, int cnt) {
@@ -264,9 +288,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   // the gain, F and both covariances are constants and only the mean is left: a_{t+1} = (T - T K Z) a_t + T K (y_t -+ d) + c
   // -- the loop at the end of this kernel.  (statsmodels' Kalman filter does the same by default, `tolerance`; the
   // reference recomputes everything every step, results agree to ~1e-13 relative.  KF_FLAG_EXACT_RECURSION switches it off.)
-  const bool steady_en = SS && STREAM && !w_tile && n >= 64;
+  const bool steady_en = SS != 0 && STREAM && !w_tile && n >= 64;
   int t_free = 0;  // first step after the last missing observation
-  if (steady_en) {
+  if (SS == 2 && t0 > 0) {
+    t_free = A.hs_tfree[b];
+  } else if (steady_en) {
     int tn = -1;
     for (int e = lane; e < n; e += KF_WAVE) {
       const double yv = ybase[e];
@@ -275,10 +301,13 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
 #pragma unroll
     for (int off = 32; off; off >>= 1) tn = max(tn, __shfl_xor(tn, off));
     t_free = tn + 1;
+    if (SS == 2 && lane == 0) A.hs_tfree[b] = t_free;
   }
 
-  int t = 0;
-  for (; t < n; ++t) {
+  int t = t0;
+  int npass = 0;       // consecutive convergence checks passed
+  bool handed = false; // (SS == 2) the covariance has converged: the steady kernels take over at step t
+  for (; t < t1; ++t) {
     if ((t & (LB - 1)) == 0) load_y_block(t);
     const bool chk = steady_en && (t & 7) == 7 && t >= t_free && t + 16 < n;  // wave-uniform
     if (chk && !w_pP) {  // the predicted covariance this step starts from, parked in the (unused) tape ring
@@ -357,20 +386,28 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     }
     bool conv = false;
     if (chk) {
+      // Converged: the one-step change of EVERY predicted-covariance entry is within 1e-15 of its scale sqrt(P_ii P_jj), on two
+      // consecutive checks (8 steps apart).  Entrywise, so that a large (diffuse) block cannot hide a small block that still moves;
+      // the frozen covariance is then within 1e-15 / (1 - rho) of the fixpoint entry by entry (rho: contraction per step).
       // (with the predicted-covariance tape on, the previous step's append still sits in the ring, mm doubles back)
-      unsigned dm = 0, pm = 0;
       wave_lds_fence();
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+        if (on[I] && 4 * I + g == bq) UX[bq] = P[I];  // the diagonal (UX is rewritten in full at the top of the next step)
+      wave_lds_fence();
+      const double dcol = UX[bq < m ? bq : 0];
+      bool bad = false;
 #pragma unroll
       for (int I = 0; I < NB; ++I) {
         const unsigned oo = w_pP ? ((o_pP[I] + 8u * (unsigned)(RING_P - mm)) & (unsigned)(8 * RING_P - 1)) : o_pP[I];
         const double old = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_pP.ring) + oo);
-        if (on[I]) {
-          dm = max(dm, abs_hi(P[I] - old));
-          pm = max(pm, abs_hi(P[I]));
-        }
+        const double drow = UX[on[I] ? 4 * I + g : 0];
+        const double df = P[I] - old;
+        bad = bad || (on[I] && !(df * df <= 1e-30 * fabs(dcol * drow)));  // (NaN: never converged)
       }
       wave_lds_fence();
-      conv = wave_absmax_hi(dm) <= 1e-15 * wave_absmax_hi(pm);
+      npass = (__ballot(bad) == 0ull) ? npass + 1 : 0;
+      conv = npass >= 2;
     }
     if (w_tile && t == 0) put_tile(t_tile + (long)n * (N4 * N4), P, P[NB - 1]);
     if (w_pa) put_a(s_pa, o_pa, P[NB - 1], vec_on);
@@ -385,10 +422,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     if ((t & (LB - 1)) == LB - 1) flush_ring(t - (LB - 1), LB);
     if (conv) {
       ++t;
+      handed = true;
       break;
     }
   }
-  if constexpr (SS && STREAM) if (t < n) {
+  if constexpr (SS == 1 && STREAM) if (t < n) {
     // ---- steady-state steps t .. n-1 (see above); P is the converged predicted tile of step t -------------------------------
     const double us = high_half_everywhere(P[NB - 1]) * mask0;  // row JA: (P Z')' with Z P Z' at JA (DPP row 0)
     const double F = H1 + readlane_f64(us, JA);
@@ -488,7 +526,21 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     s_fP.finish(lane, 1.0);
     s_pP.finish(lane, 1.0);
   }
-  if (n & (LB - 1)) flush_ring(n & ~(LB - 1), n & (LB - 1));
+  if (t & (LB - 1)) flush_ring(t & ~(LB - 1), t & (LB - 1));  // (t == n, or the step a chunk stopped at)
+  if constexpr (SS == 2) {
+    if (t < n) {  // hand-over: to the next chunk (-1) or, converged, to the steady kernels (step t)
+      double* ht = A.hs_tile + b * (long)B4_HS_STRIDE + lane;
+#pragma unroll
+      for (int I = 0; I < NB; ++I) ht[I * KF_WAVE] = P[I];
+      if (lane == 0) {
+        A.hs_logp[b] = logp;
+        A.hs_info[b] = info;
+        A.hs_ts[b] = handed ? t : -1;
+      }
+      return;
+    }
+    if (lane == 0) A.hs_ts[b] = -2;
+  }
   if (lane == 0) {
     A.logp[b] = logp;
     if (A.info) A.info[b] = info;
@@ -499,7 +551,31 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
 
 bool kf_forward_b4_ok(int m, int p, int r) { return p == 1 && m >= 1 && m + 2 <= 16 && r >= 1 && r <= 64; }
 
-int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
+// split pipeline (kf_forward_b4_steady.hip): eligible shapes.  KF_B4_SPLIT=0 / 1 in the environment forces the choice.
+bool kf_forward_b4_split_ok(const kf_handle* h, long B, int T, int p, int m, int r, unsigned flags) {
+  (void)h;
+  if (!kf_forward_b4_ok(m, p, r) || m > 10) return false;        // (m <= 10: covariance tapes through the rings)
+  if (flags & (KF_FLAG_TV_ANY | KF_FLAG_EXACT_RECURSION)) return false;
+  const char* sse = getenv("KF_STEADY_STATE");
+  if (sse && *sse && atoi(sse) == 0) return false;
+  const char* e = getenv("KF_B4_SPLIT");
+  if (e && *e) return atoi(e) != 0 && T >= 64;
+  return T >= 256 && B >= 1;
+}
+
+static int b4_split_chunk(int n) {
+  // 128 steps per recursion launch (a hand-over costs the per-draw setup again: ~3 % of 128 steps), more when the series is long
+  int ch = 128;
+  while ((n + ch - 1) / ch > B4_SPLIT_MAX_CHUNKS) ch += 32;
+  const char* e = getenv("KF_B4_SPLIT_CHUNK");
+  if (e && *e && atoi(e) >= 32) {
+    ch = (atoi(e) + 31) & ~31;
+    while ((n + ch - 1) / ch > B4_SPLIT_MAX_CHUNKS) ch += 32;
+  }
+  return ch;
+}
+
+int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!kf_forward_b4_ok(a.m, a.p, a.r) || (a.flags & KF_FLAG_TV_ANY)) {
     KF_SET_ERR(h, "forward(b4): needs p == 1, m <= 14, static matrices (got p=%d m=%d r=%d)", a.p, a.m, a.r);
     return KF_ERR_UNSUPPORTED;
@@ -514,12 +590,18 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
   const bool ss = !(a.flags & KF_FLAG_EXACT_RECURSION) && !a.tile_tape && a.T >= 64 && !(sse && *sse && atoi(sse) == 0);
   // (tried: capping the residency of this instantiation at 3 / 2 wavefronts per SIMD so that the dispatcher hands queued draws to the
   // SIMDs whose draws converged early -- headline 2.29 / 2.44 ms against 1.63: the queued wavefronts run as a second round)
+  // split pipeline: recursion chunks over compacted draw lists + the time-parallel steady kernels on the second stream
+  const bool split = ss && nb <= 3 && workspace && kf_forward_b4_split_ok(h, a.B, a.T, a.p, a.m, a.r, a.flags) &&
+                     workspace_bytes >= kf_b4_split_workspace_bytes(a.B, a.m, a.T);
+  KfFwdArgs ac = a;  // (the chunk's arguments in split mode)
 #define KF_B4_LAUNCH2(NB_, ST_, TM_)                                                                                       \
   do {                                                                                                                     \
-    if (ss && ST_ && TM_ != 16)                                                                                            \
-      hipLaunchKernelGGL((kf_fwd_b4_kernel<NB_, ST_, TM_, (ST_ && TM_ != 16)>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); \
+    if (split && ST_ && TM_ != 16)                                                                                         \
+      hipLaunchKernelGGL((kf_fwd_b4_kernel<NB_, ST_, TM_, (ST_ && TM_ != 16) ? 2 : 0>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, ac); \
+    else if (ss && ST_ && TM_ != 16)                                                                                       \
+      hipLaunchKernelGGL((kf_fwd_b4_kernel<NB_, ST_, TM_, (ST_ && TM_ != 16) ? 1 : 0>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); \
     else                                                                                                                   \
-      hipLaunchKernelGGL((kf_fwd_b4_kernel<NB_, ST_, TM_, false>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);    \
+      hipLaunchKernelGGL((kf_fwd_b4_kernel<NB_, ST_, TM_, 0>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);        \
   } while (0)
 #define KF_B4_LAUNCH(NB_, ST_)                           \
   do {                                                   \
@@ -529,6 +611,40 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
     else if (mask == 16) KF_B4_LAUNCH2(NB_, ST_, 16);    \
     else KF_B4_LAUNCH2(NB_, ST_, -1);                    \
   } while (0)
+  if (split) {
+    const int rc0 = kf_handle_aux(h);
+    if (rc0) return rc0;
+    B4SplitWs W;
+    void* wbase = (void*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    kf_b4_split_carve(wbase, a.B, a.m, a.T, &W);
+    ac.hs_tile = W.hs_tile; ac.hs_logp = W.hs_logp; ac.hs_info = W.hs_info; ac.hs_ts = W.hs_ts; ac.hs_tfree = W.hs_tfree;
+    const int ch = b4_split_chunk(a.T), nch = (a.T + ch - 1) / ch;
+    // the second stream starts behind everything already queued on the caller's stream (its inputs) ...
+    KF_HIP_CHECK(h, hipEventRecord(h->aux_ev[KF_AUX_EVENTS - 1], stream));
+    KF_HIP_CHECK(h, hipStreamWaitEvent(h->aux_stream, h->aux_ev[KF_AUX_EVENTS - 1], 0));
+    for (int c = 0; c < nch; ++c) {
+      ac.t_begin = c * ch;
+      ac.t_end = (c + 1) * ch < a.T ? (c + 1) * ch : a.T;
+      ac.list = c ? W.listR : nullptr;
+      ac.count = c ? W.cnt : nullptr;
+      switch (nb) {
+        case 1: KF_B4_LAUNCH(1, true); break;
+        case 2: KF_B4_LAUNCH(2, true); break;
+        default: KF_B4_LAUNCH(3, true); break;
+      }
+      KF_HIP_CHECK(h, hipGetLastError());
+      int rc = kf_b4_split_compact(h, W, a.B, c, stream);
+      if (rc) return rc;
+      KF_HIP_CHECK(h, hipEventRecord(h->aux_ev[c], stream));
+      KF_HIP_CHECK(h, hipStreamWaitEvent(h->aux_stream, h->aux_ev[c], 0));
+      rc = kf_b4_split_steady(h, a, W, c, h->aux_stream);
+      if (rc) return rc;
+    }
+    // ... and the caller's stream continues behind the last steady kernel
+    KF_HIP_CHECK(h, hipEventRecord(h->aux_ev[KF_AUX_EVENTS - 2], h->aux_stream));
+    KF_HIP_CHECK(h, hipStreamWaitEvent(stream, h->aux_ev[KF_AUX_EVENTS - 2], 0));
+    return KF_OK;
+  }
   switch (nb) {
     case 1: KF_B4_LAUNCH(1, true); break;
     case 2: KF_B4_LAUNCH(2, true); break;

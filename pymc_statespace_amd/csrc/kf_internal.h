@@ -22,13 +22,21 @@ struct KfAttrOnce {
   }
 };
 
+#define KF_AUX_EVENTS 34
 struct kf_handle {
   int device;
   int lanes_per_draw;  // 0 = auto
   int forward_kernel;  // KF_KERNEL_AUTO / _LDS / _ROW / _LANE
   int n_cu;
   char err[512];
+  // second stream of the split forward pipeline (kf_forward_b4.hip): the steady kernels run beside the recursion chunks.
+  // Created on first use (kf_handle_aux), forked from / joined to the caller's stream with events -- the call stays
+  // asynchronous on the caller's stream and never synchronises the host
+  int aux_ready;
+  hipStream_t aux_stream;
+  hipEvent_t aux_ev[KF_AUX_EVENTS];
 };
+int kf_handle_aux(kf_handle* h);  // KF_OK once aux_stream / aux_ev exist (current device = the handle's)
 
 // Arguments of the LDS-resident forward kernel (one struct, passed by value).
 struct KfFwdArgs {
@@ -57,6 +65,17 @@ struct KfFwdArgs {
   // slot t < T the filtered augmented tile of step t with u_hat in row JA and 1 / sqrt(F) at [JA][JA], slot T the predicted
   // tile of step 1; read back by kf_backward_b4.hip.  NULL for every public call
   double* tile_tape;
+  // internal (split pipeline of kf_forward_b4.hip, see kf_forward_b4_steady.hip): this launch runs steps [t_begin, t_end) of the
+  // draws list[0 .. *count) (list == NULL: draw = workgroup index, count ignored) and leaves each draw's tile, partial
+  // log-likelihood and status in the hand-over buffers; all NULL / 0 for every other kernel
+  int t_begin = 0, t_end = 0;
+  const int32_t* list = nullptr;
+  const int32_t* count = nullptr;
+  double* hs_tile = nullptr;    // [B][NB * 64] register image of the predicted tile at the hand-over step
+  double* hs_logp = nullptr;    // [B] log-likelihood of the steps done so far
+  int32_t* hs_info = nullptr;   // [B]
+  int32_t* hs_ts = nullptr;     // [B] -1: recursion continues in the next chunk, >= 0: converged, steady phase starts at this step, -2: finished
+  int32_t* hs_tfree = nullptr;  // [B] first step after the last missing observation (written by the first chunk)
 };
 
 struct KfBwdArgs {
@@ -160,7 +179,7 @@ KF_DECL_MP(4, 1) KF_DECL_MP(4, 2)
 int kf_launch_forward_mfma(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 // 4x4x4-block kernel (kf_forward_b4.hip): v_mfma_f64_4x4x4_4b_f64, p == 1, m <= 14, mean carried in the tile
 bool kf_forward_b4_ok(int m, int p, int r);
-int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream);
 // several scalar observations per step on the same 4x4x4 block tiles (kf_forward_b4q.hip)
 bool kf_forward_b4q_ok(int m, int p, int r);
 int kf_launch_forward_b4q(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);

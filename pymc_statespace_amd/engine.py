@@ -318,9 +318,12 @@ class KalmanEngine:
         return g
 
     def value_and_grad(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, g_logp=None, filter_type="standard",
-                       mvn_const="reference", h_diagonal=False):
+                       mvn_const="reference", h_diagonal=False, exact_recursion: Optional[bool] = None):
         """kf_filter_value_and_grad -> (logp (B,), info (B,) int32, dict of gradients a0,P0,T,Z,R,H,Q,c,d) of
-        sum_b g_logp[b] logp[b] (default: ones) in ONE call: the predicted tapes live in the workspace only."""
+        sum_b g_logp[b] logp[b] (default: ones) in ONE call: the predicted tapes live in the workspace only.
+        ``exact_recursion`` as in ``forward`` (None: the engine's default, ``set_exact_recursion``)."""
+        if exact_recursion is None:
+            exact_recursion = getattr(self, "_exact_recursion", False)
         P0 = self.to_device(P0)
         B, m = P0.shape[0], P0.shape[1]
         Z = self.to_device(Z, None)
@@ -342,6 +345,8 @@ class KalmanEngine:
         dims = self._dims(B, n, p, m, r, filter_type, mvn_const, y_per_draw)
         if h_diagonal:
             dims.flags |= _lib.KF_FLAG_H_DIAGONAL
+        if exact_recursion:
+            dims.flags |= _lib.KF_FLAG_EXACT_RECURSION
         dev, f64 = self.device, torch.float64
         logp = torch.empty(B, device=dev, dtype=f64)
         info = torch.empty(B, device=dev, dtype=torch.int32)
