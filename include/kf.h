@@ -52,7 +52,8 @@
 extern "C" {
 #endif
 
-#define KF_ABI_VERSION 4 /* 2: KF_FLAG_H_DIAGONAL, KF_KERNEL_MFMA, kf_dare, kf_simulate_statespace, workspace use by smoother/backward; \
+#define KF_ABI_VERSION 5 /* 5: KF_FLAG_STEADY_STATE; the block kernel's steady-state phase off by default below 1536 steps; kf_workspace_bytes_for(KF_WS_FORWARD) covers the split pipeline. \
+                          * 2: KF_FLAG_H_DIAGONAL, KF_KERNEL_MFMA, kf_dare, kf_simulate_statespace, workspace use by smoother/backward; \
                             3: kf_workspace_bytes_for, kf_forward_kernel_name_ws; every entry point runs on the handle's device; \
                             4: kf_dare_backward, time-varying matrices in kf_filter_backward, kf_filter_value_and_grad */
 
@@ -94,15 +95,25 @@ enum {
    * p observations of a step one at a time in the register-resident kernels -- algebraically
    * the same filter (results agree to rounding).  Off-diagonal entries are ignored when set. */
   KF_FLAG_H_DIAGONAL = 1u << 11,
-  /* Forward filter: never switch to the steady-state phase.  By default the kernels for static models -- the lane kernel
-   * (p == 1, m <= 4), the block kernel (p == 1, m <= 10) and the multi-observation block kernel (3 <= p <= 5, m >= 8) -- test
-   * every 8 (lane kernel: 16) steps whether the predicted covariance has stopped moving (largest change of an entry in one step
-   * <= 1e-15, lane kernel 3e-16, of its largest entry; no missing observation ahead; series of >= 64 steps) and from then
-   * on advance only the mean with the converged gain, writing the two constant covariances to the tapes -- what statsmodels'
-   * filter does by default (`tolerance`).  The reference recomputes every step; measured differences on the BASELINE
-   * workloads: <= 7e-14 relative on logp, <= 5e-13 absolute on the covariance tapes.  KF_STEADY_STATE=0 in the environment
-   * has the same effect as this flag. */
-  KF_FLAG_EXACT_RECURSION = 1u << 12
+  /* Forward filter: never switch to the steady-state phase.  The kernels for static models -- the lane kernel (p == 1, m <= 4),
+   * the block kernel (p == 1, m <= 10) and the multi-observation block kernel (3 <= p <= 5, m >= 8) -- can test every 8 (lane
+   * kernel: 16) steps whether the predicted covariance has stopped moving and from then on advance only the mean with the
+   * converged gain, writing the two constant covariances to the tapes -- what statsmodels' filter does by default
+   * (`tolerance`).  The test (round 3): no missing observation ahead, series of >= 64 steps, and on TWO consecutive checks the
+   * one-step change of every entry is <= 1e-15 (lane kernel 3e-16) of the largest entry AND <= 1e-13 of the entry's own scale
+   * sqrt(P_ii P_jj) -- the second condition keeps a large (diffuse) block from hiding a small block that still moves.
+   * The reference recomputes every step; measured differences on the BASELINE workloads: <= 7e-14 relative on logp, <= 5e-13
+   * absolute on the covariance tapes.
+   * DEFAULT: the lane kernel and the multi-observation block kernel use the phase; the block kernel (p == 1, 4 < m <= 10:
+   * the north-star shape) uses it only for series of >= 1536 steps (at T = 1000 the recursion at every step is the faster
+   * kernel, so the default there IS the reference's recursion) -- then, given the workspace kf_workspace_bytes asks for, as a
+   * split pipeline: recursion launches over compacted lists of the draws still converging, the converged draws' constant
+   * covariance tapes and time-parallel mean recursion from separate kernels on a second stream (kf_forward_b4_steady.hip).
+   * KF_STEADY_STATE=0 in the environment has the same effect as this flag, KF_STEADY_STATE=1 that of KF_FLAG_STEADY_STATE. */
+  KF_FLAG_EXACT_RECURSION = 1u << 12,
+  /* Forward filter: use the steady-state phase wherever the selected kernel has one, whatever the series length (the block
+   * kernel's default depends on it, see above).  KF_FLAG_EXACT_RECURSION wins when both are set. */
+  KF_FLAG_STEADY_STATE = 1u << 13
 };
 
 /* error codes */

@@ -12,13 +12,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # KF_LIB_PATH: developer override for A/B experiments with instrumented builds of the same ABI
 LIB_PATH = os.environ.get("KF_LIB_PATH") or os.path.join(_HERE, "libkf_hip.so")
 
-KF_ABI_VERSION = 4
+KF_ABI_VERSION = 5
 
 KF_FILTER = {"standard": 0, "cholesky": 1, "univariate": 2, "single": 3}
 KF_FLAG_MVN_CONST_EXACT = 1 << 0
 KF_FLAG_Y_PER_DRAW = 1 << 1
 KF_FLAG_H_DIAGONAL = 1 << 11
 KF_FLAG_EXACT_RECURSION = 1 << 12
+KF_FLAG_STEADY_STATE = 1 << 13
 KF_FLAG_TV = {"T": 1 << 4, "Z": 1 << 5, "R": 1 << 6, "H": 1 << 7, "Q": 1 << 8, "c": 1 << 9, "d": 1 << 10}
 
 KF_WS_FORWARD, KF_WS_BACKWARD, KF_WS_SMOOTHER, KF_WS_ALL = 1, 2, 4, 7

@@ -56,8 +56,12 @@ extern "C" void kf_destroy(kf_handle* h) {
   if (h && h->aux_ready) {
     KfDeviceGuard guard(h);
     (void)hipStreamSynchronize(h->aux_stream);
+    (void)hipStreamSynchronize(h->aux_stream2);
+    (void)hipStreamSynchronize(h->aux_stream3);
     for (int i = 0; i < KF_AUX_EVENTS; ++i) (void)hipEventDestroy(h->aux_ev[i]);
     (void)hipStreamDestroy(h->aux_stream);
+    (void)hipStreamDestroy(h->aux_stream2);
+    (void)hipStreamDestroy(h->aux_stream3);
   }
   free(h);
 }
@@ -67,6 +71,8 @@ int kf_handle_aux(kf_handle* h) {
   int lo = 0, hi = 0;
   KF_HIP_CHECK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = the numerically largest = lowest priority
   KF_HIP_CHECK(h, hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, lo));
+  KF_HIP_CHECK(h, hipStreamCreateWithPriority(&h->aux_stream2, hipStreamNonBlocking, lo));
+  KF_HIP_CHECK(h, hipStreamCreateWithPriority(&h->aux_stream3, hipStreamNonBlocking, hi));
   for (int i = 0; i < KF_AUX_EVENTS; ++i) KF_HIP_CHECK(h, hipEventCreateWithFlags(&h->aux_ev[i], hipEventDisableTiming));
   h->aux_ready = 1;
   return KF_OK;

@@ -3,12 +3,15 @@
 #include "kf_internal.h"
 
 constexpr int B4_HS_STRIDE = 4 * KF_WAVE;  // doubles per draw in hs_tile: the register image, row-major [16][16]
+constexpr int B4_HC_STRIDE = 24 * KF_WAVE;  // doubles per draw in hs_const (NB <= 3: 2 * 9 + 3 registers)
 constexpr int B4_SPLIT_MAX_CHUNKS = 32;
+constexpr int KF_B4_STEADY_MIN_T = 1536;  // series length from which kf_forward_b4.hip uses its steady-state phase by default
+constexpr int B4_PAIR_MAX = 1024;  // draws left in the full recursion at which the pair kernel (kf_forward_b4p.hip) takes them over: one per SIMD
 
 struct B4SplitWs {
   double* hs_tile;     // [B][B4_HS_STRIDE]
+  double* hs_const;    // [B][B4_HC_STRIDE]
   double* hs_logp;     // [B]
-  double* sp;          // [B][sps] steady-phase constants: F, rs, -, - | K | g | Z | c | a | P_filt | P_pred | A^(2^k), k = 0..5
   int32_t* hs_info;    // [B]
   int32_t* hs_ts;      // [B]
   int32_t* hs_tfree;   // [B]
@@ -16,8 +19,9 @@ struct B4SplitWs {
   int32_t* listS;      // [B] draws handed to the steady kernels, in hand-over order
   int32_t* listS_ts;   // [B] their first steady step
   int32_t* cnt;        // [4] cnt[0] = entries of listR
+  int32_t* pair_ctl;   // [4] {draws handed to the pair kernel (they are listR[0 ..)), their first step, 1 + the chunk that decided it (0: not yet)}
+  int32_t* fillq;      // [B4_SPLIT_MAX_CHUNKS] next fill item of the entries chunk c handed over
   int32_t* offS;       // [B4_SPLIT_MAX_CHUNKS + 1] chunk c handed over listS[offS[c] .. offS[c+1])
-  int sps;
 };
 
 // carve the workspace (base may be NULL: size only); returns the bytes needed
@@ -26,11 +30,10 @@ inline size_t kf_b4_split_carve(void* base, long B, int m, int n, B4SplitWs* W) 
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   char* p = (char*)base;
   size_t off = 0;
-  const int sps = (4 + 5 * m + 8 * m * m + 1) & ~1;
-  W->sps = sps;
+  (void)m;
   W->hs_tile = (double*)(p + off); off += up(sizeof(double) * (size_t)B * B4_HS_STRIDE);
+  W->hs_const = (double*)(p + off); off += up(sizeof(double) * (size_t)B * B4_HC_STRIDE);
   W->hs_logp = (double*)(p + off); off += up(sizeof(double) * (size_t)B);
-  W->sp = (double*)(p + off); off += up(sizeof(double) * (size_t)B * sps);
   W->hs_info = (int32_t*)(p + off); off += up(4 * (size_t)B);
   W->hs_ts = (int32_t*)(p + off); off += up(4 * (size_t)B);
   W->hs_tfree = (int32_t*)(p + off); off += up(4 * (size_t)B);
@@ -38,6 +41,8 @@ inline size_t kf_b4_split_carve(void* base, long B, int m, int n, B4SplitWs* W) 
   W->listS = (int32_t*)(p + off); off += up(4 * (size_t)B);
   W->listS_ts = (int32_t*)(p + off); off += up(4 * (size_t)B);
   W->cnt = (int32_t*)(p + off); off += up(16);
+  W->pair_ctl = (int32_t*)(p + off); off += up(16);
+  W->fillq = (int32_t*)(p + off); off += up(4 * (size_t)B4_SPLIT_MAX_CHUNKS);
   W->offS = (int32_t*)(p + off); off += up(4 * (size_t)(B4_SPLIT_MAX_CHUNKS + 1));
   return off + 256;  // (+ alignment slack for a base that is not 256-byte aligned)
 }
@@ -45,5 +50,6 @@ inline size_t kf_b4_split_carve(void* base, long B, int m, int n, B4SplitWs* W) 
 // the split pipeline serves: p == 1, m <= 10 (covariance tapes through the rings), static matrices, steady-state phase allowed
 bool kf_forward_b4_split_ok(const kf_handle* h, long B, int T, int p, int m, int r, unsigned flags);
 size_t kf_b4_split_workspace_bytes(long B, int m, int n);
-int kf_b4_split_compact(kf_handle* h, const B4SplitWs& W, long B, int chunk, hipStream_t stream);
-int kf_b4_split_steady(kf_handle* h, const KfFwdArgs& a, const B4SplitWs& W, int chunk, hipStream_t stream);
+int kf_b4_split_compact(kf_handle* h, const B4SplitWs& W, long B, int chunk, int t_next, int pair_ok, hipStream_t stream);
+int kf_b4_split_steady(kf_handle* h, const KfFwdArgs& a, const B4SplitWs& W, int chunk, hipStream_t s_fill, hipStream_t s_mean);
+int kf_b4_split_drain(kf_handle* h, const KfFwdArgs& a, const B4SplitWs& W, int last_chunk, hipStream_t stream);

@@ -98,7 +98,36 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   // ---- per-draw constants through an LDS scratch that aliases the loop buffers (kf_b4.h) ------------------------
   constexpr bool HALF_STATIC = B4Const<NB>::HALF;
   B4Const<NB> KC;
-  b4_setup(A, b, smem, lane, KC);
+  if (SS == 2 && t0 > 0) {
+    // a later chunk of the split pipeline: the replicated T blocks and C_ext as the first chunk left them (21 coalesced loads
+    // instead of the ~50 us of setup a full launch spends), and the zeroed transpose tile b4_setup leaves behind
+    for (int e = lane; e < 16 * TRS; e += KF_WAVE) smem[e] = 0.0;
+    const double* hc = A.hs_const + b * (long)B4_HC_STRIDE + lane;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+#pragma unroll
+      for (int K = 0; K < NB; ++K) {
+        KC.Ta[I][K] = hc[(I * NB + K) * KF_WAVE];
+        if (HALF_STATIC) KC.Tha[HALF_STATIC ? I : 0][HALF_STATIC ? K : 0] = hc[(NB * NB + I * NB + K) * KF_WAVE];
+      }
+      KC.Ch[I] = hc[(2 * NB * NB + I) * KF_WAVE];
+    }
+    wave_lds_fence();
+  } else {
+    b4_setup(A, b, smem, lane, KC);
+    if (SS == 2 && t1 < n) {
+      double* hc = A.hs_const + b * (long)B4_HC_STRIDE + lane;
+#pragma unroll
+      for (int I = 0; I < NB; ++I) {
+#pragma unroll
+        for (int K = 0; K < NB; ++K) {
+          hc[(I * NB + K) * KF_WAVE] = KC.Ta[I][K];
+          if (HALF_STATIC) hc[(NB * NB + I * NB + K) * KF_WAVE] = KC.Tha[HALF_STATIC ? I : 0][HALF_STATIC ? K : 0];
+        }
+        hc[(2 * NB * NB + I) * KF_WAVE] = KC.Ch[I];
+      }
+    }
+  }
   double (&Ta)[NB][NB] = KC.Ta;
   double (&Tha)[HALF_STATIC ? NB : 1][HALF_STATIC ? NB : 1] = KC.Tha;
   double (&Ch)[NB] = KC.Ch;
@@ -304,6 +333,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     if (SS == 2 && lane == 0) A.hs_tfree[b] = t_free;
   }
 
+  if (SS == 2) __builtin_amdgcn_s_setprio(3);  // the recursion's dependency chain before the steady kernels that share the SIMD
   int t = t0;
   int npass = 0;       // consecutive convergence checks passed
   bool handed = false; // (SS == 2) the covariance has converged: the steady kernels take over at step t
@@ -386,9 +416,12 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     }
     bool conv = false;
     if (chk) {
-      // Converged: the one-step change of EVERY predicted-covariance entry is within 1e-15 of its scale sqrt(P_ii P_jj), on two
-      // consecutive checks (8 steps apart).  Entrywise, so that a large (diffuse) block cannot hide a small block that still moves;
-      // the frozen covariance is then within 1e-15 / (1 - rho) of the fixpoint entry by entry (rho: contraction per step).
+      // Converged: on TWO consecutive checks (8 steps apart) the one-step change of the predicted covariance is within 1e-15 of
+      // its largest entry AND every entry's change is within 1e-13 of its own scale sqrt(P_ii P_jj).  The second, entrywise
+      // condition is what keeps a large (diffuse) block from hiding a small block that still moves; it cannot be as tight as the
+      // first: an entry far below its scale carries rounding noise of ~1e-15..1e-14 sqrt(P_ii P_jj) per step (measured on the
+      // VARMAX draws: at 1e-14 one draw in 25 never passes).  The frozen covariance is then within tol / (1 - rho) of the
+      // fixpoint (rho: contraction per step).
       // (with the predicted-covariance tape on, the previous step's append still sits in the ring, mm doubles back)
       wave_lds_fence();
 #pragma unroll
@@ -396,6 +429,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
         if (on[I] && 4 * I + g == bq) UX[bq] = P[I];  // the diagonal (UX is rewritten in full at the top of the next step)
       wave_lds_fence();
       const double dcol = UX[bq < m ? bq : 0];
+      unsigned pm = 0;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+        if (on[I]) pm = max(pm, abs_hi(P[I]));
+      const double lim = 1e-15 * wave_absmax_hi(pm);  // (the largest entry, from the high dwords: within 2^-20)
       bool bad = false;
 #pragma unroll
       for (int I = 0; I < NB; ++I) {
@@ -403,10 +441,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
         const double old = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_pP.ring) + oo);
         const double drow = UX[on[I] ? 4 * I + g : 0];
         const double df = P[I] - old;
-        bad = bad || (on[I] && !(df * df <= 1e-30 * fabs(dcol * drow)));  // (NaN: never converged)
+        bad = bad || (on[I] && !(fabs(df) <= lim && df * df <= 1e-26 * fabs(dcol * drow)));  // (NaN: never converged)
       }
       wave_lds_fence();
-      npass = (__ballot(bad) == 0ull) ? npass + 1 : 0;
+      const bool ok = __ballot(bad) == 0ull;
+      npass = ok ? npass + 1 : 0;
       conv = npass >= 2;
     }
     if (w_tile && t == 0) put_tile(t_tile + (long)n * (N4 * N4), P, P[NB - 1]);
@@ -560,18 +599,18 @@ bool kf_forward_b4_split_ok(const kf_handle* h, long B, int T, int p, int m, int
   if (sse && *sse && atoi(sse) == 0) return false;
   const char* e = getenv("KF_B4_SPLIT");
   if (e && *e) return atoi(e) != 0 && T >= 64;
-  return T >= 256 && B >= 1;
+  if ((flags & KF_FLAG_STEADY_STATE) || (sse && *sse && atoi(sse) != 0)) return T >= 256;
+  return T >= KF_B4_STEADY_MIN_T && B >= 1;
 }
 
 static int b4_split_chunk(int n) {
-  // 128 steps per recursion launch (a hand-over costs the per-draw setup again: ~3 % of 128 steps), more when the series is long
-  int ch = 128;
-  while ((n + ch - 1) / ch > B4_SPLIT_MAX_CHUNKS) ch += 32;
+  // a quarter of the series per recursion launch (a launch boundary costs ~40 us: drain, compaction, hand-over loads), at least
+  // 128 steps; measured (scripts/r03/split_check.py c3tune, 8192 x 2000): 128 / 256 / 384 / 512 / 768 steps 7.2 / 6.0 / 5.8 / 5.7 / 6.0 ms
+  int ch = ((n / 4 + 31) & ~31);
+  if (ch < 128) ch = 128;
   const char* e = getenv("KF_B4_SPLIT_CHUNK");
-  if (e && *e && atoi(e) >= 32) {
-    ch = (atoi(e) + 31) & ~31;
-    while ((n + ch - 1) / ch > B4_SPLIT_MAX_CHUNKS) ch += 32;
-  }
+  if (e && *e && atoi(e) >= 32) ch = (atoi(e) + 31) & ~31;
+  while ((n + ch - 1) / ch > B4_SPLIT_MAX_CHUNKS) ch += 32;
   return ch;
 }
 
@@ -580,14 +619,34 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size
     KF_SET_ERR(h, "forward(b4): needs p == 1, m <= 14, static matrices (got p=%d m=%d r=%d)", a.p, a.m, a.r);
     return KF_ERR_UNSUPPORTED;
   }
+  // Small batches with covariance tapes: the pair kernel (kf_forward_b4p.hip) from step 0.  With at most one draw per SIMD the
+  // step time is one wavefront's dependency chain, and a writer wavefront takes the tape path off it (measured, 1000 steps:
+  // 0.59 / 0.63 / 0.65 ms at 256 / 512 / 1024 draws against 0.81 / 0.83 / 0.86; beyond 2048 draws the fused kernel wins).
+  // KF_FORWARD_B4P=0 / 1 forces the choice.
+  bool pair_env_off = false;
+  {
+    const char* e = getenv("KF_FORWARD_B4P");
+    bool pair = a.B <= B4_PAIR_MAX && (a.filt_P || a.pred_P) && !(a.flags & KF_FLAG_STEADY_STATE);
+    if (e && *e) {
+      pair = atoi(e) != 0;
+      pair_env_off = !pair;
+    }
+    if (pair && !a.tile_tape && kf_forward_b4p_ok(a.m, a.p, a.r)) return kf_launch_forward_b4p(h, a, stream);
+  }
   const int lds_setup = b4_setup_doubles(a.m, a.r);
   const size_t lds = sizeof(double) * (size_t)(B4_LOOP_DOUBLES > lds_setup ? B4_LOOP_DOUBLES : lds_setup);
   const int nb = (a.m + 2 + 3) / 4;
   const int mask = (a.filt_a ? 1 : 0) | (a.pred_a ? 2 : 0) | (a.filt_P ? 4 : 0) | (a.pred_P ? 8 : 0) | (a.tile_tape ? 16 : 0);
   // steady-state phase (kernel header): a second instantiation, so that KF_FLAG_EXACT_RECURSION runs the very kernel it ran before
   // (KF_STEADY_STATE=0 in the environment: the same switch for A/B measurements)
+  // Steady-state phase: only for LONG series (T >= KF_B4_STEADY_MIN_T).  At the north-star length (T = 1000) the recursion at every
+  // step is the faster kernel on most boxes (round 3, six boxes: 1.65 - 1.73 ms against 1.78 - 1.84 with the in-kernel phase and
+  // 2.0 - 2.4 with the split pipeline) -- a launch lasts as long as its slowest SIMD, and 5 % of the structural draws never
+  // converge; at T = 2000 the split pipeline wins (C3: 5.7 against 6.8 - 7.0 ms).  KF_STEADY_STATE=1 / 0 forces it on / off.
   const char* sse = getenv("KF_STEADY_STATE");
-  const bool ss = !(a.flags & KF_FLAG_EXACT_RECURSION) && !a.tile_tape && a.T >= 64 && !(sse && *sse && atoi(sse) == 0);
+  const bool ss_env_on = (sse && *sse && atoi(sse) != 0) || (a.flags & KF_FLAG_STEADY_STATE), ss_env_off = sse && *sse && atoi(sse) == 0;
+  const bool ss = !(a.flags & KF_FLAG_EXACT_RECURSION) && !a.tile_tape && a.T >= 64 && !ss_env_off &&
+                  (a.T >= KF_B4_STEADY_MIN_T || ss_env_on || getenv("KF_B4_SPLIT") != nullptr);
   // (tried: capping the residency of this instantiation at 3 / 2 wavefronts per SIMD so that the dispatcher hands queued draws to the
   // SIMDs whose draws converged early -- headline 2.29 / 2.44 ms against 1.63: the queued wavefronts run as a second round)
   // split pipeline: recursion chunks over compacted draw lists + the time-parallel steady kernels on the second stream
@@ -617,11 +676,14 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size
     B4SplitWs W;
     void* wbase = (void*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     kf_b4_split_carve(wbase, a.B, a.m, a.T, &W);
-    ac.hs_tile = W.hs_tile; ac.hs_logp = W.hs_logp; ac.hs_info = W.hs_info; ac.hs_ts = W.hs_ts; ac.hs_tfree = W.hs_tfree;
+    ac.hs_const = W.hs_const; ac.hs_tile = W.hs_tile; ac.hs_logp = W.hs_logp; ac.hs_info = W.hs_info; ac.hs_ts = W.hs_ts; ac.hs_tfree = W.hs_tfree;
     const int ch = b4_split_chunk(a.T), nch = (a.T + ch - 1) / ch;
     // the second stream starts behind everything already queued on the caller's stream (its inputs) ...
     KF_HIP_CHECK(h, hipEventRecord(h->aux_ev[KF_AUX_EVENTS - 1], stream));
     KF_HIP_CHECK(h, hipStreamWaitEvent(h->aux_stream, h->aux_ev[KF_AUX_EVENTS - 1], 0));
+    KF_HIP_CHECK(h, hipStreamWaitEvent(h->aux_stream2, h->aux_ev[KF_AUX_EVENTS - 1], 0));
+    KF_HIP_CHECK(h, hipStreamWaitEvent(h->aux_stream3, h->aux_ev[KF_AUX_EVENTS - 1], 0));
+    const bool pair_ok = !pair_env_off && (a.filt_P || a.pred_P) && kf_forward_b4p_ok(a.m, a.p, a.r);
     for (int c = 0; c < nch; ++c) {
       ac.t_begin = c * ch;
       ac.t_end = (c + 1) * ch < a.T ? (c + 1) * ch : a.T;
@@ -633,16 +695,35 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size
         default: KF_B4_LAUNCH(3, true); break;
       }
       KF_HIP_CHECK(h, hipGetLastError());
-      int rc = kf_b4_split_compact(h, W, a.B, c, stream);
+      const bool more = ac.t_end < a.T;
+      int rc = kf_b4_split_compact(h, W, a.B, c, ac.t_end, pair_ok && more, stream);
       if (rc) return rc;
       KF_HIP_CHECK(h, hipEventRecord(h->aux_ev[c], stream));
       KF_HIP_CHECK(h, hipStreamWaitEvent(h->aux_stream, h->aux_ev[c], 0));
-      rc = kf_b4_split_steady(h, a, W, c, h->aux_stream);
+      KF_HIP_CHECK(h, hipStreamWaitEvent(h->aux_stream2, h->aux_ev[c], 0));
+      rc = kf_b4_split_steady(h, a, W, c, h->aux_stream, h->aux_stream2);
+      if (rc) return rc;
+      if (pair_ok && more && c > 0) {
+        // the pair kernel's launch for THIS hand-over point: runs only if this compaction decided the switch (pair_ctl[2] == c + 1)
+        KF_HIP_CHECK(h, hipStreamWaitEvent(h->aux_stream3, h->aux_ev[c], 0));
+        KfFwdArgs ap = a;
+        ap.list = W.listR; ap.count = W.pair_ctl; ap.t_begin = c + 1;
+        ap.hs_tile = W.hs_tile; ap.hs_logp = W.hs_logp; ap.hs_info = W.hs_info; ap.hs_ts = W.hs_ts;
+        rc = kf_launch_forward_b4p(h, ap, h->aux_stream3);
+        if (rc) return rc;
+      }
+    }
+    KF_HIP_CHECK(h, hipEventRecord(h->aux_ev[KF_AUX_EVENTS - 4], h->aux_stream3));
+    KF_HIP_CHECK(h, hipStreamWaitEvent(stream, h->aux_ev[KF_AUX_EVENTS - 4], 0));
+    {  // the recursion is done: the rest of the constant covariance tapes at full width (shares the queues of the throttled launches)
+      const int rc = kf_b4_split_drain(h, a, W, nch - 1, stream);
       if (rc) return rc;
     }
     // ... and the caller's stream continues behind the last steady kernel
     KF_HIP_CHECK(h, hipEventRecord(h->aux_ev[KF_AUX_EVENTS - 2], h->aux_stream));
     KF_HIP_CHECK(h, hipStreamWaitEvent(stream, h->aux_ev[KF_AUX_EVENTS - 2], 0));
+    KF_HIP_CHECK(h, hipEventRecord(h->aux_ev[KF_AUX_EVENTS - 3], h->aux_stream2));
+    KF_HIP_CHECK(h, hipStreamWaitEvent(stream, h->aux_ev[KF_AUX_EVENTS - 3], 0));
     return KF_OK;
   }
   switch (nb) {

@@ -461,6 +461,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
   }
 
   int t = 0;
+  int npass = 0;  // consecutive convergence checks passed
   for (; t < n; ++t) {
     if ((t & (QLB - 1)) == 0) load_y_block(t);
     const bool chk = steady_en && (t & 7) == 7 && t >= t_free && t + 16 < n;  // wave-uniform
@@ -525,18 +526,33 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
     }
     bool conv = false;
     if (chk) {
-      unsigned dm = 0, pm = 0;
+      // converged (as in kf_forward_b4.hip): on two consecutive checks the one-step change is within 1e-15 of the largest entry AND
+      // every entry's change within 1e-13 of its own scale sqrt(P_ii P_jj) -- a diffuse block cannot hide a small one that still moves
+      unsigned pm = 0;
+      bool bad = false;
+      double* DG = PO + 240;  // (m * m <= 225: the last 16 doubles of the parked image are free)
       wave_lds_fence();
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+        if (stg_off[I] < 256u * 8u && 4 * I + g == bq) DG[bq] = P[I];
+      wave_lds_fence();
+      const double dcol = DG[bq < m ? bq : 0];
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+        if (stg_off[I] < 256u * 8u) pm = max(pm, abs_hi(P[I]));
+      const double lim = 1e-15 * wave_absmax_hi(pm);
 #pragma unroll
       for (int I = 0; I < NB; ++I) {
         const bool on = stg_off[I] < 256u * 8u;
         const double old = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(PO) + (on ? stg_off[I] : 0u));
-        if (on) {
-          dm = max(dm, abs_hi(P[I] - old));
-          pm = max(pm, abs_hi(P[I]));
-        }
+        const double drow = DG[on ? 4 * I + g : 0];
+        const double df = P[I] - old;
+        bad = bad || (on && !(fabs(df) <= lim && df * df <= 1e-26 * fabs(dcol * drow)));
       }
-      conv = wave_absmax_hi(dm) <= 1e-15 * wave_absmax_hi(pm);
+      wave_lds_fence();
+      const bool ok = __ballot(bad) == 0ull;
+      npass = ok ? npass + 1 : 0;
+      conv = npass >= 2;
     }
     if (w_pa) {
       if (vec_on) st_off(t_pa, voff, 0.5 * P[NB - 1]);

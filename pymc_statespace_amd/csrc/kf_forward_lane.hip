@@ -400,6 +400,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
     for (int i = 0; i < M; ++i) a[i] = __shfl(ap[i], d + DPW * (S - 1), KF_WAVE);  // the next block starts from the last lane's prediction
   };
   int t = 0;
+  int npass = 0;  // consecutive convergence checks this lane's draw has passed
   for (; t < n; ++t) {
     const int s = t & (S - 1);
     if (steady_en && s == S - 1) {
@@ -530,7 +531,18 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
         for (int i = 0; i < M; ++i)
 #pragma unroll
           for (int j = i; j < M; ++j) still = still && (P[i][j] == P[i][j]);  // (fmax drops NaNs)
-        const bool newly = !fz && still && t >= t_free && dmax <= 3e-16 * pmax;
+        // (as in kf_forward_b4.hip: also every entry within 1e-13 of its own scale, and on two consecutive checks)
+        bool each = true;
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int j = i; j < M; ++j) {
+            const double df = P[i][j] - Pold[i][j];
+            each = each && (df * df <= 1e-26 * fabs(P[i][i] * P[j][j]));
+          }
+        const bool pass = still && t >= t_free && dmax <= 3e-16 * pmax && each;
+        npass = pass ? npass + 1 : 0;
+        const bool newly = !fz && npass >= 2;
         if constexpr (SCAN) {
           if (newly) freeze_consts(t + 1);
         }

@@ -33,7 +33,9 @@ struct kf_handle {
   // Created on first use (kf_handle_aux), forked from / joined to the caller's stream with events -- the call stays
   // asynchronous on the caller's stream and never synchronises the host
   int aux_ready;
-  hipStream_t aux_stream;
+  hipStream_t aux_stream;   // covariance fill
+  hipStream_t aux_stream2;  // mean recursion
+  hipStream_t aux_stream3;  // pair kernel: the tail of the full recursion
   hipEvent_t aux_ev[KF_AUX_EVENTS];
 };
 int kf_handle_aux(kf_handle* h);  // KF_OK once aux_stream / aux_ev exist (current device = the handle's)
@@ -71,6 +73,7 @@ struct KfFwdArgs {
   int t_begin = 0, t_end = 0;
   const int32_t* list = nullptr;
   const int32_t* count = nullptr;
+  double* hs_const = nullptr;   // [B][B4_HC_STRIDE] the first chunk's per-draw constants in register layout (T blocks, C_ext)
   double* hs_tile = nullptr;    // [B][NB * 64] register image of the predicted tile at the hand-over step
   double* hs_logp = nullptr;    // [B] log-likelihood of the steps done so far
   int32_t* hs_info = nullptr;   // [B]
@@ -180,6 +183,9 @@ int kf_launch_forward_mfma(kf_handle* h, const KfFwdArgs& a, hipStream_t stream)
 // 4x4x4-block kernel (kf_forward_b4.hip): v_mfma_f64_4x4x4_4b_f64, p == 1, m <= 14, mean carried in the tile
 bool kf_forward_b4_ok(int m, int p, int r);
 int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream);
+// recursion + tape-writer wavefront per draw (kf_forward_b4p.hip)
+bool kf_forward_b4p_ok(int m, int p, int r);
+int kf_launch_forward_b4p(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 // several scalar observations per step on the same 4x4x4 block tiles (kf_forward_b4q.hip)
 bool kf_forward_b4q_ok(int m, int p, int r);
 int kf_launch_forward_b4q(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);

@@ -161,12 +161,13 @@ class KalmanEngine:
         Standard/Cholesky filters with p > 1, m <= 48 use the register-resident kernels);
         None checks H on the device (one small reduction + host sync) when it matters.
 
-        ``exact_recursion``: True sets KF_FLAG_EXACT_RECURSION.  By default the kernels for static models (lane kernel m <= 4,
-        block kernels p == 1 / 3 <= p <= 5 with m >= 8) stop recomputing the covariance recursion once the predicted covariance
-        has converged (no missing observation ahead) and advance only the mean with the converged gain; results agree with
-        the step-by-step recursion to ~1e-13 relative (None: the engine's default, ``set_exact_recursion``)."""
+        ``exact_recursion``: True sets KF_FLAG_EXACT_RECURSION (the covariance recursion at every step, as the reference), False
+        sets KF_FLAG_STEADY_STATE (stop recomputing it once the predicted covariance has converged and no observation is
+        missing ahead, wherever the selected kernel can), None leaves the choice to the library (include/kf.h: lane kernel
+        m <= 4 and the multi-observation block kernel use the phase, the p == 1 block kernel from 1536 steps on) unless
+        ``set_exact_recursion(True)`` made exact the engine's default.  Results agree to ~1e-13 relative."""
         if exact_recursion is None:
-            exact_recursion = getattr(self, "_exact_recursion", False)
+            exact_recursion = True if getattr(self, "_exact_recursion", False) else None
         tv = set(time_varying)
         if not tv <= set(_lib.KF_FLAG_TV):
             raise ValueError(f"time_varying must be a subset of {sorted(_lib.KF_FLAG_TV)}")
@@ -230,6 +231,8 @@ class KalmanEngine:
             dims.flags |= _lib.KF_FLAG_H_DIAGONAL
         if exact_recursion:
             dims.flags |= _lib.KF_FLAG_EXACT_RECURSION
+        elif exact_recursion is not None:  # False: the caller asks for the steady-state phase (KF_FLAG_STEADY_STATE)
+            dims.flags |= _lib.KF_FLAG_STEADY_STATE
         dev, f64 = self.device, torch.float64
         if out is None:
             out = FilterResult(
@@ -323,7 +326,7 @@ class KalmanEngine:
         sum_b g_logp[b] logp[b] (default: ones) in ONE call: the predicted tapes live in the workspace only.
         ``exact_recursion`` as in ``forward`` (None: the engine's default, ``set_exact_recursion``)."""
         if exact_recursion is None:
-            exact_recursion = getattr(self, "_exact_recursion", False)
+            exact_recursion = True if getattr(self, "_exact_recursion", False) else None
         P0 = self.to_device(P0)
         B, m = P0.shape[0], P0.shape[1]
         Z = self.to_device(Z, None)
@@ -347,6 +350,8 @@ class KalmanEngine:
             dims.flags |= _lib.KF_FLAG_H_DIAGONAL
         if exact_recursion:
             dims.flags |= _lib.KF_FLAG_EXACT_RECURSION
+        elif exact_recursion is not None:  # False: the caller asks for the steady-state phase (KF_FLAG_STEADY_STATE)
+            dims.flags |= _lib.KF_FLAG_STEADY_STATE
         dev, f64 = self.device, torch.float64
         logp = torch.empty(B, device=dev, dtype=f64)
         info = torch.empty(B, device=dev, dtype=torch.int32)

@@ -81,5 +81,60 @@ if __name__ == "__main__":
         check("headline", W.WORKLOADS["headline"](), oracle_draws=256)
         check("headline logp-only", W.WORKLOADS["headline"](), oracle_draws=256, full=False)
         check("headline B=512", W.WORKLOADS["headline"](B=512), oracle_draws=64)
+    if which == "occ":
+        for B in (256, 512, 1024, 1536, 2048, 3072, 4096):
+            w = W.WORKLOADS["headline"](B=B)
+            dev = [eng.to_device(w[k]) for k in KEYS]
+            fkw = dict(filter_type="standard", mvn_const="exact")
+            rs = eng.forward(*dev, exact_recursion=True, **fkw)
+            t_full = ms(lambda: eng.forward(*dev, out=rs, exact_recursion=True, **fkw))
+            lo = eng.forward(*dev, exact_recursion=True, store_ll_obs=False, store_filtered=False, store_predicted=False, **fkw)
+            t_lo = ms(lambda: eng.forward(*dev, out=lo, exact_recursion=True, store_ll_obs=False, store_filtered=False,
+                                          store_predicted=False, **fkw))
+            os.environ["KF_FORWARD_B4P"] = "1"
+            rp = eng.forward(*dev, exact_recursion=True, **fkw)
+            t_pair = ms(lambda: eng.forward(*dev, out=rp, exact_recursion=True, **fkw))
+            os.environ["KF_FORWARD_B4P"] = "0"
+            dlp = ((rp.logp - rs.logp).abs() / rs.logp.abs().clamp_min(1)).max().item()
+            dP = (rp.predicted_covs - rs.predicted_covs).abs().max().item()
+            print(f"exact recursion B={B}: full tapes {t_full:.3f} ms, logp only {t_lo:.3f} ms | pair kernel {t_pair:.3f} ms "
+                  f"(rel dlogp {dlp:.1e}, dP {dP:.1e})", flush=True)
+            del rp
+            del dev, rs, lo
+    if which == "tune":
+        w = W.WORKLOADS["headline"]()
+        dev = [eng.to_device(w[k]) for k in KEYS]
+        fkw = dict(filter_type="standard", mvn_const="exact")
+        rs = eng.forward(*dev, **fkw)
+        os.environ["KF_B4_SPLIT"] = "1"
+        for ch in (128, 192, 256):
+            for wgs in (32, 64, 96, 128, 192, 256, 512, 2048):
+                os.environ["KF_B4_SPLIT_CHUNK"] = str(ch)
+                os.environ["KF_B4_FILL_WGS"] = str(wgs)
+                print(f"chunk {ch} throttled fill workgroups {wgs}: {ms(lambda: eng.forward(*dev, out=rs, **fkw)):.3f} ms", flush=True)
+        os.environ.pop("KF_B4_FILL_WGS")
+        for ch in (128, 256):
+            for dbg in (1, 2, 3):
+                os.environ["KF_B4_SPLIT_CHUNK"] = str(ch)
+                os.environ["KF_B4_SPLIT_DEBUG"] = str(dbg)
+                print(f"chunk {ch} skip(fill=1,scan=2) {dbg}: {ms(lambda: eng.forward(*dev, out=rs, **fkw)):.3f} ms", flush=True)
+        os.environ.pop("KF_B4_SPLIT_CHUNK"); os.environ.pop("KF_B4_SPLIT_DEBUG")
     if which in ("all", "c3"):
         check("c3", W.WORKLOADS["c3"](), ft="cholesky", oracle_draws=64)
+    if which == "c3tune":
+        w = W.WORKLOADS["c3"]()
+        dev = [eng.to_device(w[k]) for k in KEYS]
+        fkw = dict(filter_type="cholesky", mvn_const="exact")
+        rs = eng.forward(*dev, **fkw)
+        for split in ("0", "1"):
+            os.environ["KF_B4_SPLIT"] = split
+            for ch in (256, 384, 512, 768):
+                for wgs in (512, 1024, 2048):
+                    os.environ["KF_B4_SPLIT_CHUNK"] = str(ch)
+                    os.environ["KF_B4_FILL_WGS"] = str(wgs)
+                    print(f"c3 split={split} chunk {ch} fill wgs {wgs}: {ms(lambda: eng.forward(*dev, out=rs, **fkw), 5):.3f} ms", flush=True)
+                    if split == "0":
+                        break
+                if split == "0":
+                    break
+        print(f"c3 exact: {ms(lambda: eng.forward(*dev, out=rs, exact_recursion=True, **fkw), 5):.3f} ms")

@@ -16,6 +16,8 @@ w = W.WORKLOADS[name](**({"B": B} if B else {}))
 dev = [eng.to_device(w[k]) for k in ("y", "a0", "P0", "T", "Z", "R", "H", "Q")]
 ft = "cholesky" if name == "c3" else "standard"
 fkw = dict(filter_type=ft, mvn_const="exact", store_ll_obs=full, store_filtered=full, store_predicted=full)
+if len(sys.argv) > 4:
+    os.environ["KF_B4_SPLIT_DEBUG"] = sys.argv[4]
 res = eng.forward(*dev, **fkw)
 for _ in range(4):
     eng.forward(*dev, out=res, **fkw)

@@ -1,0 +1,258 @@
+"""Round-3 forward paths of the block kernel (p == 1, m <= 14), through the C-ABI, against the numpy / C oracle
+(reference pymc_statespace/filters/kalman_filter.py:126-252, 255-351, 444-505):
+
+* the PAIR kernel (csrc/kf_forward_b4p.hip: recursion wavefront + tape-writer wavefront per draw) -- what batches of
+  <= 1024 draws with covariance tapes run on, and the tail of the split pipeline;
+* the SPLIT pipeline (csrc/kf_forward_b4.hip SS = 2 + csrc/kf_forward_b4_steady.hip): recursion launches over compacted
+  draw lists, converged draws handed to the constant-covariance fill and the time-parallel mean scan on other streams --
+  the default for series of >= 1536 steps, requested below that with exact_recursion=False (KF_FLAG_STEADY_STATE);
+* the convergence test that guards every steady-state phase: entrywise on two consecutive checks (a
+  diffuse block must not hide a small block that still moves).
+
+Tolerances: |dlogp| < 1e-8 * max(1, |logp| / 1e4); tapes rtol = atol = 1e-9 (as tests/test_gpu_parity.py).
+"""
+import os
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import workloads as W
+from oracle import c_oracle as co
+from oracle import kalman_numpy as kn
+
+pytestmark = pytest.mark.gpu
+TAPES = ["filtered_states", "predicted_states", "filtered_covs", "predicted_covs", "ll_obs"]
+KEYS = ("a0", "P0", "T", "Z", "R", "H", "Q")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    from pymc_statespace_amd import KalmanEngine
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return KalmanEngine()
+
+
+def _args(w, y=None):
+    return (w["y"] if y is None else y,) + tuple(w[k] for k in KEYS)
+
+
+def _check(res, ref, tag, draws=None):
+    sl = slice(None) if draws is None else draws
+    lp = res.logp.cpu().numpy()[sl]
+    tol = 1e-8 * np.maximum(1.0, np.abs(ref["logp"]) / 1e4)
+    assert np.all(np.abs(lp - ref["logp"]) <= tol), f"{tag}: max |dlogp| = {np.abs(lp - ref['logp']).max():.2e}"
+    for k in TAPES:
+        v = getattr(res, k)
+        if v is not None:
+            assert_allclose(v.cpu().numpy()[sl], ref[k], rtol=1e-9, atol=1e-9, err_msg=f"{tag} {k}")
+
+
+# ----------------------------------------------------------------------------------------------
+# pair kernel
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m", [1, 2, 5, 6, 9, 10, 13, 14])
+@pytest.mark.parametrize("ft", ["standard", "cholesky", "univariate", "single"])
+def test_pair_kernel_matches_oracle(eng, m, ft):
+    """Every block count (NB = 1 .. 4), missing rows, intercepts, every filter's constants; identical to the fused kernel."""
+    B, n = 21, 173
+    w = W.random_dense(B, n, 1, m, min(m, 3), seed=900 + m)
+    y = w["y"].copy()
+    y[[2, 40, 41, 172]] = np.nan
+    rng = np.random.default_rng(m)
+    c, d = 0.05 * rng.standard_normal((B, m)), 0.1 * rng.standard_normal((B, 1))
+    ref = kn.kalman_filter(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact")
+    r = eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact")
+    assert not r.info.cpu().numpy().any()
+    _check(r, ref, f"pair m={m} {ft}")
+    os.environ["KF_FORWARD_B4P"] = "0"
+    try:
+        f = eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact", exact_recursion=True)
+    finally:
+        del os.environ["KF_FORWARD_B4P"]
+    for k in TAPES + ["logp"]:  # (same arithmetic: bit-identical at the north-star shape; rounding-level otherwise)
+        assert_allclose(getattr(r, k).cpu().numpy(), getattr(f, k).cpu().numpy(), rtol=1e-12, atol=1e-13, err_msg=k)
+
+
+def test_pair_kernel_partial_outputs_per_draw_data_and_flags(eng):
+    w = W.structural(B=33, n=200)
+    full = eng.forward(*_args(w), mvn_const="exact")
+    for sel in ((False, True, False), (False, False, True), (True, True, False)):
+        r = eng.forward(*_args(w), mvn_const="exact", store_ll_obs=sel[0], store_filtered=sel[1], store_predicted=sel[2])
+        assert np.array_equal(r.logp.cpu().numpy(), full.logp.cpu().numpy())
+        for k in TAPES:
+            v = getattr(r, k)
+            if v is not None:
+                assert np.array_equal(v.cpu().numpy(), getattr(full, k).cpu().numpy()), f"{sel} {k}"
+    # y per draw, a draw whose H makes F negative, a NaN parameter
+    yb = np.repeat(w["y"][None], 33, 0).copy()
+    yb[3, 150] = np.nan
+    H = w["H"].copy()
+    H[4] = -50.0
+    T = w["T"].copy()
+    T[6, 0, 0] = np.nan
+    r = eng.forward(yb, w["a0"], w["P0"], T, w["Z"], w["R"], H, w["Q"], mvn_const="exact")
+    info = r.info.cpu().numpy()
+    assert info[4] != 0 and info[6] != 0 and (info[np.r_[0:4, 5, 7:33]] == 0).all()  # (a NaN F is flagged like a negative one)
+    lp = r.logp.cpu().numpy()
+    assert np.isnan(lp[[4, 6]]).all()
+    good = np.r_[0:4, 5, 7:33]
+    ref = kn.kalman_filter(yb[good], *[w[k][good] for k in KEYS], mvn_const="exact")
+    _check(r, ref, "pair per-draw y", draws=good)
+
+
+# ----------------------------------------------------------------------------------------------
+# split pipeline
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m", [1, 2, 3, 5, 6, 7, 9, 10])
+@pytest.mark.parametrize("n", [256, 300, 1000])
+def test_split_pipeline_matches_oracle_and_exact_recursion(eng, m, n):
+    """exact_recursion=False -> KF_FLAG_STEADY_STATE: chunks of the recursion, compaction, hand-over to the fill / scan
+    kernels (and to the pair kernel once <= 1024 draws are left: at once for a batch this small)."""
+    B = 37
+    w = W.random_dense(B, n, 1, m, min(m, 3), seed=100 + m)
+    ref = co.kalman_filter(*_args(w), filter_type="standard", mvn_const="exact")
+    s = eng.forward(*_args(w), mvn_const="exact", exact_recursion=False)
+    x = eng.forward(*_args(w), mvn_const="exact", exact_recursion=True)
+    assert not s.info.cpu().numpy().any()
+    _check(s, ref, f"split m={m} n={n}")
+    assert_allclose(s.logp.cpu().numpy(), x.logp.cpu().numpy(), rtol=1e-12)
+    assert_allclose(s.predicted_covs.cpu().numpy(), x.predicted_covs.cpu().numpy(), rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("ft", ["standard", "cholesky", "univariate", "single"])
+def test_split_pipeline_filters_intercepts_and_late_missing_rows(eng, ft):
+    """A late NaN keeps every draw in the full recursion until it has passed; intercepts; the fused chunks with compaction
+    (1500 draws: more than the pair kernel takes over) and then the pair kernel's tail."""
+    B, n = 1500, 640
+    w = W.structural(B=B, n=n)
+    y = w["y"].copy()
+    y[[5, 130, 131, 300]] = np.nan
+    rng = np.random.default_rng(3)
+    c, d = 0.05 * rng.standard_normal((B, w["m"])), 0.1 * rng.standard_normal((B, 1))
+    k = 96
+    ref = kn.kalman_filter(y, *[w[x][:k] for x in KEYS], c=c[:k], d=d[:k], filter_type=ft, mvn_const="exact")
+    s = eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact", exact_recursion=False)
+    x = eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact", exact_recursion=True)
+    assert not s.info.cpu().numpy().any()
+    _check(s, ref, f"split {ft}", draws=slice(0, k))
+    assert_allclose(s.logp.cpu().numpy(), x.logp.cpu().numpy(), rtol=1e-12)
+    for kk in TAPES:
+        assert_allclose(getattr(s, kk).cpu().numpy(), getattr(x, kk).cpu().numpy(), rtol=1e-10, atol=1e-11, err_msg=kk)
+    # the phase did switch for some draw: the covariance tapes become exact constants
+    fP = s.filtered_covs.cpu().numpy()
+    assert np.any(np.all(fP[:, -1] == fP[:, -40], axis=(1, 2)))
+
+
+def test_split_pipeline_partial_outputs_and_per_draw_data(eng):
+    w = W.structural(B=1300, n=512)
+    full = eng.forward(*_args(w), mvn_const="exact", exact_recursion=False)
+    for sel in ((False, True, False), (False, False, True), (True, False, False), (False, False, False)):
+        r = eng.forward(*_args(w), mvn_const="exact", store_ll_obs=sel[0], store_filtered=sel[1], store_predicted=sel[2],
+                        exact_recursion=False)
+        assert_allclose(r.logp.cpu().numpy(), full.logp.cpu().numpy(), rtol=1e-12)
+        for k in TAPES:
+            v = getattr(r, k)
+            if v is not None:
+                assert_allclose(v.cpu().numpy(), getattr(full, k).cpu().numpy(), rtol=1e-11, atol=1e-12, err_msg=f"{sel} {k}")
+    B = 70
+    w = W.structural(B=B, n=400)
+    yb = np.repeat(w["y"][None], B, 0).copy()
+    yb[3, 350] = np.nan          # that draw enters the steady phase only behind step 350
+    yb[10] *= 1.5
+    H = w["H"].copy()
+    H[4] = -50.0                 # F < 0: flagged at the first step, logp NaN
+    r = eng.forward(yb, w["a0"], w["P0"], w["T"], w["Z"], w["R"], H, w["Q"], mvn_const="exact", exact_recursion=False)
+    x = eng.forward(yb, w["a0"], w["P0"], w["T"], w["Z"], w["R"], H, w["Q"], mvn_const="exact", exact_recursion=True)
+    assert np.array_equal(r.info.cpu().numpy(), x.info.cpu().numpy())
+    good = np.r_[0:4, 5:B]
+    ref = kn.kalman_filter(yb[good], *[w[k][good] if k != "H" else H[good] for k in KEYS], mvn_const="exact")
+    _check(r, ref, "split per-draw y", draws=good)
+
+
+def test_split_pipeline_writes_inside_its_tapes_only(eng):
+    """Guard words around every tape: the fill kernel's head / tail elements and line-aligned windows, the scan kernel's rows."""
+    import torch
+
+    from pymc_statespace_amd.engine import FilterResult
+
+    for m, n in ((10, 450), (9, 300), (6, 700)):
+        B = 11
+        w = W.structural(B=B, n=n) if m == 10 else W.random_dense(B, n, 1, m, 3, seed=m)
+        ref = eng.forward(*_args(w), mvn_const="exact", exact_recursion=True)
+
+        def guarded(*shape):
+            flat = torch.full((int(np.prod(shape)) + 6,), float("nan"), device="cuda", dtype=torch.float64)
+            return flat, flat[3:3 + int(np.prod(shape))].view(*shape)
+
+        bufs = {k: guarded(*s) for k, s in dict(ll_obs=(B, n), filtered_states=(B, n, m), predicted_states=(B, n + 1, m),
+                                                filtered_covs=(B, n, m, m), predicted_covs=(B, n + 1, m, m)).items()}
+        out = FilterResult(logp=torch.empty(B, device="cuda", dtype=torch.float64),
+                           info=torch.empty(B, device="cuda", dtype=torch.int32), **{k: v[1] for k, v in bufs.items()})
+        eng.forward(*_args(w), mvn_const="exact", out=out, exact_recursion=False)
+        for k, (flat, view) in bufs.items():
+            assert_allclose(view.cpu().numpy(), getattr(ref, k).cpu().numpy(), rtol=1e-9, atol=1e-10, err_msg=k)
+            gd = flat.cpu().numpy()
+            assert np.isnan(gd[:3]).all() and np.isnan(gd[-3:]).all(), f"m={m} {k}: wrote outside the tape"
+
+
+def test_long_series_take_the_split_pipeline_by_default(eng):
+    """T >= 1536: the library's default for the block kernel (config C3 is T = 2000); C3-shaped, Cholesky filter."""
+    w = W.structural(B=1100, n=1600)
+    k = 48
+    ref = co.kalman_filter(w["y"], *[w[x][:k] for x in KEYS], filter_type="cholesky", mvn_const="exact")
+    d = eng.forward(*_args(w), filter_type="cholesky", mvn_const="exact")
+    x = eng.forward(*_args(w), filter_type="cholesky", mvn_const="exact", exact_recursion=True)
+    _check(d, ref, "default T=1600", draws=slice(0, k))
+    fd = d.filtered_covs.cpu().numpy()
+    assert np.any(np.all(fd[:, -1] == fd[:, -200], axis=(1, 2)))  # the phase did switch: exact constants on the tape
+    assert_allclose(d.logp.cpu().numpy(), x.logp.cpu().numpy(), rtol=1e-12)
+    # T = 1000 (the north-star length): the default IS the recursion at every step
+    w = W.structural(B=1100, n=1000)
+    d = eng.forward(*_args(w), mvn_const="exact")
+    x = eng.forward(*_args(w), mvn_const="exact", exact_recursion=True)
+    for kk in TAPES + ["logp"]:
+        assert np.array_equal(getattr(d, kk).cpu().numpy(), getattr(x, kk).cpu().numpy()), kk
+
+
+# ----------------------------------------------------------------------------------------------
+# the convergence test
+# ----------------------------------------------------------------------------------------------
+def _diffuse_beside_slow(B, n, rho, seed=0):
+    """Local level with a diffuse start (P0 = 1e7) and large variance beside an AR(1) component with a small variance whose
+    covariance converges slowly (rho close to 1): under a test scaled by the LARGEST entry alone the small block is
+    still moving at ~1e-6 relative when the large one has stopped."""
+    rng = np.random.default_rng(seed)
+    m, r = 2, 2
+    T = np.zeros((B, m, m)); T[:, 0, 0] = 1.0; T[:, 1, 1] = rho
+    Z = np.ones((B, 1, m))
+    R = np.repeat(np.eye(m)[None], B, 0)
+    Q = np.zeros((B, r, r)); Q[:, 0, 0] = 1e4 * (1 + rng.random(B)); Q[:, 1, 1] = 1e-4 * (1 + rng.random(B))
+    H = np.full((B, 1, 1), 1e4)
+    a0 = np.zeros((B, m))
+    P0 = np.zeros((B, m, m)); P0[:, 0, 0] = 1e7; P0[:, 1, 1] = 1e-4 / (1 - rho ** 2) * 50
+    y = np.cumsum(100 * rng.standard_normal(n))
+    return dict(y=y[:, None], a0=a0, P0=P0, T=T, Z=Z, R=R, H=H, Q=Q, B=B, n=n, m=m)
+
+
+@pytest.mark.parametrize("kernel", ["lane", "b4"])
+@pytest.mark.parametrize("rho", [0.99, 0.999])
+def test_steady_state_test_is_entrywise(eng, kernel, rho):
+    """A diffuse 1e7 state beside a slowly converging small component: the steady-state phase must not freeze the small
+    block early -- its covariance and the log-likelihood stay within the parity tolerances of the step-by-step recursion."""
+    w = _diffuse_beside_slow(40, 1200, rho)
+    eng.set_forward_kernel(kernel)
+    try:
+        s = eng.forward(*_args(w), mvn_const="exact", exact_recursion=False)
+        x = eng.forward(*_args(w), mvn_const="exact", exact_recursion=True)
+    finally:
+        eng.set_forward_kernel("auto")
+    ps, px = s.predicted_covs.cpu().numpy(), x.predicted_covs.cpu().numpy()
+    # entrywise RELATIVE agreement of the small block (an absolute 1e-9 would hide it under the 1e4-sized entries)
+    assert_allclose(ps[:, :, 1, 1], px[:, :, 1, 1], rtol=1e-9)
+    assert_allclose(ps, px, rtol=1e-9, atol=1e-12)
+    assert_allclose(s.logp.cpu().numpy(), x.logp.cpu().numpy(), rtol=1e-11)
+    assert_allclose(s.filtered_states.cpu().numpy(), x.filtered_states.cpu().numpy(), rtol=1e-8, atol=1e-8)

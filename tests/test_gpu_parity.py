@@ -1565,9 +1565,11 @@ def test_b4_kernel_per_draw_data_not_pd_and_univariate_skip(eng):
 
 
 def test_b4_kernel_steady_state_phase_matches_exact_recursion(eng):
-    """Default: once the predicted covariance has stopped moving (and no observation is missing ahead) the block kernel
-    advances only the mean with the converged gain; KF_FLAG_EXACT_RECURSION keeps the step-by-step recursion.  Both against
-    the oracle; a series with a late missing row (steady state entered only behind it) and intercepts."""
+    """KF_FLAG_STEADY_STATE (exact_recursion=False; the default from 1536 steps on): once the predicted covariance has stopped
+    moving (and no observation is missing ahead) the block kernel advances only the mean with the converged gain;
+    KF_FLAG_EXACT_RECURSION keeps the step-by-step recursion.  Both against the oracle; a series with a late missing row
+    (steady state entered only behind it) and intercepts.  A 24-draw batch runs on the pair kernel (<= 1024 draws with
+    covariance tapes: always the recursion at every step), so the fused kernel is forced here."""
     w = W.structural(B=24, n=600)
     B, m = 24, w["m"]
     rng = np.random.default_rng(1)
@@ -1591,9 +1593,10 @@ def test_b4_kernel_steady_state_phase_matches_exact_recursion(eng):
             assert_allclose(outs[True]["filtered_covs"], outs[False]["filtered_covs"], rtol=1e-11, atol=1e-12)
             assert_allclose(outs[True]["logp"], outs[False]["logp"], rtol=1e-12)
     # partial outputs in the steady phase: every tape subset, against the full run
-    full = _np(eng.forward(*_args(w), mvn_const="exact"))
+    full = _np(eng.forward(*_args(w), mvn_const="exact", exact_recursion=False))
     for sel in ((False, True, False), (False, False, True), (True, False, False), (False, False, False)):
-        r = eng.forward(*_args(w), mvn_const="exact", store_ll_obs=sel[0], store_filtered=sel[1], store_predicted=sel[2])
+        r = eng.forward(*_args(w), mvn_const="exact", store_ll_obs=sel[0], store_filtered=sel[1], store_predicted=sel[2],
+                        exact_recursion=False)
         assert_allclose(r.logp.cpu().numpy(), full["logp"], rtol=1e-13)
         for k in TAPES:
             v = getattr(r, k)
@@ -1819,7 +1822,7 @@ def test_steady_state_per_draw_data_not_pd_and_nan_parameters(eng, name):
     H[4] = -np.abs(H[4]) - 50.0 * np.eye(H.shape[-1])
     T = w["T"].copy()
     T[6, 0, 0] = np.nan
-    r = eng.forward(yb, w["a0"], w["P0"], T, w["Z"], w["R"], H, w["Q"], mvn_const="exact", **kw)
+    r = eng.forward(yb, w["a0"], w["P0"], T, w["Z"], w["R"], H, w["Q"], mvn_const="exact", exact_recursion=False, **kw)
     x = eng.forward(yb, w["a0"], w["P0"], T, w["Z"], w["R"], H, w["Q"], mvn_const="exact", exact_recursion=True, **kw)
     assert np.array_equal(r.info.cpu().numpy(), x.info.cpu().numpy())
     lp = r.logp.cpu().numpy()
@@ -1851,7 +1854,7 @@ def test_steady_state_tapes_do_not_write_outside(eng):
                                                 filtered_covs=(B, n, m, m), predicted_covs=(B, n + 1, m, m)).items()}
         out = FilterResult(logp=torch.empty(B, device="cuda", dtype=torch.float64),
                            info=torch.empty(B, device="cuda", dtype=torch.int32), **{k: v[1] for k, v in bufs.items()})
-        eng.forward(*_args(w), mvn_const="exact", out=out, **kw)
+        eng.forward(*_args(w), mvn_const="exact", out=out, exact_recursion=False, **kw)
         for k, (flat, view) in bufs.items():
             assert_allclose(view.cpu().numpy(), getattr(ref, k).cpu().numpy(), rtol=1e-9, atol=1e-10, err_msg=k)
             gd = flat.cpu().numpy()
