@@ -377,8 +377,10 @@ def main():
                 "global_draws": B_global, "parallelism": f"draws sharded x{world}",
                 "draw_steps_per_s": B_global * n * args.steps / elapsed,
                 "covariance_recursion": "every step (KF_FLAG_EXACT_RECURSION)" if args.exact_recursion else
-                "until converged to 1e-15, then the mean only with the converged gain (library default; all outputs still "
-                "written; other_entry_points.forward_exact_recursion_ms is the same call with the recursion at every step)",
+                "library default (include/kf.h, KF_FLAG_EXACT_RECURSION): every step for p = 1, 4 < m <= 10 below 1536 steps -- the "
+                "north-star shape -- and for <= 1024 draws; else until the predicted covariance has converged, then the mean only "
+                "with the converged gain; other_entry_points.forward_exact_recursion_ms / forward_steady_state_ms time the same "
+                "call with either behaviour forced",
             },
         }
         diag = bool(p > 1 and np.all(base["H"] == base["H"] * np.eye(p)))
@@ -436,11 +438,16 @@ def main():
                                                               store_filtered=False, store_predicted=False, out=lo_res))
                 ops["logp_and_gradient_one_call_ms"] = _ms(lambda: eng.value_and_grad(*d, filter_type=ft, mvn_const="exact",
                                                                                       h_diagonal=True))
-                if not args.exact_recursion:
-                    ex_res = eng.forward(*d, exact_recursion=True, **fkw)
-                    ops["forward_exact_recursion_ms"] = _ms(lambda: eng.forward(*d, exact_recursion=True, out=ex_res, **fkw))
-                    ops["max_rel_dlogp_exact_vs_default"] = float(((ex_res.logp - res.logp).abs() / ex_res.logp.abs()).max())
-                    del ex_res
+                # the timed call runs the library's default; the same call with the covariance recursion forced at every
+                # step (KF_FLAG_EXACT_RECURSION) and with the steady-state phase requested (KF_FLAG_STEADY_STATE), and how far
+                # the three log-likelihood vectors are apart
+                ex_res = eng.forward(*d, exact_recursion=True, **fkw)
+                ops["forward_exact_recursion_ms"] = _ms(lambda: eng.forward(*d, exact_recursion=True, out=ex_res, **fkw))
+                ops["max_rel_dlogp_exact_vs_default"] = float(((ex_res.logp - res.logp).abs() / ex_res.logp.abs()).max())
+                ss_res = eng.forward(*d, exact_recursion=False, **fkw)
+                ops["forward_steady_state_ms"] = _ms(lambda: eng.forward(*d, exact_recursion=False, out=ss_res, **fkw))
+                ops["max_rel_dlogp_exact_vs_steady_state"] = float(((ex_res.logp - ss_res.logp).abs() / ex_res.logp.abs()).max())
+                del ex_res, ss_res
                 if full:
                     ops["rts_smoother_ms"] = _ms(lambda: eng.smooth(d[3], d[5], d[7], res.filtered_states,
                                                                      res.filtered_covs), reps=3)

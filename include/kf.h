@@ -100,7 +100,7 @@ enum {
    * kernel: 16) steps whether the predicted covariance has stopped moving and from then on advance only the mean with the
    * converged gain, writing the two constant covariances to the tapes -- what statsmodels' filter does by default
    * (`tolerance`).  The test (round 3): no missing observation ahead, series of >= 64 steps, and on TWO consecutive checks the
-   * one-step change of every entry is <= 1e-15 (lane kernel 3e-16) of the largest entry AND <= 1e-13 of the entry's own scale
+   * one-step change of every entry is <= 1e-15 (lane kernel 3e-16) of the largest entry AND <= 1e-12 of the entry's own scale
    * sqrt(P_ii P_jj) -- the second condition keeps a large (diffuse) block from hiding a small block that still moves.
    * The reference recomputes every step; measured differences on the BASELINE workloads: <= 7e-14 relative on logp, <= 5e-13
    * absolute on the covariance tapes.

@@ -300,8 +300,13 @@ extern "C" const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_di
   return "kf_fwd_lds_kernel";
 }
 
-int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
+int kf_launch_forward(kf_handle* h, const KfFwdArgs& a_in, void* workspace, size_t workspace_bytes,
                       hipStream_t stream) {
+  KfFwdArgs a = a_in;
+  {
+    const char* e = getenv("KF_SS_ENTRY_TOL");  // experiments: the entrywise tolerance of the steady-state test (default 1e-12)
+    if (e && *e && atof(e) > 0.0) a.ss_tol2 = atof(e) * atof(e);
+  }
   if (a.flags & KF_FLAG_TV_ANY) {
     if (((a.flags & KF_FLAG_TV_C) && !a.c) || ((a.flags & KF_FLAG_TV_D) && !a.d)) {
       KF_SET_ERR(h, "time-varying c / d flagged but the pointer is NULL");
@@ -536,6 +541,20 @@ static bool kf_vg_tile_path(const kf_handle* h, const kf_dims* d) {
   return kf_b4_selected(h, d->m, d->p, d->r, d->B) && kf_backward_b4_selected(h, d->m, d->p, d->r, d->B);
 }
 
+// value-and-gradient with the steady-state adjoint (kf_backward_steady.hip): the forward kernel must report where its
+// steady-state phase starts (the multi-observation block kernel does) and the exact adjoint behind it must take per-draw step
+// counts (kf_backward_mfma.hip: m <= 16, scalar observations).  KF_VG_STEADY=0 in the environment: the exact adjoint at every step
+static bool kf_vg_steady_path(const kf_handle* h, const kf_dims* d) {
+  if ((d->flags & (KF_FLAG_TV_ANY | KF_FLAG_EXACT_RECURSION)) || d->T < 64) return false;
+  const char* e = getenv("KF_VG_STEADY");
+  if (e && e[0] == '0') return false;
+  const char* sse = getenv("KF_STEADY_STATE");
+  if (sse && *sse && atoi(sse) == 0) return false;
+  if (!kf_b4q_selected(h, d->m, d->p, d->r, d->filter, d->flags, d->B)) return false;
+  if (!(d->p >= 3 && d->p <= 5 && d->m >= 8)) return false;  // (the shapes kf_forward_b4q.hip's steady-state phase covers)
+  return kf_backward_steady_ok(d->m, d->p, d->r) && d->m <= KF_MP_M_MAX;
+}
+
 extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, int which, size_t* bytes) {
   if (!h || !dims || !bytes) return KF_ERR_ARG;
   if (which & KF_WS_VALUE_AND_GRAD) {
@@ -543,6 +562,10 @@ extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, i
     const int rc = kf_workspace_bytes_for(h, dims, KF_WS_FORWARD | KF_WS_BACKWARD, &inner);
     if (rc) return rc;
     *bytes = kf_vg_tape_bytes(dims) + inner;
+    if (kf_vg_steady_path(h, dims)) {
+      const size_t B = (size_t)dims->B, m = (size_t)dims->m;
+      *bytes += kf_vg_round(4 * B) + kf_vg_round(8 * B * m) + 2 * kf_vg_round(8 * B * m * m);
+    }
     return KF_OK;
   }
   *bytes = 0;  // the LDS- and register-resident kernels keep all scratch on chip
@@ -702,6 +725,49 @@ extern "C" int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims, const
     a.tape_T = dims->T; a.y_T = dims->T; a.tile_tape = tape; a.init_ab = nullptr; a.init_Pb = nullptr; a.accumulate = 0;
     return kf_launch_backward_b4(h, a, w, inner_t, (hipStream_t)stream);
   }
+  if (kf_vg_steady_path(h, dims)) {
+    // Forward kernel with a steady-state phase (the multi-observation block kernel: C4): it reports where the phase starts, the
+    // steady-state adjoint (kf_backward_steady.hip: a vector recursion + one Riccati adjoint per draw) takes the steps behind that
+    // point, the exact adjoint the steps before it.  [.. | ts B | lam_ts B m | P_b B m^2 | P B m^2 | inner]
+    KF_ON_DEVICE(h);
+    int32_t* ts = reinterpret_cast<int32_t*>(w);
+    w += kf_vg_round(4 * B);
+    double* s_ab = reinterpret_cast<double*>(w);
+    w += kf_vg_round(8 * B * m);
+    double* s_Pb = reinterpret_cast<double*>(w);
+    w += kf_vg_round(8 * B * m * m);
+    double* s_P = reinterpret_cast<double*>(w);
+    w += kf_vg_round(8 * B * m * m);
+    const size_t inner_s = workspace_bytes - (size_t)(w - reinterpret_cast<char*>(workspace));
+    KfFwdArgs f;
+    f.B = dims->B; f.T = dims->T; f.p = dims->p; f.m = dims->m; f.r = dims->r; f.filter = dims->filter; f.flags = dims->flags;
+    f.y = y; f.a0 = a0; f.P0 = P0; f.Tm = T; f.Z = Z; f.R = R; f.H = H; f.Q = Q; f.c = c; f.d = d;
+    f.logp = logp; f.ll_obs = nullptr; f.filt_a = nullptr; f.pred_a = pred_a; f.filt_P = nullptr; f.pred_P = pred_P;
+    f.info = info; f.tile_tape = nullptr; f.hs_ts = ts; f.skip_steady_cov = 1;
+    rc = kf_launch_forward_b4q(h, f, (hipStream_t)stream);
+    if (rc) return rc;
+    if (!g_logp) {
+      hipLaunchKernelGGL(kf_fill_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ones,
+                         (long)B, 1.0);
+      KF_HIP_CHECK(h, hipGetLastError());
+      g_logp = ones;
+    }
+    KfBwdArgs a;
+    a.B = dims->B; a.T = dims->T; a.p = dims->p; a.m = dims->m; a.r = dims->r; a.filter = dims->filter; a.flags = dims->flags;
+    a.y = y; a.a0 = a0; a.P0 = P0; a.Tm = T; a.Z = Z; a.R = R; a.H = H; a.Q = Q; a.c = c; a.d = d;
+    a.pred_a = pred_a; a.pred_P = pred_P; a.g_logp = g_logp; a.g_ll_obs = nullptr;
+    a.g_a0 = g_a0; a.g_P0 = g_P0; a.g_T = g_T; a.g_Z = g_Z; a.g_R = g_R; a.g_H = g_H; a.g_Q = g_Q; a.g_c = g_c; a.g_d = g_d;
+    a.tape_T = dims->T; a.y_T = dims->T; a.tile_tape = nullptr; a.init_ab = nullptr; a.init_Pb = nullptr; a.accumulate = 0;
+    rc = kf_launch_backward_steady(h, a, ts, s_ab, s_Pb, s_P, (hipStream_t)stream);   // writes every gradient (zeros where it has none)
+    if (rc) return rc;
+    rc = kf_launch_dare_backward(h, dims->B, dims->m, dims->p, dims->r, T, Z, R, H, Q, s_P, s_Pb, g_T, g_Z, g_R, g_H, g_Q,
+                                 /*accumulate=*/1, nullptr, (hipStream_t)stream, /*h_diag_only=*/1);
+    if (rc) return rc;
+    a.steps = ts;
+    a.init_ab = s_ab;
+    a.accumulate = 1;
+    return kf_launch_backward(h, a, w, inner_s, (hipStream_t)stream);
+  }
   rc = kf_filter_forward(h, dims, y, a0, P0, T, Z, R, H, Q, c, d, logp, nullptr, nullptr, pred_a, nullptr, pred_P, info,
                          w, inner, stream);
   if (rc) return rc;
@@ -740,6 +806,11 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
       return KF_ERR_UNSUPPORTED;
     }
     return kf_launch_smoother_lds(h, a, (hipStream_t)stream);
+  }
+  // m <= 4 (C1, C2): one lane per draw, pseudo-inverse in registers (kf_smoother_lane.hip); KF_SMOOTHER_LANE=0 keeps the LDS kernel
+  if (kf_smoother_lane_ok(a.m) && h->forward_kernel != KF_KERNEL_LDS) {
+    const char* e = getenv("KF_SMOOTHER_LANE");
+    if (!(e && e[0] == '0')) return kf_launch_smoother_lane(h, a, (hipStream_t)stream);
   }
   // 5 <= m <= 15: block-MFMA smoother with warm-started Newton-Schulz inverses (kf_smoother_b4.hip); KF_SMOOTHER_B4=0
   // in the environment keeps the elimination kernel below (A/B measurements)

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
   const int c = lane & 15, g = lane >> 4;
   const int permc = (c & 3) * 4 + (c >> 2);
   const long b = blockIdx.x;
-  const int n = A.T, nt = A.tape_T, r_ = A.r, m = A.m, p = P1 ? 1 : A.p, mm = m * m;  // nt: tape stride (>= n)
+  const int n = A.steps ? A.steps[b] : A.T;  // (per-draw step counts: the steady-state adjoint took the steps behind)
+  const int nt = A.tape_T, r_ = A.r, m = A.m, p = P1 ? 1 : A.p, mm = m * m;  // nt: tape stride (>= n)
 
   double* EX = smem;                 // exchange: permuted write, two b128 reads give the row-indexed view
   double* HD = EX + 16;

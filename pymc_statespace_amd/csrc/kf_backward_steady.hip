@@ -1,0 +1,374 @@
+// kf_backward_steady.hip -- the STEADY-STATE ADJOINT: gradient of the log-likelihood over the steps a forward kernel ran in its
+// steady-state phase (static model, scalar observations: p == 1, the Univariate filter, or KF_FLAG_H_DIAGONAL; m <= 16, p <= 8).
+//
+// The reference's gradient is autodiff of the scan (core/statespace.py:174): the adjoint of the FULL recursion at every step,
+// three m^3 products per step and the update's adjoint per observation (kf_backward_mfma.hip: ~6000 cycles per draw-step at
+// C4).  But once the covariance recursion has converged (step ts: P_t = P to rounding for t >= ts; the forward kernel's own
+// test, kf_forward_b4.hip) the log-likelihood of the remaining steps depends on the parameters
+//   * directly and through the CONSTANT gain  K = P Z' W,  W = F^-1,  F = Z P Z' + H  -- a backward VECTOR recursion
+//         v_t = y~_t - Z a_t           mu_t = T' lam_{t+1}           vb_t = -gl_t W v_t + K' mu_t
+//         lam_t = mu_t - Z' vb_t       ( = (T (I - K Z))' lam_{t+1} + gl_t Z' W v_t )
+//     and sums of outer products:  T_b += lam_{t+1} (a_t + K v_t)',  K_b += mu_t v_t',  Z_b -= vb_t a_t',  c_b += lam_{t+1},
+//     d_b += dsign vb_t,  W_b += gl_t (F - v_t v_t') / 2   -- no m^3 work per step, ~100 instructions per draw-step;
+//   * through P(theta), the fixpoint of the Riccati map: ONE Riccati adjoint per draw (kf_dare_backward: the reference's
+//     SolveDiscreteARE.grad, utils/pytensor_scipy.py:33-60) applied to  P_b = M_b Z + Z' F_b Z  with  M_b = K_b W,
+//     W_b += M' K_b,  F_b = -W sym(W_b) W;
+// and the steps before ts get the exact adjoint (kf_backward_mfma.hip, per-draw step counts) started from
+// (a_b, P_b) = (lam_ts, 0).  Checked against torch autograd of the recursion at every step: scripts/r03/steady_adjoint_proto.py
+// (<= 1e-14 relative on every input, BASELINE workloads); the two differ by the derivative of the convergence error,
+// O(ts rho^(2 ts)).  The symmetric parts of the gradients with respect to symmetric inputs agree; H gets its diagonal only,
+// as in every scalar-observation adjoint here.
+#include "kf_internal.h"
+#include "kf_tile.h"
+
+namespace {
+
+constexpr int SA_M = 16, SA_P = 8;
+
+// LDS (doubles)
+constexpr int SA_OFF_P = 0;                       // P            m x m  (stride 16)
+constexpr int SA_OFF_T = SA_OFF_P + 256;          // T            m x m  (stride 16)
+constexpr int SA_OFF_Z = SA_OFF_T + 256;          // Z            p x 16
+constexpr int SA_OFF_K = SA_OFF_Z + 128;          // K            16 x 8 (m x p)
+constexpr int SA_OFF_W = SA_OFF_K + 128;          // W = F^-1     8 x 8
+constexpr int SA_OFF_F = SA_OFF_W + 64;           // F            8 x 8
+constexpr int SA_OFF_V = SA_OFF_F + 64;           // x = lam 16 | a 16 | y~ 8 (the rest: spare)
+constexpr int SA_OFF_X = SA_OFF_V + 96;           // epilogue scratch: 3 x 256
+constexpr int SA_TOTAL = SA_OFF_X + 768;
+
+__global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_kernel(const KfBwdArgs A, const int32_t* __restrict__ ts_all,
+                                                                 double* __restrict__ out_ab, double* __restrict__ out_Pb,
+                                                                 double* __restrict__ out_P) {
+  __shared__ __attribute__((aligned(16))) double smem[SA_TOTAL];
+  const int lane = threadIdx.x;
+  const long b = blockIdx.x;
+  const int n = A.T, m = A.m, p = A.p, mm = m * m, r_ = A.r;
+  const int ts = ts_all[b] < n ? ts_all[b] : n;
+  double* sP = smem + SA_OFF_P;
+  double* sT = smem + SA_OFF_T;
+  double* sZ = smem + SA_OFF_Z;
+  double* sK = smem + SA_OFF_K;
+  double* sW = smem + SA_OFF_W;
+  double* sF = smem + SA_OFF_F;
+  double* lam = smem + SA_OFF_V;   // (the loop's x vector starts here: lam (16) | a (16) | y~ (8))
+  double* X0 = smem + SA_OFF_X;
+  double* X1 = X0 + 256;
+  double* X2 = X1 + 256;
+
+  const double* gpa = A.pred_a + b * (long)(A.tape_T + 1) * m;
+  const double* gpP = A.pred_P + b * (long)(A.tape_T + 1) * mm;
+  const double* gT = A.Tm + b * (long)mm;
+  const double* gZ = A.Z + b * (long)p * m;
+  const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;  // :335 quirk: y_hat = Z a - d
+  const bool ypd = (A.flags & KF_FLAG_Y_PER_DRAW) != 0;
+  const double* ybase = A.y + (ypd ? b * (long)A.y_T * p : 0L);
+  const double g_all = A.g_logp ? A.g_logp[b] : 0.0;
+
+  for (int e = lane; e < SA_OFF_X; e += KF_WAVE) smem[e] = 0.0;
+  wave_lds_fence();
+  const int tsc = ts < n ? ts : n;  // (a draw that never converged: P of slot n, nothing to sweep)
+  for (int e = lane; e < mm; e += KF_WAVE) {
+    const int i = e / m, j = e - i * m;
+    const double pij = 0.5 * (gpP[(long)tsc * mm + e] + gpP[(long)tsc * mm + j * m + i]);
+    sP[i * 16 + j] = pij;
+    sT[i * 16 + j] = gT[e];
+    out_P[b * (long)mm + e] = pij;
+  }
+  for (int e = lane; e < p * m; e += KF_WAVE) sZ[(e / m) * 16 + e % m] = gZ[e];
+  wave_lds_fence();
+  // M = P Z' (m x p) into sK, F = Z M + diag(H)
+  for (int e = lane; e < m * p; e += KF_WAVE) {
+    const int i = e / p, q = e - i * p;
+    double s = 0.0;
+    for (int j = 0; j < m; ++j) s = fma(sP[i * 16 + j], sZ[q * 16 + j], s);
+    X0[i * 8 + q] = s;  // M
+  }
+  wave_lds_fence();
+  for (int e = lane; e < p * p; e += KF_WAVE) {
+    const int q = e / p, r2 = e - q * p;
+    double s = (q == r2) ? A.H[b * (long)p * p + q * p + q] : 0.0;
+    for (int i = 0; i < m; ++i) s = fma(sZ[q * 16 + i], X0[i * 8 + r2], s);
+    sF[q * 8 + r2] = s;
+  }
+  wave_lds_fence();
+  // W = F^-1: Gauss-Jordan on (F | I) by the first p lanes (lane = column of the augmented right half), pivots in order (F is SPD)
+  {
+    // X1: working copy of F (8 x 8), X2: inverse being built
+    if (lane < 64) {
+      const int q = lane >> 3, r2 = lane & 7;
+      X1[lane] = (q < p && r2 < p) ? 0.5 * (sF[q * 8 + r2] + sF[r2 * 8 + q]) : (q == r2 ? 1.0 : 0.0);
+      X2[lane] = (q == r2) ? 1.0 : 0.0;
+    }
+    wave_lds_fence();
+    for (int k = 0; k < p; ++k) {
+      const int q = lane >> 3, r2 = lane & 7;
+      const double piv = X1[k * 8 + k];
+      const double ip = 1.0 / piv;
+      const double fk = X1[q * 8 + k];            // column k of row q
+      const double rowk1 = X1[k * 8 + r2] * ip;   // normalised pivot row
+      const double rowk2 = X2[k * 8 + r2] * ip;
+      wave_lds_fence();
+      if (q == k) {
+        X1[lane] = rowk1;
+        X2[lane] = rowk2;
+      } else {
+        X1[lane] = fma(-fk, rowk1, X1[lane]);
+        X2[lane] = fma(-fk, rowk2, X2[lane]);
+      }
+      wave_lds_fence();
+    }
+    if (lane < 64) sW[lane] = ((lane >> 3) < p && (lane & 7) < p) ? 0.5 * (X2[lane] + X2[(lane & 7) * 8 + (lane >> 3)]) : 0.0;
+    wave_lds_fence();
+  }
+  // K = M W
+  for (int e = lane; e < m * p; e += KF_WAVE) {
+    const int i = e / p, q = e - i * p;
+    double s = 0.0;
+    for (int r2 = 0; r2 < p; ++r2) s = fma(X0[i * 8 + r2], sW[r2 * 8 + q], s);
+    sK[i * 8 + q] = s;
+  }
+  wave_lds_fence();
+
+  // ---- one step = ONE matrix-vector stage.  Everything a step needs is linear in x = (lam_{t+1} | a_t | y~_t):
+  //   lanes  0..15  lam_t[j] = sum_i Abar[i][j] lam_i - gl sum_l (Z' W Z)[j][l] a_l + gl sum_q (Z' W)[j][q] y~_q     (Abar = T - T K Z)
+  //   lanes 16..31  af[j]    = sum_l (I - K Z)[j][l] a_l + sum_q K[j][q] y~_q
+  //   lanes 32..47  mu[j]    = sum_i T[i][j] lam_i
+  //   lanes 48..55  v[q]     = y~_q - sum_l Z[q][l] a_l
+  //   lanes 56..63  vb[q]    = sum_i (T K)[i][q] lam_i + gl sum_l (W Z)[q][l] a_l - gl sum_r W[q][r] y~_r
+  // each lane holds its 40 coefficients in registers and reads x (40 doubles) from LDS: 40 FMAs, one LDS round trip per step.
+  // (gl is the draw's cotangent of logp: kf_filter_value_and_grad has no per-step cotangents.)
+  double* TK = X0 + 128;   // 16 x 8   (X0[0..127] holds M)
+  double* WZ = X1 + 64;    // 8 x 16
+  double* KZ = X2;         // 16 x 16
+  for (int e = lane; e < 128; e += KF_WAVE) {  // T K
+    const int i = e >> 3, q = e & 7;
+    double s2 = 0.0;
+    for (int j = 0; j < 16; ++j) s2 = fma(sT[i * 16 + j], sK[j * 8 + q], s2);
+    TK[e] = s2;
+  }
+  for (int e = lane; e < 128; e += KF_WAVE) {  // W Z
+    const int q = e >> 4, l = e & 15;
+    double s2 = 0.0;
+    for (int r2 = 0; r2 < 8; ++r2) s2 = fma(sW[q * 8 + r2], sZ[r2 * 16 + l], s2);
+    WZ[e] = s2;
+  }
+  for (int e = lane; e < 256; e += KF_WAVE) {  // K Z
+    const int j = e >> 4, l = e & 15;
+    double s2 = 0.0;
+    for (int q = 0; q < 8; ++q) s2 = fma(sK[j * 8 + q], sZ[q * 16 + l], s2);
+    KZ[e] = s2;
+  }
+  wave_lds_fence();
+  const double gl = g_all;
+  double cf[40];
+  {
+    const int j = lane & 15, q = lane & 7;
+#pragma unroll
+    for (int k = 0; k < 40; ++k) {
+      double v = 0.0;
+      if (lane < 16) {
+        if (k < 16) {  // Abar[k][j] = T[k][j] - sum_q TK[k][q] Z[q][j]
+          v = sT[k * 16 + j];
+          for (int q2 = 0; q2 < 8; ++q2) v = fma(-TK[k * 8 + q2], sZ[q2 * 16 + j], v);
+        } else if (k < 32) {  // -gl (Z' W Z)[j][l]
+          const int l = k - 16;
+          for (int q2 = 0; q2 < 8; ++q2) v = fma(sZ[q2 * 16 + j], WZ[q2 * 16 + l], v);
+          v *= -gl;
+        } else {  // gl (Z' W)[j][q]
+          const int q2 = k - 32;
+          for (int r2 = 0; r2 < 8; ++r2) v = fma(sZ[r2 * 16 + j], sW[r2 * 8 + q2], v);
+          v *= gl;
+        }
+      } else if (lane < 32) {
+        if (k >= 16 && k < 32) v = ((k - 16 == j) ? 1.0 : 0.0) - KZ[j * 16 + (k - 16)];
+        else if (k >= 32) v = sK[j * 8 + (k - 32)];
+      } else if (lane < 48) {
+        if (k < 16) v = sT[k * 16 + j];
+      } else if (lane < 56) {
+        if (k >= 16 && k < 32) v = -sZ[q * 16 + (k - 16)];
+        else if (k >= 32) v = (k - 32 == q) ? 1.0 : 0.0;
+      } else {
+        if (k < 16) v = TK[k * 8 + q];
+        else if (k < 32) v = gl * WZ[q * 16 + (k - 16)];
+        else v = -gl * sW[q * 8 + (k - 32)];
+      }
+      cf[k] = v;
+    }
+  }
+  wave_lds_fence();
+  double* XV = smem + SA_OFF_V;   // x: lam (16) | a (16) | y~ (8)
+  double* OUT = X1;               // stage outputs: lam_t (16) | af (16) | mu (16) | v (8) | vb (8)   (X1[0..63]: the inverse's scratch, dead)
+  for (int e = lane; e < 48; e += KF_WAVE) XV[e] = 0.0;
+
+  // ---- accumulators (registers; lanes over matrix entries) ----------------------------------------------------------------------
+  const int tj = lane & 15, ti4 = lane >> 4;   // T_b: column tj, rows ti4 + 4 s
+  const int kq = lane & 7, ki = lane >> 3;     // K_b: column kq, rows ki + 8 s
+  const int zj = lane & 15, zq = lane >> 4;    // Z_b: column zj, rows zq + 4 s
+  const int vq = lane >> 3, vr = lane & 7;     // sum gl v v'
+  double Tb[4] = {0.0, 0.0, 0.0, 0.0}, Kb[2] = {0.0, 0.0}, Zb[2] = {0.0, 0.0}, VV = 0.0, cb = 0.0, db = 0.0, GLs = 0.0;
+  // lanes 16 .. 16+m-1 fetch a_t, lanes 32 .. 32+p-1 fetch y~_t, one step ahead
+  const bool is_a = lane >= 16 && lane < 16 + m, is_y = lane >= 32 && lane < 32 + p;
+  const double dq = (is_y && A.d) ? A.d[b * (long)p + (lane - 32)] : 0.0;
+  auto fetch = [&](int t) -> double {
+    if (is_a) return gpa[(long)t * m + (lane - 16)];
+    if (is_y) return ybase[(long)t * p + (lane - 32)] + dsign * dq;
+    return 0.0;
+  };
+  double nxt = ts < n ? fetch(n - 1) : 0.0;
+  for (int t = n - 1; t >= ts; --t) {
+    if (is_a || is_y) XV[lane] = nxt;   // (x is laid out so that lane l in 16..39 owns element l)
+    wave_lds_fence();
+    if (t > ts) nxt = fetch(t - 1);
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 40; k += 4) {
+      const double2_t x01 = *reinterpret_cast<const double2_t*>(XV + k);
+      const double2_t x23 = *reinterpret_cast<const double2_t*>(XV + k + 2);
+      acc0 = fma(cf[k], x01.x, acc0);
+      acc1 = fma(cf[k + 1], x01.y, acc1);
+      acc0 = fma(cf[k + 2], x23.x, acc0);
+      acc1 = fma(cf[k + 3], x23.y, acc1);
+    }
+    const double o = acc0 + acc1;
+    OUT[lane] = o;
+    wave_lds_fence();
+    // accumulate with lam_{t+1} (still in x), then lam_t replaces it
+    {
+      const double afj = OUT[16 + tj];
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) Tb[s2] = fma(XV[ti4 + 4 * s2], afj, Tb[s2]);
+      const double vqv = OUT[48 + kq];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) Kb[s2] = fma(OUT[32 + ki + 8 * s2], vqv, Kb[s2]);
+      const double azj = XV[16 + zj];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) Zb[s2] = fma(-OUT[56 + zq + 4 * s2], azj, Zb[s2]);
+      VV = fma(gl * OUT[48 + vq], OUT[48 + vr], VV);
+      if (lane < 16) cb += XV[lane];
+      if (lane >= 56) db = fma(dsign, o, db);
+      GLs += gl;
+    }
+    if (lane < 16) XV[lane] = o;
+  }
+  wave_lds_fence();
+  // (the epilogue and the outputs below index vectors as the first version of this kernel did)
+  if (lane < 16) lam[lane] = XV[lane];
+  {
+    const double dbv = __shfl(db, 56 + (lane & 7));
+    db = dbv;
+  }
+  wave_lds_fence();
+
+  // ---- epilogue: (K_b, W_b) -> (P_b, Z_b, H_b) -----------------------------------------------------------------------------------------
+  double* eKb = X0;         // 16 x 8  (X0's M is dead: K is what the chain rule needs, M = K F)
+  double* eMb = X0 + 128;   // 16 x 8
+  double* eWb = X1;         // 8 x 8
+  double* eFb = X1 + 64;    // 8 x 8
+  double* eM = X1 + 128;    // 16 x 8: M = P Z'
+  double* eFZ = X2;         // 8 x 16: F_b Z
+  double* eFZP = X2 + 128;  // 8 x 16: F_b Z P
+#pragma unroll
+  for (int s = 0; s < 2; ++s) eKb[(ki + 8 * s) * 8 + kq] = Kb[s];
+  for (int e = lane; e < m * p; e += KF_WAVE) {
+    const int i = e / p, q = e - i * p;
+    double sm = 0.0;
+    for (int j = 0; j < m; ++j) sm = fma(sP[i * 16 + j], sZ[q * 16 + j], sm);
+    eM[i * 8 + q] = sm;
+  }
+  wave_lds_fence();
+  {  // W_b = (GL F - VV) / 2 + M' K_b, symmetrised
+    double s = 0.5 * (GLs * sF[vq * 8 + vr] - VV);
+    for (int i = 0; i < m; ++i) s = fma(eM[i * 8 + vq], eKb[i * 8 + vr], s);
+    eWb[lane] = (vq < p && vr < p) ? s : 0.0;
+  }
+  for (int e = lane; e < m * p; e += KF_WAVE) {  // M_b = K_b W
+    const int i = e / p, q = e - i * p;
+    double s = 0.0;
+    for (int r2 = 0; r2 < p; ++r2) s = fma(eKb[i * 8 + r2], sW[r2 * 8 + q], s);
+    eMb[i * 8 + q] = s;
+  }
+  wave_lds_fence();
+  {  // F_b = -W sym(W_b) W
+    double s = 0.0;
+    for (int r2 = 0; r2 < p; ++r2) {
+      double t2 = 0.0;
+      for (int r3 = 0; r3 < p; ++r3) t2 = fma(0.5 * (eWb[r2 * 8 + r3] + eWb[r3 * 8 + r2]), sW[r3 * 8 + vr], t2);
+      s = fma(sW[vq * 8 + r2], t2, s);
+    }
+    wave_lds_fence();
+    eFb[lane] = -s;
+  }
+  wave_lds_fence();
+  for (int e = lane; e < p * m; e += KF_WAVE) {  // F_b Z
+    const int q = e / m, j = e - q * m;
+    double s = 0.0;
+    for (int r2 = 0; r2 < p; ++r2) s = fma(eFb[q * 8 + r2], sZ[r2 * 16 + j], s);
+    eFZ[q * 16 + j] = s;
+  }
+  wave_lds_fence();
+  for (int e = lane; e < p * m; e += KF_WAVE) {  // F_b Z P
+    const int q = e / m, j = e - q * m;
+    double s = 0.0;
+    for (int l = 0; l < m; ++l) s = fma(eFZ[q * 16 + l], sP[l * 16 + j], s);
+    eFZP[q * 16 + j] = s;
+  }
+  wave_lds_fence();
+  // ---- outputs -----------------------------------------------------------------------------------------------------------------------
+  for (int e = lane; e < mm; e += KF_WAVE) {  // P_b = M_b Z + Z' F_b Z
+    const int i = e / m, j = e - i * m;
+    double s = 0.0;
+    for (int q = 0; q < p; ++q) s = fma(eMb[i * 8 + q], sZ[q * 16 + j], fma(sZ[q * 16 + i], eFZ[q * 16 + j], s));
+    out_Pb[b * (long)mm + e] = s;
+    if (A.g_P0) A.g_P0[b * (long)mm + e] = 0.0;
+  }
+  if (A.g_T) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int i = ti4 + 4 * s;
+      if (i < m && tj < m) A.g_T[b * (long)mm + i * m + tj] = Tb[s];
+    }
+  }
+  if (A.g_Z) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int q = zq + 4 * s;
+      if (q < p && zj < m) {
+        double v = Zb[s] + 2.0 * eFZP[q * 16 + zj];  // + M_b' P + 2 F_b Z P
+        for (int i = 0; i < m; ++i) v = fma(eMb[i * 8 + q], sP[i * 16 + zj], v);
+        A.g_Z[b * (long)p * m + q * m + zj] = v;
+      }
+    }
+  }
+  if (A.g_H)
+    for (int e = lane; e < p * p; e += KF_WAVE) A.g_H[b * (long)p * p + e] = (e / p == e % p) ? eFb[(e / p) * 8 + e % p] : 0.0;
+  if (lane < m) {
+    if (A.g_c) A.g_c[b * (long)m + lane] = cb;
+    if (A.g_a0) A.g_a0[b * (long)m + lane] = 0.0;
+    out_ab[b * (long)m + lane] = lam[lane];
+  }
+  if (lane < p && A.g_d) A.g_d[b * (long)p + lane] = db;
+  if (A.g_R)
+    for (int e = lane; e < m * r_; e += KF_WAVE) A.g_R[b * (long)m * r_ + e] = 0.0;
+  if (A.g_Q)
+    for (int e = lane; e < r_ * r_; e += KF_WAVE) A.g_Q[b * (long)r_ * r_ + e] = 0.0;
+}
+
+}  // namespace
+
+bool kf_backward_steady_ok(int m, int p, int r) { return m >= 1 && m <= SA_M && p >= 1 && p <= SA_P && r >= 1; }
+
+// doubles of workspace: lam_ts [B][m] | P_b [B][m][m] | P [B][m][m]  (+ the int32 ts array, B entries, kept by the caller)
+size_t kf_backward_steady_workspace_bytes(long B, int m) {
+  return sizeof(double) * (size_t)B * (size_t)(m + 2 * m * m) + 4 * (size_t)B + 256;
+}
+
+int kf_launch_backward_steady(kf_handle* h, const KfBwdArgs& a, const int32_t* ts, double* out_ab, double* out_Pb, double* out_P,
+                              hipStream_t stream) {
+  if (!kf_backward_steady_ok(a.m, a.p, a.r) || (a.flags & KF_FLAG_TV_ANY) || a.g_ll_obs) {  // (one cotangent per draw: g_logp)
+    KF_SET_ERR(h, "backward(steady): needs m <= %d, p <= %d, static matrices (got m=%d p=%d)", SA_M, SA_P, a.m, a.p);
+    return KF_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(kf_bwd_steady_kernel, dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, ts, out_ab, out_Pb, out_P);
+  KF_HIP_CHECK(h, hipGetLastError());
+  return KF_OK;
+}

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_dare_bwd_kernel(long B, int m, int
                                                               const double* Zm, const double* Rm, const double* Hm,
                                                               const double* Qm, const double* Xm, const double* gX,
                                                               double* g_T, double* g_Z, double* g_R, double* g_H,
-                                                              double* g_Q, int accumulate, int32_t* info) {
+                                                              double* g_Q, int accumulate, int32_t* info, int h_diag_only) {
   extern __shared__ double smem[];
   const int lane = threadIdx.x;
   const long b = blockIdx.x;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_dare_bwd_kernel(long B, int m, int
       double s = 0.0;
       for (int j = 0; j < m; ++j) s += SR[q1 * m + j] * K[q2 * m + j];
       double* o = g_H + b * pp + e;
-      *o = (accumulate ? *o : 0.0) + s;
+      *o = (accumulate ? *o : 0.0) + ((h_diag_only && q1 != q2) ? 0.0 : s);
     }
     __syncthreads();
   }
@@ -528,7 +528,7 @@ int kf_launch_dare(kf_handle* h, long B, int m, int p, int r, const double* T, c
 int kf_launch_dare_backward(kf_handle* h, long B, int m, int p, int r, const double* T, const double* Z, const double* R,
                             const double* H, const double* Q, const double* P, const double* g_P, double* g_T,
                             double* g_Z, double* g_R, double* g_H, double* g_Q, int accumulate, int32_t* info,
-                            hipStream_t stream) {
+                            hipStream_t stream, int h_diag_only) {
   const size_t lds = sizeof(double) * (size_t)dare_bwd_region_doubles(m, p, r);
   if (lds > KF_LDS_BYTES_MAX) {
     KF_SET_ERR(h, "dare_backward: m=%d p=%d r=%d needs %zu B of LDS per workgroup (> %d)", m, p, r, lds,
@@ -538,7 +538,7 @@ int kf_launch_dare_backward(kf_handle* h, long B, int m, int p, int r, const dou
   KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kf_dare_bwd_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kf_dare_bwd_kernel, dim3((unsigned)B), dim3(KF_WAVE), lds, stream, B, m, p, r, T, Z, R, H, Q, P,
-                     g_P, g_T, g_Z, g_R, g_H, g_Q, accumulate, info);
+                     g_P, g_T, g_Z, g_R, g_H, g_Q, accumulate, info, h_diag_only);
   KF_HIP_CHECK(h, hipGetLastError());
   return KF_OK;
 }

@@ -527,7 +527,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
     bool conv = false;
     if (chk) {
       // converged (as in kf_forward_b4.hip): on two consecutive checks the one-step change is within 1e-15 of the largest entry AND
-      // every entry's change within 1e-13 of its own scale sqrt(P_ii P_jj) -- a diffuse block cannot hide a small one that still moves
+      // every entry's change within 1e-12 of its own scale sqrt(P_ii P_jj) -- a diffuse block cannot hide a small one that still moves
       unsigned pm = 0;
       bool bad = false;
       double* DG = PO + 240;  // (m * m <= 225: the last 16 doubles of the parked image are free)
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
         const double old = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(PO) + (on ? stg_off[I] : 0u));
         const double drow = DG[on ? 4 * I + g : 0];
         const double df = P[I] - old;
-        bad = bad || (on && !(fabs(df) <= lim && df * df <= 1e-26 * fabs(dcol * drow)));
+        bad = bad || (on && !(fabs(df) <= lim && df * df <= A.ss_tol2 * fabs(dcol * drow)));
       }
       wave_lds_fence();
       const bool ok = __ballot(bad) == 0ull;
@@ -568,6 +568,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
       break;
     }
   }
+  if (A.hs_ts && lane == 0) A.hs_ts[b] = t;  // (kf_filter_value_and_grad: where the steady-state phase starts; n if it never does)
   if constexpr (SSK) if (t < n) {
     // ---- steady-state steps t .. n-1: P is the converged predicted tile of step t.  The first of them runs the ordinary
     // update once more and leaves its constants where the update put them -- W and the rows of Uh (the group), u (the single
@@ -615,7 +616,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
 #pragma unroll
     for (int I = 0; I < NB; ++I) Pp[I] = P[I];
     const int n_fill = (n - t) * mm;
-    if (w_pP && fill_first) {  // predicted covariances of steps t+1 .. n: the converged tile
+    const bool do_fill = fill_first && !A.skip_steady_cov;  // (the steady-state adjoint reads slot t of the predicted tape only)
+    if (w_pP && do_fill) {  // predicted covariances of steps t+1 .. n: the converged tile
       stage_cov(Pp);
       wave_lds_fence();
       bulk_fill(t_pP, n_fill);
@@ -638,7 +640,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
       rw[160] = 0.0;
     }
     wave_lds_fence();
-    if (w_fP && fill_first) {  // filtered covariances of steps t .. n-1
+    if (w_fP && do_fill) {  // filtered covariances of steps t .. n-1
       stage_cov(P);
       wave_lds_fence();
       bulk_fill(t_fP, n_fill);

@@ -531,14 +531,14 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
         for (int i = 0; i < M; ++i)
 #pragma unroll
           for (int j = i; j < M; ++j) still = still && (P[i][j] == P[i][j]);  // (fmax drops NaNs)
-        // (as in kf_forward_b4.hip: also every entry within 1e-13 of its own scale, and on two consecutive checks)
+        // (as in kf_forward_b4.hip: also every entry within 1e-12 of its own scale, and on two consecutive checks)
         bool each = true;
 #pragma unroll
         for (int i = 0; i < M; ++i)
 #pragma unroll
           for (int j = i; j < M; ++j) {
             const double df = P[i][j] - Pold[i][j];
-            each = each && (df * df <= 1e-26 * fabs(P[i][i] * P[j][j]));
+            each = each && (df * df <= A.ss_tol2 * fabs(P[i][i] * P[j][j]));
           }
         const bool pass = still && t >= t_free && dmax <= 3e-16 * pmax && each;
         npass = pass ? npass + 1 : 0;

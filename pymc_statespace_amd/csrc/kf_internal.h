@@ -78,6 +78,8 @@ struct KfFwdArgs {
   double* hs_logp = nullptr;    // [B] log-likelihood of the steps done so far
   int32_t* hs_info = nullptr;   // [B]
   int32_t* hs_ts = nullptr;     // [B] -1: recursion continues in the next chunk, >= 0: converged, steady phase starts at this step, -2: finished
+  double ss_tol2 = 1e-24;       // (square of) the entrywise tolerance of the steady-state test, 1e-12 of sqrt(P_ii P_jj)
+  int skip_steady_cov = 0;      // internal (kf_filter_value_and_grad): the steady-state phase leaves the constant covariance tapes unwritten
   int32_t* hs_tfree = nullptr;  // [B] first step after the last missing observation (written by the first chunk)
 };
 
@@ -119,6 +121,8 @@ struct KfBwdArgs {
   const double* init_ab;
   const double* init_Pb;
   int accumulate;
+  // internal (steady-state adjoint, kf_backward_steady.hip): per-draw number of steps to sweep instead of T (NULL: T for every draw)
+  const int32_t* steps = nullptr;
 };
 
 struct KfSmoothArgs {
@@ -210,6 +214,11 @@ bool kf_backward_b4_ok(int m, int p, int r);
 size_t kf_backward_b4_workspace_bytes(long B, int m);
 int kf_launch_backward_b4(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int kf_launch_backward_mfma(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
+// steady-state adjoint (kf_backward_steady.hip): the steps a forward kernel ran in its steady-state phase
+bool kf_backward_steady_ok(int m, int p, int r);
+size_t kf_backward_steady_workspace_bytes(long B, int m);
+int kf_launch_backward_steady(kf_handle* h, const KfBwdArgs& a, const int32_t* ts, double* out_ab, double* out_Pb, double* out_P,
+                              hipStream_t stream);
 // lane-per-draw kernels for tiny m (kf_forward_lane.hip)
 #define KF_LANE_M_MAX 4
 int kf_launch_forward_lane_m1(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
@@ -249,6 +258,9 @@ int kf_launch_backward_lds(kf_handle* h, const KfBwdArgs& a, hipStream_t stream)
 int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t workspace_bytes,
                        hipStream_t stream);
 int kf_launch_smoother_lds(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream);
+// lane-per-draw smoother with the pseudo-inverse in registers (kf_smoother_lane.hip): m <= 4, static matrices
+bool kf_smoother_lane_ok(int m);
+int kf_launch_smoother_lane(kf_handle* h, const KfSmoothArgs& a, hipStream_t stream);
 // per-draw LDS footprint of kf_smooth_lds_kernel with all 64 lanes on one draw (kf_smoother_lds.hip)
 inline bool kf_smoother_lds_fits(int m) {
   const int M2 = (m + 1) / 2;
@@ -297,7 +309,7 @@ int kf_launch_dare(kf_handle* h, long B, int m, int p, int r, const double* T, c
 int kf_launch_dare_backward(kf_handle* h, long B, int m, int p, int r, const double* T, const double* Z, const double* R,
                             const double* H, const double* Q, const double* P, const double* g_P, double* g_T,
                             double* g_Z, double* g_R, double* g_H, double* g_Q, int accumulate, int32_t* info,
-                            hipStream_t stream);
+                            hipStream_t stream, int h_diag_only = 0);
 int kf_launch_simulate_statespace(kf_handle* h, long B, int n_sims, int n, int p, int m, int r, const double* T,
                                   const double* Z, const double* R, const double* H, const double* Q,
                                   const double* x0, const double* zs, const double* zo, double* states, double* obs,

@@ -37,6 +37,13 @@ GRAD_INPUT_NAMES = ("a0", "P0", "T", "Z", "R", "H", "Q", "c", "d")
 # --------------------------------------------------------------------------------------------
 # numeric bodies (no PyTensor needed)
 # --------------------------------------------------------------------------------------------
+def _out(x):
+    """What an Op stores in output_storage: a float64 C-contiguous array of the output's OWN rank (np.ascontiguousarray
+    would turn the 0-d log-likelihood into shape (1,), which a TensorType(float64, ()) output rejects)."""
+    a = np.asarray(x, dtype=np.float64)
+    return a if a.ndim == 0 else np.ascontiguousarray(a)
+
+
 def _col(x):
     x = np.asarray(x, dtype=np.float64)
     return x[:, 0] if x.ndim == 2 and x.shape[1] == 1 else x
@@ -329,7 +336,7 @@ def _build_ops():
             grads = perform_filter_grad(*inputs, filter_type=self.filter_type,
                                         mvn_const=self.mvn_const, h_diagonal=self.h_diagonal)
             for storage, g in zip(output_storage, grads):
-                storage[0] = np.ascontiguousarray(g, dtype=np.float64)
+                storage[0] = _out(g)
 
         def infer_shape(self, fgraph, node, shapes):
             return [shapes[i] for i in range(1, 10)]
@@ -355,7 +362,7 @@ def _build_ops():
                                   h_diagonal=self.h_diagonal, want=want)
             for storage, o, var in zip(output_storage, outs, node.outputs):
                 # an output nothing consumes still needs a correctly typed placeholder
-                storage[0] = (np.ascontiguousarray(o, dtype=np.float64) if o is not None
+                storage[0] = (_out(o) if o is not None
                               else np.zeros((0,) * var.type.ndim, dtype=np.float64))
 
         def infer_shape(self, fgraph, node, shapes):
@@ -412,7 +419,7 @@ def _build_ops():
             outs = perform_logp_and_grad(*inputs, filter_type=self.filter_type, mvn_const=self.mvn_const,
                                          h_diagonal=self.h_diagonal)
             for storage, o in zip(output_storage, outs):
-                storage[0] = np.ascontiguousarray(o, dtype=np.float64)
+                storage[0] = _out(o)
 
         def infer_shape(self, fgraph, node, shapes):
             return [()] + [shapes[i] for i in range(1, 10)]
@@ -444,7 +451,7 @@ def _build_ops():
             outs = perform_filter_batched(*inputs, filter_type=self.filter_type, mvn_const=self.mvn_const,
                                           h_diagonal=self.h_diagonal, want=want)
             for storage, o, var in zip(output_storage, outs, node.outputs):
-                storage[0] = (np.ascontiguousarray(o, dtype=np.float64) if o is not None
+                storage[0] = (_out(o) if o is not None
                               else np.zeros((0,) * var.type.ndim, dtype=np.float64))
 
         def infer_shape(self, fgraph, node, shapes):
@@ -470,7 +477,7 @@ def _build_ops():
             outs = perform_steady_state_grad(*inputs[:10], g_logp=inputs[10], g_ll_obs=inputs[11],
                                              mvn_const=self.mvn_const)
             for storage, g in zip(output_storage, outs[1:]):
-                storage[0] = np.ascontiguousarray(g, dtype=np.float64)
+                storage[0] = _out(g)
 
         def infer_shape(self, fgraph, node, shapes):
             return [shapes[i] for i in range(1, 10)]
@@ -494,7 +501,7 @@ def _build_ops():
             want = self.want
             outs = perform_steady_state(*inputs, mvn_const=self.mvn_const, want=want)
             for storage, o, var in zip(output_storage, outs, node.outputs):
-                storage[0] = (np.ascontiguousarray(o, dtype=np.float64) if o is not None
+                storage[0] = (_out(o) if o is not None
                               else np.zeros((0,) * var.type.ndim, dtype=np.float64))
 
         def infer_shape(self, fgraph, node, shapes):
@@ -532,7 +539,7 @@ def _build_ops():
         def perform(self, node, inputs, output_storage):
             outs = perform_steady_state_grad(*inputs, mvn_const=self.mvn_const)
             for storage, o in zip(output_storage, outs):
-                storage[0] = np.ascontiguousarray(o, dtype=np.float64)
+                storage[0] = _out(o)
 
         def infer_shape(self, fgraph, node, shapes):
             return [()] + [shapes[i] for i in range(1, 10)]
@@ -579,7 +586,7 @@ def _build_ops():
         def perform(self, node, inputs, output_storage):
             outs = perform_smoother(*inputs)
             for storage, o in zip(output_storage, outs):
-                storage[0] = np.ascontiguousarray(o, dtype=np.float64)
+                storage[0] = _out(o)
 
         def infer_shape(self, fgraph, node, shapes):
             return [shapes[3], shapes[4]]

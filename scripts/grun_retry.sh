@@ -1,0 +1,8 @@
+#!/bin/bash
+# scripts/grun.sh with retries while every GPU slot of the pod is busy (status=transient, nothing charged)
+for i in 1 2 3 4 5 6 7 8; do
+  out=$("$(dirname "$0")/grun.sh" "$1" "$2" 2>&1)
+  if echo "$out" | grep -q "status=transient"; then sleep 45; continue; fi
+  echo "$out"; exit 0
+done
+echo "$out"; exit 3

@@ -180,7 +180,7 @@ class Alloc(Op):
 
     def perform(self, node, inputs, output_storage):
         shape = tuple(int(s) for s in inputs[1:])
-        output_storage[0][0] = np.ascontiguousarray(np.broadcast_to(np.asarray(inputs[0], dtype=np.float64), shape))
+        output_storage[0][0] = np.array(np.broadcast_to(np.asarray(inputs[0], dtype=np.float64), shape), order="C")
 
     def L_op(self, inputs, outputs, output_grads):
         return [grad_not_implemented(self, 0, inputs[0], "stand-in: Alloc")] + [DisconnectedType()() for _ in inputs[1:]]

@@ -1564,7 +1564,7 @@ def test_b4_kernel_per_draw_data_not_pd_and_univariate_skip(eng):
         eng.set_forward_kernel("auto")
 
 
-def test_b4_kernel_steady_state_phase_matches_exact_recursion(eng):
+def test_b4_kernel_steady_state_phase_matches_exact_recursion(eng, monkeypatch):
     """KF_FLAG_STEADY_STATE (exact_recursion=False; the default from 1536 steps on): once the predicted covariance has stopped
     moving (and no observation is missing ahead) the block kernel advances only the mean with the converged gain;
     KF_FLAG_EXACT_RECURSION keeps the step-by-step recursion.  Both against the oracle; a series with a late missing row
@@ -1575,6 +1575,7 @@ def test_b4_kernel_steady_state_phase_matches_exact_recursion(eng):
     rng = np.random.default_rng(1)
     c = 0.05 * rng.standard_normal((B, m))
     d = 0.1 * rng.standard_normal((B, 1))
+    monkeypatch.setenv("KF_FORWARD_B4P", "0")  # (else the pair kernel takes a batch this small over at the first hand-over point)
     for missing in ((), (5, 100, 250)):
         y = w["y"].copy()
         y[list(missing)] = np.nan

@@ -92,3 +92,70 @@ def test_grad_and_vectorize_create_the_intended_nodes():
     assert "SteadyStateGradOp" in _op_names(f)
     with pytest.raises(ValueError):
         StandardFilter().build_graph(sym[0], sym[1], sym[2], pt.vector("T1"), *sym[4:])   # filters/utilities.py:16-18
+
+
+def test_graphs_evaluate_end_to_end_with_oracle_backed_bodies(monkeypatch):
+    """function() / grad() through make_node -> perform -> infer_shape -> L_op on the CPU: the numeric bodies (GPU) are
+    replaced by the numpy / torch oracle, so that arity, output order, ranks (the 0-d log-likelihood!), shapes and the
+    gradient plumbing of the Op classes are checked here too, not only on the GPU box."""
+    import numpy as np
+    import pytensor.tensor as pt
+    from numpy.testing import assert_allclose
+
+    from conftest import load_golden
+    from oracle import kalman_numpy as kn
+    from oracle import kalman_torch as kt
+    from pymc_statespace_amd import op
+    from pymc_statespace_amd.filters import KalmanSmoother, StandardFilter
+
+    def col(x):
+        x = np.asarray(x, dtype=np.float64)
+        return x[:, 0] if x.ndim == 2 and x.shape[1] == 1 else x
+
+    def fake_filter(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standard", mvn_const="reference", h_diagonal=False,
+                    engine=None, want=(True,) * 6):
+        r = kn.kalman_filter(np.asarray(data)[..., 0], col(a0)[None], P0[None], T[None], Z[None], R[None], H[None], Q[None],
+                             c=col(c)[None], d=col(d)[None], filter_type=filter_type, mvn_const=mvn_const)
+        outs = [r["filtered_states"][0][..., None], r["predicted_states"][0][..., None], r["filtered_covs"][0],
+                r["predicted_covs"][0], np.asarray(r["logp"][0]), r["ll_obs"][0]]
+        return [o if w else None for o, w in zip(outs, want)]
+
+    def fake_logp_and_grad(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standard", mvn_const="reference",
+                           h_diagonal=False, engine=None):
+        lp, _, g = kt.logp_and_grads(np.asarray(data)[..., 0], col(a0)[None], P0[None], T[None], Z[None], R[None], H[None],
+                                     Q[None], c=col(c)[None], d=col(d)[None], filter_type=filter_type, mvn_const=mvn_const)
+        out = {k: g[k][0] for k in op.GRAD_INPUT_NAMES}
+        for k in ("a0", "c", "d"):
+            out[k] = out[k][..., None]
+        return [np.asarray(lp[0])] + [out[k] for k in op.GRAD_INPUT_NAMES]
+
+    def fake_smoother(T, R, Q, fs, fP, engine=None):
+        sa, sP = kn.kalman_smoother(T[None], R[None], Q[None], np.asarray(fs)[None, ..., 0], np.asarray(fP)[None])
+        return [sa[0][..., None], sP[0]]
+
+    monkeypatch.setattr(op, "perform_filter", fake_filter)
+    monkeypatch.setattr(op, "perform_logp_and_grad", fake_logp_and_grad)
+    monkeypatch.setattr(op, "perform_smoother", fake_smoother)
+    g = load_golden("nile_llt.npz")
+    vals = [g["y"][..., None], g["a0"][0][:, None], g["P0"][0], g["T"][0], g["Z"][0], g["R"][0], g["H"][0], g["Q"][0]]
+    sym = _symbols()
+    outs = StandardFilter().build_graph(*sym)
+    sm = KalmanSmoother().build_graph(sym[3], sym[5], sym[7], outs[0], outs[2])
+    f = pytensor.function(sym, list(outs) + list(sm), on_unused_input="ignore")
+    res = f(*vals)
+    n, m = vals[0].shape[0], 2
+    assert [r.shape for r in res] == [(n, m, 1), (n + 1, m, 1), (n, m, m), (n + 1, m, m), (), (n,), (n, m, 1), (n, m, m)]
+    assert_allclose(res[4], g["llf_obs"].sum(), rtol=2e-9)
+    logp = StandardFilter().build_graph(*sym, outputs="logp")
+    f = pytensor.function(sym, [logp] + pytensor.grad(logp, sym[1:]))
+    res = f(*vals)
+    assert res[0].shape == () and [r.shape for r in res[1:]] == [v.shape for v in vals[1:]]
+    few = StandardFilter().build_graph(*sym, outputs=("log_likelihood",))
+    f = pytensor.function(sym, [few[4], few[2], pytensor.grad(few[4], sym[3])], on_unused_input="ignore")
+    lp, fP, gT = f(*vals)
+    assert fP.shape == (0, 0, 0) and gT.shape == (m, m)
+    assert_allclose(gT, res[3], rtol=1e-12)
+    # time-varying T keeps its 3-D shape in the gradient
+    Tt = pt.tensor3("Tt")
+    lp_tv = StandardFilter().build_graph(sym[0], sym[1], sym[2], Tt, *sym[4:], outputs="logp")
+    assert pytensor.grad(lp_tv, Tt).type.ndim == 3
