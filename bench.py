@@ -407,7 +407,7 @@ def main():
             if os.path.exists(tfile):
                 try:
                     ent = json.load(open(tfile)).get(f"{args.workload}:{'full' if full else 'logp'}:B{B_local}")
-                    if ent and ent.get("kernel", "").startswith(kname):
+                    if ent and any(k.startswith(kname) for k in ent.get("kernels", [ent.get("kernel", "")])):
                         traffic, tsrc = ent["bytes"], ent.get("source")
                 except Exception:  # noqa: BLE001
                     traffic = None

@@ -96,16 +96,24 @@ __global__ __launch_bounds__(P_THREADS) __attribute__((amdgpu_waves_per_eu(B4P_W
     double* RG = smem + L::OFF_RG;
     double* YB = smem + L::OFF_YB;
 
-    double Ta[NB][NB], P[NB];
+    // (round 3: the kernel runs at <= 4 wavefronts per SIMD now -- 128 registers: T / 2 and C_ext / 2 live in registers as in
+    // kf_forward_b4.hip; with 64 registers they were a multiply per product and three LDS reads on the step's dependency chain)
+    double Ta[NB][NB], Tha[NB][NB], Chr[NB], P[NB];
     {
       B4Const<NB, false> KC;
       b4_setup(A, b, smem, lane, KC);
 #pragma unroll
       for (int I = 0; I < NB; ++I) {
         P[I] = KC.P[I];
-        CH[I * 64 + lane] = 0.5 * KC.Ch[I];  // C_ext / 2: the C operand of the second product
+        Chr[I] = 0.5 * KC.Ch[I];  // C_ext / 2: the C operand of the second product
+        CH[I * 64 + lane] = Chr[I];
 #pragma unroll
-        for (int K = 0; K < NB; ++K) Ta[I][K] = KC.Ta[I][K];
+        for (int K = 0; K < NB; ++K) {
+          Ta[I][K] = KC.Ta[I][K];
+          double th = 0.5 * KC.Ta[I][K];
+          asm volatile("" : "+v"(th));  // keep T / 2 in registers (the compiler otherwise re-multiplies per step)
+          Tha[I][K] = th;
+        }
       }
     }
     double logp = 0.0;
@@ -230,14 +238,11 @@ __global__ __launch_bounds__(P_THREADS) __attribute__((amdgpu_waves_per_eu(B4P_W
         for (int I = 0; I < NB; ++I) U[I] = mfma4(Ta[I][K], P[K], U[I]);
       transpose_via(TR, U, U);
 #pragma unroll
-      for (int I = 0; I < NB; ++I) Y[I] = CH[I * 64 + lane];
+      for (int I = 0; I < NB; ++I) Y[I] = Chr[I];
 #pragma unroll
       for (int K = 0; K < NB; ++K) {
 #pragma unroll
-        for (int I = 0; I < NB; ++I) {
-          const double uk = 0.5 * U[K];  // (T / 2) U' = T (U' / 2): exact
-          Y[I] = mfma4(Ta[I][K], uk, Y[I]);
-        }
+        for (int I = 0; I < NB; ++I) Y[I] = mfma4(Tha[I][K], U[K], Y[I]);  // (T / 2) U': exact halves
       }
       {
         double Yt[NB];

@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="$ROOT/bench.py --steps 10 --warmup 2 --no-cpu $*"
+BENCH="$ROOT/bench.py --steps 10 --warmup 2 --no-cpu --no-ops $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 $BENCH > "$OUT/bench_kt.json" 2> "$OUT/kt.log"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $BENCH > "$OUT/bench_fetch.json" 2> "$OUT/fetch.log"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $BENCH > "$OUT/bench_write.json" 2> "$OUT/write.log"

@@ -100,6 +100,17 @@ def main():
         cfg = bench["config"]
         key = f"{bench['config']['workload'].split(':')[0]}:{'full' if cfg['outputs'] == 'full_tape' else 'logp'}:B{cfg['draws_per_gpu']}"
         top = max(entries, key=lambda e: e["bytes"])
+        # a pass that is several kernels (the split pipeline: recursion chunks, compaction, fill, scan, pair kernel): traffic of the
+        # WHOLE pass = the sum over every kf_ launch of the run / the number of passes the run made (bench.py --no-ops: one
+        # allocation pass + warmup + steps identical passes)
+        passes = 1 + int(bench.get("warmup", 0)) + int(bench.get("steps", 0))
+        tot_w = sum(sum(v) for k, v in write.items() if "kf_" in k) * 1024
+        tot_f = sum(sum(v) for k, v in fetch.items() if "kf_" in k) * 1024
+        if len(entries) > 1:
+            print(f"\nwhole pass ({len(entries)} kernels, {passes} passes in the run): WRITE_SIZE = {tot_w / passes / 1e9:.4f} GB, "
+                  f"FETCH_SIZE raw = {tot_f / passes / 1e9:.4f} GB, traffic(write + 2*fetch) = {(tot_w + 2 * tot_f) / passes / 1e9:.4f} GB")
+            top = dict(kernel=top["kernel"], kernels=sorted(e["kernel"] for e in entries), bytes=int((tot_w + 2 * tot_f) / passes),
+                       write_bytes=int(tot_w / passes), fetch_bytes_raw=int(tot_f / passes))
         top.update(key=key, commit=_commit(),
                    source=f"{os.path.basename(out.rstrip('/'))}: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, "
                           "write + 2 x fetch (gfx950 wide-read correction)")
