@@ -302,3 +302,40 @@ def test_value_and_grad_with_the_steady_state_adjoint(eng, monkeypatch, ft, shap
         if nm in ("P0", "Q"):                                         # symmetric inputs: the symmetric parts agree
             a_, ref = a_ + np.swapaxes(a_, -1, -2), ref + np.swapaxes(ref, -1, -2)
         assert np.max(np.abs(a_ - ref)) / (1.0 + np.max(np.abs(ref))) < 1e-9, f"{nm} vs autograd"
+
+
+def test_split_pipeline_and_steady_adjoint_replay_from_a_hip_graph(eng):
+    """The split pipeline forks to the handle's own streams and joins back with events; the steady-state value-and-gradient
+    is five launches on the caller's stream: both must capture into a hipGraph (stream and graph semantics)
+    and replay on new data."""
+    import torch
+
+    w = W.structural(B=1300, n=512)
+    dev = [eng.to_device(x) for x in _args(w)]
+    wv = W.varmax(B=64, n=200)
+    dvv = [eng.to_device(x) for x in _args(wv)]
+
+    def step():
+        res = eng.forward(*dev, mvn_const="exact", exact_recursion=False)
+        small = eng.forward(*[d if i == 0 else d[:40] for i, d in enumerate(dev)], mvn_const="exact")   # pair kernel
+        vg = eng.value_and_grad(*dvv, mvn_const="exact", h_diagonal=True)
+        return res, small, vg
+
+    step()  # lazy initialisation (streams, events, workspaces) outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        res_c, small_c, vg_c = step()
+    rng = np.random.default_rng(1)
+    dev[0].copy_(torch.as_tensor(w["y"] + 0.3 * rng.standard_normal(w["y"].shape), device=dev[0].device))
+    dvv[0].copy_(torch.as_tensor(wv["y"] + 0.3 * rng.standard_normal(wv["y"].shape), device=dev[0].device))
+    graph.replay()
+    torch.cuda.synchronize()
+    res_e, small_e, vg_e = step()
+    torch.cuda.synchronize()
+    for k in TAPES + ["logp"]:
+        assert torch.equal(getattr(res_c, k), getattr(res_e, k)), k
+        assert torch.equal(getattr(small_c, k), getattr(small_e, k)), k
+    assert torch.equal(vg_c[0], vg_e[0])
+    for k in vg_e[2]:
+        assert torch.equal(vg_c[2][k], vg_e[2][k]), k
