@@ -113,7 +113,11 @@ enum {
   KF_FLAG_EXACT_RECURSION = 1u << 12,
   /* Forward filter: use the steady-state phase wherever the selected kernel has one, whatever the series length (the block
    * kernel's default depends on it, see above).  KF_FLAG_EXACT_RECURSION wins when both are set. */
-  KF_FLAG_STEADY_STATE = 1u << 13
+  KF_FLAG_STEADY_STATE = 1u << 13,
+  /* kf_smoother with time-varying T / R / Q: the step that smooths t uses slice t + 1 -- the pairing of the reference's own scan
+   * (kalman_smoother.py:62-77 reverses the n-long matrix sequences next to the (n-1)-long filtered tapes).  Default (flag clear):
+   * slice t, the pairing of the forward filter that produced the tapes. */
+  KF_FLAG_TV_SMOOTHER_REFERENCE_PAIRING = 1u << 14
 };
 
 /* error codes */

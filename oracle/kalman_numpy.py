@@ -438,7 +438,7 @@ def kalman_filter(data, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type="stan
                 logp=ll_obs.sum(axis=-1), ll_obs=ll_obs, batched=s["batched"])
 
 
-def kalman_smoother(T, R, Q, filtered_states, filtered_covs, time_varying=()):
+def kalman_smoother(T, R, Q, filtered_states, filtered_covs, time_varying=(), pairing="filter"):
     """KalmanSmoother.build_graph, kalman_smoother.py:56-104, batched.
 
     filtered_states (B,n,m) | (n,m) | (n,m,1); filtered_covs (B,n,m,m) | (n,m,m).
@@ -450,11 +450,15 @@ def kalman_smoother(T, R, Q, filtered_states, filtered_covs, time_varying=()):
     own scan (kalman_smoother.py:62-77) hands the n-long matrix sequences reversed next to the (n-1)-long reversed
     filtered tapes, so its step for t receives slice t + 1; with that pairing the smoother is not the adjoint of the
     filter that produced the tapes (and nothing in the reference's tests exercises it numerically: they are shape
-    tests, tests/test_kalman_filter.py:143-156).
+    tests, tests/test_kalman_filter.py:143-156).  ``pairing="reference"`` reproduces the reference's pairing (slice t + 1 at the
+    step that smooths t), so that parity against upstream can be shown for a model ported with time-varying T / R / Q;
+    the default ``"filter"`` is the pairing described above.
     """
+    if pairing not in ("filter", "reference"):
+        raise ValueError("pairing must be 'filter' or 'reference'")
     tv = set(time_varying)
     if tv:
-        return _kalman_smoother_tv(T, R, Q, filtered_states, filtered_covs, tv)
+        return _kalman_smoother_tv(T, R, Q, filtered_states, filtered_covs, tv, 1 if pairing == "reference" else 0)
     T_b, _ = _as_batch(T, 2)
     R_b, _ = _as_batch(R, 2)
     Q_b, _ = _as_batch(Q, 2)
@@ -487,7 +491,7 @@ def kalman_smoother(T, R, Q, filtered_states, filtered_covs, time_varying=()):
     return sa, sP
 
 
-def _kalman_smoother_tv(T, R, Q, filtered_states, filtered_covs, tv):
+def _kalman_smoother_tv(T, R, Q, filtered_states, filtered_covs, tv, shift=0):
     fa = np.asarray(filtered_states, dtype=np.float64)
     fP = np.asarray(filtered_covs, dtype=np.float64)
     B, n, m = fa.shape
@@ -500,7 +504,7 @@ def _kalman_smoother_tv(T, R, Q, filtered_states, filtered_covs, tv):
     sa[:, -1], sP[:, -1] = fa[:, -1], fP[:, -1]
     a_s, P_s = fa[:, -1], fP[:, -1]
     for t in range(n - 2, -1, -1):
-        Tt, Rt, Qt = at(T, "T", t), at(R, "R", t), at(Q, "Q", t)
+        Tt, Rt, Qt = at(T, "T", t + shift), at(R, "R", t + shift), at(Q, "Q", t + shift)
         a, P = fa[:, t], fP[:, t]
         a_hat = np.einsum("bij,bj->bi", Tt, a)
         P_hat = Tt @ P @ _T(Tt) + Rt @ Qt @ _T(Rt)

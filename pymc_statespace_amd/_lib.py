@@ -20,6 +20,7 @@ KF_FLAG_Y_PER_DRAW = 1 << 1
 KF_FLAG_H_DIAGONAL = 1 << 11
 KF_FLAG_EXACT_RECURSION = 1 << 12
 KF_FLAG_STEADY_STATE = 1 << 13
+KF_FLAG_TV_SMOOTHER_REFERENCE_PAIRING = 1 << 14
 KF_FLAG_TV = {"T": 1 << 4, "Z": 1 << 5, "R": 1 << 6, "H": 1 << 7, "Q": 1 << 8, "c": 1 << 9, "d": 1 << 10}
 
 KF_WS_FORWARD, KF_WS_BACKWARD, KF_WS_SMOOTHER, KF_WS_ALL = 1, 2, 4, 7

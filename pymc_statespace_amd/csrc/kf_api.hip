@@ -800,6 +800,7 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
   a.smooth_a = smooth_a; a.smooth_P = smooth_P;
   a.only_flagged = nullptr;
   if (a.flags) {
+    a.flags |= dims->flags & KF_FLAG_TV_SMOOTHER_REFERENCE_PAIRING;
     // time-varying T / R / Q (kalman_smoother.py:17-54,62-77): the LDS-resident kernel reloads the slices per step
     if (!kf_smoother_lds_fits(a.m)) {
       KF_SET_ERR(h, "kf_smoother: time-varying system matrices need the LDS-resident kernel (m=%d too large)", a.m);

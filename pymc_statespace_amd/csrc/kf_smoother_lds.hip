@@ -168,7 +168,9 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lds_kernel(const KfSmoothAr
 
   // time-varying matrices (KF_FLAG_TV_*): [B][n][.][.]; the step that smooths t predicts from t with slice t, the
   // pairing of the forward filter (kalman_filter.py:231-252: step t predicts with T[t], R[t], Q[t])
+  // (KF_FLAG_TV_SMOOTHER_REFERENCE_PAIRING: slice t + 1 instead, what the reference's scan hands its step, kalman_smoother.py:62-77)
   const bool tvT = (A.flags & KF_FLAG_TV_T) != 0, tvR = (A.flags & KF_FLAG_TV_R) != 0, tvQ = (A.flags & KF_FLAG_TV_Q) != 0;
+  const int tsh = (A.flags & KF_FLAG_TV_SMOOTHER_REFERENCE_PAIRING) ? 1 : 0;
   auto load_T = [&](int t) {
     const double* gT = A.Tm + (tvT ? b * (long)n + t : b) * mm;
     for (int e = lig; e < mm; e += G) Tl[e] = gT[e];
@@ -202,8 +204,8 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lds_kernel(const KfSmoothAr
   for (int t = n - 2; t >= 0; --t) {
     for (int e = lig; e < m; e += G) al[e] = gfa[(long)t * m + e];
     for (int e = lig; e < mm; e += G) P[e] = gfP[(long)t * mm + e];
-    if (tvT) load_T(t);
-    if (tvR || tvQ) load_RQR(t);
+    if (tvT) load_T(t + tsh);
+    if (tvR || tvQ) load_RQR(t + tsh);
     wsync();
     // a_hat = T a ; W = T P
     for (int i = lig; i < m; i += G) {

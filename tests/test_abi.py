@@ -30,6 +30,8 @@ def test_flag_bits_of_the_binding_match_the_header():
     assert _lib.KF_FLAG_Y_PER_DRAW == 1 << bits["KF_FLAG_Y_PER_DRAW"]
     assert _lib.KF_FLAG_H_DIAGONAL == 1 << bits["KF_FLAG_H_DIAGONAL"]
     assert _lib.KF_FLAG_EXACT_RECURSION == 1 << bits["KF_FLAG_EXACT_RECURSION"]
+    assert _lib.KF_FLAG_STEADY_STATE == 1 << bits["KF_FLAG_STEADY_STATE"]
+    assert _lib.KF_FLAG_TV_SMOOTHER_REFERENCE_PAIRING == 1 << bits["KF_FLAG_TV_SMOOTHER_REFERENCE_PAIRING"]
     for name, bit in _lib.KF_FLAG_TV.items():
         assert bit == 1 << bits[f"KF_FLAG_TV_{name.upper()}"]
     assert len(set(bits.values())) == len(bits)  # no two flags share a bit

@@ -938,6 +938,15 @@ def test_time_varying_smoother_matches_oracle(eng, tv, m):
     sa, sP = eng.smooth(mats["T"], mats["R"], mats["Q"], res.filtered_states, res.filtered_covs, time_varying=tv)
     assert_allclose(sa.cpu().numpy(), ra, rtol=1e-8, atol=1e-8)
     assert_allclose(sP.cpu().numpy(), rP, rtol=1e-8, atol=1e-8)
+    # pairing="reference" (KF_FLAG_TV_SMOOTHER_REFERENCE_PAIRING): slice t + 1 at the step that smooths t, what the reference's own
+    # scan hands its step (kalman_smoother.py:62-77) -- a different smoother, reproduced on request
+    ra2, rP2 = kn.kalman_smoother(mats["T"], mats["R"], mats["Q"], ref_f["filtered_states"], ref_f["filtered_covs"],
+                                  time_varying=tv, pairing="reference")
+    sa2, sP2 = eng.smooth(mats["T"], mats["R"], mats["Q"], res.filtered_states, res.filtered_covs, time_varying=tv,
+                          pairing="reference")
+    assert_allclose(sa2.cpu().numpy(), ra2, rtol=1e-8, atol=1e-8)
+    assert_allclose(sP2.cpu().numpy(), rP2, rtol=1e-8, atol=1e-8)
+    assert not np.allclose(rP2, rP, rtol=1e-6, atol=1e-9)
     # constant "time-varying" matrices reproduce the static smoother bit for bit
     const = {k: np.repeat(w[k][:, None], n, axis=1) for k in ("T", "R", "Q")}
     flt = kn.kalman_filter(*_args(w))

@@ -53,8 +53,8 @@ def test_filter_op_matches_statsmodels_golden(nile):
     n = vals[0].shape[0]
     assert [r.shape for r in res[:6]] == [(n, m, 1), (n + 1, m, 1), (n, m, m), (n + 1, m, m), (), (n,)]
     assert_allclose(res[4], g["llf_obs"].sum(), rtol=2e-9)
-    assert_allclose(res[0][..., 0], g["filtered_state"], rtol=1e-7, atol=1e-7)
-    assert_allclose(res[6][..., 0], g["smoothed_state"], rtol=1e-7, atol=1e-7)
+    assert_allclose(res[0][..., 0], g["filtered_state"][0], rtol=1e-7, atol=1e-7)
+    assert_allclose(res[6][..., 0], g["smoothed_state"][0], rtol=1e-7, atol=1e-7)
 
 
 def test_only_requested_outputs_are_computed(nile, monkeypatch):
