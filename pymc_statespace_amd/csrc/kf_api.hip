@@ -319,7 +319,7 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a_in, void* workspace, size
     return kf_launch_forward_lds(h, a, stream);
   }
   if (kf_b4_selected(h, a.m, a.p, a.r, a.B)) return kf_launch_forward_b4(h, a, workspace, workspace_bytes, stream);
-  if (kf_b4q_selected(h, a.m, a.p, a.r, a.filter, a.flags, a.B)) return kf_launch_forward_b4q(h, a, stream);
+  if (kf_b4q_selected(h, a.m, a.p, a.r, a.filter, a.flags, a.B)) return kf_launch_forward_b4q(h, a, workspace, workspace_bytes, stream);
   if (h->forward_kernel == KF_KERNEL_B4) {
     KF_SET_ERR(h, "forward(b4): needs p == 1, m <= 14, static matrices (got p=%d m=%d)", a.p, a.m);
     return KF_ERR_UNSUPPORTED;
@@ -584,6 +584,12 @@ extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, i
     const size_t sw = kf_b4_split_workspace_bytes(dims->B, m, dims->T);
     if (sw > *bytes) *bytes = sw;
   }
+  // forward, multi-observation block kernel with its steady-state phase: hand-over buffers + per-draw constants of the split phase
+  if ((which & KF_WS_FORWARD) && !(dims->flags & (KF_FLAG_TV_ANY | KF_FLAG_EXACT_RECURSION)) && p >= 3 && p <= 5 && m >= 8 && m <= 15 &&
+      dims->T >= 64 && kf_b4q_selected(h, m, p, r, dims->filter, dims->flags, dims->B)) {
+    const size_t sw = kf_b4q_split_workspace_bytes(dims->B);
+    if (sw > *bytes) *bytes = sw;
+  }
   if ((which & KF_WS_SMOOTHER) && m >= 1 && m <= KF_WG_M_MAX) {  // flags of the register-tile smoothers
     const size_t sm = kf_smoother_mfma_workspace_bytes(dims->B);
     if (sm > *bytes) *bytes = sm;
@@ -744,7 +750,7 @@ extern "C" int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims, const
     f.y = y; f.a0 = a0; f.P0 = P0; f.Tm = T; f.Z = Z; f.R = R; f.H = H; f.Q = Q; f.c = c; f.d = d;
     f.logp = logp; f.ll_obs = nullptr; f.filt_a = nullptr; f.pred_a = pred_a; f.filt_P = nullptr; f.pred_P = pred_P;
     f.info = info; f.tile_tape = nullptr; f.hs_ts = ts; f.skip_steady_cov = 1;
-    rc = kf_launch_forward_b4q(h, f, (hipStream_t)stream);
+    rc = kf_launch_forward_b4q(h, f, w, inner_s, (hipStream_t)stream);
     if (rc) return rc;
     if (!g_logp) {
       hipLaunchKernelGGL(kf_fill_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ones,

@@ -1,6 +1,7 @@
 // kf_b4_split.h -- workspace of the split forward pipeline (kf_forward_b4.hip + kf_forward_b4_steady.hip).
 #pragma once
 #include "kf_internal.h"
+#include "kf_tile.h"
 
 constexpr int B4_HS_STRIDE = 4 * KF_WAVE;  // doubles per draw in hs_tile: the register image, row-major [16][16]
 constexpr int B4_HC_STRIDE = 24 * KF_WAVE;  // doubles per draw in hs_const (NB <= 3: 2 * 9 + 3 registers)
@@ -46,6 +47,34 @@ inline size_t kf_b4_split_carve(void* base, long B, int m, int n, B4SplitWs* W) 
   W->offS = (int32_t*)(p + off); off += up(4 * (size_t)(B4_SPLIT_MAX_CHUNKS + 1));
   return off + 256;  // (+ alignment slack for a base that is not 256-byte aligned)
 }
+
+// One tape range [dst, dst + count) of a periodic image: element i = img[(phase + i) mod mm]; img has mm + 1 entries
+// (img[mm] = img[0]).  Single elements up to the first 128-byte line boundary, then 16 bytes per lane, whole lines.
+// Windows [w_lo, w_hi) of 128 elements (counted from the first line boundary) are this caller's share; the head belongs
+// to the caller with w_lo == 0.
+#ifdef __HIPCC__
+static __device__ __forceinline__ void fill_periodic(double* dst, long count, const double* img, int mm, int phase, int lane,
+                                              long w_lo, long w_hi) {
+  const long a0 = (long)((reinterpret_cast<unsigned long long>(dst) >> 3) & 15ull);
+  long lead = (16 - a0) & 15;
+  if (lead > count) lead = count;
+  if (w_lo == 0 && lane < lead) dst[lane] = img[(phase + lane) % mm];
+  const int step = 128 % mm;
+  long pos = lead + 128 * w_lo + 2 * lane;
+  int off = (int)((phase + pos) % mm);
+  const long end = (lead + 128 * w_hi < count) ? lead + 128 * w_hi : count;
+  for (; pos < end; pos += 128) {
+    if (pos + 1 < end) {
+      double2_t v = {img[off], img[off + 1]};
+      *reinterpret_cast<double2_t*>(dst + pos) = v;
+    } else {
+      dst[pos] = img[off];
+    }
+    off += step;
+    if (off >= mm) off -= mm;
+  }
+}
+#endif
 
 // the split pipeline serves: p == 1, m <= 10 (covariance tapes through the rings), static matrices, steady-state phase allowed
 bool kf_forward_b4_split_ok(const kf_handle* h, long B, int T, int p, int m, int r, unsigned flags);

@@ -101,33 +101,7 @@ __global__ __launch_bounds__(1024) void kf_b4_split_compact_kernel(const B4Split
     for (int i = tid; i < baseR; i += 1024) W.hs_ts[W.listR[i]] = -4;
 }
 
-// ---- constant covariance tapes -----------------------------------------------------------------------------------------
-// One tape range [dst, dst + count) of a periodic image: element i = img[(phase + i) mod mm]; img has mm + 1 entries
-// (img[mm] = img[0]).  Single elements up to the first 128-byte line boundary, then 16 bytes per lane, whole lines.
-// Windows [w_lo, w_hi) of 128 elements (counted from the first line boundary) are this caller's share; the head belongs
-// to the caller with w_lo == 0.
-__device__ __forceinline__ void fill_periodic(double* dst, long count, const double* img, int mm, int phase, int lane,
-                                              long w_lo, long w_hi) {
-  const long a0 = (long)((reinterpret_cast<unsigned long long>(dst) >> 3) & 15ull);
-  long lead = (16 - a0) & 15;
-  if (lead > count) lead = count;
-  if (w_lo == 0 && lane < lead) dst[lane] = img[(phase + lane) % mm];
-  const int step = 128 % mm;
-  long pos = lead + 128 * w_lo + 2 * lane;
-  int off = (int)((phase + pos) % mm);
-  const long end = (lead + 128 * w_hi < count) ? lead + 128 * w_hi : count;
-  for (; pos < end; pos += 128) {
-    if (pos + 1 < end) {
-      double2_t v = {img[off], img[off + 1]};
-      *reinterpret_cast<double2_t*>(dst + pos) = v;
-    } else {
-      dst[pos] = img[off];
-    }
-    off += step;
-    if (off >= mm) off -= mm;
-  }
-}
-
+// ---- constant covariance tapes: fill_periodic (kf_b4_split.h) ---------------------------------------------------------------
 // hs_tile[b] is the register image of the predicted tile = row-major [N4][16] (register I, lane 16 g + c holds X[4I+g][c]):
 // rows / columns 0..m-1 the covariance, JA = N4-2 the row (P Z')' with Z P Z' on the diagonal, JC = N4-1 twice the mean.
 // Work items = (hand-over entry, slice of its remaining steps); every chunk has its own queue counter fillq[c] over the entries

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "kf_b4.h"
+#include "kf_b4_split.h"
 
 namespace {
 
@@ -568,7 +569,21 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(GRP ? K
       break;
     }
   }
-  if (A.hs_ts && lane == 0) A.hs_ts[b] = t;  // (kf_filter_value_and_grad: where the steady-state phase starts; n if it never does)
+  if (A.hs_ts && lane == 0) A.hs_ts[b] = t;  // (where the steady-state phase starts; n if it never does)
+  if constexpr (SSK) if (t < n && A.hs_tile) {
+    // split steady-state phase (kf_forward_b4q_steady.hip): leave the converged tile, the log-likelihood so far and the flag; the
+    // constant covariance tapes, the mean recursion and the rest of the log-likelihood come from the kernels launched behind this one
+    if (pred_pending) flush_cov(t_pP);
+    if (t & (QLB - 1)) flush_ring(t & ~(QLB - 1), t & (QLB - 1));
+    double* ht = A.hs_tile + b * (long)B4_HS_STRIDE + lane;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) ht[I * KF_WAVE] = P[I];
+    if (lane == 0) {
+      A.hs_logp[b] = logp;
+      A.hs_info[b] = info;
+    }
+    return;
+  }
   if constexpr (SSK) if (t < n) {
     // ---- steady-state steps t .. n-1: P is the converged predicted tile of step t.  The first of them runs the ordinary
     // update once more and leaves its constants where the update put them -- W and the rows of Uh (the group), u (the single
@@ -767,7 +782,35 @@ bool kf_forward_b4q_ok(int m, int p, int r) {
   return p >= 2 && p <= QPMAX && m >= 1 && m + 1 <= 16 && r >= 1 && r <= 64;
 }
 
-int kf_launch_forward_b4q(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
+size_t kf_b4q_split_workspace_bytes(long B);
+void kf_b4q_split_carve(void* base, long B, KfFwdArgs* a, double** sp);
+int kf_b4q_split_steady(kf_handle* h, const KfFwdArgs& a, double* sp, hipStream_t s_fill, hipStream_t s_scan, hipEvent_t ev_rec,
+                        hipEvent_t ev_prep, hipEvent_t ev_fill, hipEvent_t ev_scan);
+int kf_b4q_sp_stride();
+
+// the arguments of the draws [lo, lo + cnt): every per-draw pointer moved, B = cnt
+static KfFwdArgs b4q_draw_range(const KfFwdArgs& a, long lo, long cnt) {
+  KfFwdArgs s = a;
+  const long n = a.T, m = a.m, p = a.p, r = a.r, mm = m * m;
+  s.B = cnt;
+  if (a.flags & KF_FLAG_Y_PER_DRAW) s.y = a.y + lo * n * p;
+  s.a0 = a.a0 + lo * m; s.P0 = a.P0 + lo * mm; s.Tm = a.Tm + lo * mm; s.Z = a.Z + lo * p * m; s.R = a.R + lo * m * r;
+  s.H = a.H + lo * p * p; s.Q = a.Q + lo * r * r;
+  if (a.c) s.c = a.c + lo * m;
+  if (a.d) s.d = a.d + lo * p;
+  s.logp = a.logp + lo;
+  if (a.ll_obs) s.ll_obs = a.ll_obs + lo * n;
+  if (a.filt_a) s.filt_a = a.filt_a + lo * n * m;
+  if (a.pred_a) s.pred_a = a.pred_a + lo * (n + 1) * m;
+  if (a.filt_P) s.filt_P = a.filt_P + lo * n * mm;
+  if (a.pred_P) s.pred_P = a.pred_P + lo * (n + 1) * mm;
+  if (a.info) s.info = a.info + lo;
+  s.hs_tile = a.hs_tile + lo * B4_HS_STRIDE; s.hs_logp = a.hs_logp + lo; s.hs_info = a.hs_info + lo; s.hs_ts = a.hs_ts + lo;
+  return s;
+}
+
+int kf_launch_forward_b4q(kf_handle* h, const KfFwdArgs& a_in, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  KfFwdArgs a = a_in;
   if (!kf_forward_b4q_ok(a.m, a.p, a.r) || (a.flags & KF_FLAG_TV_ANY)) {
     KF_SET_ERR(h, "forward(b4q): needs 2 <= p <= %d scalar observations, m <= 15, static matrices (got p=%d m=%d r=%d)",
                QPMAX, a.p, a.m, a.r);
@@ -783,6 +826,19 @@ int kf_launch_forward_b4q(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) 
   // steady-state phase: its own instantiation (KF_FLAG_EXACT_RECURSION / KF_STEADY_STATE=0 run the kernel without it)
   const char* sse = getenv("KF_STEADY_STATE");
   const bool ss = grp && a.p <= 5 && a.T >= 64 && !(a.flags & KF_FLAG_EXACT_RECURSION) && !(sse && *sse && atoi(sse) == 0);
+  // split steady-state phase (kf_forward_b4q_steady.hip) when the caller passed the workspace; KF_B4Q_SPLIT=0: the phase inside
+  // the recursion kernel (round 2)
+  double* sp = nullptr;
+  bool split = false;
+  {
+    const char* e = getenv("KF_B4Q_SPLIT");
+    split = ss && nb >= 3 && a.m <= 15 && workspace && workspace_bytes >= kf_b4q_split_workspace_bytes(a.B) && !(e && e[0] == '0');
+    if (split) {
+      const int rc0 = kf_handle_aux(h);
+      if (rc0) return rc0;
+      kf_b4q_split_carve(workspace, a.B, &a, &sp);
+    }
+  }
 #define KF_B4Q_LAUNCH2(NB_, TM_)                                                                                              \
   do {                                                                                                                        \
     if (ss && NB_ >= 3)                                                                                                       \
@@ -799,14 +855,33 @@ int kf_launch_forward_b4q(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) 
     else if (mask == 10) KF_B4Q_LAUNCH2(NB_, 10);    \
     else KF_B4Q_LAUNCH2(NB_, -1);                    \
   } while (0)
-  switch (nb) {
-    case 1: KF_B4Q_LAUNCH(1); break;
-    case 2: KF_B4Q_LAUNCH(2); break;
-    case 3: KF_B4Q_LAUNCH(3); break;
-    default: KF_B4Q_LAUNCH(4); break;
+  // split phase: draws in chunks of 4096 (one round of the chip's wavefront slots), so that the constants, the fill and the scan of a
+  // chunk run beside the recursion of the next one
+  const long chunk = split ? 4096 : a.B;
+  const KfFwdArgs a_all = a;
+  int ci = 0;
+  for (long lo = 0; lo < a_all.B; lo += chunk, ++ci) {
+    const long cnt = (a_all.B - lo) < chunk ? (a_all.B - lo) : chunk;
+    if (split) a = b4q_draw_range(a_all, lo, cnt);
+    switch (nb) {
+      case 1: KF_B4Q_LAUNCH(1); break;
+      case 2: KF_B4Q_LAUNCH(2); break;
+      case 3: KF_B4Q_LAUNCH(3); break;
+      default: KF_B4Q_LAUNCH(4); break;
+    }
+    KF_HIP_CHECK(h, hipGetLastError());
+    if (split) {
+      hipEvent_t* ev = h->aux_ev + 4 * (ci % 8);
+      KF_HIP_CHECK(h, hipEventRecord(ev[0], stream));
+      const int rc = kf_b4q_split_steady(h, a, sp + lo * kf_b4q_sp_stride(), h->aux_stream, h->aux_stream2, ev[0], ev[1], ev[2], ev[3]);
+      if (rc) return rc;
+      if (lo + cnt >= a_all.B) {  // the last chunk: the caller's stream continues behind both steady streams
+        KF_HIP_CHECK(h, hipStreamWaitEvent(stream, ev[2], 0));
+        KF_HIP_CHECK(h, hipStreamWaitEvent(stream, ev[3], 0));
+      }
+    }
   }
 #undef KF_B4Q_LAUNCH2
 #undef KF_B4Q_LAUNCH
-  KF_HIP_CHECK(h, hipGetLastError());
   return KF_OK;
 }

@@ -192,7 +192,8 @@ bool kf_forward_b4p_ok(int m, int p, int r);
 int kf_launch_forward_b4p(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 // several scalar observations per step on the same 4x4x4 block tiles (kf_forward_b4q.hip)
 bool kf_forward_b4q_ok(int m, int p, int r);
-int kf_launch_forward_b4q(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+int kf_launch_forward_b4q(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream);
+size_t kf_b4q_split_workspace_bytes(long B);
 // block-tile variant (kf_forward_mfma_nb.hip): 16 < m <= 48 as 2 x 2 / 3 x 3 blocks of 16 x 16
 #define KF_NB_M_MAX 48
 bool kf_forward_mfma_nb_ok(int m, int p, int r);
