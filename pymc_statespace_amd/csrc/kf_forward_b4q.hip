@@ -784,8 +784,8 @@ bool kf_forward_b4q_ok(int m, int p, int r) {
 
 size_t kf_b4q_split_workspace_bytes(long B);
 void kf_b4q_split_carve(void* base, long B, KfFwdArgs* a, double** sp);
-int kf_b4q_split_steady(kf_handle* h, const KfFwdArgs& a, double* sp, hipStream_t s_fill, hipStream_t s_scan, hipEvent_t ev_rec,
-                        hipEvent_t ev_prep, hipEvent_t ev_fill, hipEvent_t ev_scan);
+int kf_b4q_split_steady(kf_handle* h, const KfFwdArgs& a, double* sp, hipStream_t s_prep, hipStream_t s_fill, hipStream_t s_scan,
+                        hipEvent_t ev_rec, hipEvent_t ev_prep, hipEvent_t ev_fill, hipEvent_t ev_scan);
 int kf_b4q_sp_stride();
 
 // the arguments of the draws [lo, lo + cnt): every per-draw pointer moved, B = cnt
@@ -857,7 +857,13 @@ int kf_launch_forward_b4q(kf_handle* h, const KfFwdArgs& a_in, void* workspace, 
   } while (0)
   // split phase: draws in chunks of 4096 (one round of the chip's wavefront slots), so that the constants, the fill and the scan of a
   // chunk run beside the recursion of the next one
-  const long chunk = split ? 4096 : a.B;
+  long chunk = split ? 4096 : a.B;
+  {
+    const char* e = getenv("KF_B4Q_CHUNK");  // experiments
+    if (split && e && *e && atol(e) >= 256) chunk = atol(e);
+  }
+  const char* pse = getenv("KF_B4Q_PREP_STREAM");
+  hipStream_t s_prep = (pse && pse[0] == '1') ? h->aux_stream : h->aux_stream3;
   const KfFwdArgs a_all = a;
   int ci = 0;
   for (long lo = 0; lo < a_all.B; lo += chunk, ++ci) {
@@ -873,7 +879,7 @@ int kf_launch_forward_b4q(kf_handle* h, const KfFwdArgs& a_in, void* workspace, 
     if (split) {
       hipEvent_t* ev = h->aux_ev + 4 * (ci % 8);
       KF_HIP_CHECK(h, hipEventRecord(ev[0], stream));
-      const int rc = kf_b4q_split_steady(h, a, sp + lo * kf_b4q_sp_stride(), h->aux_stream, h->aux_stream2, ev[0], ev[1], ev[2], ev[3]);
+      const int rc = kf_b4q_split_steady(h, a, sp + lo * kf_b4q_sp_stride(), s_prep, h->aux_stream, h->aux_stream2, ev[0], ev[1], ev[2], ev[3]);
       if (rc) return rc;
       if (lo + cnt >= a_all.B) {  // the last chunk: the caller's stream continues behind both steady streams
         KF_HIP_CHECK(h, hipStreamWaitEvent(stream, ev[2], 0));

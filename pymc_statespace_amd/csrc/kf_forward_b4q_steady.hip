@@ -435,16 +435,18 @@ void kf_b4q_split_carve(void* base, long B, KfFwdArgs* a, double** sp) {
   if (!a->hs_ts) a->hs_ts = (int32_t*)p;  // (kf_filter_value_and_grad passes its own ts array)
 }
 
-// behind one recursion launch (event ev_rec on the caller's stream): the constants and the fill on s_fill, the scan on s_scan
-// behind the constants.  Nothing joins here: the caller makes its stream wait for ev_fill / ev_scan of the LAST chunk (both
+// behind one recursion launch (event ev_rec on the caller's stream): the constants on s_prep, the fill on s_fill and the scan on
+// s_scan behind the constants.  Nothing joins here: the caller makes its stream wait for ev_fill / ev_scan of the LAST chunk (both
 // streams run their launches in order)
-int kf_b4q_split_steady(kf_handle* h, const KfFwdArgs& a, double* sp, hipStream_t s_fill, hipStream_t s_scan, hipEvent_t ev_rec,
-                        hipEvent_t ev_prep, hipEvent_t ev_fill, hipEvent_t ev_scan) {
+int kf_b4q_split_steady(kf_handle* h, const KfFwdArgs& a, double* sp, hipStream_t s_prep, hipStream_t s_fill, hipStream_t s_scan,
+                        hipEvent_t ev_rec, hipEvent_t ev_prep, hipEvent_t ev_fill, hipEvent_t ev_scan) {
   const int m = a.m, mm = m * m;
-  KF_HIP_CHECK(h, hipStreamWaitEvent(s_fill, ev_rec, 0));
-  hipLaunchKernelGGL(kf_b4q_steady_prep_kernel, dim3((unsigned)a.B), dim3(KF_WAVE), 0, s_fill, a, sp);
+  // (the constants on their own stream: those of the next chunk are computed beside this chunk's fill)
+  KF_HIP_CHECK(h, hipStreamWaitEvent(s_prep, ev_rec, 0));
+  hipLaunchKernelGGL(kf_b4q_steady_prep_kernel, dim3((unsigned)a.B), dim3(KF_WAVE), 0, s_prep, a, sp);
   KF_HIP_CHECK(h, hipGetLastError());
-  KF_HIP_CHECK(h, hipEventRecord(ev_prep, s_fill));
+  KF_HIP_CHECK(h, hipEventRecord(ev_prep, s_prep));
+  KF_HIP_CHECK(h, hipStreamWaitEvent(s_fill, ev_prep, 0));
   if ((a.filt_P || a.pred_P) && !a.skip_steady_cov) {
     long ns = ((long)a.T * mm * 8 + 65535) / 65536;
     const int nslice = (int)(ns < 1 ? 1 : ns > 32 ? 32 : ns);
