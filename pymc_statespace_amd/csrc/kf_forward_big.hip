@@ -16,6 +16,10 @@
 // are real contractions, so they run on the matrix cores: 128x64 output tile per 512-thread
 // workgroup (8 waves, 2x2 MFMA 16x16 tiles each), K staged through LDS in chunks of 32 with the
 // next chunk prefetched into registers.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "kf_internal.h"
 
 namespace {
@@ -37,22 +41,88 @@ constexpr int GPA = GTM * GK / GNT, GPB = GTN * GK / GNT;  // staged elements pe
 // from HBM/L2 into registers while the MFMAs of the current chunk run out of LDS.
 // UPPER: the result is symmetric up to rounding and only its upper triangle is consumed (big_sym_kernel
 // mirrors it): tiles entirely below the diagonal are skipped -- a third of them at m = 367
-template <bool TRANS_B, bool ADD_E, bool UPPER = false>
-__global__ __launch_bounds__(GNT) void big_gemm_kernel(const double* __restrict__ A, long strideA,
+// Round 3, two small per-step kernels folded into the products (they were 13 % of a C5 step, each a pass over a B m^2 array):
+// PFIX (p == 1, !TRANS_B, m <= 1024): the B operand is P and becomes P_f = P - k m' - m k' + (k f) k' ON ITS WAY INTO LDS (the three
+//   vectors x.kv, x.mv, x.kfv sit in LDS; a thread stages one column and wave-uniform rows, so the fix is three LDS broadcasts and three
+//   FMAs per staged element, in big_pf_kernel's order of operations): W = T P_f without big_pf_kernel's pass over P (valid when the
+//   filtered covariance tape is not requested).  The same launch carries 8 * ceil(B / 8) * ceil(m / 32) more workgroups AHEAD of the tiles
+//   (behind them they were a 40 us tail) that compute a_hat = T a_f + c (big_apred_kernel's arithmetic) while the tiles keep the MFMA pipes busy;
+// MIRROR (with UPPER): an element (r, c) with r <= c is stored at (r, c) AND (c, r) of C (and of x.ctape), elements below the
+//   diagonal are dropped -- big_sym_kernel's mirror of the upper triangle happens in the epilogue of S = W T' + R Q R'.
+//   With x.mrow: the tile also leaves its share of the NEXT step's m = P z (p == 1) -- per row the sum over its columns, per column
+//   the sum over its rows (the mirrored elements) -- in x.mrow / x.mcol; big_gain_kernel adds the shares of the tiles that exist, in a
+//   fixed order (no atomics: the result does not depend on the order the workgroups ran in), and big_mvec_kernel's pass over P is gone.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct BigGemmExtra {
+  const double* kv;     // [B][m]  k
+  const double* mv;     // [B][m]  m = P z
+  const double* kfv;    // [B][m]  k f
+  const double* af;     // [B][m]  filtered state
+  const double* cvec;   // [B][m] or NULL
+  double* aout;         // [B][m]  a_hat
+  double* atape;        // [B] x atape_stride, or NULL
+  long atape_stride;
+  double* ctape;        // [B] x ctape_stride (m x m images), or NULL
+  long ctape_stride;
+  const double* zv;     // [B][m]  Z (p == 1), with mrow / mcol
+  double* mrow;         // [B][tiles_n][m]  partial sums of C z over the columns of one tile column, or NULL
+  double* mcol;         // [B][tiles_m][m]  the mirrored elements' share, over the rows of one tile row
+};
+constexpr int BIG_PFIX_M = 1024;
+template <bool TRANS_B, bool ADD_E, bool UPPER = false, bool PFIX = false, bool MIRROR = false>
+__global__ __launch_bounds__(GNT) __attribute__((amdgpu_waves_per_eu(4))) void big_gemm_kernel(const double* __restrict__ A, long strideA,
                                                        const double* __restrict__ Bm, long strideB,
                                                        const double* __restrict__ E, long strideE,
                                                        double* __restrict__ Cm, long strideC, int m,
-                                                       long B, int tiles_n, int tiles_m) {
+                                                       long B, int tiles_n, int tiles_m, const BigGemmExtra x) {
   __shared__ double As[GK][GLDA];  // As[k][r]  (A tile, k-major)
   __shared__ double Bs[GK][GLDB];  // Bs[k][c]
+  __shared__ double vsK[PFIX ? BIG_PFIX_M + GK : 1], vsM[PFIX ? BIG_PFIX_M + GK : 1], vsKF[PFIX ? BIG_PFIX_M + GK : 1];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int wr = wave / GWC, wc = wave % GWC;
+  if (PFIX) {  // the workgroups ahead of the tiles: a_hat = T a_f + c, four rows per wavefront at a time
+    const int nch = (m + 31) / 32;
+    const long xblocks = 8L * nch * ((B + 7) / 8);
+    if ((long)blockIdx.x < xblocks) {
+      const long Lx = blockIdx.x;
+      const long bx = (Lx & 7) + 8 * (Lx / (8L * nch));
+      if (bx >= B) return;
+      const int ch = (int)((Lx >> 3) % nch);
+      double* vs = &As[0][0];
+      for (int k = tid; k < m; k += GNT) vs[k] = x.af[bx * m + k];
+      __syncthreads();
+      const double* Tb = A + bx * strideA;
+      const int i0 = ch * 32 + wave * 4;
+      double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int k = lane; k < m; k += 64) {
+        const double av = vs[k];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc[r] = fma(Tb[(long)min(i0 + r, m - 1) * m + k], av, sacc[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double sv = wave_sum(sacc[r]);
+        const int i = i0 + r;
+        if (lane == 0 && i < m) {
+          const double v = sv + (x.cvec ? x.cvec[bx * m + i] : 0.0);
+          x.aout[bx * m + i] = v;
+          if (x.atape) x.atape[bx * x.atape_stride + i] = v;
+        }
+      }
+      return;
+    }
+  }
   // XCD-aware mapping: workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD
   // has its own L2.  All tiles of one draw share the draw's A and B rows, so they must share an
   // XCD: linear id L -> draw = (L % 8) + 8 * (L / (8 * tiles)), tile = (L / 8) % tiles.
   const int tiles = tiles_n * tiles_m;
-  const long L = blockIdx.x;
+  const long L = PFIX ? blockIdx.x - 8L * ((m + 31) / 32) * ((B + 7) / 8) : blockIdx.x;  // (a multiple of 8: the XCD of a draw is unchanged)
   const long b = (L & 7) + 8 * (L / (8L * tiles));
   if (b >= B) return;
   const int tile = (int)((L >> 3) % tiles);
@@ -60,6 +130,23 @@ __global__ __launch_bounds__(GNT) void big_gemm_kernel(const double* __restrict_
   if (UPPER && r0 > c0 + GTN - 1) return;
   const double* Ab = A + b * strideA;
   const double* Bb = Bm + b * strideB;
+  double pf_kc = 0.0, pf_mc = 0.0;  // this thread's column of the B tile (tid % GTN) is the same in every chunk
+  if (PFIX) {
+    const int mp = (m + GK - 1) / GK * GK;
+    for (int k = tid; k < mp; k += GNT) {
+      vsK[k] = k < m ? x.kv[b * m + k] : 0.0;
+      vsM[k] = k < m ? x.mv[b * m + k] : 0.0;
+      vsKF[k] = k < m ? x.kfv[b * m + k] : 0.0;
+    }
+    const int gc = c0 + (tid % GTN);
+    if (gc < m) {
+      pf_kc = x.kv[b * m + gc];
+      pf_mc = x.mv[b * m + gc];
+    }
+    // (the first __syncthreads() of the loop below orders these stores before the first stage() that reads them?  No: stage() comes
+    // first -- hence this one)
+    __syncthreads();
+  }
 
   double4_t acc[GTI][GTJ];
 #pragma unroll
@@ -92,7 +179,7 @@ __global__ __launch_bounds__(GNT) void big_gemm_kernel(const double* __restrict_
       }
     }
   };
-  auto stage = [&]() {
+  auto stage = [&](int k0) {
 #pragma unroll
     for (int q = 0; q < GPA; ++q) {
       const int e = tid + GNT * q;
@@ -107,6 +194,13 @@ __global__ __launch_bounds__(GNT) void big_gemm_kernel(const double* __restrict_
         Bs[kk][cc] = rb[q];
       } else {
         const int kk = e / GTN, cc = e - kk * GTN;
+        if (PFIX) {
+          double sv = rb[q];
+          sv -= vsK[k0 + kk] * pf_mc;
+          sv -= vsM[k0 + kk] * pf_kc;
+          sv += vsKF[k0 + kk] * pf_kc;
+          rb[q] = sv;
+        }
         Bs[kk][cc] = rb[q];
       }
     }
@@ -114,7 +208,7 @@ __global__ __launch_bounds__(GNT) void big_gemm_kernel(const double* __restrict_
 
   fetch(0);
   for (int k0 = 0; k0 < m; k0 += GK) {
-    stage();
+    stage(k0);
     __syncthreads();
     if (k0 + GK < m) fetch(k0 + GK);  // in flight during the MFMAs below
 #pragma unroll
@@ -132,9 +226,76 @@ __global__ __launch_bounds__(GNT) void big_gemm_kernel(const double* __restrict_
     }
     __syncthreads();
   }
+  // (tried first: a_hat = T a_f as one more COLUMN of the B operand of this product.  A conditional load inside the fetch splits its
+  // batch of loads -- 337 against 274 us per launch at C5 -- and as a separate instantiation of the loop for the one tile column that
+  // carries the vector still 314: the launch lasts as long as its slowest workgroups)
   // ---- epilogue: D[row = (l>>4) + 4*reg][col = l&15] ---------------------------------------------
   double* Cb = Cm + b * strideC;
   const double* Eb = ADD_E ? E + b * strideE : nullptr;
+  if (ADD_E) {
+#pragma unroll
+    for (int i = 0; i < GTI; ++i)
+#pragma unroll
+      for (int j = 0; j < GTJ; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int gr = r0 + wr * (GTM / GWR) + i * 16 + lk + 4 * rg;
+          const int gc = c0 + wc * (GTN / GWC) + j * 16 + li;
+          if (gr < m && gc < m && !(MIRROR && gr > gc)) acc[i][j][rg] += Eb[(long)gr * m + gc];
+        }
+  }
+  if (MIRROR) {
+    if (x.mrow) {  // (uniform over the launch)
+      const double* zb = x.zv + b * m;
+      double* rowbuf = &As[0][0];            // [GWC][GTM]   (the loop above ended on a barrier: As is free)
+      double* colbuf = rowbuf + GWC * GTM;   // [GWR][GTN]
+      double zc[GTJ], csum[GTJ];
+#pragma unroll
+      for (int j = 0; j < GTJ; ++j) {
+        const int gc = c0 + wc * (GTN / GWC) + j * 16 + li;
+        zc[j] = gc < m ? zb[gc] : 0.0;
+        csum[j] = 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < GTI; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int lr = wr * (GTM / GWR) + i * 16 + lk + 4 * rg, gr = r0 + lr;
+          const double zr = gr < m ? zb[gr] : 0.0;
+          double rs = 0.0;
+#pragma unroll
+          for (int j = 0; j < GTJ; ++j) {
+            const int gc = c0 + wc * (GTN / GWC) + j * 16 + li;
+            const double v = (gr < m && gc < m && gr <= gc) ? acc[i][j][rg] : 0.0;
+            rs = fma(v, zc[j], rs);
+            if (gr != gc) csum[j] = fma(v, zr, csum[j]);
+          }
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) rs += __shfl_xor(rs, o, 64);
+          if (li == 0) rowbuf[wc * GTM + lr] = rs;
+        }
+#pragma unroll
+      for (int j = 0; j < GTJ; ++j) {
+        double cs = csum[j];
+        cs += __shfl_xor(cs, 16, 64);
+        cs += __shfl_xor(cs, 32, 64);
+        if (lk == 0) colbuf[wr * GTN + wc * (GTN / GWC) + j * 16 + li] = cs;
+      }
+      __syncthreads();
+      if (tid < GTM) {
+        double sv = 0.0;
+#pragma unroll
+        for (int w = 0; w < GWC; ++w) sv += rowbuf[w * GTM + tid];
+        if (r0 + tid < m) x.mrow[(b * tiles_n + (tile % tiles_n)) * m + r0 + tid] = sv;
+      } else if (tid < GTM + GTN) {
+        const int cc = tid - GTM;
+        double sv = 0.0;
+#pragma unroll
+        for (int w = 0; w < GWR; ++w) sv += colbuf[w * GTN + cc];
+        if (c0 + cc < m) x.mcol[(b * tiles_m + (tile / tiles_n)) * m + c0 + cc] = sv;
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < GTI; ++i)
 #pragma unroll
@@ -144,9 +305,17 @@ __global__ __launch_bounds__(GNT) void big_gemm_kernel(const double* __restrict_
         int gr = r0 + wr * (GTM / GWR) + i * 16 + lk + 4 * rg;
         int gc = c0 + wc * (GTN / GWC) + j * 16 + li;
         if (gr < m && gc < m) {
-          double v = acc[i][j][rg];
-          if (ADD_E) v += Eb[(long)gr * m + gc];
+          if (MIRROR && gr > gc) continue;
+          const double v = acc[i][j][rg];
           Cb[(long)gr * m + gc] = v;
+          if (MIRROR) {
+            Cb[(long)gc * m + gr] = v;
+            if (x.ctape) {
+              double* tp = x.ctape + b * x.ctape_stride;
+              __builtin_nontemporal_store(v, tp + (long)gr * m + gc);
+              if (gr != gc) __builtin_nontemporal_store(v, tp + (long)gc * m + gr);
+            }
+          }
         }
       }
 }
@@ -181,12 +350,6 @@ __global__ __launch_bounds__(256) void big_init_kernel(const KfFwdArgs A, double
     A.logp[b] = 0.0;
     if (A.info) A.info[b] = 0;
   }
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
 }
 
 // one workgroup (256 threads) per draw; dynamic LDS: Z (p m), M (m p), K (m p), KF (m p), af (m),
@@ -434,9 +597,12 @@ __global__ __launch_bounds__(256) void big_mvec_kernel(const KfFwdArgs A, int t,
 }
 
 // per draw: v, F, chol, K, KF, a_f, ll, tapes of the filtered state, a_hat = T a_f + c
+// With mrow (p == 1, t >= 1): m = P z comes from the shares the previous step's S = W T' + R Q R' launch left behind
+// (big_gemm_kernel<.., MIRROR>), summed here in a fixed order and stored to M_out for the next launch.
 __global__ __launch_bounds__(256) void big_gain_kernel(const KfFwdArgs A, int t, const double* a_ws,
                                                        const double* M_ws, double* K_ws, double* KF_ws,
-                                                       double* af_ws) {
+                                                       double* af_ws, const double* mrow, const double* mcol,
+                                                       int tiles_n, int tiles_m, double* M_out) {
   extern __shared__ double sm[];
   const long b = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -459,9 +625,25 @@ __global__ __launch_bounds__(256) void big_gain_kernel(const KfFwdArgs A, int t,
   const bool exact_const = (A.flags & KF_FLAG_MVN_CONST_EXACT) != 0;
   const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;
   const double* yt = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n * p : 0L) + (long)t * p;
-  for (int e = tid; e < pm; e += 256) {
-    Zl[e] = A.Z[b * pm + e];
-    M[e] = M_ws[b * pm + e];
+  if (mrow) {  // p == 1
+    const double y0 = yt[0];
+    for (int e = tid; e < m; e += 256) {
+      Zl[e] = A.Z[b * m + e];
+      const int tr = e / GTM, tc = e / GTN;
+      double sv = 0.0;
+      for (int c = 0; c < tiles_n; ++c)   // the tiles of this row's tile row that are not wholly below the diagonal
+        if (tr * GTM <= c * GTN + GTN - 1) sv += mrow[(b * tiles_n + c) * m + e];
+      for (int r = 0; r < tiles_m; ++r)
+        if (r * GTM <= tc * GTN + GTN - 1) sv += mcol[(b * tiles_m + r) * m + e];
+      sv = (y0 != y0) ? 0.0 : sv;
+      M[e] = sv;
+      M_out[b * m + e] = sv;
+    }
+  } else {
+    for (int e = tid; e < pm; e += 256) {
+      Zl[e] = A.Z[b * pm + e];
+      M[e] = M_ws[b * pm + e];
+    }
   }
   for (int e = tid; e < pp; e += 256) Hl[e] = A.H[b * pp + e];
   for (int e = tid; e < m; e += 256) al[e] = a[e];
@@ -663,7 +845,8 @@ __global__ __launch_bounds__(256) void big_sym_kernel(const double* __restrict__
 
 size_t kf_forward_big_workspace_bytes(long B, int m, int p) {
   size_t mm = (size_t)m * m;
-  return sizeof(double) * ((size_t)B * (4 * mm + 2 * m + 3 * (size_t)m * p) + 64);
+  const size_t tiles = (size_t)((m + GTM - 1) / GTM + (m + GTN - 1) / GTN);  // shares of m = P z per tile row / tile column
+  return sizeof(double) * ((size_t)B * (4 * mm + 2 * m + 3 * (size_t)m * p + tiles * m) + 64);
 }
 
 int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
@@ -715,28 +898,56 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
     KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(big_pf_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pf));
   }
+  // KF_BIG_FUSE=0 in the environment: the separate a_hat / mirror kernels of round 2 (A/B measurements)
+  const char* fe = getenv("KF_BIG_FUSE");
+  const bool fuse = !(fe && fe[0] == '0');
+  // P_f formed on the way into LDS instead of by its own pass: scalar observation, m <= 1024, the filtered covariance tape not requested
+  const bool pfix = fuse && !fused_update && p == 1 && m <= BIG_PFIX_M && !a.filt_P;
+  const BigGemmExtra x0 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0L, nullptr, 0L, nullptr, nullptr, nullptr};
+  double* mrow_ws = af_ws + a.B * (size_t)m;             // [B][tgn][m]
+  double* mcol_ws = mrow_ws + a.B * (size_t)tgn * m;     // [B][tgm][m]
   for (int t = 0; t < a.T; ++t) {
     if (fused_update) {
       hipLaunchKernelGGL(big_update_kernel, dim3((unsigned)a.B), dim3(256), lds_upd, stream, a, t, a_ws,
                          P_ws, Pf_ws);
     } else {
-      hipLaunchKernelGGL(big_mvec_kernel, dim3((m + MV_ROWS - 1) / MV_ROWS, (unsigned)a.B), dim3(256), 0,
-                         stream, a, t, P_ws, M_ws);
+      const bool shares = pfix && t > 0;  // m = P z from the shares the previous step's second product left
+      if (!shares)
+        hipLaunchKernelGGL(big_mvec_kernel, dim3((m + MV_ROWS - 1) / MV_ROWS, (unsigned)a.B), dim3(256), 0,
+                           stream, a, t, P_ws, M_ws);
       hipLaunchKernelGGL(big_gain_kernel, dim3((unsigned)a.B), dim3(256), lds_gain, stream, a, t, a_ws,
-                         M_ws, K_ws, KF_ws, af_ws);
-      hipLaunchKernelGGL(big_apred_kernel, dim3((m + MV_ROWS - 1) / MV_ROWS, (unsigned)a.B), dim3(256), 0,
-                         stream, a, t, af_ws, a_ws);
-      hipLaunchKernelGGL(big_pf_kernel, dim3((m + PF_ROWS - 1) / PF_ROWS, (unsigned)a.B), dim3(256), lds_pf,
-                         stream, a, t, P_ws, M_ws, K_ws, KF_ws, Pf_ws);
+                         M_ws, K_ws, KF_ws, af_ws, shares ? mrow_ws : nullptr, shares ? mcol_ws : nullptr, tgn, tgm, M_ws);
+      if (!pfix) {
+        hipLaunchKernelGGL(big_apred_kernel, dim3((m + MV_ROWS - 1) / MV_ROWS, (unsigned)a.B), dim3(256), 0,
+                           stream, a, t, af_ws, a_ws);
+        hipLaunchKernelGGL(big_pf_kernel, dim3((m + PF_ROWS - 1) / PF_ROWS, (unsigned)a.B), dim3(256), lds_pf,
+                           stream, a, t, P_ws, M_ws, K_ws, KF_ws, Pf_ws);
+      }
     }
     // 1-D grid: 8 * tiles * ceil(B / 8) workgroups (see the XCD mapping in the kernel)
     const unsigned ggrid = (unsigned)(8L * tgn * tgm * ((a.B + 7) / 8));
-    hipLaunchKernelGGL((big_gemm_kernel<false, false>), dim3(ggrid), dim3(GNT), 0, stream,
-                       a.Tm, (long)mm, Pf_ws, (long)mm, nullptr, 0L, W_ws, (long)mm, m, a.B, tgn, tgm);
-    hipLaunchKernelGGL((big_gemm_kernel<true, true, true>), dim3(ggrid), dim3(GNT), 0, stream,
-                       W_ws, (long)mm, a.Tm, (long)mm, RQR_ws, (long)mm, Pf_ws, (long)mm, m, a.B, tgn, tgm);
-    hipLaunchKernelGGL(big_sym_kernel, dim3(ts, ts, (unsigned)a.B), dim3(256), 0, stream, Pf_ws, P_ws,
-                       a.pred_P ? a.pred_P + (size_t)(t + 1) * mm : nullptr, (long)(a.T + 1) * (long)mm, m);
+    if (pfix) {  // W = T (P - k m' - m k' + (k f) k'), and a_hat = T a_f + c by the workgroups ahead of the tiles
+      const BigGemmExtra x1 = {K_ws, M_ws, KF_ws, af_ws, a.c, a_ws, a.pred_a ? a.pred_a + (size_t)(t + 1) * m : nullptr,
+                               (long)(a.T + 1) * m, nullptr, 0L, nullptr, nullptr, nullptr};
+      const unsigned xgrid = (unsigned)(8L * ((m + 31) / 32) * ((a.B + 7) / 8));
+      hipLaunchKernelGGL((big_gemm_kernel<false, false, false, true, false>), dim3(ggrid + xgrid), dim3(GNT), 0, stream,
+                         a.Tm, (long)mm, P_ws, (long)mm, nullptr, 0L, W_ws, (long)mm, m, a.B, tgn, tgm, x1);
+    } else {
+      hipLaunchKernelGGL((big_gemm_kernel<false, false>), dim3(ggrid), dim3(GNT), 0, stream,
+                         a.Tm, (long)mm, Pf_ws, (long)mm, nullptr, 0L, W_ws, (long)mm, m, a.B, tgn, tgm, x0);
+    }
+    if (fuse) {
+      const BigGemmExtra x2 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0L,
+                               a.pred_P ? a.pred_P + (size_t)(t + 1) * mm : nullptr, (long)(a.T + 1) * (long)mm,
+                               pfix ? a.Z : nullptr, pfix ? mrow_ws : nullptr, pfix ? mcol_ws : nullptr};
+      hipLaunchKernelGGL((big_gemm_kernel<true, true, true, false, true>), dim3(ggrid), dim3(GNT), 0, stream,
+                         W_ws, (long)mm, a.Tm, (long)mm, RQR_ws, (long)mm, P_ws, (long)mm, m, a.B, tgn, tgm, x2);
+    } else {
+      hipLaunchKernelGGL((big_gemm_kernel<true, true, true>), dim3(ggrid), dim3(GNT), 0, stream,
+                         W_ws, (long)mm, a.Tm, (long)mm, RQR_ws, (long)mm, Pf_ws, (long)mm, m, a.B, tgn, tgm, x0);
+      hipLaunchKernelGGL(big_sym_kernel, dim3(ts, ts, (unsigned)a.B), dim3(256), 0, stream, Pf_ws, P_ws,
+                         a.pred_P ? a.pred_P + (size_t)(t + 1) * mm : nullptr, (long)(a.T + 1) * (long)mm, m);
+    }
   }
   KF_HIP_CHECK(h, hipGetLastError());
   return KF_OK;

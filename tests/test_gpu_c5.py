@@ -60,6 +60,39 @@ def test_workspace_forward_over_300_steps(eng, case):
 
 
 @pytest.mark.parametrize("case", sorted(LONG))
+@pytest.mark.parametrize("predicted", [True, False])
+def test_workspace_forward_fused_steps(eng, case, predicted, monkeypatch):
+    """Without the filtered covariance tape (p = 1) a step is three launches: the gain kernel (m = P z summed from the shares the
+    previous step's second product left), W = T P_f with P_f formed on the way into LDS and a_hat = T a_f + c by the workgroups
+    ahead of the tiles, S = W T' + R Q R' mirrored in its epilogue (kf_forward_big.hip, PFIX / MIRROR).  Against the oracle, and
+    against the separate kernels (KF_BIG_FUSE=0)."""
+    w = LONG[case]()
+    y = w["y"].copy()
+    y[[0, 7, 150, 299]] = np.nan
+    # 11 draws: the XCD mapping of the workgroups with a ragged last group of eight
+    rng = np.random.default_rng(5)
+    big = {k: np.concatenate([w[k]] * 6, axis=0)[:11].copy() for k in KEYS}
+    big["Z"] = big["Z"] + 0.05 * rng.standard_normal(big["Z"].shape)   # a dense Z: every tile's share of P z counts
+    big["H"] = big["H"] * (1.0 + rng.random((11, 1, 1)))
+    args = (y,) + tuple(big[k] for k in KEYS)
+    ref = kn.kalman_filter(*args, mvn_const="exact")
+    kw = dict(mvn_const="exact", store_filtered=False, store_predicted=predicted)
+    res = eng.forward(*args, **kw)
+    assert not res.info.cpu().numpy().any()
+    tol = 1e-8 * max(1.0, np.abs(ref["logp"]).max() / 1e4)
+    assert np.max(np.abs(res.logp.cpu().numpy() - ref["logp"])) < tol
+    assert_allclose(res.ll_obs.cpu().numpy(), ref["ll_obs"], rtol=1e-9, atol=1e-9)
+    if predicted:
+        assert_allclose(res.predicted_states.cpu().numpy(), ref["predicted_states"], rtol=1e-9, atol=1e-9)
+        assert_allclose(res.predicted_covs.cpu().numpy(), ref["predicted_covs"], rtol=1e-9, atol=1e-9)
+        pc = res.predicted_covs[:, 1:]
+        assert bool((pc == pc.transpose(-1, -2)).all())
+    monkeypatch.setenv("KF_BIG_FUSE", "0")
+    sep = eng.forward(*args, **kw)
+    assert_allclose(res.logp.cpu().numpy(), sep.logp.cpu().numpy(), rtol=1e-11, atol=0.0)
+
+
+@pytest.mark.parametrize("case", sorted(LONG))
 def test_workspace_smoother_over_300_steps(eng, case):
     w = LONG[case]()
     flt = kn.kalman_filter(*_args(w))
@@ -121,7 +154,8 @@ def test_c5_full_length_one_gpu_share(eng):
         sl = slice(lo, lo + 64)
         part = [dev[0]] + [x[sl] for x in dev[1:]]
         flt = eng.forward(*part, mvn_const="exact", store_ll_obs=False, store_predicted=False)
-        assert torch.equal(flt.logp, res.logp[sl])
+        # (with the filtered covariances requested P_f is formed; without, W = T P_f comes from T P and rank corrections: last-bit differences)
+        assert torch.allclose(flt.logp, res.logp[sl], rtol=1e-12, atol=0.0)
         sa, sP = eng.smooth(part[3], part[5], part[7], flt.filtered_states, flt.filtered_covs)
         torch.cuda.synchronize()
         assert torch.equal(sa[:, -1], flt.filtered_states[:, -1]) and torch.equal(sP[:, -1], flt.filtered_covs[:, -1])
