@@ -805,6 +805,11 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
   a.Tm = T; a.R = R; a.Q = Q; a.filt_a = filt_a; a.filt_P = filt_P;
   a.smooth_a = smooth_a; a.smooth_P = smooth_P;
   a.only_flagged = nullptr;
+  a.exact = (dims->flags & KF_FLAG_EXACT_RECURSION) ? 1 : 0;
+  {
+    const char* e = getenv("KF_SMOOTHER_STEADY");  // =0: as KF_FLAG_EXACT_RECURSION (A/B measurements)
+    if (e && e[0] == '0') a.exact = 1;
+  }
   if (a.flags) {
     a.flags |= dims->flags & KF_FLAG_TV_SMOOTHER_REFERENCE_PAIRING;
     // time-varying T / R / Q (kalman_smoother.py:17-54,62-77): the LDS-resident kernel reloads the slices per step

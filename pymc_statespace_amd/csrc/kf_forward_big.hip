@@ -45,7 +45,8 @@ constexpr int GPA = GTM * GK / GNT, GPB = GTN * GK / GNT;  // staged elements pe
 // PFIX (p == 1, !TRANS_B, m <= 1024): the B operand is P and becomes P_f = P - k m' - m k' + (k f) k' ON ITS WAY INTO LDS (the three
 //   vectors x.kv, x.mv, x.kfv sit in LDS; a thread stages one column and wave-uniform rows, so the fix is three LDS broadcasts and three
 //   FMAs per staged element, in big_pf_kernel's order of operations): W = T P_f without big_pf_kernel's pass over P (valid when the
-//   filtered covariance tape is not requested).  The same launch carries 8 * ceil(B / 8) * ceil(m / 32) more workgroups AHEAD of the tiles
+//   filtered covariance tape is not requested).  Measured at C5 (128 x 730): the fix costs 15 us per launch, the a_hat workgroups 17
+//   (whether 32 or 64 rows each), against 59 + 44 us for the two kernels they replace.  The same launch carries 8 * ceil(B / 8) * ceil(m / 64) more workgroups AHEAD of the tiles
 //   (behind them they were a 40 us tail) that compute a_hat = T a_f + c (big_apred_kernel's arithmetic) while the tiles keep the MFMA pipes busy;
 // MIRROR (with UPPER): an element (r, c) with r <= c is stored at (r, c) AND (c, r) of C (and of x.ctape), elements below the
 //   diagonal are dropped -- big_sym_kernel's mirror of the upper triangle happens in the epilogue of S = W T' + R Q R'.
@@ -74,6 +75,7 @@ struct BigGemmExtra {
   double* mcol;         // [B][tiles_m][m]  the mirrored elements' share, over the rows of one tile row
 };
 constexpr int BIG_PFIX_M = 1024;
+constexpr int BIG_AH_ROWS = 64;   // rows of a_hat = T a_f + c per workgroup ahead of the tiles
 template <bool TRANS_B, bool ADD_E, bool UPPER = false, bool PFIX = false, bool MIRROR = false>
 __global__ __launch_bounds__(GNT) __attribute__((amdgpu_waves_per_eu(4))) void big_gemm_kernel(const double* __restrict__ A, long strideA,
                                                        const double* __restrict__ Bm, long strideB,
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(GNT) __attribute__((amdgpu_waves_per_eu(4))) void b
   const int wave = tid >> 6, lane = tid & 63;
   const int wr = wave / GWC, wc = wave % GWC;
   if (PFIX) {  // the workgroups ahead of the tiles: a_hat = T a_f + c, four rows per wavefront at a time
-    const int nch = (m + 31) / 32;
+    const int nch = (m + BIG_AH_ROWS - 1) / BIG_AH_ROWS;
     const long xblocks = 8L * nch * ((B + 7) / 8);
     if ((long)blockIdx.x < xblocks) {
       const long Lx = blockIdx.x;
@@ -98,15 +100,18 @@ __global__ __launch_bounds__(GNT) __attribute__((amdgpu_waves_per_eu(4))) void b
       for (int k = tid; k < m; k += GNT) vs[k] = x.af[bx * m + k];
       __syncthreads();
       const double* Tb = A + bx * strideA;
-      const int i0 = ch * 32 + wave * 4;
-      double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+      constexpr int RW = BIG_AH_ROWS / 8;  // rows per wavefront, all in flight together
+      const int i0 = ch * BIG_AH_ROWS + wave * RW;
+      double sacc[RW];
+#pragma unroll
+      for (int r = 0; r < RW; ++r) sacc[r] = 0.0;
       for (int k = lane; k < m; k += 64) {
         const double av = vs[k];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sacc[r] = fma(Tb[(long)min(i0 + r, m - 1) * m + k], av, sacc[r]);
+        for (int r = 0; r < RW; ++r) sacc[r] = fma(Tb[(long)min(i0 + r, m - 1) * m + k], av, sacc[r]);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < RW; ++r) {
         const double sv = wave_sum(sacc[r]);
         const int i = i0 + r;
         if (lane == 0 && i < m) {
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(GNT) __attribute__((amdgpu_waves_per_eu(4))) void b
   // has its own L2.  All tiles of one draw share the draw's A and B rows, so they must share an
   // XCD: linear id L -> draw = (L % 8) + 8 * (L / (8 * tiles)), tile = (L / 8) % tiles.
   const int tiles = tiles_n * tiles_m;
-  const long L = PFIX ? blockIdx.x - 8L * ((m + 31) / 32) * ((B + 7) / 8) : blockIdx.x;  // (a multiple of 8: the XCD of a draw is unchanged)
+  const long L = PFIX ? blockIdx.x - 8L * ((m + BIG_AH_ROWS - 1) / BIG_AH_ROWS) * ((B + 7) / 8) : blockIdx.x;  // (a multiple of 8: the XCD of a draw is unchanged)
   const long b = (L & 7) + 8 * (L / (8L * tiles));
   if (b >= B) return;
   const int tile = (int)((L >> 3) % tiles);
@@ -929,7 +934,7 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
     if (pfix) {  // W = T (P - k m' - m k' + (k f) k'), and a_hat = T a_f + c by the workgroups ahead of the tiles
       const BigGemmExtra x1 = {K_ws, M_ws, KF_ws, af_ws, a.c, a_ws, a.pred_a ? a.pred_a + (size_t)(t + 1) * m : nullptr,
                                (long)(a.T + 1) * m, nullptr, 0L, nullptr, nullptr, nullptr};
-      const unsigned xgrid = (unsigned)(8L * ((m + 31) / 32) * ((a.B + 7) / 8));
+      const unsigned xgrid = (unsigned)(8L * ((m + BIG_AH_ROWS - 1) / BIG_AH_ROWS) * ((a.B + 7) / 8));
       hipLaunchKernelGGL((big_gemm_kernel<false, false, false, true, false>), dim3(ggrid + xgrid), dim3(GNT), 0, stream,
                          a.Tm, (long)mm, P_ws, (long)mm, nullptr, 0L, W_ws, (long)mm, m, a.B, tgn, tgm, x1);
     } else {

@@ -137,6 +137,7 @@ struct KfSmoothArgs {
   double* smooth_a;
   double* smooth_P;
   const int32_t* only_flagged;  // LDS kernel: when set, only draws with a non-zero flag are processed
+  int exact;                    // KF_FLAG_EXACT_RECURSION: every step in full (kf_smoother_b4.hip reuses a converged filter's gain otherwise)
 };
 
 // per-draw LDS footprints (in doubles) -- shared by host launchers and kernels

@@ -369,11 +369,13 @@ class KalmanEngine:
         return logp, info, g
 
     # --------------------------------------------------------------- smoother
-    def smooth(self, T, R, Q, filtered_states, filtered_covs, time_varying=(), pairing="filter"):
+    def smooth(self, T, R, Q, filtered_states, filtered_covs, time_varying=(), pairing="filter", exact_recursion=False):
         """kf_smoother -> (smoothed_states (B,n,m), smoothed_covs (B,n,m,m)).  Names in ``time_varying`` (subset of
         T, R, Q) carry a time axis after the draw axis, (B,n,.,.): the step that smooths t uses slice t (``pairing="filter"``,
         the forward filter's pairing) or slice t + 1 (``pairing="reference"``: what the reference's own scan hands its step,
-        kalman_smoother.py:62-77 -- for parity with a model ported from upstream)."""
+        kalman_smoother.py:62-77 -- for parity with a model ported from upstream).  ``exact_recursion=True``
+        (KF_FLAG_EXACT_RECURSION): the prediction covariance is inverted at every step, also where the filtered covariance on the
+        tape has stopped moving (5 <= m <= 15: kf_smoother_b4.hip reuses the last step's gain there by default)."""
         if pairing not in ("filter", "reference"):
             raise ValueError("pairing must be 'filter' or 'reference'")
         tv = set(time_varying)
@@ -395,6 +397,8 @@ class KalmanEngine:
             dims.flags |= _lib.KF_FLAG_TV[name]
         if tv and pairing == "reference":
             dims.flags |= _lib.KF_FLAG_TV_SMOOTHER_REFERENCE_PAIRING
+        if exact_recursion:
+            dims.flags |= _lib.KF_FLAG_EXACT_RECURSION
         sa = torch.empty_like(fa)
         sP = torch.empty_like(fP)
         ws, ws_bytes = self._workspace(dims, _lib.KF_WS_SMOOTHER)  # large m only (kf_smoother_big.hip)

@@ -339,3 +339,30 @@ def test_split_pipeline_and_steady_adjoint_replay_from_a_hip_graph(eng):
     assert torch.equal(vg_c[0], vg_e[0])
     for k in vg_e[2]:
         assert torch.equal(vg_c[2][k], vg_e[2][k]), k
+
+
+@pytest.mark.parametrize("m", [5, 8, 10, 12, 15])
+def test_block_smoother_reuses_the_gain_of_a_converged_filter(eng, m):
+    """kf_smoother_b4.hip: where the filtered covariance on the tape has stopped moving (one-step change <= 1e-15 x its largest entry)
+    the step reuses the last X_e = P_hat^-1 T P_f (at most 32 steps in a row); a missing stretch in the middle of the series moves the
+    covariance again and the full path takes over.  Against the pinv oracle (kalman_smoother.py:56-104) and against every step in full
+    (KF_FLAG_EXACT_RECURSION), on the tapes of both forward modes."""
+    import torch
+
+    w = W.random_dense(7, 600, 1, m, m, seed=260 + m)
+    y = w["y"].copy()
+    y[300:309] = np.nan
+    y[450] = np.nan
+    for exact_fwd in (True, False):
+        res = eng.forward(y, *[w[k] for k in KEYS], exact_recursion=exact_fwd, store_ll_obs=False, store_predicted=False)
+        fa, fP = res.filtered_states, res.filtered_covs
+        # the tape does converge: otherwise this test exercises nothing
+        d = (fP[:, 590] - fP[:, 589]).abs().flatten(1).max(1).values / fP[:, 590].abs().flatten(1).max(1).values
+        assert int((d <= 1e-15).sum()) >= 4   # (a slow draw or two among the seven keep moving: the full path beside the reuse)
+        ra, rP = kn.kalman_smoother(w["T"], w["R"], w["Q"], fa.cpu().numpy(), fP.cpu().numpy())
+        sa, sP = eng.smooth(w["T"], w["R"], w["Q"], fa, fP)
+        ea, eP = eng.smooth(w["T"], w["R"], w["Q"], fa, fP, exact_recursion=True)
+        sc_a, sc_P = 1.0 + np.abs(ra).max(), 1.0 + np.abs(rP).max()
+        assert np.abs(sa.cpu().numpy() - ra).max() / sc_a < 1e-11 and np.abs(sP.cpu().numpy() - rP).max() / sc_P < 1e-11
+        assert float((sa - ea).abs().max()) / sc_a < 1e-12 and float((sP - eP).abs().max()) / sc_P < 1e-12
+        assert torch.equal(sa[:, -1], fa[:, -1]) and torch.equal(sP[:, -1], fP[:, -1])
