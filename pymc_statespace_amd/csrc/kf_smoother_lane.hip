@@ -167,6 +167,15 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lane_kernel(const KfSmoothA
 #pragma unroll
     for (int j = 0; j < M; ++j) Ps[i][j] = 0.0;
   }
+  // m <= 2: where the filtered covariance of EVERY draw of the wavefront has stopped moving (one-step change <= 1e-15 x the larger
+  // of its largest entry and P_hat's largest diagonal entry: C2's P_f goes to zero, P_hat to R Q R') the last X and P_hat are reused --
+  // no Cholesky, no Jacobi rotation -- at most 32 steps in a row (kf_smoother_b4.hip does the same per draw).  KF_FLAG_EXACT_RECURSION:
+  // never.
+  constexpr bool REUSE = M <= 2;
+  double Xk[REUSE ? M : 1][REUSE ? M : 1], Phk[REUSE ? M : 1][REUSE ? M : 1], Pfk[REUSE ? M : 1][REUSE ? M : 1];
+  double dk = 0.0;
+  bool have_k = false;
+  int reused = 0;
   for (int t0 = ((n - 1) / S) * S; t0 >= 0; t0 -= S) {
     const int cnt = (n - t0) < S ? (n - t0) : S;
     copy(std::true_type{}, A.filt_a, nullptr, smem + L::OFF_FA, L::W_A, std::integral_constant<int, M>{}, t0, cnt);
@@ -188,13 +197,49 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lane_kernel(const KfSmoothA
           for (int j = 0; j < M; ++j) Ps[i][j] = Pf[i][j];
         }
       } else {
-        double W[M][M], Ph[M][M], ah[M];
+        double W[M][M], Ph[M][M], ah[M], X[M][M];
 #pragma unroll
         for (int i = 0; i < M; ++i) {
           double sm = 0.0;
 #pragma unroll
           for (int k = 0; k < M; ++k) sm = fma(T[i][k], af[k], sm);
           ah[i] = sm;
+        }
+        bool reuse = false;
+        if constexpr (REUSE) {
+          if (have_k && !A.exact && reused < 32) {
+            double pmax = dk;
+            bool same = true;
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+              for (int j = 0; j < M; ++j) pmax = fmax(pmax, fabs(Pf[i][j]));
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+              for (int j = 0; j < M; ++j) same = same && (fabs(Pf[i][j] - Pfk[i][j]) <= 1e-15 * pmax);
+            reuse = __all(same || !live);
+          }
+#pragma unroll
+          for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j) Pfk[i][j] = Pf[i][j];
+        }
+        if (reuse) {
+          ++reused;
+          if constexpr (REUSE) {
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+              for (int j = 0; j < M; ++j) {
+                X[i][j] = Xk[i][j];
+                Ph[i][j] = Phk[i][j];
+              }
+          }
+        } else {
+        reused = 0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
 #pragma unroll
           for (int j = 0; j < M; ++j) {
             double w = 0.0;
@@ -237,7 +282,6 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lane_kernel(const KfSmoothA
           }
         }
         // X = P_hat^-1 W: L Y = W, L' X = Y (column by column of W)
-        double X[M][M];
         if (bad) {  // singular (or indefinite by rounding) P_hat: X = pinv(P_hat) W
           double Dm[M][M], Pi[M][M];
 #pragma unroll
@@ -272,6 +316,18 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lane_kernel(const KfSmoothA
             for (int k = i + 1; k < M; ++k) v = fma(-Lc[k][i], X[k][cidx], v);
             X[i][cidx] = v * il[i];
           }
+        }
+        }
+        if constexpr (REUSE) {
+          have_k = true;
+          dk = dmax;
+#pragma unroll
+          for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+              Xk[i][j] = X[i][j];
+              Phk[i][j] = Ph[i][j];
+            }
         }
         }
         // a_s = a_f + X' (a_s' - a_hat);  P_s = P_f + X' (P_s' - P_hat) X
