@@ -327,6 +327,14 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a_in, void* workspace, size
   // measured (MI355X, 4096 draws x 1000 steps): m = 17..40 took 25..670 ms on the LDS kernel
   if (kf_nb_ok(h, a.m, a.p, a.r, a.filter, a.flags)) return kf_launch_forward_mfma_nb(h, a, stream);
   if (kf_wg_ok(h, a.m, a.p, a.r, a.filter, a.flags)) return kf_launch_forward_mfma_wg(h, a, stream);
+  // 64 < m <= 96, scalar observation, no covariance tapes (the log-likelihood-only call): P stays in LDS, one workgroup per draw
+  // (kf_forward_wgl.hip; measured at 4096 x 1000, m = 80: ... against 0.83 s on the workspace path); KF_FORWARD_WGL=0 keeps the latter
+  if (h->forward_kernel == KF_KERNEL_AUTO && a.filter != KF_FILTER_UNIVARIATE &&
+      kf_forward_wgl_ok(a.m, a.p, a.flags, a.filt_P || a.pred_P) && workspace &&
+      workspace_bytes >= kf_forward_wgl_workspace_bytes(a.B, a.m)) {
+    const char* e = getenv("KF_FORWARD_WGL");
+    if (!(e && e[0] == '0')) return kf_launch_forward_wgl(h, a, workspace, workspace_bytes, stream);
+  }
   if (!kf_forward_lds_fits(a.m, a.p)) return kf_launch_forward_big(h, a, workspace, workspace_bytes, stream);
   // 48 < m <= ~60 still fits LDS, but one workgroup per CU at m^3 LDS reads per step: measured
   // (4096 draws x 1000 steps) 2.2 s at m = 49, 3.9 s at m = 60 against 0.62 s at m = 64 on the

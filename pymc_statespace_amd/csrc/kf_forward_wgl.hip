@@ -1,0 +1,381 @@
+// kf_forward_wgl.hip -- forward filter for 64 < k_states <= 96 with the covariance RESIDENT IN LDS: one workgroup (four wavefronts,
+// one per SIMD) per draw, running all T steps; scalar observation (p == 1), static matrices, no covariance tapes (log-likelihood,
+// per-step terms, filtered / predicted STATES only -- the log-likelihood-only call a sampler makes).
+//
+// Reference recursion (kalman_filter.py:255-284 update, :231-252 predict), as kf_forward_big.hip runs it for large m:
+//     m = P z     F = z' m + H     v = y - d - z' a     k = m / F     a_f = a + k v     logp_t = -(log 2 pi + v^2 / F) / 2 - log sqrt F
+//     P_f = P - k m' - m k' + (k F) k'        a <- T a_f + c        P <- T P_f T' + R Q R'
+// Why: the HBM-workspace path moves P, P_f / W between kernels through HBM / L2 -- ~300 KB per draw and step at m = 80, 1.2 TB for
+// 4096 draws x 1000 steps: bound by that traffic and by three launches per step at 0.83 s (scripts/r03/mid_m_bench.py).  Here P
+// (m = 96: 74.5 KB) and W = T P_f (another 74.5 KB) stay in the CU's 160 KB of LDS for the whole series, T (one draw per CU: 256
+// draws x 72 KB in the L2s) is the only operand read from outside, and nothing but the log-likelihood goes back.
+//
+// Products on v_mfma_f64_16x16x4_f64.  The m x m output is NT x NT tiles of 16 x 16 (NT = 5: m <= 80, NT = 6: m <= 96); wavefront
+// w owns tile row w and a share of tile rows 4 (and 5) -- 7 / 6 / 6 / 6 tiles at NT = 5, 9 each at NT = 6 (2 x 2 blocks of 3 x 3
+// would leave one wavefront 9 of NT = 5's 25).  The operand that comes from global memory (T: the rows of the left factor in
+// W = T P_f, the rows of the right factor's transpose in S = W T') is loaded FOUR CONSECUTIVE doubles per lane: the k index inside a
+// chunk of 16 is permuted -- lane group g = lane / 16 takes k = 4 g + s at sub-step s, the LDS operand follows -- so one chunk is one
+// 32-byte load per lane and tile row instead of four strided 8-byte ones; the next chunk's loads are in flight during this chunk's
+// MFMAs.  a_hat = T a_f rides along with W (the T fragments are in registers anyway).
+#include "kf_internal.h"
+#include "kf_tile.h"
+
+namespace {
+
+constexpr int WL_NT_THREADS = 256;
+
+template <int NT>
+struct WlLds {
+  static constexpr int MP = 16 * NT, LD = MP + 1;
+  static constexpr int OFF_P = 0, OFF_W = MP * LD, OFF_V = 2 * MP * LD;
+  // vectors: a, a_f, k, m, k F, z, c; then scalars
+  static constexpr int V_A = 0, V_AF = 1, V_K = 2, V_M = 3, V_KF = 4, V_Z = 5, V_C = 6, NVEC = 7;
+  static constexpr int OFF_S = OFF_V + NVEC * MP;
+  static constexpr int TOTAL = OFF_S + 16;
+};
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double wl_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int NT>
+__global__ __launch_bounds__(WL_NT_THREADS) void kf_fwd_wgl_kernel(const KfFwdArgs A, double* __restrict__ RQR_ws) {
+  using L = WlLds<NT>;
+  constexpr int MP = L::MP, LD = L::LD;
+  constexpr int NE = NT == 5 ? 2 : 3;   // extra tiles per wavefront beyond its own tile row (NT = 5: wavefront 0 has two, the rest one)
+  constexpr int NR = NT == 5 ? 2 : 3;   // tile rows a wavefront touches: its own, 4 (and 5)
+  extern __shared__ double sm[];
+  double* Pm = sm + L::OFF_P;
+  double* Wm = sm + L::OFF_W;
+  double* va = sm + L::OFF_V + L::V_A * MP;
+  double* vaf = sm + L::OFF_V + L::V_AF * MP;
+  double* vk = sm + L::OFF_V + L::V_K * MP;
+  double* vm = sm + L::OFF_V + L::V_M * MP;
+  double* vkf = sm + L::OFF_V + L::V_KF * MP;
+  double* vz = sm + L::OFF_V + L::V_Z * MP;
+  double* vc = sm + L::OFF_V + L::V_C * MP;
+  double* sc = sm + L::OFF_S;  // [0] v, [1] F, [2] 1 / sqrt F, [3] observed
+  const long b = blockIdx.x;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int m = A.m, n = A.T, r = A.r;
+  const long mm = (long)m * m;
+  const double* Tb = A.Tm + b * mm;
+  double* RQRb = RQR_ws + b * mm;
+  const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;
+  const double dq = A.d ? A.d[b] : 0.0;
+  const double Hq = A.H[b];
+  const double* yb = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n : 0L);
+
+  // ---- the tiles of this wavefront: slot c < NT = (w, c); extras e: tile number w + 4 e of rows 4.. in row-major order ----------------
+  int er[NE], ec[NE];
+  bool eon[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int idx = w + 4 * e;
+    eon[e] = idx < (NT - 4) * NT;
+    er[e] = eon[e] ? 4 + idx / NT : 4;
+    ec[e] = eon[e] ? idx % NT : 0;
+  }
+  // tile rows whose fragments this wavefront loads: its own, 4, (5); a_hat of tile row R is written by wavefront R (R < 4), 0 (R = 4), 1 (R = 5)
+  int rrow[NR];
+  rrow[0] = w;
+  rrow[1] = 4;
+  if (NR > 2) rrow[2] = 5;
+
+  // ---- setup: P0 (zero-padded), vectors, R Q R' into the workspace, slot 0 of the predicted-state tape -------------------------------
+  for (int e = tid; e < MP * MP; e += WL_NT_THREADS) {
+    const int i = e / MP, j = e - i * MP;
+    Pm[i * LD + j] = (i < m && j < m) ? A.P0[b * mm + (long)i * m + j] : 0.0;
+  }
+  for (int e = tid; e < MP; e += WL_NT_THREADS) {
+    const bool on = e < m;
+    const double a0 = on ? A.a0[b * m + e] : 0.0;
+    va[e] = a0;
+    vz[e] = on ? A.Z[b * m + e] : 0.0;
+    vc[e] = (on && A.c) ? A.c[b * m + e] : 0.0;
+    vaf[e] = vk[e] = vm[e] = vkf[e] = 0.0;
+    if (on && A.pred_a) A.pred_a[b * (long)(n + 1) * m + e] = a0;
+  }
+  {
+    const double* gR = A.R + b * (long)m * r;
+    const double* gQ = A.Q + b * (long)r * r;
+    for (long e = tid; e < mm; e += WL_NT_THREADS) {
+      const int i = (int)(e / m), j = (int)(e - (long)i * m);
+      double s = 0.0;
+      for (int l = 0; l < r; ++l) {
+        double rq = 0.0;
+        for (int k = 0; k < r; ++k) rq += gR[i * r + k] * gQ[k * r + l];
+        s += rq * gR[j * r + l];
+      }
+      RQRb[e] = s;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  double logp = 0.0;
+  int info = 0;
+  const int KC = (m + 15) / 16;  // chunks of 16 along k
+
+  for (int t = 0; t < n; ++t) {
+    // ---- (a) m = P z: thread (row, half) sums 8 NT columns; the halves meet in the scratch (W is free here) ----------------------------
+    {
+      const int row = tid % 128, half = tid / 128;
+      if (row < MP) {
+        const double* pr = Pm + row * LD + half * (MP / 2);
+        const double* zz = vz + half * (MP / 2);
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 4
+        for (int c = 0; c < MP / 2; c += 2) {
+          s0 = fma(pr[c], zz[c], s0);
+          s1 = fma(pr[c + 1], zz[c + 1], s1);
+        }
+        Wm[half * MP + row] = s0 + s1;
+      }
+    }
+    __syncthreads();
+    // ---- (b) wavefront 0: F, v, the log-likelihood term ----------------------------------------------------------------------------------
+    if (w == 0) {
+      const double yv = yb[t];
+      const bool obs = !(yv != yv);
+      double pf = 0.0, pv = 0.0;
+      for (int e = lane; e < MP; e += 64) {
+        const double mv = obs ? Wm[e] + Wm[MP + e] : 0.0;
+        vm[e] = mv;
+        pf = fma(vz[e], mv, pf);
+        pv = fma(vz[e], va[e], pv);
+      }
+      pf = wl_wave_sum(pf);
+      pv = wl_wave_sum(pv);
+      if (lane == 0) {
+        const double F = obs ? pf + Hq : 1.0;
+        const double v = obs ? (yv + dsign * dq) - pv : 0.0;
+        const double dj = sqrt(F);
+        const double wv = v / dj;
+        const double ll = obs ? (-0.5 * (KF_LOG_2PI + wv * wv) - log(dj)) : 0.0;
+        logp += ll;
+        if (A.ll_obs) A.ll_obs[b * (long)n + t] = ll;
+        if (!(F > 0.0) && info == 0) info = ((t + 1) << 8) | 1;
+        sc[0] = v;
+        sc[1] = F;
+        sc[2] = dj;
+        sc[3] = obs ? 1.0 : 0.0;
+      }
+    }
+    __syncthreads();
+    // ---- (c) k = m / F (two divisions by sqrt F, as the Cholesky solve of the general path), k F, a_f ------------------------------------
+    const bool obs = sc[3] != 0.0;
+    {
+      const double v = sc[0], F = sc[1], dj = sc[2];
+      for (int e = tid; e < MP; e += WL_NT_THREADS) {
+        const double kk = (vm[e] / dj) / dj;
+        vk[e] = kk;
+        vkf[e] = kk * F;
+        const double af = va[e] + kk * v;
+        vaf[e] = af;
+        if (e < m && A.filt_a) A.filt_a[(b * (long)n + t) * m + e] = af;
+      }
+    }
+    __syncthreads();
+    // ---- (d) P <- P_f = P - k m' - m k' + (k F) k' in place (a missing observation: k = 0, nothing to do) -------------------------------
+    if (obs) {
+      for (int e = tid; e < MP * MP; e += WL_NT_THREADS) {
+        const int i = e / MP, j = e - i * MP;
+        double s = Pm[i * LD + j];
+        s -= vk[i] * vm[j];
+        s -= vm[i] * vk[j];
+        s += vkf[i] * vk[j];
+        Pm[i * LD + j] = s;
+      }
+      __syncthreads();
+    }
+    // ---- (e) W = T P_f, a_hat = T a_f + c -----------------------------------------------------------------------------------------------
+    double4_t acc[NT + NE];
+#pragma unroll
+    for (int sidx = 0; sidx < NT + NE; ++sidx) acc[sidx] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    {
+      // T fragments of the tile rows rrow[.]: lane (li, lk) holds T[16 R + li][k0 + 4 lk + 0..3]
+      double tf[NR][4], tn[NR][4];
+      auto load_t = [&](double (&dst)[NR][4], int k0) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+          const int row = 16 * rrow[q] + li;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int kk = k0 + 4 * lk + s;
+            dst[q][s] = (row < m && kk < m) ? Tb[(long)row * m + kk] : 0.0;
+          }
+        }
+      };
+      double ah[NR];
+#pragma unroll
+      for (int q = 0; q < NR; ++q) ah[q] = 0.0;
+      load_t(tf, 0);
+      for (int kc = 0; kc < KC; ++kc) {
+        const int k0 = 16 * kc;
+        if (kc + 1 < KC) load_t(tn, k0 + 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int kk = k0 + 4 * lk + s;
+          const double* prow = Pm + kk * LD + li;
+          double bf[NT];
+#pragma unroll
+          for (int c = 0; c < NT; ++c) bf[c] = prow[16 * c];
+          const double afk = vaf[kk];
+#pragma unroll
+          for (int q = 0; q < NR; ++q) ah[q] = fma(tf[q][s], afk, ah[q]);
+#pragma unroll
+          for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[0][s], bf[c], acc[c], 0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            if (eon[e]) {
+              const double be = prow[16 * ec[e]];
+              const double ae = (NR > 2 && er[e] == 5) ? tf[NR - 1][s] : tf[1][s];
+              acc[NT + e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be, acc[NT + e], 0, 0, 0);
+            }
+          }
+        }
+        if (kc + 1 < KC) {
+#pragma unroll
+          for (int q = 0; q < NR; ++q)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) tf[q][s] = tn[q][s];
+        }
+      }
+      // W tiles -> LDS: D[row = lk + 4 rg][col = li]
+#pragma unroll
+      for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) Wm[(16 * w + lk + 4 * rg) * LD + 16 * c + li] = acc[c][rg];
+#pragma unroll
+      for (int e = 0; e < NE; ++e)
+        if (eon[e]) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) Wm[(16 * er[e] + lk + 4 * rg) * LD + 16 * ec[e] + li] = acc[NT + e][rg];
+        }
+      // a_hat: sum over the four lane groups; written by the owner of the tile row
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+        const double sv = col_allsum(ah[q]);
+        const int R = rrow[q];
+        const bool owner = q == 0 ? true : (R == 4 ? w == 0 : w == 1);
+        const int row = 16 * R + li;
+        if (owner && lk == 0 && R < NT) {
+          const double an = sv + vc[row];
+          va[row] = row < m ? an : 0.0;
+          if (row < m && A.pred_a) A.pred_a[(b * (long)(n + 1) + t + 1) * m + row] = an;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- (f) P <- W T' + R Q R' (the accumulators start from R Q R': its loads overlap the first chunk's) -------------------------------
+    auto rqr_tile = [&](int R, int C) {
+      double4_t v;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int row = 16 * R + lk + 4 * rg, col = 16 * C + li;
+        v[rg] = (row < m && col < m) ? RQRb[(long)row * m + col] : 0.0;
+      }
+      return v;
+    };
+#pragma unroll
+    for (int c = 0; c < NT; ++c) acc[c] = rqr_tile(w, c);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) acc[NT + e] = eon[e] ? rqr_tile(er[e], ec[e]) : (double4_t){0.0, 0.0, 0.0, 0.0};
+    {
+      // right factor T': lane (lk, li) holds T[16 C + li][k0 + 4 lk + 0..3] for every tile column C (the extras' columns among them)
+      double tf[NT][4], tn[NT][4];
+      auto load_t = [&](double (&dst)[NT][4], int k0) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+          const int row = 16 * c + li;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int kk = k0 + 4 * lk + s;
+            dst[c][s] = (row < m && kk < m) ? Tb[(long)row * m + kk] : 0.0;
+          }
+        }
+      };
+      load_t(tf, 0);
+      for (int kc = 0; kc < KC; ++kc) {
+        const int k0 = 16 * kc;
+        if (kc + 1 < KC) load_t(tn, k0 + 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int kk = k0 + 4 * lk + s;
+          const double aown = Wm[(16 * w + li) * LD + kk];
+          const double a4 = Wm[(16 * 4 + li) * LD + kk];
+          const double a5 = NR > 2 ? Wm[(16 * 5 + li) * LD + kk] : 0.0;
+#pragma unroll
+          for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aown, tf[c][s], acc[c], 0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            if (eon[e]) {
+              // (the extra's column fragment: a select over the NT column fragments, wave-uniform)
+              double be = tf[0][s];
+#pragma unroll
+              for (int c = 1; c < NT; ++c) be = ec[e] == c ? tf[c][s] : be;
+              const double ae = (NR > 2 && er[e] == 5) ? a5 : a4;
+              acc[NT + e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be, acc[NT + e], 0, 0, 0);
+            }
+          }
+        }
+        if (kc + 1 < KC) {
+#pragma unroll
+          for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) tf[c][s] = tn[c][s];
+        }
+      }
+    }
+    // (P is not read by this product: the new tiles go straight in)
+    auto put = [&](int R, int C, const double4_t& v) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) Pm[(16 * R + lk + 4 * rg) * LD + 16 * C + li] = v[rg];
+    };
+#pragma unroll
+    for (int c = 0; c < NT; ++c) put(w, c, acc[c]);
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+      if (eon[e]) put(er[e], ec[e], acc[NT + e]);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    A.logp[b] = logp;
+    if (A.info) A.info[b] = info;
+  }
+}
+
+}  // namespace
+
+bool kf_forward_wgl_ok(int m, int p, unsigned flags, bool cov_tapes) {
+  return m > KF_WG_M_MAX && m <= 96 && p == 1 && !(flags & KF_FLAG_TV_ANY) && !cov_tapes;
+}
+
+size_t kf_forward_wgl_workspace_bytes(long B, int m) { return sizeof(double) * (size_t)B * m * m + 64; }
+
+int kf_launch_forward_wgl(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!kf_forward_wgl_ok(a.m, a.p, a.flags, a.filt_P || a.pred_P) || !workspace ||
+      workspace_bytes < kf_forward_wgl_workspace_bytes(a.B, a.m)) {
+    KF_SET_ERR(h, "forward(wgl): needs 64 < m <= 96, p == 1, static matrices, no covariance tapes and %zu bytes of workspace",
+               kf_forward_wgl_workspace_bytes(a.B, a.m));
+    return KF_ERR_UNSUPPORTED;
+  }
+  double* rqr = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 63) & ~(uintptr_t)63);
+  if (a.m <= 80) {
+    const int lds = (int)(sizeof(double) * WlLds<5>::TOTAL);
+    KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kf_fwd_wgl_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((kf_fwd_wgl_kernel<5>), dim3((unsigned)a.B), dim3(WL_NT_THREADS), lds, stream, a, rqr);
+  } else {
+    const int lds = (int)(sizeof(double) * WlLds<6>::TOTAL);
+    KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kf_fwd_wgl_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((kf_fwd_wgl_kernel<6>), dim3((unsigned)a.B), dim3(WL_NT_THREADS), lds, stream, a, rqr);
+  }
+  KF_HIP_CHECK(h, hipGetLastError());
+  return KF_OK;
+}

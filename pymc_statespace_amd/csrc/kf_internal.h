@@ -230,6 +230,10 @@ int kf_launch_forward_lane_m4(kf_handle* h, const KfFwdArgs& a, hipStream_t stre
 int kf_launch_forward(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
                       hipStream_t stream);
 // large-m path (kf_forward_big.hip): covariance in a caller-provided HBM workspace, MFMA GEMMs
+// kf_forward_wgl.hip: 64 < m <= 96, p == 1, static matrices, no covariance tapes -- P resident in LDS, one workgroup per draw
+bool kf_forward_wgl_ok(int m, int p, unsigned flags, bool cov_tapes);
+size_t kf_forward_wgl_workspace_bytes(long B, int m);
+int kf_launch_forward_wgl(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream);
 size_t kf_forward_big_workspace_bytes(long B, int m, int p);
 int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
                           hipStream_t stream);
