@@ -12,11 +12,14 @@
 //
 // Products on v_mfma_f64_16x16x4_f64.  The m x m output is NT x NT tiles of 16 x 16 (NT = 5: m <= 80, NT = 6: m <= 96); wavefront
 // w owns tile row w and a share of tile rows 4 (and 5) -- 7 / 6 / 6 / 6 tiles at NT = 5, 9 each at NT = 6 (2 x 2 blocks of 3 x 3
-// would leave one wavefront 9 of NT = 5's 25).  The operand that comes from global memory (T: the rows of the left factor in
-// W = T P_f, the rows of the right factor's transpose in S = W T') is loaded FOUR CONSECUTIVE doubles per lane: the k index inside a
-// chunk of 16 is permuted -- lane group g = lane / 16 takes k = 4 g + s at sub-step s, the LDS operand follows -- so one chunk is one
-// 32-byte load per lane and tile row instead of four strided 8-byte ones; the next chunk's loads are in flight during this chunk's
-// MFMAs.  a_hat = T a_f rides along with W (the T fragments are in registers anyway).
+// would leave one wavefront 9 of NT = 5's 25).  Both products have T as their LEFT factor (W = T P_f, S = T W': P_f is symmetric), and
+// a wavefront needs only the T fragments of its tile rows (its own, 4, 5): 40 - 72 doubles per lane, loaded ONCE and kept in registers
+// for the whole series together with the R Q R' tiles of its outputs -- one wavefront per SIMD has 512 registers per lane to itself.
+// Inside the loop over time only LDS is read.  (First version: T from L2 every step, S = W T' with T as the right factor: 33 us per
+// step at m = 80, 13.6 of them the second product with its 20 loads and 64 selects per chunk; scripts/r03/wgl_time.py.)  The k index
+// inside a chunk of 16 is permuted -- lane group g = lane / 16 takes k = 4 g + s at sub-step s, the LDS operand follows -- so that
+// a lane's four fragment values of a chunk are four CONSECUTIVE doubles of a row of T.  P_f is formed on the way from LDS into the
+// right-factor fragments; a_hat = T a_f rides along with W.
 #include "kf_internal.h"
 #include "kf_tile.h"
 
@@ -118,9 +121,43 @@ __global__ __launch_bounds__(WL_NT_THREADS) void kf_fwd_wgl_kernel(const KfFwdAr
   __threadfence_block();
   __syncthreads();
 
+  // ---- resident in registers for the whole series: the T fragments of the tile rows this wavefront multiplies with (lane (li, lk)
+  // holds T[16 R + li][16 kc + 4 lk + 0..3]) and the R Q R' tiles of its output tiles.  Both products have T as their LEFT factor:
+  // W = T P_f and S = T W' (P_f is symmetric), so nothing but LDS is read inside the loop over time.
+  double tfr[NR][NT][4];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) {
+    const int row = 16 * rrow[q] + li;
+    const double* tr = Tb + (long)min(row, m - 1) * m;
+#pragma unroll
+    for (int kc = 0; kc < NT; ++kc)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int kk = 16 * kc + 4 * lk + s;
+        const double tv = tr[min(kk, m - 1)];
+        tfr[q][kc][s] = (row < m && kk < m) ? tv : 0.0;
+      }
+  }
+  auto rqr_tile = [&](int R, int C) {
+    double4_t v;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int row = 16 * R + lk + 4 * rg, col = 16 * C + li;
+      v[rg] = (row < m && col < m) ? RQRb[(long)row * m + col] : 0.0;
+    }
+    return v;
+  };
+  constexpr bool RQ_REG = NT == 5;  // (NT = 6: 72 more registers than the lane has -- its R Q R' tiles come from L2 at every step)
+  double4_t rq[RQ_REG ? NT + NE : 1];
+  if (RQ_REG) {
+#pragma unroll
+    for (int c = 0; c < NT; ++c) rq[c] = rqr_tile(w, c);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) rq[NT + e] = rqr_tile(er[e], ec[e]);
+  }
+
   double logp = 0.0;
   int info = 0;
-  const int KC = (m + 15) / 16;  // chunks of 16 along k
 
   for (int t = 0; t < n; ++t) {
     // ---- (a) m = P z: thread (row, half) sums 8 NT columns; the halves meet in the scratch (W is free here) ----------------------------
@@ -164,12 +201,10 @@ __global__ __launch_bounds__(WL_NT_THREADS) void kf_fwd_wgl_kernel(const KfFwdAr
         sc[0] = v;
         sc[1] = F;
         sc[2] = dj;
-        sc[3] = obs ? 1.0 : 0.0;
       }
     }
     __syncthreads();
     // ---- (c) k = m / F (two divisions by sqrt F, as the Cholesky solve of the general path), k F, a_f ------------------------------------
-    const bool obs = sc[3] != 0.0;
     {
       const double v = sc[0], F = sc[1], dj = sc[2];
       for (int e = tid; e < MP; e += WL_NT_THREADS) {
@@ -182,69 +217,52 @@ __global__ __launch_bounds__(WL_NT_THREADS) void kf_fwd_wgl_kernel(const KfFwdAr
       }
     }
     __syncthreads();
-    // ---- (d) P <- P_f = P - k m' - m k' + (k F) k' in place (a missing observation: k = 0, nothing to do) -------------------------------
-    if (obs) {
-      for (int e = tid; e < MP * MP; e += WL_NT_THREADS) {
-        const int i = e / MP, j = e - i * MP;
-        double s = Pm[i * LD + j];
-        s -= vk[i] * vm[j];
-        s -= vm[i] * vk[j];
-        s += vkf[i] * vk[j];
-        Pm[i * LD + j] = s;
-      }
-      __syncthreads();
-    }
-    // ---- (e) W = T P_f, a_hat = T a_f + c -----------------------------------------------------------------------------------------------
+    // ---- (e) W = T P_f, a_hat = T a_f + c.  P_f = P - k m' - m k' + (k F) k' is formed on the way from LDS into the right-factor
+    // fragments (big_pf_kernel's order of operations; a missing observation has k = m = 0) ---------------------------------------------------
     double4_t acc[NT + NE];
 #pragma unroll
     for (int sidx = 0; sidx < NT + NE; ++sidx) acc[sidx] = (double4_t){0.0, 0.0, 0.0, 0.0};
     {
-      // T fragments of the tile rows rrow[.]: lane (li, lk) holds T[16 R + li][k0 + 4 lk + 0..3]
-      double tf[NR][4], tn[NR][4];
-      auto load_t = [&](double (&dst)[NR][4], int k0) {
+      double kcol[NT + NE], mcol[NT + NE];
 #pragma unroll
-        for (int q = 0; q < NR; ++q) {
-          const int row = 16 * rrow[q] + li;
+      for (int c = 0; c < NT; ++c) {
+        kcol[c] = vk[16 * c + li];
+        mcol[c] = vm[16 * c + li];
+      }
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int kk = k0 + 4 * lk + s;
-            dst[q][s] = (row < m && kk < m) ? Tb[(long)row * m + kk] : 0.0;
-          }
-        }
-      };
+      for (int e = 0; e < NE; ++e) {
+        kcol[NT + e] = vk[16 * ec[e] + li];
+        mcol[NT + e] = vm[16 * ec[e] + li];
+      }
       double ah[NR];
 #pragma unroll
       for (int q = 0; q < NR; ++q) ah[q] = 0.0;
-      load_t(tf, 0);
-      for (int kc = 0; kc < KC; ++kc) {
-        const int k0 = 16 * kc;
-        if (kc + 1 < KC) load_t(tn, k0 + 16);
+#pragma unroll
+      for (int kc = 0; kc < NT; ++kc) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const int kk = k0 + 4 * lk + s;
+          const int kk = 16 * kc + 4 * lk + s;
           const double* prow = Pm + kk * LD + li;
-          double bf[NT];
+          const double kr = vk[kk], mr = vm[kk], kfr = vkf[kk], afk = vaf[kk];
 #pragma unroll
-          for (int c = 0; c < NT; ++c) bf[c] = prow[16 * c];
-          const double afk = vaf[kk];
+          for (int q = 0; q < NR; ++q) ah[q] = fma(tfr[q][kc][s], afk, ah[q]);
 #pragma unroll
-          for (int q = 0; q < NR; ++q) ah[q] = fma(tf[q][s], afk, ah[q]);
-#pragma unroll
-          for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[0][s], bf[c], acc[c], 0, 0, 0);
-#pragma unroll
-          for (int e = 0; e < NE; ++e) {
-            if (eon[e]) {
-              const double be = prow[16 * ec[e]];
-              const double ae = (NR > 2 && er[e] == 5) ? tf[NR - 1][s] : tf[1][s];
-              acc[NT + e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be, acc[NT + e], 0, 0, 0);
-            }
+          for (int c = 0; c < NT; ++c) {
+            double bv = prow[16 * c];
+            bv -= kr * mcol[c];
+            bv -= mr * kcol[c];
+            bv += kfr * kcol[c];
+            acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(tfr[0][kc][s], bv, acc[c], 0, 0, 0);
           }
-        }
-        if (kc + 1 < KC) {
 #pragma unroll
-          for (int q = 0; q < NR; ++q)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) tf[q][s] = tn[q][s];
+          for (int e = 0; e < NE; ++e) {  // (a wavefront without this extra repeats tile (4, 0) into an accumulator nobody stores)
+            double bv = prow[16 * ec[e]];
+            bv -= kr * mcol[NT + e];
+            bv -= mr * kcol[NT + e];
+            bv += kfr * kcol[NT + e];
+            const double ae = (NR > 2 && er[e] == 5) ? tfr[NR - 1][kc][s] : tfr[1][kc][s];
+            acc[NT + e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, bv, acc[NT + e], 0, 0, 0);
+          }
         }
       }
       // W tiles -> LDS: D[row = lk + 4 rg][col = li]
@@ -273,63 +291,29 @@ __global__ __launch_bounds__(WL_NT_THREADS) void kf_fwd_wgl_kernel(const KfFwdAr
       }
     }
     __syncthreads();
-    // ---- (f) P <- W T' + R Q R' (the accumulators start from R Q R': its loads overlap the first chunk's) -------------------------------
-    auto rqr_tile = [&](int R, int C) {
-      double4_t v;
+    // ---- (f) P <- T W' + R Q R' (= T P_f T' + R Q R': P_f is symmetric); the accumulators start from R Q R' ----------------------------
+    if (RQ_REG) {
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int row = 16 * R + lk + 4 * rg, col = 16 * C + li;
-        v[rg] = (row < m && col < m) ? RQRb[(long)row * m + col] : 0.0;
-      }
-      return v;
-    };
+      for (int sidx = 0; sidx < NT + NE; ++sidx) acc[sidx] = rq[RQ_REG ? sidx : 0];
+    } else {
 #pragma unroll
-    for (int c = 0; c < NT; ++c) acc[c] = rqr_tile(w, c);
+      for (int c = 0; c < NT; ++c) acc[c] = rqr_tile(w, c);
 #pragma unroll
-    for (int e = 0; e < NE; ++e) acc[NT + e] = eon[e] ? rqr_tile(er[e], ec[e]) : (double4_t){0.0, 0.0, 0.0, 0.0};
-    {
-      // right factor T': lane (lk, li) holds T[16 C + li][k0 + 4 lk + 0..3] for every tile column C (the extras' columns among them)
-      double tf[NT][4], tn[NT][4];
-      auto load_t = [&](double (&dst)[NT][4], int k0) {
+      for (int e = 0; e < NE; ++e) acc[NT + e] = rqr_tile(er[e], ec[e]);
+    }
 #pragma unroll
-        for (int c = 0; c < NT; ++c) {
-          const int row = 16 * c + li;
+    for (int kc = 0; kc < NT; ++kc) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int kk = k0 + 4 * lk + s;
-            dst[c][s] = (row < m && kk < m) ? Tb[(long)row * m + kk] : 0.0;
-          }
-        }
-      };
-      load_t(tf, 0);
-      for (int kc = 0; kc < KC; ++kc) {
-        const int k0 = 16 * kc;
-        if (kc + 1 < KC) load_t(tn, k0 + 16);
+      for (int s = 0; s < 4; ++s) {
+        const int kk = 16 * kc + 4 * lk + s;
+        const double* wrow = Wm + li * LD + kk;   // W'[kk][16 C + li] = W[16 C + li][kk]
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int kk = k0 + 4 * lk + s;
-          const double aown = Wm[(16 * w + li) * LD + kk];
-          const double a4 = Wm[(16 * 4 + li) * LD + kk];
-          const double a5 = NR > 2 ? Wm[(16 * 5 + li) * LD + kk] : 0.0;
+        for (int c = 0; c < NT; ++c)
+          acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(tfr[0][kc][s], wrow[16 * c * LD], acc[c], 0, 0, 0);
 #pragma unroll
-          for (int c = 0; c < NT; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aown, tf[c][s], acc[c], 0, 0, 0);
-#pragma unroll
-          for (int e = 0; e < NE; ++e) {
-            if (eon[e]) {
-              // (the extra's column fragment: a select over the NT column fragments, wave-uniform)
-              double be = tf[0][s];
-#pragma unroll
-              for (int c = 1; c < NT; ++c) be = ec[e] == c ? tf[c][s] : be;
-              const double ae = (NR > 2 && er[e] == 5) ? a5 : a4;
-              acc[NT + e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be, acc[NT + e], 0, 0, 0);
-            }
-          }
-        }
-        if (kc + 1 < KC) {
-#pragma unroll
-          for (int c = 0; c < NT; ++c)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) tf[c][s] = tn[c][s];
+        for (int e = 0; e < NE; ++e) {
+          const double ae = (NR > 2 && er[e] == 5) ? tfr[NR - 1][kc][s] : tfr[1][kc][s];
+          acc[NT + e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, wrow[16 * ec[e] * LD], acc[NT + e], 0, 0, 0);
         }
       }
     }
