@@ -20,6 +20,8 @@
 // inside a chunk of 16 is permuted -- lane group g = lane / 16 takes k = 4 g + s at sub-step s, the LDS operand follows -- so that
 // a lane's four fragment values of a chunk are four CONSECUTIVE doubles of a row of T.  P_f is formed on the way from LDS into the
 // right-factor fragments; a_hat = T a_f rides along with W.
+#include <type_traits>
+
 #include "kf_internal.h"
 #include "kf_tile.h"
 
@@ -335,6 +337,252 @@ __global__ __launch_bounds__(WL_NT_THREADS) void kf_fwd_wgl_kernel(const KfFwdAr
   }
 }
 
+// ---- the same scheme for NT = 6 (80 < m <= 96): wavefront w of NW takes the tiles [NT^2 w / NW, NT^2 (w + 1) / NW) in row-major order --
+// nine tiles out of exactly two tile rows at NW = 4, so 48 doubles of T per lane instead of the 72 that the three tile rows of the
+// kernel above need (its NT = 6 instance spilled 234 registers; eight wavefronts of 4 - 5 tiles, two per SIMD, spilled 491 of 256).
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void kf_fwd_wgl_range_kernel(const KfFwdArgs A, double* __restrict__ RQR_ws) {
+  using L = WlLds<NT>;
+  constexpr int MP = L::MP, LD = L::LD, NTH = 64 * NW;
+  constexpr int TOT = NT * NT, MAXT = (TOT + NW - 1) / NW;
+  extern __shared__ double sm[];
+  double* Pm = sm + L::OFF_P;
+  double* Wm = sm + L::OFF_W;
+  double* va = sm + L::OFF_V + L::V_A * MP;
+  double* vaf = sm + L::OFF_V + L::V_AF * MP;
+  double* vk = sm + L::OFF_V + L::V_K * MP;
+  double* vm = sm + L::OFF_V + L::V_M * MP;
+  double* vkf = sm + L::OFF_V + L::V_KF * MP;
+  double* vz = sm + L::OFF_V + L::V_Z * MP;
+  double* vc = sm + L::OFF_V + L::V_C * MP;
+  double* sc = sm + L::OFF_S;
+  const long b = blockIdx.x;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  const int m = A.m, n = A.T, r = A.r;
+  const long mm = (long)m * m;
+  const double* Tb = A.Tm + b * mm;
+  double* RQRb = RQR_ws + b * mm;
+  const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;
+  const double dq = A.d ? A.d[b] : 0.0;
+  const double Hq = A.H[b];
+  const double* yb = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n : 0L);
+
+  static_assert(NT == 6 && NW == 4, "the tile tables below are those of 36 tiles on four wavefronts");
+  // wavefront w: tiles 9 w .. 9 w + 8 = two tile rows R0, R0 + 1; even w: (R0, 0..5), (R0+1, 0..2); odd w: (R0, 3..5), (R0+1, 0..5).
+  // The two shapes are two instantiations of the products below (everything about a slot is a compile-time constant: with the row
+  // of a slot chosen at run time the compiler hoisted 216 selected fragments out of the loop over time and spilled 530 registers).
+  const int R0 = (9 * w) / NT;
+
+  for (int e = tid; e < MP * MP; e += NTH) {
+    const int i = e / MP, j = e - i * MP;
+    Pm[i * LD + j] = (i < m && j < m) ? A.P0[b * mm + (long)i * m + j] : 0.0;
+  }
+  for (int e = tid; e < MP; e += NTH) {
+    const bool on = e < m;
+    const double a0 = on ? A.a0[b * m + e] : 0.0;
+    va[e] = a0;
+    vz[e] = on ? A.Z[b * m + e] : 0.0;
+    vc[e] = (on && A.c) ? A.c[b * m + e] : 0.0;
+    vaf[e] = vk[e] = vm[e] = vkf[e] = 0.0;
+    if (on && A.pred_a) A.pred_a[b * (long)(n + 1) * m + e] = a0;
+  }
+  {
+    const double* gR = A.R + b * (long)m * r;
+    const double* gQ = A.Q + b * (long)r * r;
+    for (long e = tid; e < mm; e += NTH) {
+      const int i = (int)(e / m), j = (int)(e - (long)i * m);
+      double s = 0.0;
+      for (int l = 0; l < r; ++l) {
+        double rq = 0.0;
+        for (int k = 0; k < r; ++k) rq += gR[i * r + k] * gQ[k * r + l];
+        s += rq * gR[j * r + l];
+      }
+      RQRb[e] = s;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  double tfr[2][NT][4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = 16 * min(R0 + q, NT - 1) + li;
+    const double* tr = Tb + (long)min(row, m - 1) * m;
+#pragma unroll
+    for (int kc = 0; kc < NT; ++kc)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int kk = 16 * kc + 4 * lk + s;
+        const double tv = tr[min(kk, m - 1)];
+        tfr[q][kc][s] = (row < m && kk < m) ? tv : 0.0;
+      }
+  }
+
+  double logp = 0.0;
+  int info = 0;
+  for (int t = 0; t < n; ++t) {
+    // (a) m = P z
+    {
+      const int row = tid % 128, half = (tid / 128) & 1;
+      if (row < MP && tid < 256) {
+        const double* pr = Pm + row * LD + half * (MP / 2);
+        const double* zz = vz + half * (MP / 2);
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll 4
+        for (int c = 0; c < MP / 2; c += 2) {
+          s0 = fma(pr[c], zz[c], s0);
+          s1 = fma(pr[c + 1], zz[c + 1], s1);
+        }
+        Wm[half * MP + row] = s0 + s1;
+      }
+    }
+    __syncthreads();
+    // (b) F, v, the log-likelihood term
+    if (w == 0) {
+      const double yv = yb[t];
+      const bool obs = !(yv != yv);
+      double pf = 0.0, pv = 0.0;
+      for (int e = lane; e < MP; e += 64) {
+        const double mv = obs ? Wm[e] + Wm[MP + e] : 0.0;
+        vm[e] = mv;
+        pf = fma(vz[e], mv, pf);
+        pv = fma(vz[e], va[e], pv);
+      }
+      pf = wl_wave_sum(pf);
+      pv = wl_wave_sum(pv);
+      if (lane == 0) {
+        const double F = obs ? pf + Hq : 1.0;
+        const double v = obs ? (yv + dsign * dq) - pv : 0.0;
+        const double dj = sqrt(F);
+        const double wv = v / dj;
+        const double ll = obs ? (-0.5 * (KF_LOG_2PI + wv * wv) - log(dj)) : 0.0;
+        logp += ll;
+        if (A.ll_obs) A.ll_obs[b * (long)n + t] = ll;
+        if (!(F > 0.0) && info == 0) info = ((t + 1) << 8) | 1;
+        sc[0] = v;
+        sc[1] = F;
+        sc[2] = dj;
+      }
+    }
+    __syncthreads();
+    // (c) k, k F, a_f
+    {
+      const double v = sc[0], F = sc[1], dj = sc[2];
+      for (int e = tid; e < MP; e += NTH) {
+        const double kk = (vm[e] / dj) / dj;
+        vk[e] = kk;
+        vkf[e] = kk * F;
+        const double af = va[e] + kk * v;
+        vaf[e] = af;
+        if (e < m && A.filt_a) A.filt_a[(b * (long)n + t) * m + e] = af;
+      }
+    }
+    __syncthreads();
+    auto products = [&](auto vtag) {
+      constexpr int V = decltype(vtag)::value;
+      constexpr bool OWN0 = V == 0;   // a_hat of tile row R: the wavefront whose range holds tile (R, 0)
+#define TQ(i) ((V == 0) ? ((i) >= 6 ? 1 : 0) : ((i) >= 3 ? 1 : 0))
+#define TC(i) ((V == 0) ? ((i) >= 6 ? (i) - 6 : (i)) : ((i) >= 3 ? (i) - 3 : (i) + 3))
+    // (e) W = T P_f, a_hat = T a_f + c
+    double4_t acc[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) acc[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    {
+      double kcol[MAXT], mcol[MAXT];
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) {
+        kcol[i] = vk[16 * TC(i) + li];
+        mcol[i] = vm[16 * TC(i) + li];
+      }
+      double ah0 = 0.0, ah1 = 0.0;
+#pragma unroll
+      for (int kc = 0; kc < NT; ++kc) {
+        wave_lds_fence();  // (bounds how far ahead the LDS reads are hoisted: registers)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int kk = 16 * kc + 4 * lk + s;
+          const double* prow = Pm + kk * LD + li;
+          const double kr = vk[kk], mr = vm[kk], kfr = vkf[kk], afk = vaf[kk];
+          ah0 = fma(tfr[0][kc][s], afk, ah0);
+          ah1 = fma(tfr[1][kc][s], afk, ah1);
+#pragma unroll
+          for (int i = 0; i < MAXT; ++i) {
+            double bv = prow[16 * TC(i)];
+            bv -= kr * mcol[i];
+            bv -= mr * kcol[i];
+            bv += kfr * kcol[i];
+            const double ae = TQ(i) ? tfr[1][kc][s] : tfr[0][kc][s];
+            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, bv, acc[i], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i)
+        {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) Wm[(16 * (R0 + TQ(i)) + lk + 4 * rg) * LD + 16 * TC(i) + li] = acc[i][rg];
+        }
+      const double s0 = col_allsum(ah0), s1 = col_allsum(ah1);
+      if (lk == 0) {
+        if (OWN0) {
+          const int row = 16 * R0 + li;
+          const double an = s0 + vc[row];
+          va[row] = row < m ? an : 0.0;
+          if (row < m && A.pred_a) A.pred_a[(b * (long)(n + 1) + t + 1) * m + row] = an;
+        }
+        if (true) {
+          const int row = 16 * (R0 + 1) + li;
+          const double an = s1 + vc[row];
+          va[row] = row < m ? an : 0.0;
+          if (row < m && A.pred_a) A.pred_a[(b * (long)(n + 1) + t + 1) * m + row] = an;
+        }
+      }
+    }
+    __syncthreads();
+    // (f) P <- T W' + R Q R'
+    // (R Q R' from L2 at every step)
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int row = 16 * (R0 + TQ(i)) + lk + 4 * rg, col = 16 * TC(i) + li;
+        acc[i][rg] = (row < m && col < m) ? RQRb[(long)row * m + col] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int kc = 0; kc < NT; ++kc) {
+      wave_lds_fence();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int kk = 16 * kc + 4 * lk + s;
+        const double* wrow = Wm + li * LD + kk;
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+          const double ae = TQ(i) ? tfr[1][kc][s] : tfr[0][kc][s];
+          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, wrow[16 * TC(i) * LD], acc[i], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i)
+      {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) Pm[(16 * (R0 + TQ(i)) + lk + 4 * rg) * LD + 16 * TC(i) + li] = acc[i][rg];
+      }
+#undef TQ
+#undef TC
+    };
+    if (w & 1) products(std::integral_constant<int, 1>{});
+    else products(std::integral_constant<int, 0>{});
+    __syncthreads();
+  }
+  if (tid == 0) {
+    A.logp[b] = logp;
+    if (A.info) A.info[b] = info;
+  }
+}
+
 }  // namespace
 
 bool kf_forward_wgl_ok(int m, int p, unsigned flags, bool cov_tapes) {
@@ -357,8 +605,8 @@ int kf_launch_forward_wgl(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
     hipLaunchKernelGGL((kf_fwd_wgl_kernel<5>), dim3((unsigned)a.B), dim3(WL_NT_THREADS), lds, stream, a, rqr);
   } else {
     const int lds = (int)(sizeof(double) * WlLds<6>::TOTAL);
-    KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kf_fwd_wgl_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL((kf_fwd_wgl_kernel<6>), dim3((unsigned)a.B), dim3(WL_NT_THREADS), lds, stream, a, rqr);
+    KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kf_fwd_wgl_range_kernel<6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((kf_fwd_wgl_range_kernel<6, 4>), dim3((unsigned)a.B), dim3(256), lds, stream, a, rqr);
   }
   KF_HIP_CHECK(h, hipGetLastError());
   return KF_OK;
