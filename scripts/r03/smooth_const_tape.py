@@ -1,5 +1,5 @@
 import os, sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import workloads as W
 from pymc_statespace_amd import KalmanEngine
 eng = KalmanEngine()
