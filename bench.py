@@ -69,8 +69,11 @@ def algorithmic_flops(B, n, p, m, r):
 
 def executed_flops_big(B, n, m):
     """What the workspace path actually issues on the matrix cores per launch: two m^3 products per
-    draw-step (W = P_f T', S = T W; the second on the upper-triangle tiles only -- counted in full)."""
-    return 4.0 * m ** 3 * B * n
+    draw-step -- W = T P_f in full, S = W T' + R Q R' on the 128 x 64 tiles that touch the upper triangle only
+    (kf_forward_big.hip: a tile is skipped when its first row lies below its last column)."""
+    tm, tn = -(-m // 128), -(-m // 64)
+    kept = sum(1 for i in range(tm) for j in range(tn) if not (128 * i > 64 * j + 63))
+    return (2.0 + 2.0 * kept / (tm * tn)) * m ** 3 * B * n
 
 
 def usable_cores():
@@ -387,23 +390,23 @@ def main():
         kname = eng.forward_kernel_name(B_local, n, p, m, r, filter_type=ft, h_diagonal=diag)
         if big:
             aflops = algorithmic_flops(B_local, n, p, m, r)
-            ach = aflops / (kern_ms * 1e-3) / 1e12
+            xflops = executed_flops_big(B_local, n, m)
+            ach = xflops / (kern_ms * 1e-3) / 1e12
             out["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": ach / FP64_MFMA_PEAK_TF, "traffic": None,
                 "kernel": kname, "kernel_ms": kern_ms,
                 "launches_per_step": (3 if (p == 1 and not full) else 7) * n,
-                "algorithmic_flops_per_launch": aflops,
-                "executed_tflops": executed_flops_big(B_local, n, m) / (kern_ms * 1e-3) / 1e12,
-                "executed_frac_of_peak": executed_flops_big(B_local, n, m) / (kern_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF,
-                "executed_frac_of_measured_issue_ceiling": executed_flops_big(B_local, n, m) / (kern_ms * 1e-3) / 1e12 / 45.2,
+                "executed_flops_per_launch": xflops,
+                "reference_flops_per_launch": aflops,
+                "reference_flops_tflops": aflops / (kern_ms * 1e-3) / 1e12,
                 "note": "kernel_ms = the whole forward pass (p = 1 without the filtered covariance tape: 3 launches per time "
                         "step -- gain, W = T P_f with P_f formed on the way into LDS and a_hat beside it, S = W T' + R Q R' "
-                        "mirrored in the epilogue; else 7); achieved / frac = SURVEY 8(d) dense flop count of the REFERENCE "
-                        "sequence / that time -- an accounting choice, not MFMA utilisation; executed_tflops counts the two "
-                        "m^3 MFMA products actually issued (the second on upper-triangle tiles only, counted in full): "
-                        "executed_frac_of_peak is that over 78.6 TF, executed_frac_of_measured_issue_ceiling over the 45.2 TF "
-                        "the instruction was measured to issue at (profiles/r01/fp64_issue_rates.txt)",
+                        "mirrored in the epilogue; else 7); achieved / frac = the fp64 MFMA flops ACTUALLY ISSUED (W in full, S "
+                        "on the tiles that touch the upper triangle) over that time and over the 78.6 TF dense peak; "
+                        "reference_flops_tflops = SURVEY 8(d)'s dense flop count of the REFERENCE's sequence (Joseph form, "
+                        "no symmetry) over the same time -- what the reference would have to sustain to match, not a "
+                        "utilisation (rounds 1-2 reported it as frac)",
             }
         else:
             abytes = algorithmic_bytes(B_local, n, p, m, r, full)

@@ -168,7 +168,9 @@ int kf_set_lanes_per_draw(kf_handle* h, int lanes);
  * in the 16 x 16 MFMA accumulator layout, one wavefront per draw ("mfma": p == 1 with m = 15, 16; p > 1 with m = 16)
  * or the multivariate row kernel ("row": p > 1, m <= 8, large batches); 16 < m <= 48 with the same eligibility -> covariance as 2 x 2 /
  * 3 x 3 blocks of 16 x 16 in accumulator layout ("mfma" as well); 48 < m <= 64 -> one workgroup of
- * four wavefronts per draw, one column block each ("mfma"); other tiles that fit LDS ->
+ * four wavefronts per draw, one column block each ("mfma"); 64 < m <= 96 with p == 1 (Standard / Cholesky /
+ * SingleTimeseries) and no covariance tape requested -> one workgroup per draw with the covariance resident in LDS for the
+ * whole series (needs the workspace kf_workspace_bytes_for asks for); other tiles that fit LDS ->
  * generic LDS-resident kernel ("lds", also all time-varying models); else the workspace + MFMA
  * GEMM path.  The gradient and the smoother follow the same ranges (block-tile kernels for
  * 16 < m <= 48 / 47, workgroup kernels up to m = 64).  Results agree to
@@ -177,7 +179,10 @@ enum { KF_KERNEL_AUTO = 0, KF_KERNEL_LDS = 1, KF_KERNEL_ROW = 2, KF_KERNEL_LANE 
 int kf_set_forward_kernel(kf_handle* h, int kernel);
 /* Name of the kernel kf_filter_forward would launch for `dims` (for profiles / bench logs), assuming
  * the caller passes the workspace kf_workspace_bytes asks for; the _ws form takes the size of the
- * workspace the caller will actually pass (0 = none). */
+ * workspace the caller will actually pass (0 = none).  The name is that of the call WITH covariance tapes: for 64 < m <= 96,
+ * p == 1 a call without them (filt_P == pred_P == NULL) runs kf_fwd_wgl_kernel (covariance resident in LDS) instead of the
+ * workspace path this reports; for p = 1, m <= 10 a batch of <= 1024 draws with covariance tapes runs the recursion + writer pair
+ * kernel (kf_fwd_b4p_kernel). */
 const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* dims);
 const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_dims* dims, size_t workspace_bytes);
 

@@ -3,7 +3,10 @@
       KF_FLAG_EXACT_RECURSION (pair kernel for <= 1024 draws with tapes) against the numpy oracle; batches up to 1600 draws
   logp + gradient, 3 <= p <= 5, m >= 8: steady-state adjoint against the exact adjoint at every step (KF_VG_STEADY=0) and, on
       the first draws, against torch autograd
-  smoother, m <= 4: lane kernel (pseudo-inverse in registers) against the numpy oracle (numpy.linalg.pinv per step)"""
+  smoother, m <= 4: lane kernel (pseudo-inverse in registers) against the numpy oracle (numpy.linalg.pinv per step)
+  smoother, 5 <= m <= 15, up to 500 steps: block kernel with the gain reuse against every step in full and the oracle
+  forward, 65 <= m <= 140, p = 1, log-likelihood + state tapes: the LDS-resident kernel (m <= 96) / the three-launch workspace
+      step (m > 96) against the oracle, missing observations and intercepts"""
 import os
 import sys
 import time
@@ -22,8 +25,9 @@ KEYS = ("a0", "P0", "T", "Z", "R", "H", "Q")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
 eng = KalmanEngine()
-worst = dict(fwd_logp=0.0, fwd_tapes=0.0, steady_vs_exact=0.0, vg_vs_exact=0.0, vg_vs_autograd=0.0, smooth=0.0)
-flagged, counts = 0, dict(fwd=0, vg=0, smooth=0)
+worst = dict(fwd_logp=0.0, fwd_tapes=0.0, steady_vs_exact=0.0, vg_vs_exact=0.0, vg_vs_autograd=0.0, smooth=0.0, smooth_b4=0.0,
+             smooth_b4_vs_full=0.0, mid_m_logp=0.0)
+flagged, counts = 0, dict(fwd=0, vg=0, smooth=0, smooth_b4=0, mid_m=0)
 t0 = time.time()
 
 
@@ -32,7 +36,59 @@ def rel(a, b):
 
 
 for case in range(n_cases):
-    kind = int(rng.integers(0, 10))
+    kind = int(rng.integers(0, 14))
+    if kind >= 12:  # ---- forward, 65 <= m <= 140, log-likelihood and state tapes ----------------------------------------------------
+        import torch
+        from pymc_statespace_amd.engine import FilterResult
+        m = int(rng.integers(65, 141))
+        r = int(rng.integers(1, 6))
+        n = int(rng.choice([3, 40, 120]))
+        B = int(rng.choice([1, 9, 20]))
+        w = W.random_dense(B, n, 1, m, r, seed=int(rng.integers(1 << 30)))
+        y = w["y"].copy()
+        for _ in range(int(rng.integers(0, 4))):
+            y[rng.integers(0, n)] = np.nan
+        c = 0.1 * rng.standard_normal((B, m)) if rng.integers(0, 2) else None
+        d = 0.1 * rng.standard_normal((B, 1)) if rng.integers(0, 2) else None
+        ft = str(rng.choice(["standard", "cholesky", "single"]))
+        ref = kn.kalman_filter(y, *[w[x] for x in KEYS], c=c, d=d, filter_type=ft, mvn_const="exact")
+        dev = torch.device("cuda")
+        out = FilterResult(logp=torch.empty(B, device=dev, dtype=torch.float64), ll_obs=torch.empty(B, n, device=dev, dtype=torch.float64),
+                           filtered_states=torch.empty(B, n, m, device=dev, dtype=torch.float64),
+                           predicted_states=torch.empty(B, n + 1, m, device=dev, dtype=torch.float64),
+                           filtered_covs=None, predicted_covs=None, info=torch.empty(B, device=dev, dtype=torch.int32))
+        res = eng.forward(y, *[w[x] for x in KEYS], c=c, d=d, filter_type=ft, mvn_const="exact", out=out)
+        e = max(rel(res.logp.cpu().numpy(), ref["logp"]), rel(res.ll_obs.cpu().numpy(), ref["ll_obs"]),
+                rel(res.filtered_states.cpu().numpy(), ref["filtered_states"]), rel(res.predicted_states.cpu().numpy(), ref["predicted_states"]))
+        worst["mid_m_logp"] = max(worst["mid_m_logp"], e)
+        if e > 1e-9 or res.info.cpu().numpy().any():
+            flagged += 1
+            print(f"FLAG mid-m forward case {case}: m={m} r={r} n={n} B={B} {ft}: {e:.2e}", flush=True)
+        counts["mid_m"] += 1
+        continue
+    if kind >= 10:  # ---- smoother, 5 <= m <= 15: gain reuse ------------------------------------------------------------------------
+        m = int(rng.integers(5, 16))
+        n = int(rng.choice([40, 200, 500]))
+        B = int(rng.choice([3, 40]))
+        w = W.random_dense(B, n, 1, m, m, seed=int(rng.integers(1 << 30)))
+        y = w["y"].copy()
+        for _ in range(int(rng.integers(0, 3))):
+            y[rng.integers(0, n)] = np.nan
+        res = eng.forward(y, *[w[x] for x in KEYS], mvn_const="exact", exact_recursion=bool(rng.integers(0, 2)))
+        sa, sP = eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
+        ea, eP = eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs, exact_recursion=True)
+        k = min(B, 8)
+        ra, rP = kn.kalman_smoother(w["T"][:k], w["R"][:k], w["Q"][:k], res.filtered_states[:k].cpu().numpy(),
+                                    res.filtered_covs[:k].cpu().numpy())
+        e = max(rel(sa[:k].cpu().numpy(), ra), rel(sP[:k].cpu().numpy(), rP))
+        e2 = max(rel(sa.cpu().numpy(), ea.cpu().numpy()), rel(sP.cpu().numpy(), eP.cpu().numpy()))
+        worst["smooth_b4"] = max(worst["smooth_b4"], e)
+        worst["smooth_b4_vs_full"] = max(worst["smooth_b4_vs_full"], e2)
+        if e > 1e-9 or e2 > 1e-11:
+            flagged += 1
+            print(f"FLAG block smoother case {case}: m={m} n={n} B={B}: vs oracle {e:.2e} vs every step in full {e2:.2e}", flush=True)
+        counts["smooth_b4"] += 1
+        continue
     if kind < 6:  # ---- forward, p = 1 ------------------------------------------------------------------------------------------
         m = int(rng.integers(1, 11))
         r = int(rng.integers(1, m + 1))
