@@ -328,7 +328,7 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a_in, void* workspace, size
   if (kf_nb_ok(h, a.m, a.p, a.r, a.filter, a.flags)) return kf_launch_forward_mfma_nb(h, a, stream);
   if (kf_wg_ok(h, a.m, a.p, a.r, a.filter, a.flags)) return kf_launch_forward_mfma_wg(h, a, stream);
   // 64 < m <= 96, scalar observation, no covariance tapes (the log-likelihood-only call): P stays in LDS, one workgroup per draw
-  // (kf_forward_wgl.hip; measured at 4096 x 1000: m = 70 / 80 / 96 in 0.21 / 0.21 / 0.30 s against 0.79 / 0.82 / ~0.9 s on the
+  // (kf_forward_wgl.hip; measured at 4096 x 1000: m = 70 / 80 / 96 in 0.18 / 0.18 / 0.27 s against 0.79 / 0.82 / ~0.9 s on the
   // workspace path, scripts/r03/wgl_check.py); KF_FORWARD_WGL=0 keeps the latter
   if (h->forward_kernel == KF_KERNEL_AUTO && a.filter != KF_FILTER_UNIVARIATE &&
       kf_forward_wgl_ok(a.m, a.p, a.flags, a.filt_P || a.pred_P) && workspace &&

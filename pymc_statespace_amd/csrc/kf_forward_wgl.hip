@@ -149,13 +149,21 @@ __global__ __launch_bounds__(WL_NT_THREADS) void kf_fwd_wgl_kernel(const KfFwdAr
     }
     return v;
   };
-  constexpr bool RQ_REG = NT == 5;  // (NT = 6: 72 more registers than the lane has -- its R Q R' tiles come from L2 at every step)
-  double4_t rq[RQ_REG ? NT + NE : 1];
-  if (RQ_REG) {
+  // The second product S = T W' + R Q R' is symmetric: 15 of the 25 tiles are computed -- wavefront 0: (0,0..3), 1: (1,1..4),
+  // 2: (2,2..4) and (4,0), 3: (3,3), (3,4), (4,4): at most four per wavefront instead of seven -- and written to both triangles.
+  static_assert(NT == 5, "the tile tables of the symmetric product are those of 5 x 5 tiles (NT = 6: kf_fwd_wgl_range_kernel)");
+  auto sym_tile = [&](int i, int& R, int& C) {  // slot i of this wavefront (run-time form of the tables in the product below)
+    if (w == 0) { R = 0; C = i; }
+    else if (w == 1) { R = 1; C = 1 + i; }
+    else if (w == 2) { R = i < 3 ? 2 : 4; C = i < 3 ? 2 + i : 0; }
+    else { R = i < 2 ? 3 : 4; C = i < 2 ? 3 + i : 4; }
+  };
+  double4_t rq[4];
 #pragma unroll
-    for (int c = 0; c < NT; ++c) rq[c] = rqr_tile(w, c);
-#pragma unroll
-    for (int e = 0; e < NE; ++e) rq[NT + e] = rqr_tile(er[e], ec[e]);
+  for (int i = 0; i < 4; ++i) {
+    int R, C;
+    sym_tile(i, R, C);
+    rq[i] = rqr_tile(R, C);
   }
 
   double logp = 0.0;
@@ -293,42 +301,46 @@ __global__ __launch_bounds__(WL_NT_THREADS) void kf_fwd_wgl_kernel(const KfFwdAr
       }
     }
     __syncthreads();
-    // ---- (f) P <- T W' + R Q R' (= T P_f T' + R Q R': P_f is symmetric); the accumulators start from R Q R' ----------------------------
-    if (RQ_REG) {
+    // ---- (f) P <- T W' + R Q R' (= T P_f T' + R Q R': P_f is symmetric), the upper-triangle tiles only; the accumulators start from
+    // R Q R'.  One instantiation per wavefront: which row fragment and which tile column a slot uses are compile-time constants ----
+    auto sym_product = [&](auto wtag) {
+      constexpr int WV = decltype(wtag)::value;
+      constexpr int SQ[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 1}, {0, 0, 1, 1}};   // 0: the own tile row, 1: tile row 4
+      constexpr int SC[4][4] = {{0, 1, 2, 3}, {1, 2, 3, 4}, {2, 3, 4, 0}, {3, 4, 4, 4}};
+      constexpr int NS = WV == 3 ? 3 : 4;
+      double4_t a2[4];
 #pragma unroll
-      for (int sidx = 0; sidx < NT + NE; ++sidx) acc[sidx] = rq[RQ_REG ? sidx : 0];
-    } else {
+      for (int i = 0; i < 4; ++i) a2[i] = rq[i];
 #pragma unroll
-      for (int c = 0; c < NT; ++c) acc[c] = rqr_tile(w, c);
+      for (int kc = 0; kc < NT; ++kc) {
 #pragma unroll
-      for (int e = 0; e < NE; ++e) acc[NT + e] = rqr_tile(er[e], ec[e]);
-    }
+        for (int s = 0; s < 4; ++s) {
+          const int kk = 16 * kc + 4 * lk + s;
+          const double* wrow = Wm + li * LD + kk;   // W'[kk][16 C + li] = W[16 C + li][kk]
 #pragma unroll
-    for (int kc = 0; kc < NT; ++kc) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int kk = 16 * kc + 4 * lk + s;
-        const double* wrow = Wm + li * LD + kk;   // W'[kk][16 C + li] = W[16 C + li][kk]
-#pragma unroll
-        for (int c = 0; c < NT; ++c)
-          acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(tfr[0][kc][s], wrow[16 * c * LD], acc[c], 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
-          const double ae = (NR > 2 && er[e] == 5) ? tfr[NR - 1][kc][s] : tfr[1][kc][s];
-          acc[NT + e] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, wrow[16 * ec[e] * LD], acc[NT + e], 0, 0, 0);
+          for (int i = 0; i < NS; ++i)
+            a2[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(tfr[SQ[WV][i]][kc][s], wrow[16 * SC[WV][i] * LD], a2[i], 0, 0, 0);
         }
       }
-    }
-    // (P is not read by this product: the new tiles go straight in)
-    auto put = [&](int R, int C, const double4_t& v) {
+      // (P is not read by this product: the new tiles go straight in, each into both triangles)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) Pm[(16 * R + lk + 4 * rg) * LD + 16 * C + li] = v[rg];
+      for (int i = 0; i < NS; ++i) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int R = SQ[WV][i] ? 4 : WV, C = SC[WV][i];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          Pm[(16 * R + lk + 4 * rg) * LD + 16 * C + li] = a2[i][rg];
+          if (R != C) Pm[(16 * C + li) * LD + 16 * R + lk + 4 * rg] = a2[i][rg];
+        }
+      }
     };
-#pragma unroll
-    for (int c = 0; c < NT; ++c) put(w, c, acc[c]);
-#pragma unroll
-    for (int e = 0; e < NE; ++e)
-      if (eon[e]) put(er[e], ec[e], acc[NT + e]);
+    switch (w) {
+      case 0: sym_product(std::integral_constant<int, 0>{}); break;
+      case 1: sym_product(std::integral_constant<int, 1>{}); break;
+      case 2: sym_product(std::integral_constant<int, 2>{}); break;
+      default: sym_product(std::integral_constant<int, 3>{}); break;
+    }
     __syncthreads();
   }
   if (tid == 0) {
@@ -480,7 +492,8 @@ __global__ __launch_bounds__(64 * NW) void kf_fwd_wgl_range_kernel(const KfFwdAr
     }
     __syncthreads();
     auto products = [&](auto vtag) {
-      constexpr int V = decltype(vtag)::value;
+      constexpr int WV = decltype(vtag)::value;   // the wavefront
+      constexpr int V = WV & 1;                   // the shape of its nine tiles in the first product
       constexpr bool OWN0 = V == 0;   // a_hat of tile row R: the wavefront whose range holds tile (R, 0)
 #define TQ(i) ((V == 0) ? ((i) >= 6 ? 1 : 0) : ((i) >= 3 ? 1 : 0))
 #define TC(i) ((V == 0) ? ((i) >= 6 ? (i) - 6 : (i)) : ((i) >= 3 ? (i) - 3 : (i) + 3))
@@ -540,41 +553,53 @@ __global__ __launch_bounds__(64 * NW) void kf_fwd_wgl_range_kernel(const KfFwdAr
       }
     }
     __syncthreads();
-    // (f) P <- T W' + R Q R'
-    // (R Q R' from L2 at every step)
+    // (f) P <- T W' + R Q R', symmetric: 21 of the 36 tiles, at most six per wavefront instead of nine, written to both triangles.
+    //     wavefront 0 (rows 0, 1): (0,0..5); 1 (rows 1, 2): (1,1..4), (2,2); 2 (rows 3, 4): (3,3), (3,4), (3,2), (4,2), (4,4);
+    //     3 (rows 4, 5): (5,1), (5,2), (5,3), (4,5), (5,5).  R Q R' from L2 at every step.
+    {
+      constexpr int SQ[4][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 1, 1}, {0, 0, 0, 1, 1, 1}, {1, 1, 1, 0, 1, 1}};
+      constexpr int SC[4][6] = {{0, 1, 2, 3, 4, 5}, {1, 2, 3, 4, 2, 2}, {3, 4, 2, 2, 4, 4}, {1, 2, 3, 5, 5, 5}};
+      constexpr int NS = WV == 0 ? 6 : 5;
+      double4_t a2[6];
 #pragma unroll
-    for (int i = 0; i < MAXT; ++i) {
+      for (int i = 0; i < NS; ++i) {
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int row = 16 * (R0 + TQ(i)) + lk + 4 * rg, col = 16 * TC(i) + li;
-        acc[i][rg] = (row < m && col < m) ? RQRb[(long)row * m + col] : 0.0;
+        for (int rg = 0; rg < 4; ++rg) {
+          const int row = 16 * (R0 + SQ[WV][i]) + lk + 4 * rg, col = 16 * SC[WV][i] + li;
+          a2[i][rg] = (row < m && col < m) ? RQRb[(long)row * m + col] : 0.0;
+        }
       }
-    }
 #pragma unroll
-    for (int kc = 0; kc < NT; ++kc) {
-      wave_lds_fence();
+      for (int kc = 0; kc < NT; ++kc) {
+        wave_lds_fence();
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int kk = 16 * kc + 4 * lk + s;
-        const double* wrow = Wm + li * LD + kk;
+        for (int s = 0; s < 4; ++s) {
+          const int kk = 16 * kc + 4 * lk + s;
+          const double* wrow = Wm + li * LD + kk;
 #pragma unroll
-        for (int i = 0; i < MAXT; ++i) {
-          const double ae = TQ(i) ? tfr[1][kc][s] : tfr[0][kc][s];
-          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, wrow[16 * TC(i) * LD], acc[i], 0, 0, 0);
+          for (int i = 0; i < NS; ++i)
+            a2[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(tfr[SQ[WV][i]][kc][s], wrow[16 * SC[WV][i] * LD], a2[i], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int R = R0 + SQ[WV][i], C = SC[WV][i];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          Pm[(16 * R + lk + 4 * rg) * LD + 16 * C + li] = a2[i][rg];
+          if (R != C) Pm[(16 * C + li) * LD + 16 * R + lk + 4 * rg] = a2[i][rg];
         }
       }
     }
-#pragma unroll
-    for (int i = 0; i < MAXT; ++i)
-      {
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) Pm[(16 * (R0 + TQ(i)) + lk + 4 * rg) * LD + 16 * TC(i) + li] = acc[i][rg];
-      }
 #undef TQ
 #undef TC
     };
-    if (w & 1) products(std::integral_constant<int, 1>{});
-    else products(std::integral_constant<int, 0>{});
+    switch (w) {
+      case 0: products(std::integral_constant<int, 0>{}); break;
+      case 1: products(std::integral_constant<int, 1>{}); break;
+      case 2: products(std::integral_constant<int, 2>{}); break;
+      default: products(std::integral_constant<int, 3>{}); break;
+    }
     __syncthreads();
   }
   if (tid == 0) {

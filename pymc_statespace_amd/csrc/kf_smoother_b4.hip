@@ -178,9 +178,10 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   bool have_x = false, bad = false;
   // The filter's covariance converges (kalman_filter.py:215-252 repeats one and the same update from then on); the tape then holds
   // the SAME P_f step after step, and with it P_hat, its inverse and X_e = P_hat^-1 T P_f are the last step's.  A step whose filtered
-  // covariance differs from the previous step's (the one after it in time) by at most tol_f = 1e-15 x the largest entry, everywhere,
+  // covariance differs from the previous step's (the one after it in time) by at most tol_f = 2.5e-16 x the largest entry (one unit in its last place), everywhere,
   // reuses X_e (in TA, both layouts), and the P_hat in TH: three products (U for T a_f, E, S_s) instead of six, no residual, no norm.
-  // At most SB4_REUSE steps in a row (the drift since the full step stays below 3e-14); any other step -- the start of a series, a
+  // At most SB4_REUSE steps in a row (the drift since the full step stays below 8e-15, zero on the bitwise-constant tapes a
+  // steady-state forward writes; at 1e-15 a fuzz case with cond(P_hat) ~ 1e3 differed by 2.6e-11 from every step in full); any other step -- the start of a series, a
   // missing observation -- takes the full path.  KF_FLAG_EXACT_RECURSION: never.
   double tol_f = -1.0;
   bool st = false;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
 #pragma unroll
       for (int I = 0; I < NB; ++I)
         if (on_mm[I]) mx = max(mx, abs_hi(Sf[I]));
-      tol_f = 1e-15 * wave_absmax_hi(mx);
+      tol_f = 2.5e-16 * wave_absmax_hi(mx);
     }
     reused = 0;
     }

@@ -84,7 +84,7 @@ for case in range(n_cases):
         e2 = max(rel(sa.cpu().numpy(), ea.cpu().numpy()), rel(sP.cpu().numpy(), eP.cpu().numpy()))
         worst["smooth_b4"] = max(worst["smooth_b4"], e)
         worst["smooth_b4_vs_full"] = max(worst["smooth_b4_vs_full"], e2)
-        if e > 1e-9 or e2 > 1e-11:
+        if e > 1e-9 or e2 > 3e-11:  # (the inverse amplifies the tolerated drift of the tape by cond(P_hat))
             flagged += 1
             print(f"FLAG block smoother case {case}: m={m} n={n} B={B}: vs oracle {e:.2e} vs every step in full {e2:.2e}", flush=True)
         counts["smooth_b4"] += 1
