@@ -112,7 +112,7 @@ enum {
    * KF_STEADY_STATE=0 in the environment has the same effect as this flag, KF_STEADY_STATE=1 that of KF_FLAG_STEADY_STATE.
    * kf_smoother honours the flag too: by default the block smoother (5 <= m <= 15, kf_smoother_b4.hip) and the lane smoother (m <= 2)
    * reuse the last step's gain X = P_hat^-1 T P_f wherever the FILTERED covariance on the tape has stopped moving (one-step change
-   * <= 1e-15 of its largest entry, at most 32 steps in a row; any step that is not -- the start of a series, a missing
+   * <= one unit in the last place of its largest entry -- m <= 2: 1e-15 of it -- at most 32 steps in a row; any step that is not -- the start of a series, a missing
    * observation -- is done in full); with the flag the prediction covariance is inverted at every step, as
    * kalman_smoother.py:87-97 does.  KF_SMOOTHER_STEADY=0 in the environment has the same effect. */
   KF_FLAG_EXACT_RECURSION = 1u << 12,
