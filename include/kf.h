@@ -111,10 +111,9 @@ enum {
    * covariance tapes and time-parallel mean recursion from separate kernels on a second stream (kf_forward_b4_steady.hip).
    * KF_STEADY_STATE=0 in the environment has the same effect as this flag, KF_STEADY_STATE=1 that of KF_FLAG_STEADY_STATE.
    * kf_smoother honours the flag too: by default the block smoother (5 <= m <= 15, kf_smoother_b4.hip) and the lane smoother (m <= 2)
-   * reuse the last step's gain X = P_hat^-1 T P_f wherever the FILTERED covariance on the tape has stopped moving (one-step change
-   * <= one unit in the last place of its largest entry -- m <= 2: 1e-15 of it -- at most 32 steps in a row; any step that is not -- the start of a series, a missing
-   * observation -- is done in full); with the flag the prediction covariance is inverted at every step, as
-   * kalman_smoother.py:87-97 does.  KF_SMOOTHER_STEADY=0 in the environment has the same effect. */
+   * reuse the last step's gain X = P_hat^-1 T P_f wherever the FILTERED covariance on the tape is bit for bit the next step's (the
+   * constant tapes a steady-state forward writes) instead of inverting the same matrix again; with the flag the prediction covariance
+   * is inverted at every step, as kalman_smoother.py:87-97 does.  KF_SMOOTHER_STEADY=0 in the environment has the same effect. */
   KF_FLAG_EXACT_RECURSION = 1u << 12,
   /* Forward filter: use the steady-state phase wherever the selected kernel has one, whatever the series length (the block
    * kernel's default depends on it, see above).  KF_FLAG_EXACT_RECURSION wins when both are set. */

@@ -43,7 +43,6 @@ struct Sb4Lds {
 };
 static_assert(Sb4Lds<3>::TOTAL <= 1280, "four wavefronts per SIMD need <= 10 KiB of LDS per wavefront");
 constexpr int SB4_MAXIT = 64;
-constexpr int SB4_REUSE = 32;
 
 // max over the wavefront, in every lane: DPP row rotations, then the two lane-swap levels (no LDS)
 __device__ __forceinline__ double wave_allmax_dpp(double x) {
@@ -178,14 +177,17 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   bool have_x = false, bad = false;
   // The filter's covariance converges (kalman_filter.py:215-252 repeats one and the same update from then on); the tape then holds
   // the SAME P_f step after step, and with it P_hat, its inverse and X_e = P_hat^-1 T P_f are the last step's.  A step whose filtered
-  // covariance differs from the previous step's (the one after it in time) by at most tol_f = 2.5e-16 x the largest entry (one unit in its last place), everywhere,
-  // reuses X_e (in TA, both layouts), and the P_hat in TH: three products (U for T a_f, E, S_s) instead of six, no residual, no norm.
-  // At most SB4_REUSE steps in a row (the drift since the full step stays below 8e-15, zero on the bitwise-constant tapes a
-  // steady-state forward writes; at 1e-15 a fuzz case with cond(P_hat) ~ 1e3 differed by 2.6e-11 from every step in full); any other step -- the start of a series, a
-  // missing observation -- takes the full path.  KF_FLAG_EXACT_RECURSION: never.
-  double tol_f = -1.0;
+  // covariance is BIT FOR BIT the previous step's (the one after it in time) -- what a steady-state forward writes (C3, C4: constant
+  // fills), and what an every-step recursion arrives at once it has reached its floating-point fixpoint -- reuses X_e (in TA, both
+  // layouts) and the P_hat in TH: three products (U for T a_f, E, S_s) instead of six, no residual, no norm.  The full step would have
+  // found its warm start's residual below 1e-13 and recomputed the same X_e from the same operands: the results do not change.
+  // Any other step -- the start of a series, a missing observation, a tape that still moves in its last place -- takes the full path.
+  // (Tolerances were tried first: 1e-15 of the largest entry, 32 steps in a row -- a fuzz case with cond(P_hat) ~ 1e3 came out 2.6e-11
+  // away from every step in full, the inverse amplifies the drift; one unit in the last place of sqrt(P_ii P_jj), entry by entry -- its
+  // LDS round trip for the diagonal cost the headline shape 8 %, where the tapes of an every-step forward rarely qualify anyway.)
+  // KF_FLAG_EXACT_RECURSION: never.
+  bool have_ref = false;
   bool st = false;
-  int reused = 0;
 
   for (int t = n - 2; t >= 0 && !bad; --t) {
     double Sf[NB];
@@ -333,14 +335,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     }
     have_x = true;
     if (bad) break;
-    if (!A.exact) {
-      unsigned mx = 0u;
-#pragma unroll
-      for (int I = 0; I < NB; ++I)
-        if (on_mm[I]) mx = max(mx, abs_hi(Sf[I]));
-      tol_f = 2.5e-16 * wave_absmax_hi(mx);
-    }
-    reused = 0;
+    have_ref = !A.exact;
     }
     if (t > 0) prefetch();
     // ---- X_e = X U^ ;  E = D X_e ;  S_s = S_f + X_e' E ---------------------------------------------------------------------------
@@ -384,13 +379,12 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     if (!st) to_tile(TA, Xe);
     // the next step (t - 1, its tile is on its way into PN): may it reuse this step's X_e?
     st = false;
-    if (tol_f >= 0.0 && t > 0 && reused < SB4_REUSE) {
+    if (have_ref && t > 0) {
       bool off = false;
 #pragma unroll
-      for (int I = 0; I < NB; ++I) off |= on_mm[I] && !(fabs(PN[I] - Sf[I]) <= tol_f);
+      for (int I = 0; I < NB; ++I) off |= on_mm[I] && !(PN[I] == Sf[I]);
       st = __ballot(off) == 0;
     }
-    reused = st ? reused + 1 : 0;
 #pragma unroll
     for (int K = 0; K < NB; ++K) {  // left factor (X_e')(I, K): lane (g = k, any b, q = i) holds X_e[4K+g][4I+q]
       const double* ls = TA + (4 * K + g) * TRS + 4 * q;

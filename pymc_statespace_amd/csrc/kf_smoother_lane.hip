@@ -167,15 +167,12 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lane_kernel(const KfSmoothA
 #pragma unroll
     for (int j = 0; j < M; ++j) Ps[i][j] = 0.0;
   }
-  // m <= 2: where the filtered covariance of EVERY draw of the wavefront has stopped moving (one-step change <= 1e-15 x the larger
-  // of its largest entry and P_hat's largest diagonal entry: C2's P_f goes to zero, P_hat to R Q R') the last X and P_hat are reused --
-  // no Cholesky, no Jacobi rotation -- at most 32 steps in a row (kf_smoother_b4.hip does the same per draw).  KF_FLAG_EXACT_RECURSION:
-  // never.
+  // m <= 2: where the filtered covariance of EVERY draw of the wavefront is bit for bit the previous step's (the constant tapes a
+  // steady-state forward writes; an every-step tape at its floating-point fixpoint) the last X and P_hat are reused -- no Cholesky, no
+  // Jacobi rotation; the results are those of the full step (kf_smoother_b4.hip does the same per draw).  KF_FLAG_EXACT_RECURSION: never.
   constexpr bool REUSE = M <= 2;
   double Xk[REUSE ? M : 1][REUSE ? M : 1], Phk[REUSE ? M : 1][REUSE ? M : 1], Pfk[REUSE ? M : 1][REUSE ? M : 1];
-  double dk = 0.0;
   bool have_k = false;
-  int reused = 0;
   for (int t0 = ((n - 1) / S) * S; t0 >= 0; t0 -= S) {
     const int cnt = (n - t0) < S ? (n - t0) : S;
     copy(std::true_type{}, A.filt_a, nullptr, smem + L::OFF_FA, L::W_A, std::integral_constant<int, M>{}, t0, cnt);
@@ -207,17 +204,12 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lane_kernel(const KfSmoothA
         }
         bool reuse = false;
         if constexpr (REUSE) {
-          if (have_k && !A.exact && reused < 32) {
-            double pmax = dk;
+          if (have_k && !A.exact) {
             bool same = true;
 #pragma unroll
             for (int i = 0; i < M; ++i)
 #pragma unroll
-              for (int j = 0; j < M; ++j) pmax = fmax(pmax, fabs(Pf[i][j]));
-#pragma unroll
-            for (int i = 0; i < M; ++i)
-#pragma unroll
-              for (int j = 0; j < M; ++j) same = same && (fabs(Pf[i][j] - Pfk[i][j]) <= 1e-15 * pmax);
+              for (int j = 0; j < M; ++j) same = same && (Pf[i][j] == Pfk[i][j]);
             reuse = __all(same || !live);
           }
 #pragma unroll
@@ -226,7 +218,6 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lane_kernel(const KfSmoothA
             for (int j = 0; j < M; ++j) Pfk[i][j] = Pf[i][j];
         }
         if (reuse) {
-          ++reused;
           if constexpr (REUSE) {
 #pragma unroll
             for (int i = 0; i < M; ++i)
@@ -237,7 +228,6 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lane_kernel(const KfSmoothA
               }
           }
         } else {
-        reused = 0;
 #pragma unroll
         for (int i = 0; i < M; ++i) {
 #pragma unroll
@@ -320,7 +310,6 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_lane_kernel(const KfSmoothA
         }
         if constexpr (REUSE) {
           have_k = true;
-          dk = dmax;
 #pragma unroll
           for (int i = 0; i < M; ++i)
 #pragma unroll

@@ -375,7 +375,7 @@ class KalmanEngine:
         the forward filter's pairing) or slice t + 1 (``pairing="reference"``: what the reference's own scan hands its step,
         kalman_smoother.py:62-77 -- for parity with a model ported from upstream).  ``exact_recursion=True``
         (KF_FLAG_EXACT_RECURSION): the prediction covariance is inverted at every step, also where the filtered covariance on the
-        tape has stopped moving (5 <= m <= 15: kf_smoother_b4.hip reuses the last step's gain there by default)."""
+        tape is bit for bit the next step's (5 <= m <= 15, m <= 2: the smoothers reuse the last step's gain there by default)."""
         if pairing not in ("filter", "reference"):
             raise ValueError("pairing must be 'filter' or 'reference'")
         tv = set(time_varying)

@@ -343,22 +343,24 @@ def test_split_pipeline_and_steady_adjoint_replay_from_a_hip_graph(eng):
 
 @pytest.mark.parametrize("m", [5, 8, 10, 12, 15])
 def test_block_smoother_reuses_the_gain_of_a_converged_filter(eng, m):
-    """kf_smoother_b4.hip: where the filtered covariance on the tape has stopped moving (one-step change <= 1e-15 x its largest entry)
-    the step reuses the last X_e = P_hat^-1 T P_f (at most 32 steps in a row); a missing stretch in the middle of the series moves the
-    covariance again and the full path takes over.  Against the pinv oracle (kalman_smoother.py:56-104) and against every step in full
+    """kf_smoother_b4.hip: where the filtered covariance on the tape is bit for bit the next step's (a steady-state forward's constant
+    tapes) the step reuses the last X_e = P_hat^-1 T P_f; a missing stretch in the middle of the series moves the covariance again
+    and the full path takes over.  Against the pinv oracle (kalman_smoother.py:56-104) and against every step in full
     (KF_FLAG_EXACT_RECURSION), on the tapes of both forward modes."""
     import torch
 
     w = W.random_dense(7, 600, 1, m, m, seed=260 + m)
     y = w["y"].copy()
-    y[300:309] = np.nan
-    y[450] = np.nan
+    y[100:109] = np.nan
+    y[200] = np.nan
     for exact_fwd in (True, False):
         res = eng.forward(y, *[w[k] for k in KEYS], exact_recursion=exact_fwd, store_ll_obs=False, store_predicted=False)
         fa, fP = res.filtered_states, res.filtered_covs
         # the tape does converge: otherwise this test exercises nothing
         d = (fP[:, 590] - fP[:, 589]).abs().flatten(1).max(1).values / fP[:, 590].abs().flatten(1).max(1).values
         assert int((d <= 1e-15).sum()) >= 4   # (a slow draw or two among the seven keep moving: the full path beside the reuse)
+        if not exact_fwd and m <= 10:
+            assert int((d == 0.0).sum()) >= 4  # the steady-state forward's tapes (p = 1: m <= 10) are constant to the bit: the reuse runs
         ra, rP = kn.kalman_smoother(w["T"], w["R"], w["Q"], fa.cpu().numpy(), fP.cpu().numpy())
         sa, sP = eng.smooth(w["T"], w["R"], w["Q"], fa, fP)
         ea, eP = eng.smooth(w["T"], w["R"], w["Q"], fa, fP, exact_recursion=True)
@@ -366,3 +368,38 @@ def test_block_smoother_reuses_the_gain_of_a_converged_filter(eng, m):
         assert np.abs(sa.cpu().numpy() - ra).max() / sc_a < 1e-11 and np.abs(sP.cpu().numpy() - rP).max() / sc_P < 1e-11
         assert float((sa - ea).abs().max()) / sc_a < 1e-12 and float((sP - eP).abs().max()) / sc_P < 1e-12
         assert torch.equal(sa[:, -1], fa[:, -1]) and torch.equal(sP[:, -1], fP[:, -1])
+
+
+def test_block_smoother_reuse_test_is_entrywise(eng):
+    """A diffuse, large-variance level beside five slowly converging small AR(1) components (the forward kernels' ADVICE case, one
+    size up): the smoother's gain reuse must not treat the tape as converged while the small block still moves -- every entry of the
+    smoothed covariance stays within 1e-9 of its own scale sqrt(P_ii P_jj) of the every-step result, the small block's diagonal
+    within 1e-9 relative."""
+    import torch
+
+    B, n, m = 12, 1500, 6
+    rng = np.random.default_rng(9)
+    rho = 0.999 - 0.002 * np.arange(m - 1)
+    T = np.zeros((B, m, m)); T[:, 0, 0] = 1.0
+    for i in range(1, m):
+        T[:, i, i] = rho[i - 1]
+    Z = np.ones((B, 1, m))
+    R = np.repeat(np.eye(m)[None], B, 0)
+    Q = np.zeros((B, m, m)); Q[:, 0, 0] = 1e4 * (1 + rng.random(B))
+    P0 = np.zeros((B, m, m)); P0[:, 0, 0] = 1e7
+    for i in range(1, m):
+        Q[:, i, i] = 1e-4 * (1 + rng.random(B))
+        P0[:, i, i] = 1e-4 / (1 - rho[i - 1] ** 2) * 50
+    H = np.full((B, 1, 1), 1e4)
+    y = np.cumsum(100 * rng.standard_normal(n))[:, None]
+    res = eng.forward(y, np.zeros((B, m)), P0, T, Z, R, H, Q, mvn_const="exact", exact_recursion=True, store_ll_obs=False,
+                      store_predicted=False)
+    fa, fP = res.filtered_states, res.filtered_covs
+    sa, sP = eng.smooth(T, R, Q, fa, fP)
+    ea, eP = eng.smooth(T, R, Q, fa, fP, exact_recursion=True)
+    d = torch.diagonal(eP, dim1=-2, dim2=-1)
+    scale = torch.sqrt(d.unsqueeze(-1) * d.unsqueeze(-2))
+    assert float(((sP - eP).abs() / scale).max()) < 1e-9
+    ds = torch.diagonal(sP, dim1=-2, dim2=-1)
+    assert float(((ds - d).abs() / d)[..., 1:].max()) < 1e-9
+    assert float((sa - ea).abs().max()) < 1e-7 * float(ea.abs().max())
