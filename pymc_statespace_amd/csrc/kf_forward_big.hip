@@ -848,6 +848,25 @@ __global__ __launch_bounds__(256) void big_sym_kernel(const double* __restrict__
 
 }  // namespace
 
+// The m x m x m product of this file for other callers (kf_smoother_big.hip): C = A op(B) (+ E) per draw, leading dimension m,
+// per-draw strides in doubles.  upper_mirror (needs add_e): C is symmetric -- only the tiles that touch the upper triangle are
+// computed and every element is written to both triangles.
+int kf_big_gemm_launch(hipStream_t st, bool trans_b, bool add_e, bool upper_mirror, const double* A, long sA, const double* Bm,
+                       long sB, const double* E, long sE, double* C, long sC, int m, long draws) {
+  const int tgm = (m + GTM - 1) / GTM, tgn = (m + GTN - 1) / GTN;
+  const unsigned ggrid = (unsigned)(8L * tgn * tgm * ((draws + 7) / 8));
+  const BigGemmExtra x0 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0L, nullptr, 0L, nullptr, nullptr, nullptr};
+  if (!trans_b && !add_e && !upper_mirror)
+    hipLaunchKernelGGL((big_gemm_kernel<false, false>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x0);
+  else if (trans_b && add_e && upper_mirror)
+    hipLaunchKernelGGL((big_gemm_kernel<true, true, true, false, true>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x0);
+  else if (!trans_b && add_e && upper_mirror)
+    hipLaunchKernelGGL((big_gemm_kernel<false, true, true, false, true>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x0);
+  else
+    return KF_ERR_UNSUPPORTED;
+  return hipGetLastError() == hipSuccess ? KF_OK : KF_ERR_HIP;
+}
+
 size_t kf_forward_big_workspace_bytes(long B, int m, int p) {
   size_t mm = (size_t)m * m;
   const size_t tiles = (size_t)((m + GTM - 1) / GTM + (m + GTN - 1) / GTN);  // shares of m = P z per tile row / tile column

@@ -235,6 +235,9 @@ bool kf_forward_wgl_ok(int m, int p, unsigned flags, bool cov_tapes);
 size_t kf_forward_wgl_workspace_bytes(long B, int m);
 int kf_launch_forward_wgl(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream);
 size_t kf_forward_big_workspace_bytes(long B, int m, int p);
+// kf_forward_big.hip's 128 x 64-tile fp64-MFMA product for m x m operands (see there)
+int kf_big_gemm_launch(hipStream_t st, bool trans_b, bool add_e, bool upper_mirror, const double* A, long sA, const double* Bm,
+                       long sB, const double* E, long sE, double* C, long sC, int m, long draws);
 int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
                           hipStream_t stream);
 inline bool kf_forward_lds_fits(int m, int p) {

@@ -574,13 +574,23 @@ int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace,
                      a.smooth_P, n, m);
   const long sTape = (long)n * mm;
   const unsigned tb = (unsigned)((m + 31) / 32);
+  // KF_SMOOTHER_BIG_GEMM=0: the four full-size products on this file's own kernel (A/B measurements); m < 128: its smaller tiles fit better
+  const char* bge = getenv("KF_SMOOTHER_BIG_GEMM");
+  const bool big_full = m >= 128 && !(bge && bge[0] == '0');
   for (int t = n - 2; t >= 0; --t) {
     const double* Pf = a.filt_P + (long)t * mm;
     const double* Psn = a.smooth_P + (long)(t + 1) * mm;
     double* Ps = a.smooth_P + (long)t * mm;
     // W = T P_f ; P_hat = W T' + RQR' ; D = P_s[t+1] - P_hat
-    gemm<false, EPI_STORE>(st, B, a.Tm, mm, m, Pf, sTape, m, nullptr, 0, 0, W, mm, m, m, m, m);
-    gemm<true, EPI_ADD>(st, B, W, mm, m, a.Tm, mm, m, RQR, mm, m, PH, mm, m, m, m, m);
+    // (the four full-size products on kf_forward_big.hip's 128 x 64-tile kernel, the symmetric ones on the tiles that touch the upper
+    //  triangle with both triangles written: 334 / 346 / 335 / 419 us on this file's 64 x 64-tile kernel -> 270 / 255 / 270 / 255 at C5)
+    if (big_full) {
+      kf_big_gemm_launch(st, false, false, false, a.Tm, mm, Pf, sTape, nullptr, 0, W, mm, m, B);
+      kf_big_gemm_launch(st, true, true, true, W, mm, a.Tm, mm, RQR, mm, PH, mm, m, B);
+    } else {
+      gemm<false, EPI_STORE>(st, B, a.Tm, mm, m, Pf, sTape, m, nullptr, 0, 0, W, mm, m, m, m, m);
+      gemm<true, EPI_ADD>(st, B, W, mm, m, a.Tm, mm, m, RQR, mm, m, PH, mm, m, m, m, m);
+    }
     hipLaunchKernelGGL(sb_sub_kernel, dim3(eb, (unsigned)B), dim3(256), 0, st, Psn, sTape, PH, mm, Dm, mm, mm);
     hipLaunchKernelGGL(sb_scale_kernel, dim3((unsigned)B), dim3(256), 0, st, PH, mm, m, scale);
     // blocked Cholesky of P_hat (lower, in place)
@@ -617,9 +627,11 @@ int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace,
       if (k1 > 0) gemm<false, EPI_RSUB>(st, B, U + k1, mm, m, Wk, mm, m, W, mm, m, W, mm, m, k1, m, nb);
     }
     // E = D X ; G = X' ; P_s[t] = G E + P_f[t] ; a_s[t]
-    gemm<false, EPI_STORE>(st, B, Dm, mm, m, W, mm, m, nullptr, 0, 0, Em, mm, m, m, m, m);
+    if (big_full) kf_big_gemm_launch(st, false, false, false, Dm, mm, W, mm, nullptr, 0, Em, mm, m, B);
+    else gemm<false, EPI_STORE>(st, B, Dm, mm, m, W, mm, m, nullptr, 0, 0, Em, mm, m, m, m, m);
     hipLaunchKernelGGL(sb_transpose_kernel, dim3(tb, tb, (unsigned)B), dim3(256), 0, st, W, mm, U, mm, m);
-    gemm<false, EPI_ADD>(st, B, U, mm, m, Em, mm, m, Pf, sTape, m, Ps, sTape, m, m, m, m);
+    if (big_full) kf_big_gemm_launch(st, false, true, true, U, mm, Em, mm, Pf, sTape, Ps, sTape, m, B);
+    else gemm<false, EPI_ADD>(st, B, U, mm, m, Em, mm, m, Pf, sTape, m, Ps, sTape, m, m, m, m);
     hipLaunchKernelGGL(sb_avec_kernel, dim3((unsigned)B), dim3(256), sizeof(double) * 2 * m, st, a.Tm, U, mm,
                        a.filt_a, a.smooth_a, n, m, t);
   }
