@@ -343,6 +343,8 @@ int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, si
   const size_t sh_f = sizeof(double) * (m + NT / KF_WAVE);
   const size_t sh_a = sizeof(double) * (4 * m + NT + NT / KF_WAVE);
   const long sTape = (long)(n + 1) * mm;
+  const char* bge = getenv("KF_SMOOTHER_BIG_GEMM");
+  const bool big_full = m >= 128 && !(bge && bge[0] == '0');
   for (int t = n - 1; t >= 0; --t) {
     // ab_f = T' ab'
     hipLaunchKernelGGL(bb_colmatvec_kernel, dim3(cc, (unsigned)B), dim3(NT), sh_mv, st, a.Tm, mm, W.abp, (long)m,
@@ -355,10 +357,18 @@ int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, si
       hipLaunchKernelGGL(bb_fwd_update_kernel, dim3(rc, (unsigned)B), dim3(NT), sh_f, st, a, W, t, qq);
     }
     // X1 = Pb T ; Sb = X1' T ; Tb_m += X1 P_f
-    kf_sb_gemm(st, B, false, 0, W.PB, mm, m, a.Tm, mm, m, nullptr, 0, 0, X1, mm, m, m, m, m);
-    kf_sb_transpose(st, B, X1, mm, X1t, mm, m);
-    kf_sb_gemm(st, B, false, 0, X1t, mm, m, a.Tm, mm, m, nullptr, 0, 0, W.SB, mm, m, m, m, m);
-    kf_sb_gemm(st, B, false, 1, X1, mm, m, W.Pc, mm, m, TBm, mm, m, TBm, mm, m, m, m, m);
+    // (m >= 128: on kf_forward_big.hip's 128 x 64-tile product, 270 against 335 us per launch at C5; KF_SMOOTHER_BIG_GEMM=0: this file's)
+    if (big_full) {
+      kf_big_gemm_launch(st, false, false, false, W.PB, mm, a.Tm, mm, nullptr, 0, X1, mm, m, B);
+      kf_sb_transpose(st, B, X1, mm, X1t, mm, m);
+      kf_big_gemm_launch(st, false, false, false, X1t, mm, a.Tm, mm, nullptr, 0, W.SB, mm, m, B);
+      kf_big_gemm_launch(st, false, true, false, X1, mm, W.Pc, mm, TBm, mm, TBm, mm, m, B);
+    } else {
+      kf_sb_gemm(st, B, false, 0, W.PB, mm, m, a.Tm, mm, m, nullptr, 0, 0, X1, mm, m, m, m, m);
+      kf_sb_transpose(st, B, X1, mm, X1t, mm, m);
+      kf_sb_gemm(st, B, false, 0, X1t, mm, m, a.Tm, mm, m, nullptr, 0, 0, W.SB, mm, m, m, m, m);
+      kf_sb_gemm(st, B, false, 1, X1, mm, m, W.Pc, mm, m, TBm, mm, m, TBm, mm, m, m, m, m);
+    }
     double* ain = W.abfA;
     double* aother = W.abfB;
     for (int qq = p - 1; qq >= 0; --qq) {

@@ -862,6 +862,8 @@ int kf_big_gemm_launch(hipStream_t st, bool trans_b, bool add_e, bool upper_mirr
     hipLaunchKernelGGL((big_gemm_kernel<true, true, true, false, true>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x0);
   else if (!trans_b && add_e && upper_mirror)
     hipLaunchKernelGGL((big_gemm_kernel<false, true, true, false, true>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x0);
+  else if (!trans_b && add_e && !upper_mirror)   // (E may be C itself: every element is read and written by the same thread)
+    hipLaunchKernelGGL((big_gemm_kernel<false, true>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x0);
   else
     return KF_ERR_UNSUPPORTED;
   return hipGetLastError() == hipSuccess ? KF_OK : KF_ERR_HIP;
