@@ -193,3 +193,21 @@ def test_workspace_smoother_pinv_for_singular_prediction_covariance(eng):
     assert_allclose(sa[0], ra[0], rtol=1e-6, atol=1e-6)
     assert_allclose(sP[0], rP[0], rtol=1e-6, atol=1e-6)
     assert_allclose(sP[0, :, 0, :], sP[0, :, 1, :], rtol=0, atol=1e-7)   # the two states stay perfectly correlated
+
+
+@pytest.mark.parametrize("m,B,n", [(97, 1, 1), (130, 1, 3), (367, 2, 2), (200, 9, 4)])
+def test_workspace_forward_fused_edge_shapes(eng, m, B, n):
+    """The three-launch step at its edges: one draw (seven empty slots in the group of eight the workgroup mapping uses), one step
+    (no share of P z from a previous step), a series that is missing from end to end."""
+    w = W.random_dense(B, n, 1, m, 3, seed=600 + m)
+    w["y"] = np.nan_to_num(w["y"], nan=0.3)   # (a one-step series standardises to NaN)
+    args = (w["y"],) + tuple(w[k] for k in KEYS)
+    ref = kn.kalman_filter(*args, mvn_const="exact")
+    res = eng.forward(*args, mvn_const="exact", store_filtered=False, store_predicted=True)
+    assert not res.info.cpu().numpy().any()
+    assert_allclose(res.logp.cpu().numpy(), ref["logp"], rtol=1e-11, atol=1e-12)
+    assert_allclose(res.predicted_states.cpu().numpy(), ref["predicted_states"], rtol=1e-9, atol=1e-10)
+    assert_allclose(res.predicted_covs.cpu().numpy(), ref["predicted_covs"], rtol=1e-9, atol=1e-10)
+    y = np.full_like(w["y"], np.nan)
+    res = eng.forward(y, *[w[k] for k in KEYS], mvn_const="exact", store_filtered=False, store_predicted=False)
+    assert np.array_equal(res.logp.cpu().numpy(), np.zeros(B))

@@ -75,3 +75,19 @@ def test_lds_resident_forward_long_series_and_per_draw_data(eng):
                       store_predicted=False)
     info = bad.info.cpu().numpy()
     assert info[2] == ((1 << 8) | 1) and not info[[0, 1, 3, 4, 5]].any()
+
+
+@pytest.mark.parametrize("m,B,n", [(65, 1, 1), (80, 1, 2), (96, 3, 1), (72, 300, 5)])
+def test_lds_resident_forward_edge_shapes(eng, m, B, n):
+    """One draw, one / two steps, a batch larger than the chip's 256 CUs; a series that is missing from end to end."""
+    w = W.random_dense(B, n, 1, m, m, seed=500 + m)   # r = m: a full-rank R Q R'
+    w["y"] = np.nan_to_num(w["y"], nan=0.3)   # (a one-step series standardises to NaN)
+    args = (w["y"],) + tuple(w[k] for k in KEYS)
+    ref = kn.kalman_filter(*args, mvn_const="exact")
+    res = eng.forward(*args, mvn_const="exact", store_filtered=False, store_predicted=False)
+    assert not res.info.cpu().numpy().any()
+    assert_allclose(res.logp.cpu().numpy(), ref["logp"], rtol=1e-11, atol=1e-12)
+    assert_allclose(res.ll_obs.cpu().numpy(), ref["ll_obs"], rtol=1e-10, atol=1e-11)
+    y = np.full_like(w["y"], np.nan)
+    res = eng.forward(y, *[w[k] for k in KEYS], mvn_const="exact", store_filtered=False, store_predicted=False)
+    assert np.array_equal(res.logp.cpu().numpy(), np.zeros(B)) and np.array_equal(res.ll_obs.cpu().numpy(), np.zeros((B, n)))
