@@ -221,21 +221,71 @@ __global__ __launch_bounds__(256) void sb_potrf_inv_kernel(double* A, long sA, i
     }
     __syncthreads();
   }
-  // inverse by forward substitution, one column per thread: L x = e_c
-  if (tid < nb) {
-    const int c = tid;
-    for (int i = c; i < nb; ++i) {
-      double s = (i == c) ? 1.0 : 0.0;
-      for (int k = c; k < i; ++k) s -= L[i][k] * I[k][c];
-      I[i][c] = s / L[i][i];
+  // inverse of the factor by blocks, 16 -> 32 -> 64: inv([A 0; B C]) = [inv A, 0; -inv(C) B inv(A), inv C].  (One column per thread
+  // by forward substitution -- a chain of 2000 dependent LDS reads in thread 0 -- was most of this kernel's 83 us.)
+  static_assert(NB == 64, "the block recursion below is written for 64 x 64");
+  __shared__ double T2[32][33];
+  if (tid < NB && tid >= nb) L[tid][tid] = 1.0;   // identity padding (not written back)
+  __syncthreads();
+  {  // the four diagonal 16 x 16 blocks: wavefront q, lane c < 16 = column c, the column in registers
+    const int q = tid >> 6, c = tid & 63, o = 16 * q;
+    if (c < 16) {
+      double x[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        double sv = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) sv = fma(-L[o + i][o + k], x[k], sv);
+        x[i] = (i >= c) ? sv / L[o + i][o + i] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) I[o + i][o + c] = x[i];
     }
+  }
+  __syncthreads();
+  for (int pq = 0; pq < 2; ++pq) {  // the two 32 x 32 blocks: off-diagonal 16 x 16 = -inv(C) (B inv(A)), one element per thread
+    const int a0 = 32 * pq, b0 = a0 + 16, r = tid >> 4, c = tid & 15;
+    double sv = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sv = fma(L[b0 + r][a0 + k], I[a0 + k][a0 + c], sv);
+    T2[r][c] = sv;
+    __syncthreads();
+    double uv = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) uv = fma(I[b0 + r][b0 + k], T2[k][c], uv);
+    __syncthreads();
+    I[b0 + r][a0 + c] = -uv;
+  }
+  __syncthreads();
+  {  // the 64 x 64 block: off-diagonal 32 x 32, four elements per thread
+    const int r = tid >> 3, c0 = (tid & 7) * 4;
+    double sv[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const double l = L[32 + r][k];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) sv[u] = fma(l, I[k][c0 + u], sv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) T2[r][c0 + u] = sv[u];
+    __syncthreads();
+    double uv[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const double ci = I[32 + r][32 + k];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) uv[u] = fma(ci, T2[k][c0 + u], uv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) I[32 + r][c0 + u] = -uv[u];
   }
   __syncthreads();
   for (int e = tid; e < NB * NB; e += 256) {
     const int i = e / NB, j = e - i * NB;
     if (i < nb && j <= i) Ab[(long)i * m + j] = L[i][j];
-    LINV[b * sL + e] = I[i][j];
-    LINVT[b * sL + e] = I[j][i];
+    const bool in = i < nb && j < nb;
+    LINV[b * sL + e] = in ? I[i][j] : 0.0;
+    LINVT[b * sL + e] = in ? I[j][i] : 0.0;
   }
 }
 
