@@ -316,6 +316,49 @@ __global__ __launch_bounds__(256) void sb_avec_kernel(const double* Tm, const do
   }
 }
 
+// The same in two launches over (row chunks, draws), one wavefront per row (whole lines of T / G; sb_avec_kernel runs one workgroup
+// per draw: 155 us at C5's 128 draws):  df = a_s[t+1] - T a_f[t]  ;  a_s[t] = a_f[t] + G df
+constexpr int AV_ROWS = 16;
+__global__ __launch_bounds__(256) void sb_avec1_kernel(const double* Tm, const double* filt_a, const double* smooth_a, double* df,
+                                                       int n, int m, int t) {
+  extern __shared__ double sh[];
+  const long b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double* fa = filt_a + (b * (long)n + t) * m;
+  for (int k = threadIdx.x; k < m; k += 256) sh[k] = fa[k];
+  __syncthreads();
+  const double* gT = Tm + b * (long)m * m;
+  const double* sn = smooth_a + (b * (long)n + t + 1) * m;
+  for (int rr = wave; rr < AV_ROWS; rr += 4) {
+    const int i = blockIdx.x * AV_ROWS + rr;
+    if (i >= m) break;
+    double s = 0.0;
+    for (int k = lane; k < m; k += 64) s = fma(gT[(long)i * m + k], sh[k], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) df[b * m + i] = sn[i] - s;
+  }
+}
+__global__ __launch_bounds__(256) void sb_avec2_kernel(const double* G, long sG, const double* filt_a, const double* df,
+                                                       double* smooth_a, int n, int m, int t) {
+  extern __shared__ double sh[];
+  const long b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int k = threadIdx.x; k < m; k += 256) sh[k] = df[b * m + k];
+  __syncthreads();
+  const double* Gb = G + b * sG;
+  const double* fa = filt_a + (b * (long)n + t) * m;
+  for (int rr = wave; rr < AV_ROWS; rr += 4) {
+    const int i = blockIdx.x * AV_ROWS + rr;
+    if (i >= m) break;
+    double s = 0.0;
+    for (int k = lane; k < m; k += 64) s = fma(Gb[(long)i * m + k], sh[k], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) smooth_a[(b * (long)n + t) * m + i] = fa[i] + s;
+  }
+}
+
 // scale[b] = max diag(P_hat[b]) (P_hat is PSD: its largest entry is on the diagonal)
 __global__ __launch_bounds__(256) void sb_scale_kernel(const double* PH, long sP, int m, double* scale) {
   __shared__ double red[256];
@@ -682,8 +725,11 @@ int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace,
     hipLaunchKernelGGL(sb_transpose_kernel, dim3(tb, tb, (unsigned)B), dim3(256), 0, st, W, mm, U, mm, m);
     if (big_full) kf_big_gemm_launch(st, false, true, true, U, mm, Em, mm, Pf, sTape, Ps, sTape, m, B);
     else gemm<false, EPI_ADD>(st, B, U, mm, m, Em, mm, m, Pf, sTape, m, Ps, sTape, m, m, m, m);
-    hipLaunchKernelGGL(sb_avec_kernel, dim3((unsigned)B), dim3(256), sizeof(double) * 2 * m, st, a.Tm, U, mm,
-                       a.filt_a, a.smooth_a, n, m, t);
+    // (E is free again: its first B m doubles carry df between the two launches)
+    hipLaunchKernelGGL(sb_avec1_kernel, dim3((unsigned)((m + AV_ROWS - 1) / AV_ROWS), (unsigned)B), dim3(256), sizeof(double) * m, st,
+                       a.Tm, a.filt_a, a.smooth_a, Em, n, m, t);
+    hipLaunchKernelGGL(sb_avec2_kernel, dim3((unsigned)((m + AV_ROWS - 1) / AV_ROWS), (unsigned)B), dim3(256), sizeof(double) * m, st,
+                       U, mm, a.filt_a, Em, a.smooth_a, n, m, t);
   }
   // draws whose P_hat was not safely positive definite at some step: the whole series again with pinv
   hipLaunchKernelGGL(sb_pinv_redo_kernel, dim3((unsigned)B), dim3(PNT), 0, st, a, flags, RQR, W, PH, Dm, U);
