@@ -63,7 +63,7 @@ __global__ __launch_bounds__(WL_NT_THREADS) void kf_fwd_wgl_kernel(const KfFwdAr
   double* vkf = sm + L::OFF_V + L::V_KF * MP;
   double* vz = sm + L::OFF_V + L::V_Z * MP;
   double* vc = sm + L::OFF_V + L::V_C * MP;
-  double* sc = sm + L::OFF_S;  // [0] v, [1] F, [2] 1 / sqrt F, [3] observed
+  double* sc = sm + L::OFF_S;  // [0] v, [1] F, [2] sqrt F
   const long b = blockIdx.x;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
@@ -325,8 +325,6 @@ __global__ __launch_bounds__(WL_NT_THREADS) void kf_fwd_wgl_kernel(const KfFwdAr
       // (P is not read by this product: the new tiles go straight in, each into both triangles)
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int R = SQ[WV][i] ? 4 : WV, C = SC[WV][i];
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
