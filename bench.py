@@ -102,6 +102,105 @@ def usable_cores():
     return n, quota
 
 
+class GpuTelemetry:
+    """Shader clock and socket power of the GPU this rank runs on, from the amdgpu hwmon files an ordinary user can read
+    (`/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input` in Hz, `power1_input` in uW; what `rocm-smi --showclocks
+    --showpower` prints).  The forward kernels are issue-bound, so their time follows the shader clock: an idle MI355X sits in
+    deep sleep (~100 MHz) and takes tens of milliseconds of load to reach its sustained clock (profiles/r04/clock_ramp.txt),
+    longer than the driver's 5 warm-up steps -- bench.py therefore spins the clocks up before the W warm-up steps (untimed,
+    reported as `clock_spinup`) and samples sclk / power over the timed region (`roofline.sclk_mhz`)."""
+
+    def __init__(self, torch_index=0):
+        import glob
+        self.freq = self.power = None
+        self.fmax_mhz = None
+        want = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(torch_index)
+            want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        except Exception:  # noqa: BLE001
+            want = None
+        cands = []
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")):
+            dev = os.path.realpath(os.path.join(os.path.dirname(f), "..", ".."))
+            cands.append((os.path.basename(dev), f))
+        pick = [f for bdf, f in cands if want and bdf.startswith(want)] or [f for _, f in cands[:1]]
+        if pick:
+            self.freq = pick[0]
+            pw = os.path.join(os.path.dirname(pick[0]), "power1_input")
+            self.power = pw if os.path.exists(pw) else None
+            try:
+                lv = open(os.path.join(os.path.dirname(pick[0]), "..", "..", "pp_dpm_sclk")).read()
+                self.fmax_mhz = max(float(x.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+                                    for x in lv.strip().splitlines())
+            except Exception:  # noqa: BLE001
+                self.fmax_mhz = None
+        self._stop = None
+        self.samples = []
+
+    def read(self):
+        """(sclk MHz, socket W) now, or (None, None)."""
+        try:
+            f = float(open(self.freq).read()) / 1e6 if self.freq else None
+            p = float(open(self.power).read()) / 1e6 if self.power else None
+            return f, p
+        except Exception:  # noqa: BLE001
+            return None, None
+
+    def start(self):
+        import threading
+        self.samples = []
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                self.samples.append(self.read())
+                time.sleep(0.002)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+
+    def stop(self):
+        """Summary of the samples taken since start()."""
+        if self._stop is None:
+            return {}
+        self._stop.set()
+        self._thr.join()
+        fs = [f for f, _ in self.samples if f is not None]
+        ps = [p for _, p in self.samples if p is not None]
+        if not fs:
+            return {"sclk_mhz": None, "note": "no readable amdgpu hwmon freq1_input on this box"}
+        out = {"sclk_mhz": sum(fs) / len(fs), "sclk_mhz_min": min(fs), "sclk_mhz_max": max(fs), "samples": len(fs),
+               "sclk_mhz_dpm_max": self.fmax_mhz,
+               "source": "amdgpu hwmon freq1_input / power1_input sampled every ~2 ms over the timed region"}
+        if ps:
+            out["socket_power_w"] = sum(ps) / len(ps)
+        return out
+
+
+def clock_spinup(fn, sync, tel, max_s=2.0, enabled=True):
+    """Untimed: repeat the step until the shader clock has left deep sleep and two consecutive readings agree within 2 %
+    (or max_s).  Without telemetry: 0.4 s of the same work."""
+    if not enabled:
+        return {"enabled": False}
+    t0 = time.perf_counter()
+    last, n, f = None, 0, None
+    while time.perf_counter() - t0 < max_s:
+        for _ in range(8):
+            fn()
+        sync()
+        n += 8
+        f, _ = tel.read()
+        if f is None:
+            if time.perf_counter() - t0 > 0.4:
+                break
+            continue
+        if last is not None and f > 400.0 and abs(f - last) <= 0.02 * f and time.perf_counter() - t0 > 0.15:
+            break
+        last = f
+    return {"enabled": True, "steps": n, "ms": (time.perf_counter() - t0) * 1e3, "sclk_mhz_at_end": f}
+
+
 def cpu_baseline(w, filter_type, full_tape=True, target_s=12.0, n_sample=None, n_steps=None, mvn_const="exact"):
     """The C restatement of the reference algorithm (oracle/kf_oracle.c, kind "port") on the
     host cores, on the leading draws of the SAME workload, computing the same outputs.
@@ -207,6 +306,8 @@ def parse_args():
     ap.add_argument("--no-strong-probe", action="store_true",
                     help="N > 1, weak: skip the extra strong-scaling measurement")
     ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--no-spinup", action="store_true",
+                    help="skip the untimed clock spin-up before the warm-up steps (measures from a cold, deep-sleep clock)")
     return ap.parse_args()
 
 
@@ -291,7 +392,14 @@ def main():
     gathered, res = one_step(d, B_global)   # allocates the output tapes once; reused by every step
     torch.cuda.synchronize()
 
-    def timed(inputs, Bg, out, steps, warmup):
+    tel = GpuTelemetry(dev.index)
+    spin = {}
+    tel_timed = {}
+
+    def timed(inputs, Bg, out, steps, warmup, main=False):
+        if main:
+            spin.update(clock_spinup(lambda: sk.forward_local(*inputs, out=out, **fkw), torch.cuda.synchronize, tel,
+                                     enabled=not args.no_spinup))
         for _ in range(warmup):
             one_step(inputs, Bg, out)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -299,6 +407,8 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+        if main:
+            tel.start()
         t0 = time.perf_counter()
         for k in range(steps):
             # the events bracket the filter launch only; the all-gather of the per-draw
@@ -311,6 +421,8 @@ def main():
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        if main:
+            tel_timed.update(tel.stop())
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64,
                                 device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -319,7 +431,7 @@ def main():
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if steps else float("nan")
         return elapsed, kern_ms
 
-    elapsed, kern_ms = timed(d, B_global, res, args.steps, args.warmup)
+    elapsed, kern_ms = timed(d, B_global, res, args.steps, args.warmup, main=True)
     gathered = res_holder["g"]
 
     # ---- N > 1, weak: the extra strong-scaling measurement (global batch = the 1-GPU run's) -----------
@@ -426,6 +538,13 @@ def main():
                 "kernel": kname, "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_launch": abytes,
             }
+        out["roofline"].update({k: v for k, v in tel_timed.items() if k != "note"})
+        out["roofline"]["clock_spinup"] = dict(spin, note="untimed, BEFORE the W warm-up steps: the same step repeated until the "
+                                               "shader clock has left deep sleep and settled (an idle MI355X idles at ~100 MHz and the "
+                                               "issue-bound kernels follow sclk); --no-spinup measures from the cold clock")
+        if tel_timed.get("sclk_mhz"):
+            # the kernel is issue-bound: its time in shader cycles is the box-independent figure
+            out["roofline"]["kernel_mcycles_at_sclk"] = kern_ms * 1e-3 * tel_timed["sclk_mhz"]
         if strong_obj is not None:
             out["strong_scaling"] = strong_obj
         if world == 1 and not big and not args.no_ops:

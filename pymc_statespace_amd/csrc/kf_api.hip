@@ -28,7 +28,7 @@ extern "C" int kf_create(kf_handle** out, int device) {
   h->device = device;
   h->lanes_per_draw = 0;
   h->forward_kernel = KF_KERNEL_AUTO;
-  const char* envk = getenv("KF_FORWARD_KERNEL");
+  const char* envk = kf_env_switch("KF_FORWARD_KERNEL");
   if (envk && *envk) {
     if (!strcmp(envk, "auto")) h->forward_kernel = KF_KERNEL_AUTO;
     else if (!strcmp(envk, "lds")) h->forward_kernel = KF_KERNEL_LDS;
@@ -42,7 +42,7 @@ extern "C" int kf_create(kf_handle** out, int device) {
       return KF_ERR_ARG;
     }
   }
-  const char* env = getenv("KF_LANES_PER_DRAW");
+  const char* env = kf_env_switch("KF_LANES_PER_DRAW");
   if (env) h->lanes_per_draw = atoi(env);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
@@ -194,7 +194,7 @@ static bool kf_b4q_selected(const kf_handle* h, int m, int p, int r, int filter,
   if (!(filter == KF_FILTER_UNIVARIATE || (flags & KF_FLAG_H_DIAGONAL))) return false;
   if (h->forward_kernel == KF_KERNEL_B4) return true;
   if (h->forward_kernel != KF_KERNEL_AUTO) return false;
-  const char* e = getenv("KF_FORWARD_B4Q");
+  const char* e = kf_env_switch("KF_FORWARD_B4Q");
   if (e && *e) return atoi(e) != 0;
   return m >= 9 || B <= 2L * 4 * h->n_cu;
 }
@@ -204,7 +204,7 @@ static bool kf_backward_b4_selected(const kf_handle* h, int m, int p, int r, lon
   if (!kf_backward_b4_ok(m, p, r)) return false;
   if (h->forward_kernel != KF_KERNEL_AUTO && h->forward_kernel != KF_KERNEL_B4 && h->forward_kernel != KF_KERNEL_MFMA)
     return false;
-  const char* e = getenv("KF_BACKWARD_B4");  // (read per call: tests switch it)
+  const char* e = kf_env_switch("KF_BACKWARD_B4");  // (read per call: tests switch it)
   if (e && e[0]) return e[0] != '0';
   // measured (scripts/r02/bwd_sweep.py, 1000 steps, ms): 4096 draws m = 5 / 6 / 8 / 10 / 14: 1.72 / 1.78 / 2.46 / 2.56 / 3.69 against
   // 2.54 / 2.30 / 2.63 / 3.20 / 4.15 (round-1 choice); m = 2 / 4: 1.22 / 1.71 against 0.89 / 1.53, but 0.60 / 0.69 against
@@ -304,7 +304,7 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a_in, void* workspace, size
                       hipStream_t stream) {
   KfFwdArgs a = a_in;
   {
-    const char* e = getenv("KF_SS_ENTRY_TOL");  // experiments: the entrywise tolerance of the steady-state test (default 1e-12)
+    const char* e = kf_env_experiment("KF_SS_ENTRY_TOL");  // experiments: the entrywise tolerance of the steady-state test (default 1e-12)
     if (e && *e && atof(e) > 0.0) a.ss_tol2 = atof(e) * atof(e);
   }
   if (a.flags & KF_FLAG_TV_ANY) {
@@ -333,7 +333,7 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a_in, void* workspace, size
   if (h->forward_kernel == KF_KERNEL_AUTO && a.filter != KF_FILTER_UNIVARIATE &&
       kf_forward_wgl_ok(a.m, a.p, a.flags, a.filt_P || a.pred_P) && workspace &&
       workspace_bytes >= kf_forward_wgl_workspace_bytes(a.B, a.m)) {
-    const char* e = getenv("KF_FORWARD_WGL");
+    const char* e = kf_env_switch("KF_FORWARD_WGL");
     if (!(e && e[0] == '0')) return kf_launch_forward_wgl(h, a, workspace, workspace_bytes, stream);
   }
   if (!kf_forward_lds_fits(a.m, a.p)) return kf_launch_forward_big(h, a, workspace, workspace_bytes, stream);
@@ -443,6 +443,18 @@ int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t
     }
     return kf_launch_backward_lds(h, a, stream);
   }
+  // per-draw step counts (the steady-state adjoint's hand-over, kf_filter_value_and_grad): kf_backward_mfma.hip is the one adjoint
+  // that honours them -- whatever forward kernel was forced on the handle; any other shape is refused, never swept in full
+  if (a.steps) {
+    const bool ok = a.m <= KF_MP_M_MAX && a.p <= KF_MP_P_MAX &&
+                    (a.p == 1 || a.filter == KF_FILTER_UNIVARIATE || (a.flags & KF_FLAG_H_DIAGONAL));
+    if (!ok) {
+      KF_SET_ERR(h, "backward: per-draw step counts need the accumulator-layout adjoint (m <= %d, p <= %d, scalar observations; "
+                 "got p=%d m=%d)", KF_MP_M_MAX, KF_MP_P_MAX, a.p, a.m);
+      return KF_ERR_UNSUPPORTED;
+    }
+    return kf_launch_backward_mfma(h, a, stream);
+  }
   // scalar observation, m <= 14: adjoint of the augmented recursion on 4x4x4 block MFMAs (kf_backward_b4.hip); needs
   // B (m + m^2) doubles of workspace for the hand-over of its last step (else the 16x16 tile adjoint below)
   if (kf_backward_b4_selected(h, a.m, a.p, a.r, a.B) && workspace &&
@@ -545,7 +557,7 @@ static size_t kf_vg_tape_bytes(const kf_dims* d) {
 // value-and-gradient through the 4x4x4-block kernels' tile tape: both kernels selected, static, a series to sweep
 static bool kf_vg_tile_path(const kf_handle* h, const kf_dims* d) {
   if ((d->flags & KF_FLAG_TV_ANY) || d->T < 2) return false;
-  const char* e = getenv("KF_VG_TILE_TAPE");  // =0: compact tapes (A/B measurements)
+  const char* e = kf_env_switch("KF_VG_TILE_TAPE");  // =0: compact tapes (A/B measurements)
   if (e && e[0] == '0') return false;
   return kf_b4_selected(h, d->m, d->p, d->r, d->B) && kf_backward_b4_selected(h, d->m, d->p, d->r, d->B);
 }
@@ -555,9 +567,9 @@ static bool kf_vg_tile_path(const kf_handle* h, const kf_dims* d) {
 // counts (kf_backward_mfma.hip: m <= 16, scalar observations).  KF_VG_STEADY=0 in the environment: the exact adjoint at every step
 static bool kf_vg_steady_path(const kf_handle* h, const kf_dims* d) {
   if ((d->flags & (KF_FLAG_TV_ANY | KF_FLAG_EXACT_RECURSION)) || d->T < 64) return false;
-  const char* e = getenv("KF_VG_STEADY");
+  const char* e = kf_env_switch("KF_VG_STEADY");
   if (e && e[0] == '0') return false;
-  const char* sse = getenv("KF_STEADY_STATE");
+  const char* sse = kf_env_switch("KF_STEADY_STATE");
   if (sse && *sse && atoi(sse) == 0) return false;
   if (!kf_b4q_selected(h, d->m, d->p, d->r, d->filter, d->flags, d->B)) return false;
   if (!(d->p >= 3 && d->p <= 5 && d->m >= 8)) return false;  // (the shapes kf_forward_b4q.hip's steady-state phase covers)
@@ -816,7 +828,7 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
   a.only_flagged = nullptr;
   a.exact = (dims->flags & KF_FLAG_EXACT_RECURSION) ? 1 : 0;
   {
-    const char* e = getenv("KF_SMOOTHER_STEADY");  // =0: as KF_FLAG_EXACT_RECURSION (A/B measurements)
+    const char* e = kf_env_switch("KF_SMOOTHER_STEADY");  // =0: as KF_FLAG_EXACT_RECURSION (A/B measurements)
     if (e && e[0] == '0') a.exact = 1;
   }
   if (a.flags) {
@@ -830,7 +842,7 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
   }
   // m <= 4 (C1, C2): one lane per draw, pseudo-inverse in registers (kf_smoother_lane.hip); KF_SMOOTHER_LANE=0 keeps the LDS kernel
   if (kf_smoother_lane_ok(a.m) && h->forward_kernel != KF_KERNEL_LDS) {
-    const char* e = getenv("KF_SMOOTHER_LANE");
+    const char* e = kf_env_switch("KF_SMOOTHER_LANE");
     if (!(e && e[0] == '0')) return kf_launch_smoother_lane(h, a, (hipStream_t)stream);
   }
   // 5 <= m <= 15: block-MFMA smoother with warm-started Newton-Schulz inverses (kf_smoother_b4.hip); KF_SMOOTHER_B4=0
@@ -845,7 +857,7 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
     // 7.9 against 7.1 / 8.7 / 9.1 / 9.7, 16384 draws 11.9 / 12.5 / 13.3 / 16.5 against 13.3 / 16.5 / 16.9 / 17.9; C4 (VARMA, m = 15, 1000
     // steps) 16384 / 8192 / 4096 draws: 22.1 / 12.2 / 6.9 against 35.5 / 18.6 / 10.0 -- the one shape left to the elimination kernel is
     // m = 12 between 3072 and 8192 draws
-    const char* e = getenv("KF_SMOOTHER_B4");
+    const char* e = kf_env_switch("KF_SMOOTHER_B4");
     const long wave3 = 3L * 4 * (h->n_cu > 0 ? h->n_cu : 256);
     const bool pick = (e && e[0]) ? e[0] != '0' : (a.m != 12 || a.B <= wave3 || a.B >= 8192);
     if (pick) return kf_launch_smoother_b4(h, a, workspace, workspace_bytes, (hipStream_t)stream);

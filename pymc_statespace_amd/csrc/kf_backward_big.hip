@@ -343,7 +343,7 @@ int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, si
   const size_t sh_f = sizeof(double) * (m + NT / KF_WAVE);
   const size_t sh_a = sizeof(double) * (4 * m + NT + NT / KF_WAVE);
   const long sTape = (long)(n + 1) * mm;
-  const char* bge = getenv("KF_SMOOTHER_BIG_GEMM");
+  const char* bge = kf_env_switch("KF_SMOOTHER_BIG_GEMM");
   const bool big_full = m >= 128 && !(bge && bge[0] == '0');
   for (int t = n - 1; t >= 0; --t) {
     // ab_f = T' ab'

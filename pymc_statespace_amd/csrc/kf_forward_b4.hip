@@ -596,9 +596,9 @@ bool kf_forward_b4_split_ok(const kf_handle* h, long B, int T, int p, int m, int
   (void)h;
   if (!kf_forward_b4_ok(m, p, r) || m > 10) return false;        // (m <= 10: covariance tapes through the rings)
   if (flags & (KF_FLAG_TV_ANY | KF_FLAG_EXACT_RECURSION)) return false;
-  const char* sse = getenv("KF_STEADY_STATE");
+  const char* sse = kf_env_switch("KF_STEADY_STATE");
   if (sse && *sse && atoi(sse) == 0) return false;
-  const char* e = getenv("KF_B4_SPLIT");
+  const char* e = kf_env_switch("KF_B4_SPLIT");
   if (e && *e) return atoi(e) != 0 && T >= 64;
   if ((flags & KF_FLAG_STEADY_STATE) || (sse && *sse && atoi(sse) != 0)) return T >= 256;
   return T >= KF_B4_STEADY_MIN_T && B >= 1;
@@ -609,7 +609,7 @@ static int b4_split_chunk(int n) {
   // 128 steps; measured (scripts/r03/split_check.py c3tune, 8192 x 2000): 128 / 256 / 384 / 512 / 768 steps 7.2 / 6.0 / 5.8 / 5.7 / 6.0 ms
   int ch = ((n / 4 + 31) & ~31);
   if (ch < 128) ch = 128;
-  const char* e = getenv("KF_B4_SPLIT_CHUNK");
+  const char* e = kf_env_experiment("KF_B4_SPLIT_CHUNK");
   if (e && *e && atoi(e) >= 32) ch = (atoi(e) + 31) & ~31;
   while ((n + ch - 1) / ch > B4_SPLIT_MAX_CHUNKS) ch += 32;
   return ch;
@@ -626,8 +626,12 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size
   // KF_FORWARD_B4P=0 / 1 forces the choice.
   bool pair_env_off = false;
   {
-    const char* e = getenv("KF_FORWARD_B4P");
-    bool pair = a.B <= B4_PAIR_MAX && (a.filt_P || a.pred_P) && !(a.flags & KF_FLAG_STEADY_STATE);
+    const char* e = kf_env_switch("KF_FORWARD_B4P");
+    // (the pair kernel is the recursion at every step: a caller who asked for the steady-state phase -- the flag, or KF_STEADY_STATE=1
+    // in the environment, which include/kf.h documents as the same request -- gets the kernels that have one)
+    const char* sreq = kf_env_switch("KF_STEADY_STATE");
+    const bool steady_requested = !(a.flags & KF_FLAG_EXACT_RECURSION) && ((a.flags & KF_FLAG_STEADY_STATE) || (sreq && atoi(sreq) != 0));
+    bool pair = a.B <= B4_PAIR_MAX && (a.filt_P || a.pred_P) && !steady_requested;
     if (e && *e) {
       pair = atoi(e) != 0;
       pair_env_off = !pair;
@@ -644,10 +648,10 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size
   // step is the faster kernel on most boxes (round 3, six boxes: 1.65 - 1.73 ms against 1.78 - 1.84 with the in-kernel phase and
   // 2.0 - 2.4 with the split pipeline) -- a launch lasts as long as its slowest SIMD, and 5 % of the structural draws never
   // converge; at T = 2000 the split pipeline wins (C3: 5.7 against 6.8 - 7.0 ms).  KF_STEADY_STATE=1 / 0 forces it on / off.
-  const char* sse = getenv("KF_STEADY_STATE");
+  const char* sse = kf_env_switch("KF_STEADY_STATE");
   const bool ss_env_on = (sse && *sse && atoi(sse) != 0) || (a.flags & KF_FLAG_STEADY_STATE), ss_env_off = sse && *sse && atoi(sse) == 0;
   const bool ss = !(a.flags & KF_FLAG_EXACT_RECURSION) && !a.tile_tape && a.T >= 64 && !ss_env_off &&
-                  (a.T >= KF_B4_STEADY_MIN_T || ss_env_on || getenv("KF_B4_SPLIT") != nullptr);
+                  (a.T >= KF_B4_STEADY_MIN_T || ss_env_on || kf_env_switch("KF_B4_SPLIT") != nullptr);
   // (tried: capping the residency of this instantiation at 3 / 2 wavefronts per SIMD so that the dispatcher hands queued draws to the
   // SIMDs whose draws converged early -- headline 2.29 / 2.44 ms against 1.63: the queued wavefronts run as a second round)
   // split pipeline: recursion chunks over compacted draw lists + the time-parallel steady kernels on the second stream

@@ -337,17 +337,14 @@ static int b4_fill_slices(const KfFwdArgs& a) {
 // behind the compaction of `chunk`: a throttled fill launch (s_fill) and the mean scan of the draws that chunk handed over (s_mean)
 int kf_b4_split_steady(kf_handle* h, const KfFwdArgs& a, const B4SplitWs& W, int chunk, hipStream_t s_fill, hipStream_t s_mean) {
   const int m = a.m, mm = m * m;
-  const char* dbg = getenv("KF_B4_SPLIT_DEBUG");  // measurements only (results incomplete): 1 skips the fill, 2 the scan
-  const int skip = dbg && *dbg ? atoi(dbg) : 0;
-  if ((a.filt_P || a.pred_P) && !(skip & 1)) {
-    const char* e = getenv("KF_B4_FILL_WGS");
+  if (a.filt_P || a.pred_P) {
+    const char* e = kf_env_experiment("KF_B4_FILL_WGS");
     int wgs = e && *e ? atoi(e) : 1024;  // (C3, 8192 x 2000: 512 / 1024 / 2048 workgroups 6.1 / 5.7 / 5.9 ms)
     if (wgs < 1) wgs = 1;
     hipLaunchKernelGGL(kf_b4_steady_fill_kernel, dim3((unsigned)wgs), dim3(KF_WAVE), sizeof(double) * (size_t)(2 * mm + 4), s_fill, a, W,
                        chunk, b4_fill_slices(a));
   }
   const unsigned grid = (unsigned)(a.B < 2048 ? a.B : 2048);
-  if (skip & 2) return KF_OK;
 #define KF_MEAN(M_) \
   case M_: hipLaunchKernelGGL((kf_b4_steady_scan_kernel<M_>), dim3(grid), dim3(KF_WAVE), 0, s_mean, a, W, chunk); break;
   switch (m) {
@@ -363,9 +360,7 @@ int kf_b4_split_steady(kf_handle* h, const KfFwdArgs& a, const B4SplitWs& W, int
 
 // behind the last recursion launch: whatever the throttled launches left, at full width
 int kf_b4_split_drain(kf_handle* h, const KfFwdArgs& a, const B4SplitWs& W, int last_chunk, hipStream_t stream) {
-  const char* dbg = getenv("KF_B4_SPLIT_DEBUG");
-  const int skip = dbg && *dbg ? atoi(dbg) : 0;
-  if (!(a.filt_P || a.pred_P) || (skip & 1)) return KF_OK;
+  if (!(a.filt_P || a.pred_P)) return KF_OK;
   const int mm = a.m * a.m;
   hipLaunchKernelGGL(kf_b4_steady_fill_kernel, dim3(2048), dim3(KF_WAVE), sizeof(double) * (size_t)(2 * mm + 4), stream, a, W,
                      last_chunk, b4_fill_slices(a));

@@ -821,17 +821,17 @@ int kf_launch_forward_b4q(kf_handle* h, const KfFwdArgs& a_in, void* workspace, 
   const int nb = (a.m + 1 + 3) / 4;
   const int mask = (a.filt_a ? 1 : 0) | (a.pred_a ? 2 : 0) | (a.filt_P ? 4 : 0) | (a.pred_P ? 8 : 0);
   // KF_B4Q_GROUP=0 in the environment: every observation one at a time (A/B measurements)
-  const char* ge = getenv("KF_B4Q_GROUP");
+  const char* ge = kf_env_switch("KF_B4Q_GROUP");
   const bool grp = nb >= 3 && a.p >= 3 && !(ge && *ge && atoi(ge) == 0);
   // steady-state phase: its own instantiation (KF_FLAG_EXACT_RECURSION / KF_STEADY_STATE=0 run the kernel without it)
-  const char* sse = getenv("KF_STEADY_STATE");
+  const char* sse = kf_env_switch("KF_STEADY_STATE");
   const bool ss = grp && a.p <= 5 && a.T >= 64 && !(a.flags & KF_FLAG_EXACT_RECURSION) && !(sse && *sse && atoi(sse) == 0);
   // split steady-state phase (kf_forward_b4q_steady.hip) when the caller passed the workspace; KF_B4Q_SPLIT=0: the phase inside
   // the recursion kernel (round 2)
   double* sp = nullptr;
   bool split = false;
   {
-    const char* e = getenv("KF_B4Q_SPLIT");
+    const char* e = kf_env_switch("KF_B4Q_SPLIT");
     split = ss && nb >= 3 && a.m <= 15 && workspace && workspace_bytes >= kf_b4q_split_workspace_bytes(a.B) && !(e && e[0] == '0');
     if (split) {
       const int rc0 = kf_handle_aux(h);
@@ -859,10 +859,10 @@ int kf_launch_forward_b4q(kf_handle* h, const KfFwdArgs& a_in, void* workspace, 
   // chunk run beside the recursion of the next one
   long chunk = split ? 4096 : a.B;
   {
-    const char* e = getenv("KF_B4Q_CHUNK");  // experiments
+    const char* e = kf_env_experiment("KF_B4Q_CHUNK");  // experiments
     if (split && e && *e && atol(e) >= 256) chunk = atol(e);
   }
-  const char* pse = getenv("KF_B4Q_PREP_STREAM");
+  const char* pse = kf_env_experiment("KF_B4Q_PREP_STREAM");
   hipStream_t s_prep = (pse && pse[0] == '1') ? h->aux_stream : h->aux_stream3;
   const KfFwdArgs a_all = a;
   int ci = 0;

@@ -925,7 +925,7 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pf));
   }
   // KF_BIG_FUSE=0 in the environment: the separate a_hat / mirror kernels of round 2 (A/B measurements)
-  const char* fe = getenv("KF_BIG_FUSE");
+  const char* fe = kf_env_switch("KF_BIG_FUSE");
   const bool fuse = !(fe && fe[0] == '0');
   // P_f formed on the way into LDS instead of by its own pass: scalar observation, m <= 1024, the filtered covariance tape not requested
   const bool pfix = fuse && !fused_update && p == 1 && m <= BIG_PFIX_M && !a.filt_P;

@@ -638,7 +638,7 @@ int KF_CAT(kf_launch_forward_lane_m, KF_LANE_M)(kf_handle* h, const KfFwdArgs& a
   const int mask = (a.filt_a ? 1 : 0) | (a.pred_a ? 2 : 0) | (a.filt_P ? 4 : 0) | (a.pred_P ? 8 : 0);
   KfFwdArgs a_ = a;
   {
-    const char* sse = getenv("KF_STEADY_STATE");  // =0: step-by-step recursion (A/B measurements), as KF_FLAG_EXACT_RECURSION
+    const char* sse = kf_env_switch("KF_STEADY_STATE");  // =0: step-by-step recursion (A/B measurements), as KF_FLAG_EXACT_RECURSION
     if (sse && *sse && atoi(sse) == 0) a_.flags |= KF_FLAG_EXACT_RECURSION;
   }
   const bool ss = !(a_.flags & KF_FLAG_EXACT_RECURSION) && a.T >= 64;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/kf.h"
@@ -21,6 +22,26 @@ struct KfAttrOnce {
     if (dev >= 0 && dev < 64) done |= 1ull << dev;
   }
 };
+
+// Environment switches (table: INTEGRATION.md).  Two classes, so that nothing in the environment can make an entry point return
+// incomplete results or change a documented tolerance:
+//   kf_env_switch      documented selectors between COMPLETE, parity-tested paths (KF_STEADY_STATE, KF_B4_SPLIT, KF_FORWARD_B4P,
+//                      KF_VG_STEADY, ...): read per call (tests flip them), each value's results are held to parity by
+//                      tests/test_gpu_switches.py
+//   kf_env_experiment  tuning knobs of the measurement scripts (chunk sizes, workgroup counts, the convergence tolerance): compiled in
+//                      only with -DKF_EXPERIMENTS (make XFLAGS=-DKF_EXPERIMENTS); a product build ignores them
+inline const char* kf_env_switch(const char* name) {
+  const char* e = getenv(name);
+  return (e && *e) ? e : nullptr;
+}
+inline const char* kf_env_experiment(const char* name) {
+#ifdef KF_EXPERIMENTS
+  return kf_env_switch(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 #define KF_AUX_EVENTS 34
 struct kf_handle {

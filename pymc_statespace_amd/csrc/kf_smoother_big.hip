@@ -668,7 +668,7 @@ int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace,
   const long sTape = (long)n * mm;
   const unsigned tb = (unsigned)((m + 31) / 32);
   // KF_SMOOTHER_BIG_GEMM=0: the four full-size products on this file's own kernel (A/B measurements); m < 128: its smaller tiles fit better
-  const char* bge = getenv("KF_SMOOTHER_BIG_GEMM");
+  const char* bge = kf_env_switch("KF_SMOOTHER_BIG_GEMM");
   const bool big_full = m >= 128 && !(bge && bge[0] == '0');
   for (int t = n - 2; t >= 0; --t) {
     const double* Pf = a.filt_P + (long)t * mm;

@@ -369,13 +369,17 @@ class KalmanEngine:
         return logp, info, g
 
     # --------------------------------------------------------------- smoother
-    def smooth(self, T, R, Q, filtered_states, filtered_covs, time_varying=(), pairing="filter", exact_recursion=False):
+    def smooth(self, T, R, Q, filtered_states, filtered_covs, time_varying=(), pairing="filter",
+               exact_recursion: Optional[bool] = None):
         """kf_smoother -> (smoothed_states (B,n,m), smoothed_covs (B,n,m,m)).  Names in ``time_varying`` (subset of
         T, R, Q) carry a time axis after the draw axis, (B,n,.,.): the step that smooths t uses slice t (``pairing="filter"``,
         the forward filter's pairing) or slice t + 1 (``pairing="reference"``: what the reference's own scan hands its step,
         kalman_smoother.py:62-77 -- for parity with a model ported from upstream).  ``exact_recursion=True``
         (KF_FLAG_EXACT_RECURSION): the prediction covariance is inverted at every step, also where the filtered covariance on the
-        tape is bit for bit the next step's (5 <= m <= 15, m <= 2: the smoothers reuse the last step's gain there by default)."""
+        tape is bit for bit the next step's (5 <= m <= 15, m <= 2: the smoothers reuse the last step's gain there by default);
+        None: the engine's default (``set_exact_recursion``), as in ``forward`` / ``value_and_grad``."""
+        if exact_recursion is None:
+            exact_recursion = bool(getattr(self, "_exact_recursion", False))
         if pairing not in ("filter", "reference"):
             raise ValueError("pairing must be 'filter' or 'reference'")
         tv = set(time_varying)
