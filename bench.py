@@ -185,11 +185,14 @@ def clock_spinup(fn, sync, tel, max_s=2.0, enabled=True):
         return {"enabled": False}
     t0 = time.perf_counter()
     last, n, f = None, 0, None
+    per = 1   # steps between clock readings: ~10 ms of work (8 steps at the headline, 1 for C5's 0.4 - 3.4 s passes)
     while time.perf_counter() - t0 < max_s:
-        for _ in range(8):
+        t1 = time.perf_counter()
+        for _ in range(per):
             fn()
         sync()
-        n += 8
+        n += per
+        per = max(1, min(8, int(0.01 / max(1e-6, (time.perf_counter() - t1) / per))))
         f, _ = tel.read()
         if f is None:
             if time.perf_counter() - t0 > 0.4:
@@ -306,6 +309,13 @@ def parse_args():
     ap.add_argument("--no-strong-probe", action="store_true",
                     help="N > 1, weak: skip the extra strong-scaling measurement")
     ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--time-varying", default="", metavar="NAMES",
+                    help="comma-separated subset of T,Z,R,H,Q,c,d: those matrices get a time axis (B,n,.,.) -- the same values at "
+                         "every step, so results equal the static run's -- and the call takes the time-varying path "
+                         "(KF_FLAG_TV_*, SURVEY 8(f) row 3; reference filters/kalman_filter.py:79-124)")
+    ap.add_argument("--dense-h", action="store_true",
+                    help="p > 1: replace the workload's diagonal H by a dense positive definite one (reference "
+                         "kalman_filter.py:262-275 takes any PD H); no KF_FLAG_H_DIAGONAL kernels")
     ap.add_argument("--no-spinup", action="store_true",
                     help="skip the untimed clock spin-up before the warm-up steps (measures from a cold, deep-sleep clock)")
     return ap.parse_args()
@@ -355,6 +365,14 @@ def main():
     kw = {} if B0 is None else {"B": B0}
     base = W.WORKLOADS[args.workload](**kw)   # the 1-GPU workload (seeded)
     B0, n, p, m, r = base["B"], base["n"], base["p"], base["m"], base["r"]
+    tv = tuple(x for x in args.time_varying.split(",") if x)
+    if args.dense_h:
+        if p < 2:
+            sys.exit("--dense-h needs a workload with p > 1 (c4, c4_m10)")
+        rng_h = np.random.default_rng(99)
+        Lh = np.tril(0.05 * rng_h.standard_normal((B0, p, p)), -1)
+        Lh[:, np.arange(p), np.arange(p)] = np.sqrt(np.einsum("bii->bi", base["H"]))
+        base = dict(base, H=Lh @ np.swapaxes(Lh, 1, 2), name=base["name"] + "+denseH")
     big = m > 64                               # HBM-workspace path (C5): logp only, MFMA bound
     full = not (args.logp_only or big)
     strong = args.scaling == "strong"
@@ -364,9 +382,21 @@ def main():
     sk = ShardedKalman(eng)
     fkw = dict(filter_type=ft, mvn_const="exact", store_ll_obs=full or big, store_filtered=full,
                store_predicted=full)
+    if tv:
+        fkw["time_varying"] = tv
+    if args.dense_h:
+        fkw["h_diagonal"] = False
 
     def shard_of(w, lo, hi):
-        return [eng.to_device(w["y"])] + [eng.to_device(w[k][lo:hi]) for k in KEYS]
+        out = [eng.to_device(w["y"])]
+        for k in KEYS:
+            x = eng.to_device(w[k][lo:hi])
+            if k in tv:   # the same slice at every step, materialised: (B, n, rows, cols) in HBM, read slice by slice
+                x = x[:, None].expand(x.shape[0], n, *x.shape[1:]).contiguous()
+            out.append(x)
+        if "c" in tv or "d" in tv:
+            sys.exit("--time-varying c / d: not wired into bench.py (the workloads have no intercepts)")
+        return out
 
     # ---- the timed configuration -------------------------------------------------------------------
     if strong or world == 1:
@@ -488,6 +518,7 @@ def main():
                             f"(p={p}, r={r}), {ft} filter, "
                             f"{'all six reference outputs written to HBM' if full else 'logp only'}",
                 "draws_per_gpu": B_local, "T": n, "k_states": m, "k_endog": p, "k_posdef": r,
+                "time_varying": list(tv), "dense_h": bool(args.dense_h),
                 "filter": ft, "outputs": "full_tape" if full else "logp_only",
                 "global_draws": B_global, "parallelism": f"draws sharded x{world}",
                 "draw_steps_per_s": B_global * n * args.steps / elapsed,
@@ -499,7 +530,7 @@ def main():
             },
         }
         diag = bool(p > 1 and np.all(base["H"] == base["H"] * np.eye(p)))
-        kname = eng.forward_kernel_name(B_local, n, p, m, r, filter_type=ft, h_diagonal=diag)
+        kname = eng.forward_kernel_name(B_local, n, p, m, r, filter_type=ft, h_diagonal=diag, time_varying=tv)
         if big:
             aflops = algorithmic_flops(B_local, n, p, m, r)
             xflops = executed_flops_big(B_local, n, m)
@@ -522,6 +553,8 @@ def main():
             }
         else:
             abytes = algorithmic_bytes(B_local, n, p, m, r, full)
+            tv_elems = {"T": m * m, "Z": p * m, "R": m * r, "H": p * p, "Q": r * r}
+            abytes += sum(8 * B_local * (n - 1) * tv_elems[k] for k in tv)   # a time-varying matrix is read slice by slice
             achieved = abytes / (kern_ms * 1e-3) / 1e9
             traffic, tsrc = None, None
             tfile = os.path.join(ROOT, "profiles", "traffic.json")
@@ -547,6 +580,41 @@ def main():
             out["roofline"]["kernel_mcycles_at_sclk"] = kern_ms * 1e-3 * tel_timed["sclk_mhz"]
         if strong_obj is not None:
             out["strong_scaling"] = strong_obj
+        if world == 1 and big and not args.no_ops:
+            # m > 64 (C5): the smoother and the gradient over a PREFIX of the series (their tapes are m^2 doubles per draw and step:
+            # 1.1 MB at m = 367), per time step -- the recursions cost the same at every step.  AFTER and outside the timed region
+            ops = {}
+            try:
+                ns = int(max(6, min(40, 20e9 // (B_local * m * m * 8))))
+                d40 = [d[0][:ns].contiguous()] + d[1:]
+
+                def _ms1(fn):
+                    fn()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t0) * 1e3
+                r40 = eng.forward(*d40, filter_type=ft, mvn_const="exact", store_ll_obs=False, store_predicted=False)
+                ops["prefix_steps"] = ns
+                ops["rts_smoother_ms_per_step"] = _ms1(lambda: eng.smooth(d[3], d[5], d[7], r40.filtered_states,
+                                                                         r40.filtered_covs)) / (ns - 1)
+                del r40
+                torch.cuda.empty_cache()
+                r40 = eng.forward(*d40, filter_type=ft, mvn_const="exact", store_ll_obs=False, store_filtered=False)
+                ops["forward_with_predicted_tapes_ms_per_step"] = _ms1(lambda: eng.forward(
+                    *d40, filter_type=ft, mvn_const="exact", store_ll_obs=False, store_filtered=False, out=r40)) / ns
+                ops["gradient_sweep_ms_per_step"] = _ms1(lambda: eng.backward(
+                    *d40, predicted_states=r40.predicted_states, predicted_covs=r40.predicted_covs,
+                    g_logp=torch.ones(B_local, dtype=torch.float64, device=dev), filter_type=ft, mvn_const="exact")) / ns
+                del r40
+                torch.cuda.empty_cache()
+                ops["logp_and_gradient_one_call_ms_per_step"] = _ms1(lambda: eng.value_and_grad(
+                    *d40, filter_type=ft, mvn_const="exact")) / ns
+                ops["forward_ms_per_step"] = kern_ms / n
+            except Exception as e:  # noqa: BLE001 -- an extra must never break the contract line
+                ops["error"] = str(e)[:300]
+            out["other_entry_points"] = ops
         if world == 1 and not big and not args.no_ops:
             # the other entry points on the same resident inputs, AFTER and outside the timed region (not part of `value`):
             # log-likelihood only, logp + gradient in one call (kf_filter_value_and_grad), RTS smoother over the filtered tapes
@@ -560,12 +628,17 @@ def main():
                 return (time.perf_counter() - t0) / reps * 1e3
             ops = {}
             try:
+                xkw = {k: v for k, v in fkw.items() if k in ("time_varying", "h_diagonal")}
                 lo_res = eng.forward(*d, filter_type=ft, mvn_const="exact", store_ll_obs=False, store_filtered=False,
-                                     store_predicted=False)
+                                     store_predicted=False, **xkw)
                 ops["logp_only_ms"] = _ms(lambda: eng.forward(*d, filter_type=ft, mvn_const="exact", store_ll_obs=False,
-                                                              store_filtered=False, store_predicted=False, out=lo_res))
-                ops["logp_and_gradient_one_call_ms"] = _ms(lambda: eng.value_and_grad(*d, filter_type=ft, mvn_const="exact",
-                                                                                      h_diagonal=True))
+                                                              store_filtered=False, store_predicted=False, out=lo_res, **xkw))
+                if not tv:
+                    ops["logp_and_gradient_one_call_ms"] = _ms(lambda: eng.value_and_grad(
+                        *d, filter_type=ft, mvn_const="exact", h_diagonal=not args.dense_h))
+                    # the same with the adjoint of the recursion at every step (KF_FLAG_EXACT_RECURSION: no steady-state adjoint)
+                    ops["logp_and_gradient_exact_recursion_ms"] = _ms(lambda: eng.value_and_grad(
+                        *d, filter_type=ft, mvn_const="exact", h_diagonal=not args.dense_h, exact_recursion=True))
                 # the timed call runs the library's default; the same call with the covariance recursion forced at every
                 # step (KF_FLAG_EXACT_RECURSION) and with the steady-state phase requested (KF_FLAG_STEADY_STATE), and how far
                 # the three log-likelihood vectors are apart
@@ -577,8 +650,9 @@ def main():
                 ops["max_rel_dlogp_exact_vs_steady_state"] = float(((ex_res.logp - ss_res.logp).abs() / ex_res.logp.abs()).max())
                 del ex_res, ss_res
                 if full:
+                    tvs = tuple(k for k in tv if k in ("T", "R", "Q"))
                     ops["rts_smoother_ms"] = _ms(lambda: eng.smooth(d[3], d[5], d[7], res.filtered_states,
-                                                                     res.filtered_covs), reps=3)
+                                                                     res.filtered_covs, time_varying=tvs), reps=3)
             except Exception as e:  # noqa: BLE001 -- an extra must never break the contract line
                 ops["error"] = str(e)[:200]
             out["other_entry_points"] = ops

@@ -576,6 +576,20 @@ static bool kf_vg_steady_path(const kf_handle* h, const kf_dims* d) {
   return kf_backward_steady_ok(d->m, d->p, d->r) && d->m <= KF_MP_M_MAX;
 }
 
+// value-and-gradient through the tile tape WITH the steady-state adjoint (p == 1, m <= 10: the block kernel's tapes go through its LDS
+// rings): the forward kernel reports each draw's convergence point ts, leaves the tile tape of steps < ts and a_t of steps >= ts;
+// kf_bwd_steady_kernel + kf_dare_bwd_kernel take the steps behind ts, kf_bwd_b4_kernel (per-draw step counts) the steps before it.
+// KF_VG_STEADY=0 / KF_STEADY_STATE=0 / KF_FLAG_EXACT_RECURSION: the exact adjoint at every step
+static bool kf_vg_tile_steady_path(const kf_handle* h, const kf_dims* d) {
+  if (!kf_vg_tile_path(h, d)) return false;
+  if ((d->flags & KF_FLAG_EXACT_RECURSION) || d->T < 64 || d->m > 10) return false;
+  const char* e = kf_env_switch("KF_VG_STEADY");
+  if (e && e[0] == '0') return false;
+  const char* sse = kf_env_switch("KF_STEADY_STATE");
+  if (sse && atoi(sse) == 0) return false;
+  return kf_backward_steady_ok(d->m, d->p, d->r);
+}
+
 extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, int which, size_t* bytes) {
   if (!h || !dims || !bytes) return KF_ERR_ARG;
   if (which & KF_WS_VALUE_AND_GRAD) {
@@ -583,6 +597,10 @@ extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, i
     const int rc = kf_workspace_bytes_for(h, dims, KF_WS_FORWARD | KF_WS_BACKWARD, &inner);
     if (rc) return rc;
     *bytes = kf_vg_tape_bytes(dims) + inner;
+    if (kf_vg_tile_steady_path(h, dims)) {
+      const size_t B = (size_t)dims->B, m = (size_t)dims->m, n1 = (size_t)dims->T + 1;
+      *bytes += kf_vg_round(8 * B * n1 * m) + kf_vg_round(4 * B) + kf_vg_round(8 * B * m) + 3 * kf_vg_round(8 * B * m * m);
+    }
     if (kf_vg_steady_path(h, dims)) {
       const size_t B = (size_t)dims->B, m = (size_t)dims->m;
       *bytes += kf_vg_round(4 * B) + kf_vg_round(8 * B * m) + 2 * kf_vg_round(8 * B * m * m);
@@ -736,6 +754,19 @@ extern "C" int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims, const
     f.y = y; f.a0 = a0; f.P0 = P0; f.Tm = T; f.Z = Z; f.R = R; f.H = H; f.Q = Q; f.c = c; f.d = d;
     f.logp = logp; f.ll_obs = nullptr; f.filt_a = nullptr; f.pred_a = nullptr; f.filt_P = nullptr; f.pred_P = nullptr;
     f.info = info; f.tile_tape = tape;
+    const bool tsteady = kf_vg_tile_steady_path(h, dims);
+    int32_t* ts = nullptr;
+    double *s_pa = nullptr, *s_ab = nullptr, *s_Pb = nullptr, *s_P = nullptr, *s_Pc = nullptr;
+    if (tsteady) {  // [.. | pred_a B (T+1) m | ts B | lam_ts B m | P_b B m^2 | P B m^2 | P as the forward left it B m^2 | inner]
+      s_pa = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * n1 * m);
+      ts = reinterpret_cast<int32_t*>(w); w += kf_vg_round(4 * B);
+      s_ab = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * m);
+      s_Pb = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * m * m);
+      s_P = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * m * m);
+      s_Pc = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * m * m);
+      f.pred_a = s_pa; f.hs_ts = ts; f.vg_P = s_Pc;
+    }
+    const size_t inner_ts = workspace_bytes - (size_t)(w - reinterpret_cast<char*>(workspace));
     rc = kf_launch_forward_b4(h, f, nullptr, 0, (hipStream_t)stream);
     if (rc) return rc;
     if (!g_logp) {
@@ -743,6 +774,21 @@ extern "C" int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims, const
                          (long)B, 1.0);
       KF_HIP_CHECK(h, hipGetLastError());
       g_logp = ones;
+    }
+    if (tsteady) {
+      KfBwdArgs a;
+      a.B = dims->B; a.T = dims->T; a.p = dims->p; a.m = dims->m; a.r = dims->r; a.filter = dims->filter; a.flags = dims->flags;
+      a.y = y; a.a0 = a0; a.P0 = P0; a.Tm = T; a.Z = Z; a.R = R; a.H = H; a.Q = Q; a.c = c; a.d = d;
+      a.pred_a = s_pa; a.pred_P = nullptr; a.g_logp = g_logp; a.g_ll_obs = nullptr;
+      a.g_a0 = g_a0; a.g_P0 = g_P0; a.g_T = g_T; a.g_Z = g_Z; a.g_R = g_R; a.g_H = g_H; a.g_Q = g_Q; a.g_c = g_c; a.g_d = g_d;
+      a.tape_T = dims->T; a.y_T = dims->T; a.tile_tape = nullptr; a.init_ab = nullptr; a.init_Pb = nullptr; a.accumulate = 0;
+      rc = kf_launch_backward_steady(h, a, ts, s_ab, s_Pb, s_P, (hipStream_t)stream, s_Pc);  // writes every gradient (zeros where it has none)
+      if (rc) return rc;
+      rc = kf_launch_dare_backward(h, dims->B, dims->m, dims->p, dims->r, T, Z, R, H, Q, s_P, s_Pb, g_T, g_Z, g_R, g_H, g_Q,
+                                   /*accumulate=*/1, nullptr, (hipStream_t)stream, /*h_diag_only=*/1);
+      if (rc) return rc;
+      a.pred_a = nullptr; a.tile_tape = tape; a.steps = ts; a.init_ab = s_ab; a.accumulate = 1;
+      return kf_launch_backward_b4(h, a, w, inner_ts, (hipStream_t)stream);
     }
     KfBwdArgs a;
     a.B = dims->B; a.T = dims->T; a.p = dims->p; a.m = dims->m; a.r = dims->r; a.filter = dims->filter; a.flags = dims->flags;

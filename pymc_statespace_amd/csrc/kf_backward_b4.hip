@@ -51,7 +51,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   const int g = lane >> 4, bq = lane & 15, q = lane & 3;
   const int fb = q * 4 + ((lane >> 2) & 3);  // position of column bq in a transpose-tile row / the exchange vector
   const long b = blockIdx.x;
-  const int n = A.T, m = A.m, mm = m * m, r_ = A.r;
+  // per-draw step counts (the steady-state adjoint took the steps behind ts = steps[b], kf_backward_steady.hip): the sweep runs
+  // steps ts-1 .. 1 from G = d L / d S_ts, the de-augmentation's inverse of (a_b, P_b) = (init_ab, 0); tapes / y stay strided by
+  // tape_T / y_T and indexed by the absolute step
+  const int n = A.steps ? (A.steps[b] < A.T ? A.steps[b] : A.T) : A.T;
+  const int m = A.m, mm = m * m, r_ = A.r;
 
   double* TR = smem;
   double* UX = smem + BB_OFF_UX;
@@ -146,6 +150,18 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     G[I] = Tb[I] = 0.0;
     if (CB_REG) Cbr[CB_REG ? I : 0] = 0.0;
     else CB[I * KF_WAVE + lane] = 0.0;
+  }
+  if (A.init_ab) {
+    // a enters the tile as S[i][JC] = S[JC][i] = 2 a_i: with G symmetric, a_b[i] = 4 G[i][JC] (the epilogue below); the derived
+    // entries (row / column JA) carry no adjoint of their own -- any extension of the objective off the consistent tiles has the
+    // same total derivative
+    const double* ib = A.init_ab + b * (long)m;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      const int rr = 4 * I + g;
+      if (rr < m && bq == JC) G[I] = 0.25 * ib[rr];
+      else if (rr == JC && bq < m) G[I] = 0.25 * ib[bq];
+    }
   }
   double Hb = 0.0, dacc = 0.0;
 
@@ -282,6 +298,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   }
 
   // ---- after the sweep: G = d L / d S_1.  Chain rule to (T, Z, R, Q, H, c, d), de-augmentation to (a_b, P_b) ------------------
+  const bool acc = A.accumulate != 0;  // (the steady-state adjoint's shares are in the outputs already)
   double cb_fin[NB];
 #pragma unroll
   for (int I = 0; I < NB; ++I) cb_fin[I] = CB_REG ? Cbr[CB_REG ? I : 0] : CB[I * KF_WAVE + lane];
@@ -341,7 +358,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   const double CAA = EC[JA * N4 + JA], CAC = EC[JA * N4 + JC], GAA = EG[JA * N4 + JA], GAC = EG[JA * N4 + JC];
   for (int e = lane; e < mm; e += KF_WAVE) {
     const int i = e / m, j = e - i * m;
-    if (A.g_T) A.g_T[b * (long)mm + e] = EB[i * N4 + j] + vz[i] * vt[j];
+    if (A.g_T) A.g_T[b * (long)mm + e] = (acc ? A.g_T[b * (long)mm + e] : 0.0) + EB[i * N4 + j] + vz[i] * vt[j];
     // symmetrised adjoint of R Q R' (the recursion sees sym(R Q R') only, kalman_filter.py:221)
     Ms[e] = 0.5 * (EC[i * N4 + j] + EC[j * N4 + i]) + vA[i] * vz[j] + vz[i] * vA[j] + CAA * vz[i] * vz[j];
     // adjoint of P_pred[1] (symmetric)
@@ -358,14 +375,14 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
       s += 2.0 * 0.5 * (P1[i * p1s + j] + P1[j * p1s + i]) * v1[j];                 // S_1 column JA = P_1 z'
     }
     s += 2.0 * CAA * vq[i] + 4.0 * CAC * ci + 2.0 * GAA * vp[i] + 4.0 * GAC * a1f * a1[i * a1s];
-    if (A.g_Z) A.g_Z[b * (long)m + i] = s;
-    if (A.g_c) A.g_c[b * (long)m + i] = 4.0 * EC[i * N4 + JC] + 4.0 * CAC * vz[i];
+    if (A.g_Z) A.g_Z[b * (long)m + i] = (acc ? A.g_Z[b * (long)m + i] : 0.0) + s;
+    if (A.g_c) A.g_c[b * (long)m + i] = (acc ? A.g_c[b * (long)m + i] : 0.0) + 4.0 * EC[i * N4 + JC] + 4.0 * CAC * vz[i];
     scratch[b * (long)m + i] = 4.0 * EG[i * N4 + JC] + 4.0 * GAC * vz[i];   // adjoint of a_pred[1]
   }
   if (lane == 0) {
-    if (A.g_H) A.g_H[b] = Hb;
+    if (A.g_H) A.g_H[b] = (acc ? A.g_H[b] : 0.0) + Hb;
   }
-  if (lane == JC && A.g_d) A.g_d[b] = -2.0 * dsign * dacc;
+  if (lane == JC && A.g_d) A.g_d[b] = (acc ? A.g_d[b] : 0.0) + -2.0 * dsign * dacc;
   wave_lds_fence();
   // R_b = Ms R (Q + Q') ;  Q_b = R' Ms R
   for (int e = lane; e < m * r_; e += KF_WAVE) {
@@ -380,14 +397,14 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
       const int i = e / r_, l = e - i * r_;
       double s = 0.0;
       for (int k = 0; k < r_; ++k) s += MR[i * r_ + k] * (gQ[k * r_ + l] + gQ[l * r_ + k]);
-      A.g_R[b * (long)m * r_ + e] = s;
+      A.g_R[b * (long)m * r_ + e] = (acc ? A.g_R[b * (long)m * r_ + e] : 0.0) + s;
     }
   if (A.g_Q)
     for (int e = lane; e < r_ * r_; e += KF_WAVE) {
       const int k = e / r_, l = e - k * r_;
       double s = 0.0;
       for (int i = 0; i < m; ++i) s += gR[i * r_ + k] * MR[i * r_ + l];
-      A.g_Q[b * (long)r_ * r_ + e] = s;
+      A.g_Q[b * (long)r_ * r_ + e] = (acc ? A.g_Q[b * (long)r_ * r_ + e] : 0.0) + s;
     }
 }
 
@@ -439,6 +456,7 @@ int kf_launch_backward_b4(kf_handle* h, const KfBwdArgs& a, void* workspace, siz
   tail.init_ab = scratch;               // [B][m]
   tail.init_Pb = scratch + a.B * a.m;   // [B][m][m]
   tail.accumulate = 1;
+  tail.steps = nullptr;  // (the tail is step 0 of every draw, whatever part of the sweep the steady-state adjoint took)
   if (a.tile_tape) {  // the tail's one tape row is the caller's (a0, P0) itself
     tail.tile_tape = nullptr;
     tail.pred_a = a.a0;

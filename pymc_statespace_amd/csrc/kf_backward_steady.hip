@@ -38,7 +38,7 @@ constexpr int SA_TOTAL = SA_OFF_X + 768;
 
 __global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_kernel(const KfBwdArgs A, const int32_t* __restrict__ ts_all,
                                                                  double* __restrict__ out_ab, double* __restrict__ out_Pb,
-                                                                 double* __restrict__ out_P) {
+                                                                 double* __restrict__ out_P, const double* __restrict__ P_conv) {
   __shared__ __attribute__((aligned(16))) double smem[SA_TOTAL];
   const int lane = threadIdx.x;
   const long b = blockIdx.x;
@@ -56,7 +56,9 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_kernel(const KfBwdArgs 
   double* X2 = X1 + 256;
 
   const double* gpa = A.pred_a + b * (long)(A.tape_T + 1) * m;
-  const double* gpP = A.pred_P + b * (long)(A.tape_T + 1) * mm;
+  // the converged predicted covariance: slot ts of the predicted tape, or (P_conv: the p == 1 block kernel keeps no compact
+  // covariance tape) the [B][m][m] array the forward kernel left
+  const double* gpP = P_conv ? P_conv + b * (long)mm : A.pred_P + b * (long)(A.tape_T + 1) * mm;
   const double* gT = A.Tm + b * (long)mm;
   const double* gZ = A.Z + b * (long)p * m;
   const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;  // :335 quirk: y_hat = Z a - d
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_kernel(const KfBwdArgs 
 
   for (int e = lane; e < SA_OFF_X; e += KF_WAVE) smem[e] = 0.0;
   wave_lds_fence();
-  const int tsc = ts < n ? ts : n;  // (a draw that never converged: P of slot n, nothing to sweep)
+  const int tsc = P_conv ? 0 : (ts < n ? ts : n);  // (a draw that never converged: P of slot n, nothing to sweep)
   for (int e = lane; e < mm; e += KF_WAVE) {
     const int i = e / m, j = e - i * m;
     const double pij = 0.5 * (gpP[(long)tsc * mm + e] + gpP[(long)tsc * mm + j * m + i]);
@@ -363,12 +365,12 @@ size_t kf_backward_steady_workspace_bytes(long B, int m) {
 }
 
 int kf_launch_backward_steady(kf_handle* h, const KfBwdArgs& a, const int32_t* ts, double* out_ab, double* out_Pb, double* out_P,
-                              hipStream_t stream) {
+                              hipStream_t stream, const double* P_conv) {
   if (!kf_backward_steady_ok(a.m, a.p, a.r) || (a.flags & KF_FLAG_TV_ANY) || a.g_ll_obs) {  // (one cotangent per draw: g_logp)
     KF_SET_ERR(h, "backward(steady): needs m <= %d, p <= %d, static matrices (got m=%d p=%d)", SA_M, SA_P, a.m, a.p);
     return KF_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(kf_bwd_steady_kernel, dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, ts, out_ab, out_Pb, out_P);
+  hipLaunchKernelGGL(kf_bwd_steady_kernel, dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, ts, out_ab, out_Pb, out_P, P_conv);
   KF_HIP_CHECK(h, hipGetLastError());
   return KF_OK;
 }

@@ -69,10 +69,15 @@ __device__ __forceinline__ void sfor(F&& f) {
 // SS: 0 the recursion at every step (KF_FLAG_EXACT_RECURSION); 1 the steady-state phase inside this kernel (no workspace); 2 one
 // CHUNK of the split pipeline (kf_forward_b4_steady.hip): steps [A.t_begin, A.t_end) of the draws A.list names, the wavefront
 // leaves as soon as its covariance has converged and hands the draw to the time-parallel steady kernels
+// TM == 16 with SS == 1 ("VGS"): the forward half of kf_filter_value_and_grad with the steady-state adjoint behind it
+// (kf_backward_steady.hip): the tile tape is written for the steps of the covariance recursion only; from the convergence point ts
+// on the mean recursion leaves a_t in the compact predicted-state tape (slots ts .. n) -- all the steady-state adjoint reads -- and
+// the draw reports ts (A.hs_ts) and its converged predicted covariance (A.vg_P)
 template <int NB, bool STREAM, int TM, int SS>
 __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) void kf_fwd_b4_kernel(const KfFwdArgs A) {
   // (waves_per_eu(4): <= 128 registers, and the compiler then keeps MFMA results in VGPRs -- no v_accvgpr moves)
   constexpr int N4 = 4 * NB, JA = N4 - 2, JC = N4 - 1;
+  constexpr bool VGS = TM == 16 && SS == 1 && STREAM;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const int g = lane >> 4, bq = lane & 15;       // bq = 4 b + q: column index of the lane
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   // the gain, F and both covariances are constants and only the mean is left: a_{t+1} = (T - T K Z) a_t + T K (y_t -+ d) + c
   // -- the loop at the end of this kernel.  (statsmodels' Kalman filter does the same by default, `tolerance`; the
   // reference recomputes everything every step, results agree to ~1e-13 relative.  KF_FLAG_EXACT_RECURSION switches it off.)
-  const bool steady_en = SS != 0 && STREAM && !w_tile && n >= 64;
+  const bool steady_en = SS != 0 && STREAM && (!w_tile || VGS) && n >= 64;
   int t_free = 0;  // first step after the last missing observation
   if (SS == 2 && t0 > 0) {
     t_free = A.hs_tfree[b];
@@ -466,6 +471,19 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       break;
     }
   }
+  if constexpr (VGS) {
+    // t = the first step of the steady-state phase (n: the covariance never converged); P = the predicted tile of step t
+    if (lane == 0) A.hs_ts[b] = t;
+    double* vp = A.vg_P + b * (long)mm;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+      if (on[I]) vp[(4 * I + g) * m + bq] = P[I];
+    if (t < n) {  // a_t .. a_n into slots t .. n of the compact predicted-state tape
+      s_pa.init(A.pred_a + (b * (long)(n + 1) + t) * m, smem + B4_OFF_RA + RING_A);
+      o_pa = s_pa.slot(bq);
+      put_a(s_pa, o_pa, P[NB - 1], vec_on);
+    }
+  }
   if constexpr (SS == 1 && STREAM) if (t < n) {
     // ---- steady-state steps t .. n-1 (see above); P is the converged predicted tile of step t -------------------------------
     const double us = high_half_everywhere(P[NB - 1]) * mask0;  // row JA: (P Z')' with Z P Z' at JA (DPP row 0)
@@ -554,7 +572,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       // (tried: both constant covariance tapes written in one go at the start of this phase, as kf_forward_b4q.hip does -- headline
       // 1.81 ms against 1.63, C3 6.7 against 6.2: the burst of stores delays the window flushes of the SIMD's other wavefronts)
       if (w_fP) put_P(s_fP, o_fP, Pf);
-      if (w_pa) put_a(s_pa, o_pa, o1 + o1, row0);
+      if (w_pa || VGS) put_a(s_pa, o_pa, o1 + o1, row0);
       if (w_pP) put_P(s_pP, o_pP, P);
       if ((t & (LB - 1)) == LB - 1) flush_ring(t - (LB - 1), LB);
     }
@@ -641,7 +659,11 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size
   const int lds_setup = b4_setup_doubles(a.m, a.r);
   const size_t lds = sizeof(double) * (size_t)(B4_LOOP_DOUBLES > lds_setup ? B4_LOOP_DOUBLES : lds_setup);
   const int nb = (a.m + 2 + 3) / 4;
-  const int mask = (a.filt_a ? 1 : 0) | (a.pred_a ? 2 : 0) | (a.filt_P ? 4 : 0) | (a.pred_P ? 8 : 0) | (a.tile_tape ? 16 : 0);
+  // kf_filter_value_and_grad with the steady-state adjoint behind it ("VGS", kernel header): the tile tape for the recursion's steps,
+  // a_t in the compact predicted-state tape from the convergence point on -- pred_a is then NOT a tape request (mask stays 16)
+  const bool vgs = a.tile_tape && a.hs_ts && a.vg_P && a.pred_a && !a.filt_a && !a.filt_P && !a.pred_P && a.T >= 64 &&
+                   !(a.flags & KF_FLAG_EXACT_RECURSION);
+  const int mask = (a.filt_a ? 1 : 0) | ((a.pred_a && !vgs) ? 2 : 0) | (a.filt_P ? 4 : 0) | (a.pred_P ? 8 : 0) | (a.tile_tape ? 16 : 0);
   // steady-state phase (kernel header): a second instantiation, so that KF_FLAG_EXACT_RECURSION runs the very kernel it ran before
   // (KF_STEADY_STATE=0 in the environment: the same switch for A/B measurements)
   // Steady-state phase: only for LONG series (T >= KF_B4_STEADY_MIN_T).  At the north-star length (T = 1000) the recursion at every
@@ -672,6 +694,8 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size
     if (mask == 15) KF_B4_LAUNCH2(NB_, ST_, 15);         \
     else if (mask == 0) KF_B4_LAUNCH2(NB_, ST_, 0);      \
     else if (mask == 10) KF_B4_LAUNCH2(NB_, ST_, 10);    \
+    else if (mask == 16 && vgs && ST_)                   \
+      hipLaunchKernelGGL((kf_fwd_b4_kernel<NB_, ST_, 16, ST_ ? 1 : 0>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); \
     else if (mask == 16) KF_B4_LAUNCH2(NB_, ST_, 16);    \
     else KF_B4_LAUNCH2(NB_, ST_, -1);                    \
   } while (0)

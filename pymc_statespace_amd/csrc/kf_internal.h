@@ -102,6 +102,7 @@ struct KfFwdArgs {
   double ss_tol2 = 1e-24;       // (square of) the entrywise tolerance of the steady-state test, 1e-12 of sqrt(P_ii P_jj)
   int skip_steady_cov = 0;      // internal (kf_filter_value_and_grad): the steady-state phase leaves the constant covariance tapes unwritten
   int32_t* hs_tfree = nullptr;  // [B] first step after the last missing observation (written by the first chunk)
+  double* vg_P = nullptr;       // internal (kf_filter_value_and_grad, block kernel + steady-state adjoint): [B][m][m] the predicted covariance at hs_ts[b]
 };
 
 struct KfBwdArgs {
@@ -241,7 +242,7 @@ int kf_launch_backward_mfma(kf_handle* h, const KfBwdArgs& a, hipStream_t stream
 bool kf_backward_steady_ok(int m, int p, int r);
 size_t kf_backward_steady_workspace_bytes(long B, int m);
 int kf_launch_backward_steady(kf_handle* h, const KfBwdArgs& a, const int32_t* ts, double* out_ab, double* out_Pb, double* out_P,
-                              hipStream_t stream);
+                              hipStream_t stream, const double* P_conv = nullptr);
 // lane-per-draw kernels for tiny m (kf_forward_lane.hip)
 #define KF_LANE_M_MAX 4
 int kf_launch_forward_lane_m1(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);

@@ -89,11 +89,13 @@ class KalmanEngine:
         True passes KF_FLAG_EXACT_RECURSION, i.e. the forward kernels never switch to their steady-state phase."""
         self._exact_recursion = bool(on)
 
-    def forward_kernel_name(self, B, n, p, m, r, filter_type="standard", h_diagonal=False) -> str:
+    def forward_kernel_name(self, B, n, p, m, r, filter_type="standard", h_diagonal=False, time_varying=()) -> str:
         """Kernel ``forward`` launches for this shape (``forward`` always passes the workspace)."""
         dims = self._dims(B, n, p, m, r, filter_type)
         if h_diagonal:
             dims.flags |= _lib.KF_FLAG_H_DIAGONAL
+        for name in time_varying:
+            dims.flags |= _lib.KF_FLAG_TV[name]
         return self.lib.kf_forward_kernel_name(self._h, C.byref(dims)).decode()
 
     def _workspace(self, dims, which=_lib.KF_WS_ALL):

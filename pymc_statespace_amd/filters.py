@@ -75,18 +75,21 @@ class BaseFilter:
         return self._engine
 
     # -- symbolic (PyTensor) ---------------------------------------------------------------
-    def build_graph(self, data, a0, P0, T, Z, R, H, Q, c=None, d=None, mode=None, outputs="all"):
+    def build_graph(self, data, a0, P0, T, Z, R, H, Q, c=None, d=None, mode=None, outputs="all", batched=False):
         """Reference signature (kalman_filter.py:126-128).  Returns
         [filtered_states, predicted_states, filtered_covariances, predicted_covariances,
          log_likelihood, ll_obs]; the node computes and copies back only the outputs the compiled graph
         consumes.  ``outputs="logp"`` (extension) returns the log-likelihood alone from the fused
-        value-and-gradient Op (see op.py) -- what a model that registers no tape Deterministics needs."""
-        from .op import kalman_filter_graph  # imports pytensor; fails loudly without it
+        value-and-gradient Op (see op.py) -- what a model that registers no tape Deterministics needs.
+        ``batched=True`` (extension): a0 .. Q (and c, d) carry ONE leading axis of B parameter draws -- the graph
+        ``pytensor.graph.replace.vectorize_graph`` makes of the per-draw one, built directly; every output gains the leading
+        axis and ``outputs="logp"`` is logp (B,) whose gradient costs ONE kf_filter_value_and_grad call for all draws."""
+        from .op import kalman_filter_batched_graph, kalman_filter_graph  # imports pytensor; fails loudly without it
 
         self.mode = mode
-        return kalman_filter_graph(data, a0, P0, T, Z, R, H, Q, c=c, d=d,
-                                   filter_type=self.filter_type, mvn_const=self.mvn_const,
-                                   h_diagonal=self.h_diagonal, outputs=outputs)
+        build = kalman_filter_batched_graph if batched else kalman_filter_graph
+        return build(data, a0, P0, T, Z, R, H, Q, c=c, d=d, filter_type=self.filter_type, mvn_const=self.mvn_const,
+                     h_diagonal=self.h_diagonal, outputs=outputs)
 
     def update(self, *args, **kwargs):
         # reference BaseFilter.update raises (kalman_filter.py:225-229); the fused kernels

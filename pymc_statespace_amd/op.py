@@ -144,7 +144,7 @@ def perform_filter_batched(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="stand
     layouts (a0 (B,m,1), ...) -> the six reference outputs with a leading B (logp (B,), ll_obs (B,n))."""
     eng = engine or get_engine()
     data = np.asarray(data, dtype=np.float64)
-    if data.ndim == 3:
+    if data.ndim in (3, 4):  # (n,p,1) shared by all draws, or (B,n,p,1): one series per draw (KF_FLAG_Y_PER_DRAW)
         data = data[..., 0]
 
     def vec(x):
@@ -165,6 +165,35 @@ def perform_filter_batched(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="stand
         res.logp.cpu().numpy(),
         res.ll_obs.cpu().numpy() if want[5] else None,
     ]
+
+
+def perform_logp_and_grad_batched(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standard",
+                                  mvn_const="reference", h_diagonal=False, engine=None):
+    """B draws, value AND gradient, in ONE ``kf_filter_value_and_grad`` call -- the sampler's call over a batch of draws
+    (vectorised chains, SMC particles, ``vectorize_graph`` over the model's logp; the loop this replaces is the per-draw Python
+    loop of reference core/statespace.py:230-236 wrapped around the Potential of :174).
+    data (n,p,1) shared by all draws -- or (B,n,p,1), one series per draw -- and every other input with a leading axis B in the
+    reference layouts (a0 (B,m,1), P0 (B,m,m), ..., c (B,m,1), d (B,p,1)) -> [logp (B,), g_a0 (B,m,1), g_P0, g_T, g_Z, g_R,
+    g_H, g_Q, g_c (B,m,1), g_d (B,p,1)]: row b of every gradient is d logp[b] / d (that input's row b)."""
+    eng = engine or get_engine()
+    data = np.asarray(data, dtype=np.float64)
+    if data.ndim in (3, 4):
+        data = data[..., 0]
+
+    def vec(x):
+        x = np.asarray(x, dtype=np.float64)
+        return x[..., 0] if x.ndim == 3 and x.shape[-1] == 1 else x
+
+    mats = [np.asarray(x, dtype=np.float64) for x in (P0, T, Z, R, H, Q)]
+    if any(x.ndim != 3 for x in mats):
+        raise NotImplementedError("the batched log-likelihood Op takes static system matrices with ONE leading draw axis")
+    logp, info, g = eng.value_and_grad(data, vec(a0), *mats, vec(c), vec(d), filter_type=filter_type,
+                                       mvn_const=mvn_const, h_diagonal=bool(h_diagonal))
+    _raise_if_not_pd(info)
+    out = {k: g[k].cpu().numpy() for k in GRAD_INPUT_NAMES}
+    for k in ("a0", "c", "d"):
+        out[k] = out[k][..., None]
+    return [logp.cpu().numpy()] + [out[k] for k in GRAD_INPUT_NAMES]
 
 
 def perform_filter_grad(data, a0, P0, T, Z, R, H, Q, c, d, predicted_states, predicted_covs,
@@ -285,6 +314,17 @@ def perform_smoother(T, R, Q, filtered_states, filtered_covs, engine=None):
 _OPS = None
 
 
+def _placeholder(ndim):
+    """What an Op stores for an output it was told not to compute: zero-size for ndim >= 1, NaN for a 0-d output
+    (np.zeros(()) would be the VALUE 0.0 -- a silent wrong answer for a log-likelihood; NaN cannot be mistaken for one)."""
+    return np.zeros((0,) * ndim, dtype=np.float64) if ndim else np.asarray(np.nan, dtype=np.float64)
+
+
+def _shapes_following_want(shapes, want):
+    """infer_shape of an Op with a ``want`` mask: an output that is not computed has the placeholder's shape."""
+    return [s if w else (0,) * len(s) for s, w in zip(shapes, want)]
+
+
 OUTPUT_NAMES = ("filtered_states", "predicted_states", "filtered_covariances", "predicted_covariances",
                 "log_likelihood", "ll_obs")
 
@@ -362,13 +402,13 @@ def _build_ops():
                                   h_diagonal=self.h_diagonal, want=want)
             for storage, o, var in zip(output_storage, outs, node.outputs):
                 # an output nothing consumes still needs a correctly typed placeholder
-                storage[0] = (_out(o) if o is not None
-                              else np.zeros((0,) * var.type.ndim, dtype=np.float64))
+                storage[0] = _out(o) if o is not None else _placeholder(var.type.ndim)
 
         def infer_shape(self, fgraph, node, shapes):
             n = shapes[0][0]
             m = shapes[3][-1]  # T is (m,m), or (n,m,m) when time-varying
-            return [(n, m, 1), (n + 1, m, 1), (n, m, m), (n + 1, m, m), (), (n,)]
+            want = tuple(self.want[:4]) + (True, self.want[5])  # (the log-likelihood is always computed)
+            return _shapes_following_want([(n, m, 1), (n + 1, m, 1), (n, m, m), (n + 1, m, m), (), (n,)], want)
 
         def connection_pattern(self, node):
             # data is never differentiated; every system matrix reaches every output
@@ -394,10 +434,11 @@ def _build_ops():
                         for k in range(1, 10)]
                 fused = KalmanLogpOp(self.filter_type, self.mvn_const, self.h_diagonal)(*inputs)
                 return [DisconnectedType()()] + [g_logp * fused[1 + k] for k in range(9)]
+            # (zero cotangents shaped from the INPUTS: outputs[5] is a zero-size placeholder when ll_obs was not requested)
             if isinstance(g_logp.type, DisconnectedType):
-                g_logp = pt.zeros_like(outputs[4])
+                g_logp = pt.zeros(())
             if isinstance(g_ll.type, DisconnectedType):
-                g_ll = pt.zeros_like(outputs[5])
+                g_ll = pt.zeros((inputs[0].shape[0],))
             grads = KalmanFilterGradOp(self.filter_type, self.mvn_const, self.h_diagonal)(
                 *inputs, outputs[1], outputs[3], g_logp, g_ll)
             return [DisconnectedType()()] + list(grads)
@@ -432,6 +473,43 @@ def _build_ops():
             g = output_grads[0]
             return [DisconnectedType()()] + [g * outputs[1 + k] for k in range(9)]
 
+    def _bcast_rows(g, like):
+        """cotangent g (B,) against a (B, ...) gradient array: g[:, None, ...] * like."""
+        return g.dimshuffle(0, *(["x"] * (like.type.ndim - 1))) * like
+
+    class KalmanLogpBatchedOp(Op):
+        """[logp (B,), g_a0, g_P0, g_T, g_Z, g_R, g_H, g_Q, g_c, g_d] = Op(data, a0, P0, T, Z, R, H, Q, c, d) with a leading draw
+        axis B on a0 .. d (data (n,p,1) shared, or (B,n,p,1)): value and gradient of B draws from ONE perform = ONE
+        kf_filter_value_and_grad call (perform_logp_and_grad_batched).  What ``vectorize_graph`` maps ``KalmanLogpOp`` to, and
+        what ``KalmanFilterBatchedOp`` differentiates its log-likelihood through: the batch-of-draws axis reaches the batched
+        kernels WITH gradients through ``build_statespace_graph()``."""
+        __props__ = ("filter_type", "mvn_const", "h_diagonal")
+
+        def __init__(self, filter_type="standard", mvn_const="reference", h_diagonal=False):
+            self.filter_type, self.mvn_const, self.h_diagonal = filter_type, mvn_const, bool(h_diagonal)
+
+        def make_node(self, data, a0, P0, T, Z, R, H, Q, c, d):
+            ins = [pt.as_tensor_variable(x) for x in (data, a0, P0, T, Z, R, H, Q, c, d)]
+            if any(v.type.ndim != 3 for v in ins[1:]) or ins[0].type.ndim not in (3, 4):
+                raise TypeError("KalmanLogpBatchedOp: a0 .. d carry one leading draw axis (3-D each); data is (n,p,1) or (B,n,p,1)")
+            return Apply(self, ins, [pt.vector(dtype=f64)] + [ins[i].type() for i in range(1, 10)])
+
+        def perform(self, node, inputs, output_storage):
+            outs = perform_logp_and_grad_batched(*inputs, filter_type=self.filter_type, mvn_const=self.mvn_const,
+                                                 h_diagonal=self.h_diagonal)
+            for storage, o in zip(output_storage, outs):
+                storage[0] = _out(o)
+
+        def infer_shape(self, fgraph, node, shapes):
+            return [(shapes[2][0],)] + [shapes[i] for i in range(1, 10)]
+
+        def connection_pattern(self, node):
+            return [[False] * 10] + [[True] + [False] * 9 for _ in range(9)]
+
+        def L_op(self, inputs, outputs, output_grads):
+            g = output_grads[0]  # (B,): draw b's cotangent scales row b of every gradient array
+            return [DisconnectedType()()] + [_bcast_rows(g, outputs[1 + k]) for k in range(9)]
+
     class KalmanFilterBatchedOp(Op):
         """KalmanFilterOp with a leading draw axis B on a0 .. d (data shared): outputs B-leading."""
         __props__ = ("filter_type", "mvn_const", "h_diagonal", "want")
@@ -451,16 +529,26 @@ def _build_ops():
             outs = perform_filter_batched(*inputs, filter_type=self.filter_type, mvn_const=self.mvn_const,
                                           h_diagonal=self.h_diagonal, want=want)
             for storage, o, var in zip(output_storage, outs, node.outputs):
-                storage[0] = (_out(o) if o is not None
-                              else np.zeros((0,) * var.type.ndim, dtype=np.float64))
+                storage[0] = _out(o) if o is not None else _placeholder(var.type.ndim)
 
         def infer_shape(self, fgraph, node, shapes):
-            n, B, m = shapes[0][0], shapes[3][0], shapes[3][1]
-            return [(B, n, m, 1), (B, n + 1, m, 1), (B, n, m, m), (B, n + 1, m, m), (B,), (B, n)]
+            n, B, m = shapes[0][-3], shapes[3][0], shapes[3][1]
+            want = tuple(self.want[:4]) + (True, self.want[5])
+            return _shapes_following_want([(B, n, m, 1), (B, n + 1, m, 1), (B, n, m, m), (B, n + 1, m, m), (B,), (B, n)], want)
+
+        def connection_pattern(self, node):
+            return [[False] * 6] + [[True] * 6 for _ in range(9)]
 
         def L_op(self, inputs, outputs, output_grads):
-            return [grad_not_implemented(self, k, inputs[k], "use KalmanLogpOp per draw for gradients")
-                    for k in range(10)]
+            # gradients flow through the per-draw log-likelihoods only, and come from the fused batched value-and-gradient
+            # node (one kf_filter_value_and_grad call for all B draws)
+            others = [output_grads[i] for i in (0, 1, 2, 3, 5)]
+            if any(not isinstance(g.type, DisconnectedType) for g in others):
+                return [DisconnectedType()()] + [
+                    grad_not_implemented(self, k, inputs[k], "the batched filter is differentiated through log_likelihood only")
+                    for k in range(1, 10)]
+            fused = KalmanLogpBatchedOp(self.filter_type, self.mvn_const, self.h_diagonal)(*inputs)
+            return [DisconnectedType()()] + [_bcast_rows(output_grads[4], fused[1 + k]) for k in range(9)]
 
     class SteadyStateGradOp(Op):
         """gradients = Op(data, a0, P0, T, Z, R, H, Q, c, d, g_logp, g_ll_obs) -- perform_steady_state_grad."""
@@ -501,8 +589,7 @@ def _build_ops():
             want = self.want
             outs = perform_steady_state(*inputs, mvn_const=self.mvn_const, want=want)
             for storage, o, var in zip(output_storage, outs, node.outputs):
-                storage[0] = (_out(o) if o is not None
-                              else np.zeros((0,) * var.type.ndim, dtype=np.float64))
+                storage[0] = _out(o) if o is not None else _placeholder(var.type.ndim)
 
         def infer_shape(self, fgraph, node, shapes):
             n, m = shapes[0][0], shapes[3][0]
@@ -554,15 +641,18 @@ def _build_ops():
     try:  # vectorize_graph (PyMC's draw-vectorised predictive sampling) -> the batched kernels
         from pytensor.graph.replace import _vectorize_node
 
-        @_vectorize_node.register(KalmanFilterOp)
-        def _vectorize_kalman_filter(op, node, data, *mats):
+        def _batched_inputs(node, data, mats):
+            """Inputs of a per-draw node after vectorize_graph gave some of them ONE leading draw axis -> (data, B-leading mats),
+            or None when nothing is batched.  Unbatched matrices are broadcast along the new axis."""
             core = [v.type.ndim for v in node.inputs[1:]]  # a0, c, d are (m,1) / (p,1) columns: 2-D per draw
             if any(nd != 2 for nd in core):
                 raise NotImplementedError("vectorize_graph over a time-varying Kalman filter node")
-            if data.type.ndim != node.inputs[0].type.ndim or not any(
-                    x.type.ndim > nd for x, nd in zip(mats, core)):
-                return op.make_node(data, *mats)
-            B = None
+            d_extra = data.type.ndim - node.inputs[0].type.ndim
+            if d_extra not in (0, 1):
+                raise NotImplementedError("one leading batch axis only")
+            if d_extra == 0 and not any(x.type.ndim > nd for x, nd in zip(mats, core)):
+                return None
+            B = data.shape[0] if d_extra else None
             for x, nd in zip(mats, core):
                 if x.type.ndim == nd + 1:
                     B = x.shape[0]
@@ -570,7 +660,22 @@ def _build_ops():
                     raise NotImplementedError("one leading batch axis only")
             mats = [x if x.type.ndim == nd + 1 else pt.broadcast_to(x, (B,) + tuple(x.shape))
                     for x, nd in zip(mats, core)]
-            return KalmanFilterBatchedOp(op.filter_type, op.mvn_const, op.h_diagonal, op.want).make_node(data, *mats)
+            return data, mats
+
+        @_vectorize_node.register(KalmanFilterOp)
+        def _vectorize_kalman_filter(op, node, data, *mats):
+            bi = _batched_inputs(node, data, mats)
+            if bi is None:
+                return op.make_node(data, *mats)
+            return KalmanFilterBatchedOp(op.filter_type, op.mvn_const, op.h_diagonal, op.want).make_node(bi[0], *bi[1])
+
+        @_vectorize_node.register(KalmanLogpOp)
+        def _vectorize_kalman_logp(op, node, data, *mats):
+            # the sampler's node over a batch of draws: logp (B,) and the nine gradient arrays from ONE perform
+            bi = _batched_inputs(node, data, mats)
+            if bi is None:
+                return op.make_node(data, *mats)
+            return KalmanLogpBatchedOp(op.filter_type, op.mvn_const, op.h_diagonal).make_node(bi[0], *bi[1])
     except ImportError:  # pragma: no cover - older PyTensor
         pass
 
@@ -598,9 +703,31 @@ def _build_ops():
     _OPS = dict(pt=pt, pytensor=pytensor, KalmanFilterOp=KalmanFilterOp,
                 KalmanFilterGradOp=KalmanFilterGradOp, KalmanSmootherOp=KalmanSmootherOp,
                 KalmanLogpOp=KalmanLogpOp, KalmanFilterBatchedOp=KalmanFilterBatchedOp,
+                KalmanLogpBatchedOp=KalmanLogpBatchedOp,
                 SteadyStateFilterOp=SteadyStateFilterOp, SteadyStateGradOp=SteadyStateGradOp,
                 SteadyStateLogpOp=SteadyStateLogpOp)
     return _OPS
+
+
+def kalman_filter_batched_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type="standard",
+                                mvn_const="reference", h_diagonal=False, outputs="all"):
+    """``kalman_filter_graph`` for inputs that already carry ONE leading draw axis B (a0 (B,m,1), P0 (B,m,m), ...; data (n,p,1)
+    shared or (B,n,p,1)): the graph ``vectorize_graph`` would produce, built directly.  ``outputs="logp"``: logp (B,) from
+    ``KalmanLogpBatchedOp`` (value and gradients of all draws from one C-ABI call); otherwise the six B-leading outputs."""
+    ops = _build_ops()
+    pt = ops["pt"]
+    a0, P0, T, Z, R, H, Q = (pt.as_tensor_variable(x) for x in (a0, P0, T, Z, R, H, Q))
+    for prm, name in zip((T, Z, R, H, Q), ("T", "Z", "R", "H", "Q")):
+        if prm.ndim != 3:
+            raise ValueError(f"Matrix {name} has {prm.ndim} dimensions, a batch of static matrices has 3 (draws, rows, columns).")
+    if c is None:
+        c = pt.zeros((T.shape[0], T.shape[-1], 1))
+    if d is None:
+        d = pt.zeros((Z.shape[0], Z.shape[-2], 1))
+    if outputs == "logp":
+        return ops["KalmanLogpBatchedOp"](filter_type, mvn_const, h_diagonal)(data, a0, P0, T, Z, R, H, Q, c, d)[0]
+    return list(ops["KalmanFilterBatchedOp"](filter_type, mvn_const, h_diagonal, want_mask(outputs))(
+        data, a0, P0, T, Z, R, H, Q, c, d))
 
 
 def kalman_filter_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type="standard",

@@ -69,6 +69,9 @@ class Variable:
     def sum(self):
         return SumAll()(self)
 
+    def dimshuffle(self, *order):
+        return DimShuffle(order)(self)
+
     def __repr__(self):
         return self.name or (f"{type(self.owner.op).__name__}.{self.index}" if self.owner else "<var>")
 
@@ -183,7 +186,11 @@ class Alloc(Op):
         output_storage[0][0] = np.array(np.broadcast_to(np.asarray(inputs[0], dtype=np.float64), shape), order="C")
 
     def L_op(self, inputs, outputs, output_grads):
-        return [grad_not_implemented(self, 0, inputs[0], "stand-in: Alloc")] + [DisconnectedType()() for _ in inputs[1:]]
+        # broadcast_to(x, (B,) + x.shape): the cotangent of x is the sum over the leading axes the broadcast added
+        # (same-rank broadcasting of size-1 axes is not needed by the adapter's graphs)
+        extra = self.ndim - inputs[0].ndim
+        gx = SumLeading(extra)(output_grads[0]) if extra else output_grads[0]
+        return [gx] + [DisconnectedType()() for _ in inputs[1:]]
 
     def connection_pattern(self, node):
         return [[True]] + [[False] for _ in node.inputs[1:]]
@@ -217,6 +224,45 @@ class Add(_Elemwise):
     def L_op(self, inputs, outputs, output_grads):
         (g,) = output_grads
         return [_unbroadcast(g, inputs[0]), _unbroadcast(g, inputs[1])]
+
+
+class DimShuffle(Op):
+    """x.dimshuffle(0, 'x', 'x'): permute the axes named by integers, insert a broadcastable axis for every 'x'."""
+    __props__ = ("order",)
+
+    def __init__(self, order):
+        self.order = tuple(order)
+
+    def make_node(self, x):
+        x = as_tensor_variable(x)
+        if sorted(o for o in self.order if o != "x") != list(range(x.ndim)):
+            raise ValueError(f"dimshuffle{self.order} does not name every axis of a {x.ndim}-d input once")
+        return Apply(self, [x], [Variable(TensorType("float64", len(self.order)))])
+
+    def perform(self, node, inputs, output_storage):
+        x = np.transpose(np.asarray(inputs[0]), [o for o in self.order if o != "x"])
+        output_storage[0][0] = np.ascontiguousarray(x[tuple(None if o == "x" else slice(None) for o in self.order)])
+
+    def L_op(self, inputs, outputs, output_grads):
+        return [grad_not_implemented(self, 0, inputs[0], "stand-in: DimShuffle")]
+
+
+class SumLeading(Op):
+    """sum over the first k axes."""
+    __props__ = ("k",)
+
+    def __init__(self, k):
+        self.k = int(k)
+
+    def make_node(self, x):
+        x = as_tensor_variable(x)
+        return Apply(self, [x], [Variable(TensorType("float64", x.ndim - self.k))])
+
+    def perform(self, node, inputs, output_storage):
+        output_storage[0][0] = np.asarray(np.sum(inputs[0], axis=tuple(range(self.k))), dtype=np.float64)
+
+    def L_op(self, inputs, outputs, output_grads):
+        return [grad_not_implemented(self, 0, inputs[0], "stand-in: SumLeading")]
 
 
 class SumAll(Op):

@@ -1,0 +1,158 @@
+"""Round-4 paths through the C-ABI against the oracle:
+
+* kf_filter_value_and_grad for the scalar-observation block kernel (p == 1, m <= 10) with the STEADY-STATE ADJOINT behind each
+  draw's convergence point (csrc/kf_forward_b4.hip "VGS" instantiation -> kf_bwd_steady_kernel -> kf_dare_bwd_kernel ->
+  kf_bwd_b4_kernel with per-draw step counts).  The reference's gradient is autodiff of the scan at every step
+  (core/statespace.py:174; kalman_filter.py:215-223, 255-284): asserted at 1e-10 of the largest entry against the exact adjoint
+  at every step (KF_VG_STEADY=0) and at 1e-9 against torch autograd of the restated recursion, including late missing
+  observations (the phase may start only behind the last of them) and draws whose covariance never converges.
+"""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import workloads as W
+
+pytestmark = pytest.mark.gpu
+KEYS = ("a0", "P0", "T", "Z", "R", "H", "Q")
+GRADS = ("a0", "P0", "T", "Z", "R", "H", "Q", "c", "d")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    from pymc_statespace_amd import KalmanEngine
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return KalmanEngine()
+
+
+def _never_converging(w, idx):
+    """Give the draws `idx` a unit-root level with a large Q / tiny H ratio drift: a random-walk-plus-drift state whose
+    predicted covariance keeps growing (P0 far from the fixpoint and T with an eigenvalue of exactly one, a second one above
+    0.9999: the Riccati iteration moves by ~1e-6 of itself per step for thousands of steps)."""
+    w = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in w.items()}
+    for b in idx:
+        w["T"][b, 0, 0] = 1.0
+        w["T"][b, 0, 1] = 1.0
+        w["T"][b, 1, 1] = 1.0
+        w["P0"][b] = 1e3 * np.eye(w["m"])
+        w["Q"][b] *= 1e-8
+    return w
+
+
+def _compare(eng, monkeypatch, w, y, ft, c=None, d=None, k=4, need_steady=True):
+    from oracle import kalman_torch as kt
+
+    B, m, p = w["B"], w["m"], w["p"]
+    rng = np.random.default_rng(11)
+    gl = 1.0 + 0.3 * rng.standard_normal(B)
+    args = (y,) + tuple(w[x] for x in KEYS)
+    kw = dict(c=c, d=d, g_logp=gl, filter_type=ft, mvn_const="exact")
+    lp, info, g = eng.value_and_grad(*args, **kw)
+    monkeypatch.setenv("KF_VG_STEADY", "0")
+    lpx, infox, gx = eng.value_and_grad(*args, **kw)
+    monkeypatch.delenv("KF_VG_STEADY")
+    lpe, _, ge = eng.value_and_grad(*args, exact_recursion=True, **kw)
+    assert not info.cpu().numpy().any() and not infox.cpu().numpy().any()
+    assert_allclose(lp.cpu().numpy(), lpx.cpu().numpy(), rtol=1e-12)
+    assert_allclose(lpe.cpu().numpy(), lpx.cpu().numpy(), rtol=0, atol=0)   # the flag and the switch select the same path
+    differs = False
+    for nm in GRADS:
+        a_, x_ = g[nm].cpu().numpy(), gx[nm].cpu().numpy()
+        assert np.all(np.isfinite(a_)), nm
+        differs = differs or not np.array_equal(a_, x_)
+        scale = 1.0 + np.max(np.abs(x_.reshape(B, -1)), axis=1)
+        err = np.max(np.abs(a_ - x_).reshape(B, -1), axis=1) / scale
+        assert err.max() < 1e-10, f"{nm} vs the exact adjoint: {err.max():.2e} (draw {err.argmax()})"
+        assert np.array_equal(ge[nm].cpu().numpy(), x_), nm
+    if need_steady:
+        assert differs, "the steady-state adjoint did not run (bitwise equal to the exact adjoint)"
+    cs = None if c is None else c[:k]
+    ds = None if d is None else d[:k]
+    rlp, _, rg = kt.logp_and_grads(y, *[w[x][:k] for x in KEYS], c=cs, d=ds, filter_type=ft, mvn_const="exact", g_logp=gl[:k])
+    assert np.max(np.abs(lp[:k].cpu().numpy() - rlp) / np.maximum(1.0, np.abs(rlp) / 1e4)) < 1e-8
+    for nm in GRADS:
+        a_ = g[nm].cpu().numpy()[:k].reshape(rg[nm].shape)
+        ref = rg[nm]
+        if nm in ("P0", "Q"):   # symmetric inputs: the symmetric parts agree
+            a_, ref = a_ + np.swapaxes(a_, -1, -2), ref + np.swapaxes(ref, -1, -2)
+        assert np.max(np.abs(a_ - ref)) / (1.0 + np.max(np.abs(ref))) < 1e-9, f"{nm} vs autograd"
+
+
+@pytest.mark.parametrize("ft", ["standard", "cholesky", "univariate", "single"])
+def test_value_and_grad_block_kernel_with_the_steady_state_adjoint(eng, monkeypatch, ft):
+    w = W.structural(B=24, n=400)
+    rng = np.random.default_rng(3)
+    c, d = 0.05 * rng.standard_normal((w["B"], w["m"])), 0.1 * rng.standard_normal((w["B"], 1))
+    _compare(eng, monkeypatch, w, w["y"], ft, c=c, d=d)
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 5, 6, 7, 9, 10])
+def test_value_and_grad_steady_state_adjoint_every_block_count(eng, monkeypatch, m):
+    """m + 2 <= 4 / 8 / 12: one, two and three 4 x 4 blocks per tile row; dense random stable models."""
+    w = W.random_dense(B=16, n=300, p=1, m=m, r=max(1, m // 2), seed=40 + m)
+    if m <= 4:
+        eng.set_forward_kernel("b4")   # (AUTO hands m <= 4 to the lane kernel: force the block kernels)
+    try:
+        _compare(eng, monkeypatch, w, w["y"], "standard")
+    finally:
+        eng.set_forward_kernel("auto")
+
+
+def test_value_and_grad_steady_state_adjoint_late_nans_and_slow_draws(eng, monkeypatch):
+    """Missing observations late in the series (the phase starts behind the last one, or never: fewer than 16 steps left) and
+    draws whose covariance never converges (the whole sweep is the exact adjoint's; the steady-state adjoint and the Riccati
+    adjoint see zero steps and must leave exact zeros, no NaN from 0 * inf)."""
+    w = _never_converging(W.structural(B=20, n=320), [1, 7, 19])
+    y = w["y"].copy()
+    y[[5, 130, 131, 250]] = np.nan
+    _compare(eng, monkeypatch, w, y, "standard", k=8)
+    y2 = w["y"].copy()
+    y2[[10, 311]] = np.nan          # nothing can converge behind step 311 (16 steps must remain): every draw takes the exact path
+    _compare(eng, monkeypatch, w, y2, "standard", k=2, need_steady=False)
+
+
+def test_value_and_grad_steady_state_adjoint_large_batch_and_default_cotangent(eng, monkeypatch):
+    """More draws than wavefront slots of the chip (queued workgroups), g_logp = NULL (ones), per-draw series."""
+    w = W.structural(B=6000, n=200)
+    args = (w["y"],) + tuple(w[x] for x in KEYS)
+    lp, info, g = eng.value_and_grad(*args, mvn_const="exact")
+    monkeypatch.setenv("KF_VG_STEADY", "0")
+    lpx, _, gx = eng.value_and_grad(*args, mvn_const="exact")
+    monkeypatch.delenv("KF_VG_STEADY")
+    assert_allclose(lp.cpu().numpy(), lpx.cpu().numpy(), rtol=1e-12)
+    for nm in GRADS:
+        a_, x_ = g[nm].cpu().numpy(), gx[nm].cpu().numpy()
+        scale = 1.0 + np.max(np.abs(x_.reshape(6000, -1)), axis=1)
+        assert (np.max(np.abs(a_ - x_).reshape(6000, -1), axis=1) / scale).max() < 1e-10, nm
+    wy = W.structural(B=12, n=260)
+    rng = np.random.default_rng(2)
+    ys = wy["y"][None] + 0.2 * rng.standard_normal((12,) + wy["y"].shape)
+    _compare(eng, monkeypatch, wy, ys[0], "standard")     # shared series
+    lp, _, g = eng.value_and_grad(ys, *[wy[x] for x in KEYS], mvn_const="exact")
+    for b in (0, 5, 11):
+        lpb, _, gb = eng.value_and_grad(ys[b], *[wy[x][b:b + 1] for x in KEYS], mvn_const="exact")
+        assert_allclose(lp[b].item(), lpb[0].item(), rtol=1e-13)
+        for nm in GRADS:
+            assert_allclose(g[nm][b].cpu().numpy(), gb[nm][0].cpu().numpy(), rtol=1e-9, atol=1e-11, err_msg=nm)
+
+
+def test_forcing_the_block_kernel_keeps_the_c4_gradient_right(eng):
+    """with the forward kernel forced to 'b4' the steady-state value-and-gradient of a C4-like shape used to fall
+    through to the LDS adjoint, which ignores the per-draw step counts.  Per-draw step counts now always reach the adjoint that
+    honours them."""
+    w = W.varmax(B=16, n=300)
+    args = (w["y"],) + tuple(w[x] for x in KEYS)
+    kw = dict(filter_type="standard", mvn_const="exact", h_diagonal=True)
+    try:
+        eng.set_forward_kernel("b4")
+        lp, _, g = eng.value_and_grad(*args, **kw)
+        lpx, _, gx = eng.value_and_grad(*args, exact_recursion=True, **kw)
+    finally:
+        eng.set_forward_kernel("auto")
+    assert_allclose(lp.cpu().numpy(), lpx.cpu().numpy(), rtol=1e-12)
+    for nm in GRADS:
+        a_, x_ = g[nm].cpu().numpy(), gx[nm].cpu().numpy()
+        assert np.max(np.abs(a_ - x_)) / (1.0 + np.max(np.abs(x_))) < 1e-10, nm

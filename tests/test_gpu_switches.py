@@ -1,0 +1,154 @@
+"""Every environment switch INTEGRATION.md documents selects between COMPLETE, parity-held paths:
+each switch value is set in turn and the entry point it acts on must stay within the parity tolerances of the default path
+(which tests/test_gpu_parity.py holds to the oracle): |dlogp| <= 1e-8 max(1, |logp| / 1e4), tapes and gradients 1e-9.
+The measurement-script knobs (KF_B4_SPLIT_CHUNK, KF_B4_FILL_WGS, KF_B4Q_CHUNK, KF_B4Q_PREP_STREAM, KF_SS_ENTRY_TOL) exist only in
+-DKF_EXPERIMENTS builds and the removed KF_B4_SPLIT_DEBUG not at all: a product build must ignore them bit for bit.
+Reference behaviour the paths implement: pymc_statespace/filters/kalman_filter.py:126-252, kalman_smoother.py:56-104."""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+import workloads as W
+
+pytestmark = pytest.mark.gpu
+KEYS = ("a0", "P0", "T", "Z", "R", "H", "Q")
+TAPES = ["filtered_states", "predicted_states", "filtered_covs", "predicted_covs", "ll_obs"]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    from pymc_statespace_amd import KalmanEngine
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return KalmanEngine()
+
+
+def _args(w):
+    return (w["y"],) + tuple(w[k] for k in KEYS)
+
+
+def _fwd(eng, w, **kw):
+    res = eng.forward(*_args(w), mvn_const="exact", **kw)
+    out = {"logp": res.logp.cpu().numpy(), "info": res.info.cpu().numpy()}
+    for k in TAPES:
+        v = getattr(res, k)
+        if v is not None:
+            out[k] = v.cpu().numpy()
+    return out
+
+
+def _close(a, b, tag):
+    tol = 1e-8 * np.maximum(1.0, np.abs(b["logp"]) / 1e4)
+    assert np.all(np.abs(a["logp"] - b["logp"]) <= tol), f"{tag}: logp {np.abs(a['logp'] - b['logp']).max():.2e}"
+    assert np.array_equal(a["info"], b["info"]), tag
+    for k in TAPES:
+        if k in b:
+            assert_allclose(a[k], b[k], rtol=1e-9, atol=1e-9, err_msg=f"{tag} {k}")
+
+
+FORWARD_CASES = [
+    # (switch, values, workload, forward kwargs)
+    ("KF_STEADY_STATE", ("0", "1"), lambda: W.structural(B=1500, n=400), {}),
+    ("KF_STEADY_STATE", ("0", "1"), lambda: W.arma11(B=300, n=300), {}),
+    ("KF_STEADY_STATE", ("0", "1"), lambda: W.varmax(B=64, n=200), {"h_diagonal": True}),
+    ("KF_B4_SPLIT", ("0", "1"), lambda: W.structural(B=1500, n=400), {"exact_recursion": False}),
+    ("KF_FORWARD_B4P", ("0", "1"), lambda: W.structural(B=200, n=150), {}),
+    ("KF_FORWARD_B4P", ("1",), lambda: W.structural(B=1500, n=150), {}),
+    ("KF_B4Q_SPLIT", ("0",), lambda: W.varmax(B=64, n=200), {"h_diagonal": True}),
+    ("KF_B4Q_GROUP", ("0",), lambda: W.varmax(B=64, n=200), {"h_diagonal": True}),
+    ("KF_FORWARD_B4Q", ("0", "1"), lambda: W.varmax(B=64, n=120), {"h_diagonal": True}),
+    ("KF_BIG_FUSE", ("0",), lambda: W.random_dense(B=6, n=12, p=1, m=100, r=3, seed=5), {"store_filtered": False}),
+    ("KF_FORWARD_WGL", ("0",), lambda: W.random_dense(B=6, n=12, p=1, m=70, r=3, seed=6),
+     {"store_filtered": False, "store_predicted": False}),
+]
+
+
+@pytest.mark.parametrize("case", range(len(FORWARD_CASES)))
+def test_forward_switches_stay_within_parity(eng, monkeypatch, case):
+    name, values, make, kw = FORWARD_CASES[case]
+    w = make()
+    monkeypatch.delenv(name, raising=False)
+    base = _fwd(eng, w, **kw)
+    assert not base["info"].any()
+    for v in values:
+        monkeypatch.setenv(name, v)
+        _close(_fwd(eng, w, **kw), base, f"{name}={v}")
+    monkeypatch.delenv(name, raising=False)
+
+
+SMOOTHER_CASES = [
+    ("KF_SMOOTHER_LANE", "0", lambda: W.arma11(B=200, n=150)),
+    ("KF_SMOOTHER_B4", "0", lambda: W.structural(B=200, n=150)),
+    ("KF_SMOOTHER_STEADY", "0", lambda: W.structural(B=200, n=300)),
+    ("KF_SMOOTHER_STEADY", "0", lambda: W.arma11(B=200, n=300)),
+    ("KF_SMOOTHER_BIG_GEMM", "0", lambda: W.random_dense(B=3, n=6, p=1, m=130, r=3, seed=8)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(SMOOTHER_CASES)))
+def test_smoother_switches_stay_within_parity(eng, monkeypatch, case):
+    name, v, make = SMOOTHER_CASES[case]
+    w = make()
+    res = eng.forward(*_args(w), mvn_const="exact", store_predicted=False, store_ll_obs=False)
+    monkeypatch.delenv(name, raising=False)
+    sa, sP = eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
+    monkeypatch.setenv(name, v)
+    sa2, sP2 = eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
+    monkeypatch.delenv(name)
+    sc = 1.0 + float(sP.abs().max())
+    assert float((sa - sa2).abs().max()) <= 1e-9 * (1.0 + float(sa.abs().max())), name
+    assert float((sP - sP2).abs().max()) <= 1e-9 * sc, name
+
+
+GRAD_CASES = [
+    ("KF_VG_STEADY", "0", lambda: W.varmax(B=32, n=200), {"h_diagonal": True}),
+    ("KF_VG_STEADY", "0", lambda: W.structural(B=32, n=300), {}),
+    ("KF_VG_TILE_TAPE", "0", lambda: W.structural(B=32, n=200), {}),
+    ("KF_BACKWARD_B4", "0", lambda: W.structural(B=32, n=200), {}),
+    ("KF_BACKWARD_B4", "1", lambda: W.arma11(B=2000, n=100), {}),
+    ("KF_STEADY_STATE", "0", lambda: W.structural(B=32, n=300), {}),
+    ("KF_SMOOTHER_BIG_GEMM", "0", lambda: W.random_dense(B=3, n=6, p=1, m=130, r=3, seed=9), {}),
+]
+
+
+@pytest.mark.parametrize("case", range(len(GRAD_CASES)))
+def test_gradient_switches_stay_within_parity(eng, monkeypatch, case):
+    name, v, make, kw = GRAD_CASES[case]
+    w = make()
+    monkeypatch.delenv(name, raising=False)
+    lp, info, g = eng.value_and_grad(*_args(w), mvn_const="exact", **kw)
+    monkeypatch.setenv(name, v)
+    lp2, info2, g2 = eng.value_and_grad(*_args(w), mvn_const="exact", **kw)
+    monkeypatch.delenv(name)
+    assert not info.cpu().numpy().any() and not info2.cpu().numpy().any()
+    assert_allclose(lp2.cpu().numpy(), lp.cpu().numpy(), rtol=1e-11)
+    for k in g:
+        a_, b_ = g[k].cpu().numpy(), g2[k].cpu().numpy()
+        B = a_.shape[0]
+        scale = 1.0 + np.max(np.abs(a_.reshape(B, -1)), axis=1)
+        assert (np.max(np.abs(a_ - b_).reshape(B, -1), axis=1) / scale).max() < 1e-9, f"{name}={v}: {k}"
+
+
+def test_experiment_knobs_are_ignored_by_a_product_build(eng, monkeypatch):
+    """KF_B4_SPLIT_DEBUG used to skip the constant-tape fill / the mean scan of the split pipeline and still return KF_OK; it is
+    gone, and the tuning knobs of the measurement scripts are compiled in only with -DKF_EXPERIMENTS."""
+    w = W.structural(B=1500, n=400)
+    wv = W.varmax(B=64, n=200)
+    for k in ("KF_B4_SPLIT_DEBUG", "KF_SS_ENTRY_TOL", "KF_B4_SPLIT_CHUNK", "KF_B4_FILL_WGS", "KF_B4Q_CHUNK", "KF_B4Q_PREP_STREAM"):
+        monkeypatch.delenv(k, raising=False)
+    base = _fwd(eng, w, exact_recursion=False)
+    basev = _fwd(eng, wv, h_diagonal=True)
+    monkeypatch.setenv("KF_B4_SPLIT_DEBUG", "3")
+    monkeypatch.setenv("KF_SS_ENTRY_TOL", "1e-2")
+    monkeypatch.setenv("KF_B4_SPLIT_CHUNK", "64")
+    monkeypatch.setenv("KF_B4_FILL_WGS", "3")
+    monkeypatch.setenv("KF_B4Q_CHUNK", "256")
+    monkeypatch.setenv("KF_B4Q_PREP_STREAM", "1")
+    got = _fwd(eng, w, exact_recursion=False)
+    gotv = _fwd(eng, wv, h_diagonal=True)
+    for k in base:
+        assert np.array_equal(got[k], base[k]), k      # complete tapes (no skipped fill / scan), the documented tolerance
+    for k in basev:
+        assert np.array_equal(gotv[k], basev[k]), k

@@ -43,6 +43,14 @@ def test_every_op_class_builds_a_node_with_the_reference_arity():
         assert all(row == [True] + [False] * 9 for row in pat[1:])
     node = ops["KalmanFilterBatchedOp"]().make_node(sym[0], *[pt.tensor3(f"b{k}") for k in range(9)])
     assert [o.type.ndim for o in node.outputs] == [4, 4, 4, 4, 1, 2]
+    pat = node.op.connection_pattern(node)
+    assert len(pat) == 10 and all(len(row) == 6 for row in pat) and not any(pat[0])
+    node = ops["KalmanLogpBatchedOp"]().make_node(sym[0], *[pt.tensor3(f"b{k}") for k in range(9)])
+    assert [o.type.ndim for o in node.outputs] == [1] + [3] * 9
+    pat = node.op.connection_pattern(node)
+    assert not any(pat[0]) and all(row == [True] + [False] * 9 for row in pat[1:])
+    with pytest.raises(TypeError):
+        ops["KalmanLogpBatchedOp"]().make_node(*ins)       # per-draw (2-D) inputs are not a batch
     node = ops["KalmanSmootherOp"]().make_node(sym[3], sym[5], sym[7], pt.tensor3("fs"), pt.tensor3("fP"))
     assert len(node.inputs) == 5 and [o.type.ndim for o in node.outputs] == [3, 3]
     node = ops["KalmanFilterGradOp"]().make_node(*ins, pt.tensor3("pa"), pt.tensor3("pP"), pt.scalar("g"), pt.vector("gl"))
@@ -159,3 +167,92 @@ def test_graphs_evaluate_end_to_end_with_oracle_backed_bodies(monkeypatch):
     Tt = pt.tensor3("Tt")
     lp_tv = StandardFilter().build_graph(sym[0], sym[1], sym[2], Tt, *sym[4:], outputs="logp")
     assert pytensor.grad(lp_tv, Tt).type.ndim == 3
+
+
+def test_the_batch_axis_reaches_one_value_and_gradient_node(monkeypatch):
+    """Row (b2) of the scope table: ``vectorize_graph`` over the sampler's node (KalmanLogpOp) and the gradient of a batched
+    filter's log-likelihoods both end in ONE KalmanLogpBatchedOp node = one kf_filter_value_and_grad call for all draws
+    (reference: the per-draw loop of core/statespace.py:230-236 around the Potential of :174).  Numeric bodies replaced by the
+    torch oracle; the GPU half is tests/test_pytensor_op.py."""
+    import numpy as np
+    import pytensor.tensor as pt
+    from numpy.testing import assert_allclose
+    from pytensor.graph.replace import vectorize_graph
+
+    from conftest import load_golden
+    from oracle import kalman_torch as kt
+    from pymc_statespace_amd import op
+    from pymc_statespace_amd.filters import StandardFilter
+
+    calls = []
+
+    def fake_batched(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standard", mvn_const="reference", h_diagonal=False,
+                     engine=None):
+        calls.append(np.asarray(P0).shape[0])
+        lp, _, g = kt.logp_and_grads(np.asarray(data)[..., 0], a0[..., 0], P0, T, Z, R, H, Q, c=c[..., 0], d=d[..., 0],
+                                     filter_type=filter_type, mvn_const=mvn_const)
+        out = {k: g[k] for k in op.GRAD_INPUT_NAMES}
+        for k in ("a0", "c", "d"):
+            out[k] = out[k][..., None]
+        return [lp] + [out[k] for k in op.GRAD_INPUT_NAMES]
+
+    def fake_filter_batched(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standard", mvn_const="reference", h_diagonal=False,
+                            engine=None, want=(True,) * 6):
+        # (the stand-in evaluates the forward node for the SHAPE of its log-likelihoods; real PyTensor infers it)
+        from oracle import kalman_numpy as kn
+        r = kn.kalman_filter(np.asarray(data)[..., 0], a0[..., 0], P0, T, Z, R, H, Q, c=c[..., 0], d=d[..., 0],
+                             filter_type=filter_type, mvn_const=mvn_const)
+        outs = [r["filtered_states"][..., None], r["predicted_states"][..., None], r["filtered_covs"], r["predicted_covs"],
+                r["logp"], r["ll_obs"]]
+        return [o if w or k == 4 else None for k, (o, w) in enumerate(zip(outs, want))]
+
+    monkeypatch.setattr(op, "perform_logp_and_grad_batched", fake_batched)
+    monkeypatch.setattr(op, "perform_filter_batched", fake_filter_batched)
+    g = load_golden("nile_llt.npz")
+    B = 5
+    scale = np.linspace(0.5, 2.0, B)
+    vals = [g["y"][..., None], g["a0"][0][:, None], g["P0"][0], g["T"][0], g["Z"][0], g["R"][0], g["H"][0], g["Q"][0]]
+    Hs, Qs = scale[:, None, None] * vals[6], scale[::-1, None, None] * vals[7]
+    sym = _symbols()
+    # (a) vectorize_graph over the per-draw logp node: H and Q gain a draw axis, everything else is broadcast
+    logp = StandardFilter().build_graph(*sym, outputs="logp")
+    bH, bQ = pt.tensor3("H_draws"), pt.tensor3("Q_draws")
+    blogp = vectorize_graph(logp, replace={sym[6]: bH, sym[7]: bQ})
+    assert blogp.type.ndim == 1
+    w = pt.vector("w")
+    cost = (w * blogp).sum()
+    ins = sym[:6] + [bH, bQ, w]
+    f = pytensor.function(ins, [blogp] + pytensor.grad(cost, [bH, bQ, sym[3]]))
+    names = _op_names(f)
+    assert names.count("KalmanLogpBatchedOp") == 1 and "KalmanLogpOp" not in names
+    wv = np.arange(1.0, B + 1.0)
+    lp, gH, gQ, gT = f(*vals[:6], Hs, Qs, wv)
+    assert calls == [B], "value and gradients of all draws from ONE batched call"
+    ref_lp, _, ref_g = kt.logp_and_grads(g["y"], np.repeat(g["a0"], B, 0), np.repeat(g["P0"], B, 0), np.repeat(g["T"], B, 0),
+                                         np.repeat(g["Z"], B, 0), np.repeat(g["R"], B, 0), Hs, Qs, g_logp=wv)
+    assert lp.shape == (B,) and gH.shape == (B, 1, 1) and gQ.shape == (B, 2, 2)
+    assert_allclose(lp, ref_lp, rtol=1e-12)
+    assert_allclose(gH, ref_g["H"], rtol=1e-10)
+    assert_allclose(gQ, ref_g["Q"], rtol=1e-10)
+    assert_allclose(gT, ref_g["T"].sum(0), rtol=1e-9, atol=1e-9)   # T was broadcast to all draws: its gradient sums over them
+    # (b) the batched filter's log-likelihood differentiates through the same node
+    calls.clear()
+    sym3 = [sym[0]] + [pt.tensor3(nm) for nm in ("a0", "P0", "T", "Z", "R", "H", "Q")]
+    outs = StandardFilter().build_graph(*sym3, batched=True)
+    assert [o.type.ndim for o in outs] == [4, 4, 4, 4, 1, 2]
+    gT = pytensor.grad(outs[4].sum(), sym3[3])
+    f = pytensor.function(sym3, gT, on_unused_input="ignore")
+    assert "KalmanLogpBatchedOp" in _op_names(f)
+    rep = lambda x: np.repeat(x[None], B, 0)  # noqa: E731
+    got = f(vals[0], rep(vals[1]), rep(vals[2]), rep(vals[3]), rep(vals[4]), rep(vals[5]), Hs, Qs)
+    _, _, ref_g1 = kt.logp_and_grads(g["y"], np.repeat(g["a0"], B, 0), np.repeat(g["P0"], B, 0), np.repeat(g["T"], B, 0),
+                                      np.repeat(g["Z"], B, 0), np.repeat(g["R"], B, 0), Hs, Qs)
+    assert got.shape == (B, 2, 2) and calls == [B]
+    assert_allclose(got, ref_g1["T"], rtol=1e-9, atol=1e-9)
+    with pytest.raises(Exception, match="(?i)not implemented|undefined|null"):   # tapes stay undifferentiated
+        pytensor.grad(outs[0].sum(), sym3[3])
+    # (c) built directly: logp (B,) from the batched node
+    blp = StandardFilter().build_graph(*sym3, outputs="logp", batched=True)
+    f = pytensor.function(sym3, blp)
+    assert _op_names(f).count("KalmanLogpBatchedOp") == 1
+    assert_allclose(f(vals[0], rep(vals[1]), rep(vals[2]), rep(vals[3]), rep(vals[4]), rep(vals[5]), Hs, Qs), ref_lp, rtol=1e-12)

@@ -171,3 +171,99 @@ def test_time_varying_inputs_keep_their_shape_in_the_gradient(nile):
     lp, gT = f(vals[0], vals[1], vals[2], Tv, *vals[4:])
     assert gT.shape == (n, m, m)
     assert_allclose(lp, g["llf_obs"].sum(), rtol=2e-9)
+
+
+def test_vectorized_logp_node_value_and_gradients_from_one_c_abi_call(nile, monkeypatch):
+    """Scope row (b2): the batch-of-draws axis is reachable WITH gradients through build_graph.  ``vectorize_graph`` of
+    ``build_graph(..., outputs="logp")`` over B = 64 Nile-LLT draws: one KalmanLogpBatchedOp node, exactly ONE
+    kf_filter_value_and_grad call for the values and all gradients, value of draw 0 against the statsmodels golden vector,
+    every draw's value and gradients against the autograd oracle.  Reference loop replaced: core/statespace.py:230-236 around
+    the Potential of :174; Op pattern utils/pytensor_scipy.py:11-60."""
+    import pytensor.tensor as pt
+    from pytensor.graph.replace import vectorize_graph
+
+    from oracle import kalman_torch as kt
+    from pymc_statespace_amd import _lib
+    from pymc_statespace_amd.filters import StandardFilter
+
+    g, vals, m, p = nile
+    B = 64
+    rng = np.random.default_rng(7)
+    sH = np.concatenate([[1.0], np.exp(rng.normal(0, 0.5, B - 1))])
+    sQ = np.concatenate([[1.0], np.exp(rng.normal(0, 0.5, B - 1))])
+    Hs, Qs = sH[:, None, None] * vals[6], sQ[:, None, None] * vals[7]
+    Ts = np.repeat(vals[3][None], B, 0)
+    Ts[1:, 0, 0] = rng.uniform(0.8, 1.0, B - 1)
+
+    lib = _lib.load()
+    n_calls = {"vg": 0, "fwd": 0}
+    real_vg, real_fwd = lib.kf_filter_value_and_grad, lib.kf_filter_forward
+
+    def spy_vg(*a):
+        n_calls["vg"] += 1
+        return real_vg(*a)
+
+    def spy_fwd(*a):
+        n_calls["fwd"] += 1
+        return real_fwd(*a)
+
+    monkeypatch.setattr(lib, "kf_filter_value_and_grad", spy_vg)
+    monkeypatch.setattr(lib, "kf_filter_forward", spy_fwd)
+
+    sym = _symbols()
+    logp = StandardFilter().build_graph(*sym, outputs="logp")
+    bT, bH, bQ = pt.tensor3("T_draws"), pt.tensor3("H_draws"), pt.tensor3("Q_draws")
+    blogp = vectorize_graph(logp, replace={sym[3]: bT, sym[6]: bH, sym[7]: bQ})
+    w = pt.vector("w")
+    cost = (w * blogp).sum()
+    ins = [sym[0], sym[1], sym[2], bT, sym[4], sym[5], bH, bQ, w]
+    f = pytensor.function(ins, [blogp] + pytensor.grad(cost, [bT, bH, bQ]))
+    kal = [type(nd.op).__name__ for nd in f.maker.fgraph.toposort() if "Kalman" in type(nd.op).__name__]
+    assert kal == ["KalmanLogpBatchedOp"], kal
+    wv = rng.uniform(0.5, 1.5, B)
+    lp, gT, gH, gQ = f(vals[0], vals[1], vals[2], Ts, vals[4], vals[5], Hs, Qs, wv)
+    assert n_calls == {"vg": 1, "fwd": 0}, n_calls
+    assert lp.shape == (B,) and gT.shape == (B, m, m) and gH.shape == (B, p, p) and gQ.shape == (B, m, m)
+    assert_allclose(lp[0], g["llf_obs"].sum(), rtol=2e-9)          # draw 0 is the golden draw
+    rep = lambda x: np.repeat(x, B, 0)  # noqa: E731
+    rlp, _, rg = kt.logp_and_grads(g["y"], rep(g["a0"]), rep(g["P0"]), Ts, rep(g["Z"]), rep(g["R"]), Hs, Qs, g_logp=wv)
+    assert_allclose(lp, rlp, rtol=1e-11)
+    for name, got in (("T", gT), ("H", gH), ("Q", gQ)):
+        scale = np.abs(rg[name]).max(axis=(1, 2), keepdims=True)
+        assert np.max(np.abs(got - rg[name]) / scale) < 1e-8, name
+
+    # the batched filter's log-likelihoods differentiate through the same node; built directly with batched=True
+    sym3 = [sym[0]] + [pt.tensor3(nm) for nm in ("a0", "P0", "T", "Z", "R", "H", "Q")]
+    outs = StandardFilter().build_graph(*sym3, outputs=("log_likelihood",), batched=True)
+    gQ2 = pytensor.grad((outs[4]).sum(), sym3[7])
+    f2 = pytensor.function(sym3, [outs[4], gQ2], on_unused_input="ignore")
+    rp = lambda x: np.repeat(x[None], B, 0)  # noqa: E731
+    n_calls.update(vg=0, fwd=0)
+    lp2, gQ2v = f2(vals[0], rp(vals[1]), rp(vals[2]), Ts, rp(vals[4]), rp(vals[5]), Hs, Qs)
+    assert n_calls["vg"] == 1
+    _, _, rg1 = kt.logp_and_grads(g["y"], rep(g["a0"]), rep(g["P0"]), Ts, rep(g["Z"]), rep(g["R"]), Hs, Qs)
+    assert_allclose(lp2, rlp, rtol=1e-11)
+    scale = np.abs(rg1["Q"]).max(axis=(1, 2), keepdims=True)
+    assert np.max(np.abs(gQ2v - rg1["Q"]) / scale) < 1e-8
+
+
+def test_batched_logp_op_with_one_series_per_draw(nile):
+    """data with a leading draw axis (B,n,p,1): KF_FLAG_Y_PER_DRAW through the batched value-and-gradient node."""
+    import pytensor.tensor as pt
+
+    from oracle import kalman_torch as kt
+    from pymc_statespace_amd.filters import StandardFilter
+
+    g, vals, m, p = nile
+    B = 3
+    data4 = pt.tensor4("data_draws")
+    sym3 = [data4] + [pt.tensor3(nm) for nm in ("a0", "P0", "T", "Z", "R", "H", "Q")]
+    blp = StandardFilter().build_graph(*sym3, outputs="logp", batched=True)
+    f = pytensor.function(sym3, [blp, pytensor.grad(blp.sum(), sym3[6])])
+    ys = np.stack([vals[0], vals[0][::-1].copy(), 0.5 * vals[0]])
+    rp = lambda x: np.repeat(x[None], B, 0)  # noqa: E731
+    lp, gH = f(ys, *[rp(v) for v in vals[1:]])
+    for b in range(B):
+        rlp, _, rg = kt.logp_and_grads(ys[b, :, :, 0], g["a0"], g["P0"], g["T"], g["Z"], g["R"], g["H"], g["Q"])
+        assert_allclose(lp[b], rlp[0], rtol=1e-11)
+        assert_allclose(gH[b], rg["H"][0], rtol=1e-8)
