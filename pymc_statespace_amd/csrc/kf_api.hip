@@ -587,7 +587,15 @@ static bool kf_vg_tile_steady_path(const kf_handle* h, const kf_dims* d) {
   if (e && e[0] == '0') return false;
   const char* sse = kf_env_switch("KF_STEADY_STATE");
   if (sse && atoi(sse) == 0) return false;
-  return kf_backward_steady_ok(d->m, d->p, d->r);
+  if (!kf_backward_steady_ok(d->m, d->p, d->r)) return false;
+  if ((d->flags & KF_FLAG_STEADY_STATE) || (e && e[0] == '1') || (sse && atoi(sse) != 0)) return true;
+  // AUTO: where it wins.  A launch lasts as long as its most loaded SIMD: below one round of the chip's wavefront slots (4 per
+  // SIMD) that is the slowest draw's chain -- a draw whose covariance never converges gains nothing and the steady-state adjoint's
+  // kernel is one more link -- measured (scripts/r04/vg_time.py sweep, structural m = 10, ms, steady ; exact): 512 draws x 1000
+  // 1.87 ; 1.25, 2048 x 1000 2.30 ; 1.68, 4096 x 1000 2.91 ; 2.88, 4096 x 2000 5.41 ; 5.78, 8192 x 1000 5.01 ; 5.66,
+  // 8192 x 2000 (C3) 8.71 ; 11.33
+  const long slots = 16L * (h->n_cu > 0 ? h->n_cu : 256);
+  return (d->B >= slots && d->T >= 1536) || d->B >= 2 * slots;
 }
 
 extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, int which, size_t* bytes) {
@@ -599,7 +607,7 @@ extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, i
     *bytes = kf_vg_tape_bytes(dims) + inner;
     if (kf_vg_tile_steady_path(h, dims)) {
       const size_t B = (size_t)dims->B, m = (size_t)dims->m, n1 = (size_t)dims->T + 1;
-      *bytes += kf_vg_round(8 * B * n1 * m) + kf_vg_round(4 * B) + kf_vg_round(8 * B * m) + 3 * kf_vg_round(8 * B * m * m);
+      *bytes += kf_vg_round(8 * B * n1 * m) + 2 * kf_vg_round(4 * B) + kf_vg_round(8 * B * m) + 3 * kf_vg_round(8 * B * m * m);
     }
     if (kf_vg_steady_path(h, dims)) {
       const size_t B = (size_t)dims->B, m = (size_t)dims->m;
@@ -710,6 +718,59 @@ __global__ void kf_fill_kernel(double* x, long n, double v) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = v;
 }
+
+// Launch order of draws whose sweeps have very different lengths (the steady-state adjoint and the exact adjoint behind the block
+// kernel: ts[b] steps of one, n - ts[b] of the other).  One wavefront per draw, four resident per SIMD: a launch lasts as long as its
+// most loaded SIMD, and with draws in their natural order that is a SIMD that happens to hold two slow draws (measured at the
+// headline shape: the exact adjoint over 49 % of the steps took 82 % of the full sweep's time).  Measured placement on MI355X
+// (scripts/probes/wg_placement.hip: 4096 one-wave workgroups, 10 KB of LDS each): workgroups i, i + S, i + 2 S, i + 3 S share SIMD
+// number i, S = 4 x CUs.  So: rank the draws by ts, longest first (counting sort on 2048 buckets), and deal them out in snake order
+// -- round 0 left to right, round 1 right to left, ... -- so that every SIMD gets one draw of each quarter and about the same
+// total; draws beyond 4 S keep descending order (the dispatcher hands them to whichever SIMD frees a slot first: longest first).
+// The order only decides WHERE a draw runs: results do not depend on it.
+constexpr int KF_ORD_BINS = 2048;
+__global__ __launch_bounds__(1024) void kf_vg_order_kernel(const int32_t* __restrict__ ts, int n, int B, int S, int32_t* __restrict__ list) {
+  __shared__ int hist[KF_ORD_BINS];   // bucket j = KF_ORD_BINS - 1 - key: ascending j = descending ts
+  __shared__ int wsum[64];
+  const int tid = threadIdx.x;
+  for (int j = tid; j < KF_ORD_BINS; j += 1024) hist[j] = 0;
+  __syncthreads();
+  auto bucket = [&](int v) {
+    v = v < 0 ? 0 : (v > n ? n : v);
+    const int key = (int)(((long)v * (KF_ORD_BINS - 1)) / (n > 0 ? n : 1));
+    return KF_ORD_BINS - 1 - key;
+  };
+  for (int b = tid; b < B; b += 1024) atomicAdd(&hist[bucket(ts[b])], 1);
+  __syncthreads();
+  if (tid < 64) {  // exclusive prefix over the buckets: lane l owns buckets [32 l, 32 l + 32)
+    int loc = 0;
+    for (int k = 0; k < 32; ++k) loc += hist[32 * tid + k];
+    int incl = loc;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int up = __shfl_up(incl, off);
+      if (tid >= off) incl += up;
+    }
+    int run = incl - loc;
+    for (int k = 0; k < 32; ++k) {
+      const int c = hist[32 * tid + k];
+      hist[32 * tid + k] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  (void)wsum;
+  const int R = 4 * S;
+  for (int b = tid; b < B; b += 1024) {
+    const int r = atomicAdd(&hist[bucket(ts[b])], 1);   // rank, longest first (order inside a bucket: as the atomics fall)
+    int pos = r;
+    if (r < R) {
+      const int round = r / S, col = r - round * S;
+      const int len = (B - round * S) < S ? (B - round * S) : S;
+      pos = round * S + ((round & 1) ? (len - 1 - col) : col);
+    }
+    list[pos] = b;
+  }
+}
 }  // namespace
 
 extern "C" int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims, const double* y, const double* a0,
@@ -755,11 +816,12 @@ extern "C" int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims, const
     f.logp = logp; f.ll_obs = nullptr; f.filt_a = nullptr; f.pred_a = nullptr; f.filt_P = nullptr; f.pred_P = nullptr;
     f.info = info; f.tile_tape = tape;
     const bool tsteady = kf_vg_tile_steady_path(h, dims);
-    int32_t* ts = nullptr;
+    int32_t *ts = nullptr, *order = nullptr;
     double *s_pa = nullptr, *s_ab = nullptr, *s_Pb = nullptr, *s_P = nullptr, *s_Pc = nullptr;
-    if (tsteady) {  // [.. | pred_a B (T+1) m | ts B | lam_ts B m | P_b B m^2 | P B m^2 | P as the forward left it B m^2 | inner]
+    if (tsteady) {  // [.. | pred_a B (T+1) m | ts B | order B | lam_ts B m | P_b B m^2 | P B m^2 | P as the forward left it B m^2 | inner]
       s_pa = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * n1 * m);
       ts = reinterpret_cast<int32_t*>(w); w += kf_vg_round(4 * B);
+      order = reinterpret_cast<int32_t*>(w); w += kf_vg_round(4 * B);
       s_ab = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * m);
       s_Pb = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * m * m);
       s_P = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * m * m);
@@ -782,6 +844,12 @@ extern "C" int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims, const
       a.pred_a = s_pa; a.pred_P = nullptr; a.g_logp = g_logp; a.g_ll_obs = nullptr;
       a.g_a0 = g_a0; a.g_P0 = g_P0; a.g_T = g_T; a.g_Z = g_Z; a.g_R = g_R; a.g_H = g_H; a.g_Q = g_Q; a.g_c = g_c; a.g_d = g_d;
       a.tape_T = dims->T; a.y_T = dims->T; a.tile_tape = nullptr; a.init_ab = nullptr; a.init_Pb = nullptr; a.accumulate = 0;
+      if (dims->B <= 0x7fffffffL) {  // the launch order of the two sweeps (see kf_vg_order_kernel)
+        hipLaunchKernelGGL(kf_vg_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ts, (int)dims->T, (int)dims->B,
+                           4 * (h->n_cu > 0 ? h->n_cu : 256), order);
+        KF_HIP_CHECK(h, hipGetLastError());
+        a.list = order;
+      }
       rc = kf_launch_backward_steady(h, a, ts, s_ab, s_Pb, s_P, (hipStream_t)stream, s_Pc);  // writes every gradient (zeros where it has none)
       if (rc) return rc;
       rc = kf_launch_dare_backward(h, dims->B, dims->m, dims->p, dims->r, T, Z, R, H, Q, s_P, s_Pb, g_T, g_Z, g_R, g_H, g_Q,

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   const int lane = threadIdx.x;
   const int g = lane >> 4, bq = lane & 15, q = lane & 3;
   const int fb = q * 4 + ((lane >> 2) & 3);  // position of column bq in a transpose-tile row / the exchange vector
-  const long b = blockIdx.x;
+  const long b = A.list ? (long)A.list[blockIdx.x] : (long)blockIdx.x;
   // per-draw step counts (the steady-state adjoint took the steps behind ts = steps[b], kf_backward_steady.hip): the sweep runs
   // steps ts-1 .. 1 from G = d L / d S_ts, the de-augmentation's inverse of (a_b, P_b) = (init_ab, 0); tapes / y stay strided by
   // tape_T / y_T and indexed by the absolute step
@@ -457,6 +457,7 @@ int kf_launch_backward_b4(kf_handle* h, const KfBwdArgs& a, void* workspace, siz
   tail.init_Pb = scratch + a.B * a.m;   // [B][m][m]
   tail.accumulate = 1;
   tail.steps = nullptr;  // (the tail is step 0 of every draw, whatever part of the sweep the steady-state adjoint took)
+  tail.list = nullptr;
   if (a.tile_tape) {  // the tail's one tape row is the caller's (a0, P0) itself
     tail.tile_tape = nullptr;
     tail.pred_a = a.a0;

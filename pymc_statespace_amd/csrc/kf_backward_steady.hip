@@ -25,35 +25,54 @@ namespace {
 
 constexpr int SA_M = 16, SA_P = 8;
 
-// LDS (doubles)
-constexpr int SA_OFF_P = 0;                       // P            m x m  (stride 16)
-constexpr int SA_OFF_T = SA_OFF_P + 256;          // T            m x m  (stride 16)
-constexpr int SA_OFF_Z = SA_OFF_T + 256;          // Z            p x 16
-constexpr int SA_OFF_K = SA_OFF_Z + 128;          // K            16 x 8 (m x p)
-constexpr int SA_OFF_W = SA_OFF_K + 128;          // W = F^-1     8 x 8
-constexpr int SA_OFF_F = SA_OFF_W + 64;           // F            8 x 8
-constexpr int SA_OFF_V = SA_OFF_F + 64;           // x = lam 16 | a 16 | y~ 8 (the rest: spare)
-constexpr int SA_OFF_X = SA_OFF_V + 96;           // epilogue scratch: 3 x 256
-constexpr int SA_TOTAL = SA_OFF_X + 768;
+// LDS map (doubles), PS = the stride of the p axis (1: scalar observation -- the p == 1 block kernels' adjoint; 8: up to eight).
+// Persistent pieces, the loop's two vectors, and ONE scratch region shared by the setup (T, M, T K, W Z, the inverse's work space)
+// and the epilogue (K_b, M_b, W_b, F_b, M, F_b Z, F_b Z P).  Round 3's layout took 14 KB per wavefront: 11 wavefronts per CU, so a
+// 4096-draw launch ran as 1.45 rounds (headline: 1.20 ms); PS = 1 takes 5.6 KB, PS = 8 12.2 KB.
+template <int PS>
+struct SaLds {
+  static constexpr int OFF_P = 0;                          // P            m x m  (stride 16)
+  static constexpr int OFF_Z = 256;                        // Z            p x 16
+  static constexpr int OFF_K = OFF_Z + 16 * PS;            // K            16 x PS (m x p)
+  static constexpr int OFF_W = OFF_K + 16 * PS;            // W = F^-1     PS x PS
+  static constexpr int OFF_F = OFF_W + PS * PS;            // F            PS x PS
+  static constexpr int OFF_V = (OFF_F + PS * PS + 1) & ~1; // x = lam 16 | a 16 | y~ PS (padded to 48)
+  static constexpr int OFF_O = OFF_V + 48;                 // stage outputs: lam_t 16 | af 16 | mu 16 | v 8 | vb 8
+  static constexpr int OFF_S = OFF_O + 64;                 // scratch of the setup / the epilogue
+  // setup:    T 256 | M 16 PS | T K 16 PS | W Z PS 16 | Gauss-Jordan work space 2 x 64 (PS > 1)
+  static constexpr int S_T = OFF_S, S_M = S_T + 256, S_TK = S_M + 16 * PS, S_WZ = S_TK + 16 * PS, S_GJ = S_WZ + 16 * PS;
+  static constexpr int SETUP_END = S_GJ + (PS > 1 ? 128 : 0);
+  // epilogue: K_b 16 PS | M_b 16 PS | W_b PS PS | F_b PS PS | M 16 PS | F_b Z PS 16 | F_b Z P PS 16
+  static constexpr int E_KB = OFF_S, E_MB = E_KB + 16 * PS, E_WB = E_MB + 16 * PS, E_FB = E_WB + PS * PS, E_M = E_FB + PS * PS,
+                       E_FZ = E_M + 16 * PS, E_FZP = E_FZ + 16 * PS;
+  static constexpr int EPI_END = E_FZP + 16 * PS;
+  static constexpr int TOTAL = SETUP_END > EPI_END ? SETUP_END : EPI_END;
+  static constexpr int ZERO_END = OFF_S;                   // zeroed before the setup (rows / columns beyond m, p stay zero)
+};
 
-__global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_kernel(const KfBwdArgs A, const int32_t* __restrict__ ts_all,
+// MS: k_states rounded up (12 / 16) -- the x vector a lane multiplies is lam (MS) | a (MS) | y~ (PS): at m <= 12 its coefficients take
+// 26 register pairs instead of 34 and the kernel fits four wavefronts per SIMD without spilling (PS == 1)
+template <int PS, int MS>
+__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(PS == 1 ? 4 : 3))) void kf_bwd_steady_kernel(const KfBwdArgs A, const int32_t* __restrict__ ts_all,
                                                                  double* __restrict__ out_ab, double* __restrict__ out_Pb,
                                                                  double* __restrict__ out_P, const double* __restrict__ P_conv) {
-  __shared__ __attribute__((aligned(16))) double smem[SA_TOTAL];
+  using L = SaLds<PS>;
+  __shared__ __attribute__((aligned(16))) double smem[L::TOTAL];
   const int lane = threadIdx.x;
-  const long b = blockIdx.x;
+  const long b = A.list ? (long)A.list[blockIdx.x] : (long)blockIdx.x;
   const int n = A.T, m = A.m, p = A.p, mm = m * m, r_ = A.r;
   const int ts = ts_all[b] < n ? ts_all[b] : n;
-  double* sP = smem + SA_OFF_P;
-  double* sT = smem + SA_OFF_T;
-  double* sZ = smem + SA_OFF_Z;
-  double* sK = smem + SA_OFF_K;
-  double* sW = smem + SA_OFF_W;
-  double* sF = smem + SA_OFF_F;
-  double* lam = smem + SA_OFF_V;   // (the loop's x vector starts here: lam (16) | a (16) | y~ (8))
-  double* X0 = smem + SA_OFF_X;
-  double* X1 = X0 + 256;
-  double* X2 = X1 + 256;
+  double* sP = smem + L::OFF_P;
+  double* sZ = smem + L::OFF_Z;
+  double* sK = smem + L::OFF_K;
+  double* sW = smem + L::OFF_W;
+  double* sF = smem + L::OFF_F;
+  double* XV = smem + L::OFF_V;    // x: lam (MS) | a (MS) | y~ (PS)
+  double* OUT = smem + L::OFF_O;   // lam_t (16) | af (16) | mu (16) | v (8) | vb (8)
+  double* sT = smem + L::S_T;
+  double* sM = smem + L::S_M;
+  double* TK = smem + L::S_TK;
+  double* WZ = smem + L::S_WZ;
 
   const double* gpa = A.pred_a + b * (long)(A.tape_T + 1) * m;
   // the converged predicted covariance: slot ts of the predicted tape, or (P_conv: the p == 1 block kernel keeps no compact
@@ -66,7 +85,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_kernel(const KfBwdArgs 
   const double* ybase = A.y + (ypd ? b * (long)A.y_T * p : 0L);
   const double g_all = A.g_logp ? A.g_logp[b] : 0.0;
 
-  for (int e = lane; e < SA_OFF_X; e += KF_WAVE) smem[e] = 0.0;
+  for (int e = lane; e < L::TOTAL; e += KF_WAVE) smem[e] = 0.0;
   wave_lds_fence();
   const int tsc = P_conv ? 0 : (ts < n ? ts : n);  // (a draw that never converged: P of slot n, nothing to sweep)
   for (int e = lane; e < mm; e += KF_WAVE) {
@@ -78,27 +97,32 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_kernel(const KfBwdArgs 
   }
   for (int e = lane; e < p * m; e += KF_WAVE) sZ[(e / m) * 16 + e % m] = gZ[e];
   wave_lds_fence();
-  // M = P Z' (m x p) into sK, F = Z M + diag(H)
+  // M = P Z' (m x p), F = Z M + diag(H)
   for (int e = lane; e < m * p; e += KF_WAVE) {
     const int i = e / p, q = e - i * p;
     double s = 0.0;
     for (int j = 0; j < m; ++j) s = fma(sP[i * 16 + j], sZ[q * 16 + j], s);
-    X0[i * 8 + q] = s;  // M
+    sM[i * PS + q] = s;
   }
   wave_lds_fence();
   for (int e = lane; e < p * p; e += KF_WAVE) {
     const int q = e / p, r2 = e - q * p;
     double s = (q == r2) ? A.H[b * (long)p * p + q * p + q] : 0.0;
-    for (int i = 0; i < m; ++i) s = fma(sZ[q * 16 + i], X0[i * 8 + r2], s);
-    sF[q * 8 + r2] = s;
+    for (int i = 0; i < m; ++i) s = fma(sZ[q * 16 + i], sM[i * PS + r2], s);
+    sF[q * PS + r2] = s;
   }
   wave_lds_fence();
-  // W = F^-1: Gauss-Jordan on (F | I) by the first p lanes (lane = column of the augmented right half), pivots in order (F is SPD)
-  {
-    // X1: working copy of F (8 x 8), X2: inverse being built
-    if (lane < 64) {
+  // W = F^-1
+  if constexpr (PS == 1) {
+    if (lane == 0) sW[0] = 1.0 / sF[0];
+    wave_lds_fence();
+  } else {
+    // Gauss-Jordan on (F | I), lane = entry of the 8 x 8 work matrices, pivots in order (F is SPD)
+    double* X1 = smem + L::S_GJ;  // working copy of F
+    double* X2 = X1 + 64;         // inverse being built
+    {
       const int q = lane >> 3, r2 = lane & 7;
-      X1[lane] = (q < p && r2 < p) ? 0.5 * (sF[q * 8 + r2] + sF[r2 * 8 + q]) : (q == r2 ? 1.0 : 0.0);
+      X1[lane] = (q < p && r2 < p) ? 0.5 * (sF[q * PS + r2] + sF[r2 * PS + q]) : (q == r2 ? 1.0 : 0.0);
       X2[lane] = (q == r2) ? 1.0 : 0.0;
     }
     wave_lds_fence();
@@ -119,15 +143,15 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_kernel(const KfBwdArgs 
       }
       wave_lds_fence();
     }
-    if (lane < 64) sW[lane] = ((lane >> 3) < p && (lane & 7) < p) ? 0.5 * (X2[lane] + X2[(lane & 7) * 8 + (lane >> 3)]) : 0.0;
+    sW[lane] = ((lane >> 3) < p && (lane & 7) < p) ? 0.5 * (X2[lane] + X2[(lane & 7) * 8 + (lane >> 3)]) : 0.0;
     wave_lds_fence();
   }
   // K = M W
   for (int e = lane; e < m * p; e += KF_WAVE) {
     const int i = e / p, q = e - i * p;
     double s = 0.0;
-    for (int r2 = 0; r2 < p; ++r2) s = fma(X0[i * 8 + r2], sW[r2 * 8 + q], s);
-    sK[i * 8 + q] = s;
+    for (int r2 = 0; r2 < p; ++r2) s = fma(sM[i * PS + r2], sW[r2 * PS + q], s);
+    sK[i * PS + q] = s;
   }
   wave_lds_fence();
 
@@ -137,69 +161,66 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_kernel(const KfBwdArgs 
   //   lanes 32..47  mu[j]    = sum_i T[i][j] lam_i
   //   lanes 48..55  v[q]     = y~_q - sum_l Z[q][l] a_l
   //   lanes 56..63  vb[q]    = sum_i (T K)[i][q] lam_i + gl sum_l (W Z)[q][l] a_l - gl sum_r W[q][r] y~_r
-  // each lane holds its 40 coefficients in registers and reads x (40 doubles) from LDS: 40 FMAs, one LDS round trip per step.
+  // each lane holds its 32 + PS coefficients in registers and reads x from LDS: one LDS round trip per step.
   // (gl is the draw's cotangent of logp: kf_filter_value_and_grad has no per-step cotangents.)
-  double* TK = X0 + 128;   // 16 x 8   (X0[0..127] holds M)
-  double* WZ = X1 + 64;    // 8 x 16
-  double* KZ = X2;         // 16 x 16
-  for (int e = lane; e < 128; e += KF_WAVE) {  // T K
-    const int i = e >> 3, q = e & 7;
+  for (int e = lane; e < 16 * PS; e += KF_WAVE) {  // T K
+    const int i = e / PS, q = e - i * PS;
     double s2 = 0.0;
-    for (int j = 0; j < 16; ++j) s2 = fma(sT[i * 16 + j], sK[j * 8 + q], s2);
+    for (int j = 0; j < 16; ++j) s2 = fma(sT[i * 16 + j], sK[j * PS + q], s2);
     TK[e] = s2;
   }
-  for (int e = lane; e < 128; e += KF_WAVE) {  // W Z
+  for (int e = lane; e < 16 * PS; e += KF_WAVE) {  // W Z
     const int q = e >> 4, l = e & 15;
     double s2 = 0.0;
-    for (int r2 = 0; r2 < 8; ++r2) s2 = fma(sW[q * 8 + r2], sZ[r2 * 16 + l], s2);
+    for (int r2 = 0; r2 < PS; ++r2) s2 = fma(sW[q * PS + r2], sZ[r2 * 16 + l], s2);
     WZ[e] = s2;
-  }
-  for (int e = lane; e < 256; e += KF_WAVE) {  // K Z
-    const int j = e >> 4, l = e & 15;
-    double s2 = 0.0;
-    for (int q = 0; q < 8; ++q) s2 = fma(sK[j * 8 + q], sZ[q * 16 + l], s2);
-    KZ[e] = s2;
   }
   wave_lds_fence();
   const double gl = g_all;
-  double cf[40];
+  constexpr int NX = 2 * MS + (PS == 1 ? 2 : PS);   // x entries a lane multiplies (padded to whole 16-byte reads)
+  double cf[NX];
   {
     const int j = lane & 15, q = lane & 7;
+    const bool qok = q < PS;
 #pragma unroll
-    for (int k = 0; k < 40; ++k) {
+    for (int k = 0; k < NX; ++k) {
       double v = 0.0;
+      const int l = k - MS;        // index into a (MS <= k < 2 MS)
+      const int yq = k - 2 * MS;   // index into y~ (k >= 2 MS)
       if (lane < 16) {
-        if (k < 16) {  // Abar[k][j] = T[k][j] - sum_q TK[k][q] Z[q][j]
+        if (k < MS) {  // Abar[k][j] = T[k][j] - sum_q TK[k][q] Z[q][j]
           v = sT[k * 16 + j];
-          for (int q2 = 0; q2 < 8; ++q2) v = fma(-TK[k * 8 + q2], sZ[q2 * 16 + j], v);
-        } else if (k < 32) {  // -gl (Z' W Z)[j][l]
-          const int l = k - 16;
-          for (int q2 = 0; q2 < 8; ++q2) v = fma(sZ[q2 * 16 + j], WZ[q2 * 16 + l], v);
+          for (int q2 = 0; q2 < PS; ++q2) v = fma(-TK[k * PS + q2], sZ[q2 * 16 + j], v);
+        } else if (k < 2 * MS) {  // -gl (Z' W Z)[j][l]
+          for (int q2 = 0; q2 < PS; ++q2) v = fma(sZ[q2 * 16 + j], WZ[q2 * 16 + l], v);
           v *= -gl;
-        } else {  // gl (Z' W)[j][q]
-          const int q2 = k - 32;
-          for (int r2 = 0; r2 < 8; ++r2) v = fma(sZ[r2 * 16 + j], sW[r2 * 8 + q2], v);
+        } else if (yq < PS) {  // gl (Z' W)[j][q]
+          for (int r2 = 0; r2 < PS; ++r2) v = fma(sZ[r2 * 16 + j], sW[r2 * PS + yq], v);
           v *= gl;
         }
       } else if (lane < 32) {
-        if (k >= 16 && k < 32) v = ((k - 16 == j) ? 1.0 : 0.0) - KZ[j * 16 + (k - 16)];
-        else if (k >= 32) v = sK[j * 8 + (k - 32)];
+        if (k >= MS && k < 2 * MS) {  // (I - K Z)[j][l]
+          v = (l == j) ? 1.0 : 0.0;
+          for (int q2 = 0; q2 < PS; ++q2) v = fma(-sK[j * PS + q2], sZ[q2 * 16 + l], v);
+        } else if (k >= 2 * MS && yq < PS) {
+          v = sK[j * PS + yq];
+        }
       } else if (lane < 48) {
-        if (k < 16) v = sT[k * 16 + j];
+        if (k < MS) v = sT[k * 16 + j];
       } else if (lane < 56) {
-        if (k >= 16 && k < 32) v = -sZ[q * 16 + (k - 16)];
-        else if (k >= 32) v = (k - 32 == q) ? 1.0 : 0.0;
-      } else {
-        if (k < 16) v = TK[k * 8 + q];
-        else if (k < 32) v = gl * WZ[q * 16 + (k - 16)];
-        else v = -gl * sW[q * 8 + (k - 32)];
+        if (qok) {
+          if (k >= MS && k < 2 * MS) v = -sZ[q * 16 + l];
+          else if (k >= 2 * MS && yq < PS) v = (yq == q) ? 1.0 : 0.0;
+        }
+      } else if (qok) {
+        if (k < MS) v = TK[k * PS + q];
+        else if (k < 2 * MS) v = gl * WZ[q * 16 + l];
+        else if (yq < PS) v = -gl * sW[q * PS + yq];
       }
       cf[k] = v;
     }
   }
   wave_lds_fence();
-  double* XV = smem + SA_OFF_V;   // x: lam (16) | a (16) | y~ (8)
-  double* OUT = X1;               // stage outputs: lam_t (16) | af (16) | mu (16) | v (8) | vb (8)   (X1[0..63]: the inverse's scratch, dead)
   for (int e = lane; e < 48; e += KF_WAVE) XV[e] = 0.0;
 
   // ---- accumulators (registers; lanes over matrix entries) ----------------------------------------------------------------------
@@ -218,18 +239,16 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_kernel(const KfBwdArgs 
   };
   double nxt = ts < n ? fetch(n - 1) : 0.0;
   for (int t = n - 1; t >= ts; --t) {
-    if (is_a || is_y) XV[lane] = nxt;   // (x is laid out so that lane l in 16..39 owns element l)
+    if (is_a) XV[MS + lane - 16] = nxt;
+    if (is_y) XV[2 * MS + lane - 32] = nxt;
     wave_lds_fence();
     if (t > ts) nxt = fetch(t - 1);
     double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-    for (int k = 0; k < 40; k += 4) {
+    for (int k = 0; k < NX; k += 2) {
       const double2_t x01 = *reinterpret_cast<const double2_t*>(XV + k);
-      const double2_t x23 = *reinterpret_cast<const double2_t*>(XV + k + 2);
       acc0 = fma(cf[k], x01.x, acc0);
       acc1 = fma(cf[k + 1], x01.y, acc1);
-      acc0 = fma(cf[k + 2], x23.x, acc0);
-      acc1 = fma(cf[k + 3], x23.y, acc1);
     }
     const double o = acc0 + acc1;
     OUT[lane] = o;
@@ -238,11 +257,12 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_kernel(const KfBwdArgs 
     {
       const double afj = OUT[16 + tj];
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) Tb[s2] = fma(XV[ti4 + 4 * s2], afj, Tb[s2]);
+      for (int s2 = 0; s2 < 4; ++s2)   // (rows >= MS read past lam: finite values, the rows are never stored)
+        Tb[s2] = fma(XV[ti4 + 4 * s2], afj, Tb[s2]);
       const double vqv = OUT[48 + kq];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) Kb[s2] = fma(OUT[32 + ki + 8 * s2], vqv, Kb[s2]);
-      const double azj = XV[16 + zj];
+      const double azj = XV[MS + (zj < MS ? zj : 0)];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) Zb[s2] = fma(-OUT[56 + zq + 4 * s2], azj, Zb[s2]);
       VV = fma(gl * OUT[48 + vq], OUT[48 + vr], VV);
@@ -250,61 +270,62 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_kernel(const KfBwdArgs 
       if (lane >= 56) db = fma(dsign, o, db);
       GLs += gl;
     }
-    if (lane < 16) XV[lane] = o;
+    if (lane < MS) XV[lane] = o;
   }
   wave_lds_fence();
-  // (the epilogue and the outputs below index vectors as the first version of this kernel did)
-  if (lane < 16) lam[lane] = XV[lane];
   {
     const double dbv = __shfl(db, 56 + (lane & 7));
     db = dbv;
   }
+  const double lam_fin = (lane < MS) ? XV[lane] : 0.0;
   wave_lds_fence();
 
-  // ---- epilogue: (K_b, W_b) -> (P_b, Z_b, H_b) -----------------------------------------------------------------------------------------
-  double* eKb = X0;         // 16 x 8  (X0's M is dead: K is what the chain rule needs, M = K F)
-  double* eMb = X0 + 128;   // 16 x 8
-  double* eWb = X1;         // 8 x 8
-  double* eFb = X1 + 64;    // 8 x 8
-  double* eM = X1 + 128;    // 16 x 8: M = P Z'
-  double* eFZ = X2;         // 8 x 16: F_b Z
-  double* eFZP = X2 + 128;  // 8 x 16: F_b Z P
+  // ---- epilogue: (K_b, W_b) -> (P_b, Z_b, H_b); its buffers take the setup's scratch -------------------------------------------------
+  double* eKb = smem + L::E_KB;    // 16 x PS
+  double* eMb = smem + L::E_MB;    // 16 x PS
+  double* eWb = smem + L::E_WB;    // PS x PS
+  double* eFb = smem + L::E_FB;    // PS x PS
+  double* eM = smem + L::E_M;      // 16 x PS: M = P Z'
+  double* eFZ = smem + L::E_FZ;    // PS x 16: F_b Z
+  double* eFZP = smem + L::E_FZP;  // PS x 16: F_b Z P
+  const bool vok = vq < PS && vr < PS;
 #pragma unroll
-  for (int s = 0; s < 2; ++s) eKb[(ki + 8 * s) * 8 + kq] = Kb[s];
+  for (int s = 0; s < 2; ++s)
+    if (kq < PS) eKb[(ki + 8 * s) * PS + kq] = Kb[s];
+  wave_lds_fence();
   for (int e = lane; e < m * p; e += KF_WAVE) {
     const int i = e / p, q = e - i * p;
     double sm = 0.0;
     for (int j = 0; j < m; ++j) sm = fma(sP[i * 16 + j], sZ[q * 16 + j], sm);
-    eM[i * 8 + q] = sm;
+    eM[i * PS + q] = sm;
   }
   wave_lds_fence();
-  {  // W_b = (GL F - VV) / 2 + M' K_b, symmetrised
-    double s = 0.5 * (GLs * sF[vq * 8 + vr] - VV);
-    for (int i = 0; i < m; ++i) s = fma(eM[i * 8 + vq], eKb[i * 8 + vr], s);
-    eWb[lane] = (vq < p && vr < p) ? s : 0.0;
+  if (vok) {  // W_b = (GL F - VV) / 2 + M' K_b, symmetrised
+    double s = 0.5 * (GLs * sF[vq * PS + vr] - VV);
+    for (int i = 0; i < m; ++i) s = fma(eM[i * PS + vq], eKb[i * PS + vr], s);
+    eWb[vq * PS + vr] = (vq < p && vr < p) ? s : 0.0;
   }
   for (int e = lane; e < m * p; e += KF_WAVE) {  // M_b = K_b W
     const int i = e / p, q = e - i * p;
     double s = 0.0;
-    for (int r2 = 0; r2 < p; ++r2) s = fma(eKb[i * 8 + r2], sW[r2 * 8 + q], s);
-    eMb[i * 8 + q] = s;
+    for (int r2 = 0; r2 < p; ++r2) s = fma(eKb[i * PS + r2], sW[r2 * PS + q], s);
+    eMb[i * PS + q] = s;
   }
   wave_lds_fence();
-  {  // F_b = -W sym(W_b) W
+  if (vok) {  // F_b = -W sym(W_b) W
     double s = 0.0;
     for (int r2 = 0; r2 < p; ++r2) {
       double t2 = 0.0;
-      for (int r3 = 0; r3 < p; ++r3) t2 = fma(0.5 * (eWb[r2 * 8 + r3] + eWb[r3 * 8 + r2]), sW[r3 * 8 + vr], t2);
-      s = fma(sW[vq * 8 + r2], t2, s);
+      for (int r3 = 0; r3 < p; ++r3) t2 = fma(0.5 * (eWb[r2 * PS + r3] + eWb[r3 * PS + r2]), sW[r3 * PS + vr], t2);
+      s = fma(sW[vq * PS + r2], t2, s);
     }
-    wave_lds_fence();
-    eFb[lane] = -s;
+    eFb[vq * PS + vr] = -s;
   }
   wave_lds_fence();
   for (int e = lane; e < p * m; e += KF_WAVE) {  // F_b Z
     const int q = e / m, j = e - q * m;
     double s = 0.0;
-    for (int r2 = 0; r2 < p; ++r2) s = fma(eFb[q * 8 + r2], sZ[r2 * 16 + j], s);
+    for (int r2 = 0; r2 < p; ++r2) s = fma(eFb[q * PS + r2], sZ[r2 * 16 + j], s);
     eFZ[q * 16 + j] = s;
   }
   wave_lds_fence();
@@ -319,7 +340,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_kernel(const KfBwdArgs 
   for (int e = lane; e < mm; e += KF_WAVE) {  // P_b = M_b Z + Z' F_b Z
     const int i = e / m, j = e - i * m;
     double s = 0.0;
-    for (int q = 0; q < p; ++q) s = fma(eMb[i * 8 + q], sZ[q * 16 + j], fma(sZ[q * 16 + i], eFZ[q * 16 + j], s));
+    for (int q = 0; q < p; ++q) s = fma(eMb[i * PS + q], sZ[q * 16 + j], fma(sZ[q * 16 + i], eFZ[q * 16 + j], s));
     out_Pb[b * (long)mm + e] = s;
     if (A.g_P0) A.g_P0[b * (long)mm + e] = 0.0;
   }
@@ -336,17 +357,17 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_kernel(const KfBwdArgs 
       const int q = zq + 4 * s;
       if (q < p && zj < m) {
         double v = Zb[s] + 2.0 * eFZP[q * 16 + zj];  // + M_b' P + 2 F_b Z P
-        for (int i = 0; i < m; ++i) v = fma(eMb[i * 8 + q], sP[i * 16 + zj], v);
+        for (int i = 0; i < m; ++i) v = fma(eMb[i * PS + q], sP[i * 16 + zj], v);
         A.g_Z[b * (long)p * m + q * m + zj] = v;
       }
     }
   }
   if (A.g_H)
-    for (int e = lane; e < p * p; e += KF_WAVE) A.g_H[b * (long)p * p + e] = (e / p == e % p) ? eFb[(e / p) * 8 + e % p] : 0.0;
+    for (int e = lane; e < p * p; e += KF_WAVE) A.g_H[b * (long)p * p + e] = (e / p == e % p) ? eFb[(e / p) * PS + e % p] : 0.0;
   if (lane < m) {
     if (A.g_c) A.g_c[b * (long)m + lane] = cb;
     if (A.g_a0) A.g_a0[b * (long)m + lane] = 0.0;
-    out_ab[b * (long)m + lane] = lam[lane];
+    out_ab[b * (long)m + lane] = lam_fin;
   }
   if (lane < p && A.g_d) A.g_d[b * (long)p + lane] = db;
   if (A.g_R)
@@ -370,7 +391,13 @@ int kf_launch_backward_steady(kf_handle* h, const KfBwdArgs& a, const int32_t* t
     KF_SET_ERR(h, "backward(steady): needs m <= %d, p <= %d, static matrices (got m=%d p=%d)", SA_M, SA_P, a.m, a.p);
     return KF_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(kf_bwd_steady_kernel, dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, ts, out_ab, out_Pb, out_P, P_conv);
+#define KF_SA_LAUNCH(PS_, MS_) \
+  hipLaunchKernelGGL((kf_bwd_steady_kernel<PS_, MS_>), dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, ts, out_ab, out_Pb, out_P, P_conv)
+  if (a.p == 1 && a.m <= 12) KF_SA_LAUNCH(1, 12);
+  else if (a.p == 1) KF_SA_LAUNCH(1, 16);
+  else if (a.m <= 12) KF_SA_LAUNCH(8, 12);
+  else KF_SA_LAUNCH(8, 16);
+#undef KF_SA_LAUNCH
   KF_HIP_CHECK(h, hipGetLastError());
   return KF_OK;
 }

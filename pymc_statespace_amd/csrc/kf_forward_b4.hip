@@ -101,8 +101,10 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   double* YB = smem + B4_OFF_YB;
 
   // ---- per-draw constants through an LDS scratch that aliases the loop buffers (kf_b4.h) ------------------------
-  constexpr bool HALF_STATIC = B4Const<NB>::HALF;
-  B4Const<NB> KC;
+  // (VGS: T / 2 is not kept as a second register set -- 18 registers that this instantiation, which carries the convergence test AND
+  // the tile tape, would otherwise spill; the 1/2 is applied after the symmetrisation instead, three multiplies per step)
+  constexpr bool HALF_STATIC = B4Const<NB>::HALF && !VGS;
+  B4Const<NB, HALF_STATIC> KC;
   if (SS == 2 && t0 > 0) {
     // a later chunk of the split pipeline: the replicated T blocks and C_ext as the first chunk left them (21 coalesced loads
     // instead of the ~50 us of setup a full launch spends), and the zeroed transpose tile b4_setup leaves behind

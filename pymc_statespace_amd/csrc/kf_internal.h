@@ -145,6 +145,9 @@ struct KfBwdArgs {
   int accumulate;
   // internal (steady-state adjoint, kf_backward_steady.hip): per-draw number of steps to sweep instead of T (NULL: T for every draw)
   const int32_t* steps = nullptr;
+  // internal: workgroup i processes draw list[i] (NULL: draw i) -- a launch whose draws need very different step counts is ordered
+  // so that the wavefronts sharing a SIMD carry about the same total (kf_vg_order_kernel, kf_api.hip)
+  const int32_t* list = nullptr;
 };
 
 struct KfSmoothArgs {

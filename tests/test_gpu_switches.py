@@ -104,7 +104,8 @@ def test_smoother_switches_stay_within_parity(eng, monkeypatch, case):
 
 GRAD_CASES = [
     ("KF_VG_STEADY", "0", lambda: W.varmax(B=32, n=200), {"h_diagonal": True}),
-    ("KF_VG_STEADY", "0", lambda: W.structural(B=32, n=300), {}),
+    ("KF_VG_STEADY", "0", lambda: W.structural(B=32, n=300), {"exact_recursion": False}),
+    ("KF_VG_STEADY", "1", lambda: W.structural(B=32, n=300), {}),
     ("KF_VG_TILE_TAPE", "0", lambda: W.structural(B=32, n=200), {}),
     ("KF_BACKWARD_B4", "0", lambda: W.structural(B=32, n=200), {}),
     ("KF_BACKWARD_B4", "1", lambda: W.arma11(B=2000, n=100), {}),
