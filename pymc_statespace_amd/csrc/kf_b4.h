@@ -88,8 +88,11 @@ struct TapeStream {
     return (byte_off + 8u * (unsigned)cnt) & (unsigned)(8 * RING - 1);
   }
   __device__ __forceinline__ void window(int w0, int lo, int hi, int lane, double scale) {
+    // (w0 is a multiple of GRAN and a window never wraps: the ring position is a wave-uniform base plus a lane constant -- one
+    // vector add per window instead of the add / and / shift of the general element number)
+    const int lane2 = 2 * (lane & (GRAN / 2 - 1));
     const int e = w0 + 2 * lane;
-    double2_t v = *reinterpret_cast<const double2_t*>(ring + (e & (RING - 1)));
+    double2_t v = *reinterpret_cast<const double2_t*>(ring + ((w0 & (RING - 1)) + lane2));
     v.x *= scale;
     v.y *= scale;
     char* dst = reinterpret_cast<char*>(tape + (w0 - e0));  // (may point below the tape: only lanes >= lo store)

@@ -49,8 +49,17 @@ constexpr int B4_OFF_RA = B4_OFF_YB + 2 * LB;     // state tapes: 2 rings of RIN
 constexpr int RING_A = 128, GRAN_A = 64;
 constexpr int B4_OFF_RP = B4_OFF_RA + 2 * RING_A; // covariance tapes: 2 rings of RING_P (or one m x m image + dump slots)
 constexpr int RING_P = 256, GRAN_P = 128;
-constexpr int B4_LOOP_DOUBLES = B4_OFF_RP + 2 * RING_P;
+constexpr int B4_OFF_DUMP = B4_OFF_RP + 2 * RING_P;  // one slot per lane: where lanes that have nothing to exchange write (no exec masking)
+constexpr int B4_LOOP_DOUBLES = B4_OFF_DUMP + KF_WAVE;
 static_assert(B4_LOOP_DOUBLES <= 1280, "four wavefronts per SIMD need <= 10 KiB of LDS per wavefront");
+// Round 4: the step loop writes LDS WITHOUT exec masks.  Measured (profiles/r04/headline_pin.txt): a wave-step is 206 instructions
+// at 4.6 SIMD cycles each, 70 of them scalar -- and half of those were the s_and_saveexec / s_or / s_cbranch_execz around ten
+// predicated ds_writes (tape-ring appends of the lanes inside the m x m block, the u exchange of DPP row 0).  Now every lane
+// writes: a lane without a tape element writes into the DEAD ZONE of its ring -- the GRAN - (elements per step) positions right
+// behind this step's append, which the next steps overwrite before any window that contains them is flushed (a window leaves only
+// when the append position has passed its end, and appends are contiguous) -- and a lane outside DPP row 0 exchanges into its own
+// dump slot.
+static_assert(RING_P >= 2 * GRAN_P && RING_A >= 2 * GRAN_A, "dead zone: a ring holds one unflushed window plus one being filled");
 // (the covariance rings hold GRAN_P - 1 left-over doubles + one step: m * m <= RING_P - GRAN_P + 1, i.e. m <= 11; used for NB <= 3)
 
 template <int I, int N, typename F>
@@ -158,10 +167,16 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
 
   // u exchange: DPP row 0 writes u[column] at position 4 q + b, reads {u[q], u[4+q], u[8+q], u[12+q]};
   // the other rows read zeros
-  double* ux_w = UX + fb;
-  const double* ux_r = (g == 0) ? UX + 4 * (lane & 3) : UX + 16;
-  const double mask0 = (g == 0 && bq < N4) ? 1.0 : 0.0;  // u lives in DPP row 0 (k = 0 of the rank-one MFMA)
-  const double adjm = (lane == JC) ? 1.0 : 0.0;
+  // Round 4: in the step loop u stays where the tile has it -- row JA = DPP row 2 of the last register -- and the rank-one MFMA
+  // contracts over k = 2 instead of k = 0 (the move to row 0 was two v_permlane32_swap and four copies per step); the steady-state
+  // loops below keep their row-0 layout
+  double* ux_w = (g == 2) ? UX + fb : smem + B4_OFF_DUMP + lane;
+  const double* ux_r = (g == 2) ? UX + 4 * (lane & 3) : UX + 16;
+  const double mask2 = (g == 2 && bq < N4) ? 1.0 : 0.0;
+  const double adjm = (lane == 32 + JC) ? 1.0 : 0.0;
+  double* ux_w0 = (g == 0) ? UX + fb : smem + B4_OFF_DUMP + lane;   // (steady-state loops: u in DPP row 0)
+  const double* ux_r0 = (g == 0) ? UX + 4 * (lane & 3) : UX + 16;
+  const double mask0 = (g == 0 && bq < N4) ? 1.0 : 0.0;
   const bool vec_on = g == 3 && bq < m;                  // row JC of the tile = 2 a'
   // (a later chunk of the split pipeline continues the tapes at step t0: predicted slot t0 was written by the chunk before)
   const int ps0 = t0 ? t0 + 1 : 0;
@@ -176,8 +191,16 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   TapeStream<RING_A, GRAN_A> s_fa, s_pa;
   s_fa.init(t_fa, smem + B4_OFF_RA);
   s_pa.init(t_pa, smem + B4_OFF_RA + RING_A);
-  unsigned o_fa = s_fa.slot(bq), o_pa = s_pa.slot(bq);
-  auto put_a = [&](TapeStream<RING_A, GRAN_A>& st, unsigned& off, double twice_a, bool lanes_on) {
+  // (the step loop's writers are the lanes of tile row JC; every other lane appends into the dead zone, see above: m + 32 <= GRAN_A)
+  const int ka = vec_on ? bq : m + (lane & 31);
+  unsigned o_fa = s_fa.slot(ka), o_pa = s_pa.slot(ka);
+  auto put_a = [&](TapeStream<RING_A, GRAN_A>& st, unsigned& off, double twice_a) {
+    *reinterpret_cast<double*>(reinterpret_cast<char*>(st.ring) + off) = twice_a;
+    off = TapeStream<RING_A, GRAN_A>::next(off, m);
+    st.appended(m, lane, 0.5);
+  };
+  // the steady-state loops' writers are the lanes of DPP row 0: masked appends at per-column offsets (set at the phase's entry)
+  auto put_a_row = [&](TapeStream<RING_A, GRAN_A>& st, unsigned& off, double twice_a, bool lanes_on) {
     if (lanes_on) *reinterpret_cast<double*>(reinterpret_cast<char*>(st.ring) + off) = twice_a;
     off = TapeStream<RING_A, GRAN_A>::next(off, m);
     st.appended(m, lane, 0.5);
@@ -192,13 +215,16 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   for (int I = 0; I < NB; ++I) {
     const int rr = 4 * I + g;
     on[I] = rr < m && bq < m;
-    o_fP[I] = s_fP.slot(on[I] ? rr * m + bq : 0);
-    o_pP[I] = s_pP.slot(on[I] ? rr * m + bq : 0);
+    // (lanes outside the m x m block: the dead zone behind the step's mm elements -- GRAN_P - mm >= 7 positions for m <= 11)
+    const int dz = GRAN_P - mm > 0 ? GRAN_P - mm : 1;
+    const int kp = on[I] ? rr * m + bq : mm + (lane % dz);
+    o_fP[I] = s_fP.slot(kp);
+    o_pP[I] = s_pP.slot(kp);
   }
   auto put_P = [&](TapeStream<RING_P, GRAN_P>& st, unsigned (&off)[NB], const double (&Preg)[NB]) {
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
-      if (on[I]) *reinterpret_cast<double*>(reinterpret_cast<char*>(st.ring) + off[I]) = Preg[I];
+      *reinterpret_cast<double*>(reinterpret_cast<char*>(st.ring) + off[I]) = Preg[I];
       off[I] = TapeStream<RING_P, GRAN_P>::next(off[I], mm);
     }
     st.appended(mm, lane, 1.0);
@@ -253,7 +279,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     }
   }
   // predicted tape slot 0 = (a0, P0 as given: the caller's P0, not its symmetrised upper triangle)
-  if (w_pa && t0 == 0) put_a(s_pa, o_pa, P[NB - 1], vec_on);
+  if (w_pa && t0 == 0) put_a(s_pa, o_pa, P[NB - 1]);
   if (w_pP && t0 == 0) {
     if (STREAM) {
       double P0g[NB];
@@ -353,24 +379,23 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
         if (on[I]) *reinterpret_cast<double*>(reinterpret_cast<char*>(s_pP.ring) + o_pP[I]) = P[I];
     }
     const double2_t yo = *reinterpret_cast<const double2_t*>(YB + 2 * (t & (LB - 1)));  // {-2 (y -+ d), observed}
-    // ---- update: u = row JA of the tile (DPP row 2 of the last register) brought to DPP row 0 ---------------
-    const double raw = high_half_everywhere(P[NB - 1]);
-    const double u = fma(raw, mask0, adjm * yo.x);  // u_JC = 2 Z a - 2 (y -+ d) = -2 v
-    // left factor of the rank-one step: block I of u replicated over the four slots (k = 0: DPP row 0 only).
-    // One LDS exchange, issued before F / rs are known: u_rep[I] at lane (g = 0, any b, q) = u[4 I + q]
-    if (g == 0) *ux_w = u;
+    // ---- update: u = row JA of the tile (DPP row 2 of the last register), in place ---------------------------------------
+    const double u = fma(P[NB - 1], mask2, adjm * yo.x);  // u_JC = 2 Z a - 2 (y -+ d) = -2 v
+    // left factor of the rank-one step: block I of u replicated over the four slots (k = 2: DPP row 2 only).
+    // One LDS exchange, issued before F / rs are known: u_rep[I] at lane (g = 2, any b, q) = u[4 I + q]
+    *ux_w = u;  // (the other rows: their dump slots)
     wave_lds_fence();
     const double2_t ur01 = *reinterpret_cast<const double2_t*>(ux_r);
     double2_t ur23 = {0.0, 0.0};
     if (NB > 2) ur23 = *reinterpret_cast<const double2_t*>(ux_r + 2);
     wave_lds_fence();
     const double urep[4] = {ur01.x, ur01.y, ur23.x, ur23.y};
-    const double F = H1 + readlane_f64(u, JA);
+    const double F = H1 + readlane_f64(u, 32 + JA);
     // missing -> no update (rs = 0).  F <= 0: flagged when the ring is evaluated (info, NaN ll); the clamp only
     // keeps 0 * rsqrt(F) finite on a missing / skipped step (Univariate skips F == 0, :468-471: u is 0 there)
     const double rs = fast_rsqrt(fmax(F, 1e-300)) * yo.y;
     const double uh = u * rs;
-    if (lane == JC) {
+    if (lane == 32 + JC) {
       double2_t fq = {F, uh};
       *reinterpret_cast<double2_t*>(RG + 2 * (t & (LB - 1))) = fq;
     }
@@ -379,7 +404,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     for (int I = 0; I < NB; ++I) P[I] = mfma4_nega(urep[I] * rs, uh, P[I]);
     if (w_tile) {
       const double rs_t = (univariate && F == 0.0) ? 0.0 : rs;  // a skipped step has no adjoint terms (:468-471)
-      const double rowv = low_half_everywhere((lane == JA) ? rs_t : uh);  // DPP row 0 -> row 2 (= row JA of the last register)
+      const double rowv = (lane == 32 + JA) ? rs_t : uh;          // (u_hat sits in row JA of the last register already)
       put_tile(t_tile + (long)t * (N4 * N4), P, (g == (JA & 3)) ? rowv : P[NB - 1]);
     }
     if (!STREAM && pred_pending) {  // (image mode) predicted covariance of the previous step: tile image -> HBM
@@ -388,7 +413,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       pred_pending = false;
     }
     // ---- filtered tapes -----------------------------------------------------------------------------------------------
-    if (w_fa) put_a(s_fa, o_fa, P[NB - 1], vec_on);
+    if (w_fa) put_a(s_fa, o_fa, P[NB - 1]);
     if (w_fP) {
       if (STREAM) put_P(s_fP, o_fP, P);
       else stage_cov(P);  // flushed below, behind the MFMAs
@@ -457,7 +482,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       conv = npass >= 2;
     }
     if (w_tile && t == 0) put_tile(t_tile + (long)n * (N4 * N4), P, P[NB - 1]);
-    if (w_pa) put_a(s_pa, o_pa, P[NB - 1], vec_on);
+    if (w_pa) put_a(s_pa, o_pa, P[NB - 1]);
     if (w_pP) {
       if (STREAM) {
         put_P(s_pP, o_pP, P);
@@ -483,23 +508,27 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     if (t < n) {  // a_t .. a_n into slots t .. n of the compact predicted-state tape
       s_pa.init(A.pred_a + (b * (long)(n + 1) + t) * m, smem + B4_OFF_RA + RING_A);
       o_pa = s_pa.slot(bq);
-      put_a(s_pa, o_pa, P[NB - 1], vec_on);
+      put_a_row(s_pa, o_pa, P[NB - 1], vec_on);
     }
   }
   if constexpr (SS == 1 && STREAM) if (t < n) {
     // ---- steady-state steps t .. n-1 (see above); P is the converged predicted tile of step t -------------------------------
+    if constexpr (!VGS) {  // this phase's state-tape writers are the lanes of DPP row 0: per-column offsets from here on
+      o_fa = s_fa.slot(bq);
+      o_pa = s_pa.slot(bq);
+    }
     const double us = high_half_everywhere(P[NB - 1]) * mask0;  // row JA: (P Z')' with Z P Z' at JA (DPP row 0)
     const double F = H1 + readlane_f64(us, JA);
     const double rs = fast_rsqrt(fmax(F, 1e-300));
     const double uh = us * rs;
     // filtered covariance: one more rank-one step (its mean row / column is not used)
-    if (g == 0) *ux_w = us;
+    *ux_w0 = us;
     wave_lds_fence();
     double Pf[NB];
     {
-      const double2_t ur01 = *reinterpret_cast<const double2_t*>(ux_r);
+      const double2_t ur01 = *reinterpret_cast<const double2_t*>(ux_r0);
       double2_t ur23 = {0.0, 0.0};
-      if (NB > 2) ur23 = *reinterpret_cast<const double2_t*>(ux_r + 2);
+      if (NB > 2) ur23 = *reinterpret_cast<const double2_t*>(ux_r0 + 2);
       wave_lds_fence();
       const double urep[4] = {ur01.x, ur01.y, ur23.x, ur23.y};
 #pragma unroll
@@ -569,12 +598,12 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
         double2_t fq = {F, -2.0 * (yt - o1) * rs};
         *reinterpret_cast<double2_t*>(RG + 2 * (t & (LB - 1))) = fq;
       }
-      if (g == 0) *ux_w = o1;  // a_{t+1} (its JA / JC slots are rewritten at the top of the next step)
-      if (w_fa) put_a(s_fa, o_fa, o2 + o2, row0);
+      *ux_w0 = o1;  // a_{t+1} (its JA / JC slots are rewritten at the top of the next step)
+      if (w_fa) put_a_row(s_fa, o_fa, o2 + o2, row0);
       // (tried: both constant covariance tapes written in one go at the start of this phase, as kf_forward_b4q.hip does -- headline
       // 1.81 ms against 1.63, C3 6.7 against 6.2: the burst of stores delays the window flushes of the SIMD's other wavefronts)
       if (w_fP) put_P(s_fP, o_fP, Pf);
-      if (w_pa || VGS) put_a(s_pa, o_pa, o1 + o1, row0);
+      if (w_pa || VGS) put_a_row(s_pa, o_pa, o1 + o1, row0);
       if (w_pP) put_P(s_pP, o_pP, P);
       if ((t & (LB - 1)) == LB - 1) flush_ring(t - (LB - 1), LB);
     }
