@@ -68,6 +68,13 @@ __device__ __forceinline__ double uniform_f64(double x) {  // lane 0's value as 
 // written in full KiB), and an 80-byte store costs a whole wave-instruction.  Here elements are appended to a ring
 // indexed by their ABSOLUTE element number (address / 8 relative to a GRAN-aligned base) and leave for HBM only as
 // windows of GRAN doubles that start on GRAN * 8-byte boundaries: 16 bytes per lane, whole lines, every lane busy.
+// LDS by absolute byte address (the low dword of a generic pointer into LDS): a ds_write whose address register is the ring slot
+// itself -- through a generic pointer the compiler adds the (zero) base of the dynamic LDS block again at every store
+typedef double __attribute__((address_space(3))) kf_lds_f64;
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }
+__device__ __forceinline__ void lds_store_f64(unsigned addr, double v) { *(kf_lds_f64*)(size_t)addr = v; }
+__device__ __forceinline__ double lds_load_f64(unsigned addr) { return *(const kf_lds_f64*)(size_t)addr; }
+
 template <int RING, int GRAN>
 struct TapeStream {
   double* ring;
@@ -86,6 +93,17 @@ struct TapeStream {
   __device__ __forceinline__ unsigned slot(int o) const { return (unsigned)(((E + o) & (RING - 1)) * 8); }
   __device__ __forceinline__ static unsigned next(unsigned byte_off, int cnt) {
     return (byte_off + 8u * (unsigned)cnt) & (unsigned)(8 * RING - 1);
+  }
+  // the same as absolute LDS byte addresses, for rings that START ON A MULTIPLE OF THEIR SIZE (8 RING bytes): advancing is an add and
+  // one bit-field insert, and the address goes into the ds_write as it stands
+  __device__ __forceinline__ unsigned slot_abs(int o) const { return lds_addr(ring) + slot(o); }
+  __device__ __forceinline__ static unsigned next_abs(unsigned addr, int cnt) {
+    constexpr unsigned MASK = (unsigned)(8 * RING - 1);
+    return (addr & ~MASK) | ((addr + 8u * (unsigned)cnt) & MASK);
+  }
+  __device__ __forceinline__ static unsigned back_abs(unsigned addr, int cnt) {  // `cnt` elements back (the previous append)
+    constexpr unsigned MASK = (unsigned)(8 * RING - 1);
+    return (addr & ~MASK) | ((addr + 8u * (unsigned)(RING - cnt)) & MASK);
   }
   __device__ __forceinline__ void window(int w0, int lo, int hi, int lane, double scale) {
     // (w0 is a multiple of GRAN and a window never wraps: the ring position is a wave-uniform base plus a lane constant -- one
@@ -147,8 +165,10 @@ struct B4Const {
 // `scratch`: LDS private to this wavefront, >= max(b4_setup_doubles(m, r), 16 * TRS) doubles.  All
 // synchronisation is wave-local (LDS executes a wavefront's instructions in order).  On return
 // scratch[0 .. 16 TRS) is a zeroed transpose tile except for the entries the registers wrote.
+// `tile` (default: scratch itself): where the zeroed transpose tile is left, anywhere inside the scratch.
 template <int NB, bool HALF_>
-__device__ __forceinline__ void b4_setup(const KfFwdArgs& A, long b, double* scratch, int lane, B4Const<NB, HALF_>& K) {
+__device__ __forceinline__ void b4_setup(const KfFwdArgs& A, long b, double* scratch, int lane, B4Const<NB, HALF_>& K,
+                                         double* tile = nullptr) {
   constexpr int N4 = 4 * NB, JA = N4 - 2, JC = N4 - 1;
   constexpr bool HALF_STATIC = HALF_;
   const int g = lane >> 4, bq = lane & 15;
@@ -259,7 +279,7 @@ __device__ __forceinline__ void b4_setup(const KfFwdArgs& A, long b, double* scr
   }
   // C_ext must be bitwise symmetric (both mirrored entries are the same sum in a different order otherwise):
   // transpose once through the tile and average -- also zeroes the tile rows no register ever writes
-  double* TR = scratch;
+  double* TR = tile ? tile : scratch;
   for (int e = lane; e < 16 * TRS; e += KF_WAVE) TR[e] = 0.0;
   wave_lds_fence();
 #pragma unroll

@@ -42,14 +42,18 @@ namespace {
 
 constexpr int LB = 32;                  // steps per y block / likelihood ring
 // loop-time LDS (doubles); 16 wavefronts per CU must fit 160 KiB: <= 1280 doubles each
-constexpr int B4_OFF_UX = 16 * TRS;               // u by column index (16) | zeros (4)
+// (round 4: the tape rings come FIRST, each on a multiple of its own size -- their slots are kept as absolute LDS addresses and
+// advanced with one bit-field insert, kf_b4.h TapeStream::next_abs -- then the transpose tile and the small buffers)
+constexpr int RING_P = 256, GRAN_P = 128;
+constexpr int RING_A = 128, GRAN_A = 64;
+constexpr int B4_OFF_RP = 0;                      // covariance tapes: 2 rings of RING_P (or one m x m image + dump slots)
+constexpr int B4_OFF_RA = B4_OFF_RP + 2 * RING_P; // state tapes: 2 rings of RING_A
+constexpr int B4_OFF_TR = B4_OFF_RA + 2 * RING_A; // transpose tile, 16 rows of TRS
+constexpr int B4_OFF_UX = B4_OFF_TR + 16 * TRS;   // u by column index (16) | zeros (4)
 constexpr int B4_OFF_RG = B4_OFF_UX + 20;         // likelihood ring: LB x {F, u_hat_JC}
 constexpr int B4_OFF_YB = B4_OFF_RG + 2 * LB;     // y block: LB x {-2 (y -+ d) or 0, observed ? 1 : 0}
-constexpr int B4_OFF_RA = B4_OFF_YB + 2 * LB;     // state tapes: 2 rings of RING_A
-constexpr int RING_A = 128, GRAN_A = 64;
-constexpr int B4_OFF_RP = B4_OFF_RA + 2 * RING_A; // covariance tapes: 2 rings of RING_P (or one m x m image + dump slots)
-constexpr int RING_P = 256, GRAN_P = 128;
-constexpr int B4_OFF_DUMP = B4_OFF_RP + 2 * RING_P;  // one slot per lane: where lanes that have nothing to exchange write (no exec masking)
+constexpr int B4_OFF_DUMP = B4_OFF_YB + 2 * LB;   // one slot per lane: where lanes that have nothing to exchange write (no exec masking)
+static_assert((B4_OFF_RP * 8) % (RING_P * 8) == 0 && (B4_OFF_RA * 8) % (RING_A * 8) == 0, "rings start on multiples of their size");
 constexpr int B4_LOOP_DOUBLES = B4_OFF_DUMP + KF_WAVE;
 static_assert(B4_LOOP_DOUBLES <= 1280, "four wavefronts per SIMD need <= 10 KiB of LDS per wavefront");
 // Round 4: the step loop writes LDS WITHOUT exec masks.  Measured (profiles/r04/headline_pin.txt): a wave-step is 206 instructions
@@ -103,7 +107,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     t1 = A.t_end < n ? A.t_end : n;
   }
 
-  double* TR = smem;
+  if (lds_addr(smem) & (unsigned)(8 * RING_P - 1)) __builtin_trap();  // (the dynamic block is the kernel's only LDS: it starts at 0)
+  double* TR = smem + B4_OFF_TR;
   double* STG = smem + B4_OFF_RP;  // !STREAM: compact m x m image (<= 196 doubles) + 64 dump slots at 256
   double* UX = smem + B4_OFF_UX;
   double* RG = smem + B4_OFF_RG;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   if (SS == 2 && t0 > 0) {
     // a later chunk of the split pipeline: the replicated T blocks and C_ext as the first chunk left them (21 coalesced loads
     // instead of the ~50 us of setup a full launch spends), and the zeroed transpose tile b4_setup leaves behind
-    for (int e = lane; e < 16 * TRS; e += KF_WAVE) smem[e] = 0.0;
+    for (int e = lane; e < 16 * TRS; e += KF_WAVE) TR[e] = 0.0;
     const double* hc = A.hs_const + b * (long)B4_HC_STRIDE + lane;
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     }
     wave_lds_fence();
   } else {
-    b4_setup(A, b, smem, lane, KC);
+    b4_setup(A, b, smem, lane, KC, TR);
     if (SS == 2 && t1 < n) {
       double* hc = A.hs_const + b * (long)B4_HC_STRIDE + lane;
 #pragma unroll
@@ -193,16 +198,16 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   s_pa.init(t_pa, smem + B4_OFF_RA + RING_A);
   // (the step loop's writers are the lanes of tile row JC; every other lane appends into the dead zone, see above: m + 32 <= GRAN_A)
   const int ka = vec_on ? bq : m + (lane & 31);
-  unsigned o_fa = s_fa.slot(ka), o_pa = s_pa.slot(ka);
+  unsigned o_fa = s_fa.slot_abs(ka), o_pa = s_pa.slot_abs(ka);   // (absolute LDS addresses)
   auto put_a = [&](TapeStream<RING_A, GRAN_A>& st, unsigned& off, double twice_a) {
-    *reinterpret_cast<double*>(reinterpret_cast<char*>(st.ring) + off) = twice_a;
-    off = TapeStream<RING_A, GRAN_A>::next(off, m);
+    lds_store_f64(off, twice_a);
+    off = TapeStream<RING_A, GRAN_A>::next_abs(off, m);
     st.appended(m, lane, 0.5);
   };
   // the steady-state loops' writers are the lanes of DPP row 0: masked appends at per-column offsets (set at the phase's entry)
   auto put_a_row = [&](TapeStream<RING_A, GRAN_A>& st, unsigned& off, double twice_a, bool lanes_on) {
-    if (lanes_on) *reinterpret_cast<double*>(reinterpret_cast<char*>(st.ring) + off) = twice_a;
-    off = TapeStream<RING_A, GRAN_A>::next(off, m);
+    if (lanes_on) lds_store_f64(off, twice_a);
+    off = TapeStream<RING_A, GRAN_A>::next_abs(off, m);
     st.appended(m, lane, 0.5);
   };
   // covariance tapes
@@ -218,14 +223,14 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     // (lanes outside the m x m block: the dead zone behind the step's mm elements -- GRAN_P - mm >= 7 positions for m <= 11)
     const int dz = GRAN_P - mm > 0 ? GRAN_P - mm : 1;
     const int kp = on[I] ? rr * m + bq : mm + (lane % dz);
-    o_fP[I] = s_fP.slot(kp);
-    o_pP[I] = s_pP.slot(kp);
+    o_fP[I] = s_fP.slot_abs(kp);
+    o_pP[I] = s_pP.slot_abs(kp);
   }
   auto put_P = [&](TapeStream<RING_P, GRAN_P>& st, unsigned (&off)[NB], const double (&Preg)[NB]) {
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
-      *reinterpret_cast<double*>(reinterpret_cast<char*>(st.ring) + off[I]) = Preg[I];
-      off[I] = TapeStream<RING_P, GRAN_P>::next(off[I], mm);
+      lds_store_f64(off[I], Preg[I]);
+      off[I] = TapeStream<RING_P, GRAN_P>::next_abs(off[I], mm);
     }
     st.appended(mm, lane, 1.0);
   };
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     if (chk && !w_pP) {  // the predicted covariance this step starts from, parked in the (unused) tape ring
 #pragma unroll
       for (int I = 0; I < NB; ++I)
-        if (on[I]) *reinterpret_cast<double*>(reinterpret_cast<char*>(s_pP.ring) + o_pP[I]) = P[I];
+        if (on[I]) lds_store_f64(o_pP[I], P[I]);
     }
     const double2_t yo = *reinterpret_cast<const double2_t*>(YB + 2 * (t & (LB - 1)));  // {-2 (y -+ d), observed}
     // ---- update: u = row JA of the tile (DPP row 2 of the last register), in place ---------------------------------------
@@ -470,8 +475,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       bool bad = false;
 #pragma unroll
       for (int I = 0; I < NB; ++I) {
-        const unsigned oo = w_pP ? ((o_pP[I] + 8u * (unsigned)(RING_P - mm)) & (unsigned)(8 * RING_P - 1)) : o_pP[I];
-        const double old = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_pP.ring) + oo);
+        const unsigned oo = w_pP ? TapeStream<RING_P, GRAN_P>::back_abs(o_pP[I], mm) : o_pP[I];
+        const double old = lds_load_f64(oo);
         const double drow = UX[on[I] ? 4 * I + g : 0];
         const double df = P[I] - old;
         bad = bad || (on[I] && !(fabs(df) <= lim && df * df <= A.ss_tol2 * fabs(dcol * drow)));  // (NaN: never converged)
@@ -507,15 +512,15 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       if (on[I]) vp[(4 * I + g) * m + bq] = P[I];
     if (t < n) {  // a_t .. a_n into slots t .. n of the compact predicted-state tape
       s_pa.init(A.pred_a + (b * (long)(n + 1) + t) * m, smem + B4_OFF_RA + RING_A);
-      o_pa = s_pa.slot(bq);
+      o_pa = s_pa.slot_abs(bq);
       put_a_row(s_pa, o_pa, P[NB - 1], vec_on);
     }
   }
   if constexpr (SS == 1 && STREAM) if (t < n) {
     // ---- steady-state steps t .. n-1 (see above); P is the converged predicted tile of step t -------------------------------
     if constexpr (!VGS) {  // this phase's state-tape writers are the lanes of DPP row 0: per-column offsets from here on
-      o_fa = s_fa.slot(bq);
-      o_pa = s_pa.slot(bq);
+      o_fa = s_fa.slot_abs(bq);
+      o_pa = s_pa.slot_abs(bq);
     }
     const double us = high_half_everywhere(P[NB - 1]) * mask0;  // row JA: (P Z')' with Z P Z' at JA (DPP row 0)
     const double F = H1 + readlane_f64(us, JA);
