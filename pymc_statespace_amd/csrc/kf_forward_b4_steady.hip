@@ -41,40 +41,56 @@ __global__ __launch_bounds__(1024) void kf_b4_split_compact_kernel(const B4Split
     if (chunk == 0) W.offS[0] = 0;
   }
   __syncthreads();
-  for (int b0 = 0; b0 < B; b0 += 1024) {
-    const int b = b0 + tid;
-    const int st = b < B ? W.hs_ts[b] : -2;
-    const bool isR = st == -1, isS = st >= 0;
-    const unsigned long long mR = __ballot(isR), mS = __ballot(isS);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const int pR = __popcll(mR & below), pS = __popcll(mS & below);
-    if (lane == 0) {
-      wsR[wv] = __popcll(mR);
-      wsS[wv] = __popcll(mS);
+  // Round 4: the status words of 8192 draws are loaded FIRST, eight independent loads per thread, then compacted out of registers.
+  // The kernel runs beside the constant-tape fill, which keeps the HBM write queues full: with one load -> barrier -> store ->
+  // barrier round per 1024 draws every round paid a memory round trip of tens of microseconds (profiles/r03/c3_split_timeline.txt:
+  // 12.5 us alone, 737 and 840 us beside the fill -- and the next recursion launch waits behind it).
+  constexpr int CU_ = 8;
+  for (int b00 = 0; b00 < B; b00 += 1024 * CU_) {
+    int stv[CU_];
+#pragma unroll
+    for (int u = 0; u < CU_; ++u) {
+      const int b = b00 + u * 1024 + tid;
+      stv[u] = b < B ? W.hs_ts[b] : -2;
     }
-    __syncthreads();
-    int oR = baseR, oS = baseS;
-    for (int w = 0; w < wv; ++w) {
-      oR += wsR[w];
-      oS += wsS[w];
-    }
-    if (isR) W.listR[oR + pR] = b;
-    if (isS) {
-      W.listS[oS + pS] = b;
-      W.listS_ts[oS + pS] = st;
-      W.hs_ts[b] = -3;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int r = 0, s = 0;
-      for (int w = 0; w < 16; ++w) {
-        r += wsR[w];
-        s += wsS[w];
+#pragma unroll
+    for (int u = 0; u < CU_; ++u) {
+      const int b0 = b00 + u * 1024;
+      if (b0 >= B) break;   // (uniform)
+      const int b = b0 + tid;
+      const int st = stv[u];
+      const bool isR = st == -1, isS = st >= 0;
+      const unsigned long long mR = __ballot(isR), mS = __ballot(isS);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const int pR = __popcll(mR & below), pS = __popcll(mS & below);
+      if (lane == 0) {
+        wsR[wv] = __popcll(mR);
+        wsS[wv] = __popcll(mS);
       }
-      baseR += r;
-      baseS += s;
+      __syncthreads();
+      int oR = baseR, oS = baseS;
+      for (int w = 0; w < wv; ++w) {
+        oR += wsR[w];
+        oS += wsS[w];
+      }
+      if (isR) W.listR[oR + pR] = b;
+      if (isS) {
+        W.listS[oS + pS] = b;
+        W.listS_ts[oS + pS] = st;
+        W.hs_ts[b] = -3;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int r = 0, s = 0;
+        for (int w = 0; w < 16; ++w) {
+          r += wsR[w];
+          s += wsS[w];
+        }
+        baseR += r;
+        baseS += s;
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   // Once at most B4_PAIR_MAX draws are left in the full recursion a SIMD holds one of them at most, and compaction has nothing
   // more to give: they go to the pair kernel (kf_forward_b4p.hip: recursion + tape-writer wavefront), which runs them to the end
