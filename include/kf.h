@@ -216,7 +216,15 @@ int kf_filter_forward(kf_handle* h, const kf_dims* dims,
  * core/statespace.py:174).  The forward filter keeps its predicted tapes inside the workspace and the adjoint sweep
  * consumes them there: nothing but logp, info and the nine gradient arrays is written for the caller.  Gradient
  * conventions as kf_filter_backward.  workspace: kf_workspace_bytes_for(h, dims, KF_WS_VALUE_AND_GRAD, &bytes) --
- * B (T + 1)(m + m^2) doubles of tape plus what the two passes need themselves. */
+ * B (T + 1)(m + m^2) doubles of tape plus what the two passes need themselves.
+ * Steady-state adjoint (static models, scalar observations): where the forward kernel has a steady-state phase the steps behind
+ * each draw's convergence point are differentiated as what they are -- a linear mean recursion with a constant gain plus ONE
+ * Riccati adjoint per draw (kf_backward_steady.hip, kf_dare_backward) -- and only the steps before it by the adjoint of the full
+ * recursion; agrees with the adjoint at every step to <= 1e-12 of a gradient's largest entry on the BASELINE workloads (asserted
+ * at 1e-10).  Used by default for the multi-observation block kernel (3 <= p <= 5, m >= 8: C4) and, round 4, for the p == 1 block
+ * kernel (m <= 10) from two rounds of the chip's wavefront slots on (B >= 32 x CUs), or one round with T >= 1536 -- below that a
+ * launch lasts as long as its slowest draw's chain and the phase gains nothing (measured: kf_api.hip).  KF_FLAG_STEADY_STATE
+ * requests it for any batch, KF_FLAG_EXACT_RECURSION (or KF_VG_STEADY=0 in the environment) the adjoint at every step. */
 int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims,
                              const double* y, const double* a0, const double* P0,
                              const double* T, const double* Z, const double* R,

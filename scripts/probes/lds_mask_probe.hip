@@ -6,9 +6,9 @@
 typedef double double2_t __attribute__((ext_vector_type(2)));
 template <int MODE, int OP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void probe(double* out, int iters) {
-  __shared__ __attribute__((aligned(16))) double lds[1024];
+  __shared__ __attribute__((aligned(16))) double lds[1280];
   const int lane = threadIdx.x;
-  for (int e = lane; e < 1024; e += 64) lds[e] = e;
+  for (int e = lane; e < 1280; e += 64) lds[e] = e;
   __syncthreads();
   const bool on = MODE == 0 ? true : (MODE == 1 ? (lane >> 4) == 2 : lane == 7);
   double2_t acc = {0.0, 0.0};
@@ -23,10 +23,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void pr
           asm volatile("" : "+v"(v));
           acc += v;
         }
-      } else {
+      } else if (OP == 1) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           dst[64 * k] = acc.x + k;
+          asm volatile("" ::: "memory");
+        }
+      } else if (OP == 2) {  // ds_write_b128
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          double2_t v = {acc.x + k, acc.y};
+          reinterpret_cast<double2_t*>(lds)[lane + 64 * (k & 3)] = v;
+          asm volatile("" ::: "memory");
+        }
+      } else if (OP == 3) {  // ds_read_b64
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          double v = lds[lane + 64 * k];
+          asm volatile("" : "+v"(v));
+          acc.x += v;
+        }
+      } else if (OP == 4) {  // two b64 writes the compiler may fuse into ds_write2_b64 (stride 72 doubles)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          dst[8 * k] = acc.x + k;
+          dst[8 * k + 72 * 8] = acc.y + k;
           asm volatile("" ::: "memory");
         }
       }
@@ -59,5 +80,8 @@ int main() {
   run<0, 1>("ds_write_b64, 64 lanes");
   run<1, 1>("ds_write_b64, 16 lanes (one row)");
   run<2, 1>("ds_write_b64, 1 lane");
+  run<0, 2>("ds_write_b128, 64 lanes");
+  run<0, 3>("ds_read_b64, 64 lanes");
+  run<0, 4>("ds_write2_b64 (4 per iteration, x2)");
   return 0;
 }

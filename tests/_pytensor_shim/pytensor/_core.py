@@ -458,6 +458,13 @@ def _vectorize_node(op, node, *batched_inputs):
     raise NotImplementedError(f"stand-in: no vectorize rule for {type(op).__name__}")
 
 
+@_vectorize_node.register(Shape_i)
+def _vectorize_shape_i(op, node, x):
+    # a core dimension of an input that gained leading batch axes: the same entry, counted from the new front (a scalar, unbatched)
+    extra = x.type.ndim - node.inputs[0].type.ndim
+    return Shape_i(op.i + extra).make_node(x)
+
+
 def vectorize_node(node, *batched_inputs):
     return _vectorize_node(node.op, node, *batched_inputs)
 

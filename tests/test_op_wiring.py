@@ -235,6 +235,14 @@ def test_the_batch_axis_reaches_one_value_and_gradient_node(monkeypatch):
     assert_allclose(gH, ref_g["H"], rtol=1e-10)
     assert_allclose(gQ, ref_g["Q"], rtol=1e-10)
     assert_allclose(gT, ref_g["T"].sum(0), rtol=1e-9, atol=1e-9)   # T was broadcast to all draws: its gradient sums over them
+    # (a2) T batched as well: the default intercepts zeros((T.shape[-1], 1)) hang off a Shape_i node whose input gains the draw axis
+    calls.clear()
+    bT = pt.tensor3("T_draws")
+    blogp2 = vectorize_graph(logp, replace={sym[3]: bT, sym[6]: bH, sym[7]: bQ})
+    f = pytensor.function([sym[0], sym[1], sym[2], bT, sym[4], sym[5], bH, bQ], blogp2)
+    assert _op_names(f).count("KalmanLogpBatchedOp") == 1
+    assert_allclose(f(vals[0], vals[1], vals[2], np.repeat(vals[3][None], B, 0), vals[4], vals[5], Hs, Qs), ref_lp, rtol=1e-12)
+    assert calls == [B]
     # (b) the batched filter's log-likelihood differentiates through the same node
     calls.clear()
     sym3 = [sym[0]] + [pt.tensor3(nm) for nm in ("a0", "P0", "T", "Z", "R", "H", "Q")]
