@@ -93,7 +93,12 @@ enum {
   /* The caller asserts that every draw's H is diagonal (e.g. VARMAX measurement error,
    * models/VARMAX.py:80-83).  Standard/CholeskyFilter with p > 1 and m <= 48 may then process the
    * p observations of a step one at a time in the register-resident kernels -- algebraically
-   * the same filter (results agree to rounding).  Off-diagonal entries are ignored when set. */
+   * the same filter (results agree to rounding).  Off-diagonal entries are ignored when set.
+   * Round 4: WITHOUT the flag a dense H (Standard / Cholesky, 2 <= p <= 8, a shape one of those kernels takes) is whitened per draw --
+   * H = L L', y* = L^-1 y, Z* = L^-1 Z, d* = L^-1 d, log det L subtracted per observed step: the same state moments and
+   * log-likelihood to rounding (kf_forward_whiten.hip) -- given the workspace kf_workspace_bytes_for asks for (B T p doubles for the
+   * per-draw series); a partially missing row or an H that is not positive definite makes the dense LDS kernel redo the batch.
+   * The gradient of a dense-H model still runs on the LDS adjoint (entrywise g_H). */
   KF_FLAG_H_DIAGONAL = 1u << 11,
   /* Forward filter: never switch to the steady-state phase.  The kernels for static models -- the lane kernel (p == 1, m <= 4),
    * the block kernel (p == 1, m <= 10) and the multi-observation block kernel (3 <= p <= 5, m >= 8) -- can test every 8 (lane

@@ -268,12 +268,20 @@ static int kf_launch_forward_mp(kf_handle* h, const KfFwdArgs& a, hipStream_t st
   return KF_ERR_UNSUPPORTED;
 }
 
+static bool kf_whiten_shape_ok(const kf_handle* h, int m, int p, int r, int T, int filter, unsigned flags, long B);
+static size_t kf_whiten_total_bytes(const kf_handle* h, const kf_dims* d);
+
 extern "C" const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* d) {
   return kf_forward_kernel_name_ws(h, d, (size_t)-1);
 }
 
 extern "C" const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_dims* d, size_t workspace_bytes) {
   if (!h || !d) return "";
+  if (kf_whiten_shape_ok(h, d->m, d->p, d->r, d->T, d->filter, d->flags, d->B) && workspace_bytes >= kf_whiten_total_bytes(h, d)) {
+    kf_dims d2 = *d;  // dense H, whitened: the diagonal-H kernel of the shape (behind kf_whiten_kernel)
+    d2.flags |= KF_FLAG_H_DIAGONAL | KF_FLAG_Y_PER_DRAW;
+    return kf_forward_kernel_name_ws(h, &d2, workspace_bytes);
+  }
   const bool row_ok = d->p == 1 && d->m <= KF_ROW_M_MAX;
   if (d->flags & KF_FLAG_TV_ANY) return "kf_fwd_lds_kernel";
   if (kf_b4_selected(h, d->m, d->p, d->r, d->B)) return "kf_fwd_b4_kernel";
@@ -300,9 +308,36 @@ extern "C" const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_di
   return "kf_fwd_lds_kernel";
 }
 
+// Dense H with p > 1 (Standard / Cholesky) on the scalar-observation kernels by whitening (kf_forward_whiten.hip): eligible when
+// one of those kernels takes the shape once H is diagonal, the dense (LDS) kernel fits as the fallback, and no kernel was forced.
+// KF_FORWARD_WHITEN=0 in the environment keeps the dense kernel.
+static bool kf_whiten_shape_ok(const kf_handle* h, int m, int p, int r, int T, int filter, unsigned flags, long B) {
+  if (p < 2 || p > 8 || (flags & (KF_FLAG_TV_ANY | KF_FLAG_H_DIAGONAL))) return false;
+  if (filter != KF_FILTER_STANDARD && filter != KF_FILTER_CHOLESKY) return false;
+  if (h->forward_kernel != KF_KERNEL_AUTO || !kf_forward_lds_fits(m, p)) return false;
+  const char* e = kf_env_switch("KF_FORWARD_WHITEN");
+  if (e && e[0] == '0') return false;
+  const unsigned fd = flags | KF_FLAG_H_DIAGONAL;
+  return kf_b4q_selected(h, m, p, r, filter, fd, B) || kf_nb_ok(h, m, p, r, filter, fd) || kf_wg_ok(h, m, p, r, filter, fd) ||
+         kf_mp_ok(h, m, p, T, filter, fd);
+}
+static size_t kf_whiten_total_bytes(const kf_handle* h, const kf_dims* d) {
+  kf_dims d2 = *d;
+  d2.flags |= KF_FLAG_H_DIAGONAL | KF_FLAG_Y_PER_DRAW;
+  size_t inner = 0;
+  (void)kf_workspace_bytes_for(h, &d2, KF_WS_FORWARD, &inner);
+  return kf_forward_whiten_workspace_bytes(d->B, d->T, d->p, d->m) + inner + 256;
+}
+
 int kf_launch_forward(kf_handle* h, const KfFwdArgs& a_in, void* workspace, size_t workspace_bytes,
                       hipStream_t stream) {
   KfFwdArgs a = a_in;
+  if (kf_whiten_shape_ok(h, a.m, a.p, a.r, a.T, a.filter, a.flags, a.B) && workspace) {
+    kf_dims d0;
+    d0.B = a.B; d0.T = a.T; d0.p = a.p; d0.m = a.m; d0.r = a.r; d0.filter = a.filter; d0.flags = a.flags;
+    if (workspace_bytes >= kf_whiten_total_bytes(h, &d0))
+      return kf_launch_forward_whitened(h, a, workspace, workspace_bytes, stream, kf_launch_forward);
+  }
   {
     const char* e = kf_env_experiment("KF_SS_ENTRY_TOL");  // experiments: the entrywise tolerance of the steady-state test (default 1e-12)
     if (e && *e && atof(e) > 0.0) a.ss_tol2 = atof(e) * atof(e);
@@ -617,6 +652,9 @@ extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, i
   }
   *bytes = 0;  // the LDS- and register-resident kernels keep all scratch on chip
   const int m = dims->m, p = dims->p, r = dims->r;
+  // forward, dense H with p > 1: the whitened inputs (one series per draw) + what the diagonal-H kernel needs itself
+  if ((which & KF_WS_FORWARD) && dims->T >= 1 && kf_whiten_shape_ok(h, m, p, r, dims->T, dims->filter, dims->flags, dims->B))
+    *bytes = kf_whiten_total_bytes(h, dims);
   const bool tile_kernels = h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_MFMA;
   const bool scalar_obs = p == 1 || dims->filter == KF_FILTER_UNIVARIATE || (dims->flags & KF_FLAG_H_DIAGONAL);
   // forward: HBM-workspace path for tiles beyond LDS and, when no on-chip kernel takes the shape, for m > 48

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lds_kernel(const KfFwdArgs A) 
   const bool tvD = A.flags & KF_FLAG_TV_D;
   const bool tv_any = (A.flags & KF_FLAG_TV_ANY) != 0;
 
+  if (A.run_if && *A.run_if == 0) return;  // (fallback launch of kf_forward_whiten.hip: nothing to redo)
   long b = (long)blockIdx.x * DPB + grp;
   const bool live = b < A.B;  // tail groups compute a clone of the last draw, store nothing
   if (!live) b = A.B - 1;

@@ -102,6 +102,7 @@ struct KfFwdArgs {
   double ss_tol2 = 1e-24;       // (square of) the entrywise tolerance of the steady-state test, 1e-12 of sqrt(P_ii P_jj)
   int skip_steady_cov = 0;      // internal (kf_filter_value_and_grad): the steady-state phase leaves the constant covariance tapes unwritten
   int32_t* hs_tfree = nullptr;  // [B] first step after the last missing observation (written by the first chunk)
+  const int32_t* run_if = nullptr;  // internal (kf_forward_whiten.hip): the LDS kernel exits at once unless *run_if != 0
   double* vg_P = nullptr;       // internal (kf_filter_value_and_grad, block kernel + steady-state adjoint): [B][m][m] the predicted covariance at hs_ts[b]
 };
 
@@ -265,6 +266,10 @@ int kf_big_gemm_launch(hipStream_t st, bool trans_b, bool add_e, bool upper_mirr
                        long sB, const double* E, long sE, double* C, long sC, int m, long draws);
 int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
                           hipStream_t stream);
+// dense H with p > 1 on the scalar-observation kernels by whitening (kf_forward_whiten.hip)
+size_t kf_forward_whiten_workspace_bytes(long B, int T, int p, int m);
+int kf_launch_forward_whitened(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                               int (*inner)(kf_handle*, const KfFwdArgs&, void*, size_t, hipStream_t));
 inline bool kf_forward_lds_fits(int m, int p) {
   size_t lds = sizeof(double) * ((size_t)kf_pair_table_doubles(m) + (size_t)kf_fwd_region_doubles(m, p));
   return lds <= KF_LDS_BYTES_MAX;

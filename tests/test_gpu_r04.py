@@ -169,3 +169,80 @@ def test_forcing_the_block_kernel_keeps_the_c4_gradient_right(eng):
         if nm == "H":
             a_, x_ = np.einsum("bii->bi", a_), np.einsum("bii->bi", x_)
         assert np.max(np.abs(a_ - x_)) / (1.0 + np.max(np.abs(x_))) < 1e-10, nm
+
+
+# ----------------------------------------------------------------------------------------------
+# dense H with p > 1 by whitening (csrc/kf_forward_whiten.hip)
+# ----------------------------------------------------------------------------------------------
+def _fwd_np(res):
+    out = {"logp": res.logp.cpu().numpy(), "info": res.info.cpu().numpy()}
+    for k in ("filtered_states", "predicted_states", "filtered_covs", "predicted_covs", "ll_obs"):
+        out[k] = getattr(res, k).cpu().numpy()
+    return out
+
+
+@pytest.mark.parametrize("ft", ["standard", "cholesky"])
+@pytest.mark.parametrize("mvn", ["exact", "reference"])
+@pytest.mark.parametrize("shape", [(2, 4, 2), (3, 9, 3), (5, 15, 5), (5, 10, 5), (8, 12, 4), (4, 20, 6), (3, 33, 5)])
+def test_dense_H_runs_on_the_scalar_observation_kernels_by_whitening(eng, monkeypatch, ft, mvn, shape):
+    """Reference Standard / Cholesky updates with any positive definite H (kalman_filter.py:262-275, 289-305): the whitened path
+    against the numpy oracle (1e-8 on logp, 1e-9 on tapes and ll_obs) and against the dense LDS kernel it replaces, with whole
+    rows missing and intercepts; the kernel the call takes is a diagonal-H one."""
+    from oracle import kalman_numpy as kn
+
+    p, m, r = shape
+    w = W.random_dense(B=24, n=90, p=p, m=m, r=r, seed=100 + p + m, h_diag=False)
+    y = w["y"].copy()
+    y[[4, 30, 31]] = np.nan
+    rng = np.random.default_rng(p * m)
+    c, d = 0.05 * rng.standard_normal((24, m)), 0.1 * rng.standard_normal((24, p))
+    args = (y,) + tuple(w[k] for k in KEYS)
+    assert "lds" not in eng.forward_kernel_name(24, 90, p, m, r, filter_type=ft)
+    got = _fwd_np(eng.forward(*args, c, d, filter_type=ft, mvn_const=mvn))
+    monkeypatch.setenv("KF_FORWARD_WHITEN", "0")
+    assert "lds" in eng.forward_kernel_name(24, 90, p, m, r, filter_type=ft)
+    dense = _fwd_np(eng.forward(*args, c, d, filter_type=ft, mvn_const=mvn))
+    monkeypatch.delenv("KF_FORWARD_WHITEN")
+    # (cholesky_triangle="correct": the build never reproduces the reference's wrong-triangle solve for p > 1, SURVEY row A8)
+    ref = kn.kalman_filter(*args, c=c, d=d, filter_type=ft, mvn_const=mvn, cholesky_triangle="correct")
+    assert not got["info"].any()
+    for other, tag in ((ref, "oracle"), (dense, "dense kernel")):
+        tol = 1e-8 * np.maximum(1.0, np.abs(other["logp"]) / 1e4)
+        assert np.all(np.abs(got["logp"] - other["logp"]) <= tol), tag
+        for k in ("filtered_states", "predicted_states", "filtered_covs", "predicted_covs", "ll_obs"):
+            assert_allclose(got[k], other[k], rtol=1e-9, atol=1e-9, err_msg=f"{tag} {k}")
+    assert got["ll_obs"][0, 4] == 0.0 and got["ll_obs"][0, 30] == 0.0   # whole-row NaN: no update, ll 0 (:195-213, :268)
+
+
+def test_dense_H_falls_back_where_whitening_does_not_apply(eng):
+    """A partially missing row (L^-1 would spread the NaN: the row-deletion semantics need the original observations) and an H
+    that is not positive definite raise the device flag: the dense kernel redoes the batch behind the whitened one, with no host
+    synchronisation in between -- results are the dense path's, per-draw data and one-draw batches included."""
+    from oracle import kalman_numpy as kn
+
+    w = W.random_dense(B=10, n=60, p=3, m=6, r=3, seed=5, h_diag=False)
+    y = w["y"].copy()
+    y[7, 1] = np.nan                      # one cell of a row
+    y[20] = np.nan
+    args = (y,) + tuple(w[k] for k in KEYS)
+    got = _fwd_np(eng.forward(*args, filter_type="standard", mvn_const="exact"))
+    ref = kn.kalman_filter(*args, filter_type="standard", mvn_const="exact", partial_missing="delete")
+    assert np.all(np.abs(got["logp"] - ref["logp"]) <= 1e-8 * np.maximum(1.0, np.abs(ref["logp"]) / 1e4))
+    for k in ("filtered_states", "predicted_covs", "ll_obs"):
+        assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=k)
+    # per-draw series, one of them with a partially missing row
+    ys = np.repeat(w["y"][None], 10, 0)
+    ys[3, 11, 2] = np.nan
+    got = _fwd_np(eng.forward(ys, *[w[k] for k in KEYS], filter_type="cholesky", mvn_const="exact"))
+    for b in (0, 3, 9):
+        rb = kn.kalman_filter(ys[b], *[w[k][b:b + 1] for k in KEYS], filter_type="cholesky", mvn_const="exact",
+                              cholesky_triangle="correct", partial_missing="delete")
+        assert abs(got["logp"][b] - rb["logp"][0]) <= 1e-8 * max(1.0, abs(rb["logp"][0]) / 1e4)
+        assert_allclose(got["predicted_states"][b], rb["predicted_states"][0], rtol=1e-9, atol=1e-9)
+    # H not positive definite in one draw: the dense path's answer (F may still be PD: H only enters through F = Z P Z' + H)
+    w2 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in w.items()}
+    w2["H"][4] = 0.0
+    got = _fwd_np(eng.forward(w["y"], *[w2[k] for k in KEYS], filter_type="standard", mvn_const="exact"))
+    ref = kn.kalman_filter(w["y"], *[w2[k] for k in KEYS], filter_type="standard", mvn_const="exact")
+    assert np.all(np.abs(got["logp"] - ref["logp"]) <= 1e-8 * np.maximum(1.0, np.abs(ref["logp"]) / 1e4))
+    assert_allclose(got["filtered_covs"], ref["filtered_covs"], rtol=1e-9, atol=1e-9)

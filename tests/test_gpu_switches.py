@@ -60,6 +60,7 @@ FORWARD_CASES = [
     ("KF_B4Q_SPLIT", ("0",), lambda: W.varmax(B=64, n=200), {"h_diagonal": True}),
     ("KF_B4Q_GROUP", ("0",), lambda: W.varmax(B=64, n=200), {"h_diagonal": True}),
     ("KF_FORWARD_B4Q", ("0", "1"), lambda: W.varmax(B=64, n=120), {"h_diagonal": True}),
+    ("KF_FORWARD_WHITEN", ("0",), lambda: W.random_dense(B=64, n=100, p=5, m=15, r=5, seed=3, h_diag=False), {}),
     ("KF_BIG_FUSE", ("0",), lambda: W.random_dense(B=6, n=12, p=1, m=100, r=3, seed=5), {"store_filtered": False}),
     ("KF_FORWARD_WGL", ("0",), lambda: W.random_dense(B=6, n=12, p=1, m=70, r=3, seed=6),
      {"store_filtered": False, "store_predicted": False}),
