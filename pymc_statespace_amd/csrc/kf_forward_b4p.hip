@@ -134,7 +134,9 @@ __global__ __launch_bounds__(P_THREADS) __attribute__((amdgpu_waves_per_eu(B4P_W
     const bool univariate = A.filter == KF_FILTER_UNIVARIATE;
     const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;  // :335 quirk: y_hat = Z a - d
     const bool exact_const = (A.flags & KF_FLAG_MVN_CONST_EXACT) != 0;
-    const bool row0 = g == 0 && bq < N4;  // u lives in DPP row 0 (k = 0 of the rank-one MFMA)
+    // (round 4: u stays in DPP row 2, where row JA of the tile is -- the rank-one MFMA contracts over k = 2; the two v_permlane32_swap
+    // that brought it to row 0 sat on the step's dependency chain, which is all this kernel's step time is made of)
+    const bool row2 = g == 2 && bq < N4;
     // lanes of the unused block slot (bq >= N4: NB = 3) read zeros back, so that their registers stay zero
     const bool col_ok = bq < N4;
     const int tr_r = bq * TRS + 4 * g;
@@ -207,21 +209,20 @@ __global__ __launch_bounds__(P_THREADS) __attribute__((amdgpu_waves_per_eu(B4P_W
       double* UX = slot + L::TILE;
       const double2_t yo = *reinterpret_cast<const double2_t*>(YB + 2 * (t & (P_LB - 1)));  // {-2 (y -+ d), observed}
       // ---- update (kf_forward_b4.hip) ----------------------------------------------------------------------------------
-      const double raw = high_half_everywhere(P[NB - 1]);
-      double u = row0 ? raw : 0.0;
-      if (lane == JC) u += yo.x;  // u_JC = 2 Z a - 2 (y -+ d) = -2 v
-      if (g == 0) UX[fb] = u;
+      double u = row2 ? P[NB - 1] : 0.0;
+      if (lane == 32 + JC) u += yo.x;  // u_JC = 2 Z a - 2 (y -+ d) = -2 v
+      if (g == 2) UX[fb] = u;
       wave_lds_fence();
-      const double* ux_r = (g == 0) ? UX + 4 * (lane & 3) : UX + 16;
+      const double* ux_r = (g == 2) ? UX + 4 * (lane & 3) : UX + 16;
       const double2_t ur01 = *reinterpret_cast<const double2_t*>(ux_r);
       double2_t ur23 = {0.0, 0.0};
       if (NB > 2) ur23 = *reinterpret_cast<const double2_t*>(ux_r + 2);
       wave_lds_fence();
       const double urep[4] = {ur01.x, ur01.y, ur23.x, ur23.y};
-      const double F = H1 + readlane_f64(u, JA);
+      const double F = H1 + readlane_f64(u, 32 + JA);
       const double rs = fast_rsqrt(fmax(F, 1e-300)) * yo.y;
       const double uh = u * rs;
-      if (lane == JC) {
+      if (lane == 32 + JC) {
         double2_t fq = {F, uh};
         *reinterpret_cast<double2_t*>(RG + 2 * (t & (P_LB - 1))) = fq;
         UX[20] = rs;
