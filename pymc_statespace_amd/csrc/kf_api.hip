@@ -283,7 +283,13 @@ extern "C" const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_di
     return kf_forward_kernel_name_ws(h, &d2, workspace_bytes);
   }
   const bool row_ok = d->p == 1 && d->m <= KF_ROW_M_MAX;
-  if (d->flags & KF_FLAG_TV_ANY) return "kf_fwd_lds_kernel";
+  if (d->flags & KF_FLAG_TV_ANY) {
+    const char* e = kf_env_switch("KF_FORWARD_B4TV");
+    if ((h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_B4) && kf_forward_b4tv_ok(d->m, d->p, d->r, d->flags) &&
+        !(e && e[0] == '0'))
+      return "kf_fwd_b4tv_kernel";
+    return "kf_fwd_lds_kernel";
+  }
   if (kf_b4_selected(h, d->m, d->p, d->r, d->B)) return "kf_fwd_b4_kernel";
   if (kf_b4q_selected(h, d->m, d->p, d->r, d->filter, d->flags, d->B)) return "kf_fwd_b4q_kernel";
   if (kf_nb_ok(h, d->m, d->p, d->r, d->filter, d->flags)) return "kf_fwd_mfma_nb_kernel";
@@ -346,6 +352,12 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a_in, void* workspace, size
     if (((a.flags & KF_FLAG_TV_C) && !a.c) || ((a.flags & KF_FLAG_TV_D) && !a.d)) {
       KF_SET_ERR(h, "time-varying c / d flagged but the pointer is NULL");
       return KF_ERR_ARG;
+    }
+    // scalar observation, m <= 10, R and Q static: the block kernel with per-step slices (kf_fwd_b4tv_kernel); KF_FORWARD_B4TV=0 in
+    // the environment keeps the LDS kernel
+    if ((h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_B4) && kf_forward_b4tv_ok(a.m, a.p, a.r, a.flags)) {
+      const char* e = kf_env_switch("KF_FORWARD_B4TV");
+      if (!(e && e[0] == '0')) return kf_launch_forward_b4tv(h, a, stream);
     }
     if (!kf_forward_lds_fits(a.m, a.p)) {
       KF_SET_ERR(h, "time-varying system matrices need the LDS-resident kernel (m=%d p=%d too large)", a.m, a.p);

@@ -641,6 +641,265 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   }
 }
 
+
+// ---- time-varying system matrices on the block tiles (round 4) --------------------------------------------------------------------
+// Reference: a 3-D system matrix is a sequence, time on axis 0, and step t uses slice t for its update AND its predict
+// (filters/utilities.py:1-20, kalman_filter.py:79-124, 231-252).  Rounds 1-3 sent every KF_FLAG_TV_* call to the round-1 LDS kernel
+// (headline shape with a time-varying T: 12.9 ms = 0.10 of the HBM peak, profiles/r04/tv_dense_lines.txt).  This kernel is the block
+// kernel above with what a static model lets it hoist taken back into the step:
+//   * no "Z alpha" row in the tile (its entries would need Z_{t+1} T_t): u = S z_t is three MFMAs with z_t as a one-row left factor
+//     (DPP row 0 gets z' S; F = H_t + (z' S) z_t by a row sum), the rank-one update contracts over k = 0;
+//   * T_t's replicated left-factor blocks, z_t in both layouts and c_t are loaded per step -- each right AFTER its last use in the
+//     step, so the loads fly during the rest of it -- ; H_t and d_t come with the 32-step observation block;
+//   * R / Q stay static (a time-varying R Q R' is m^2 r + m r^2 products per step: those calls keep the LDS kernel), no steady-state
+//     phase, no tile tape.
+// Tapes through the same LDS rings, dead zones and absolute slot addresses as above.
+template <int NB>
+__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) void kf_fwd_b4tv_kernel(const KfFwdArgs A) {
+  constexpr int N4 = 4 * NB, JC = N4 - 1;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const int g = lane >> 4, bq = lane & 15, q = lane & 3;
+  const int fb = q * 4 + ((lane >> 2) & 3);
+  const long b = blockIdx.x;
+  const int n = A.T, m = A.m, mm = m * m, r_ = A.r;
+  const bool tvT = A.flags & KF_FLAG_TV_T, tvZ = A.flags & KF_FLAG_TV_Z, tvH = A.flags & KF_FLAG_TV_H;
+  const bool tvC = (A.flags & KF_FLAG_TV_C) && A.c, tvD = (A.flags & KF_FLAG_TV_D) && A.d;
+  if (lds_addr(smem) & (unsigned)(8 * RING_P - 1)) __builtin_trap();
+  double* TR = smem + B4_OFF_TR;
+  double* UX = smem + B4_OFF_UX;
+  double* RG = smem + B4_OFF_RG;
+  double* YB = smem + B4_OFF_YB;
+  double* HB = smem + B4_OFF_DUMP;  // LB entries of H_t in the first half of the dump slots; the second half takes the u exchange of rows 1 .. 3
+  for (int e = lane; e < B4_LOOP_DOUBLES; e += KF_WAVE) smem[e] = 0.0;
+  wave_lds_fence();
+
+  // ---- per-draw constants and the first slices -------------------------------------------------------------------------------------
+  const double* gT = A.Tm + (tvT ? b * (long)n : b) * mm;   // slice 0
+  const double* gZ = A.Z + (tvZ ? b * (long)n : b) * m;
+  const double* gc = A.c ? A.c + (tvC ? b * (long)n : b) * m : nullptr;
+  const double* gR = A.R + b * (long)m * r_;
+  const double* gQ = A.Q + b * (long)r_ * r_;
+  const double* gP = A.P0 + b * (long)mm;
+  double Ta[NB][NB], zA[NB], Ch[NB], P[NB];
+  bool on[NB], cJ[NB];        // the m x m block; the carrier entries (row < m, column JC) and (row JC, column < m)
+  int cidx[NB];               // ... and which entry of c they take
+  auto load_T = [&](const double* Tt) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int K = 0; K < NB; ++K) {
+        const int ti = 4 * I + q, tk = 4 * K + g;
+        Ta[I][K] = (ti < m && tk < m) ? Tt[ti * m + tk] : ((ti == JC && tk == JC) ? 1.0 : 0.0);
+      }
+  };
+  auto load_z = [&](const double* zt, double& zc) {
+#pragma unroll
+    for (int K = 0; K < NB; ++K) zA[K] = (q == 0 && 4 * K + g < m) ? zt[4 * K + g] : 0.0;   // one-row left factor
+    zc = (g == 0 && bq < m) ? zt[bq] : 0.0;                                                  // row-0 layout
+  };
+  double zc;
+  load_T(gT);
+  load_z(gZ, zc);
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    const int rr = 4 * I + g;
+    on[I] = rr < m && bq < m;
+    cJ[I] = (rr < m && bq == JC) || (rr == JC && bq < m);
+    cidx[I] = rr < m ? rr : (bq < m ? bq : 0);
+    double cv = 0.0, pv = 0.0;
+    if (on[I]) {
+      double s1 = 0.0, s2 = 0.0;   // R Q R' at (rr, bq) and at (bq, rr): their mean is bitwise symmetric across the mirrored lanes
+      for (int l = 0; l < r_; ++l) {
+        double rq1 = 0.0, rq2 = 0.0;
+        for (int k = 0; k < r_; ++k) {
+          rq1 += gR[rr * r_ + k] * gQ[k * r_ + l];
+          rq2 += gR[bq * r_ + k] * gQ[k * r_ + l];
+        }
+        s1 += rq1 * gR[bq * r_ + l];
+        s2 += rq2 * gR[rr * r_ + l];
+      }
+      cv = 0.5 * (s1 + s2);
+      pv = (bq >= rr) ? gP[rr * m + bq] : gP[bq * m + rr];
+    } else if (cJ[I]) {
+      pv = 2.0 * A.a0[b * (long)m + cidx[I]];
+    }
+    Ch[I] = (cJ[I] && gc) ? 2.0 * gc[cidx[I]] : cv;   // C_t: R Q R' on the state block, 2 c_t on the carrier entries (disjoint lanes)
+    P[I] = pv;
+  }
+
+  double H1 = tvH ? 0.0 : A.H[b];
+  const double d1 = (A.d && !tvD) ? A.d[b] : 0.0;
+  const bool univariate = A.filter == KF_FILTER_UNIVARIATE;
+  const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;  // :335 quirk: y_hat = Z a - d
+  const bool exact_const = (A.flags & KF_FLAG_MVN_CONST_EXACT) != 0;
+  double* ux_w = (g == 0) ? UX + fb : smem + B4_OFF_DUMP + 32 + (lane & 31);   // (rows 1 .. 3: dump slots)
+  const double* ux_r = (g == 0) ? UX + 4 * q : UX + 16;
+  const bool vec_on = g == 3 && bq < m;   // row JC of the tile = 2 a'
+
+  double* t_fa = A.filt_a ? A.filt_a + b * (long)n * m : nullptr;
+  double* t_pa = A.pred_a ? A.pred_a + b * (long)(n + 1) * m : nullptr;
+  double* t_fP = A.filt_P ? A.filt_P + b * (long)n * mm : nullptr;
+  double* t_pP = A.pred_P ? A.pred_P + b * (long)(n + 1) * mm : nullptr;
+  const bool w_fa = t_fa != nullptr, w_pa = t_pa != nullptr, w_fP = t_fP != nullptr, w_pP = t_pP != nullptr;
+  TapeStream<RING_A, GRAN_A> s_fa, s_pa;
+  s_fa.init(t_fa, smem + B4_OFF_RA);
+  s_pa.init(t_pa, smem + B4_OFF_RA + RING_A);
+  const int ka = vec_on ? bq : m + (lane & 31);
+  unsigned o_fa = s_fa.slot_abs(ka), o_pa = s_pa.slot_abs(ka);
+  auto put_a = [&](TapeStream<RING_A, GRAN_A>& st, unsigned& off, double twice_a) {
+    lds_store_f64(off, twice_a);
+    off = TapeStream<RING_A, GRAN_A>::next_abs(off, m);
+    st.appended(m, lane, 0.5);
+  };
+  TapeStream<RING_P, GRAN_P> s_fP, s_pP;
+  s_fP.init(t_fP, smem + B4_OFF_RP);
+  s_pP.init(t_pP, smem + B4_OFF_RP + RING_P);
+  unsigned o_fP[NB], o_pP[NB];
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    const int dz = GRAN_P - mm > 0 ? GRAN_P - mm : 1;
+    const int kp = on[I] ? (4 * I + g) * m + bq : mm + (lane % dz);
+    o_fP[I] = s_fP.slot_abs(kp);
+    o_pP[I] = s_pP.slot_abs(kp);
+  }
+  auto put_P = [&](TapeStream<RING_P, GRAN_P>& st, unsigned (&off)[NB], const double (&Preg)[NB]) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      lds_store_f64(off[I], Preg[I]);
+      off[I] = TapeStream<RING_P, GRAN_P>::next_abs(off[I], mm);
+    }
+    st.appended(mm, lane, 1.0);
+  };
+  if (w_pa) put_a(s_pa, o_pa, P[NB - 1]);
+  if (w_pP) {
+    double P0g[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) P0g[I] = on[I] ? gP[(4 * I + g) * m + bq] : 0.0;   // slot 0 = the caller's P0 as given
+    put_P(s_pP, o_pP, P0g);
+  }
+  auto transpose_tile = [&](const double (&X)[NB], double (&Xt)[NB]) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I) TR[(4 * I + g) * TRS + fb] = X[I];
+    wave_lds_fence();
+    const double* src = TR + bq * TRS + 4 * g;
+    const double2_t t01 = *reinterpret_cast<const double2_t*>(src);
+    double2_t t23 = {0.0, 0.0};
+    if (NB > 2) t23 = *reinterpret_cast<const double2_t*>(src + 2);
+    wave_lds_fence();
+    Xt[0] = t01.x;
+    if (NB > 1) Xt[NB > 1 ? 1 : 0] = t01.y;
+    if (NB > 2) Xt[NB > 2 ? 2 : 0] = t23.x;
+  };
+  double logp = 0.0;
+  int info = 0;
+  auto flush_ring = [&](int tb, int cnt) {
+    __syncthreads();
+    const int ls = lane & (LB - 1);
+    const double2_t fq = *reinterpret_cast<const double2_t*>(RG + 2 * ls);
+    const bool act = lane < cnt;
+    const bool observed = act && YB[2 * ls + 1] != 0.0;
+    const double Fv = fq.x;
+    const bool skipped = observed && univariate && Fv == 0.0;      // :468-471
+    const bool notpd = observed && !skipped && !(Fv > 0.0);
+    const unsigned long long bad = __ballot(notpd);
+    if (bad != 0ull && info == 0) info = ((tb + __ffsll((long long)bad)) << 8) | 1;
+    const double quad = 0.25 * fq.y * fq.y;                          // v^2 / F
+    double llv;
+    if (!observed) llv = 0.0;
+    else if (skipped) llv = exact_const ? -0.5 * KF_LOG_2PI : 0.0;
+    else if (univariate && !exact_const && Fv == 1.0 && quad == 0.0) llv = 0.0;  // :497-500
+    else llv = -0.5 * (KF_LOG_2PI + log(Fv) + quad);
+    if (act && A.ll_obs) st_stream(A.ll_obs + b * (long)n + tb + lane, llv);
+    logp += col_allsum(row_allsum(llv));
+    __syncthreads();
+  };
+  const double* ybase = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n : 0L);
+  auto load_y_block = [&](int t) {
+    const int cnt = (n - t) < LB ? (n - t) : LB;
+    if (lane < cnt) {
+      const double yv = ybase[(long)t + lane];
+      const double dv = tvD ? A.d[b * (long)n + t + lane] : d1;
+      const bool ob = !(yv != yv);
+      double2_t e = {ob ? -2.0 * (yv + dsign * dv) : 0.0, ob ? 1.0 : 0.0};
+      *reinterpret_cast<double2_t*>(YB + 2 * lane) = e;
+      if (tvH) HB[lane] = A.H[b * (long)n + t + lane];
+    }
+    wave_lds_fence();
+  };
+
+  for (int t = 0; t < n; ++t) {
+    if ((t & (LB - 1)) == 0) load_y_block(t);
+    const double2_t yo = *reinterpret_cast<const double2_t*>(YB + 2 * (t & (LB - 1)));  // {-2 (y -+ d_t), observed}
+    if (tvH) H1 = HB[t & (LB - 1)];
+    // ---- update: u = S z_t (z' S in DPP row 0), F = H_t + z' S z ------------------------------------------------------------------
+    double rrow = mfma4(zA[0], P[0], 0.0);
+#pragma unroll
+    for (int K = 1; K < NB; ++K) rrow = mfma4(zA[K], P[K], rrow);
+    const double uA = readlane_f64(row_allsum(rrow * zc), 0);
+    const long tn = (t + 1 < n) ? t + 1 : t;        // (the slices of the next step: loaded behind their last use in this one)
+    if (tvZ) load_z(A.Z + (b * (long)n + tn) * m, zc);
+    const double u = rrow + ((lane == JC) ? yo.x : 0.0);  // u_JC = 2 z a - 2 (y -+ d) = -2 v   (rows 1 .. 3 of rrow are exact zeros)
+    *ux_w = u;
+    wave_lds_fence();
+    const double2_t ur01 = *reinterpret_cast<const double2_t*>(ux_r);
+    double2_t ur23 = {0.0, 0.0};
+    if (NB > 2) ur23 = *reinterpret_cast<const double2_t*>(ux_r + 2);
+    wave_lds_fence();
+    const double urep[4] = {ur01.x, ur01.y, ur23.x, ur23.y};
+    const double F = H1 + uA;
+    const double rs = fast_rsqrt(fmax(F, 1e-300)) * yo.y;
+    const double uh = u * rs;
+    if (lane == JC) {
+      double2_t fq = {F, uh};
+      *reinterpret_cast<double2_t*>(RG + 2 * (t & (LB - 1))) = fq;
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) P[I] = mfma4_nega(urep[I] * rs, uh, P[I]);
+    if (w_fa) put_a(s_fa, o_fa, P[NB - 1]);
+    if (w_fP) put_P(s_fP, o_fP, P);
+    // ---- predict: tile <- sym(T_t tile T_t' + C_t) -----------------------------------------------------------------------------------
+    double U[NB], Y[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) U[I] = mfma4(Ta[I][0], P[0], 0.0);
+#pragma unroll
+    for (int K = 1; K < NB; ++K)
+#pragma unroll
+      for (int I = 0; I < NB; ++I) U[I] = mfma4(Ta[I][K], P[K], U[I]);
+    transpose_tile(U, U);
+#pragma unroll
+    for (int I = 0; I < NB; ++I) Y[I] = Ch[I];
+#pragma unroll
+    for (int K = 0; K < NB; ++K)
+#pragma unroll
+      for (int I = 0; I < NB; ++I) Y[I] = mfma4(Ta[I][K], U[K], Y[I]);
+    if (tvT) load_T(A.Tm + (b * (long)n + tn) * mm);
+    if (tvC) {
+      const double* ct = A.c + (b * (long)n + tn) * m;
+#pragma unroll
+      for (int I = 0; I < NB; ++I) Ch[I] = cJ[I] ? 2.0 * ct[cidx[I]] : Ch[I];
+    }
+    {
+      double Yt[NB];
+      transpose_tile(Y, Yt);
+#pragma unroll
+      for (int I = 0; I < NB; ++I) P[I] = 0.5 * (Y[I] + Yt[I]);
+    }
+    if (w_pa) put_a(s_pa, o_pa, P[NB - 1]);
+    if (w_pP) put_P(s_pP, o_pP, P);
+    if ((t & (LB - 1)) == LB - 1) flush_ring(t - (LB - 1), LB);
+  }
+  s_fa.finish(lane, 0.5);
+  s_pa.finish(lane, 0.5);
+  s_fP.finish(lane, 1.0);
+  s_pP.finish(lane, 1.0);
+  if (n & (LB - 1)) flush_ring(n & ~(LB - 1), n & (LB - 1));
+  if (lane == 0) {
+    A.logp[b] = logp;
+    if (A.info) A.info[b] = info;
+  }
+}
+
 }  // namespace
 
 bool kf_forward_b4_ok(int m, int p, int r) { return p == 1 && m >= 1 && m + 2 <= 16 && r >= 1 && r <= 64; }
@@ -799,6 +1058,29 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size
   }
 #undef KF_B4_LAUNCH2
 #undef KF_B4_LAUNCH
+  KF_HIP_CHECK(h, hipGetLastError());
+  return KF_OK;
+}
+
+
+// time-varying T / Z / H / c / d on the block tiles: p == 1, m <= 10 (the tape rings), R and Q static
+bool kf_forward_b4tv_ok(int m, int p, int r, unsigned flags) {
+  if (!(flags & KF_FLAG_TV_ANY) || (flags & (KF_FLAG_TV_R | KF_FLAG_TV_Q))) return false;
+  return p == 1 && m >= 1 && m <= 10 && r >= 1 && r <= 64;
+}
+
+int kf_launch_forward_b4tv(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
+  if (!kf_forward_b4tv_ok(a.m, a.p, a.r, a.flags) || a.tile_tape) {
+    KF_SET_ERR(h, "forward(b4tv): needs p == 1, m <= 10, time-varying T / Z / H / c / d only (got p=%d m=%d flags=%#x)", a.p, a.m, a.flags);
+    return KF_ERR_UNSUPPORTED;
+  }
+  const size_t lds = sizeof(double) * (size_t)B4_LOOP_DOUBLES;
+  const int nb = (a.m + 2 + 3) / 4;
+  switch (nb) {
+    case 1: hipLaunchKernelGGL((kf_fwd_b4tv_kernel<1>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); break;
+    case 2: hipLaunchKernelGGL((kf_fwd_b4tv_kernel<2>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); break;
+    default: hipLaunchKernelGGL((kf_fwd_b4tv_kernel<3>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); break;
+  }
   KF_HIP_CHECK(h, hipGetLastError());
   return KF_OK;
 }

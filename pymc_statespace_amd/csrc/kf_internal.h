@@ -214,6 +214,9 @@ int kf_launch_forward_mfma(kf_handle* h, const KfFwdArgs& a, hipStream_t stream)
 // 4x4x4-block kernel (kf_forward_b4.hip): v_mfma_f64_4x4x4_4b_f64, p == 1, m <= 14, mean carried in the tile
 bool kf_forward_b4_ok(int m, int p, int r);
 int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream);
+// time-varying T / Z / H / c / d on the block tiles (kf_forward_b4.hip, kf_fwd_b4tv_kernel)
+bool kf_forward_b4tv_ok(int m, int p, int r, unsigned flags);
+int kf_launch_forward_b4tv(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
 // recursion + tape-writer wavefront per draw (kf_forward_b4p.hip)
 bool kf_forward_b4p_ok(int m, int p, int r);
 int kf_launch_forward_b4p(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);

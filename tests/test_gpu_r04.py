@@ -246,3 +246,83 @@ def test_dense_H_falls_back_where_whitening_does_not_apply(eng):
     ref = kn.kalman_filter(w["y"], *[w2[k] for k in KEYS], filter_type="standard", mvn_const="exact")
     assert np.all(np.abs(got["logp"] - ref["logp"]) <= 1e-8 * np.maximum(1.0, np.abs(ref["logp"]) / 1e4))
     assert_allclose(got["filtered_covs"], ref["filtered_covs"], rtol=1e-9, atol=1e-9)
+
+
+# ----------------------------------------------------------------------------------------------
+# time-varying T / Z / H / c / d on the block tiles (csrc/kf_forward_b4.hip: kf_fwd_b4tv_kernel)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ft", ["standard", "cholesky", "univariate", "single"])
+@pytest.mark.parametrize("tv", [("T",), ("Z",), ("H", "d"), ("c",), ("T", "Z", "H", "c", "d")])
+@pytest.mark.parametrize("m", [1, 2, 3, 6, 7, 10])
+def test_time_varying_block_kernel_matches_oracle(eng, monkeypatch, ft, tv, m):
+    """Reference: 3-D system matrices, time on axis 0, slice t used by the update AND the predict of step t
+    (filters/utilities.py:1-20, kalman_filter.py:79-124, 231-252).  p = 1, m <= 10, R / Q static: the block kernel with per-step
+    slices, against the numpy oracle (1e-8 on logp, 1e-9 on the tapes) and against the LDS kernel it replaces; missing observations,
+    static intercepts beside time-varying ones, partial tape requests."""
+    from oracle import kalman_numpy as kn
+
+    B, n, r = 9, 70, max(1, m // 2)
+    w = W.random_dense(B, n, 1, m, r, seed=900 + m)
+    rng = np.random.default_rng(m)
+    mats = dict(T=w["T"], Z=w["Z"], R=w["R"], H=w["H"], Q=w["Q"],
+                c=0.1 * rng.standard_normal((B, m)), d=0.1 * rng.standard_normal((B, 1)))
+    for name in tv:
+        x = np.repeat(mats[name][:, None], n, axis=1)
+        wob = 0.8 + 0.2 * np.cos(0.37 * np.arange(n) + len(name))
+        mats[name] = x * wob.reshape((1, n) + (1,) * (x.ndim - 2))
+        if name in ("Z", "c", "d"):
+            mats[name] = mats[name] + 0.05 * rng.standard_normal(mats[name].shape)
+    y = w["y"].copy()
+    y[[4, 33, 34]] = np.nan
+    args = (y, w["a0"], w["P0"], mats["T"], mats["Z"], mats["R"], mats["H"], mats["Q"], mats["c"], mats["d"])
+    assert eng.forward_kernel_name(B, n, 1, m, r, filter_type=ft, time_varying=tv) == "kf_fwd_b4tv_kernel"
+    res = eng.forward(*args, filter_type=ft, mvn_const="exact", time_varying=tv)
+    got = _fwd_np(res)
+    ref = kn.kalman_filter_time_varying(*args, time_varying=tv, filter_type=ft, mvn_const="exact")
+    monkeypatch.setenv("KF_FORWARD_B4TV", "0")
+    assert eng.forward_kernel_name(B, n, 1, m, r, filter_type=ft, time_varying=tv) == "kf_fwd_lds_kernel"
+    lds = _fwd_np(eng.forward(*args, filter_type=ft, mvn_const="exact", time_varying=tv))
+    monkeypatch.delenv("KF_FORWARD_B4TV")
+    assert not got["info"].any()
+    for other, tag in ((ref, "oracle"), (lds, "lds kernel")):
+        assert np.max(np.abs(got["logp"] - other["logp"])) < 1e-8, tag
+        for k in ("filtered_states", "predicted_states", "filtered_covs", "predicted_covs", "ll_obs"):
+            assert_allclose(got[k], other[k], rtol=1e-9, atol=1e-9, err_msg=f"{tag} {k}")
+    # logp only / predicted tapes only: the same numbers
+    lo = eng.forward(*args, filter_type=ft, mvn_const="exact", time_varying=tv, store_ll_obs=False, store_filtered=False,
+                     store_predicted=False)
+    assert np.array_equal(lo.logp.cpu().numpy(), got["logp"])
+    po = eng.forward(*args, filter_type=ft, mvn_const="exact", time_varying=tv, store_filtered=False)
+    assert np.array_equal(po.predicted_covs.cpu().numpy(), got["predicted_covs"])
+
+
+def test_time_varying_block_kernel_edges(eng):
+    """One step, one draw, a batch beyond the chip's wavefront slots, a series that is not a multiple of the 32-step block, per-draw
+    data, F <= 0 flagged; R / Q time-varying keeps the LDS kernel."""
+    from oracle import kalman_numpy as kn
+
+    for B, n, m in ((1, 1, 4), (1, 33, 10), (5000, 40, 5), (3, 97, 9)):
+        w = W.random_dense(B, n, 1, m, 2, seed=B + n)
+        Tt = np.repeat(w["T"][:, None], n, axis=1) * (0.9 + 0.1 * np.cos(np.arange(n)))[None, :, None, None]
+        args = (w["y"], w["a0"], w["P0"], Tt, w["Z"], w["R"], w["H"], w["Q"])
+        res = eng.forward(*args, mvn_const="exact", time_varying=("T",))
+        k = min(B, 6)
+        ref = kn.kalman_filter_time_varying(w["y"], *[a[:k] for a in args[1:]], time_varying=("T",), mvn_const="exact")
+        assert np.max(np.abs(res.logp.cpu().numpy()[:k] - ref["logp"])) < 1e-8
+        assert_allclose(res.predicted_covs.cpu().numpy()[:k], ref["predicted_covs"], rtol=1e-9, atol=1e-9)
+        assert_allclose(res.filtered_states.cpu().numpy()[:k], ref["filtered_states"], rtol=1e-9, atol=1e-9)
+    w = W.random_dense(4, 50, 1, 6, 2, seed=3)
+    ys = np.repeat(w["y"][None], 4, 0) + 0.1 * np.random.default_rng(0).standard_normal((4, 50, 1))
+    Zt = np.repeat(w["Z"][:, None], 50, axis=1) * (1.0 + 0.1 * np.sin(np.arange(50)))[None, :, None, None]
+    res = eng.forward(ys, w["a0"], w["P0"], w["T"], Zt, w["R"], w["H"], w["Q"], mvn_const="exact", time_varying=("Z",))
+    for b in range(4):
+        ref = kn.kalman_filter_time_varying(ys[b], *[w[k][b:b + 1] for k in ("a0", "P0", "T")], Zt[b:b + 1],
+                                            *[w[k][b:b + 1] for k in ("R", "H", "Q")], time_varying=("Z",), mvn_const="exact")
+        assert abs(res.logp[b].item() - ref["logp"][0]) < 1e-8
+    Hneg = w["H"].copy()
+    Hneg[2] = -50.0
+    res = eng.forward(w["y"], w["a0"], w["P0"], np.repeat(w["T"][:, None], 50, axis=1), w["Z"], w["R"], Hneg, w["Q"],
+                      mvn_const="exact", time_varying=("T",))
+    info = res.info.cpu().numpy()
+    assert info[2] != 0 and not info[[0, 1, 3]].any()
+    assert eng.forward_kernel_name(4, 50, 1, 6, 2, time_varying=("T", "Q")) == "kf_fwd_lds_kernel"

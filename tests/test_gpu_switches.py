@@ -31,7 +31,11 @@ def _args(w):
 
 
 def _fwd(eng, w, **kw):
-    res = eng.forward(*_args(w), mvn_const="exact", **kw)
+    args = list(_args(w))
+    for nm in kw.get("time_varying", ()):   # the named matrix repeated along a time axis (same values: equals the static run)
+        i = 1 + KEYS.index(nm)
+        args[i] = np.repeat(args[i][:, None], w["n"], axis=1)
+    res = eng.forward(*args, mvn_const="exact", **kw)
     out = {"logp": res.logp.cpu().numpy(), "info": res.info.cpu().numpy()}
     for k in TAPES:
         v = getattr(res, k)
@@ -60,6 +64,7 @@ FORWARD_CASES = [
     ("KF_B4Q_SPLIT", ("0",), lambda: W.varmax(B=64, n=200), {"h_diagonal": True}),
     ("KF_B4Q_GROUP", ("0",), lambda: W.varmax(B=64, n=200), {"h_diagonal": True}),
     ("KF_FORWARD_B4Q", ("0", "1"), lambda: W.varmax(B=64, n=120), {"h_diagonal": True}),
+    ("KF_FORWARD_B4TV", ("0",), lambda: W.structural(B=64, n=120), {"time_varying": ("T",)}),
     ("KF_FORWARD_WHITEN", ("0",), lambda: W.random_dense(B=64, n=100, p=5, m=15, r=5, seed=3, h_diag=False), {}),
     ("KF_BIG_FUSE", ("0",), lambda: W.random_dense(B=6, n=12, p=1, m=100, r=3, seed=5), {"store_filtered": False}),
     ("KF_FORWARD_WGL", ("0",), lambda: W.random_dense(B=6, n=12, p=1, m=70, r=3, seed=6),
