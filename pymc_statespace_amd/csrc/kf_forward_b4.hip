@@ -654,7 +654,9 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
 //   * R / Q stay static (a time-varying R Q R' is m^2 r + m r^2 products per step: those calls keep the LDS kernel), no steady-state
 //     phase, no tile tape.
 // Tapes through the same LDS rings, dead zones and absolute slot addresses as above.
-template <int NB>
+// TVM: the flags this instantiation may meet (a superset of the call's): code for the others is not compiled in -- with all five
+// paths in one body the compiler kept 25 pointers and 9 lane masks live and spilled them (40 v_readlane per step)
+template <int NB, unsigned TVM>
 __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) void kf_fwd_b4tv_kernel(const KfFwdArgs A) {
   constexpr int N4 = 4 * NB, JC = N4 - 1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -663,8 +665,9 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   const int fb = q * 4 + ((lane >> 2) & 3);
   const long b = blockIdx.x;
   const int n = A.T, m = A.m, mm = m * m, r_ = A.r;
-  const bool tvT = A.flags & KF_FLAG_TV_T, tvZ = A.flags & KF_FLAG_TV_Z, tvH = A.flags & KF_FLAG_TV_H;
-  const bool tvC = (A.flags & KF_FLAG_TV_C) && A.c, tvD = (A.flags & KF_FLAG_TV_D) && A.d;
+  const bool tvT = (TVM & KF_FLAG_TV_T) && (A.flags & KF_FLAG_TV_T), tvZ = (TVM & KF_FLAG_TV_Z) && (A.flags & KF_FLAG_TV_Z);
+  const bool tvH = (TVM & KF_FLAG_TV_H) && (A.flags & KF_FLAG_TV_H);
+  const bool tvC = (TVM & KF_FLAG_TV_C) && (A.flags & KF_FLAG_TV_C) && A.c, tvD = (TVM & KF_FLAG_TV_D) && (A.flags & KF_FLAG_TV_D) && A.d;
   if (lds_addr(smem) & (unsigned)(8 * RING_P - 1)) __builtin_trap();
   double* TR = smem + B4_OFF_TR;
   double* UX = smem + B4_OFF_UX;
@@ -684,13 +687,23 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   double Ta[NB][NB], zA[NB], Ch[NB], P[NB];
   bool on[NB], cJ[NB];        // the m x m block; the carrier entries (row < m, column JC) and (row JC, column < m)
   int cidx[NB];               // ... and which entry of c they take
+  // T_t's block (I, K) is a wave-uniform base plus ONE lane offset (q m + g): scalar base + 32-bit vector offset loads; the lane
+  // masks are three row and three column predicates
+  const int t_lo = q * m + g;
+  bool rowok[NB], colok[NB];
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    rowok[I] = 4 * I + q < m;
+    colok[I] = 4 * I + g < m;
+  }
   auto load_T = [&](const double* Tt) {
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
       for (int K = 0; K < NB; ++K) {
-        const int ti = 4 * I + q, tk = 4 * K + g;
-        Ta[I][K] = (ti < m && tk < m) ? Tt[ti * m + tk] : ((ti == JC && tk == JC) ? 1.0 : 0.0);
+        const double* blk = Tt + (4 * I * m + 4 * K);
+        const double fix = (I == NB - 1 && K == NB - 1 && q == 3 && g == 3) ? 1.0 : 0.0;   // T_ext[JC][JC] = 1
+        Ta[I][K] = (rowok[I] && colok[K]) ? blk[t_lo] : fix;
       }
   };
   auto load_z = [&](const double* zt, double& zc) {
@@ -828,10 +841,20 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     wave_lds_fence();
   };
 
+  // T_{t+2} is pulled towards the L2 one step before its loads are issued: one 8-byte load per 64-byte line by the first lanes, its
+  // value consumed a whole step later (so nothing ever waits for it): the real loads of T_{t+1}, issued late in step t and needed
+  // early in step t + 1, then find their lines on the way instead of starting a full HBM round trip
+  double pf_prev = 0.0, pf_sum = 0.0;
+  const bool pf_lane = tvT && lane * 8 < mm;
   for (int t = 0; t < n; ++t) {
     if ((t & (LB - 1)) == 0) load_y_block(t);
     const double2_t yo = *reinterpret_cast<const double2_t*>(YB + 2 * (t & (LB - 1)));  // {-2 (y -+ d_t), observed}
     if (tvH) H1 = HB[t & (LB - 1)];
+    if (TVM & KF_FLAG_TV_T) {
+      pf_sum += pf_prev;
+      const long t2 = (t + 2 < n) ? t + 2 : t;
+      pf_prev = pf_lane ? A.Tm[(b * (long)n + t2) * mm + lane * 8] : 0.0;
+    }
     // ---- update: u = S z_t (z' S in DPP row 0), F = H_t + z' S z ------------------------------------------------------------------
     double rrow = mfma4(zA[0], P[0], 0.0);
 #pragma unroll
@@ -895,7 +918,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   s_pP.finish(lane, 1.0);
   if (n & (LB - 1)) flush_ring(n & ~(LB - 1), n & (LB - 1));
   if (lane == 0) {
-    A.logp[b] = logp;
+    A.logp[b] = (pf_sum + pf_prev == 1.2345e300) ? 0.0 : logp;   // (keeps the prefetch loads alive; never true for finite T)
     if (A.info) A.info[b] = info;
   }
 }
@@ -1076,11 +1099,21 @@ int kf_launch_forward_b4tv(kf_handle* h, const KfFwdArgs& a, hipStream_t stream)
   }
   const size_t lds = sizeof(double) * (size_t)B4_LOOP_DOUBLES;
   const int nb = (a.m + 2 + 3) / 4;
+  constexpr unsigned M_T = KF_FLAG_TV_T, M_TZ = KF_FLAG_TV_T | KF_FLAG_TV_Z,
+                     M_ALL = KF_FLAG_TV_T | KF_FLAG_TV_Z | KF_FLAG_TV_H | KF_FLAG_TV_C | KF_FLAG_TV_D;
+  const unsigned tvf = a.flags & KF_FLAG_TV_ANY;
+#define KF_TV_LAUNCH(NB_)                                                                                                   \
+  do {                                                                                                                      \
+    if (!(tvf & ~M_T)) hipLaunchKernelGGL((kf_fwd_b4tv_kernel<NB_, M_T>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);          \
+    else if (!(tvf & ~M_TZ)) hipLaunchKernelGGL((kf_fwd_b4tv_kernel<NB_, M_TZ>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);   \
+    else hipLaunchKernelGGL((kf_fwd_b4tv_kernel<NB_, M_ALL>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);                       \
+  } while (0)
   switch (nb) {
-    case 1: hipLaunchKernelGGL((kf_fwd_b4tv_kernel<1>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); break;
-    case 2: hipLaunchKernelGGL((kf_fwd_b4tv_kernel<2>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); break;
-    default: hipLaunchKernelGGL((kf_fwd_b4tv_kernel<3>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); break;
+    case 1: KF_TV_LAUNCH(1); break;
+    case 2: KF_TV_LAUNCH(2); break;
+    default: KF_TV_LAUNCH(3); break;
   }
+#undef KF_TV_LAUNCH
   KF_HIP_CHECK(h, hipGetLastError());
   return KF_OK;
 }
