@@ -354,8 +354,18 @@ def kalman_filter_time_varying(data, a0, P0, T, Z, R, H, Q, c=None, d=None, time
     Hm = _split_time_varying(H, "H", tv, 2)
     Qm = _split_time_varying(Q, "Q", tv, 2)
     p = Zm.shape[-2]
-    cm = np.zeros((1, 1, m)) if c is None else _split_time_varying(np.asarray(c).reshape(np.asarray(c).shape[:-1]) if np.asarray(c).shape[-1] == 1 and np.asarray(c).ndim > 1 and np.asarray(c).shape[-2] == m else c, "c", tv, 1)
-    dm = np.zeros((1, 1, p)) if d is None else _split_time_varying(np.asarray(d).reshape(np.asarray(d).shape[:-1]) if np.asarray(d).shape[-1] == 1 and np.asarray(d).ndim > 1 and np.asarray(d).shape[-2] == p else d, "d", tv, 1)
+    def _vec(x, name, dim):
+        """(.., dim, 1) columns -> (.., dim); a batched time-varying vector given as (B, n, dim) is taken as it is (at dim == 1 its
+        trailing axis is not a column axis: round-4 fuzz, n = m = 1)."""
+        x = np.asarray(x, dtype=np.float64)
+        if name in tv and batched and x.shape == (B, n, dim):
+            return x
+        if x.shape[-1] == 1 and x.ndim > 1 and x.shape[-2] == dim:
+            return x.reshape(x.shape[:-1])
+        return x
+
+    cm = np.zeros((1, 1, m)) if c is None else _split_time_varying(_vec(c, "c", m), "c", tv, 1)
+    dm = np.zeros((1, 1, p)) if d is None else _split_time_varying(_vec(d, "d", p), "d", tv, 1)
 
     def at(x, t):
         xt = x[:, t if x.shape[1] > 1 else 0]
