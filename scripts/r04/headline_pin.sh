@@ -25,7 +25,7 @@ leg() {  # leg <name> <command...>: clocks before, sampled during (max / mean re
   local P=$!
   "$@"
   kill $P 2>/dev/null; wait $P 2>/dev/null
-  awk -v n="$name" '{s+=$4; if($4>mx)mx=$4; pw+=$9; if($9>pmx)pmx=$9; c++} END{if(c)printf "[clk] %s during: %d samples, sclk mean %.0f max %.0f MHz, power mean %.0f max %.0f W (incl. process start-up at idle clocks)\n", n, c, s/c, mx, pw/c, pmx}' $O/poll_$name.txt >> $O/clocks.txt
+  awk -v n="$name" '{s+=$5; if($5>mx)mx=$5; pw+=$11; if($11>pmx)pmx=$11; c++} END{if(c)printf "[clk] %s during: %d samples, sclk mean %.0f max %.0f MHz, power mean %.0f max %.0f W (incl. process start-up at idle clocks)\n", n, c, s/c, mx, pw/c, pmx}' $O/poll_$name.txt >> $O/clocks.txt
   clk "$name after" >> $O/clocks.txt
 }
 : > $O/clocks.txt
