@@ -618,7 +618,8 @@ def main():
         if world == 1 and not big and not args.no_ops:
             # the other entry points on the same resident inputs, AFTER and outside the timed region (not part of `value`):
             # log-likelihood only, logp + gradient in one call (kf_filter_value_and_grad), RTS smoother over the filtered tapes
-            def _ms(fn, reps=5):
+            def _ms(fn, reps=10):
+                fn()
                 fn()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -639,6 +640,9 @@ def main():
                     # the same with the adjoint of the recursion at every step (KF_FLAG_EXACT_RECURSION: no steady-state adjoint)
                     ops["logp_and_gradient_exact_recursion_ms"] = _ms(lambda: eng.value_and_grad(
                         *d, filter_type=ft, mvn_const="exact", h_diagonal=not args.dense_h, exact_recursion=True))
+                    # ... and with the steady-state adjoint requested (KF_FLAG_STEADY_STATE), whatever AUTO picked above
+                    ops["logp_and_gradient_steady_state_ms"] = _ms(lambda: eng.value_and_grad(
+                        *d, filter_type=ft, mvn_const="exact", h_diagonal=not args.dense_h, exact_recursion=False))
                 # the timed call runs the library's default; the same call with the covariance recursion forced at every
                 # step (KF_FLAG_EXACT_RECURSION) and with the steady-state phase requested (KF_FLAG_STEADY_STATE), and how far
                 # the three log-likelihood vectors are apart
