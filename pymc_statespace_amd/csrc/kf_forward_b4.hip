@@ -1023,13 +1023,14 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size
     B4SplitWs W;
     void* wbase = (void*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     kf_b4_split_carve(wbase, a.B, a.m, a.T, &W);
+    KfAuxJoinGuard join_guard(h, stream);
     ac.hs_const = W.hs_const; ac.hs_tile = W.hs_tile; ac.hs_logp = W.hs_logp; ac.hs_info = W.hs_info; ac.hs_ts = W.hs_ts; ac.hs_tfree = W.hs_tfree;
     const int ch = b4_split_chunk(a.T), nch = (a.T + ch - 1) / ch;
     // the second stream starts behind everything already queued on the caller's stream (its inputs) ...
-    KF_HIP_CHECK(h, hipEventRecord(h->aux_ev[KF_AUX_EVENTS - 1], stream));
-    KF_HIP_CHECK(h, hipStreamWaitEvent(h->aux_stream, h->aux_ev[KF_AUX_EVENTS - 1], 0));
-    KF_HIP_CHECK(h, hipStreamWaitEvent(h->aux_stream2, h->aux_ev[KF_AUX_EVENTS - 1], 0));
-    KF_HIP_CHECK(h, hipStreamWaitEvent(h->aux_stream3, h->aux_ev[KF_AUX_EVENTS - 1], 0));
+    KF_HIP_CHECK(h, hipEventRecord(h->aux_ev[33], stream));
+    KF_HIP_CHECK(h, hipStreamWaitEvent(h->aux_stream, h->aux_ev[33], 0));
+    KF_HIP_CHECK(h, hipStreamWaitEvent(h->aux_stream2, h->aux_ev[33], 0));
+    KF_HIP_CHECK(h, hipStreamWaitEvent(h->aux_stream3, h->aux_ev[33], 0));
     const bool pair_ok = !pair_env_off && (a.filt_P || a.pred_P) && kf_forward_b4p_ok(a.m, a.p, a.r);
     for (int c = 0; c < nch; ++c) {
       ac.t_begin = c * ch;
@@ -1060,17 +1061,18 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size
         if (rc) return rc;
       }
     }
-    KF_HIP_CHECK(h, hipEventRecord(h->aux_ev[KF_AUX_EVENTS - 4], h->aux_stream3));
-    KF_HIP_CHECK(h, hipStreamWaitEvent(stream, h->aux_ev[KF_AUX_EVENTS - 4], 0));
+    KF_HIP_CHECK(h, hipEventRecord(h->aux_ev[30], h->aux_stream3));
+    KF_HIP_CHECK(h, hipStreamWaitEvent(stream, h->aux_ev[30], 0));
     {  // the recursion is done: the rest of the constant covariance tapes at full width (shares the queues of the throttled launches)
       const int rc = kf_b4_split_drain(h, a, W, nch - 1, stream);
       if (rc) return rc;
     }
     // ... and the caller's stream continues behind the last steady kernel
-    KF_HIP_CHECK(h, hipEventRecord(h->aux_ev[KF_AUX_EVENTS - 2], h->aux_stream));
-    KF_HIP_CHECK(h, hipStreamWaitEvent(stream, h->aux_ev[KF_AUX_EVENTS - 2], 0));
-    KF_HIP_CHECK(h, hipEventRecord(h->aux_ev[KF_AUX_EVENTS - 3], h->aux_stream2));
-    KF_HIP_CHECK(h, hipStreamWaitEvent(stream, h->aux_ev[KF_AUX_EVENTS - 3], 0));
+    KF_HIP_CHECK(h, hipEventRecord(h->aux_ev[32], h->aux_stream));
+    KF_HIP_CHECK(h, hipStreamWaitEvent(stream, h->aux_ev[32], 0));
+    KF_HIP_CHECK(h, hipEventRecord(h->aux_ev[31], h->aux_stream2));
+    KF_HIP_CHECK(h, hipStreamWaitEvent(stream, h->aux_ev[31], 0));
+    join_guard.dismiss();
     return KF_OK;
   }
   switch (nb) {

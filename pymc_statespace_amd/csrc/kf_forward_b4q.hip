@@ -865,6 +865,7 @@ int kf_launch_forward_b4q(kf_handle* h, const KfFwdArgs& a_in, void* workspace, 
   const char* pse = kf_env_experiment("KF_B4Q_PREP_STREAM");
   hipStream_t s_prep = (pse && pse[0] == '1') ? h->aux_stream : h->aux_stream3;
   const KfFwdArgs a_all = a;
+  KfAuxJoinGuard join_guard(split ? h : nullptr, stream);
   int ci = 0;
   for (long lo = 0; lo < a_all.B; lo += chunk, ++ci) {
     const long cnt = (a_all.B - lo) < chunk ? (a_all.B - lo) : chunk;
@@ -889,5 +890,6 @@ int kf_launch_forward_b4q(kf_handle* h, const KfFwdArgs& a_in, void* workspace, 
   }
 #undef KF_B4Q_LAUNCH2
 #undef KF_B4Q_LAUNCH
+  join_guard.dismiss();
   return KF_OK;
 }

@@ -43,7 +43,7 @@ inline const char* kf_env_experiment(const char* name) {
 #endif
 }
 
-#define KF_AUX_EVENTS 34
+#define KF_AUX_EVENTS 38  // 0 .. 33: the split pipelines' own; 34 .. 36: KfAuxJoinGuard
 struct kf_handle {
   int device;
   int lanes_per_draw;  // 0 = auto
@@ -60,6 +60,27 @@ struct kf_handle {
   hipEvent_t aux_ev[KF_AUX_EVENTS];
 };
 int kf_handle_aux(kf_handle* h);  // KF_OK once aux_stream / aux_ev exist (current device = the handle's)
+// Scope guard of a launcher that forks work onto the handle's streams: whichever way the function is left -- an error return in the
+// middle of the chunk loop included -- the caller's stream ends up behind everything the three streams were given, so the caller may
+// reuse or free its buffers and an active hipGraph capture is left with every fork joined.  The success path makes
+// its own, finer joins and dismisses the guard.
+struct KfAuxJoinGuard {
+  kf_handle* h;
+  hipStream_t stream;
+  bool armed;
+  KfAuxJoinGuard(kf_handle* h_, hipStream_t s) : h(h_), stream(s), armed(true) {}
+  void dismiss() { armed = false; }
+  ~KfAuxJoinGuard() {
+    if (!armed || !h || !h->aux_ready) return;
+    hipStream_t aux[3] = {h->aux_stream, h->aux_stream2, h->aux_stream3};
+    for (int i = 0; i < 3; ++i) {
+      hipEvent_t ev = h->aux_ev[KF_AUX_EVENTS - 4 + i];
+      if (hipEventRecord(ev, aux[i]) == hipSuccess) (void)hipStreamWaitEvent(stream, ev, 0);
+    }
+  }
+  KfAuxJoinGuard(const KfAuxJoinGuard&) = delete;
+  KfAuxJoinGuard& operator=(const KfAuxJoinGuard&) = delete;
+};
 
 // Arguments of the LDS-resident forward kernel (one struct, passed by value).
 struct KfFwdArgs {
