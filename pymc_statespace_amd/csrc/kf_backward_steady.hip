@@ -376,6 +376,260 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(PS == 1
     for (int e = lane; e < r_ * r_; e += KF_WAVE) A.g_Q[b * (long)r_ * r_ + e] = 0.0;
 }
 
+
+// ---- the same adjoint, TIME-PARALLEL (round 4; p == 1, m <= 10) ---------------------------------------------------------------------
+// kf_bwd_steady_kernel walks the steps one at a time and is LDS-bound: every lane reads the whole x vector back per step (13 broadcast
+// ds_read_b128 + 13 ds_read_b64 for the accumulations: headline 0.75 ms, C3 3.4 ms -- the largest kernel of C3's value-and-gradient).
+// But behind the convergence point nothing is nonlinear:
+//     v_t = y~_t - z a_t   (a_t is on the forward kernel's tape)          w_t = gl W v_t
+//     lam_t = Abar' lam_{t+1} + z' w_t                                     (Abar = T - T K z)
+// is an affine recursion in lam with DATA inputs -- a prefix scan over time, ONE STEP PER LANE, 64 steps at a time, latest step in lane 0:
+// six Hillis-Steele levels, each a matrix-vector product with (Abar')^(2^k) read from LDS as broadcasts (the forward mean scan of
+// kf_forward_b4_steady.hip, reversed) -- and every accumulation is a sum over time of an outer product of lam_{t+1} with (a_t | y~_t | 1):
+//     S1 = sum lam_{t+1} a_t'     S2 = sum lam_{t+1} y~_t     S3 = sum lam_{t+1}     (lanes over the entries, 64 steps from two LDS row blocks)
+//     Sva = sum v_t a_t           Sv = sum v_t                Svv = sum v_t^2        (per lane, one wave reduction per draw)
+// from which, with sigma = S2 - S1 z' = sum lam_{t+1} v_t and tk = T K:
+//     T_b = S1 + sigma K'    K_b = T' sigma    Z_b = gl W Sva' - tk' S1    c_b = S3    d_b = dsign (tk' S3 - gl W Sv)    VV = gl Svv
+// -- the sums kf_bwd_steady_kernel accumulates step by step; the epilogue (K_b, W_b) -> (P_b, Z_b, H_b) is that kernel's at p = 1.
+// ~35 instructions and ~14 LDS operations per draw-step instead of ~80 and 26.  Results agree with the sequential kernel to rounding
+// (1e-13 of a gradient's largest entry; KF_VG_STEADY_SCAN=0 keeps the sequential kernel).
+template <int M>
+__global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_scan_kernel(const KfBwdArgs A, const int32_t* __restrict__ ts_all,
+                                                                      double* __restrict__ out_ab, double* __restrict__ out_Pb,
+                                                                      double* __restrict__ out_P, const double* __restrict__ P_conv) {
+  constexpr int MM = M * M, NC = M + 2;          // columns of the right rows: a (M) | y~ | 1
+  constexpr int NPAIR = M * NC;                  // entries of (S1 | S2 | S3)
+  __shared__ __attribute__((aligned(16))) double sAP[6 * MM + 2];        // (Abar')^(2^k), k = 0 .. 5, row-major
+  __shared__ __attribute__((aligned(16))) double rowsL[KF_WAVE * M];      // lam_{t+1} of the block's steps, one row per lane
+  __shared__ __attribute__((aligned(16))) double rowsA[KF_WAVE * NC];     // (a_t | y~_t | 1)
+  __shared__ __attribute__((aligned(16))) double sP[MM], sT[MM], sS[NPAIR + 2];
+  __shared__ __attribute__((aligned(16))) double sV[10 * M + 8];
+  const int lane = threadIdx.x;
+  const long b = A.list ? (long)A.list[blockIdx.x] : (long)blockIdx.x;
+  const int n = A.T, r_ = A.r;
+  const int ts = ts_all[b] < n ? ts_all[b] : n;
+  const double* gpa = A.pred_a + b * (long)(A.tape_T + 1) * M;
+  const double* gpP = P_conv + b * (long)MM;
+  const double* gT = A.Tm + b * (long)MM;
+  const double* gZ = A.Z + b * (long)M;
+  const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;  // :335 quirk: y_hat = Z a - d
+  const double* ybase = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)A.y_T : 0L);
+  const double d1 = A.d ? A.d[b] : 0.0;
+  const double gl = A.g_logp ? A.g_logp[b] : 0.0;
+  double* vz = sV;            // z
+  double* vK = sV + M;        // K = P z' / F
+  double* vM = sV + 2 * M;    // M = P z'
+  double* vTK = sV + 3 * M;   // T K
+  double* vX = sV + 4 * M;    // scratch vectors of the epilogue (6 M)
+  for (int e = lane; e < MM; e += KF_WAVE) {
+    const int i = e / M, j = e - i * M;
+    const double pij = 0.5 * (gpP[e] + gpP[j * M + i]);
+    sP[e] = pij;
+    sT[e] = gT[e];
+    out_P[b * (long)MM + e] = pij;
+  }
+  if (lane < M) vz[lane] = gZ[lane];
+  wave_lds_fence();
+  if (lane < M) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) s = fma(sP[lane * M + j], vz[j], s);
+    vM[lane] = s;
+  }
+  wave_lds_fence();
+  double F = A.H[b];
+#pragma unroll
+  for (int i = 0; i < M; ++i) F = fma(vz[i], vM[i], F);
+  const double W = 1.0 / F;
+  if (lane < M) vK[lane] = vM[lane] * W;
+  wave_lds_fence();
+  if (lane < M) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) s = fma(sT[lane * M + j], vK[j], s);
+    vTK[lane] = s;
+  }
+  wave_lds_fence();
+  for (int x = lane; x < MM; x += KF_WAVE) {   // (Abar')[i][l] = Abar[l][i] = T[l][i] - tk[l] z[i]
+    const int i = x / M, l = x - i * M;
+    sAP[x] = fma(-vTK[l], vz[i], sT[l * M + i]);
+  }
+  wave_lds_fence();
+#pragma unroll 1
+  for (int k = 1; k < 6; ++k) {
+    const double* src = sAP + (k - 1) * MM;
+    for (int x = lane; x < MM; x += KF_WAVE) {
+      const int i = x / M, j = x - i * M;
+      double v = 0.0;
+#pragma unroll
+      for (int l = 0; l < M; ++l) v = fma(src[i * M + l], src[l * M + j], v);
+      sAP[k * MM + x] = v;
+    }
+    wave_lds_fence();
+  }
+  double z[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) z[i] = vz[i];
+  // this lane's entries of (S1 | S2 | S3): e = lane and lane + 64
+  const int e0 = lane, e1 = lane + KF_WAVE;
+  const bool p0 = e0 < NPAIR, p1 = e1 < NPAIR;
+  const int i0 = p0 ? e0 / NC : 0, j0 = p0 ? e0 - i0 * NC : 0;
+  const int i1 = p1 ? e1 / NC : 0, j1 = p1 ? e1 - i1 * NC : 0;
+  double acc0 = 0.0, acc1 = 0.0;
+  double sva[M], sv = 0.0, svv = 0.0, carry[M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    sva[i] = 0.0;
+    carry[i] = 0.0;
+  }
+  for (int te = n; te > ts; te -= KF_WAVE) {
+    const int tb = (te - KF_WAVE) > ts ? te - KF_WAVE : ts;
+    const int cnt = te - tb;
+    const bool act = lane < cnt;
+    const int t = act ? te - 1 - lane : ts;
+    double a[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) a[i] = act ? gpa[(long)t * M + i] : 0.0;
+    const double yt = act ? ybase[t] + dsign * d1 : 0.0;
+    double za = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) za = fma(z[i], a[i], za);
+    const double v = yt - za;
+    const double w = gl * W * v;
+    double x[M], xs[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      double u = z[i] * w;
+      if (lane == 0) {   // the block behind this one enters through the latest step
+#pragma unroll
+        for (int l = 0; l < M; ++l) u = fma(sAP[i * M + l], carry[l], u);
+      }
+      x[i] = u;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int s = 1 << k;
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        const double up = __shfl_up(x[i], s);
+        xs[i] = lane >= s ? up : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        double vv = x[i];
+#pragma unroll
+        for (int l = 0; l < M; ++l) vv = fma(sAP[k * MM + i * M + l], xs[l], vv);
+        x[i] = vv;
+      }
+    }
+    // lane j holds lam of step te - 1 - j; lam_{t+1} of that step is the lane before it (the carry for lane 0)
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const double up = __shfl_up(x[i], 1);
+      const double l1 = lane == 0 ? carry[i] : up;
+      rowsL[lane * M + i] = act ? l1 : 0.0;
+      rowsA[lane * NC + i] = a[i];
+      sva[i] = fma(v, a[i], sva[i]);
+    }
+    rowsA[lane * NC + M] = yt;
+    rowsA[lane * NC + M + 1] = act ? 1.0 : 0.0;
+    sv += v;
+    svv = fma(v, v, svv);
+    wave_lds_fence();
+#pragma unroll 8
+    for (int s2 = 0; s2 < KF_WAVE; ++s2) {
+      acc0 = fma(rowsL[s2 * M + i0], rowsA[s2 * NC + j0], acc0);
+      acc1 = fma(rowsL[s2 * M + i1], rowsA[s2 * NC + j1], acc1);
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) carry[i] = __shfl(x[i], cnt - 1);
+  }
+  // ---- sums -> LDS; wave reductions of the per-lane data sums ----------------------------------------------------------------------
+  wave_lds_fence();
+  if (p0) sS[e0] = acc0;
+  if (p1) sS[e1] = acc1;
+#pragma unroll
+  for (int off = 32; off; off >>= 1) {
+    sv += __shfl_xor(sv, off);
+    svv += __shfl_xor(svv, off);
+#pragma unroll
+    for (int i = 0; i < M; ++i) sva[i] += __shfl_xor(sva[i], off);
+  }
+  wave_lds_fence();
+  // sigma = S2 - S1 z,  K_b = T' sigma
+  double* vSig = vX;
+  double* vKb = vX + M;
+  double* vMb = vX + 2 * M;
+  double* vFZ = vX + 3 * M;
+  double* vFZP = vX + 4 * M;
+  if (lane < M) {
+    double s = sS[lane * NC + M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) s = fma(-sS[lane * NC + j], z[j], s);
+    vSig[lane] = s;
+  }
+  wave_lds_fence();
+  if (lane < M) {
+    double s = 0.0;
+#pragma unroll
+    for (int l = 0; l < M; ++l) s = fma(sT[l * M + lane], vSig[l], s);
+    vKb[lane] = s;
+  }
+  wave_lds_fence();
+  const double GLs = gl * (double)(n - ts);
+  double Wb = 0.5 * (GLs * F - gl * svv);   // W_b = (GL F - VV) / 2 + M' K_b
+#pragma unroll
+  for (int i = 0; i < M; ++i) Wb = fma(vM[i], vKb[i], Wb);
+  const double Fb = -W * Wb * W;
+  if (lane < M) {
+    vMb[lane] = vKb[lane] * W;   // M_b = K_b W
+    vFZ[lane] = Fb * z[lane];    // F_b Z
+  }
+  wave_lds_fence();
+  if (lane < M) {
+    double s = 0.0;
+#pragma unroll
+    for (int l = 0; l < M; ++l) s = fma(vFZ[l], sP[l * M + lane], s);
+    vFZP[lane] = s;              // F_b Z P
+  }
+  wave_lds_fence();
+  for (int e = lane; e < MM; e += KF_WAVE) {
+    const int i = e / M, j = e - i * M;
+    out_Pb[b * (long)MM + e] = fma(vMb[i], z[j], z[i] * vFZ[j]);   // P_b = M_b Z + Z' F_b Z
+    if (A.g_P0) A.g_P0[b * (long)MM + e] = 0.0;
+    if (A.g_T) A.g_T[b * (long)MM + e] = fma(vSig[i], vK[j], sS[i * NC + j]);   // T_b = S1 + sigma K'
+  }
+  if (lane < M) {
+    if (A.g_Z) {
+      double zb = gl * W * sva[lane];       // Z_b = gl W Sva - tk' S1 ...
+      double mp = 0.0;
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        zb = fma(-vTK[i], sS[i * NC + lane], zb);
+        mp = fma(vMb[i], sP[i * M + lane], mp);
+      }
+      A.g_Z[b * (long)M + lane] = zb + 2.0 * vFZP[lane] + mp;   // ... + M_b' P + 2 F_b Z P
+    }
+    if (A.g_c) A.g_c[b * (long)M + lane] = sS[lane * NC + M + 1];
+    if (A.g_a0) A.g_a0[b * (long)M + lane] = 0.0;
+    out_ab[b * (long)M + lane] = carry[lane < M ? lane : 0];
+  }
+  if (lane == 0) {
+    if (A.g_H) A.g_H[b] = Fb;
+    if (A.g_d) {
+      double s = -gl * W * sv;
+#pragma unroll
+      for (int i = 0; i < M; ++i) s = fma(vTK[i], sS[i * NC + M + 1], s);
+      A.g_d[b] = dsign * s;
+    }
+  }
+  if (A.g_R)
+    for (int e = lane; e < M * r_; e += KF_WAVE) A.g_R[b * (long)M * r_ + e] = 0.0;
+  if (A.g_Q)
+    for (int e = lane; e < r_ * r_; e += KF_WAVE) A.g_Q[b * (long)r_ * r_ + e] = 0.0;
+}
+
 }  // namespace
 
 bool kf_backward_steady_ok(int m, int p, int r) { return m >= 1 && m <= SA_M && p >= 1 && p <= SA_P && r >= 1; }
@@ -390,6 +644,21 @@ int kf_launch_backward_steady(kf_handle* h, const KfBwdArgs& a, const int32_t* t
   if (!kf_backward_steady_ok(a.m, a.p, a.r) || (a.flags & KF_FLAG_TV_ANY) || a.g_ll_obs) {  // (one cotangent per draw: g_logp)
     KF_SET_ERR(h, "backward(steady): needs m <= %d, p <= %d, static matrices (got m=%d p=%d)", SA_M, SA_P, a.m, a.p);
     return KF_ERR_UNSUPPORTED;
+  }
+  // p == 1, m <= 10 with the converged covariance handed over (the p == 1 block kernel's value-and-gradient): the time-parallel form
+  {
+    const char* e = kf_env_switch("KF_VG_STEADY_SCAN");
+    if (a.p == 1 && a.m <= 10 && P_conv && !(e && e[0] == '0')) {
+#define KF_SS_LAUNCH(M_) \
+  case M_: hipLaunchKernelGGL((kf_bwd_steady_scan_kernel<M_>), dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, ts, out_ab, out_Pb, out_P, P_conv); break;
+      switch (a.m) {
+        KF_SS_LAUNCH(1) KF_SS_LAUNCH(2) KF_SS_LAUNCH(3) KF_SS_LAUNCH(4) KF_SS_LAUNCH(5) KF_SS_LAUNCH(6) KF_SS_LAUNCH(7) KF_SS_LAUNCH(8)
+        KF_SS_LAUNCH(9) KF_SS_LAUNCH(10)
+      }
+#undef KF_SS_LAUNCH
+      KF_HIP_CHECK(h, hipGetLastError());
+      return KF_OK;
+    }
   }
 #define KF_SA_LAUNCH(PS_, MS_) \
   hipLaunchKernelGGL((kf_bwd_steady_kernel<PS_, MS_>), dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, ts, out_ab, out_Pb, out_P, P_conv)

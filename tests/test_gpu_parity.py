@@ -1307,9 +1307,9 @@ def test_multivariate_row_kernels_match_oracle(eng, pmr, ft, mvn):
 
 
 def test_multivariate_row_kernel_needs_diagonal_h(eng):
-    """Joint filters with a dense H stay on the LDS kernel (auto) / are refused (forced row)."""
+    """Joint filters with a dense H are whitened onto the diagonal-H kernel of the shape (auto) / are refused (forced row)."""
     w = W.random_dense(5, 20, 3, 8, 3, seed=5, h_diag=False)
-    assert eng.forward_kernel_name(5, 20, 3, 8, 3, "standard", False) == "kf_fwd_lds_kernel"
+    assert eng.forward_kernel_name(5, 20, 3, 8, 3, "standard", False) == "kf_fwd_b4q_kernel"   # behind kf_whiten_kernel
     assert eng.forward_kernel_name(5, 20, 3, 8, 3, "univariate", False) == "kf_fwd_b4q_kernel"
     assert eng.forward_kernel_name(16384, 20, 3, 8, 3, "univariate", False) == "kf_fwd_rowsplit_mp_kernel"
     out = _np(eng.forward(*_args(w)))  # auto-detects the dense H
@@ -1454,7 +1454,7 @@ def test_auto_kernel_selection(eng):
     assert name(4096, 1000, 1, 17, 5) == "kf_fwd_mfma_nb_kernel"
     assert name(4096, 1000, 1, 48, 5) == "kf_fwd_mfma_nb_kernel"
     assert name(4096, 1000, 3, 30, 5, "standard", True) == "kf_fwd_mfma_nb_kernel"
-    assert name(4096, 1000, 3, 30, 5, "standard", False) == "kf_fwd_lds_kernel"    # dense H
+    assert name(4096, 1000, 3, 30, 5, "standard", False) == "kf_fwd_mfma_nb_kernel"    # dense H: whitened (kf_forward_whiten.hip)
     assert name(4096, 1000, 1, 49, 5) == "kf_fwd_mfma_wg_kernel"
     assert name(4096, 1000, 1, 64, 5) == "kf_fwd_mfma_wg_kernel"
     assert name(4096, 1000, 3, 60, 5, "standard", False) == "big_gemm_kernel"      # dense H

@@ -146,6 +146,41 @@ def test_value_and_grad_steady_state_adjoint_large_batch_and_default_cotangent(e
             assert_allclose(g[nm][b].cpu().numpy(), gb[nm][0].cpu().numpy(), rtol=1e-9, atol=1e-11, err_msg=nm)
 
 
+@pytest.mark.parametrize("m,n", [(1, 210), (3, 277), (6, 400), (10, 333), (10, 1000)])
+def test_time_parallel_steady_state_adjoint_matches_the_sequential_one(eng, monkeypatch, m, n):
+    """kf_bwd_steady_scan_kernel (64 steps per wavefront pass, prefix scan of the affine lambda recursion) against
+    kf_bwd_steady_kernel (step by step; KF_VG_STEADY_SCAN=0): the same sums in a different order -- rounding only.  Series lengths
+    that leave full, partial and single-step last blocks; a missing observation early on (the phase starts behind it)."""
+    w = W.structural(B=40, n=n) if m == 10 else W.random_dense(B=40, n=n, p=1, m=m, r=max(1, m // 2), seed=90 + m)
+    y = w["y"].copy()
+    y[7] = np.nan
+    rng = np.random.default_rng(m)
+    gl = 1.0 + 0.3 * rng.standard_normal(w["B"])
+    c, d = 0.05 * rng.standard_normal((w["B"], w["m"])), 0.1 * rng.standard_normal((w["B"], 1))
+    args = (y,) + tuple(w[x] for x in KEYS)
+    if m <= 4:
+        eng.set_forward_kernel("b4")
+    try:
+        for ft in ("standard", "single"):
+            kw = dict(c=c, d=d, g_logp=gl, filter_type=ft, mvn_const="exact", exact_recursion=False)
+            lp, info, g = eng.value_and_grad(*args, **kw)
+            monkeypatch.setenv("KF_VG_STEADY_SCAN", "0")
+            lps, _, gs = eng.value_and_grad(*args, **kw)
+            monkeypatch.delenv("KF_VG_STEADY_SCAN")
+            assert not info.cpu().numpy().any()
+            assert np.array_equal(lp.cpu().numpy(), lps.cpu().numpy())
+            differs = False
+            for nm in GRADS:
+                a_, x_ = g[nm].cpu().numpy(), gs[nm].cpu().numpy()
+                differs = differs or not np.array_equal(a_, x_)
+                scale = 1.0 + np.max(np.abs(x_.reshape(w["B"], -1)), axis=1)
+                err = np.max(np.abs(a_ - x_).reshape(w["B"], -1), axis=1) / scale
+                assert err.max() < 1e-12, f"{ft} {nm}: {err.max():.2e} (draw {err.argmax()})"
+            assert differs, "the switch selected the same kernel twice"
+    finally:
+        eng.set_forward_kernel("auto")
+
+
 def test_forcing_the_block_kernel_keeps_the_c4_gradient_right(eng):
     """with the forward kernel forced to 'b4' the steady-state value-and-gradient of a C4-like shape used to fall
     through to the LDS adjoint, which ignores the per-draw step counts.  Per-draw step counts now always reach the adjoint that
