@@ -643,6 +643,14 @@ def main():
                     # ... and with the steady-state adjoint requested (KF_FLAG_STEADY_STATE), whatever AUTO picked above
                     ops["logp_and_gradient_steady_state_ms"] = _ms(lambda: eng.value_and_grad(
                         *d, filter_type=ft, mvn_const="exact", h_diagonal=not args.dense_h, exact_recursion=False))
+                    # the calls above repeat ONE set of parameters, so the placement hint the steady-state path takes from the
+                    # previous call's convergence points (include/kf.h; outputs never depend on it) is exact; without it:
+                    os.environ["KF_VG_SCHED_HINT"] = "0"
+                    try:
+                        ops["logp_and_gradient_no_placement_hint_ms"] = _ms(lambda: eng.value_and_grad(
+                            *d, filter_type=ft, mvn_const="exact", h_diagonal=not args.dense_h))
+                    finally:
+                        del os.environ["KF_VG_SCHED_HINT"]
                 # the timed call runs the library's default; the same call with the covariance recursion forced at every
                 # step (KF_FLAG_EXACT_RECURSION) and with the steady-state phase requested (KF_FLAG_STEADY_STATE), and how far
                 # the three log-likelihood vectors are apart

@@ -227,9 +227,15 @@ int kf_filter_forward(kf_handle* h, const kf_dims* dims,
  * Riccati adjoint per draw (kf_backward_steady.hip, kf_dare_backward) -- and only the steps before it by the adjoint of the full
  * recursion; agrees with the adjoint at every step to <= 1e-12 of a gradient's largest entry on the BASELINE workloads (asserted
  * at 1e-10).  Used by default for the multi-observation block kernel (3 <= p <= 5, m >= 8: C4) and, round 4, for the p == 1 block
- * kernel (m <= 10) from two rounds of the chip's wavefront slots on (B >= 32 x CUs), or one round with T >= 1536 -- below that a
- * launch lasts as long as its slowest draw's chain and the phase gains nothing (measured: kf_api.hip).  KF_FLAG_STEADY_STATE
- * requests it for any batch, KF_FLAG_EXACT_RECURSION (or KF_VG_STEADY=0 in the environment) the adjoint at every step. */
+ * kernel (m <= 10) from two rounds of the chip's wavefront slots on (B >= 32 x CUs), or one round (B >= 16 x CUs) with T >= 768 --
+ * below that a launch lasts as long as its slowest draw's chain and the phase gains nothing (measured: kf_api.hip).  There the
+ * steps behind the convergence point are time-parallel in BOTH directions (kf_bwd_steady_scan_kernel: the forward means and the
+ * adjoint as prefix scans, 64 steps per wavefront pass).  KF_FLAG_STEADY_STATE requests the steady-state adjoint for any batch,
+ * KF_FLAG_EXACT_RECURSION (or KF_VG_STEADY=0 in the environment) the adjoint at every step.
+ * Workspace reuse: on that path the launch order of the forward kernel's workgroups follows the convergence points the PREVIOUS
+ * call left in the same workspace (same B, T, m: a sampler's successive calls) -- draws that will run long are spread over the
+ * SIMDs.  This decides only WHERE a draw runs: every output is bitwise the same with a fresh, a reused or an overwritten
+ * workspace (KF_VG_SCHED_HINT=0 in the environment: natural order). */
 int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims,
                              const double* y, const double* a0, const double* P0,
                              const double* T, const double* Z, const double* R,

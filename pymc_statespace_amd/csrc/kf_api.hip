@@ -637,12 +637,12 @@ static bool kf_vg_tile_steady_path(const kf_handle* h, const kf_dims* d) {
   if (!kf_backward_steady_ok(d->m, d->p, d->r)) return false;
   if ((d->flags & KF_FLAG_STEADY_STATE) || (e && e[0] == '1') || (sse && atoi(sse) != 0)) return true;
   // AUTO: where it wins.  A launch lasts as long as its most loaded SIMD: below one round of the chip's wavefront slots (4 per
-  // SIMD) that is the slowest draw's chain -- a draw whose covariance never converges gains nothing and the steady-state adjoint's
-  // kernel is one more link -- measured (scripts/r04/vg_time.py sweep, structural m = 10, ms, steady ; exact): 512 draws x 1000
-  // 1.87 ; 1.25, 2048 x 1000 2.30 ; 1.68, 4096 x 1000 2.91 ; 2.88, 4096 x 2000 5.41 ; 5.78, 8192 x 1000 5.01 ; 5.66,
-  // 8192 x 2000 (C3) 8.71 ; 11.33
+  // SIMD) that is the slowest draw's chain -- a draw whose covariance never converges gains nothing and the steady-state kernels are
+  // more links -- measured (scripts/r04/vg_time.py sweep, structural m = 10, ms, steady ; exact -- profiles/r04/vg_sweep_*.txt):
+  // 512 draws x 1000 1.54 ; 1.15, 2048 x 1000 1.71 ; 1.56, 4096 x 500 1.41 ; 1.41, 4096 x 1000 2.15 ; 2.78, 4096 x 2000 4.04 ; 5.61,
+  // 8192 x 500 2.61 ; 2.78, 8192 x 1000 3.55 ; 5.49, 8192 x 2000 (C3) 5.66 ; 11.0
   const long slots = 16L * (h->n_cu > 0 ? h->n_cu : 256);
-  return (d->B >= slots && d->T >= 1536) || d->B >= 2 * slots;
+  return (d->B >= slots && d->T >= 768) || d->B >= 2 * slots;
 }
 
 extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, int which, size_t* bytes) {
@@ -654,7 +654,7 @@ extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, i
     *bytes = kf_vg_tape_bytes(dims) + inner;
     if (kf_vg_tile_steady_path(h, dims)) {
       const size_t B = (size_t)dims->B, m = (size_t)dims->m, n1 = (size_t)dims->T + 1;
-      *bytes += kf_vg_round(8 * B * n1 * m) + 2 * kf_vg_round(4 * B) + kf_vg_round(8 * B * m) + 3 * kf_vg_round(8 * B * m * m);
+      *bytes += kf_vg_round(8 * B * n1 * m) + 3 * kf_vg_round(4 * B) + kf_vg_round(64) + kf_vg_round(8 * B * m) + 3 * kf_vg_round(8 * B * m * m);
     }
     if (kf_vg_steady_path(h, dims)) {
       const size_t B = (size_t)dims->B, m = (size_t)dims->m;
@@ -779,10 +779,28 @@ __global__ void kf_fill_kernel(double* x, long n, double v) {
 // total; draws beyond 4 S keep descending order (the dispatcher hands them to whichever SIMD frees a slot first: longest first).
 // The order only decides WHERE a draw runs: results do not depend on it.
 constexpr int KF_ORD_BINS = 2048;
-__global__ __launch_bounds__(1024) void kf_vg_order_kernel(const int32_t* __restrict__ ts, int n, int B, int S, int32_t* __restrict__ list) {
+//
+// The FORWARD launch of a value-and-gradient call is ordered the same way from the convergence points of the PREVIOUS call that used the
+// same workspace (hint != NULL: the ts slot still holds them; hdr = {magic, B, n, m} says so -- a sampler's successive calls move the
+// parameters a little, the convergence points with them).  check != 0: a header that does not match (first call, another shape, a
+// workspace someone else wrote to) gives the identity order; whatever the slot holds, the list is a permutation.  check == 0: the
+// header is (re)written for the next call.
+constexpr int KF_ORD_MAGIC = 0x6b665f74;
+__global__ __launch_bounds__(1024) void kf_vg_order_kernel(const int32_t* __restrict__ ts, int n, int B, int S, int32_t* __restrict__ list,
+                                                           int32_t* __restrict__ hdr, int check, int m) {
   __shared__ int hist[KF_ORD_BINS];   // bucket j = KF_ORD_BINS - 1 - key: ascending j = descending ts
   __shared__ int wsum[64];
   const int tid = threadIdx.x;
+  if (hdr) {
+    if (check) {
+      if (hdr[0] != KF_ORD_MAGIC || hdr[1] != B || hdr[2] != n || hdr[3] != m) {
+        for (int b = tid; b < B; b += 1024) list[b] = b;
+        return;
+      }
+    } else if (tid < 4) {
+      hdr[tid] = tid == 0 ? KF_ORD_MAGIC : tid == 1 ? B : tid == 2 ? n : m;
+    }
+  }
   for (int j = tid; j < KF_ORD_BINS; j += 1024) hist[j] = 0;
   __syncthreads();
   auto bucket = [&](int v) {
@@ -855,6 +873,14 @@ extern "C" int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims, const
   if (tile) {
     // [ones | tile tape | inner]: the forward kernel leaves the predicted tile of every step, the adjoint reads it back
     w = reinterpret_cast<char*>(pred_a);
+    const bool tsteady = kf_vg_tile_steady_path(h, dims);
+    int32_t *ts = nullptr, *order = nullptr, *order_f = nullptr, *hdr = nullptr;
+    if (tsteady) {  // [ones | ts B | header | order B | forward order B | tile tape | ...]: ahead of the tape, at offsets that depend on B only
+      ts = reinterpret_cast<int32_t*>(w); w += kf_vg_round(4 * B);
+      hdr = reinterpret_cast<int32_t*>(w); w += kf_vg_round(64);
+      order = reinterpret_cast<int32_t*>(w); w += kf_vg_round(4 * B);
+      order_f = reinterpret_cast<int32_t*>(w); w += kf_vg_round(4 * B);
+    }
     double* tape = reinterpret_cast<double*>(w);
     const size_t n4 = 4 * ((m + 2 + 3) / 4);
     w += kf_vg_round(8 * B * n1 * n4 * n4);
@@ -865,18 +891,23 @@ extern "C" int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims, const
     f.y = y; f.a0 = a0; f.P0 = P0; f.Tm = T; f.Z = Z; f.R = R; f.H = H; f.Q = Q; f.c = c; f.d = d;
     f.logp = logp; f.ll_obs = nullptr; f.filt_a = nullptr; f.pred_a = nullptr; f.filt_P = nullptr; f.pred_P = nullptr;
     f.info = info; f.tile_tape = tape;
-    const bool tsteady = kf_vg_tile_steady_path(h, dims);
-    int32_t *ts = nullptr, *order = nullptr;
     double *s_pa = nullptr, *s_ab = nullptr, *s_Pb = nullptr, *s_P = nullptr, *s_Pc = nullptr;
-    if (tsteady) {  // [.. | pred_a B (T+1) m | ts B | order B | lam_ts B m | P_b B m^2 | P B m^2 | P as the forward left it B m^2 | inner]
+    if (tsteady) {  // [.. | pred_a B (T+1) m | lam_ts B m | P_b B m^2 | P B m^2 | P as the forward left it B m^2 | inner]
       s_pa = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * n1 * m);
-      ts = reinterpret_cast<int32_t*>(w); w += kf_vg_round(4 * B);
-      order = reinterpret_cast<int32_t*>(w); w += kf_vg_round(4 * B);
       s_ab = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * m);
       s_Pb = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * m * m);
       s_P = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * m * m);
       s_Pc = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * m * m);
       f.pred_a = s_pa; f.hs_ts = ts; f.vg_P = s_Pc;
+      f.vg_stop = kf_backward_steady_scan_ok(dims->m, dims->p) ? 1 : 0;   // the steps behind ts: forward AND backward in the scan kernel
+      // placement of the forward launch from the previous call's convergence points (kf_vg_order_kernel; KF_VG_SCHED_HINT=0: natural order)
+      const char* sh = kf_env_switch("KF_VG_SCHED_HINT");
+      if (dims->B <= 0x7fffffffL && !(sh && sh[0] == '0')) {
+        hipLaunchKernelGGL(kf_vg_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ts, (int)dims->T, (int)dims->B,
+                           4 * (h->n_cu > 0 ? h->n_cu : 256), order_f, hdr, 1, (int)dims->m);
+        KF_HIP_CHECK(h, hipGetLastError());
+        f.order = order_f;
+      }
     }
     const size_t inner_ts = workspace_bytes - (size_t)(w - reinterpret_cast<char*>(workspace));
     rc = kf_launch_forward_b4(h, f, nullptr, 0, (hipStream_t)stream);
@@ -896,9 +927,12 @@ extern "C" int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims, const
       a.tape_T = dims->T; a.y_T = dims->T; a.tile_tape = nullptr; a.init_ab = nullptr; a.init_Pb = nullptr; a.accumulate = 0;
       if (dims->B <= 0x7fffffffL) {  // the launch order of the two sweeps (see kf_vg_order_kernel)
         hipLaunchKernelGGL(kf_vg_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ts, (int)dims->T, (int)dims->B,
-                           4 * (h->n_cu > 0 ? h->n_cu : 256), order);
+                           4 * (h->n_cu > 0 ? h->n_cu : 256), order, hdr, 0, (int)dims->m);
         KF_HIP_CHECK(h, hipGetLastError());
         a.list = order;
+      }
+      if (f.vg_stop) {
+        a.fwd_pred_a = s_pa; a.fwd_logp = logp; a.fwd_info = info;
       }
       rc = kf_launch_backward_steady(h, a, ts, s_ab, s_Pb, s_P, (hipStream_t)stream, s_Pc);  // writes every gradient (zeros where it has none)
       if (rc) return rc;

@@ -42,8 +42,11 @@ __host__ __device__ inline int bb_epilogue_doubles(int n4, int m, int r) {
 // TILE: the tape is kf_forward_b4.hip's own tile tape (KfBwdArgs::tile_tape, kf_filter_value_and_grad): slot t holds S_f of
 // step t in the layout the registers want it, with u_hat in its (otherwise unused) row JA and 1 / sqrt(F) at [JA][JA] --
 // no tape image to assemble, no matrix-vector product, no rsqrt, no rank-one MFMAs; slot T holds the predicted tile S_1
+#ifndef KF_BWD_AHEAD
+#define KF_BWD_AHEAD 2
+#endif
 template <int NB, bool TILE>
-__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3 ? 4 : 3))) void kf_bwd_b4_kernel(
+__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((NB <= 3 && KF_BWD_AHEAD <= 2) ? 4 : 3))) void kf_bwd_b4_kernel(
     const KfBwdArgs A, double* __restrict__ scratch) {
   constexpr int N4 = 4 * NB, JA = N4 - 2, JC = N4 - 1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -117,8 +120,14 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     else { src[I] = gpa; stp[I] = 0; sh[I] = 0; }
     src[I] += (long)(n - 1) * stp[I];
   }
-  double PN[NB];
-  auto prefetch = [&]() {
+  // the tape is read TWO steps ahead, into two register sets the (manually unrolled) loop alternates between: a tape line comes from
+  // HBM (the forward kernel wrote n x 1.2 KB per draw, long evicted from L2), ~2 us under load, and with the load issued one step ahead
+  // a wavefront running alone on its SIMD -- the tail of every launch, and all of a launch of <= 1024 draws -- waited for it at the
+  // top of every step (0.72 us per step against the forward kernel's 0.48)
+  // (the compact-tape instantiations have no registers for the second set: one step ahead, as before)
+  constexpr int AHEAD = TILE ? KF_BWD_AHEAD : 1;
+  double PR[AHEAD][NB];
+  auto prefetch = [&](double (&PN)[NB]) {
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
       PN[I] = *src[I];
@@ -170,9 +179,12 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   const double* ux_rep = (g == 0) ? UX + 4 * q : UX + 16;   // {v[q], v[4+q], v[8+q], v[12+q]}: block I of v replicated
   const double* ux_row = (q == 0) ? UX + 4 * g : UX + 16;   // {v[g], v[4+g], v[8+g], v[12+g]}: one-row left factor
 
-  prefetch();
+  prefetch(PR[0]);
+#pragma unroll
+  for (int j = 1; j < AHEAD; ++j)
+    if (n - 1 - j >= 1) prefetch(PR[j]);
   stage_block(n - 1);
-  for (int t = n - 1; t >= 1; --t) {
+  auto step = [&](const int t, double (&PN)[NB]) __attribute__((always_inline)) {
     double Sx[NB];
 #pragma unroll
     for (int I = 0; I < NB; ++I) Sx[I] = TILE ? PN[I] : ldexp(PN[I], sh[I]);
@@ -264,7 +276,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
       }
     }
     wave_lds_fence();
-    if (t > 1) prefetch();
+    if (t > AHEAD) prefetch(PN);   // step t - AHEAD
     // ---- g = -2 G_f ut - (gl / 4) ut_C e_C (row-0 layout) -------------------------------------------------------------------------
     const double m2rs = TILE ? -2.0 : -2.0 * rs;  // (TILE: u_hat itself went through the exchange)
     double gv = mfma4(urow[0] * m2rs, Gf[0], 0.0);
@@ -295,6 +307,20 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     for (int I = 0; I < NB; ++I) G[I] = mfma4(0.5 * brep[I], eA_row0, Gf[I]);
     G[NB - 1] = mfma4(eA_rep, 0.5 * ub, G[NB - 1]);
     G[NB - 1] = fma(mAA, Fb, G[NB - 1]);
+  };
+  {
+    int t = n - 1;
+    for (; t >= AHEAD; t -= AHEAD) {
+#pragma unroll
+      for (int j = 0; j < AHEAD; ++j) step(t - j, PR[j]);
+    }
+    if constexpr (AHEAD == 2) {
+      if (t == 1) step(1, PR[0]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < AHEAD - 1; ++j)
+        if (t - j >= 1) step(t - j, PR[j]);
+    }
   }
 
   // ---- after the sweep: G = d L / d S_1.  Chain rule to (T, Z, R, Q, H, c, d), de-augmentation to (a_b, P_b) ------------------

@@ -470,6 +470,69 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_scan_kernel(const KfBwd
   double z[M];
 #pragma unroll
   for (int i = 0; i < M; ++i) z[i] = vz[i];
+  // ---- forward: the means of the steps behind ts (A.fwd_logp; the block kernel stopped at ts) -------------------------------------------
+  // a_{t+1} = Abar a_t + tk y~_t + c, 63 steps per pass: lane 0 carries a_tb, lane j >= 1 the forcing of step tb + j - 1, six levels with
+  // Abar^(2^k) = the stored matrices read by columns (kf_b4_steady_scan_kernel's scan, kf_forward_b4_steady.hip); then every lane finishes
+  // its own step's log-likelihood term and the rows leave through LDS as whole lines
+  if (A.fwd_logp) {
+    if (ts < n) {
+      constexpr int STEPS = KF_WAVE - 1;
+      double* wpa = A.fwd_pred_a + b * (long)(A.tape_T + 1) * M;
+      double gk[M], cc[M], acur[M];
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        gk[i] = vTK[i];
+        cc[i] = A.c ? A.c[b * (long)M + i] : 0.0;
+        acur[i] = wpa[(long)ts * M + i];
+      }
+      const bool quirk = A.filter == KF_FILTER_UNIVARIATE && !(A.flags & KF_FLAG_MVN_CONST_EXACT) && F == 1.0;  // :497-500
+      const double llconst = -0.5 * (KF_LOG_2PI + log(F));
+      double acc = 0.0;
+      for (int tb = ts; tb < n; tb += STEPS) {
+        const int t = tb + lane;
+        const int cnt = (n - tb) < STEPS ? (n - tb) : STEPS;
+        const double yt = t < n ? ybase[t] + dsign * d1 : 0.0;
+        const double yprev = __shfl_up(yt, 1);
+        double x[M], xs[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) x[i] = lane == 0 ? acur[i] : fma(gk[i], yprev, cc[i]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const int s = 1 << k;
+#pragma unroll
+          for (int i = 0; i < M; ++i) {
+            const double up = __shfl_up(x[i], s);
+            xs[i] = lane >= s ? up : 0.0;
+          }
+#pragma unroll
+          for (int l = 0; l < M; ++l)
+#pragma unroll
+            for (int i = 0; i < M; ++i) x[i] = fma(sAP[k * MM + l * M + i], xs[l], x[i]);
+        }
+        double za = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) za = fma(z[i], x[i], za);
+        const double v = yt - za;
+        const double quad = v * v * W;
+        if (lane < cnt) acc += (quirk && quad == 0.0) ? 0.0 : llconst - 0.5 * quad;
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < M; ++i) rowsL[lane * M + i] = x[i];
+        wave_lds_fence();
+        // lanes 1 .. cnt hold a_{tb+1} .. a_{tb+cnt}
+        for (int pos = lane; pos < cnt * M; pos += KF_WAVE) wpa[(long)(tb + 1) * M + pos] = rowsL[M + pos];
+#pragma unroll
+        for (int i = 0; i < M; ++i) acur[i] = __shfl(x[i], KF_WAVE - 1);
+      }
+#pragma unroll
+      for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
+      if (lane == 0) {
+        A.fwd_logp[b] += acc;
+        if (!(F > 0.0) && A.fwd_info && A.fwd_info[b] == 0) A.fwd_info[b] = ((ts + 1) << 8) | 1;
+      }
+    }
+    __threadfence();   // the rows are read back below (other lanes, other cache lines of this CU's L1)
+  }
   // this lane's entries of (S1 | S2 | S3): e = lane and lane + 64
   const int e0 = lane, e1 = lane + KF_WAVE;
   const bool p0 = e0 < NPAIR, p1 = e1 < NPAIR;
@@ -632,6 +695,11 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_scan_kernel(const KfBwd
 
 }  // namespace
 
+bool kf_backward_steady_scan_ok(int m, int p) {
+  const char* e = kf_env_switch("KF_VG_STEADY_SCAN");
+  return p == 1 && m >= 1 && m <= 10 && !(e && e[0] == '0');
+}
+
 bool kf_backward_steady_ok(int m, int p, int r) { return m >= 1 && m <= SA_M && p >= 1 && p <= SA_P && r >= 1; }
 
 // doubles of workspace: lam_ts [B][m] | P_b [B][m][m] | P [B][m][m]  (+ the int32 ts array, B entries, kept by the caller)
@@ -647,8 +715,7 @@ int kf_launch_backward_steady(kf_handle* h, const KfBwdArgs& a, const int32_t* t
   }
   // p == 1, m <= 10 with the converged covariance handed over (the p == 1 block kernel's value-and-gradient): the time-parallel form
   {
-    const char* e = kf_env_switch("KF_VG_STEADY_SCAN");
-    if (a.p == 1 && a.m <= 10 && P_conv && !(e && e[0] == '0')) {
+    if (P_conv && kf_backward_steady_scan_ok(a.m, a.p)) {
 #define KF_SS_LAUNCH(M_) \
   case M_: hipLaunchKernelGGL((kf_bwd_steady_scan_kernel<M_>), dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, ts, out_ab, out_Pb, out_P, P_conv); break;
       switch (a.m) {
@@ -658,6 +725,10 @@ int kf_launch_backward_steady(kf_handle* h, const KfBwdArgs& a, const int32_t* t
 #undef KF_SS_LAUNCH
       KF_HIP_CHECK(h, hipGetLastError());
       return KF_OK;
+    }
+    if (a.fwd_logp) {
+      KF_SET_ERR(h, "backward(steady): the forward hand-over needs the time-parallel kernel (m=%d p=%d)", a.m, a.p);
+      return KF_ERR_UNSUPPORTED;
     }
   }
 #define KF_SA_LAUNCH(PS_, MS_) \

@@ -106,6 +106,9 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     t0 = A.t_begin;
     t1 = A.t_end < n ? A.t_end : n;
   }
+  if constexpr (VGS) {
+    if (A.order) b = A.order[blockIdx.x];
+  }
 
   if (lds_addr(smem) & (unsigned)(8 * RING_P - 1)) __builtin_trap();  // (the dynamic block is the kernel's only LDS: it starts at 0)
   double* TR = smem + B4_OFF_TR;
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       put_a_row(s_pa, o_pa, P[NB - 1], vec_on);
     }
   }
-  if constexpr (SS == 1 && STREAM) if (t < n) {
+  if constexpr (SS == 1 && STREAM) if (t < n && !(VGS && A.vg_stop)) {
     // ---- steady-state steps t .. n-1 (see above); P is the converged predicted tile of step t -------------------------------
     if constexpr (!VGS) {  // this phase's state-tape writers are the lanes of DPP row 0: per-column offsets from here on
       o_fa = s_fa.slot_abs(bq);

@@ -125,6 +125,9 @@ struct KfFwdArgs {
   int32_t* hs_tfree = nullptr;  // [B] first step after the last missing observation (written by the first chunk)
   const int32_t* run_if = nullptr;  // internal (kf_forward_whiten.hip): the LDS kernel exits at once unless *run_if != 0
   double* vg_P = nullptr;       // internal (kf_filter_value_and_grad, block kernel + steady-state adjoint): [B][m][m] the predicted covariance at hs_ts[b]
+  const int32_t* order = nullptr;  // internal, with vg_P: workgroup i runs draw order[i] (kf_vg_order_kernel, kf_api.hip: placement only)
+  int vg_stop = 0;              // internal, with vg_P: the kernel ends at hs_ts[b] (logp / info up to there, a_ts in pred_a) -- the steps behind it are
+                                // kf_bwd_steady_scan_kernel's, forward and backward (kf_backward_steady.hip)
 };
 
 struct KfBwdArgs {
@@ -170,6 +173,12 @@ struct KfBwdArgs {
   // internal: workgroup i processes draw list[i] (NULL: draw i) -- a launch whose draws need very different step counts is ordered
   // so that the wavefronts sharing a SIMD carry about the same total (kf_vg_order_kernel, kf_api.hip)
   const int32_t* list = nullptr;
+  // internal (kf_bwd_steady_scan_kernel): when fwd_logp is set the kernel first runs the FORWARD mean recursion of the steps behind ts[b]
+  // (a_ts is in fwd_pred_a's slot ts; a_t of the later steps is written there, pred_a must alias it), adds their log-likelihood to
+  // fwd_logp[b] and marks fwd_info[b]
+  double* fwd_pred_a = nullptr;
+  double* fwd_logp = nullptr;
+  int32_t* fwd_info = nullptr;
 };
 
 struct KfSmoothArgs {
@@ -268,6 +277,7 @@ int kf_launch_backward_b4(kf_handle* h, const KfBwdArgs& a, void* workspace, siz
 int kf_launch_backward_mfma(kf_handle* h, const KfBwdArgs& a, hipStream_t stream);
 // steady-state adjoint (kf_backward_steady.hip): the steps a forward kernel ran in its steady-state phase
 bool kf_backward_steady_ok(int m, int p, int r);
+bool kf_backward_steady_scan_ok(int m, int p);   // the time-parallel kernel takes the shape (and KF_VG_STEADY_SCAN=0 is not set)
 size_t kf_backward_steady_workspace_bytes(long B, int m);
 int kf_launch_backward_steady(kf_handle* h, const KfBwdArgs& a, const int32_t* ts, double* out_ab, double* out_Pb, double* out_P,
                               hipStream_t stream, const double* P_conv = nullptr);
