@@ -118,7 +118,12 @@ enum {
    * kf_smoother honours the flag too: by default the block smoother (5 <= m <= 15, kf_smoother_b4.hip) and the lane smoother (m <= 2)
    * reuse the last step's gain X = P_hat^-1 T P_f wherever the FILTERED covariance on the tape is bit for bit the next step's (the
    * constant tapes a steady-state forward writes) instead of inverting the same matrix again; with the flag the prediction covariance
-   * is inverted at every step, as kalman_smoother.py:87-97 does.  KF_SMOOTHER_STEADY=0 in the environment has the same effect. */
+   * is inverted at every step, as kalman_smoother.py:87-97 does.  KF_SMOOTHER_STEADY=0 in the environment has the same effect.
+   * Series of >= 1536 steps, 5 <= m <= 10 (round 4, kf_smoother_b4_steady.hip): the steps from the last one down to the first whose
+   * filtered covariance is the last step's within 1e-14 of its largest entry -- every covariance of that range is read and compared --
+   * are smoothed with one gain: the mean by a prefix scan over time, the covariance recursed to its fixpoint and written as a
+   * constant; <= 6e-13 of a draw's largest entry away from every step in full on the BASELINE workloads.  Not with this flag
+   * (KF_SMOOTHER_SPLIT=0 / 1 in the environment: never / for any series length). */
   KF_FLAG_EXACT_RECURSION = 1u << 12,
   /* Forward filter: use the steady-state phase wherever the selected kernel has one, whatever the series length (the block
    * kernel's default depends on it, see above).  KF_FLAG_EXACT_RECURSION wins when both are set. */

@@ -688,7 +688,8 @@ extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, i
     if (sw > *bytes) *bytes = sw;
   }
   if ((which & KF_WS_SMOOTHER) && m >= 1 && m <= KF_WG_M_MAX) {  // flags of the register-tile smoothers
-    const size_t sm = kf_smoother_mfma_workspace_bytes(dims->B);
+    size_t sm = kf_smoother_mfma_workspace_bytes(dims->B);
+    if (kf_smoother_b4_ok(m, r) && m <= 10) sm += kf_smoother_b4_split_workspace_bytes(dims->B, m);  // kf_smoother_b4_steady.hip
     if (sm > *bytes) *bytes = sm;
   }
   if ((which & KF_WS_BACKWARD) && m >= 1 && p >= 1 && dims->T >= 1 && !kf_backward_lds_fits(m, p) &&
@@ -840,6 +841,13 @@ __global__ __launch_bounds__(1024) void kf_vg_order_kernel(const int32_t* __rest
   }
 }
 }  // namespace
+
+int kf_launch_order(kf_handle* h, const int32_t* keys, int n, long B, int32_t* list, hipStream_t stream) {
+  hipLaunchKernelGGL(kf_vg_order_kernel, dim3(1), dim3(1024), 0, stream, keys, n, (int)B, 4 * (h->n_cu > 0 ? h->n_cu : 256), list,
+                     (int32_t*)nullptr, 0, 0);
+  KF_HIP_CHECK(h, hipGetLastError());
+  return KF_OK;
+}
 
 extern "C" int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims, const double* y, const double* a0,
                                         const double* P0, const double* T, const double* Z, const double* R,

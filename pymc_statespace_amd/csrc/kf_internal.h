@@ -355,6 +355,13 @@ int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, si
                            hipStream_t stream);
 // register-tile smoother (kf_smoother_mfma.hip): m <= 16, needs 4 B + 64 bytes of workspace (flags)
 size_t kf_smoother_mfma_workspace_bytes(long B);
+// launch order of one-wavefront-per-draw kernels whose draws need very different times (kf_vg_order_kernel, kf_api.hip): list = the
+// draws by descending key (0 .. n), dealt out in snake order over the SIMDs; B <= INT_MAX.  Placement only.
+int kf_launch_order(kf_handle* h, const int32_t* keys, int n, long B, int32_t* list, hipStream_t stream);
+// the smoother behind the filter's convergence point, time-parallel (kf_smoother_b4_steady.hip): 5 <= m <= 10, static matrices
+bool kf_smoother_b4_split_ok(const KfSmoothArgs& a);
+size_t kf_smoother_b4_split_workspace_bytes(long B, int m);
+int kf_launch_smoother_b4_steady(kf_handle* h, const KfSmoothArgs& a, void* ws, int32_t** start, int32_t** list, hipStream_t stream);
 int kf_launch_smoother_mfma(kf_handle* h, const KfSmoothArgs& a, void* workspace, size_t workspace_bytes,
                             hipStream_t stream);
 // block-tile smoother (kf_smoother_mfma_nb.hip): 16 < m <= 47, same flag workspace

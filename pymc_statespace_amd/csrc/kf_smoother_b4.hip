@@ -66,15 +66,23 @@ __device__ __forceinline__ double wave_allmax_dpp(double x) {
 // values (no separate NaN test).  Returns a wave-uniform lower bound of max |x| within 2^-20.
 template <int NB>
 __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3 ? 4 : 3))) void kf_smooth_b4_kernel(
-    const KfSmoothArgs A, int32_t* flags) {
+    const KfSmoothArgs A, int32_t* flags, const int32_t* __restrict__ start, const int32_t* __restrict__ list) {
   constexpr int N4 = 4 * NB, JC = N4 - 1;
   using L = Sb4Lds<NB>;
   __shared__ __attribute__((aligned(16))) double smem[L::TOTAL];
   const int lane = threadIdx.x;
   const int g = lane >> 4, bq = lane & 15, q = lane & 3;
   const int fb = q * 4 + ((lane >> 2) & 3);
-  const long b = blockIdx.x;
+  // start / list (kf_smoother_b4_steady.hip): the steps from start[b] on are done -- the sweep resumes from the smoothed moments of
+  // step start[b] (>= n: nothing was done) --, workgroup i takes draw list[i] (placement: the draws need start[b] steps each)
+  const long b = list ? (long)list[blockIdx.x] : (long)blockIdx.x;
   const int n = A.T, m = A.m, mm = m * m, r_ = A.r;
+  const bool resume = start && start[b] < n;
+  const int t0 = resume ? start[b] : n - 1;   // the step whose smoothed moments the sweep starts from
+  if (resume && t0 == 0) {
+    if (threadIdx.x == 0) flags[b] = 0;
+    return;
+  }
   double* TA = smem;
   double* TX = smem + L::OFF_TX;
   double* TU = smem + L::OFF_TU;
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     else if (rr < m && bq == JC) { src[I] = gfa + rr; stp[I] = m; on_tp[I] = true; }
     else if (rr == JC && bq < m) { src[I] = gfa + bq; stp[I] = m; on_tp[I] = true; }
     else { src[I] = gfa; stp[I] = 0; on_tp[I] = false; }  // (a finite value: such tile entries never reach an output, see below)
-    src[I] += (long)(n - 1) * stp[I];
+    src[I] += (long)(resume ? t0 - 1 : n - 1) * stp[I];
   }
   const bool on_jc = g == 3 && bq == JC;  // tile entry (JC, JC): DPP row 3 of the last register
   for (int e = lane; e < L::TOTAL; e += KF_WAVE) smem[e] = 0.0;
@@ -163,12 +171,23 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     wave_lds_fence();
   };
   // ---- last step: smoothed = filtered ----------------------------------------------------------------------------------------
-  prefetch();
   double Ps[NB];
+  if (resume) {
+    const double* gsa = A.smooth_a + (b * (long)n + t0) * m;
+    const double* gsP = A.smooth_P + (b * (long)n + t0) * mm;
 #pragma unroll
-  for (int I = 0; I < NB; ++I) Ps[I] = on_tp[I] ? PN[I] : 0.0;
-  store_moments(n - 1, Ps);
-  if (n > 1) prefetch();
+    for (int I = 0; I < NB; ++I) {
+      const int rr = 4 * I + g;
+      Ps[I] = (rr < m && bq < m) ? gsP[rr * m + bq] : ((rr < m && bq == JC) ? gsa[rr] : ((rr == JC && bq < m) ? gsa[bq] : 0.0));
+    }
+    prefetch();
+  } else {
+    prefetch();
+#pragma unroll
+    for (int I = 0; I < NB; ++I) Ps[I] = on_tp[I] ? PN[I] : 0.0;
+    store_moments(n - 1, Ps);
+    if (n > 1) prefetch();
+  }
 
   double X[NB];
 #pragma unroll
@@ -189,7 +208,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   bool have_ref = false;
   bool st = false;
 
-  for (int t = n - 2; t >= 0 && !bad; --t) {
+  for (int t = t0 - 1; t >= 0 && !bad; --t) {
     double Sf[NB];
 #pragma unroll
     for (int I = 0; I < NB; ++I) Sf[I] = PN[I];  // (entries outside the tape image stay confined to unused rows / columns and (JC, JC))
@@ -413,9 +432,16 @@ int kf_launch_smoother_b4(kf_handle* h, const KfSmoothArgs& a, void* workspace, 
     return KF_ERR_UNSUPPORTED;
   }
   int32_t* flags = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(workspace) + 63) & ~(uintptr_t)63);
+  // behind the filter's convergence point: the time-parallel kernels (kf_smoother_b4_steady.hip), when the caller's workspace holds them
+  int32_t *start = nullptr, *list = nullptr;
+  const size_t base = kf_smoother_mfma_workspace_bytes(a.B);
+  if (kf_smoother_b4_split_ok(a) && workspace_bytes >= base + kf_smoother_b4_split_workspace_bytes(a.B, a.m)) {
+    const int rc = kf_launch_smoother_b4_steady(h, a, reinterpret_cast<char*>(workspace) + base, &start, &list, stream);
+    if (rc) return rc;
+  }
   const int nb = (a.m + 1 + 3) / 4;
 #define KF_SB4(NB_) \
-  hipLaunchKernelGGL((kf_smooth_b4_kernel<NB_>), dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, flags)
+  hipLaunchKernelGGL((kf_smooth_b4_kernel<NB_>), dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, flags, start, list)
   switch (nb) {
     case 2: KF_SB4(2); break;
     case 3: KF_SB4(3); break;

@@ -402,3 +402,101 @@ def test_time_varying_block_kernel_edges(eng):
     info = res.info.cpu().numpy()
     assert info[2] != 0 and not info[[0, 1, 3]].any()
     assert eng.forward_kernel_name(4, 50, 1, 6, 2, time_varying=("T", "Q")) == "kf_fwd_lds_kernel"
+
+
+# ---- RTS smoother: the time-parallel kernels behind the filter's convergence point (kf_smoother_b4_steady.hip) -------------------------
+def _smooth_both(eng, monkeypatch, w, res, **kw):
+    args = (w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
+    monkeypatch.setenv("KF_SMOOTHER_SPLIT", "1")
+    sa, sP = eng.smooth(*args, **kw)
+    monkeypatch.setenv("KF_SMOOTHER_SPLIT", "0")
+    xa, xP = eng.smooth(*args, **kw)
+    monkeypatch.delenv("KF_SMOOTHER_SPLIT")
+    return sa.cpu().numpy(), sP.cpu().numpy(), xa.cpu().numpy(), xP.cpu().numpy()
+
+
+def _rel(a_, x_):
+    B = a_.shape[0]
+    return (np.max(np.abs(a_ - x_).reshape(B, -1), axis=1) / (1.0 + np.max(np.abs(x_).reshape(B, -1), axis=1))).max()
+
+
+@pytest.mark.parametrize("fwd", ["every_step", "steady_state"])
+@pytest.mark.parametrize("m", [5, 6, 8, 9, 10])
+def test_smoother_behind_the_convergence_point_matches_every_step(eng, monkeypatch, m, fwd):
+    """Mean as a prefix scan, covariance recursed to its fixpoint and filled, the steps before the filter's convergence point in
+    kf_smooth_b4_kernel from the hand-over moments: against every step in that kernel (1e-11 of a draw's largest entry: the
+    tape tolerance 1e-14 times the conditioning of P_hat) and against the oracle on the same tapes (1e-9, the suite's bound)."""
+    from oracle import kalman_numpy as kn
+
+    w = W.structural(B=48, n=700) if m == 10 else W.random_dense(B=48, n=300 + 37 * m, p=1, m=m, r=max(1, m // 2), seed=130 + m)
+    y = w["y"].copy()
+    y[11] = np.nan   # an early missing observation: inside the part kf_smooth_b4_kernel keeps
+    res = eng.forward(y, *[w[k] for k in KEYS], mvn_const="exact", store_predicted=False, store_ll_obs=False,
+                      exact_recursion=(fwd == "every_step"))
+    sa, sP, xa, xP = _smooth_both(eng, monkeypatch, w, res)
+    assert np.all(np.isfinite(sa)) and np.all(np.isfinite(sP))
+    assert not (np.array_equal(sa, xa) and np.array_equal(sP, xP)), "the switch selected the same path twice"
+    assert _rel(sa, xa) < 1e-11 and _rel(sP, xP) < 1e-11, (_rel(sa, xa), _rel(sP, xP))
+    na, nP = kn.kalman_smoother(w["T"], w["R"], w["Q"], res.filtered_states.cpu().numpy(), res.filtered_covs.cpu().numpy())
+    assert_allclose(sa, na, rtol=1e-9, atol=1e-9)
+    assert_allclose(sP, nP, rtol=1e-9, atol=1e-9)
+
+
+def test_smoother_behind_the_convergence_point_edges(eng, monkeypatch):
+    """A missing observation late in the series (the filtered covariance of that step differs: the range ends above it), a missing
+    LAST observation (nothing qualifies: the whole series stays in kf_smooth_b4_kernel), draws whose filter never converges, a
+    series that ends inside the first 64-step block, KF_FLAG_EXACT_RECURSION (never split)."""
+    from oracle import kalman_numpy as kn
+
+    w = _never_converging(W.structural(B=40, n=520), [0, 9, 39])
+    for nan_at in ([300], [519], [255, 256, 450], []):
+        y = w["y"].copy()
+        y[nan_at] = np.nan
+        res = eng.forward(y, *[w[k] for k in KEYS], mvn_const="exact", store_predicted=False, store_ll_obs=False)
+        sa, sP, xa, xP = _smooth_both(eng, monkeypatch, w, res)
+        assert _rel(sa, xa) < 1e-11 and _rel(sP, xP) < 1e-11, (nan_at, _rel(sa, xa), _rel(sP, xP))
+        if nan_at == [519]:
+            assert np.array_equal(sa, xa) and np.array_equal(sP, xP)   # P_f[n-1] is a one-off: every step in the sequential kernel
+        na, nP = kn.kalman_smoother(w["T"], w["R"], w["Q"], res.filtered_states.cpu().numpy(), res.filtered_covs.cpu().numpy())
+        ok = [b for b in range(40) if b not in (0, 9, 39)]   # (the diffuse draws, P0 = 1e3 I with Q ~ 1e-9: cond(P_hat) ~ 1e8, both paths
+        assert_allclose(sa[ok], na[ok], rtol=1e-9, atol=1e-9)   #  sit 1e-7 from the oracle's solve there -- and 1e-11 from each other)
+        assert_allclose(sP[ok], nP[ok], rtol=1e-9, atol=1e-9)
+        assert_allclose(sa, na, rtol=1e-5, atol=1e-5)
+    ws = W.structural(B=12, n=150)
+    res = eng.forward(*[ws[k] for k in ("y",) + KEYS], mvn_const="exact", store_predicted=False, store_ll_obs=False)
+    sa, sP, xa, xP = _smooth_both(eng, monkeypatch, ws, res)
+    assert _rel(sa, xa) < 1e-11 and _rel(sP, xP) < 1e-11
+    sa, sP, xa, xP = _smooth_both(eng, monkeypatch, ws, res, exact_recursion=True)
+    assert np.array_equal(sa, xa) and np.array_equal(sP, xP)
+
+
+def test_smoother_split_is_the_default_for_long_series_and_keeps_the_pinv_fallback(eng, monkeypatch):
+    """>= 1536 steps: AUTO takes the split (bitwise the forced run).  A draw whose P_hat is singular fails the Cholesky pivot test
+    and is left to kf_smooth_b4_kernel and the pseudo-inverse kernel behind it, next to draws that take the split."""
+    from oracle import kalman_numpy as kn
+
+    w = W.structural(B=24, n=1600)
+    res = eng.forward(*[w[k] for k in ("y",) + KEYS], mvn_const="exact", store_predicted=False, store_ll_obs=False)
+    args = (w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
+    da, dP = eng.smooth(*args)
+    monkeypatch.setenv("KF_SMOOTHER_SPLIT", "1")
+    fa, fP = eng.smooth(*args)
+    monkeypatch.setenv("KF_SMOOTHER_SPLIT", "0")
+    xa, xP = eng.smooth(*args)
+    monkeypatch.delenv("KF_SMOOTHER_SPLIT")
+    assert np.array_equal(da.cpu().numpy(), fa.cpu().numpy()) and np.array_equal(dP.cpu().numpy(), fP.cpu().numpy())
+    assert not np.array_equal(dP.cpu().numpy(), xP.cpu().numpy())
+    assert _rel(da.cpu().numpy(), xa.cpu().numpy()) < 1e-11 and _rel(dP.cpu().numpy(), xP.cpu().numpy()) < 1e-11
+    # singular P_hat: two perfectly correlated states inside an m = 6 model
+    ws = W.random_dense(B=6, n=200, p=1, m=6, r=3, seed=5)
+    for b in (1, 4):
+        ws["T"][b, 1, :] = ws["T"][b, 0, :]
+        ws["R"][b, 1, :] = ws["R"][b, 0, :]
+        ws["P0"][b] = 0.0
+        ws["P0"][b, 2:, 2:] = np.eye(4)
+    res = eng.forward(*[ws[k] for k in ("y",) + KEYS], mvn_const="exact", store_predicted=False, store_ll_obs=False)
+    sa, sP, xa, xP = _smooth_both(eng, monkeypatch, ws, res)
+    na, nP = kn.kalman_smoother(ws["T"], ws["R"], ws["Q"], res.filtered_states.cpu().numpy(), res.filtered_covs.cpu().numpy())
+    assert_allclose(sa, na, rtol=1e-7, atol=1e-7)
+    assert_allclose(sP, nP, rtol=1e-7, atol=1e-7)
+    assert_allclose(sa, xa, rtol=1e-7, atol=1e-7)
