@@ -32,10 +32,109 @@
 
 namespace {
 
+// ---- which steps qualify: a guess by bisection, then every covariance of the guessed range compared -------------------------------------
+// (entry e of the last filtered covariance, its tolerance) for this lane's entries e = lane, lane + 64, ...: the rule of the header
+template <int NQ>
+__device__ __forceinline__ void ref_and_tol(const double* __restrict__ pl, int m, int mm, int lane, double tol_rel, double (&ref)[NQ],
+                                            double (&tol)[NQ]) {
+  unsigned pm = 0u;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int e = lane + q * KF_WAVE;
+    ref[q] = e < mm ? pl[e] : 0.0;
+    pm = max(pm, abs_hi(ref[q]));
+  }
+  const double pmax = wave_absmax_hi(pm);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int e = lane + q * KF_WAVE;
+    const int i = e < mm ? e / m : 0, j = e < mm ? e - i * m : 0;
+    tol[q] = fmin(tol_rel * pmax, 1e-12 * sqrt(fabs(pl[i * m + i] * pl[j * m + j])));   // (NaN: nothing ever matches)
+  }
+}
+
+// guess[b] = the first step from which the filtered covariance matches the last one, by bisection (a converged filter stays converged
+// unless an observation is missing later: kf_smooth_b4_verify_kernel below finds such steps); tbad[b] = -1
+__global__ __launch_bounds__(KF_WAVE) void kf_smooth_b4_guess_kernel(const KfSmoothArgs A, int32_t* __restrict__ guess,
+                                                                      int32_t* __restrict__ tbad, const double tol_rel) {
+  constexpr int NQ = 2;   // m <= 10
+  const long b = blockIdx.x;
+  const int lane = threadIdx.x, m = A.m, mm = m * m, n = A.T;
+  const double* gfP = A.filt_P + b * (long)n * mm;
+  double ref[NQ], tol[NQ];
+  ref_and_tol<NQ>(gfP + (long)(n - 1) * mm, m, mm, lane, tol_rel, ref, tol);
+  int lo = 0, hi = n - 1;   // invariant: step lo - 1 does not match (or lo == 0), step hi does
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    bool off = false;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int e = lane + q * KF_WAVE;
+      if (e < mm) off = off || !(fabs(gfP[(long)mid * mm + e] - ref[q]) <= tol[q]);
+    }
+    if (__ballot(off) != 0ull) lo = mid + 1;
+    else hi = mid;
+  }
+  if (lane == 0) {
+    guess[b] = lo;
+    tbad[b] = -1;
+  }
+}
+
+// one wavefront per (64-step block, draw): the block's filtered covariances against the last one; tbad[b] = the latest step that differs.
+// (reference, tolerance) pairs in LDS, one ds_read_b128 per element; M a template parameter: the element -> entry index is a
+// multiply-shift (the first version, runtime m and three cached loads per element, ran at 2 TB/s)
+template <int M>
+__global__ __launch_bounds__(KF_WAVE) void kf_smooth_b4_verify_kernel(const KfSmoothArgs A, const int32_t* __restrict__ guess,
+                                                                       int32_t* __restrict__ tbad, const double tol_rel) {
+  constexpr int MM = M * M, NQ = (MM + KF_WAVE - 1) / KF_WAVE;
+  __shared__ __attribute__((aligned(16))) double sRef[2 * MM];
+  const long b = blockIdx.y;
+  const int lane = threadIdx.x, n = A.T;
+  const int te = n - 1 - KF_WAVE * (int)blockIdx.x;   // steps [tb, te), as kf_smooth_b4_steady_kernel's blocks
+  const int gs = guess[b];
+  if (te <= gs) return;
+  const int tb = te > KF_WAVE ? te - KF_WAVE : 0;
+  const int lo = tb > gs ? tb : gs;
+  const double* gfP = A.filt_P + b * (long)n * MM;
+  double ref[NQ], tol[NQ];
+  ref_and_tol<NQ>(gfP + (long)(n - 1) * MM, M, MM, lane, tol_rel, ref, tol);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    if (lane + q * KF_WAVE < MM) {
+      sRef[2 * (lane + q * KF_WAVE)] = ref[q];
+      sRef[2 * (lane + q * KF_WAVE) + 1] = tol[q];
+    }
+  wave_lds_fence();
+  const double* blk = gfP + (long)lo * MM;
+  const int cnt = (te - lo) * MM;
+  int bad = -1;
+  constexpr int UNR = 10;
+  for (int e0 = lane; e0 < cnt; e0 += UNR * KF_WAVE) {
+    double v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int e = e0 + u * KF_WAVE;
+      v[u] = e < cnt ? blk[e] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int e = e0 + u * KF_WAVE;
+      const int tt = e / MM, idx = e - tt * MM;
+      const double2_t rt = *reinterpret_cast<const double2_t*>(sRef + 2 * idx);
+      if (e < cnt && !(fabs(v[u] - rt.x) <= rt.y)) bad = max(bad, lo + tt);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off; off >>= 1) bad = max(bad, __shfl_xor(bad, off));
+  if (lane == 0 && bad >= 0) atomicMax(tbad + b, bad);
+}
+
 template <int M>
 __global__ __launch_bounds__(KF_WAVE) void kf_smooth_b4_steady_kernel(const KfSmoothArgs A, int32_t* __restrict__ start,
                                                                        int32_t* __restrict__ fill_rng, double* __restrict__ Pinf,
-                                                                       const double tol_rel) {
+                                                                       const double tol_rel, const int32_t* __restrict__ guess,
+                                                                       const int32_t* __restrict__ tbad_all) {
   constexpr int MM = M * M;
   __shared__ __attribute__((aligned(16))) double sG[6 * MM + 2];   // G^(2^k), row-major
   __shared__ __attribute__((aligned(16))) double sRef[2 * MM];     // (P_f[n-1], tolerance) entry by entry
@@ -212,36 +311,17 @@ __global__ __launch_bounds__(KF_WAVE) void kf_smooth_b4_steady_kernel(const KfSm
   double* sD = sPs;         // D = P_s - P_hat
   for (int e = lane; e < MM; e += KF_WAVE) sD[e] = sP[e] - sPh[e];
   wave_lds_fence();
+  const int t_lim = max(guess[b], tbad_all[b] + 1);
   bool conv = false;   // the covariance recursion has stopped moving: P_s[t] = its last value for every t <= t_c
   int t_c = n - 1, st = n - 1;
   for (int te = n - 1; te > 0; te -= KF_WAVE) {
     const int tb = te > KF_WAVE ? te - KF_WAVE : 0;
     const int cnt = te - tb;
-    // (1) the filtered covariances of the block against P_f[n-1]
-    int tbad = -1;
-    {
-      const double* blk = gfP + (long)tb * MM;
-      constexpr int UNR = 10;   // loads in flight per lane: one at a time, the loop is a chain of HBM latencies (2 ms per launch, measured)
-      for (int e0 = lane; e0 < cnt * MM; e0 += UNR * KF_WAVE) {
-        double v[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          const int e = e0 + u * KF_WAVE;
-          v[u] = e < cnt * MM ? blk[e] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          const int e = e0 + u * KF_WAVE;
-          const int tt = e / MM, idx = e - tt * MM;
-          const double2_t rt = *reinterpret_cast<const double2_t*>(sRef + 2 * idx);
-          if (e < cnt * MM && !(fabs(v[u] - rt.x) <= rt.y)) tbad = max(tbad, tb + tt);
-        }
-      }
-#pragma unroll
-      for (int off = 32; off; off >>= 1) tbad = max(tbad, __shfl_xor(tbad, off));
-    }
+    // (1) the steps of the block whose filtered covariance is P_f[n-1] within tolerance: those from t_lim on (kf_smooth_b4_guess_kernel
+    // / _verify_kernel: every covariance from the guess on has been compared)
+    const int tbad = t_lim > tb ? t_lim - 1 : -1;
     const int nvalid = tbad < 0 ? cnt : te - 1 - tbad;   // lanes 0 .. nvalid-1 hold steps above the mismatch
-    if (nvalid == 0) break;
+    if (nvalid <= 0) break;
     // (2) means
     {
       const bool act = lane < cnt;
@@ -376,10 +456,10 @@ bool kf_smoother_b4_split_ok(const KfSmoothArgs& a) {
   return a.T >= 1536;
 }
 
-// [start B | fill range 2 B | launch order B | P_inf B m^2]
+// [start B | fill range 2 B | launch order B | guess B | latest mismatch B | P_inf B m^2]
 size_t kf_smoother_b4_split_workspace_bytes(long B, int m) {
   const size_t seg = (sizeof(int32_t) * (size_t)B + 63) & ~(size_t)63;
-  return 4 * seg + sizeof(double) * (size_t)B * m * m + 256;
+  return 6 * seg + sizeof(double) * (size_t)B * m * m + 256;
 }
 
 int kf_launch_smoother_b4_steady(kf_handle* h, const KfSmoothArgs& a, void* ws, int32_t** start, int32_t** list, hipStream_t stream) {
@@ -388,14 +468,32 @@ int kf_launch_smoother_b4_steady(kf_handle* h, const KfSmoothArgs& a, void* ws, 
   int32_t* st = reinterpret_cast<int32_t*>(w); w += seg;
   int32_t* rng = reinterpret_cast<int32_t*>(w); w += 2 * seg;
   int32_t* ord = reinterpret_cast<int32_t*>(w); w += seg;
+  int32_t* gss = reinterpret_cast<int32_t*>(w); w += seg;
+  int32_t* tbd = reinterpret_cast<int32_t*>(w); w += seg;
   double* pinf = reinterpret_cast<double*>(w);
   double tol = 1e-14;
   {
     const char* e = kf_env_switch("KF_SMOOTHER_SPLIT_TOL");
     if (e && atof(e) > 0.0) tol = atof(e);
   }
+  hipLaunchKernelGGL(kf_smooth_b4_guess_kernel, dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, gss, tbd, tol);
+  KF_HIP_CHECK(h, hipGetLastError());
+  const int nblk = (a.T - 1 + KF_WAVE - 1) / KF_WAVE;
+  for (long b0 = 0; b0 < a.B; b0 += 65535) {   // (grid.y <= 65535)
+    KfSmoothArgs av = a;
+    const long nb = a.B - b0 < 65535 ? a.B - b0 : 65535;
+    av.filt_P = a.filt_P + b0 * (long)a.T * a.m * a.m;
+#define KF_SV(M_) \
+  case M_: hipLaunchKernelGGL((kf_smooth_b4_verify_kernel<M_>), dim3((unsigned)nblk, (unsigned)nb), dim3(KF_WAVE), 0, stream, av, gss + b0, tbd + b0, tol); break;
+    switch (a.m) {
+      KF_SV(5) KF_SV(6) KF_SV(7) KF_SV(8) KF_SV(9) KF_SV(10)
+      default: return KF_ERR_UNSUPPORTED;
+    }
+#undef KF_SV
+    KF_HIP_CHECK(h, hipGetLastError());
+  }
 #define KF_SS(M_) \
-  case M_: hipLaunchKernelGGL((kf_smooth_b4_steady_kernel<M_>), dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, st, rng, pinf, tol); break;
+  case M_: hipLaunchKernelGGL((kf_smooth_b4_steady_kernel<M_>), dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, st, rng, pinf, tol, gss, tbd); break;
   switch (a.m) {
     KF_SS(5) KF_SS(6) KF_SS(7) KF_SS(8) KF_SS(9) KF_SS(10)
     default: return KF_ERR_UNSUPPORTED;
