@@ -23,7 +23,14 @@ cp gpurun_out/r04_strong_final/strong_proxy.md $O/strong_proxy.md
 scripts/r04/tv_dense.sh > $O/tv_dense_lines.txt 2>&1
 python3 scripts/r04/vg_time.py > $O/vg_time.txt 2>&1
 python3 scripts/r04/vg_time.py sweep > $O/vg_sweep.txt 2>&1
+python3 scripts/r04/vg_time.py hint > $O/vg_placement_hint.txt 2>&1
 scripts/r04/vg_prof.sh > $O/vg_kernel_stats.txt 2>&1
+python3 scripts/r04/smooth_split_check.py c3 > $O/smooth_split_c3.txt 2>&1
+KF_SMOOTHER_SPLIT=1 python3 scripts/r04/smooth_split_check.py headline > $O/smooth_split_headline_forced.txt 2>&1
+( cd /tmp; export TMPDIR=/tmp; for w in headline c3; do
+    KF_SMOOTHER_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/r04_smooth/prof_$w -- python3 $ROOT/scripts/r04/smooth_prof.py $w > /dev/null 2>&1
+    echo "== $w (KF_SMOOTHER_SPLIT=1)"; python3 $ROOT/scripts/kernel_stats.py $ROOT/gpurun_out/r04_smooth/prof_$w 7
+  done ) > $O/smooth_split_kernel_stats.txt 2>&1
 scripts/r04/c3_run.sh > $O/c3_run.txt 2>&1
 cp gpurun_out/r04_c3/c3_split_timeline.txt $O/c3_split_timeline.txt
 python3 -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1
