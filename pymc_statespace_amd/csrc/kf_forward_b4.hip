@@ -370,7 +370,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     }
 #pragma unroll
     for (int off = 32; off; off >>= 1) tn = max(tn, __shfl_xor(tn, off));
-    t_free = tn + 1;
+    t_free = __builtin_amdgcn_readfirstlane(tn + 1);   // (wave-uniform: the convergence test's branch is a scalar one)
     if (SS == 2 && lane == 0) A.hs_tfree[b] = t_free;
   }
 

@@ -1457,7 +1457,8 @@ def test_auto_kernel_selection(eng):
     assert name(4096, 1000, 3, 30, 5, "standard", False) == "kf_fwd_mfma_nb_kernel"    # dense H: whitened (kf_forward_whiten.hip)
     assert name(4096, 1000, 1, 49, 5) == "kf_fwd_mfma_wg_kernel"
     assert name(4096, 1000, 1, 64, 5) == "kf_fwd_mfma_wg_kernel"
-    assert name(4096, 1000, 3, 60, 5, "standard", False) == "big_gemm_kernel"      # dense H
+    assert name(4096, 1000, 3, 60, 5, "standard", False) == "kf_fwd_mfma_wg_kernel"   # dense H: whitened
+    assert name(4096, 1000, 9, 60, 5, "standard", False) == "big_gemm_kernel"         # dense H, p > 8: no whitening
     assert name(4096, 1000, 1, 65, 5) == "big_gemm_kernel"
     assert name(16384, 1000, 5, 15, 5, "standard", True) == "kf_fwd_b4q_kernel"    # C4
     assert name(16384, 1000, 5, 10, 5, "standard", True) == "kf_fwd_b4q_kernel"

@@ -259,7 +259,7 @@ def _fwd_np(res):
 
 @pytest.mark.parametrize("ft", ["standard", "cholesky"])
 @pytest.mark.parametrize("mvn", ["exact", "reference"])
-@pytest.mark.parametrize("shape", [(2, 4, 2), (3, 9, 3), (5, 15, 5), (5, 10, 5), (8, 12, 4), (4, 20, 6), (3, 33, 5)])
+@pytest.mark.parametrize("shape", [(2, 4, 2), (3, 9, 3), (5, 15, 5), (5, 10, 5), (8, 12, 4), (4, 20, 6), (3, 33, 5), (3, 60, 5)])
 def test_dense_H_runs_on_the_scalar_observation_kernels_by_whitening(eng, monkeypatch, ft, mvn, shape):
     """Reference Standard / Cholesky updates with any positive definite H (kalman_filter.py:262-275, 289-305): the whitened path
     against the numpy oracle (1e-8 on logp, 1e-9 on tapes and ll_obs) and against the dense LDS kernel it replaces, with whole
