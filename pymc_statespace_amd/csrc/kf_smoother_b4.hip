@@ -352,6 +352,21 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
       if (rnorm > 0.5 * rprev && rnorm <= 1e-7) break;
       if (++it > SB4_MAXIT || !(rnorm == rnorm)) bad = true;
     }
+    // A numerically singular P_hat (cond >~ 1e10: rank-deficient R Q R' behind a long series) is not for this kernel: its residual
+    // test passes -- |I - P_hat X| stays small in the directions that matter least -- while the error of X along the near-null
+    // directions makes the smoothed recursion itself unstable (a fuzz case with cond = 1.4e12, profiles/r04/fuzz_summary_b.txt: the
+    // smoothed covariance grew fivefold per step to 1e30 where the reference's pinv stays at 1e0).  ||X||_inf ||P_hat||_1 (the norm of
+    // the last cold start: P_hat moves slowly) at every cold start and every 32nd step (at every step that iterated it cost the
+    // headline 5 %: the slow draws iterate at every step and set the launch's length; a flagged draw is redone as a whole, so when the
+    // flag is raised does not matter); such a draw goes to the pseudo-inverse kernel behind this one.
+#ifndef KF_NO_COND_GUARD
+    if ((cold || (t & 31) == 0) && !bad) {
+      double xs_ = 0.0;
+#pragma unroll
+      for (int I = 0; I < NB; ++I) xs_ = fmax(xs_, row_allsum(on_mm[I] ? fabs(X[I]) : 0.0));
+      if (!(uniform_f64(wave_allmax_dpp(xs_)) * s_pad < 1e10)) bad = true;
+    }
+#endif
     have_x = true;
     if (bad) break;
     have_ref = !A.exact;
