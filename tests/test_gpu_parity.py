@@ -1462,7 +1462,7 @@ def test_auto_kernel_selection(eng):
     assert name(4096, 1000, 1, 65, 5) == "big_gemm_kernel"
     assert name(16384, 1000, 5, 15, 5, "standard", True) == "kf_fwd_b4q_kernel"    # C4
     assert name(16384, 1000, 5, 10, 5, "standard", True) == "kf_fwd_b4q_kernel"
-    assert name(16384, 1000, 5, 15, 5, "standard", False) == "kf_fwd_lds_kernel"   # dense H
+    assert name(16384, 1000, 5, 15, 5, "standard", False) == "kf_fwd_b4q_kernel"   # dense H: whitened (C4 with a dense H)
     assert name(16384, 1000, 5, 15, 5, "univariate", False) == "kf_fwd_b4q_kernel"
     assert name(16384, 1000, 3, 8, 3, "standard", True) == "kf_fwd_rowsplit_mp_kernel"  # m <= 8: packed rows once the batch fills the chip
     assert name(1024, 1000, 3, 8, 3, "standard", True) == "kf_fwd_b4q_kernel"
