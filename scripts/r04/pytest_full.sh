@@ -1,0 +1,5 @@
+#!/bin/bash
+# the full GPU suite at the stamped commit -> gpurun_out/r04_final/pytest_gpu.txt
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT; O=$ROOT/gpurun_out/r04_final; mkdir -p $O
+python3 -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1
+tail -3 $O/pytest_gpu.txt; cat .kf_commit
