@@ -623,6 +623,28 @@ static bool kf_vg_steady_path(const kf_handle* h, const kf_dims* d) {
   return kf_backward_steady_ok(d->m, d->p, d->r) && d->m <= KF_MP_M_MAX;
 }
 
+// value-and-gradient behind the LANE kernel (p == 1, m <= 4 where AUTO does not take the block kernels: C2) with the steady-state
+// adjoint: the lane kernel reports where each draw's steady-state phase starts and writes every slot of the compact tapes;
+// kf_bwd_steady_scan_kernel takes the steps behind that point (a_t and the converged covariance from the tapes), kf_dare_bwd_kernel
+// the Riccati adjoint, kf_bwd_b4_kernel (compact tapes, per-draw step counts, snake order) the steps before it.  C2 (ARMA(1,1),
+// 4096 x 1000): 1.12 -> 0.59 ms.  KF_VG_STEADY=0 / KF_FLAG_EXACT_RECURSION: the full sweep as before; =1 / KF_FLAG_STEADY_STATE: any batch.
+static bool kf_vg_lane_steady_path(const kf_handle* h, const kf_dims* d) {
+  if ((d->flags & (KF_FLAG_TV_ANY | KF_FLAG_EXACT_RECURSION)) || d->T < 64 || d->p != 1 || d->m > KF_LANE_M_MAX) return false;
+  if (d->B > 0x7fffffffL) return false;
+  if (h->forward_kernel != KF_KERNEL_AUTO && h->forward_kernel != KF_KERNEL_LANE) return false;
+  if (kf_b4_selected(h, d->m, d->p, d->r, d->B)) return false;   // (the tile-tape path)
+  const char* e = kf_env_switch("KF_VG_STEADY");
+  if (e && e[0] == '0') return false;
+  const char* sse = kf_env_switch("KF_STEADY_STATE");
+  if (sse && *sse && atoi(sse) == 0) return false;
+  if (!(kf_backward_steady_scan_ok(d->m, d->p) && kf_backward_b4_ok(d->m, d->p, d->r))) return false;
+  if ((d->flags & KF_FLAG_STEADY_STATE) || (e && e[0] == '1') || (sse && atoi(sse) != 0)) return true;
+  // AUTO: up to two rounds of the chip's wavefront slots -- the sweep before the convergence point runs one wavefront per draw, the
+  // full sweep it replaces packs 64 / m^2 draws into one.  Measured (ARMA(1,1) x 1000 steps, ms, this path ; the full sweep):
+  // 512 draws 0.49 ; 0.98, 4096 (C2) 0.59 ; 1.31 (1.12 with the round-3 default), 16384 1.77 ; 1.56; m = 1 / 3 at 4096: 0.98 ; 2.14, 1.66 ; 2.60
+  return d->B <= 32L * (h->n_cu > 0 ? h->n_cu : 256);
+}
+
 // value-and-gradient through the tile tape WITH the steady-state adjoint (p == 1, m <= 10: the block kernel's tapes go through its LDS
 // rings): the forward kernel reports each draw's convergence point ts, leaves the tile tape of steps < ts and a_t of steps >= ts;
 // kf_bwd_steady_kernel + kf_dare_bwd_kernel take the steps behind ts, kf_bwd_b4_kernel (per-draw step counts) the steps before it.
@@ -659,6 +681,11 @@ extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, i
     if (kf_vg_steady_path(h, dims)) {
       const size_t B = (size_t)dims->B, m = (size_t)dims->m;
       *bytes += kf_vg_round(4 * B) + kf_vg_round(8 * B * m) + 2 * kf_vg_round(8 * B * m * m);
+    }
+    if (kf_vg_lane_steady_path(h, dims)) {
+      const size_t B = (size_t)dims->B, m = (size_t)dims->m;
+      *bytes += 2 * kf_vg_round(4 * B) + kf_vg_round(8 * B * m) + 2 * kf_vg_round(8 * B * m * m) +
+                kf_backward_b4_workspace_bytes(dims->B, dims->m) + 64;
     }
     return KF_OK;
   }
@@ -1000,6 +1027,51 @@ extern "C" int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims, const
     a.init_ab = s_ab;
     a.accumulate = 1;
     return kf_launch_backward(h, a, w, inner_s, (hipStream_t)stream);
+  }
+  if (kf_vg_lane_steady_path(h, dims)) {
+    // [.. | ts B | order B | lam_ts B m | P_b B m^2 | P B m^2 | the block adjoint's hand-over | inner]
+    KF_ON_DEVICE(h);
+    int32_t* ts = reinterpret_cast<int32_t*>(w); w += kf_vg_round(4 * B);
+    int32_t* order = reinterpret_cast<int32_t*>(w); w += kf_vg_round(4 * B);
+    double* s_ab = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * m);
+    double* s_Pb = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * m * m);
+    double* s_P = reinterpret_cast<double*>(w); w += kf_vg_round(8 * B * m * m);
+    const size_t inner_l = workspace_bytes - (size_t)(w - reinterpret_cast<char*>(workspace));
+    KfFwdArgs f;
+    f.B = dims->B; f.T = dims->T; f.p = dims->p; f.m = dims->m; f.r = dims->r; f.filter = dims->filter; f.flags = dims->flags;
+    f.y = y; f.a0 = a0; f.P0 = P0; f.Tm = T; f.Z = Z; f.R = R; f.H = H; f.Q = Q; f.c = c; f.d = d;
+    f.logp = logp; f.ll_obs = nullptr; f.filt_a = nullptr; f.pred_a = pred_a; f.filt_P = nullptr; f.pred_P = pred_P;
+    f.info = info; f.tile_tape = nullptr; f.hs_ts = ts;
+    switch (dims->m) {
+      case 1: rc = kf_launch_forward_lane_m1(h, f, (hipStream_t)stream); break;
+      case 2: rc = kf_launch_forward_lane_m2(h, f, (hipStream_t)stream); break;
+      case 3: rc = kf_launch_forward_lane_m3(h, f, (hipStream_t)stream); break;
+      default: rc = kf_launch_forward_lane_m4(h, f, (hipStream_t)stream); break;
+    }
+    if (rc) return rc;
+    if (!g_logp) {
+      hipLaunchKernelGGL(kf_fill_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ones,
+                         (long)B, 1.0);
+      KF_HIP_CHECK(h, hipGetLastError());
+      g_logp = ones;
+    }
+    KfBwdArgs a;
+    a.B = dims->B; a.T = dims->T; a.p = dims->p; a.m = dims->m; a.r = dims->r; a.filter = dims->filter; a.flags = dims->flags;
+    a.y = y; a.a0 = a0; a.P0 = P0; a.Tm = T; a.Z = Z; a.R = R; a.H = H; a.Q = Q; a.c = c; a.d = d;
+    a.pred_a = pred_a; a.pred_P = pred_P; a.g_logp = g_logp; a.g_ll_obs = nullptr;
+    a.g_a0 = g_a0; a.g_P0 = g_P0; a.g_T = g_T; a.g_Z = g_Z; a.g_R = g_R; a.g_H = g_H; a.g_Q = g_Q; a.g_c = g_c; a.g_d = g_d;
+    a.tape_T = dims->T; a.y_T = dims->T; a.tile_tape = nullptr; a.init_ab = nullptr; a.init_Pb = nullptr; a.accumulate = 0;
+    hipLaunchKernelGGL(kf_vg_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ts, (int)dims->T, (int)dims->B,
+                       4 * (h->n_cu > 0 ? h->n_cu : 256), order, (int32_t*)nullptr, 0, 0);
+    KF_HIP_CHECK(h, hipGetLastError());
+    a.list = order;
+    rc = kf_launch_backward_steady(h, a, ts, s_ab, s_Pb, s_P, (hipStream_t)stream);   // writes every gradient (zeros where it has none)
+    if (rc) return rc;
+    rc = kf_launch_dare_backward(h, dims->B, dims->m, dims->p, dims->r, T, Z, R, H, Q, s_P, s_Pb, g_T, g_Z, g_R, g_H, g_Q,
+                                 /*accumulate=*/1, nullptr, (hipStream_t)stream, /*h_diag_only=*/1);
+    if (rc) return rc;
+    a.steps = ts; a.init_ab = s_ab; a.accumulate = 1;
+    return kf_launch_backward_b4(h, a, w, inner_l, (hipStream_t)stream);
   }
   rc = kf_filter_forward(h, dims, y, a0, P0, T, Z, R, H, Q, c, d, logp, nullptr, nullptr, pred_a, nullptr, pred_P, info,
                          w, inner, stream);

@@ -409,7 +409,8 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_steady_scan_kernel(const KfBwd
   const int n = A.T, r_ = A.r;
   const int ts = ts_all[b] < n ? ts_all[b] : n;
   const double* gpa = A.pred_a + b * (long)(A.tape_T + 1) * M;
-  const double* gpP = P_conv + b * (long)MM;
+  // the converged covariance: handed over (block kernel), or slot ts of the compact predicted tape (lane kernel: every slot written)
+  const double* gpP = P_conv ? P_conv + b * (long)MM : A.pred_P + (b * (long)(A.tape_T + 1) + (ts < n ? ts : n)) * MM;
   const double* gT = A.Tm + b * (long)MM;
   const double* gZ = A.Z + b * (long)M;
   const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;  // :335 quirk: y_hat = Z a - d
@@ -715,7 +716,7 @@ int kf_launch_backward_steady(kf_handle* h, const KfBwdArgs& a, const int32_t* t
   }
   // p == 1, m <= 10 with the converged covariance handed over (the p == 1 block kernel's value-and-gradient): the time-parallel form
   {
-    if (P_conv && kf_backward_steady_scan_ok(a.m, a.p)) {
+    if ((P_conv || a.pred_P) && kf_backward_steady_scan_ok(a.m, a.p)) {
 #define KF_SS_LAUNCH(M_) \
   case M_: hipLaunchKernelGGL((kf_bwd_steady_scan_kernel<M_>), dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, ts, out_ab, out_Pb, out_P, P_conv); break;
       switch (a.m) {

@@ -239,6 +239,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
     t_free = tn + 1;
   }
   bool fz = false;
+  int ts_own = n;   // first step of this lane's draw in the steady-state phase (KfFwdArgs::hs_ts: the steady-state adjoint's steps)
   double Pold[M][M];
   // DPW == 4 (SCAN): a frozen draw slot takes the sixteen steps of a block SIDE BY SIDE on its sixteen lanes.  The steady recursion
   // is affine,  a_{t+1} = A a_t + w_t,  A = T - (T K) Z,  w_t = (T K)(y_t -+ d) + c,  so  a_{t+j} = A^j a_t + sum_{i<j} A^{j-1-i} w_{t+i}:
@@ -547,6 +548,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
           if (newly) freeze_consts(t + 1);
         }
         fz = fz || newly;
+        if (newly) ts_own = t + 1;
         if (__all(fz)) {
           ++t;
           break;
@@ -567,6 +569,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
   } else if (t < n) {
     // ---- steady-state steps t .. n-1 (t is a multiple of S), one after the other ----------------------------------------------------
     freeze_consts(t);
+    ts_own = t;   // (every slot of the wavefront changes over here)
     const bool degenerate = zDegen;
     const double Fraw = zFraw, invF = zInvF;
     double K[M];
@@ -622,6 +625,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
   if (owner && live) {
     A.logp[b] = smem[L::OFF_ACC + d];
     if (A.info) A.info[b] = info;
+    if (A.hs_ts) A.hs_ts[b] = ts_own;
   }
 }
 

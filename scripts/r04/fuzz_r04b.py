@@ -5,7 +5,9 @@
           never-converging draws, per-draw series
   smooth  RTS smoother with the time-parallel kernels behind the filter's convergence point forced (KF_SMOOTHER_SPLIT=1) against every
           step in kf_smooth_b4_kernel and the numpy oracle; tapes of an every-step and of a steady-state forward, missing observations
-          anywhere (also the last one), slow draws, 5 <= m <= 10"""
+          anywhere (also the last one), slow draws, 5 <= m <= 10
+  lane    logp + gradient behind the lane kernel (m <= 3 where AUTO keeps it; m = 4 with the lane kernel forced): the default -- steady-
+          state adjoint behind each draw's convergence point, exact sweep over the compact tapes before it -- against the full sweep"""
 import os
 import sys
 import time
@@ -23,8 +25,8 @@ GRADS = ("a0", "P0", "T", "Z", "R", "H", "Q", "c", "d")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 41)
 eng = KalmanEngine()
-worst = dict(vgs_vs_exact=0.0, smooth_vs_every_step=0.0, smooth_vs_oracle=0.0)
-counts = dict(vgs=0, smooth=0, smooth_split_taken=0)
+worst = dict(vgs_vs_exact=0.0, smooth_vs_every_step=0.0, smooth_vs_oracle=0.0, lane_vs_exact=0.0)
+counts = dict(vgs=0, smooth=0, smooth_split_taken=0, lane=0, lane_steady_taken=0)
 flagged = 0
 t0 = time.time()
 
@@ -45,7 +47,7 @@ def slow(w, idx):
 
 
 for case in range(n_cases):
-    kind = int(rng.integers(0, 2))
+    kind = int(rng.integers(0, 3))
     seed = int(rng.integers(1 << 30))
     n = int(rng.choice([64, 65, 100, 127, 128, 129, 191, 200, 320, 700]))
     B = int(rng.choice([1, 3, 20, 70]))
@@ -90,6 +92,44 @@ for case in range(n_cases):
             print(f"FLAG vgs case {case} seed {seed}: {w['name']} m={m} r={w['r']} n={n} B={B} {ft} y{y.shape} c={c is not None} d={d is not None} "
                   f"gl={gl is not None}: vs exact {e:.2e} in {ewhere} draw {bb}: {a_[bb][:4]} vs {x_[bb][:4]}; logp {lp[bb].item():.6g} "
                   f"{lpx[bb].item():.6g} nan rows {np.argwhere(np.isnan(y.reshape(-1, n)[0] if y.ndim == 3 else y[:, 0])).ravel()[:6]}", flush=True)
+    elif kind == 2:   # ---- value and gradient behind the lane kernel ---------------------------------------------------------------------
+        m = int(rng.integers(1, 5))
+        r = int(rng.integers(1, 3))
+        B = int(rng.choice([1, 3, 5, 20, 70, 300]))
+        ft = str(rng.choice(["standard", "cholesky", "univariate", "single"]))
+        w = W.arma11(B=B, n=n, seed=seed) if (m == 2 and rng.integers(0, 2)) else W.random_dense(B, n, 1, m, r, seed=seed)
+        m = w["m"]
+        y = w["y"].copy()
+        if rng.integers(0, 4) == 0:
+            y = y[None] + 0.1 * rng.standard_normal((B,) + y.shape)
+        for _ in range(int(rng.integers(0, 3))):
+            y[..., rng.integers(0, n), :] = np.nan
+        c = 0.05 * rng.standard_normal((B, m)) if rng.integers(0, 2) else None
+        d = 0.1 * rng.standard_normal((B, 1)) if rng.integers(0, 2) else None
+        gl = 1.0 + 0.3 * rng.standard_normal(B) if rng.integers(0, 2) else None
+        args = (y,) + tuple(w[x] for x in KEYS)
+        kw = dict(c=c, d=d, g_logp=gl, filter_type=ft, mvn_const="exact")
+        eng.set_forward_kernel("lane")
+        try:
+            lp, info, g = eng.value_and_grad(*args, **kw)
+            lpx, infox, gx = eng.value_and_grad(*args, exact_recursion=True, **kw)
+        finally:
+            eng.set_forward_kernel("auto")
+        e = rel_rows(lp.cpu().numpy()[:, None], lpx.cpu().numpy()[:, None])
+        ewhere = "logp"
+        taken = False
+        for nm in GRADS:
+            taken = taken or not np.array_equal(g[nm].cpu().numpy(), gx[nm].cpu().numpy())
+            en = rel_rows(g[nm].cpu().numpy(), gx[nm].cpu().numpy())
+            if not (en <= e):
+                e, ewhere = en, nm
+        worst["lane_vs_exact"] = max(worst["lane_vs_exact"], e)
+        counts["lane"] += 1
+        counts["lane_steady_taken"] += int(taken)
+        if not (e <= 1e-10) or not np.array_equal(info.cpu().numpy(), infox.cpu().numpy()):
+            flagged += 1
+            print(f"FLAG lane case {case} seed {seed}: {w['name']} m={m} r={w['r']} n={n} B={B} {ft} y{y.shape} c={c is not None} d={d is not None}: "
+                  f"vs the full sweep {e:.2e} in {ewhere}", flush=True)
     else:   # ---- smoother, split forced --------------------------------------------------------------------------------------------------
         m = int(rng.integers(5, 11))
         r = int(rng.integers(1, 5))

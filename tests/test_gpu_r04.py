@@ -529,3 +529,77 @@ def test_block_smoother_hands_numerically_singular_draws_to_the_pinv_kernel(eng,
     finally:
         eng.set_forward_kernel("auto")
     assert_allclose(sP[4], lP[4], rtol=1e-9, atol=1e-9)   # the flagged draw IS the pseudo-inverse kernel's
+
+
+# ---- logp + gradient behind the lane kernel (m <= 4) with the steady-state adjoint -------------------------------------------------------
+@pytest.mark.parametrize("ft", ["standard", "cholesky", "univariate", "single"])
+@pytest.mark.parametrize("m", [1, 2, 3])
+def test_value_and_grad_behind_the_lane_kernel_with_the_steady_state_adjoint(eng, monkeypatch, m, ft):
+    """AUTO keeps m <= 3 on the lane kernel; its value-and-gradient call now takes the steps behind each draw's convergence point
+    with kf_bwd_steady_scan_kernel (a_t and the converged covariance from the compact tapes) + the Riccati adjoint and sweeps only
+    the steps before it (kf_bwd_b4_kernel on the compact tapes, per-draw step counts).  Against the full sweep (1e-10), torch
+    autograd on the first draws (1e-9); intercepts, a missing observation, per-draw cotangents; more draws than one wavefront
+    packs and a batch that is not a multiple of it."""
+    from oracle import kalman_torch as kt
+
+    nb = 2100 if m == 3 else 37   # (AUTO hands m = 3 to the block kernels up to 2048 draws)
+    w = W.arma11(B=nb, n=300) if m == 2 else W.random_dense(B=nb, n=300, p=1, m=m, r=1, seed=60 + m)
+    y = w["y"].copy()
+    y[9] = np.nan
+    rng = np.random.default_rng(m)
+    B = w["B"]
+    c, d = 0.05 * rng.standard_normal((B, m)), 0.1 * rng.standard_normal((B, 1))
+    gl = 1.0 + 0.3 * rng.standard_normal(B)
+    args = (y,) + tuple(w[x] for x in KEYS)
+    kw = dict(c=c, d=d, g_logp=gl, filter_type=ft, mvn_const="exact")
+    assert eng.forward_kernel_name(B, 300, 1, m, w["r"], filter_type=ft) == "kf_fwd_lane_kernel"
+    lp, info, g = eng.value_and_grad(*args, **kw)
+    lpx, infox, gx = eng.value_and_grad(*args, exact_recursion=True, **kw)
+    assert not info.cpu().numpy().any() and not infox.cpu().numpy().any()
+    assert_allclose(lp.cpu().numpy(), lpx.cpu().numpy(), rtol=1e-12)
+    differs = False
+    for nm in GRADS:
+        a_, x_ = g[nm].cpu().numpy(), gx[nm].cpu().numpy()
+        differs = differs or not np.array_equal(a_, x_)
+        scale = 1.0 + np.max(np.abs(x_.reshape(B, -1)), axis=1)
+        assert (np.max(np.abs(a_ - x_).reshape(B, -1), axis=1) / scale).max() < 1e-10, nm
+    assert differs, "the steady-state adjoint did not run"
+    k = 3
+    rlp, _, rg = kt.logp_and_grads(y, *[w[x][:k] for x in KEYS], c=c[:k], d=d[:k], filter_type=ft, mvn_const="exact", g_logp=gl[:k])
+    for nm in GRADS:
+        a_, ref = g[nm].cpu().numpy()[:k].reshape(rg[nm].shape), rg[nm]
+        if nm in ("P0", "Q"):
+            a_, ref = a_ + np.swapaxes(a_, -1, -2), ref + np.swapaxes(ref, -1, -2)
+        assert np.max(np.abs(a_ - ref)) / (1.0 + np.max(np.abs(ref))) < 1e-9, f"{nm} vs autograd"
+
+
+def test_value_and_grad_behind_the_lane_kernel_edges(eng, monkeypatch):
+    """Draws that never converge next to draws that do (ts = T: the whole sweep is the exact one), a missing observation late in the
+    series, the switch (KF_VG_STEADY=0) and the batch rule (beyond two rounds of wavefront slots AUTO keeps the packed full sweep:
+    bitwise the flag's result)."""
+    w = W.arma11(B=50, n=400)
+    w["T"][[3, 17]] = np.array([[1.0, 1.0], [0.0, 1.0]])     # a unit root: the predicted covariance keeps growing
+    w["P0"][[3, 17]] = 1e3 * np.eye(2)
+    y = w["y"].copy()
+    y[[20, 300]] = np.nan     # (the phase can start two 16-step blocks behind the last missing observation: step 320 of 400)
+    args = (y,) + tuple(w[x] for x in KEYS)
+    lp, info, g = eng.value_and_grad(*args, mvn_const="exact")
+    lpx, _, gx = eng.value_and_grad(*args, mvn_const="exact", exact_recursion=True)
+    monkeypatch.setenv("KF_VG_STEADY", "0")
+    lps, _, gs = eng.value_and_grad(*args, mvn_const="exact")
+    monkeypatch.delenv("KF_VG_STEADY")
+    assert_allclose(lp.cpu().numpy(), lpx.cpu().numpy(), rtol=1e-12)
+    for nm in GRADS:
+        a_, x_ = g[nm].cpu().numpy(), gx[nm].cpu().numpy()
+        assert np.all(np.isfinite(a_)), nm
+        scale = 1.0 + np.max(np.abs(x_.reshape(50, -1)), axis=1)
+        assert (np.max(np.abs(a_ - x_).reshape(50, -1), axis=1) / scale).max() < 1e-10, nm
+        assert (np.max(np.abs(gs[nm].cpu().numpy() - x_).reshape(50, -1), axis=1) / scale).max() < 1e-10, nm   # the switch: the full sweep
+    assert any(not np.array_equal(g[nm].cpu().numpy(), gs[nm].cpu().numpy()) for nm in GRADS), "the steady-state adjoint did not run"
+    big = W.arma11(B=9000, n=64)
+    argb = (big["y"],) + tuple(big[x] for x in KEYS)
+    _, _, gb = eng.value_and_grad(*argb, mvn_const="exact")
+    monkeypatch.setenv("KF_VG_STEADY", "0")
+    _, _, gbs = eng.value_and_grad(*argb, mvn_const="exact")
+    monkeypatch.delenv("KF_VG_STEADY")
+    assert all(np.array_equal(gb[nm].cpu().numpy(), gbs[nm].cpu().numpy()) for nm in GRADS)   # AUTO: not beyond 32 x CUs draws
