@@ -606,7 +606,12 @@ static bool kf_vg_tile_path(const kf_handle* h, const kf_dims* d) {
   if ((d->flags & KF_FLAG_TV_ANY) || d->T < 2) return false;
   const char* e = kf_env_switch("KF_VG_TILE_TAPE");  // =0: compact tapes (A/B measurements)
   if (e && e[0] == '0') return false;
-  return kf_b4_selected(h, d->m, d->p, d->r, d->B) && kf_backward_b4_selected(h, d->m, d->p, d->r, d->B);
+  if (kf_b4_selected(h, d->m, d->p, d->r, d->B) && kf_backward_b4_selected(h, d->m, d->p, d->r, d->B)) return true;
+  // 5 <= m <= 8 at batches where the FORWARD alone is faster on the packed row kernels (kf_b4_auto): the call as a whole is not --
+  // measured (scripts/r04/vg_rowshapes.py, 500 steps, ms, row forward + row-split adjoint ; block kernels): m = 6 at 16384 / 32768
+  // draws 4.19 ; 1.81 / 8.55 ; 3.48, m = 8 6.04 ; 2.52 / 12.0 ; 4.89 (m <= 4 stays with the lane kernel: 1.67 ; 1.85 at 16384 draws)
+  return h->forward_kernel == KF_KERNEL_AUTO && d->m >= 5 && kf_forward_b4_ok(d->m, d->p, d->r) &&
+         kf_backward_b4_selected(h, d->m, d->p, d->r, d->B);
 }
 
 // value-and-gradient with the steady-state adjoint (kf_backward_steady.hip): the forward kernel must report where its

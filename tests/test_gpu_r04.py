@@ -603,3 +603,28 @@ def test_value_and_grad_behind_the_lane_kernel_edges(eng, monkeypatch):
     _, _, gbs = eng.value_and_grad(*argb, mvn_const="exact")
     monkeypatch.delenv("KF_VG_STEADY")
     assert all(np.array_equal(gb[nm].cpu().numpy(), gbs[nm].cpu().numpy()) for nm in GRADS)   # AUTO: not beyond 32 x CUs draws
+
+
+@pytest.mark.parametrize("m", [5, 6, 8])
+def test_value_and_grad_takes_the_block_kernels_where_the_forward_alone_would_not(eng, m):
+    """16384+ draws of a 5 <= m <= 8 model: AUTO runs the FORWARD alone on the packed row kernels, the value-and-gradient call on
+    the block kernels (tile tape, 2.3 - 2.5 times faster there: scripts/r04/vg_rowshapes.py) -- the same bits as with them forced,
+    and the row-kernel path's numbers to rounding."""
+    B = 20000
+    w = W.random_dense(B, 70, 1, m, 2, seed=m)
+    assert eng.forward_kernel_name(B, 70, 1, m, 2).startswith("kf_fwd_row")
+    args = (w["y"],) + tuple(w[x] for x in KEYS)
+    lp, _, g = eng.value_and_grad(*args, mvn_const="exact")
+    try:
+        eng.set_forward_kernel("b4")
+        lpb, _, gb = eng.value_and_grad(*args, mvn_const="exact")
+        eng.set_forward_kernel("row")
+        lpr, _, gr = eng.value_and_grad(*args, mvn_const="exact")
+    finally:
+        eng.set_forward_kernel("auto")
+    assert np.array_equal(lp.cpu().numpy(), lpb.cpu().numpy())
+    for nm in GRADS:
+        assert np.array_equal(g[nm].cpu().numpy(), gb[nm].cpu().numpy()), nm
+        a_, x_ = g[nm].cpu().numpy(), gr[nm].cpu().numpy()
+        scale = 1.0 + np.max(np.abs(x_.reshape(B, -1)), axis=1)
+        assert (np.max(np.abs(a_ - x_).reshape(B, -1), axis=1) / scale).max() < 1e-10, nm
