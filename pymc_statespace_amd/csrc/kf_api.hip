@@ -623,7 +623,12 @@ static bool kf_vg_steady_path(const kf_handle* h, const kf_dims* d) {
   if (e && e[0] == '0') return false;
   const char* sse = kf_env_switch("KF_STEADY_STATE");
   if (sse && *sse && atoi(sse) == 0) return false;
-  if (!kf_b4q_selected(h, d->m, d->p, d->r, d->filter, d->flags, d->B)) return false;
+  // (m = 8 beyond 2048 draws: the FORWARD alone is faster on the packed multi-observation row kernel, the call is not -- p = 3,
+  // 16384 x 300: 8.84 ms against 6.65 on the block kernels, scripts/r04/vg_dispatch_sweep.py)
+  const char* fe = kf_env_switch("KF_FORWARD_B4Q");
+  const bool for_the_call = h->forward_kernel == KF_KERNEL_AUTO && kf_forward_b4q_ok(d->m, d->p, d->r) &&
+                            (d->filter == KF_FILTER_UNIVARIATE || (d->flags & KF_FLAG_H_DIAGONAL)) && !(fe && *fe && atoi(fe) == 0);
+  if (!kf_b4q_selected(h, d->m, d->p, d->r, d->filter, d->flags, d->B) && !for_the_call) return false;
   if (!(d->p >= 3 && d->p <= 5 && d->m >= 8)) return false;  // (the shapes kf_forward_b4q.hip's steady-state phase covers)
   return kf_backward_steady_ok(d->m, d->p, d->r) && d->m <= KF_MP_M_MAX;
 }
@@ -715,7 +720,8 @@ extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, i
   }
   // forward, multi-observation block kernel with its steady-state phase: hand-over buffers + per-draw constants of the split phase
   if ((which & KF_WS_FORWARD) && !(dims->flags & (KF_FLAG_TV_ANY | KF_FLAG_EXACT_RECURSION)) && p >= 3 && p <= 5 && m >= 8 && m <= 15 &&
-      dims->T >= 64 && kf_b4q_selected(h, m, p, r, dims->filter, dims->flags, dims->B)) {
+      dims->T >= 64 && (kf_b4q_selected(h, m, p, r, dims->filter, dims->flags, dims->B) ||
+                        ((which & KF_WS_BACKWARD) && kf_vg_steady_path(h, dims)))) {
     const size_t sw = kf_b4q_split_workspace_bytes(dims->B);
     if (sw > *bytes) *bytes = sw;
   }

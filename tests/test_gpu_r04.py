@@ -628,3 +628,29 @@ def test_value_and_grad_takes_the_block_kernels_where_the_forward_alone_would_no
         a_, x_ = g[nm].cpu().numpy(), gr[nm].cpu().numpy()
         scale = 1.0 + np.max(np.abs(x_.reshape(B, -1)), axis=1)
         assert (np.max(np.abs(a_ - x_).reshape(B, -1), axis=1) / scale).max() < 1e-10, nm
+
+
+def test_value_and_grad_takes_the_multi_observation_block_kernel_at_m8_large_batches(eng):
+    """p = 3, m = 8 beyond 2048 draws: the forward alone runs on the packed row kernel, the value-and-gradient call on
+    kf_fwd_b4q_kernel + the steady-state adjoint (the same bits as with the block kernels forced)."""
+    B = 5000
+    w = W.random_dense(B, 120, 3, 8, 2, seed=38)
+    assert "rowsplit" in eng.forward_kernel_name(B, 120, 3, 8, 2, h_diagonal=True)
+    args = (w["y"],) + tuple(w[x] for x in KEYS)
+    kw = dict(mvn_const="exact", h_diagonal=True)
+    lp, _, g = eng.value_and_grad(*args, **kw)
+    try:
+        eng.set_forward_kernel("b4")
+        lpb, _, gb = eng.value_and_grad(*args, **kw)
+        eng.set_forward_kernel("row")
+        lpr, _, gr = eng.value_and_grad(*args, **kw)
+    finally:
+        eng.set_forward_kernel("auto")
+    assert np.array_equal(lp.cpu().numpy(), lpb.cpu().numpy())
+    for nm in GRADS:
+        assert np.array_equal(g[nm].cpu().numpy(), gb[nm].cpu().numpy()), nm
+        a_, x_ = g[nm].cpu().numpy(), gr[nm].cpu().numpy()
+        if nm in ("P0", "H"):   # (the block path returns the symmetric / diagonal parts, DESIGN section 3)
+            continue
+        scale = 1.0 + np.max(np.abs(x_.reshape(B, -1)), axis=1)
+        assert (np.max(np.abs(a_ - x_).reshape(B, -1), axis=1) / scale).max() < 1e-9, nm
