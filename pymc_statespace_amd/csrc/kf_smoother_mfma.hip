@@ -30,6 +30,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   const int c = lane & 15, g = lane >> 4;
   const int permc = (c & 3) * 4 + (c >> 2);
   const long b = blockIdx.x;
+  // (behind kf_smooth_b4_kernel: only the draws it flagged -- this kernel's own verdict replaces the flag)
+  if (A.only_flagged && A.only_flagged[b] == 0) return;
   const int n = A.T, r_ = A.r, m = A.m, mm = m * m;
   const bool c_ok = c < m;
 

@@ -507,8 +507,9 @@ def test_block_smoother_hands_numerically_singular_draws_to_the_pinv_kernel(eng,
     """Rank-one state noise behind a long series: cond(P_hat) = 1.4e12 on draw 4 of this batch (found by scripts/r04/fuzz_r04b.py).
     The Newton-Schulz kernel's residual test passed there while the error of its inverse along the near-null directions made the
     smoothed recursion unstable -- 1e30 where the reference's pinv gives 1e0.  The kernel now estimates the conditioning
-    (||X|| ||P_hat||) and hands such a draw to the pseudo-inverse kernel: the result is that kernel's, finite and as close to the
-    oracle as cond x eps allows; the well-conditioned draws of the batch are untouched."""
+    (||X|| ||P_hat||) and hands such a draw to the elimination kernel (and that one, at pivots below 1e-9, to the pseudo-inverse
+    kernel): the result is that kernel's, finite and as close to the oracle as cond x eps allows; the well-conditioned draws of the
+    batch are untouched."""
     from oracle import kalman_numpy as kn
 
     w = W.random_dense(8, 200, 1, 10, 1, seed=618827647)
@@ -523,12 +524,10 @@ def test_block_smoother_hands_numerically_singular_draws_to_the_pinv_kernel(eng,
         err = np.max(np.abs(sP - nP).reshape(8, -1), axis=1) / (1.0 + np.max(np.abs(nP).reshape(8, -1), axis=1))
         assert err[4] < 5e-2, err            # (the elimination kernel and the LDS kernel sit at 1e-2 on this draw as well)
         assert np.all(err[[0, 1, 3, 6, 7]] < 1e-8), err
-    try:
-        eng.set_forward_kernel("lds")
-        la, lP = [x.cpu().numpy() for x in eng.smooth(*args)]
-    finally:
-        eng.set_forward_kernel("auto")
-    assert_allclose(sP[4], lP[4], rtol=1e-9, atol=1e-9)   # the flagged draw IS the pseudo-inverse kernel's
+    monkeypatch.setenv("KF_SMOOTHER_B4", "0")
+    ea, eP = [x.cpu().numpy() for x in eng.smooth(*args)]
+    monkeypatch.delenv("KF_SMOOTHER_B4")
+    assert_allclose(sP[4], eP[4], rtol=1e-9, atol=1e-9)   # the flagged draw IS the elimination kernel's (then, if that flags too, pinv)
 
 
 # ---- logp + gradient behind the lane kernel (m <= 4) with the steady-state adjoint -------------------------------------------------------
