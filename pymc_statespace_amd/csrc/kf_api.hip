@@ -170,11 +170,19 @@ static bool kf_b4_auto(const kf_handle* h, int m, long B) {
   if (m >= 9) return true;
   const long n_simd = (h ? h->n_cu : 256) * 4L;
   if (m >= 7) return (B * m + KF_WAVE - 1) / KF_WAVE < 2 * n_simd;  // else the row kernel (as before)
-  if (m >= 4) return B < 16384;
+  // (round 4, scripts/r04/fwd_dispatch_sweep.py, full tapes: past one round of wavefront slots the block kernel's time doubles while
+  // the packed row kernel's barely moves -- m = 4 / 5 / 6 at 6144 draws x 300 steps 0.53 / 0.56 / 0.58 ms against 0.29 / 0.43 / 0.45, at
+  // 8192 x 1000 m = 4: 2.00 against 0.96; log-likelihood only it is a tie at m = 5, 6 up to 8192 draws)
+  if (m >= 4) return B <= 16L * (h ? h->n_cu : 256);
   // m <= 3: the lane kernel (4 .. 64 draws per wavefront, LDS-staged tapes; scripts/r02/lane_time.py, full ; logp ms):
   //   m = 2: 0.46 / 0.51 / 0.52 ; 0.33 - 0.35 at 512 / 2048 / 4096 draws against 0.47 / 0.54 / 0.71 ; 0.32 - 0.50 here
   //   m = 3: 0.76 / 0.84 / 0.92 against 0.58 / 0.69 / 0.98
   return m == 3 && B <= 2048;
+}
+// m = 4 past one round of wavefront slots: the packed row kernel, not the lane kernel (AUTO only; full tapes at 16384 / 32768 / 65536
+// draws x 300 steps: 0.46 / 0.75 / 1.70 ms against 0.64 / 1.19 / 2.54, log-likelihood only 0.35 / 0.43 / 0.70 against 0.36 / 0.50 / 0.98)
+static bool kf_row_over_lane(const kf_handle* h, int m, long B) {
+  return h->forward_kernel == KF_KERNEL_AUTO && m == 4 && B > 16L * (h->n_cu > 0 ? h->n_cu : 256);
 }
 static bool kf_b4_selected(const kf_handle* h, int m, int p, int r, long B) {
   if (!kf_forward_b4_ok(m, p, r)) return false;
@@ -302,7 +310,7 @@ extern "C" const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_di
     return "big_gemm_kernel";
   if (h->forward_kernel == KF_KERNEL_MFMA)
     return kf_mp_ok(h, d->m, d->p, d->T, d->filter, d->flags) ? "kf_fwd_mfma_kernel" : "";
-  if (d->p == 1 && d->m <= KF_LANE_M_MAX &&
+  if (d->p == 1 && d->m <= KF_LANE_M_MAX && !kf_row_over_lane(h, d->m, d->B) &&
       (h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_LANE))
     return "kf_fwd_lane_kernel";
   const bool mp_ok = kf_mp_ok(h, d->m, d->p, d->T, d->filter, d->flags);
@@ -405,7 +413,7 @@ int kf_launch_forward(kf_handle* h, const KfFwdArgs& a_in, void* workspace, size
     KF_SET_ERR(h, "forward(lane): needs p == 1 and m <= %d (got p=%d m=%d)", KF_LANE_M_MAX, a.p, a.m);
     return KF_ERR_UNSUPPORTED;
   }
-  if (lane_ok && (h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_LANE)) {
+  if (lane_ok && !kf_row_over_lane(h, a.m, a.B) && (h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_LANE)) {
     switch (a.m) {
       case 1: return kf_launch_forward_lane_m1(h, a, stream);
       case 2: return kf_launch_forward_lane_m2(h, a, stream);

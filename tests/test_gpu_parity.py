@@ -806,7 +806,8 @@ def test_lane_kernels_match_oracle(eng, m, ft):
     c = 0.1 * rng.standard_normal((B, m))
     d = 0.1 * rng.standard_normal((B, 1))
     ref = kn.kalman_filter(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact")
-    assert eng.forward_kernel_name(32768, 70, 1, m, w["r"]) == "kf_fwd_lane_kernel"  # AUTO: large batches
+    # AUTO at large batches: the lane kernel for m <= 3, the packed row kernel for m = 4 (round 4: 1.5x faster on full tapes)
+    assert eng.forward_kernel_name(32768, 70, 1, m, w["r"]) == ("kf_fwd_lane_kernel" if m <= 3 else "kf_fwd_row_kernel")
     eng.set_forward_kernel("lane")
     try:
         out = _np(eng.forward(*_args(w, y), c=c, d=d, filter_type=ft, mvn_const="exact"))
