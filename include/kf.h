@@ -237,7 +237,7 @@ int kf_filter_forward(kf_handle* h, const kf_dims* dims,
  * steps behind the convergence point are time-parallel in BOTH directions (kf_bwd_steady_scan_kernel: the forward means and the
  * adjoint as prefix scans, 64 steps per wavefront pass).  KF_FLAG_STEADY_STATE requests the steady-state adjoint for any batch,
  * KF_FLAG_EXACT_RECURSION (or KF_VG_STEADY=0 in the environment) the adjoint at every step.
- * Behind the lane kernel (p == 1, m <= 3, and m = 4 where AUTO keeps it) the same split applies up to 32 x CUs draws: the scan
+ * Behind the lane kernel (p == 1, m <= 3) the same split applies up to 32 x CUs draws: the scan
  * kernel takes a_t and the converged covariance from the compact tapes, kf_bwd_b4_kernel the steps before the change-over.
  * Workspace reuse: on the block kernels' path the launch order of the forward kernel's workgroups follows the convergence points the PREVIOUS
  * call left in the same workspace (same B, T, m: a sampler's successive calls) -- draws that will run long are spread over the

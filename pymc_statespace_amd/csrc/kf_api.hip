@@ -647,7 +647,9 @@ static bool kf_vg_steady_path(const kf_handle* h, const kf_dims* d) {
 // the Riccati adjoint, kf_bwd_b4_kernel (compact tapes, per-draw step counts, snake order) the steps before it.  C2 (ARMA(1,1),
 // 4096 x 1000): 1.12 -> 0.59 ms.  KF_VG_STEADY=0 / KF_FLAG_EXACT_RECURSION: the full sweep as before; =1 / KF_FLAG_STEADY_STATE: any batch.
 static bool kf_vg_lane_steady_path(const kf_handle* h, const kf_dims* d) {
-  if ((d->flags & (KF_FLAG_TV_ANY | KF_FLAG_EXACT_RECURSION)) || d->T < 64 || d->p != 1 || d->m > KF_LANE_M_MAX) return false;
+  // (m <= 3: at m = 4 the lane kernel is AUTO's choice only beyond 4096 draws, where the packed row kernels + the full row-split sweep
+  // are faster -- 8192 x 1000: 2.48 ms against 2.79 on this path)
+  if ((d->flags & (KF_FLAG_TV_ANY | KF_FLAG_EXACT_RECURSION)) || d->T < 64 || d->p != 1 || d->m > 3) return false;
   if (d->B > 0x7fffffffL) return false;
   if (h->forward_kernel != KF_KERNEL_AUTO && h->forward_kernel != KF_KERNEL_LANE) return false;
   if (kf_b4_selected(h, d->m, d->p, d->r, d->B)) return false;   // (the tile-tape path)
