@@ -653,3 +653,45 @@ def test_value_and_grad_takes_the_multi_observation_block_kernel_at_m8_large_bat
             continue
         scale = 1.0 + np.max(np.abs(x_.reshape(B, -1)), axis=1)
         assert (np.max(np.abs(a_ - x_).reshape(B, -1), axis=1) / scale).max() < 1e-9, nm
+
+
+@pytest.mark.parametrize("m", [2, 10])
+def test_steady_state_paths_replay_from_a_hip_graph(eng, monkeypatch, m):
+    """The round's multi-kernel paths -- value-and-gradient with the order kernels, the time-parallel adjoint, the Riccati adjoint
+    and the exact sweep (block kernels at m = 10, lane kernel at m = 2); the smoother with bisection, verification, scan, fill and
+    the resumed sweep -- are plain launches on the caller's stream: captured once, replayed on new data, bitwise an eager run."""
+    import torch
+
+    B, n = 40, 260
+    w = W.structural(B=B, n=n) if m == 10 else W.arma11(B=B, n=n)
+    dev = [eng.to_device(w[k]) for k in ("y",) + KEYS]
+    monkeypatch.setenv("KF_SMOOTHER_SPLIT", "1")
+
+    def step():
+        vg = eng.value_and_grad(*dev, mvn_const="exact", exact_recursion=False)
+        res = eng.forward(*dev, mvn_const="exact", store_predicted=False, store_ll_obs=False)
+        sm = eng.smooth(dev[3], dev[5], dev[7], res.filtered_states, res.filtered_covs) if m == 10 else None
+        return vg, sm
+
+    step()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        vg_c, sm_c = step()
+    y2 = w["y"] + 0.3 * np.random.default_rng(1).standard_normal(w["y"].shape)
+    dev[0].copy_(torch.as_tensor(y2, device=dev[0].device))
+    graph.replay()
+    graph.replay()   # (twice: the second forward launch is placed by the first replay's convergence points)
+    torch.cuda.synchronize()
+    vg_e, sm_e = step()
+    torch.cuda.synchronize()
+    assert torch.equal(vg_c[0], vg_e[0]) and torch.equal(vg_c[1], vg_e[1])
+    for k in vg_e[2]:
+        assert torch.equal(vg_c[2][k], vg_e[2][k]), k
+    if sm_e is not None:
+        assert torch.equal(sm_c[0], sm_e[0]) and torch.equal(sm_c[1], sm_e[1])
+    lpx, _, gx = eng.value_and_grad(*dev, mvn_const="exact", exact_recursion=True)
+    assert_allclose(vg_c[0].cpu().numpy(), lpx.cpu().numpy(), rtol=1e-12)
+    for k in gx:
+        a_, x_ = vg_c[2][k].cpu().numpy(), gx[k].cpu().numpy()
+        assert np.max(np.abs(a_ - x_)) / (1.0 + np.max(np.abs(x_))) < 1e-9, k
