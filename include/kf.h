@@ -52,7 +52,8 @@
 extern "C" {
 #endif
 
-#define KF_ABI_VERSION 5 /* 5: KF_FLAG_STEADY_STATE; the block kernel's steady-state phase off by default below 1536 steps; kf_workspace_bytes_for(KF_WS_FORWARD) covers the split pipeline. \
+#define KF_ABI_VERSION 6 /* 6: kf_smoother_from_filter. \
+                          * 5: KF_FLAG_STEADY_STATE; the block kernel's steady-state phase off by default below 1536 steps; kf_workspace_bytes_for(KF_WS_FORWARD) covers the split pipeline. \
                           * 2: KF_FLAG_H_DIAGONAL, KF_KERNEL_MFMA, kf_dare, kf_simulate_statespace, workspace use by smoother/backward; \
                             3: kf_workspace_bytes_for, kf_forward_kernel_name_ws; every entry point runs on the handle's device; \
                             4: kf_dare_backward, time-varying matrices in kf_filter_backward, kf_filter_value_and_grad */
@@ -288,6 +289,24 @@ int kf_smoother(kf_handle* h, const kf_dims* dims,
                 const double* filt_a, const double* filt_P,
                 double* smooth_a, double* smooth_P,
                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same smoothed moments from the FILTER's own tapes (extension; kf_smoother_bf.hip).  The reference never runs its smoother on
+ * anything but the outputs of its filter on the same model (core/statespace.py:164-197: build_statespace_graph hands
+ * filtered_states / filtered_covariances straight to KalmanSmoother.build_graph), and with the filter's PREDICTED tapes and the
+ * observation side of the model (y, Z, H, d) the smoothed moments follow without inverting the prediction covariance -- the
+ * backward recursion of de Jong / Durbin & Koopman (what statsmodels computes):
+ *     v = y - Z a_t - d,  F = Z P_t Z' + H,  K = P_t Z' / F,  L = T (I - K Z)         (a_t, P_t = pred_a[t], pred_P[t])
+ *     r_{t-1} = Z' v / F + L' r_t,   N_{t-1} = Z' Z / F + L' N_t L,   smooth_a[t] = a_t + P_t r_{t-1},   smooth_P[t] = P_t - P_t N_{t-1} P_t
+ * Equal to kf_smoother's output up to rounding (<= 5e-14 of a draw's largest entry on the BASELINE workloads; asserted at 1e-9 in
+ * tests/test_gpu_r05.py), 1.5 - 2x faster at the north-star shape, every draw at the same cost, and a singular prediction
+ * covariance (the reference's pinv case) is no special case.  pred_a [B][T+1][m], pred_P [B][T+1][m][m] as kf_filter_forward wrote
+ * them (slots 0 .. T-1 are read); y, Z, H, d, T as passed to it (d may be NULL); dims->filter: KF_FILTER_SINGLE keeps that
+ * filter's sign of d (kalman_filter.py:335); dims->flags: KF_FLAG_Y_PER_DRAW only.  R, Q are not needed.
+ * Supported: p == 1, m <= 15, static matrices; anything else returns KF_ERR_UNSUPPORTED (use kf_smoother on the filtered tapes).
+ * No workspace. */
+int kf_smoother_from_filter(kf_handle* h, const kf_dims* dims, const double* y, const double* T, const double* Z,
+                            const double* H, const double* d, const double* pred_a, const double* pred_P,
+                            double* smooth_a, double* smooth_P, void* stream);
 
 /* ---- the step before the filter ---------------------------
  * Batched theta -> matrix assembly: out[b][:] = tmpl[:], then out[b][dst[i]] = theta[b][src[i]]

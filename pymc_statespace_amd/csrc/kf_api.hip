@@ -1181,6 +1181,29 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
   return kf_launch_smoother_lds(h, a, (hipStream_t)stream);
 }
 
+extern "C" int kf_smoother_from_filter(kf_handle* h, const kf_dims* dims, const double* y, const double* T, const double* Z,
+                                       const double* H, const double* d, const double* pred_a, const double* pred_P,
+                                       double* smooth_a, double* smooth_P, void* stream) {
+  int rc = check_dims(h, dims, true);
+  if (rc) return rc;
+  if (!y || !T || !Z || !H || !pred_a || !pred_P || !smooth_a || !smooth_P) {
+    KF_SET_ERR(h, "kf_smoother_from_filter: all pointers but d must be non-NULL");
+    return KF_ERR_ARG;
+  }
+  if (!kf_smoother_bf_ok(dims->m, dims->p, dims->flags)) {
+    KF_SET_ERR(h, "kf_smoother_from_filter: needs p == 1, m <= 15 and static matrices (p=%d m=%d flags=0x%x); use kf_smoother",
+               dims->p, dims->m, dims->flags);
+    return KF_ERR_UNSUPPORTED;
+  }
+  KF_ON_DEVICE(h);
+  KfSmoothBfArgs a;
+  a.B = dims->B; a.T = dims->T; a.m = dims->m; a.filter = dims->filter;
+  a.flags = dims->flags & KF_FLAG_Y_PER_DRAW;
+  a.y = y; a.Tm = T; a.Z = Z; a.H = H; a.d = d; a.pred_a = pred_a; a.pred_P = pred_P;
+  a.smooth_a = smooth_a; a.smooth_P = smooth_P;
+  return kf_launch_smoother_bf(h, a, (hipStream_t)stream);
+}
+
 extern "C" int kf_assemble(kf_handle* h, int64_t B, int32_t n_theta, const double* theta, int64_t total,
                            const double* tmpl, int32_t n_map, const int32_t* dst, const int32_t* src,
                            double* out, void* stream) {

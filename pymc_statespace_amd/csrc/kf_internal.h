@@ -196,6 +196,25 @@ struct KfSmoothArgs {
   int exact;                    // KF_FLAG_EXACT_RECURSION: every step in full (kf_smoother_b4.hip reuses a converged filter's gain otherwise)
 };
 
+// kf_smoother_from_filter (kf_smoother_bf.hip): the smoothed moments from the filter's predicted tapes, no inverse
+struct KfSmoothBfArgs {
+  long B;
+  int T, m;
+  int filter;      // KF_FILTER_SINGLE flips the sign of d (kalman_filter.py:335)
+  unsigned flags;  // KF_FLAG_Y_PER_DRAW
+  const double* y;
+  const double* Tm;
+  const double* Z;
+  const double* H;
+  const double* d;       // nullable
+  const double* pred_a;  // [B][T+1][m]
+  const double* pred_P;  // [B][T+1][m][m]
+  double* smooth_a;
+  double* smooth_P;
+};
+bool kf_smoother_bf_ok(int m, int p, unsigned flags);
+int kf_launch_smoother_bf(kf_handle* h, const KfSmoothBfArgs& a, hipStream_t stream);
+
 // per-draw LDS footprints (in doubles) -- shared by host launchers and kernels
 __host__ __device__ inline int kf_fwd_region_doubles(int m, int p) {
   int mm = m * m, pm = p * m, pp = p * p;

@@ -19,7 +19,7 @@
 // ends the range there) -- and kf_smooth_b4_kernel takes the steps below start[b] from (a_s, P_s)[start[b]] as before.  P_hat^-1 once
 // per draw by Cholesky (a pivot below 1e-2 of the largest diagonal entry: the draw is left to kf_smooth_b4_kernel and its fallbacks).
 //
-// Tolerance: |P_f[t] - P_f[n-1]|_ij <= 1e-14 max|P_f| AND <= 1e-12 sqrt(P_ii P_jj) (KF_SMOOTHER_SPLIT_TOL in the environment: the
+// Tolerance: |P_f[t] - P_f[n-1]|_ij <= 1e-14 max|P_f| AND <= 1e-12 sqrt(P_ii P_jj) (KF_SMOOTHER_SPLIT_TOL, measurement builds only -- kf_env_experiment --: the
 // first factor).  1e-15, the forward kernels' one-step test, is below the rounding jitter of a converged recursion relative to its
 // LAST value and accepted a median of four steps.  Against every step in full the smoothed moments move by the tolerance times the
 // conditioning of P_hat -- measured (tests/test_gpu_r04.py, scripts/r04/smooth_split_check.py): <= 6e-13 of a draw's largest entry
@@ -481,7 +481,7 @@ int kf_launch_smoother_b4_steady(kf_handle* h, const KfSmoothArgs& a, void* ws, 
   double* pinf = reinterpret_cast<double*>(w);
   double tol = 1e-14;
   {
-    const char* e = kf_env_switch("KF_SMOOTHER_SPLIT_TOL");
+    const char* e = kf_env_experiment("KF_SMOOTHER_SPLIT_TOL");  // (a documented tolerance: measurement builds only, kf_internal.h)
     if (e && atof(e) > 0.0) tol = atof(e);
   }
   hipLaunchKernelGGL(kf_smooth_b4_guess_kernel, dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, gss, tbd, tol);

@@ -1,10 +1,13 @@
-"""Multi-GPU: shard the batch-of-draws axis, all-gather the per-draw log-likelihoods.
+"""Multi-GPU: shard the batch-of-draws axis, all-gather the per-draw log-likelihoods (and, when the sampler asks for
+them, the per-draw gradients -- SURVEY.md section 8e: "gradients, when requested, are gathered the same way").
 
 Draws are independent (time is sequential only WITHIN a draw), so the path shards with no
 halo and no reduction: rank k filters draws [lo_k, hi_k) on its own GPU and the only exchange
 is one all-gather of B/world doubles per rank -- over RCCL on xGMI when
-the process group's backend is "nccl" (= RCCL on ROCm), over gloo in the CPU tests.  Output
-tapes stay sharded (at the large configs they do not fit one GPU).
+the process group's backend is "nccl" (= RCCL on ROCm), over gloo in the CPU tests.  A value-and-gradient
+call packs logp, info and the nine gradient arrays of a draw into one row and gathers THAT: still one
+collective per evaluation (the message is latency-bound on xGMI: B/world x (2 + n_theta) doubles).  Output
+tapes -- filtered, predicted, smoothed -- stay sharded (at the large configs they do not fit one GPU).
 
 One process per GPU; `torch.distributed` must already be initialised by the launcher
 (torchrun / `python -m torch.distributed.run`).
@@ -121,3 +124,76 @@ class ShardedKalman:
 
         full = sharded_logp(local, [a0, P0, T, Z, R, H, Q], B, self.group, shared_inputs=(y,))
         return (full, holder["res"]) if return_local else full
+
+    # ------------------------------------------------------------------ logp + gradient (what NUTS evaluates)
+    GRAD_KEYS = ("a0", "P0", "T", "Z", "R", "H", "Q", "c", "d")
+
+    def value_and_grad_local(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, **kw):
+        """kf_filter_value_and_grad on this rank's draws -> (logp, info, dict of gradients).  An empty shard skips the
+        launch and returns empty tensors of the right trailing shapes."""
+        if T.shape[0] == 0:
+            dev, f64 = self.engine.device, torch.float64
+            m, p, r = T.shape[-1], Z.shape[-2], R.shape[-1]
+            shp = dict(a0=(m,), P0=(m, m), T=(m, m), Z=(p, m), R=(m, r), H=(p, p), Q=(r, r), c=(m,), d=(p,))
+            return (torch.empty(0, device=dev, dtype=f64), torch.empty(0, device=dev, dtype=torch.int32),
+                    {k: torch.empty((0,) + shp[k], device=dev, dtype=f64) for k in self.GRAD_KEYS})
+        return self.engine.value_and_grad(y, a0, P0, T, Z, R, H, Q, c, d, **kw)
+
+    def gather_value_and_grad(self, logp, info, grads, B_global: int):
+        """ONE all-gather for logp, info and the nine gradient arrays: each draw's values packed into a row
+        [logp | info | g_a0 | g_P0 | ... | g_d] (info travels as a double: exact for int32).  Returns the full
+        (B_global, ...) arrays on every rank."""
+        if self._world() == 1:
+            return logp, info, grads
+        b = logp.shape[0]
+        import math
+
+        cols = [logp.reshape(b, 1), info.to(logp.dtype).reshape(b, 1)]
+        cols += [grads[k].reshape(b, math.prod(grads[k].shape[1:])) for k in self.GRAD_KEYS]  # (an empty shard: 0 x width)
+        widths = [c.shape[1] for c in cols]
+        full = all_gather_draws(torch.cat(cols, dim=1), B_global, self.group)
+        parts = torch.split(full, widths, dim=1)
+        out = {k: parts[2 + i].reshape((B_global,) + tuple(grads[k].shape[1:])) for i, k in enumerate(self.GRAD_KEYS)}
+        return parts[0].reshape(B_global).contiguous(), parts[1].reshape(B_global).to(torch.int32), out
+
+    def value_and_grad(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, B_global: int, gather_grads: bool = True, **kw):
+        """This rank's shard in; (logp (B_global,), info (B_global,), gradients) out on every rank -- gathered like the
+        log-likelihoods (``gather_grads=False``: only logp and info are gathered, the gradients stay this rank's shard,
+        for a caller that reduces them over theta locally first).  g_logp, when given, is this rank's shard of it."""
+        logp, info, g = self.value_and_grad_local(y, a0, P0, T, Z, R, H, Q, c, d, **kw)
+        if self._world() == 1:
+            return logp, info, g
+        if gather_grads:
+            return self.gather_value_and_grad(logp, info, g, B_global)
+        b = logp.shape[0]
+        full = all_gather_draws(torch.stack([logp, info.to(logp.dtype)], dim=1).reshape(b, 2), B_global, self.group)
+        return full[:, 0].contiguous(), full[:, 1].to(torch.int32), g
+
+    # ------------------------------------------------------------------ smoother: tapes stay where they were filtered
+    def smooth_local(self, T, R, Q, filtered_states, filtered_covs, **kw):
+        """kf_smoother on this rank's tapes; nothing is exchanged (a smoothed tape is as large as the filtered one it came
+        from -- C5: 0.8 TB over the job).  An empty shard returns empty tapes."""
+        if T.shape[0] == 0:
+            return torch.empty_like(filtered_states), torch.empty_like(filtered_covs)
+        return self.engine.smooth(T, R, Q, filtered_states, filtered_covs, **kw)
+
+    def smooth_from_filter_local(self, data, T, Z, H, predicted_states, predicted_covs, **kw):
+        """kf_smoother_from_filter on this rank's predicted tapes (p == 1, m <= 15); nothing is exchanged."""
+        if T.shape[0] == 0:
+            dev, f64 = self.engine.device, torch.float64
+            n, m = predicted_states.shape[1] - 1, T.shape[-1]
+            return torch.empty(0, n, m, device=dev, dtype=f64), torch.empty(0, n, m, m, device=dev, dtype=f64)
+        return self.engine.smooth_from_filter(data, T, Z, H, predicted_states, predicted_covs, **kw)
+
+    def filter_and_smooth(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, B_global: int, **fkw):
+        """Forward filter + smoother of this rank's draws: (gathered logp (B_global,), this rank's FilterResult, this rank's
+        smoothed states and covariances) -- build_statespace_graph + build_smoother_graph (core/statespace.py:164-197) for a
+        shard.  The only exchange is the logp all-gather."""
+        res = self.forward_local(y, a0, P0, T, Z, R, H, Q, c, d, **fkw)
+        full = self.gather_logp(res.logp, B_global)
+        if T.shape[0] == 0:
+            dev, f64 = self.engine.device, torch.float64
+            n, m = y.shape[-2], T.shape[-1]
+            return full, res, torch.empty(0, n, m, device=dev, dtype=f64), torch.empty(0, n, m, m, device=dev, dtype=f64)
+        sa, sP = self.engine.smooth(T, R, Q, res.filtered_states, res.filtered_covs)
+        return full, res, sa, sP

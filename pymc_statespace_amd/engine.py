@@ -414,6 +414,42 @@ class KalmanEngine:
         return sa, sP
 
 
+    def smooth_from_filter_ok(self, p: int, m: int, time_varying=()) -> bool:
+        """Does kf_smoother_from_filter take this shape (p == 1, m <= 15, static matrices)?"""
+        return p == 1 and 1 <= m <= 15 and not tuple(time_varying)
+
+    def smooth_from_filter(self, data, T, Z, H, predicted_states, predicted_covs, d=None, filter_type: str = "standard"):
+        """kf_smoother_from_filter -> (smoothed_states (B,n,m), smoothed_covs (B,n,m,m)) from the FILTER's predicted tapes
+        (B,n+1,m), (B,n+1,m,m) and the observation side of the model it ran on (data, Z, H, d) -- the same moments
+        ``smooth`` computes from the filtered tapes (kalman_smoother.py:56-104) up to rounding, without inverting the prediction
+        covariance (include/kf.h).  p == 1, m <= 15, static matrices; ``filter_type="single"`` keeps that filter's sign of d."""
+        if filter_type not in _lib.KF_FILTER:
+            raise ValueError(f"unknown filter_type {filter_type!r}")
+        T = self.to_device(T)
+        B, m = T.shape[0], T.shape[-1]
+        T = self.to_device(T, (B, m, m))
+        pa = self.to_device(predicted_states)
+        n = pa.shape[1] - 1
+        pa = self.to_device(pa, (B, n + 1, m))
+        pP = self.to_device(predicted_covs, (B, n + 1, m, m))
+        Z = self.to_device(Z, (B, 1, m))
+        H = self.to_device(H, (B, 1, 1))
+        d = None if d is None else self.to_device(d, (B, 1))
+        y = self.to_device(data)
+        per_draw = y.ndim == 3  # (n, 1) shared or (B, n, 1), as in forward
+        y = self.to_device(y, (B, n, 1) if per_draw else (n, 1))
+        dims = self._dims(B, n, 1, m, 1)
+        dims.filter = _lib.KF_FILTER[filter_type]
+        if per_draw:
+            dims.flags |= _lib.KF_FLAG_Y_PER_DRAW
+        sa = torch.empty(B, n, m, device=self.device, dtype=torch.float64)
+        sP = torch.empty(B, n, m, m, device=self.device, dtype=torch.float64)
+        rc = self.lib.kf_smoother_from_filter(self._h, C.byref(dims), _ptr(y), _ptr(T), _ptr(Z), _ptr(H), _ptr(d),
+                                              _ptr(pa), _ptr(pP), _ptr(sa), _ptr(sP), self._stream())
+        self._check(rc, "kf_smoother_from_filter")
+        return sa, sP
+
+
     # ------------------------------------------------- before the filter (section 8f row 1)
     def lyapunov(self, T, R=None, Q=None, S=None):
         """kf_lyapunov: P (B,m,m) with P = T P T' + S, S given or R Q R'.  Returns (P, info)."""

@@ -308,6 +308,59 @@ def perform_smoother(T, R, Q, filtered_states, filtered_covs, engine=None):
     return [sa[0].cpu().numpy()[..., None], sP[0].cpu().numpy()]
 
 
+def perform_smoother_batched(T, R, Q, filtered_states, filtered_covs, engine=None):
+    """B draws from ONE ``kf_smoother`` call: T (B,m,m), R (B,m,r), Q (B,r,r), filtered_states (B,n,m,1), filtered_covs
+    (B,n,m,m) -> [smoothed_states (B,n,m,1), smoothed_covs (B,n,m,m)].  The loop this replaces: one KalmanSmoother graph call
+    per posterior draw (reference core/statespace.py:283-302 over :176-197)."""
+    eng = engine or get_engine()
+    T, R, Q = (np.asarray(x, dtype=np.float64) for x in (T, R, Q))
+    if T.ndim != 3 or R.ndim != 3 or Q.ndim != 3:
+        raise NotImplementedError("the batched smoother Op takes static T, R, Q with ONE leading draw axis")
+    fa = np.asarray(filtered_states, dtype=np.float64)
+    if fa.ndim == 4:
+        fa = fa[..., 0]
+    sa, sP = eng.smooth(T, R, Q, fa, np.asarray(filtered_covs, dtype=np.float64))
+    return [sa.cpu().numpy()[..., None], sP.cpu().numpy()]
+
+
+def smoother_from_filter_applies(p, m, ndims):
+    """May the smoothed moments come from the filter's predicted tapes (kf_smoother_from_filter)?  p == 1, m <= 15 and every
+    system matrix static (``ndims``: the per-draw ranks of T, Z, H, R, Q)."""
+    return p == 1 and m <= 15 and all(nd == 2 for nd in ndims)
+
+
+def perform_smoother_fused(data, T, Z, R, H, Q, d, filtered_states, filtered_covs, predicted_states, predicted_covs,
+                           filter_type="standard", engine=None, batched=False):
+    """The smoother behind THIS library's filter node (``kalman_smoother_graph`` finds it: the reference never smooths anything
+    but its own filter's outputs, core/statespace.py:164-197).  All of the filter's tapes are at hand, so the numeric body picks
+    the cheaper recursion: for p == 1, m <= 15 and static matrices ``kf_smoother_from_filter`` on the PREDICTED tapes (no
+    pinv(P_hat): include/kf.h), otherwise ``kf_smoother`` on the filtered ones (kalman_smoother.py:56-104 as it stands).
+    Shapes: the per-draw reference layouts, or with ONE leading draw axis on everything but a shared data when ``batched``."""
+    eng = engine or get_engine()
+    lead = 1 if batched else 0
+    Ta, Za, Ha = (np.asarray(x, dtype=np.float64) for x in (T, Z, H))
+    p, m = Za.shape[-2], Ta.shape[-1]
+    nds = [np.asarray(x).ndim - lead for x in (T, Z, H, R, Q)]
+    if not smoother_from_filter_applies(p, m, nds):
+        return (perform_smoother_batched if batched else perform_smoother)(T, R, Q, filtered_states, filtered_covs, engine=eng)
+    y = np.asarray(data, dtype=np.float64)
+    if y.ndim == 3 + lead or (batched and y.ndim == 3):  # (n,p,1) [shared] or (B,n,p,1)
+        y = y[..., 0]
+    pa = np.asarray(predicted_states, dtype=np.float64)
+    if pa.ndim == 3 + lead:
+        pa = pa[..., 0]
+    pP = np.asarray(predicted_covs, dtype=np.float64)
+    dv = np.asarray(d, dtype=np.float64)
+    if dv.ndim == 2 + lead:
+        dv = dv[..., 0]
+    if not batched:
+        Ta, Za, Ha, pa, pP, dv = Ta[None], Za[None], Ha[None], pa[None], pP[None], dv[None]
+    sa, sP = eng.smooth_from_filter(y, Ta, Za, Ha, pa, pP, d=dv, filter_type=filter_type)
+    if not batched:
+        sa, sP = sa[0], sP[0]
+    return [sa.cpu().numpy()[..., None], sP.cpu().numpy()]
+
+
 # --------------------------------------------------------------------------------------------
 # PyTensor Ops (built on first use)
 # --------------------------------------------------------------------------------------------
@@ -700,10 +753,101 @@ def _build_ops():
             return [grad_not_implemented(self, k, inputs[k], "the RTS smoother is not differentiated")
                     for k in range(5)]
 
+    class KalmanSmootherBatchedOp(Op):
+        """KalmanSmootherOp with ONE leading draw axis B on every input: T (B,m,m), R, Q, filtered_states (B,n,m,1),
+        filtered_covs (B,n,m,m) -> B-leading outputs from ONE kf_smoother call.  What ``vectorize_graph`` maps
+        ``KalmanSmootherOp`` to (sample_conditional_posterior's per-draw loop, reference core/statespace.py:283-302)."""
+        __props__ = ()
+
+        def make_node(self, T, R, Q, filtered_states, filtered_covs):
+            ins = [pt.as_tensor_variable(x) for x in (T, R, Q, filtered_states, filtered_covs)]
+            if [v.type.ndim for v in ins] != [3, 3, 3, 4, 4]:
+                raise TypeError("KalmanSmootherBatchedOp: static T, R, Q and the filtered tapes, ONE leading draw axis each")
+            return Apply(self, ins, [pt.tensor4(dtype=f64), pt.tensor4(dtype=f64)])
+
+        def perform(self, node, inputs, output_storage):
+            outs = perform_smoother_batched(*inputs)
+            for storage, o in zip(output_storage, outs):
+                storage[0] = _out(o)
+
+        def infer_shape(self, fgraph, node, shapes):
+            return [shapes[3], shapes[4]]
+
+        def L_op(self, inputs, outputs, output_grads):
+            return [grad_not_implemented(self, k, inputs[k], "the RTS smoother is not differentiated")
+                    for k in range(5)]
+
+    class KalmanSmootherFusedOp(Op):
+        """(smoothed_states, smoothed_covs) = Op(data, T, Z, R, H, Q, d, filtered_states, filtered_covs, predicted_states,
+        predicted_covs): the smoother of a model whose tapes come from ``KalmanFilterOp`` on the same graph -- what
+        ``kalman_smoother_graph`` builds when it finds that node behind ``filtered_states`` (perform_smoother_fused: the
+        predicted-tape recursion where it applies, the reference's recursion on the filtered tapes otherwise).
+        ``batched``: every input but a shared ``data`` carries ONE leading draw axis (the ``vectorize_graph`` image)."""
+        __props__ = ("filter_type", "batched")
+
+        def __init__(self, filter_type="standard", batched=False):
+            self.filter_type, self.batched = filter_type, bool(batched)
+
+        def make_node(self, *args):
+            ins = [pt.as_tensor_variable(x) for x in args]
+            if len(ins) != 11:
+                raise TypeError("KalmanSmootherFusedOp takes 11 inputs")
+            out = pt.tensor4 if self.batched else pt.tensor3
+            return Apply(self, ins, [out(dtype=f64), out(dtype=f64)])
+
+        def perform(self, node, inputs, output_storage):
+            outs = perform_smoother_fused(*inputs, filter_type=self.filter_type, batched=self.batched)
+            for storage, o in zip(output_storage, outs):
+                storage[0] = _out(o)
+
+        def infer_shape(self, fgraph, node, shapes):
+            return [shapes[7], shapes[8]]
+
+        def L_op(self, inputs, outputs, output_grads):
+            return [grad_not_implemented(self, k, inputs[k], "the smoother is not differentiated") for k in range(11)]
+
+    try:
+        from pytensor.graph.replace import _vectorize_node as _vn
+
+        def _lead_all(node_inputs, new_inputs, shared=()):
+            """One leading draw axis on every input (broadcasting the ones vectorize_graph left alone), or None when nothing is
+            batched.  ``shared``: positions that may stay unbatched (the data)."""
+            extra = [x.type.ndim - v.type.ndim for x, v in zip(new_inputs, node_inputs)]
+            if any(e not in (0, 1) for e in extra):
+                raise NotImplementedError("one leading batch axis only")
+            if not any(extra):
+                return None
+            B = next(x.shape[0] for x, e in zip(new_inputs, extra) if e)
+            return [x if (e or i in shared) else pt.broadcast_to(x, (B,) + tuple(x.shape))
+                    for i, (x, e) in enumerate(zip(new_inputs, extra))]
+
+        @_vn.register(KalmanSmootherOp)
+        def _vectorize_kalman_smoother(op, node, *ins):
+            if any(v.type.ndim != 2 for v in node.inputs[:3]):
+                raise NotImplementedError("vectorize_graph over a time-varying smoother node")
+            led = _lead_all(node.inputs, ins)
+            if led is None:
+                return op.make_node(*ins)
+            return KalmanSmootherBatchedOp().make_node(*led)
+
+        @_vn.register(KalmanSmootherFusedOp)
+        def _vectorize_kalman_smoother_fused(op, node, *ins):
+            if op.batched:
+                raise NotImplementedError("one leading batch axis only")
+            if any(v.type.ndim != 2 for v in node.inputs[1:6]):
+                raise NotImplementedError("vectorize_graph over a time-varying smoother node")
+            led = _lead_all(node.inputs, ins, shared=(0,))
+            if led is None:
+                return op.make_node(*ins)
+            return KalmanSmootherFusedOp(op.filter_type, batched=True).make_node(*led)
+    except ImportError:  # pragma: no cover - older PyTensor
+        pass
+
     _OPS = dict(pt=pt, pytensor=pytensor, KalmanFilterOp=KalmanFilterOp,
                 KalmanFilterGradOp=KalmanFilterGradOp, KalmanSmootherOp=KalmanSmootherOp,
                 KalmanLogpOp=KalmanLogpOp, KalmanFilterBatchedOp=KalmanFilterBatchedOp,
-                KalmanLogpBatchedOp=KalmanLogpBatchedOp,
+                KalmanLogpBatchedOp=KalmanLogpBatchedOp, KalmanSmootherBatchedOp=KalmanSmootherBatchedOp,
+                KalmanSmootherFusedOp=KalmanSmootherFusedOp,
                 SteadyStateFilterOp=SteadyStateFilterOp, SteadyStateGradOp=SteadyStateGradOp,
                 SteadyStateLogpOp=SteadyStateLogpOp)
     return _OPS
@@ -775,6 +919,25 @@ def steady_state_filter_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, mvn_c
     return list(ops["SteadyStateFilterOp"](mvn_const, want_mask(outputs))(data, a0, P0, T, Z, R, H, Q, c, d))
 
 
-def kalman_smoother_graph(T, R, Q, filtered_states, filtered_covariances):
+def kalman_smoother_graph(T, R, Q, filtered_states, filtered_covariances, fuse=True):
+    """Symbolic KalmanSmoother.build_graph (reference kalman_smoother.py:56-85).  The reference only ever smooths the outputs of
+    its own filter on the same model (core/statespace.py:164-197); when ``filtered_states`` and ``filtered_covariances`` ARE
+    outputs 0 and 2 of one ``KalmanFilterOp`` / ``KalmanFilterBatchedOp`` node that also computes its predicted tapes, the
+    smoother node takes that node's inputs and predicted tapes along (``KalmanSmootherFusedOp``): for p == 1, m <= 15 and static
+    matrices its body is ``kf_smoother_from_filter`` -- same moments, no pinv(P_hat).  ``fuse=False`` (or tapes of any other
+    origin): the reference's recursion on the filtered tapes."""
     ops = _build_ops()
-    return tuple(ops["KalmanSmootherOp"]()(T, R, Q, filtered_states, filtered_covariances))
+    pt = ops["pt"]
+    fs, fc = pt.as_tensor_variable(filtered_states), pt.as_tensor_variable(filtered_covariances)
+    own = getattr(fs, "owner", None)
+    if fuse and own is not None and getattr(fc, "owner", None) is own and isinstance(
+            own.op, (ops["KalmanFilterOp"], ops["KalmanFilterBatchedOp"])):
+        batched = isinstance(own.op, ops["KalmanFilterBatchedOp"])
+        want = own.op.want
+        if own.outputs[0] is fs and own.outputs[2] is fc and want[1] and want[3]:
+            data, _a0, _P0, fT, fZ, fR, fH, fQ, _c, fd = own.inputs
+            return tuple(ops["KalmanSmootherFusedOp"](own.op.filter_type, batched)(
+                data, T, fZ, R, fH, Q, fd, fs, fc, own.outputs[1], own.outputs[3]))
+    if fs.type.ndim == 4:
+        return tuple(ops["KalmanSmootherBatchedOp"]()(T, R, Q, fs, fc))
+    return tuple(ops["KalmanSmootherOp"]()(T, R, Q, fs, fc))

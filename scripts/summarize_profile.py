@@ -54,6 +54,7 @@ def pmc(d, counter):
 def main():
     out = sys.argv[1]
     bench = None
+    benches = {}
     print(f"# profile summary: {out}")
     for tag in ("kt", "fetch", "write"):
         f = os.path.join(out, f"bench_{tag}.json")
@@ -66,6 +67,7 @@ def main():
                           f"frac={j['roofline']['frac']:.4f}  [{j['config']['workload']}]")
                     abytes = j["roofline"].get("algorithmic_bytes_per_launch")
                     bench = j
+                    benches[tag] = j
     print("\n## rocprofv3 --kernel-trace --stats (kernel_stats.csv)")
     print(f"{'kernel':60s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}")
     for r in sorted(kernel_stats(os.path.join(out, "kt")), key=lambda r: -float(r["TotalDurationNs"])):
@@ -103,14 +105,22 @@ def main():
         # a pass that is several kernels (the split pipeline: recursion chunks, compaction, fill, scan, pair kernel): traffic of the
         # WHOLE pass = the sum over every kf_ launch of the run / the number of passes the run made (bench.py --no-ops: one
         # allocation pass + warmup + steps identical passes)
-        passes = 1 + int(bench.get("warmup", 0)) + int(bench.get("steps", 0))
-        tot_w = sum(sum(v) for k, v in write.items() if "kf_" in k) * 1024
-        tot_f = sum(sum(v) for k, v in fetch.items() if "kf_" in k) * 1024
+        # Round 5: the clock spin-up bench.py runs before the warm-up (roofline.clock_spinup.steps, a
+        # different number in every run) makes passes too; each --pmc leg is its own run, so each sum is divided by ITS run's count
+        def passes_of(tag):
+            j = benches.get(tag) or bench
+            spin = ((j.get("roofline") or {}).get("clock_spinup") or {}).get("steps", 0) or 0
+            return 1 + int(spin) + int(j.get("warmup", 0)) + int(j.get("steps", 0))
+
+        p_w, p_f = passes_of("write"), passes_of("fetch")
+        tot_w = sum(sum(v) for k, v in write.items() if "kf_" in k) * 1024 / p_w
+        tot_f = sum(sum(v) for k, v in fetch.items() if "kf_" in k) * 1024 / p_f
         if len(entries) > 1:
-            print(f"\nwhole pass ({len(entries)} kernels, {passes} passes in the run): WRITE_SIZE = {tot_w / passes / 1e9:.4f} GB, "
-                  f"FETCH_SIZE raw = {tot_f / passes / 1e9:.4f} GB, traffic(write + 2*fetch) = {(tot_w + 2 * tot_f) / passes / 1e9:.4f} GB")
-            top = dict(kernel=top["kernel"], kernels=sorted(e["kernel"] for e in entries), bytes=int((tot_w + 2 * tot_f) / passes),
-                       write_bytes=int(tot_w / passes), fetch_bytes_raw=int(tot_f / passes))
+            print(f"\nwhole pass ({len(entries)} kernels; {p_w} / {p_f} passes in the write / fetch run, spin-up included): "
+                  f"WRITE_SIZE = {tot_w / 1e9:.4f} GB, FETCH_SIZE raw = {tot_f / 1e9:.4f} GB, "
+                  f"traffic(write + 2*fetch) = {(tot_w + 2 * tot_f) / 1e9:.4f} GB")
+            top = dict(kernel=top["kernel"], kernels=sorted(e["kernel"] for e in entries), bytes=int(tot_w + 2 * tot_f),
+                       write_bytes=int(tot_w), fetch_bytes_raw=int(tot_f), passes_write_run=p_w, passes_fetch_run=p_f)
         top.update(key=key, commit=_commit(),
                    source=f"{os.path.basename(out.rstrip('/'))}: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, "
                           "write + 2 x fetch (gfx950 wide-read correction)")

@@ -164,3 +164,15 @@ def test_experiment_knobs_are_ignored_by_a_product_build(eng, monkeypatch):
         assert np.array_equal(got[k], base[k]), k      # complete tapes (no skipped fill / scan), the documented tolerance
     for k in basev:
         assert np.array_equal(gotv[k], basev[k]), k
+
+
+def test_smoother_split_tolerance_is_not_an_environment_switch(eng, monkeypatch):
+    """KF_SMOOTHER_SPLIT_TOL loosened a documented tolerance (include/kf.h: 1e-14 of the largest entry) in a
+    product build.  It is a kf_env_experiment knob now: set to 1e-3, the smoothed moments are bit for bit the default's."""
+    w = W.structural(B=96, n=1600)   # (>= 1536 steps: the split path is AUTO's choice)
+    res = eng.forward(*[w[k] for k in ("y", "a0", "P0", "T", "Z", "R", "H", "Q")], exact_recursion=False)
+    monkeypatch.delenv("KF_SMOOTHER_SPLIT_TOL", raising=False)
+    sa, sP = eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
+    monkeypatch.setenv("KF_SMOOTHER_SPLIT_TOL", "1e-3")
+    ta, tP = eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
+    assert np.array_equal(sa.cpu().numpy(), ta.cpu().numpy()) and np.array_equal(sP.cpu().numpy(), tP.cpu().numpy())
