@@ -665,6 +665,22 @@ def main():
                     tvs = tuple(k for k in tv if k in ("T", "R", "Q"))
                     ops["rts_smoother_ms"] = _ms(lambda: eng.smooth(d[3], d[5], d[7], res.filtered_states,
                                                                      res.filtered_covs, time_varying=tvs), reps=3)
+                    # the same smoothed moments from the filter's PREDICTED tapes (kf_smoother_from_filter: what the smoother
+                    # node behind this library's filter node runs -- op.kalman_smoother_graph; p == 1, m <= 15, static), and how
+                    # far the two are apart, relative to each draw's largest entry
+                    if not tv and eng.smooth_from_filter_ok(w_mine["p"], w_mine["m"]):
+                        sff = lambda: eng.smooth_from_filter(d[0], d[3], d[4], d[6], res.predicted_states,  # noqa: E731
+                                                             res.predicted_covs, filter_type=ft)
+                        ops["smoother_from_filter_ms"] = _ms(sff, reps=3)
+                        sa, sP = sff()
+                        ra, rP = eng.smooth(d[3], d[5], d[7], res.filtered_states, res.filtered_covs)
+                        nB = sa.shape[0]
+                        dev_ = lambda x, r: float(((x - r).abs().reshape(nB, -1).max(dim=1).values /  # noqa: E731
+                                                   (1e-300 + r.abs().reshape(nB, -1).max(dim=1).values)).max())
+                        ops["smoother_from_filter_vs_rts_max_rel"] = {"states": dev_(sa, ra), "covariances": dev_(sP, rP)}
+                        nbytes = 2 * 8 * (sa.numel() + sP.numel())
+                        ops["smoother_from_filter_frac_of_hbm_peak"] = nbytes / (ops["smoother_from_filter_ms"] * 1e-3) / (HBM_PEAK_GBS * 1e9)
+                        del sa, sP, ra, rP
             except Exception as e:  # noqa: BLE001 -- an extra must never break the contract line
                 ops["error"] = str(e)[:200]
             out["other_entry_points"] = ops

@@ -297,9 +297,13 @@ int kf_smoother(kf_handle* h, const kf_dims* dims,
  * backward recursion of de Jong / Durbin & Koopman (what statsmodels computes):
  *     v = y - Z a_t - d,  F = Z P_t Z' + H,  K = P_t Z' / F,  L = T (I - K Z)         (a_t, P_t = pred_a[t], pred_P[t])
  *     r_{t-1} = Z' v / F + L' r_t,   N_{t-1} = Z' Z / F + L' N_t L,   smooth_a[t] = a_t + P_t r_{t-1},   smooth_P[t] = P_t - P_t N_{t-1} P_t
- * Equal to kf_smoother's output up to rounding (<= 5e-14 of a draw's largest entry on the BASELINE workloads; asserted at 1e-9 in
- * tests/test_gpu_r05.py), 1.5 - 2x faster at the north-star shape, every draw at the same cost, and a singular prediction
- * covariance (the reference's pinv case) is no special case.  pred_a [B][T+1][m], pred_P [B][T+1][m][m] as kf_filter_forward wrote
+ * Equal to kf_smoother's output up to rounding (measured <= 2e-12 of a draw's largest entry at the BASELINE sizes, asserted at 1e-11;
+ * small shapes at rtol = atol = 1e-9 against the restated reference recursion, tests/test_gpu_r05.py), 1.8x faster at the north-star
+ * shape (4.65 -> 2.62 ms), every draw at the same cost, and a singular prediction covariance (the reference's pinv case) is no
+ * special case.  Conditioning: smooth_P[t] = P_f - P_f M P_f subtracts terms of the size of the FILTERED covariance, as the
+ * reference's G (P_s[t+1] - P_hat) G' does; with a near-diffuse start (P0 = 1e6 I) both lose the same ~10 digits in the first
+ * steps and differ there by ~1e-10 of the largest filtered entry (the reference's own test leaves smoothed covariances [:5] out of
+ * its comparison with statsmodels for this, tests/test_kalman_filter.py:236-241).  pred_a [B][T+1][m], pred_P [B][T+1][m][m] as kf_filter_forward wrote
  * them (slots 0 .. T-1 are read); y, Z, H, d, T as passed to it (d may be NULL); dims->filter: KF_FILTER_SINGLE keeps that
  * filter's sign of d (kalman_filter.py:335); dims->flags: KF_FLAG_Y_PER_DRAW only.  R, Q are not needed.
  * Supported: p == 1, m <= 15, static matrices; anything else returns KF_ERR_UNSUPPORTED (use kf_smoother on the filtered tapes).

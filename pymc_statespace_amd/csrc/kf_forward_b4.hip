@@ -671,6 +671,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   const bool tvT = (TVM & KF_FLAG_TV_T) && (A.flags & KF_FLAG_TV_T), tvZ = (TVM & KF_FLAG_TV_Z) && (A.flags & KF_FLAG_TV_Z);
   const bool tvH = (TVM & KF_FLAG_TV_H) && (A.flags & KF_FLAG_TV_H);
   const bool tvC = (TVM & KF_FLAG_TV_C) && (A.flags & KF_FLAG_TV_C) && A.c, tvD = (TVM & KF_FLAG_TV_D) && (A.flags & KF_FLAG_TV_D) && A.d;
+  const bool tvR = (TVM & KF_FLAG_TV_R) && (A.flags & KF_FLAG_TV_R), tvQ = (TVM & KF_FLAG_TV_Q) && (A.flags & KF_FLAG_TV_Q);
+  constexpr bool RQM = (TVM & (KF_FLAG_TV_R | KF_FLAG_TV_Q)) != 0;   // this instantiation rebuilds C_t = R_t Q_t R_t' per step (r <= 4)
   if (lds_addr(smem) & (unsigned)(8 * RING_P - 1)) __builtin_trap();
   double* TR = smem + B4_OFF_TR;
   double* UX = smem + B4_OFF_UX;
@@ -714,9 +716,25 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     for (int K = 0; K < NB; ++K) zA[K] = (q == 0 && 4 * K + g < m) ? zt[4 * K + g] : 0.0;   // one-row left factor
     zc = (g == 0 && bq < m) ? zt[bq] : 0.0;                                                  // row-0 layout
   };
+  // Round 5: time-varying R / Q (r <= 4).  C_t = R_t (Q_t R_t') is four MFMAs on per-step slices: Q R' (r x N4, one register) from
+  // Q_t as a left factor and R_t' as a right factor, then one MFMA per row block with R_t's blocks as left factors -- no LDS; the
+  // symmetrisation of the predict step (kalman_filter.py:221) makes the tile symmetric whatever the rounding of C_t's two halves.
+  double Rl[RQM ? NB : 1], Rt = 0.0, Ql = 0.0;   // R_t[4I+q][g], R_t[bq][g], Q_t[q][g]  (g < r)
+  auto load_R = [&](const double* Rs) {
+    if constexpr (RQM) {
+#pragma unroll
+      for (int I = 0; I < NB; ++I) Rl[I] = (4 * I + q < m && g < r_) ? Rs[(4 * I + q) * r_ + g] : 0.0;
+      Rt = (bq < m && g < r_) ? Rs[bq * r_ + g] : 0.0;
+    }
+  };
+  auto load_Q = [&](const double* Qs) {
+    if constexpr (RQM) Ql = (q < r_ && g < r_) ? Qs[q * r_ + g] : 0.0;
+  };
   double zc;
   load_T(gT);
   load_z(gZ, zc);
+  load_R(A.R + (tvR ? b * (long)n : b) * (long)m * r_);
+  load_Q(A.Q + (tvQ ? b * (long)n : b) * (long)r_ * r_);
 #pragma unroll
   for (int I = 0; I < NB; ++I) {
     const int rr = 4 * I + g;
@@ -726,6 +744,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     double cv = 0.0, pv = 0.0;
     if (on[I]) {
       double s1 = 0.0, s2 = 0.0;   // R Q R' at (rr, bq) and at (bq, rr): their mean is bitwise symmetric across the mirrored lanes
+      if constexpr (!RQM)          // (time-varying R / Q: rebuild_C below, from the slices)
       for (int l = 0; l < r_; ++l) {
         double rq1 = 0.0, rq2 = 0.0;
         for (int k = 0; k < r_; ++k) {
@@ -744,6 +763,17 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     P[I] = pv;
   }
 
+  auto rebuild_C = [&]() {   // the state block of C_t from the slices in Rl / Rt / Ql; the carrier entries (2 c_t) stay
+    if constexpr (RQM) {
+      const double QRt = mfma4(Ql, Rt, 0.0);
+#pragma unroll
+      for (int I = 0; I < NB; ++I) {
+        const double cs = mfma4(Rl[I], QRt, 0.0);
+        Ch[I] = cJ[I] ? Ch[I] : cs;
+      }
+    }
+  };
+  rebuild_C();
   double H1 = tvH ? 0.0 : A.H[b];
   const double d1 = (A.d && !tvD) ? A.d[b] : 0.0;
   const bool univariate = A.filter == KF_FILTER_UNIVARIATE;
@@ -904,6 +934,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       const double* ct = A.c + (b * (long)n + tn) * m;
 #pragma unroll
       for (int I = 0; I < NB; ++I) Ch[I] = cJ[I] ? 2.0 * ct[cidx[I]] : Ch[I];
+    }
+    if constexpr (RQM) {   // the next step's R / Q slices and C_{t+1} (behind the last use of C_t, the products above)
+      if (tvR) load_R(A.R + (b * (long)n + tn) * (long)m * r_);
+      if (tvQ) load_Q(A.Q + (b * (long)n + tn) * (long)r_ * r_);
+      rebuild_C();
     }
     {
       double Yt[NB];
@@ -1091,27 +1126,31 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size
 }
 
 
-// time-varying T / Z / H / c / d on the block tiles: p == 1, m <= 10 (the tape rings), R and Q static
+// time-varying T / Z / H / c / d on the block tiles: p == 1, m <= 10 (the tape rings); R / Q too when r <= 4 (round 5)
 bool kf_forward_b4tv_ok(int m, int p, int r, unsigned flags) {
-  if (!(flags & KF_FLAG_TV_ANY) || (flags & (KF_FLAG_TV_R | KF_FLAG_TV_Q))) return false;
+  if (!(flags & KF_FLAG_TV_ANY)) return false;
+  if ((flags & (KF_FLAG_TV_R | KF_FLAG_TV_Q)) && r > 4) return false;   // (round 5: R_t / Q_t slices as single 4 x 4 block factors)
   return p == 1 && m >= 1 && m <= 10 && r >= 1 && r <= 64;
 }
 
 int kf_launch_forward_b4tv(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
   if (!kf_forward_b4tv_ok(a.m, a.p, a.r, a.flags) || a.tile_tape) {
-    KF_SET_ERR(h, "forward(b4tv): needs p == 1, m <= 10, time-varying T / Z / H / c / d only (got p=%d m=%d flags=%#x)", a.p, a.m, a.flags);
+    KF_SET_ERR(h, "forward(b4tv): needs p == 1, m <= 10 (time-varying R / Q: r <= 4) (got p=%d m=%d r=%d flags=%#x)", a.p, a.m, a.r, a.flags);
     return KF_ERR_UNSUPPORTED;
   }
   const size_t lds = sizeof(double) * (size_t)B4_LOOP_DOUBLES;
   const int nb = (a.m + 2 + 3) / 4;
   constexpr unsigned M_T = KF_FLAG_TV_T, M_TZ = KF_FLAG_TV_T | KF_FLAG_TV_Z,
-                     M_ALL = KF_FLAG_TV_T | KF_FLAG_TV_Z | KF_FLAG_TV_H | KF_FLAG_TV_C | KF_FLAG_TV_D;
+                     M_ALL = KF_FLAG_TV_T | KF_FLAG_TV_Z | KF_FLAG_TV_H | KF_FLAG_TV_C | KF_FLAG_TV_D,
+                     M_RQ = KF_FLAG_TV_R | KF_FLAG_TV_Q, M_ALLRQ = M_ALL | M_RQ;
   const unsigned tvf = a.flags & KF_FLAG_TV_ANY;
 #define KF_TV_LAUNCH(NB_)                                                                                                   \
   do {                                                                                                                      \
     if (!(tvf & ~M_T)) hipLaunchKernelGGL((kf_fwd_b4tv_kernel<NB_, M_T>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);          \
     else if (!(tvf & ~M_TZ)) hipLaunchKernelGGL((kf_fwd_b4tv_kernel<NB_, M_TZ>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);   \
-    else hipLaunchKernelGGL((kf_fwd_b4tv_kernel<NB_, M_ALL>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);                       \
+    else if (!(tvf & ~M_ALL)) hipLaunchKernelGGL((kf_fwd_b4tv_kernel<NB_, M_ALL>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);  \
+    else if (!(tvf & ~M_RQ)) hipLaunchKernelGGL((kf_fwd_b4tv_kernel<NB_, M_RQ>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);    \
+    else hipLaunchKernelGGL((kf_fwd_b4tv_kernel<NB_, M_ALLRQ>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);                     \
   } while (0)
   switch (nb) {
     case 1: KF_TV_LAUNCH(1); break;

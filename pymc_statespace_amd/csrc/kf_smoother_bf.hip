@@ -35,6 +35,22 @@
 namespace {
 
 constexpr int BF_LB = 32;  // steps per observation block
+// row_allsum (kf_tile.h) without the copies its update_dpp(x, x) form makes before every v_mov_dpp (all lanes are written: no old value)
+template <int CTRL>
+__device__ __forceinline__ double bf_dpp(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bf_row_allsum(double x) {
+  asm volatile("" : "+v"(x));
+  x += bf_dpp<0x128>(x);
+  x += bf_dpp<0x124>(x);
+  x += bf_dpp<0x122>(x);
+  x += bf_dpp<0x121>(x);
+  return x;
+}
+
 template <int NB>
 struct BfLds {
   static constexpr int TILE_D = 4 * NB * TRS;
@@ -206,7 +222,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     double zP = mfma4(Zl[0], Sf[0], 0.0);
 #pragma unroll
     for (int K = 1; K < NB; ++K) zP = mfma4(Zl[K], Sf[K], zP);
-    const double F = H1 + readlane_f64(row_allsum(zP * Zb), 0);
+    const double F = H1 + readlane_f64(bf_row_allsum(zP * Zb), 0);
     const bool upd = yo.y != 0.0 && F > 0.0;  // (F <= 0: the filter flagged the draw; UnivariateFilter skips F == 0, :468-471)
     const double rF = upd ? fast_rcp(F) : 0.0;
     const double v = yo.x - readlane_f64(zP, JC);
@@ -257,9 +273,12 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     }
 #pragma unroll
     for (int I = 0; I < NB; ++I) TN[(4 * I + g) * TRS + fb] = Mn[I];
-    // P_f as a left factor (column JC, a_f, left out)
+    // Pf_ext as a left factor.  Its column JC (a_f) must not take part: row JC of Y is set aside (a_s needs it) and zeroed instead
+    // -- one select, not one per register
 #pragma unroll
-    for (int I = 0; I < NB; ++I) TP[(4 * I + g) * TRS + fb] = col_jc ? 0.0 : Pf[I];
+    for (int I = 0; I < NB; ++I) TP[(4 * I + g) * TRS + fb] = Pf[I];
+    const double yjc = Y[NB - 1];
+    if (row_jc) Y[NB - 1] = 0.0;
     wave_lds_fence();
     left_factor(TN, nl);  // (the next step's)
     double S[NB];
@@ -274,7 +293,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
         S[I] = acc;
       }
     }
-    if (row_jc) S[NB - 1] = Pf[NB - 1] + Y[NB - 1];  // row JC: a_s' = a_f' + (P_f T' r_t)'
+    if (row_jc) S[NB - 1] = Pf[NB - 1] + yjc;  // row JC: a_s' = a_f' + (P_f T' r_t)'
     wave_lds_fence();
     store_moments(t, S);
   }

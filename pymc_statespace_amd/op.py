@@ -223,6 +223,38 @@ def perform_filter_grad(data, a0, P0, T, Z, R, H, Q, c, d, predicted_states, pre
     return [out[k] for k in GRAD_INPUT_NAMES]
 
 
+def perform_filter_grad_batched(data, a0, P0, T, Z, R, H, Q, c, d, predicted_states, predicted_covs,
+                                g_logp, g_ll_obs, filter_type="standard", mvn_const="reference",
+                                h_diagonal=False, engine=None):
+    """``perform_filter_grad`` with ONE leading draw axis on a0 .. d, the predicted tapes, g_logp (B,) and g_ll_obs (B,n): the
+    gradients of sum_b (g_logp[b] logp[b] + <g_ll_obs[b], ll_obs[b]>) from ONE kf_filter_backward call, row b of each = draw b's.
+    What a cotangent on the batched filter's ``ll_obs`` needs (a model that masks or sums ll_obs -- a burn-in -- after
+    ``vectorize_graph``; the per-draw node differentiates it through KalmanFilterGradOp)."""
+    eng = engine or get_engine()
+    data = np.asarray(data, dtype=np.float64)
+    if data.ndim in (3, 4):
+        data = data[..., 0]
+
+    def vec(x):
+        x = np.asarray(x, dtype=np.float64)
+        return x[..., 0] if x.ndim == 3 and x.shape[-1] == 1 else x
+
+    mats = [np.asarray(x, dtype=np.float64) for x in (P0, T, Z, R, H, Q)]
+    if any(x.ndim != 3 for x in mats):
+        raise NotImplementedError("the batched gradient Op takes static system matrices with ONE leading draw axis")
+    pa = np.asarray(predicted_states, dtype=np.float64)
+    if pa.ndim == 4:
+        pa = pa[..., 0]
+    g = eng.backward(data, vec(a0), *mats, vec(c), vec(d), predicted_states=pa,
+                     predicted_covs=np.asarray(predicted_covs, dtype=np.float64),
+                     g_logp=np.asarray(g_logp, dtype=np.float64), g_ll_obs=np.asarray(g_ll_obs, dtype=np.float64),
+                     filter_type=filter_type, mvn_const=mvn_const, want_cd=True, h_diagonal=h_diagonal)
+    out = {k: g[k].cpu().numpy() for k in GRAD_INPUT_NAMES}
+    for k in ("a0", "c", "d"):
+        out[k] = out[k][..., None]
+    return [out[k] for k in GRAD_INPUT_NAMES]
+
+
 def _steady_inputs(data, a0, P0, T, Z, R, H, Q, c):
     data = np.asarray(data, dtype=np.float64)
     if data.ndim == 3:
@@ -563,6 +595,27 @@ def _build_ops():
             g = output_grads[0]  # (B,): draw b's cotangent scales row b of every gradient array
             return [DisconnectedType()()] + [_bcast_rows(g, outputs[1 + k]) for k in range(9)]
 
+    class KalmanFilterBatchedGradOp(Op):
+        """KalmanFilterGradOp with ONE leading draw axis: gradients = Op(data, a0 .. d, predicted_states, predicted_covs,
+        g_logp (B,), g_ll_obs (B,n)) -- perform_filter_grad_batched, one kf_filter_backward call for all draws."""
+        __props__ = ("filter_type", "mvn_const", "h_diagonal")
+
+        def __init__(self, filter_type="standard", mvn_const="reference", h_diagonal=False):
+            self.filter_type, self.mvn_const, self.h_diagonal = filter_type, mvn_const, bool(h_diagonal)
+
+        def make_node(self, *args):
+            args = [pt.as_tensor_variable(a) for a in args]
+            return Apply(self, args, [args[i].type() for i in range(1, 10)])
+
+        def perform(self, node, inputs, output_storage):
+            grads = perform_filter_grad_batched(*inputs, filter_type=self.filter_type, mvn_const=self.mvn_const,
+                                                h_diagonal=self.h_diagonal)
+            for storage, g in zip(output_storage, grads):
+                storage[0] = _out(g)
+
+        def infer_shape(self, fgraph, node, shapes):
+            return [shapes[i] for i in range(1, 10)]
+
     class KalmanFilterBatchedOp(Op):
         """KalmanFilterOp with a leading draw axis B on a0 .. d (data shared): outputs B-leading."""
         __props__ = ("filter_type", "mvn_const", "h_diagonal", "want")
@@ -593,15 +646,28 @@ def _build_ops():
             return [[False] * 6] + [[True] * 6 for _ in range(9)]
 
         def L_op(self, inputs, outputs, output_grads):
-            # gradients flow through the per-draw log-likelihoods only, and come from the fused batched value-and-gradient
-            # node (one kf_filter_value_and_grad call for all B draws)
-            others = [output_grads[i] for i in (0, 1, 2, 3, 5)]
+            # gradients flow through the per-draw log-likelihoods (logp, ll_obs) only.  A cotangent on logp alone comes from the
+            # fused batched value-and-gradient node (one kf_filter_value_and_grad call for all B draws); one on ll_obs (ADVICE
+            # round 4: a burn-in mask after vectorize_graph) from the batched adjoint over this node's predicted tapes
+            others = [output_grads[i] for i in (0, 1, 2, 3)]
             if any(not isinstance(g.type, DisconnectedType) for g in others):
                 return [DisconnectedType()()] + [
-                    grad_not_implemented(self, k, inputs[k], "the batched filter is differentiated through log_likelihood only")
+                    grad_not_implemented(self, k, inputs[k], "the batched filter is differentiated through log_likelihood / ll_obs only")
                     for k in range(1, 10)]
-            fused = KalmanLogpBatchedOp(self.filter_type, self.mvn_const, self.h_diagonal)(*inputs)
-            return [DisconnectedType()()] + [_bcast_rows(output_grads[4], fused[1 + k]) for k in range(9)]
+            g_logp, g_ll = output_grads[4], output_grads[5]
+            if isinstance(g_ll.type, DisconnectedType):
+                fused = KalmanLogpBatchedOp(self.filter_type, self.mvn_const, self.h_diagonal)(*inputs)
+                return [DisconnectedType()()] + [_bcast_rows(g_logp, fused[1 + k]) for k in range(9)]
+            if not (self.want[1] and self.want[3]):
+                return [DisconnectedType()()] + [
+                    grad_not_implemented(self, k, inputs[k], "a cotangent on ll_obs needs the predicted tapes: request "
+                                         "predicted_states and predicted_covariances")
+                    for k in range(1, 10)]
+            if isinstance(g_logp.type, DisconnectedType):
+                g_logp = pt.zeros((inputs[2].shape[0],))
+            grads = KalmanFilterBatchedGradOp(self.filter_type, self.mvn_const, self.h_diagonal)(
+                *inputs, outputs[1], outputs[3], g_logp, g_ll)
+            return [DisconnectedType()()] + list(grads)
 
     class SteadyStateGradOp(Op):
         """gradients = Op(data, a0, P0, T, Z, R, H, Q, c, d, g_logp, g_ll_obs) -- perform_steady_state_grad."""
@@ -847,7 +913,7 @@ def _build_ops():
                 KalmanFilterGradOp=KalmanFilterGradOp, KalmanSmootherOp=KalmanSmootherOp,
                 KalmanLogpOp=KalmanLogpOp, KalmanFilterBatchedOp=KalmanFilterBatchedOp,
                 KalmanLogpBatchedOp=KalmanLogpBatchedOp, KalmanSmootherBatchedOp=KalmanSmootherBatchedOp,
-                KalmanSmootherFusedOp=KalmanSmootherFusedOp,
+                KalmanSmootherFusedOp=KalmanSmootherFusedOp, KalmanFilterBatchedGradOp=KalmanFilterBatchedGradOp,
                 SteadyStateFilterOp=SteadyStateFilterOp, SteadyStateGradOp=SteadyStateGradOp,
                 SteadyStateLogpOp=SteadyStateLogpOp)
     return _OPS

@@ -375,7 +375,7 @@ def test_time_varying_block_kernel_matches_oracle(eng, monkeypatch, ft, tv, m):
 
 def test_time_varying_block_kernel_edges(eng):
     """One step, one draw, a batch beyond the chip's wavefront slots, a series that is not a multiple of the 32-step block, per-draw
-    data, F <= 0 flagged; R / Q time-varying keeps the LDS kernel."""
+    data, F <= 0 flagged; R / Q time-varying with r > 4 keeps the LDS kernel."""
     from oracle import kalman_numpy as kn
 
     for B, n, m in ((1, 1, 4), (1, 33, 10), (5000, 40, 5), (3, 97, 9)):
@@ -402,7 +402,9 @@ def test_time_varying_block_kernel_edges(eng):
                       mvn_const="exact", time_varying=("T",))
     info = res.info.cpu().numpy()
     assert info[2] != 0 and not info[[0, 1, 3]].any()
-    assert eng.forward_kernel_name(4, 50, 1, 6, 2, time_varying=("T", "Q")) == "kf_fwd_lds_kernel"
+    # (round 5: R / Q time-varying ride the block kernel too while r <= 4; beyond that the LDS kernel)
+    assert eng.forward_kernel_name(4, 50, 1, 6, 2, time_varying=("T", "Q")) == "kf_fwd_b4tv_kernel"
+    assert eng.forward_kernel_name(4, 50, 1, 6, 5, time_varying=("T", "Q")) == "kf_fwd_lds_kernel"
 
 
 # ---- RTS smoother: the time-parallel kernels behind the filter's convergence point (kf_smoother_b4_steady.hip) -------------------------
