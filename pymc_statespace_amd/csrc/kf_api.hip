@@ -838,7 +838,6 @@ constexpr int KF_ORD_MAGIC = 0x6b665f74;
 __global__ __launch_bounds__(1024) void kf_vg_order_kernel(const int32_t* __restrict__ ts, int n, int B, int S, int32_t* __restrict__ list,
                                                            int32_t* __restrict__ hdr, int check, int m) {
   __shared__ int hist[KF_ORD_BINS];   // bucket j = KF_ORD_BINS - 1 - key: ascending j = descending ts
-  __shared__ int wsum[64];
   const int tid = threadIdx.x;
   if (hdr) {
     if (check) {
@@ -875,7 +874,6 @@ __global__ __launch_bounds__(1024) void kf_vg_order_kernel(const int32_t* __rest
     }
   }
   __syncthreads();
-  (void)wsum;
   const int R = 4 * S;
   for (int b = tid; b < B; b += 1024) {
     const int r = atomicAdd(&hist[bucket(ts[b])], 1);   // rank, longest first (order inside a bucket: as the atomics fall)

@@ -110,7 +110,17 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     if (A.order) b = A.order[blockIdx.x];
   }
 
-  if (lds_addr(smem) & (unsigned)(8 * RING_P - 1)) __builtin_trap();  // (the dynamic block is the kernel's only LDS: it starts at 0)
+  // The tape rings' absolute slot addresses need the dynamic block on a multiple of the ring size -- true while it is the kernel's
+  // only LDS (it then starts at 0).  The HOST checks that before every launch (b4_static_lds_free: hipFuncGetAttributes, static
+  // shared size 0, else KF_ERR_UNSUPPORTED -- ADVICE round 4: a device trap would take the whole context down); should a build slip
+  // through regardless, the draw comes back as NaN with its info word set instead of being written through misplaced rings
+  if (lds_addr(smem) & (unsigned)(8 * RING_P - 1)) {
+    if (lane == 0) {
+      A.logp[b] = __builtin_nan("");
+      if (A.info) A.info[b] = 0x7fffff01;
+    }
+    return;
+  }
   double* TR = smem + B4_OFF_TR;
   double* STG = smem + B4_OFF_RP;  // !STREAM: compact m x m image (<= 196 doubles) + 64 dump slots at 256
   double* UX = smem + B4_OFF_UX;
@@ -673,7 +683,13 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   const bool tvC = (TVM & KF_FLAG_TV_C) && (A.flags & KF_FLAG_TV_C) && A.c, tvD = (TVM & KF_FLAG_TV_D) && (A.flags & KF_FLAG_TV_D) && A.d;
   const bool tvR = (TVM & KF_FLAG_TV_R) && (A.flags & KF_FLAG_TV_R), tvQ = (TVM & KF_FLAG_TV_Q) && (A.flags & KF_FLAG_TV_Q);
   constexpr bool RQM = (TVM & (KF_FLAG_TV_R | KF_FLAG_TV_Q)) != 0;   // this instantiation rebuilds C_t = R_t Q_t R_t' per step (r <= 4)
-  if (lds_addr(smem) & (unsigned)(8 * RING_P - 1)) __builtin_trap();
+  if (lds_addr(smem) & (unsigned)(8 * RING_P - 1)) {   // (see kf_fwd_b4_kernel: checked on the host before the launch)
+    if (lane == 0) {
+      A.logp[b] = __builtin_nan("");
+      if (A.info) A.info[b] = 0x7fffff01;
+    }
+    return;
+  }
   double* TR = smem + B4_OFF_TR;
   double* UX = smem + B4_OFF_UX;
   double* RG = smem + B4_OFF_RG;
@@ -877,6 +893,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   // T_{t+2} is pulled towards the L2 one step before its loads are issued: one 8-byte load per 64-byte line by the first lanes, its
   // value consumed a whole step later (so nothing ever waits for it): the real loads of T_{t+1}, issued late in step t and needed
   // early in step t + 1, then find their lines on the way instead of starting a full HBM round trip
+  // (the loads used to be kept alive by folding their sum into a never-true comparison that could zero logp; now
+  // the sum ends in an empty `asm volatile` -- the compiler must keep the loads, and logp is written unconditionally)
   double pf_prev = 0.0, pf_sum = 0.0;
   const bool pf_lane = tvT && lane * 8 < mm;
   for (int t = 0; t < n; ++t) {
@@ -936,8 +954,9 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       for (int I = 0; I < NB; ++I) Ch[I] = cJ[I] ? 2.0 * ct[cidx[I]] : Ch[I];
     }
     if constexpr (RQM) {   // the next step's R / Q slices and C_{t+1} (behind the last use of C_t, the products above)
-      if (tvR) load_R(A.R + (b * (long)n + tn) * (long)m * r_);
-      if (tvQ) load_Q(A.Q + (b * (long)n + tn) * (long)r_ * r_);
+      // (a static R / Q is re-read too -- from L1 / L2 -- rather than held across the step: five more live doubles spill)
+      load_R(A.R + (tvR ? b * (long)n + tn : b) * (long)m * r_);
+      load_Q(A.Q + (tvQ ? b * (long)n + tn : b) * (long)r_ * r_);
       rebuild_C();
     }
     {
@@ -956,12 +975,47 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   s_pP.finish(lane, 1.0);
   if (n & (LB - 1)) flush_ring(n & ~(LB - 1), n & (LB - 1));
   if (lane == 0) {
-    A.logp[b] = (pf_sum + pf_prev == 1.2345e300) ? 0.0 : logp;   // (keeps the prefetch loads alive; never true for finite T)
+    A.logp[b] = logp;
     if (A.info) A.info[b] = info;
   }
+  pf_sum += pf_prev;
+  asm volatile("" ::"v"(pf_sum));
 }
 
 }  // namespace
+
+// Host-side guard of the kernels above: their tape rings are addressed by ABSOLUTE LDS address and need the dynamic
+// LDS block on a multiple of 8 RING_P bytes, i.e. at 0 -- which holds exactly while the kernel has no static __shared__ of its own
+// (an inlined helper with one, a debug build or a toolchain change would move it).  Checked once per kernel function.
+#include <mutex>
+#include <unordered_map>
+static int b4_static_lds_free(kf_handle* h, const void* kernel) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> seen;
+  size_t stat = 0;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = seen.find(kernel);
+    if (it == seen.end()) {
+      hipFuncAttributes attr;
+      KF_HIP_CHECK(h, hipFuncGetAttributes(&attr, kernel));
+      it = seen.emplace(kernel, attr.sharedSizeBytes).first;
+    }
+    stat = it->second;
+  }
+  if (stat != 0) {
+    KF_SET_ERR(h, "forward(b4): this build's kernel carries %zu bytes of static LDS; its tape rings need the dynamic block at address 0", stat);
+    return KF_ERR_UNSUPPORTED;
+  }
+  return KF_OK;
+}
+#define KF_B4_GO(KERNEL_, ARGS_)                                                                    \
+  do {                                                                                              \
+    auto kfn_ = KERNEL_;                                                                            \
+    const int rc_ = b4_static_lds_free(h, reinterpret_cast<const void*>(kfn_));                     \
+    if (rc_) return rc_;                                                                            \
+    hipLaunchKernelGGL(kfn_, dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, ARGS_);               \
+  } while (0)
 
 bool kf_forward_b4_ok(int m, int p, int r) { return p == 1 && m >= 1 && m + 2 <= 16 && r >= 1 && r <= 64; }
 
@@ -1039,11 +1093,11 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size
 #define KF_B4_LAUNCH2(NB_, ST_, TM_)                                                                                       \
   do {                                                                                                                     \
     if (split && ST_ && TM_ != 16)                                                                                         \
-      hipLaunchKernelGGL((kf_fwd_b4_kernel<NB_, ST_, TM_, (ST_ && TM_ != 16) ? 2 : 0>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, ac); \
+      KF_B4_GO((kf_fwd_b4_kernel<NB_, ST_, TM_, (ST_ && TM_ != 16) ? 2 : 0>), ac); \
     else if (ss && ST_ && TM_ != 16)                                                                                       \
-      hipLaunchKernelGGL((kf_fwd_b4_kernel<NB_, ST_, TM_, (ST_ && TM_ != 16) ? 1 : 0>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); \
+      KF_B4_GO((kf_fwd_b4_kernel<NB_, ST_, TM_, (ST_ && TM_ != 16) ? 1 : 0>), a); \
     else                                                                                                                   \
-      hipLaunchKernelGGL((kf_fwd_b4_kernel<NB_, ST_, TM_, 0>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);        \
+      KF_B4_GO((kf_fwd_b4_kernel<NB_, ST_, TM_, 0>), a);        \
   } while (0)
 #define KF_B4_LAUNCH(NB_, ST_)                           \
   do {                                                   \
@@ -1051,7 +1105,7 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size
     else if (mask == 0) KF_B4_LAUNCH2(NB_, ST_, 0);      \
     else if (mask == 10) KF_B4_LAUNCH2(NB_, ST_, 10);    \
     else if (mask == 16 && vgs && ST_)                   \
-      hipLaunchKernelGGL((kf_fwd_b4_kernel<NB_, ST_, 16, ST_ ? 1 : 0>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); \
+      KF_B4_GO((kf_fwd_b4_kernel<NB_, ST_, 16, ST_ ? 1 : 0>), a); \
     else if (mask == 16) KF_B4_LAUNCH2(NB_, ST_, 16);    \
     else KF_B4_LAUNCH2(NB_, ST_, -1);                    \
   } while (0)
@@ -1142,15 +1196,16 @@ int kf_launch_forward_b4tv(kf_handle* h, const KfFwdArgs& a, hipStream_t stream)
   const int nb = (a.m + 2 + 3) / 4;
   constexpr unsigned M_T = KF_FLAG_TV_T, M_TZ = KF_FLAG_TV_T | KF_FLAG_TV_Z,
                      M_ALL = KF_FLAG_TV_T | KF_FLAG_TV_Z | KF_FLAG_TV_H | KF_FLAG_TV_C | KF_FLAG_TV_D,
-                     M_RQ = KF_FLAG_TV_R | KF_FLAG_TV_Q, M_ALLRQ = M_ALL | M_RQ;
+                     M_RQ = KF_FLAG_TV_R | KF_FLAG_TV_Q, M_TRQ = M_T | M_RQ, M_ALLRQ = M_ALL | M_RQ;
   const unsigned tvf = a.flags & KF_FLAG_TV_ANY;
 #define KF_TV_LAUNCH(NB_)                                                                                                   \
   do {                                                                                                                      \
-    if (!(tvf & ~M_T)) hipLaunchKernelGGL((kf_fwd_b4tv_kernel<NB_, M_T>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);          \
-    else if (!(tvf & ~M_TZ)) hipLaunchKernelGGL((kf_fwd_b4tv_kernel<NB_, M_TZ>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);   \
-    else if (!(tvf & ~M_ALL)) hipLaunchKernelGGL((kf_fwd_b4tv_kernel<NB_, M_ALL>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);  \
-    else if (!(tvf & ~M_RQ)) hipLaunchKernelGGL((kf_fwd_b4tv_kernel<NB_, M_RQ>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);    \
-    else hipLaunchKernelGGL((kf_fwd_b4tv_kernel<NB_, M_ALLRQ>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);                     \
+    if (!(tvf & ~M_T)) KF_B4_GO((kf_fwd_b4tv_kernel<NB_, M_T>), a);          \
+    else if (!(tvf & ~M_TZ)) KF_B4_GO((kf_fwd_b4tv_kernel<NB_, M_TZ>), a);   \
+    else if (!(tvf & ~M_ALL)) KF_B4_GO((kf_fwd_b4tv_kernel<NB_, M_ALL>), a);  \
+    else if (!(tvf & ~M_RQ)) KF_B4_GO((kf_fwd_b4tv_kernel<NB_, M_RQ>), a);    \
+    else if (!(tvf & ~M_TRQ)) KF_B4_GO((kf_fwd_b4tv_kernel<NB_, M_TRQ>), a);  \
+    else KF_B4_GO((kf_fwd_b4tv_kernel<NB_, M_ALLRQ>), a);                     \
   } while (0)
   switch (nb) {
     case 1: KF_TV_LAUNCH(1); break;
