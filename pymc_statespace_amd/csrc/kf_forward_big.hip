@@ -73,7 +73,38 @@ struct BigGemmExtra {
   const double* zv;     // [B][m]  Z (p == 1), with mrow / mcol
   double* mrow;         // [B][tiles_n][m]  partial sums of C z over the columns of one tile column, or NULL
   double* mcol;         // [B][tiles_m][m]  the mirrored elements' share, over the rows of one tile row
+  // Round 5: block sparsity of the STATIC factor.  tmask[b][rb] (rb = 64-row block of T) has bit kc set when T[64 rb .. +64][32 kc .. +32]
+  // holds a non-zero (big_tmask_kernel, once per call, m <= 1024); a K chunk whose T block is all zero contributes exact zeros to the
+  // accumulators and is skipped -- no loads, no staging, no MFMAs, bit for bit the same product.  tmask_on_b: T is the (transposed)
+  // B operand -- the tile's 64 columns are rows c0 .. of T -- else the A operand (the tile's 128 rows = two 64-row blocks).
+  // The reference's model classes build T from identity / companion / seasonal blocks (models/SARIMAX.py:59-98, VARMAX.py:95-143,
+  // the daily-seasonality notebook): at C5 (m = 367) 61 % of W = T P_f's chunks and 38 % of S = W T' + R Q R''s survive.
+  const uint32_t* tmask = nullptr;
+  int tmask_rb = 0;     // 64-row blocks per draw
+  int tmask_on_b = 0;
+  // the same map of E (R Q R': non-zero only where R has rows -- a 3 x 3 corner of the 367 x 367 matrix at C5, yet 138 MB per launch
+  // as a dense read): a tile whose block of E is all zero does not load it
+  const uint32_t* emask = nullptr;
 };
+
+// tmask[b][rb]: which 32-column chunks of the 64-row block rb of T[b] hold a non-zero (m <= 1024: at most 32 chunks)
+__global__ __launch_bounds__(256) void big_tmask_kernel(const double* __restrict__ T, int m, uint32_t* __restrict__ tmask) {
+  __shared__ unsigned bits;
+  const int rb = blockIdx.x, nrb = gridDim.x;
+  const long b = blockIdx.y;
+  if (threadIdx.x == 0) bits = 0u;
+  __syncthreads();
+  const double* Tb = T + b * (long)m * m;
+  const int r0 = rb * 64, r1 = min(r0 + 64, m);
+  unsigned mine = 0u;
+  for (long e = (long)r0 * m + threadIdx.x; e < (long)r1 * m; e += 256) {
+    const double v = Tb[e];
+    if (v != 0.0 || v != v) mine |= 1u << (unsigned)((e % m) / 32);   // (a NaN counts: it must reach the product)
+  }
+  if (mine) atomicOr(&bits, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) tmask[b * nrb + rb] = bits;
+}
 constexpr int BIG_PFIX_M = 1024;
 constexpr int BIG_AH_ROWS = 64;   // rows of a_hat = T a_f + c per workgroup ahead of the tiles
 template <bool TRANS_B, bool ADD_E, bool UPPER = false, bool PFIX = false, bool MIRROR = false>
@@ -82,8 +113,11 @@ __global__ __launch_bounds__(GNT) __attribute__((amdgpu_waves_per_eu(4))) void b
                                                        const double* __restrict__ E, long strideE,
                                                        double* __restrict__ Cm, long strideC, int m,
                                                        long B, int tiles_n, int tiles_m, const BigGemmExtra x) {
-  __shared__ double As[GK][GLDA];  // As[k][r]  (A tile, k-major)
-  __shared__ double Bs[GK][GLDB];  // Bs[k][c]
+  // one block: As[k][r] (A tile, k-major) | Bs[k][c]; the MIRROR epilogue transposes half a tile through its first 64 x 65 doubles
+  __shared__ double lds_raw[GK * GLDA + GK * GLDB];
+  static_assert(GK * GLDA + GK * GLDB >= 64 * 65, "the mirror epilogue's transpose buffer");
+  double (*As)[GLDA] = reinterpret_cast<double (*)[GLDA]>(lds_raw);
+  double (*Bs)[GLDB] = reinterpret_cast<double (*)[GLDB]>(lds_raw + GK * GLDA);
   __shared__ double vsK[PFIX ? BIG_PFIX_M + GK : 1], vsM[PFIX ? BIG_PFIX_M + GK : 1], vsKF[PFIX ? BIG_PFIX_M + GK : 1];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -105,7 +139,10 @@ __global__ __launch_bounds__(GNT) __attribute__((amdgpu_waves_per_eu(4))) void b
       double sacc[RW];
 #pragma unroll
       for (int r = 0; r < RW; ++r) sacc[r] = 0.0;
+      // (round 5: 64-column pieces of T whose two 32-column chunks are all zero in this 64-row block are not read -- the same sums)
+      const unsigned tbits = x.tmask ? x.tmask[bx * x.tmask_rb + ch] : 0xffffffffu;
       for (int k = lane; k < m; k += 64) {
+        if (!((tbits >> ((k - lane) / 32)) & 3u)) continue;
         const double av = vs[k];
 #pragma unroll
         for (int r = 0; r < RW; ++r) sacc[r] = fma(Tb[(long)min(i0 + r, m - 1) * m + k], av, sacc[r]);
@@ -211,25 +248,51 @@ __global__ __launch_bounds__(GNT) __attribute__((amdgpu_waves_per_eu(4))) void b
     }
   };
 
-  fetch(0);
-  for (int k0 = 0; k0 < m; k0 += GK) {
+  // K chunks: all of them, or (x.tmask) only those whose block of the static factor T holds a non-zero
+  const int nch = (m + GK - 1) / GK;
+  const bool use_mask = x.tmask != nullptr && nch <= 32;
+  unsigned km = 0u;
+  if (use_mask) {
+    const uint32_t* tm = x.tmask + b * x.tmask_rb;
+    if (x.tmask_on_b) {
+      km = tm[c0 / 64];
+    } else {
+      km = tm[r0 / 64];
+      if (r0 / 64 + 1 < x.tmask_rb) km |= tm[r0 / 64 + 1];
+    }
+    km = (unsigned)__builtin_amdgcn_readfirstlane((int)km);
+  }
+  auto next_chunk = [&](int after) -> int {  // wave-uniform; -1: none left
+    if (!use_mask) return after + 1 < nch ? after + 1 : -1;
+    const unsigned rest = after >= 31 ? 0u : (km & (0xffffffffu << (after + 1)));
+    return rest ? __ffs((int)rest) - 1 : -1;
+  };
+  int kc = next_chunk(-1);
+  if (kc >= 0) fetch(kc * GK);
+  while (kc >= 0) {
+    const int k0 = kc * GK;
     stage(k0);
     __syncthreads();
-    if (k0 + GK < m) fetch(k0 + GK);  // in flight during the MFMAs below
+    const int kn = next_chunk(kc);
+    if (kn >= 0) fetch(kn * GK);  // in flight during the MFMAs below
+    const int kend = (m - k0 + 3) & ~3;   // (the last chunk's k beyond m are staged zeros: their MFMAs are skipped)
 #pragma unroll
     for (int ks = 0; ks < GK; ks += 4) {
-      double af[GTI], bf[GTJ];
+      if (ks < kend) {
+        double af[GTI], bf[GTJ];
 #pragma unroll
-      for (int i = 0; i < GTI; ++i) af[i] = As[ks + lk][wr * (GTM / GWR) + i * 16 + li];  // A[i=l&15][k=l>>4]
+        for (int i = 0; i < GTI; ++i) af[i] = As[ks + lk][wr * (GTM / GWR) + i * 16 + li];  // A[i=l&15][k=l>>4]
 #pragma unroll
-      for (int j = 0; j < GTJ; ++j) bf[j] = Bs[ks + lk][wc * (GTN / GWC) + j * 16 + li];  // B[k=l>>4][j=l&15]
+        for (int j = 0; j < GTJ; ++j) bf[j] = Bs[ks + lk][wc * (GTN / GWC) + j * 16 + li];  // B[k=l>>4][j=l&15]
 #pragma unroll
-      for (int i = 0; i < GTI; ++i)
+        for (int i = 0; i < GTI; ++i)
 #pragma unroll
-        for (int j = 0; j < GTJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < GTJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
     }
     __syncthreads();
+    kc = kn;
   }
   // (tried first: a_hat = T a_f as one more COLUMN of the B operand of this product.  A conditional load inside the fetch splits its
   // batch of loads -- 337 against 274 us per launch at C5 -- and as a separate instantiation of the loop for the one tile column that
@@ -237,7 +300,14 @@ __global__ __launch_bounds__(GNT) __attribute__((amdgpu_waves_per_eu(4))) void b
   // ---- epilogue: D[row = (l>>4) + 4*reg][col = l&15] ---------------------------------------------
   double* Cb = Cm + b * strideC;
   const double* Eb = ADD_E ? E + b * strideE : nullptr;
-  if (ADD_E) {
+  bool e_here = ADD_E;
+  if (ADD_E && x.emask) {   // (wave-uniform) any non-zero of E in this tile's rows x columns?
+    const uint32_t* em = x.emask + b * x.tmask_rb;
+    unsigned rows = em[r0 / 64];
+    if (r0 / 64 + 1 < x.tmask_rb) rows |= em[r0 / 64 + 1];
+    e_here = ((rows >> (c0 / 32)) & 3u) != 0u;
+  }
+  if (ADD_E && e_here) {
 #pragma unroll
     for (int i = 0; i < GTI; ++i)
 #pragma unroll
@@ -313,16 +383,43 @@ __global__ __launch_bounds__(GNT) __attribute__((amdgpu_waves_per_eu(4))) void b
           if (MIRROR && gr > gc) continue;
           const double v = acc[i][j][rg];
           Cb[(long)gr * m + gc] = v;
-          if (MIRROR) {
-            Cb[(long)gc * m + gr] = v;
-            if (x.ctape) {
-              double* tp = x.ctape + b * x.ctape_stride;
-              __builtin_nontemporal_store(v, tp + (long)gr * m + gc);
-              if (gr != gc) __builtin_nontemporal_store(v, tp + (long)gc * m + gr);
-            }
-          }
+          if (MIRROR && x.ctape) __builtin_nontemporal_store(v, x.ctape + b * x.ctape_stride + (long)gr * m + gc);
         }
       }
+  if (MIRROR) {
+    // The mirrored copy (c, r) of every element above the diagonal.  Round 5: through an LDS transpose, half a tile (64 rows) at a
+    // time, so that the stores run along rows -- as 8-byte stores straight from the accumulators every lane of a wave-instruction
+    // hit a different line (a third of S = W T' + R Q R''s launch at C5 once the all-zero K chunks were skipped)
+    double* tp = x.ctape ? x.ctape + b * x.ctape_stride : nullptr;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();   // (the buffer: free of the loop's tiles / of the shares above / of the previous half)
+      if ((wr >> 1) == half) {
+#pragma unroll
+        for (int i = 0; i < GTI; ++i)
+#pragma unroll
+          for (int j = 0; j < GTJ; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const int rl = (wr & 1) * (GTM / GWR) + i * 16 + lk + 4 * rg;   // row within the half
+              const int cl = wc * (GTN / GWC) + j * 16 + li;
+              lds_raw[cl * 65 + rl] = acc[i][j][rg];
+            }
+      }
+      __syncthreads();
+      const int rbase = r0 + 64 * half;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int cl = tid >> 3, rl = (tid & 7) + 8 * e;
+        const int gr = rbase + rl, gc = c0 + cl;
+        if (gr < gc && gc < m) {   // (gr < gc < m)
+          const double v = lds_raw[cl * 65 + rl];
+          Cb[(long)gc * m + gr] = v;
+          if (tp) __builtin_nontemporal_store(v, tp + (long)gc * m + gr);
+        }
+      }
+    }
+  }
 }
 
 // RQR' per draw, initial state into the workspace, predicted tape slot 0
@@ -872,7 +969,8 @@ int kf_big_gemm_launch(hipStream_t st, bool trans_b, bool add_e, bool upper_mirr
 size_t kf_forward_big_workspace_bytes(long B, int m, int p) {
   size_t mm = (size_t)m * m;
   const size_t tiles = (size_t)((m + GTM - 1) / GTM + (m + GTN - 1) / GTN);  // shares of m = P z per tile row / tile column
-  return sizeof(double) * ((size_t)B * (4 * mm + 2 * m + 3 * (size_t)m * p + tiles * m) + 64);
+  const size_t tmask_words = 2 * (size_t)B * ((m + 63) / 64);   // big_tmask_kernel's block maps of T and of R Q R'
+  return sizeof(double) * ((size_t)B * (4 * mm + 2 * m + 3 * (size_t)m * p + tiles * m) + 64) + 4 * tmask_words + 64;
 }
 
 int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
@@ -932,6 +1030,19 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
   const BigGemmExtra x0 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0L, nullptr, 0L, nullptr, nullptr, nullptr};
   double* mrow_ws = af_ws + a.B * (size_t)m;             // [B][tgn][m]
   double* mcol_ws = mrow_ws + a.B * (size_t)tgn * m;     // [B][tgm][m]
+  // block map of T (static, m <= 1024): K chunks of all-zero blocks are skipped in both products.  KF_BIG_TMASK=0 in the
+  // environment: every chunk (A/B measurements; the results are bit for bit the same)
+  uint32_t *tmask_ws = nullptr, *emask_ws = nullptr;
+  const int tmask_rb = (m + 63) / 64;
+  {
+    const char* te = kf_env_switch("KF_BIG_TMASK");
+    if (m <= 1024 && !(te && te[0] == '0')) {
+      tmask_ws = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(mcol_ws + a.B * (size_t)tgm * m) + 63) & ~(uintptr_t)63);
+      hipLaunchKernelGGL(big_tmask_kernel, dim3((unsigned)tmask_rb, (unsigned)a.B), dim3(256), 0, stream, a.Tm, m, tmask_ws);
+      emask_ws = tmask_ws + a.B * (size_t)tmask_rb;
+      hipLaunchKernelGGL(big_tmask_kernel, dim3((unsigned)tmask_rb, (unsigned)a.B), dim3(256), 0, stream, RQR_ws, m, emask_ws);
+    }
+  }
   for (int t = 0; t < a.T; ++t) {
     if (fused_update) {
       hipLaunchKernelGGL(big_update_kernel, dim3((unsigned)a.B), dim3(256), lds_upd, stream, a, t, a_ws,
@@ -953,24 +1064,30 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
     // 1-D grid: 8 * tiles * ceil(B / 8) workgroups (see the XCD mapping in the kernel)
     const unsigned ggrid = (unsigned)(8L * tgn * tgm * ((a.B + 7) / 8));
     if (pfix) {  // W = T (P - k m' - m k' + (k f) k'), and a_hat = T a_f + c by the workgroups ahead of the tiles
-      const BigGemmExtra x1 = {K_ws, M_ws, KF_ws, af_ws, a.c, a_ws, a.pred_a ? a.pred_a + (size_t)(t + 1) * m : nullptr,
-                               (long)(a.T + 1) * m, nullptr, 0L, nullptr, nullptr, nullptr};
+      BigGemmExtra x1 = {K_ws, M_ws, KF_ws, af_ws, a.c, a_ws, a.pred_a ? a.pred_a + (size_t)(t + 1) * m : nullptr,
+                         (long)(a.T + 1) * m, nullptr, 0L, nullptr, nullptr, nullptr};
+      x1.tmask = tmask_ws; x1.tmask_rb = tmask_rb; x1.tmask_on_b = 0;
       const unsigned xgrid = (unsigned)(8L * ((m + BIG_AH_ROWS - 1) / BIG_AH_ROWS) * ((a.B + 7) / 8));
       hipLaunchKernelGGL((big_gemm_kernel<false, false, false, true, false>), dim3(ggrid + xgrid), dim3(GNT), 0, stream,
                          a.Tm, (long)mm, P_ws, (long)mm, nullptr, 0L, W_ws, (long)mm, m, a.B, tgn, tgm, x1);
     } else {
+      BigGemmExtra xa = x0;
+      xa.tmask = tmask_ws; xa.tmask_rb = tmask_rb; xa.tmask_on_b = 0;
       hipLaunchKernelGGL((big_gemm_kernel<false, false>), dim3(ggrid), dim3(GNT), 0, stream,
-                         a.Tm, (long)mm, Pf_ws, (long)mm, nullptr, 0L, W_ws, (long)mm, m, a.B, tgn, tgm, x0);
+                         a.Tm, (long)mm, Pf_ws, (long)mm, nullptr, 0L, W_ws, (long)mm, m, a.B, tgn, tgm, xa);
     }
+    BigGemmExtra xb = x0;   // S = W T' + R Q R': T is the transposed B operand
+    xb.tmask = tmask_ws; xb.tmask_rb = tmask_rb; xb.tmask_on_b = 1; xb.emask = emask_ws;
     if (fuse) {
-      const BigGemmExtra x2 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0L,
-                               a.pred_P ? a.pred_P + (size_t)(t + 1) * mm : nullptr, (long)(a.T + 1) * (long)mm,
-                               pfix ? a.Z : nullptr, pfix ? mrow_ws : nullptr, pfix ? mcol_ws : nullptr};
+      BigGemmExtra x2 = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0L,
+                         a.pred_P ? a.pred_P + (size_t)(t + 1) * mm : nullptr, (long)(a.T + 1) * (long)mm,
+                         pfix ? a.Z : nullptr, pfix ? mrow_ws : nullptr, pfix ? mcol_ws : nullptr};
+      x2.tmask = tmask_ws; x2.tmask_rb = tmask_rb; x2.tmask_on_b = 1; x2.emask = emask_ws;
       hipLaunchKernelGGL((big_gemm_kernel<true, true, true, false, true>), dim3(ggrid), dim3(GNT), 0, stream,
                          W_ws, (long)mm, a.Tm, (long)mm, RQR_ws, (long)mm, P_ws, (long)mm, m, a.B, tgn, tgm, x2);
     } else {
       hipLaunchKernelGGL((big_gemm_kernel<true, true, true>), dim3(ggrid), dim3(GNT), 0, stream,
-                         W_ws, (long)mm, a.Tm, (long)mm, RQR_ws, (long)mm, Pf_ws, (long)mm, m, a.B, tgn, tgm, x0);
+                         W_ws, (long)mm, a.Tm, (long)mm, RQR_ws, (long)mm, Pf_ws, (long)mm, m, a.B, tgn, tgm, xb);
       hipLaunchKernelGGL(big_sym_kernel, dim3(ts, ts, (unsigned)a.B), dim3(256), 0, stream, Pf_ws, P_ws,
                          a.pred_P ? a.pred_P + (size_t)(t + 1) * mm : nullptr, (long)(a.T + 1) * (long)mm, m);
     }

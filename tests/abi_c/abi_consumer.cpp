@@ -60,6 +60,7 @@ int main(int argc, char** argv) {
   auto forward = sym<decltype(&kf_filter_forward)>(lib, "kf_filter_forward");
   auto backward = sym<decltype(&kf_filter_backward)>(lib, "kf_filter_backward");
   auto smoother = sym<decltype(&kf_smoother)>(lib, "kf_smoother");
+  auto smoother_ff = sym<decltype(&kf_smoother_from_filter)>(lib, "kf_smoother_from_filter");
   auto ws_bytes = sym<decltype(&kf_workspace_bytes)>(lib, "kf_workspace_bytes");
   auto abi = sym<decltype(&kf_abi_version)>(lib, "kf_abi_version");
   CHECK(abi() == KF_ABI_VERSION);
@@ -140,6 +141,16 @@ int main(int argc, char** argv) {
     std::vector<double> hsa = to_host(sa, n * m);
     CHECK(hsa[(n - 1) * m] == hfa[(n - 1) * m] && hsa[(n - 1) * m + 1] == hfa[(n - 1) * m + 1]);
     CHECK(fabs(hsa[0] - 1119.9055522554306) < 1e-5);  // smoothed state[0], SURVEY 8(c)
+    // the same moments from the filter's predicted tapes (ABI 6): no R, Q, no workspace
+    double* sa2 = to_dev(std::vector<double>(n * m));
+    double* sP2 = to_dev(std::vector<double>(n * m * m));
+    rc = smoother_ff(h, &dims, dy, T, Z, H, nullptr, pa, pP, sa2, sP2, nullptr);
+    if (rc != KF_OK) fprintf(stderr, "%s\n", last_error(h));
+    CHECK(rc == KF_OK);
+    CHECK(hipDeviceSynchronize() == hipSuccess);
+    std::vector<double> hsa2 = to_host(sa2, n * m);
+    CHECK(fabs(hsa2[0] - 1119.9055522554306) < 1e-5);
+    for (int e = 0; e < n * m; ++e) CHECK(fabs(hsa2[e] - hsa[e]) < 1e-7 * (1.0 + fabs(hsa[e])));
 
     double* g1 = to_dev({1.0});
     double* gH = to_dev({0.0});

@@ -9,6 +9,8 @@
   step equal to the filtered moments, intercept d with SingleTimeseriesFilter's sign.
 * time-varying R / Q on the block tiles (kf_fwd_b4tv_kernel, r <= 4): reference filters/kalman_filter.py:79-124, 231-252 -- slice t of
   every flagged matrix at step t -- against the numpy oracle and the LDS kernel it replaces.
+* block sparsity of T in the m > 64 workspace path (kf_forward_big.hip, big_tmask_kernel): K chunks whose block of T is all zero are
+  skipped; bit for bit the product with every chunk (KF_BIG_TMASK=0), and the oracle's numbers.
 """
 import numpy as np
 import pytest
@@ -219,3 +221,39 @@ def test_time_varying_Q_headline_shape_property(eng):
     assert float(((tv.logp - st.logp).abs() / st.logp.abs()).max()) < 1e-12
     assert float((tv.predicted_covs - st.predicted_covs).abs().max()) < 1e-11
     assert float((tv.filtered_states - st.filtered_states).abs().max()) < 1e-10
+
+
+@pytest.mark.parametrize("case", ["seasonal_m151", "seasonal_m367", "dense_m130", "seasonal_m151_dense_rows"])
+def test_big_path_skips_zero_blocks_of_T_bit_for_bit(eng, monkeypatch, case):
+    """The reference's seasonal / companion T (the daily-seasonality notebook, models/SARIMAX.py:59-98) is a shifted identity with
+    a few dense rows: most 64 x 32 blocks are zero, and their K chunks add exact zeros.  Skipping them must not change a bit."""
+    if case == "seasonal_m151":
+        w = W.daily_seasonal(B=5, n=6, s=150)
+    elif case == "seasonal_m367":
+        w = W.daily_seasonal(B=3, n=4)
+    elif case == "dense_m130":
+        w = W.random_dense(3, 5, 1, 130, 3, seed=12)
+    else:
+        w = W.daily_seasonal(B=4, n=5, s=150)
+        rng = np.random.default_rng(3)
+        w["T"] = w["T"].copy()
+        w["T"][:, 70, :] = 0.01 * rng.standard_normal((4, w["m"]))     # a dense row in the second 64-row block
+        w["T"][1, :, 140] = 0.01 * rng.standard_normal(w["m"])          # a dense column in one draw only: per-draw maps
+    assert w["m"] > 96
+    args = _args(w)
+    got = _fwd_np(eng.forward(*args, mvn_const="exact"))
+    monkeypatch.setenv("KF_BIG_TMASK", "0")
+    ref = _fwd_np(eng.forward(*args, mvn_const="exact"))
+    monkeypatch.delenv("KF_BIG_TMASK")
+    for k in got:
+        assert np.array_equal(got[k], ref[k]), k
+    orc = kn.kalman_filter(*args, mvn_const="exact")
+    assert np.max(np.abs(got["logp"] - orc["logp"])) <= 1e-8 * max(1.0, np.abs(orc["logp"]).max() / 1e4)
+    assert_allclose(got["predicted_covs"], orc["predicted_covs"], rtol=1e-9, atol=1e-9)
+    # logp only (the P_f-on-the-way-into-LDS product): the same log-likelihoods
+    lo = eng.forward(*args, mvn_const="exact", store_ll_obs=False, store_filtered=False, store_predicted=False)
+    assert np.max(np.abs(lo.logp.cpu().numpy() - orc["logp"])) <= 1e-8 * max(1.0, np.abs(orc["logp"]).max() / 1e4)
+    monkeypatch.setenv("KF_BIG_TMASK", "0")
+    lo0 = eng.forward(*args, mvn_const="exact", store_ll_obs=False, store_filtered=False, store_predicted=False)
+    monkeypatch.delenv("KF_BIG_TMASK")
+    assert np.array_equal(lo.logp.cpu().numpy(), lo0.logp.cpu().numpy())
