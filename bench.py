@@ -510,6 +510,41 @@ def main():
             }
         dist.barrier()
 
+    # ---- N > 1: the other two entry points a sampler / post-processing step calls, sharded the same way (outside the timed region):
+    # logp + gradient (one kf_filter_value_and_grad per rank + ONE all-gather of the packed rows [logp | info | nine gradients]) and the
+    # smoother over this rank's own tapes (nothing exchanged); max over ranks of the wall time per call
+    multi_ops = None
+    if world > 1 and not big and not args.no_ops and not tv:
+        def _ms_all(fn, reps=5):
+            fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            el = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], dtype=torch.float64,
+                              device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            return float(el.item())
+
+        multi_ops = {}
+        try:
+            vkw = dict(filter_type=ft, mvn_const="exact", h_diagonal=not args.dense_h)
+            multi_ops["logp_and_gradient_gathered_ms"] = _ms_all(lambda: sk.value_and_grad(*d, B_global=B_global, **vkw))
+            multi_ops["logp_and_gradient_local_grads_ms"] = _ms_all(
+                lambda: sk.value_and_grad(*d, B_global=B_global, gather_grads=False, **vkw))
+            if full and B_local > 0:
+                multi_ops["rts_smoother_local_ms"] = _ms_all(
+                    lambda: sk.smooth_local(d[3], d[5], d[7], res.filtered_states, res.filtered_covs), reps=3)
+                if eng.smooth_from_filter_ok(w_mine["p"], w_mine["m"]):
+                    multi_ops["smoother_from_filter_local_ms"] = _ms_all(
+                        lambda: sk.smooth_from_filter_local(d[0], d[3], d[4], d[6], res.predicted_states, res.predicted_covs,
+                                                            filter_type=ft), reps=3)
+        except Exception as e:  # noqa: BLE001 -- an extra must never break the contract line
+            multi_ops["error"] = str(e)[:200]
+
     parity_failed = False
     if rank == 0:
         out = {
@@ -629,6 +664,8 @@ def main():
             except Exception as e:  # noqa: BLE001 -- an extra must never break the contract line
                 ops["error"] = str(e)[:300]
             out["other_entry_points"] = ops
+        if multi_ops is not None:
+            out["other_entry_points_sharded"] = multi_ops
         if world == 1 and not big and not args.no_ops:
             # the other entry points on the same resident inputs, AFTER and outside the timed region (not part of `value`):
             # log-likelihood only, logp + gradient in one call (kf_filter_value_and_grad), RTS smoother over the filtered tapes

@@ -64,8 +64,20 @@ ref = co.kalman_filter(w["y"], *[w[k] for k in ("a0", "P0", "T", "Z", "R", "H", 
                        mvn_const="exact", full=False)["logp"]
 err = float(np.abs(full.cpu().numpy() - ref).max())
 assert err < 1e-8, err
-g, res = sk.forward(dev[0], *[x[lo:hi] for x in dev[1:]], B_global=B, mvn_const="exact")
+shard = [x[lo:hi] for x in dev[1:]]
+g, res = sk.forward(dev[0], *shard, B_global=B, mvn_const="exact")
 assert torch.equal(g, full) and res.filtered_covs.shape[0] == hi - lo
+# round 5: logp + gradient, gathered with ONE all-gather of the packed rows; smoothed tapes stay on the rank
+lp, info, gr = sk.value_and_grad(dev[0], *shard, B_global=B, mvn_const="exact")
+lp1, info1, gr1 = eng.value_and_grad(*dev, mvn_const="exact")
+assert lp.shape == (B,) and not info.any() and float((lp - lp1).abs().max()) < 1e-9
+for k in sk.GRAD_KEYS:
+    assert gr[k].shape == gr1[k].shape, k
+    scale = gr1[k].abs().reshape(B, -1).max(dim=1).values.clamp_min(1e-300)
+    assert float(((gr[k] - gr1[k]).abs().reshape(B, -1).max(dim=1).values / scale).max()) < 1e-9, k
+sa, sP = sk.smooth_local(shard[2], shard[4], shard[6], res.filtered_states, res.filtered_covs)
+fa, fP = sk.smooth_from_filter_local(dev[0], shard[2], shard[3], shard[5], res.predicted_states, res.predicted_covs)
+assert sa.shape[0] == hi - lo and float((sa - fa).abs().max()) < 1e-9 and float((sP - fP).abs().max()) < 1e-9
 dist.barrier()
 dist.destroy_process_group()
 if rank == 0:
@@ -126,6 +138,12 @@ def test_bench_two_ranks_sharing_the_gpu(scaling):
         assert j["config"]["global_draws"] == 600 and j["config"]["draws_per_gpu"] == 300
         assert "strong_scaling" not in j
     assert j["parity"]["max_abs_dlogp_vs_oracle"] < 1e-8
+    # round 5: the sharded logp + gradient (one all-gather of the packed rows) and the per-rank smoothers are timed beside the forward
+    ops = j["other_entry_points_sharded"]
+    assert "error" not in ops, ops
+    for k in ("logp_and_gradient_gathered_ms", "logp_and_gradient_local_grads_ms", "rts_smoother_local_ms",
+              "smoother_from_filter_local_ms"):
+        assert ops[k] > 0.0, k
 
 
 def test_engine_on_another_device_than_the_current_one():
