@@ -99,7 +99,8 @@ enum {
    * H = L L', y* = L^-1 y, Z* = L^-1 Z, d* = L^-1 d, log det L subtracted per observed step: the same state moments and
    * log-likelihood to rounding (kf_forward_whiten.hip) -- given the workspace kf_workspace_bytes_for asks for (B T p doubles for the
    * per-draw series); a partially missing row or an H that is not positive definite makes the dense LDS kernel redo the batch.
-   * The gradient of a dense-H model still runs on the LDS adjoint (entrywise g_H). */
+   * The gradient of a dense-H model: kf_filter_value_and_grad whitens too (round 5, m <= 16: see there); kf_filter_backward on the caller's
+   * own tapes still runs the LDS adjoint (entrywise g_H). */
   KF_FLAG_H_DIAGONAL = 1u << 11,
   /* Forward filter: never switch to the steady-state phase.  The kernels for static models -- the lane kernel (p == 1, m <= 4),
    * the block kernel (p == 1, m <= 10) and the multi-observation block kernel (3 <= p <= 5, m >= 8) -- can test every 8 (lane
@@ -240,6 +241,15 @@ int kf_filter_forward(kf_handle* h, const kf_dims* dims,
  * KF_FLAG_EXACT_RECURSION (or KF_VG_STEADY=0 in the environment) the adjoint at every step.
  * Behind the lane kernel (p == 1, m <= 3) the same split applies up to 32 x CUs draws: the scan
  * kernel takes a_t and the converged covariance from the compact tapes, kf_bwd_b4_kernel the steps before the change-over.
+ * Dense H with p > 1 (round 5; Standard / Cholesky, 2 <= p <= 8, m <= 16, no KF_FLAG_H_DIAGONAL): the call whitens the model per draw
+ * (H = L L', y* = L^-1 y, Z* = L^-1 Z, d* = L^-1 d: kf_forward_whiten.hip), evaluates value and gradient of the whitened model on the
+ * scalar-observation kernels above, and maps the gradients back -- g_Z = L^-T g_Z*, g_d = L^-T g_d*, and the FULL p x p
+ * g_H = L^-T G* L^-1 with G* = -(g n I + sum_t vb_t y~*_t' + g_Z* Z*') / 2 from the invariance of the joint likelihood under
+ * (y*, Z*, d*, H*) -> (A y*, A Z*, A d*, A H* A') (n: fully observed steps; vb_t: the adjoint of the innovation, accumulated by the
+ * adjoint kernels).  C4 with a dense H: 415 -> 24 ms (14.6 with a diagonal one).  g_H is symmetric; g_P0 is the symmetric part of the
+ * entrywise gradient, as with KF_FLAG_H_DIAGONAL (all a symmetric P0 can see).  A partially missing row or an H that is not positive
+ * definite raises a device flag and the dense LDS kernels, launched behind with run_if = flag, redo the batch (no host
+ * synchronisation).  KF_FORWARD_WHITEN=0 in the environment keeps the dense adjoint for everything.
  * Workspace reuse: on the block kernels' path the launch order of the forward kernel's workgroups follows the convergence points the PREVIOUS
  * call left in the same workspace (same B, T, m: a sampler's successive calls) -- draws that will run long are spread over the
  * SIMDs.  This decides only WHERE a draw runs: every output is bitwise the same with a fresh, a reused or an overwritten

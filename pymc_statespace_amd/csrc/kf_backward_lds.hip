@@ -129,6 +129,7 @@ __host__ __device__ inline int bwd_region_doubles(int m, int p) {
 template <int G, int MT>
 __global__ __launch_bounds__(KF_WAVE) void kf_bwd_lds_kernel(const KfBwdArgs A) {
   extern __shared__ double smem[];
+  if (A.run_if && *A.run_if == 0) return;  // (the dense redo behind a whitened value-and-gradient call: nothing to redo)
   constexpr int DPB = KF_WAVE / G;
   const int lane = threadIdx.x;
   const int lig = lane % G;

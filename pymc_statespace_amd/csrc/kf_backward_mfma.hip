@@ -33,7 +33,7 @@ constexpr int PMAXQ = KF_MP_P_MAX;
 
 // dynamic LDS (doubles)
 __host__ __device__ inline int bwd_mfma_lds_doubles(int p) {
-  return 16 /*EX*/ + 2 * PMAXQ /*HD, DL*/ + 2 * PMAXQ /*HB, DB*/ + p * (2 * 16 /*ZC, ZR*/ + 3 * 16 /*MC, MP, AQ*/ + 4 /*SC*/ + 16 /*ZB*/ + 64 /*YB*/) + 64 /*GL*/ + 256 /*final tile*/ + 8 * KF_WAVE /*ACC*/;
+  return 16 /*EX*/ + 2 * PMAXQ /*HD, DL*/ + 2 * PMAXQ /*HB, DB*/ + p * (2 * 16 /*ZC, ZR*/ + 3 * 16 /*MC, MP, AQ*/ + 4 /*SC*/ + 16 /*ZB*/ + 64 /*YB*/) + 64 /*GL*/ + 256 /*final tile*/ + 8 * KF_WAVE /*ACC*/ + 64 /*GY*/;
 }
 
 // (capping the allocation at 128 VGPRs for a fourth wavefront per SIMD spills ~30 values and is
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
   // per-lane accumulators that are touched once per step live in LDS, not in VGPRs (slot s of lane
   // l at ACC[s*64 + l]: conflict-free): Gs = sum Gm (slots 0..3), sum ab' a_f' (slots 4..7)
   double* ACC = FT + 256;
+  double* GY = ACC + 8 * KF_WAVE;       // (g_yy requested) sum_t vb_q (y -+ d)_q', 8 x 8
 
   const bool c_ok = c < m;
   double TA[KS], TB[KS];  // T' tile (TA[s] = T[c][4s+g]) and T tile (TB[s] = T[4s+g][c])
@@ -126,6 +127,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
   double4_t TBm = {0.0, 0.0, 0.0, 0.0};
   double abp = (A.init_ab && c_ok) ? A.init_ab[b * (long)m + c] : 0.0, cb = 0.0, hbv = 0.0, dbv = 0.0;
   const bool acc_out = A.accumulate != 0;
+  const bool want_yy = A.g_yy != nullptr;
+  GY[lane] = 0.0;
   auto put = [&](double* dst, double v) { *dst = acc_out ? *dst + v : v; };
 
   double PN[KS], an;
@@ -320,6 +323,10 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
         hbv += Fb;
         dbv += dsign * vb;
       }
+      if (want_yy && g == 0 && c < p) {   // (vb = 0 on a missing / skipped observation: its y never counts)
+        const double yc = yrow[c];
+        GY[q * 8 + c] = fma(vb, (yc != yc) ? 0.0 : yc + dsign * DL[c], GY[q * 8 + c]);
+      }
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) PB[s] = SB[s];
@@ -350,6 +357,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
       put(A.g_H + b * (long)p * p + e, (q1 == q2) ? HB[q1] : 0.0);
     }
   if (A.g_d && lane < p) put(A.g_d + b * (long)p + lane, DB[lane]);
+  if (want_yy)
+    for (int e = lane; e < p * p; e += KF_WAVE) put(A.g_yy + b * (long)p * p + e, GY[(e / p) * 8 + e % p]);
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     if (!on[s]) continue;

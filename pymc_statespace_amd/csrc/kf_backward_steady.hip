@@ -229,6 +229,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(PS == 1
   const int zj = lane & 15, zq = lane >> 4;    // Z_b: column zj, rows zq + 4 s
   const int vq = lane >> 3, vr = lane & 7;     // sum gl v v'
   double Tb[4] = {0.0, 0.0, 0.0, 0.0}, Kb[2] = {0.0, 0.0}, Zb[2] = {0.0, 0.0}, VV = 0.0, cb = 0.0, db = 0.0, GLs = 0.0;
+  double GYv = 0.0;   // (g_yy requested: the dense-H gradient by whitening, kf_api.hip) sum_t vb_t y~_t' at (vq, vr)
+  const bool want_yy = A.g_yy != nullptr;
   // lanes 16 .. 16+m-1 fetch a_t, lanes 32 .. 32+p-1 fetch y~_t, one step ahead
   const bool is_a = lane >= 16 && lane < 16 + m, is_y = lane >= 32 && lane < 32 + p;
   const double dq = (is_y && A.d) ? A.d[b * (long)p + (lane - 32)] : 0.0;
@@ -266,6 +268,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(PS == 1
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) Zb[s2] = fma(-OUT[56 + zq + 4 * s2], azj, Zb[s2]);
       VV = fma(gl * OUT[48 + vq], OUT[48 + vr], VV);
+      if (want_yy) GYv = fma(OUT[56 + vq], XV[2 * MS + vr], GYv);
       if (lane < 16) cb += XV[lane];
       if (lane >= 56) db = fma(dsign, o, db);
       GLs += gl;
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(PS == 1
     out_ab[b * (long)m + lane] = lam_fin;
   }
   if (lane < p && A.g_d) A.g_d[b * (long)p + lane] = db;
+  if (want_yy && vq < p && vr < p) A.g_yy[b * (long)p * p + vq * p + vr] = GYv;
   if (A.g_R)
     for (int e = lane; e < m * r_; e += KF_WAVE) A.g_R[b * (long)m * r_ + e] = 0.0;
   if (A.g_Q)

@@ -35,6 +35,7 @@ struct KfWhitenWs {
   double* logdet;   // [B]
   int32_t* nobs;    // [B] fully observed steps
   int32_t* flag;    // [1] != 0: fall back to the dense path
+  double* Li = nullptr;   // [B][p][p] L^-1, kept for the gradient's way back (kf_unwhiten_grad_kernel); NULL for a forward call
 };
 
 __global__ __launch_bounds__(KF_WAVE) void kf_whiten_kernel(const KfFwdArgs A, const KfWhitenWs W) {
@@ -81,6 +82,8 @@ __global__ __launch_bounds__(KF_WAVE) void kf_whiten_kernel(const KfFwdArgs A, c
     if (bad) atomicOr(W.flag, 2);
   }
   __syncthreads();
+  if (W.Li)
+    for (int e = lane; e < p * p; e += KF_WAVE) W.Li[b * (long)p * p + e] = Li[(e / p) * WH_P + e % p];
   // Z* = L^-1 Z, d* = L^-1 d, H* = I
   const double* gZ = A.Z + b * (long)p * m;
   for (int e = lane; e < p * m; e += KF_WAVE) {
@@ -154,7 +157,101 @@ size_t wh_carve(void* base, long B, int T, int p, int m, KfWhitenWs* W) {
   return off + 256;
 }
 
+// The gradient's way back (round 5).  The whitened call returned, per draw, g_Z* = dlogp/dZ*, g_d*, and Gamma~ = sum_t vb_t y~*_t'
+// (vb: the adjoint of the innovation; y~* = y* - d*).  The joint likelihood is invariant under y*, Z*, d* -> A y*, A Z*, A d*,
+// H* -> A H* A' up to -n log|det A| per fully observed step; its derivative at A = I, H* = I gives the FULL p x p
+//     G* = dlogp*/dH* = -(g n I + Gamma~ + g_Z* Z*') / 2        (g: the draw's cotangent; the d terms cancel),
+// which no scalar-observation adjoint can produce by itself (they see diag H* only).  With H = L H* L' for the fixed L:
+//     g_H = L^-T sym(G*) L^-1        g_Z = L^-T g_Z*        g_d = L^-T g_d*        logp = logp* - n log det L.
+__global__ __launch_bounds__(KF_WAVE) void kf_unwhiten_grad_kernel(long B, int p, int m, const KfWhitenGrad W, const double* g_logp,
+                                                                    double* logp, double* g_Z, double* g_H, double* g_d) {
+  __shared__ double Li[WH_P * WH_P], G[WH_P * WH_P], X[WH_P * WH_P];
+  const int lane = threadIdx.x;
+  const long b = blockIdx.x;
+  if (*W.flag != 0) return;   // (the dense path redoes the batch)
+  const double gl = g_logp ? g_logp[b] : 1.0;
+  const double nb = (double)W.nobs[b];
+  const int i = lane / WH_P, j = lane % WH_P;
+  Li[lane] = (i < p && j < p) ? W.Li[b * (long)p * p + i * p + j] : 0.0;
+  double gij = 0.0;
+  if (i < p && j < p) {
+    gij = W.gyy[b * (long)p * p + i * p + j] + ((i == j) ? gl * nb : 0.0);
+    const double* gz = W.gZs + b * (long)p * m + (long)i * m;
+    const double* zs = W.Zs + b * (long)p * m + (long)j * m;
+    for (int k = 0; k < m; ++k) gij = fma(gz[k], zs[k], gij);
+  }
+  G[lane] = -0.5 * gij;
+  __syncthreads();
+  const double gs = 0.5 * (G[i * WH_P + j] + G[j * WH_P + i]);
+  __syncthreads();
+  G[lane] = gs;
+  __syncthreads();
+  {  // X = sym(G*) L^-1, then g_H = L^-T X
+    double s = 0.0;
+    for (int k = 0; k < p; ++k) s = fma(G[i * WH_P + k], Li[k * WH_P + j], s);
+    X[lane] = s;
+  }
+  __syncthreads();
+  if (i < p && j < p && g_H) {
+    double s = 0.0;
+    for (int k = 0; k < p; ++k) s = fma(Li[k * WH_P + i], X[k * WH_P + j], s);
+    g_H[b * (long)p * p + i * p + j] = s;
+  }
+  if (g_Z)
+    for (int e = lane; e < p * m; e += KF_WAVE) {
+      const int q = e / m, c = e - q * m;
+      double s = 0.0;
+      for (int k = q; k < p; ++k) s = fma(Li[k * WH_P + q], W.gZs[b * (long)p * m + (long)k * m + c], s);   // (L^-1 is lower triangular)
+      g_Z[b * (long)p * m + e] = s;
+    }
+  if (g_d && lane < p) {
+    double s = 0.0;
+    for (int k = lane; k < p; ++k) s = fma(Li[k * WH_P + lane], W.gds[b * (long)p + k], s);
+    g_d[b * (long)p + lane] = s;
+  }
+  if (lane == 0 && logp) logp[b] -= nb * W.logdet[b];
+}
+
 }  // namespace
+
+size_t kf_whiten_grad_carve(void* base, long B, int T, int p, int m, KfWhitenGrad* W) {
+  char* q = reinterpret_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* r = q + off; off += wh_round(bytes); return r; };
+  W->flag = reinterpret_cast<int32_t*>(take(256));   // FIRST: the dense redo behind the whitened call reuses everything after it
+  W->ys = reinterpret_cast<double*>(take(8 * (size_t)B * T * p));
+  W->Zs = reinterpret_cast<double*>(take(8 * (size_t)B * p * m));
+  W->ds = reinterpret_cast<double*>(take(8 * (size_t)B * p));
+  W->Hs = reinterpret_cast<double*>(take(8 * (size_t)B * p * p));
+  W->logdet = reinterpret_cast<double*>(take(8 * (size_t)B));
+  W->Li = reinterpret_cast<double*>(take(8 * (size_t)B * p * p));
+  W->gZs = reinterpret_cast<double*>(take(8 * (size_t)B * p * m));
+  W->gds = reinterpret_cast<double*>(take(8 * (size_t)B * p));
+  W->gHs = reinterpret_cast<double*>(take(8 * (size_t)B * p * p));
+  W->gyy = reinterpret_cast<double*>(take(8 * (size_t)B * p * p));
+  W->nobs = reinterpret_cast<int32_t*>(take(4 * (size_t)B));
+  return off + 256;
+}
+
+int kf_launch_whiten_for_grad(kf_handle* h, const KfFwdArgs& a, const KfWhitenGrad& G, hipStream_t stream) {
+  if (a.p > WH_P || a.p < 2) {
+    KF_SET_ERR(h, "whitening: needs 2 <= p <= %d", WH_P);
+    return KF_ERR_UNSUPPORTED;
+  }
+  KfWhitenWs W;
+  W.ys = G.ys; W.Zs = G.Zs; W.ds = G.ds; W.Hs = G.Hs; W.logdet = G.logdet; W.nobs = G.nobs; W.flag = G.flag; W.Li = G.Li;
+  hipLaunchKernelGGL(kf_whiten_clear_kernel, dim3(1), dim3(1), 0, stream, W.flag);
+  hipLaunchKernelGGL(kf_whiten_kernel, dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, W);
+  KF_HIP_CHECK(h, hipGetLastError());
+  return KF_OK;
+}
+
+int kf_launch_unwhiten_grad(kf_handle* h, long B, int p, int m, const KfWhitenGrad& W, const double* g_logp, double* logp,
+                            double* g_Z, double* g_H, double* g_d, hipStream_t stream) {
+  hipLaunchKernelGGL(kf_unwhiten_grad_kernel, dim3((unsigned)B), dim3(KF_WAVE), 0, stream, B, p, m, W, g_logp, logp, g_Z, g_H, g_d);
+  KF_HIP_CHECK(h, hipGetLastError());
+  return KF_OK;
+}
 
 size_t kf_forward_whiten_workspace_bytes(long B, int T, int p, int m) {
   KfWhitenWs W;

@@ -58,6 +58,9 @@ struct kf_handle {
   hipStream_t aux_stream2;  // mean recursion
   hipStream_t aux_stream3;  // pair kernel: the tail of the full recursion
   hipEvent_t aux_ev[KF_AUX_EVENTS];
+  // internal (kf_filter_value_and_grad on a dense-H model, kf_api.hip): while the whitened inner call runs, where its adjoints leave
+  // sum_t vb_t y~_t' (KfBwdArgs::g_yy); NULL otherwise
+  double* vg_gyy;
 };
 int kf_handle_aux(kf_handle* h);  // KF_OK once aux_stream / aux_ev exist (current device = the handle's)
 // Scope guard of a launcher that forks work onto the handle's streams: whichever way the function is left -- an error return in the
@@ -168,6 +171,12 @@ struct KfBwdArgs {
   const double* init_ab;
   const double* init_Pb;
   int accumulate;
+  // internal (round 5, the gradient of a dense-H model by whitening, kf_api.hip): [B][p][p], sum over the steps of vb_t y~_t' -- the
+  // adjoint of the innovation times the observation (y -+ d) -- written (accumulate: added to) by the scalar-observation adjoints
+  // that can carry it (kf_backward_mfma.hip, kf_backward_steady.hip); NULL for every public call
+  double* g_yy = nullptr;
+  // internal: the LDS adjoint exits at once unless *run_if != 0 (the dense redo behind a whitened call, like KfFwdArgs::run_if)
+  const int32_t* run_if = nullptr;
   // internal (steady-state adjoint, kf_backward_steady.hip): per-draw number of steps to sweep instead of T (NULL: T for every draw)
   const int32_t* steps = nullptr;
   // internal: workgroup i processes draw list[i] (NULL: draw i) -- a launch whose draws need very different step counts is ordered
@@ -321,6 +330,15 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
                           hipStream_t stream);
 // dense H with p > 1 on the scalar-observation kernels by whitening (kf_forward_whiten.hip)
 size_t kf_forward_whiten_workspace_bytes(long B, int T, int p, int m);
+// the gradient of a dense-H model through the same whitening (round 5): whitened inputs + L^-1 + the whitened gradients' scratch
+struct KfWhitenGrad {
+  double *ys, *Zs, *ds, *Hs, *logdet, *Li, *gZs, *gds, *gHs, *gyy;   // Li [B][p][p]; gZs [B][p][m]; gds [B][p]; gHs, gyy [B][p][p]
+  int32_t *nobs, *flag;
+};
+size_t kf_whiten_grad_carve(void* base, long B, int T, int p, int m, KfWhitenGrad* W);
+int kf_launch_whiten_for_grad(kf_handle* h, const KfFwdArgs& a, const KfWhitenGrad& W, hipStream_t stream);
+int kf_launch_unwhiten_grad(kf_handle* h, long B, int p, int m, const KfWhitenGrad& W, const double* g_logp, double* logp,
+                            double* g_Z, double* g_H, double* g_d, hipStream_t stream);
 int kf_launch_forward_whitened(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream,
                                int (*inner)(kf_handle*, const KfFwdArgs&, void*, size_t, hipStream_t));
 inline bool kf_forward_lds_fits(int m, int p) {
