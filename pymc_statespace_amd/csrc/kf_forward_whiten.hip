@@ -12,7 +12,7 @@
 //                           number of fully observed steps; raises a device flag when the trick does not apply --
 //                           a PARTIALLY missing row (L^-1 spreads the NaN over the observations behind it: the row-deletion
 //                           semantics of such a step, pinned by statsmodels, need the original observations) or an H that is not
-//                           positive definite
+//                           positive definite (a Cholesky pivot below 1e-8 of H's largest diagonal entry counts as that)
 //     (the selected diagonal-H forward kernel, KF_FLAG_H_DIAGONAL | KF_FLAG_Y_PER_DRAW, H* = I)
 //     kf_whiten_fix_kernel  logp and ll_obs minus log det L per observed step
 //     kf_fwd_lds_kernel     launched behind them with KfFwdArgs::run_if = the flag: exits at once when the flag is clear, redoes the
@@ -54,10 +54,15 @@ __global__ __launch_bounds__(KF_WAVE) void kf_whiten_kernel(const KfFwdArgs A, c
   bool bad = false;
   if (lane == 0) {
     double ld = 0.0;
+    //  a RELATIVE pivot rule: a pivot below 1e-8 of the largest diagonal entry -- cond(H) beyond ~1e8, L^-1 of norm
+    // ~1e4 -- is left to the dense path like an H that is not positive definite (the smoother split's Cholesky uses 1e-2 for the
+    // same reason: an absolute `s > 0` accepts a pivot of 1e-300)
+    double hmax = 0.0;
+    for (int j = 0; j < p; ++j) hmax = fmax(hmax, L[j * WH_P + j]);
     for (int j = 0; j < p; ++j) {
       double s = L[j * WH_P + j];
       for (int k = 0; k < j; ++k) s -= L[j * WH_P + k] * L[j * WH_P + k];
-      if (!(s > 0.0)) {
+      if (!(s > 1e-8 * hmax)) {
         bad = true;
         s = 1.0;
       }

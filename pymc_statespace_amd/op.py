@@ -356,16 +356,17 @@ def perform_smoother_batched(T, R, Q, filtered_states, filtered_covs, engine=Non
 
 
 def smoother_from_filter_applies(p, m, ndims):
-    """May the smoothed moments come from the filter's predicted tapes (kf_smoother_from_filter)?  p == 1, m <= 15 and every
-    system matrix static (``ndims``: the per-draw ranks of T, Z, H, R, Q)."""
-    return p == 1 and m <= 15 and all(nd == 2 for nd in ndims)
+    """Should the smoothed moments come from the filter's predicted tapes (kf_smoother_from_filter)?  p == 1, 5 <= m <= 15 and
+    every system matrix static (``ndims``: the per-draw ranks of T, Z, H, R, Q).  The entry point takes m <= 4 too, but there the
+    lane-per-draw RTS kernel is the faster one (C2, 4096 x 1000, m = 2: 0.76 against 0.99 ms)."""
+    return p == 1 and 5 <= m <= 15 and all(nd == 2 for nd in ndims)
 
 
 def perform_smoother_fused(data, T, Z, R, H, Q, d, filtered_states, filtered_covs, predicted_states, predicted_covs,
                            filter_type="standard", engine=None, batched=False):
     """The smoother behind THIS library's filter node (``kalman_smoother_graph`` finds it: the reference never smooths anything
     but its own filter's outputs, core/statespace.py:164-197).  All of the filter's tapes are at hand, so the numeric body picks
-    the cheaper recursion: for p == 1, m <= 15 and static matrices ``kf_smoother_from_filter`` on the PREDICTED tapes (no
+    the cheaper recursion: for p == 1, 5 <= m <= 15 and static matrices ``kf_smoother_from_filter`` on the PREDICTED tapes (no
     pinv(P_hat): include/kf.h), otherwise ``kf_smoother`` on the filtered ones (kalman_smoother.py:56-104 as it stands).
     Shapes: the per-draw reference layouts, or with ONE leading draw axis on everything but a shared data when ``batched``."""
     eng = engine or get_engine()
@@ -989,7 +990,7 @@ def kalman_smoother_graph(T, R, Q, filtered_states, filtered_covariances, fuse=T
     """Symbolic KalmanSmoother.build_graph (reference kalman_smoother.py:56-85).  The reference only ever smooths the outputs of
     its own filter on the same model (core/statespace.py:164-197); when ``filtered_states`` and ``filtered_covariances`` ARE
     outputs 0 and 2 of one ``KalmanFilterOp`` / ``KalmanFilterBatchedOp`` node that also computes its predicted tapes, the
-    smoother node takes that node's inputs and predicted tapes along (``KalmanSmootherFusedOp``): for p == 1, m <= 15 and static
+    smoother node takes that node's inputs and predicted tapes along (``KalmanSmootherFusedOp``): for p == 1, 5 <= m <= 15 and static
     matrices its body is ``kf_smoother_from_filter`` -- same moments, no pinv(P_hat).  ``fuse=False`` (or tapes of any other
     origin): the reference's recursion on the filtered tapes."""
     ops = _build_ops()

@@ -1,0 +1,205 @@
+"""Random-shape parity sweep of round 5's paths.  usage: python scripts/r05/fuzz_r05.py [n_cases] [seed]
+  sff     kf_smoother_from_filter (p = 1, 1 <= m <= 15) against the restated reference recursion on the filtered tapes of the same call
+          and against kf_smoother: every filter type, missing observations anywhere (also first / last), intercept d, per-draw series,
+          slow (unit-root) draws, series lengths around the 32-step block boundary
+  tvrq    time-varying R / Q (+ random other flags) on the block kernel (m <= 10, r <= 4) against the numpy oracle
+  denseh  kf_filter_value_and_grad on a dense H (2 <= p <= 8, m <= 16) against torch autograd of the joint recursion: whole-row missing
+          steps, intercepts, per-draw cotangents; now and then a partially missing row / a singular H (the dense redo)
+  tmask   m > 64 workspace path with random block-sparse T against every chunk (KF_BIG_TMASK=0): bit for bit"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import workloads as W  # noqa: E402
+from oracle import kalman_numpy as kn  # noqa: E402
+from oracle import kalman_torch as kt  # noqa: E402
+from pymc_statespace_amd import KalmanEngine  # noqa: E402
+
+KEYS = ("a0", "P0", "T", "Z", "R", "H", "Q")
+GRADS = ("a0", "P0", "T", "Z", "R", "H", "Q", "c", "d")
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 51)
+eng = KalmanEngine()
+worst = dict(sff_vs_oracle=0.0, sff_vs_kf_smoother=0.0, tvrq_logp=0.0, tvrq_tapes=0.0, denseh_logp=0.0, denseh_grad=0.0)
+counts = dict(sff=0, tvrq=0, denseh=0, denseh_redo=0, tmask=0)
+flagged = []
+t0 = time.time()
+
+
+def rel_rows(a_, x_):
+    B = a_.shape[0]
+    return float(np.max(np.max(np.abs(a_ - x_).reshape(B, -1), axis=1) / (1.0 + np.max(np.abs(x_).reshape(B, -1), axis=1))))
+
+
+def slow(w, idx):
+    for b in idx:
+        if w["m"] >= 2:
+            w["T"][b, 0, 0] = 1.0
+            w["T"][b, 0, 1] = 1.0
+            w["T"][b, 1, 1] = 1.0
+            w["P0"][b] = 1e3 * np.eye(w["m"])
+            w["Q"][b] = w["Q"][b] * 1e-8
+
+
+for case in range(n_cases):
+    kind = int(rng.integers(0, 4))
+    seed = int(rng.integers(1 << 30))
+    tag = ""
+    try:
+        if kind == 0:   # ---- smoother from the filter's tapes ---------------------------------------------------------------------------
+            n = int(rng.choice([1, 2, 31, 32, 33, 64, 65, 100, 200, 320]))
+            B = int(rng.choice([1, 3, 20, 70]))
+            m = int(rng.integers(1, 16))
+            r = int(rng.integers(1, m + 1))
+            ft = str(rng.choice(["standard", "cholesky", "univariate", "single"]))
+            struct = rng.integers(0, 3) == 0 and n >= 31
+            w = W.structural(B=B, n=n, seed=seed) if struct else W.random_dense(B, n, 1, m, r, seed=seed)
+            m = w["m"]
+            if struct and rng.integers(0, 2) == 0:
+                slow(w, rng.integers(0, B, size=max(1, B // 8)))
+            y = w["y"].copy()
+            if rng.integers(0, 4) == 0:
+                y = y[None] + 0.1 * rng.standard_normal((B,) + y.shape)
+            for _ in range(int(rng.integers(0, 4))):
+                y[..., int(rng.choice([0, n - 1, rng.integers(0, n)])), :] = np.nan
+            d = 0.1 * rng.standard_normal((B, 1)) if rng.integers(0, 2) else None
+            tag = f"sff m={m} n={n} B={B} ft={ft} struct={struct} seed={seed}"
+            res = eng.forward(y, *[w[k] for k in KEYS], d=d, filter_type=ft, mvn_const="exact")
+            if res.info.cpu().numpy().any():
+                continue
+            sa, sP = eng.smooth_from_filter(y, w["T"], w["Z"], w["H"], res.predicted_states, res.predicted_covs, d=d, filter_type=ft)
+            ra, rP = eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
+            na, nP = kn.kalman_smoother(w["T"], w["R"], w["Q"], res.filtered_states.cpu().numpy(), res.filtered_covs.cpu().numpy())
+            fmax = np.abs(res.filtered_covs.cpu().numpy()).reshape(B, -1).max(axis=1)
+            # deviations relative to the draw's largest FILTERED covariance entry (the scale both recursions subtract at)
+            eo = max(rel_rows(sa.cpu().numpy(), na.reshape(sa.shape)),
+                     float((np.abs(sP.cpu().numpy() - nP).reshape(B, -1).max(axis=1) / (1.0 + fmax)).max()))
+            ek = max(rel_rows(sa.cpu().numpy(), ra.cpu().numpy()),
+                     float((np.abs(sP.cpu().numpy() - rP.cpu().numpy()).reshape(B, -1).max(axis=1) / (1.0 + fmax)).max()))
+            worst["sff_vs_oracle"] = max(worst["sff_vs_oracle"], eo)
+            worst["sff_vs_kf_smoother"] = max(worst["sff_vs_kf_smoother"], ek)
+            counts["sff"] += 1
+            if not (eo < 1e-8):
+                flagged.append((tag, "vs oracle", eo))
+        elif kind == 1:  # ---- time-varying R / Q on the block kernel --------------------------------------------------------------------
+            n = int(rng.choice([1, 31, 33, 64, 70, 129]))
+            B = int(rng.choice([1, 5, 40]))
+            m = int(rng.integers(1, 11))
+            r = int(rng.integers(1, min(m, 4) + 1))
+            ft = str(rng.choice(["standard", "cholesky", "univariate", "single"]))
+            w = W.random_dense(B, n, 1, m, r, seed=seed)
+            mats = dict(T=w["T"], Z=w["Z"], R=w["R"], H=w["H"], Q=w["Q"], c=0.1 * rng.standard_normal((B, m)), d=0.1 * rng.standard_normal((B, 1)))
+            tv = [nm for nm in ("R", "Q") if rng.integers(0, 2)] or ["Q"]
+            tv += [nm for nm in ("T", "Z", "H", "c", "d") if rng.integers(0, 4) == 0]
+            for name in tv:
+                x = np.repeat(mats[name][:, None], n, axis=1)
+                wob = 0.8 + 0.2 * np.cos(0.37 * np.arange(n) + len(name))
+                mats[name] = x * wob.reshape((1, n) + (1,) * (x.ndim - 2))
+                if name in ("Z", "c", "d", "R"):
+                    mats[name] = mats[name] + 0.05 * rng.standard_normal(mats[name].shape)
+            y = w["y"].copy()
+            for _ in range(int(rng.integers(0, 3))):
+                y[int(rng.integers(0, n))] = np.nan
+            tag = f"tvrq m={m} r={r} n={n} B={B} ft={ft} tv={tv} seed={seed}"
+            args = (y, w["a0"], w["P0"], mats["T"], mats["Z"], mats["R"], mats["H"], mats["Q"], mats["c"], mats["d"])
+            assert eng.forward_kernel_name(B, n, 1, m, r, filter_type=ft, time_varying=tuple(tv)) == "kf_fwd_b4tv_kernel"
+            res = eng.forward(*args, filter_type=ft, mvn_const="exact", time_varying=tuple(tv))
+            ref = kn.kalman_filter_time_varying(*args, time_varying=tuple(tv), filter_type=ft, mvn_const="exact")
+            if res.info.cpu().numpy().any():
+                continue
+            el = float(np.max(np.abs(res.logp.cpu().numpy() - ref["logp"]) / np.maximum(1.0, np.abs(ref["logp"]) / 1e4)))
+            et = max(rel_rows(res.predicted_covs.cpu().numpy(), ref["predicted_covs"]),
+                     rel_rows(res.filtered_states.cpu().numpy(), ref["filtered_states"].reshape(B, n, m)))
+            worst["tvrq_logp"] = max(worst["tvrq_logp"], el)
+            worst["tvrq_tapes"] = max(worst["tvrq_tapes"], et)
+            counts["tvrq"] += 1
+            if not (el < 1e-8 and et < 1e-9):
+                flagged.append((tag, "logp/tapes", (el, et)))
+        elif kind == 2:  # ---- dense-H value and gradient --------------------------------------------------------------------------------
+            n = int(rng.choice([2, 17, 40, 70]))
+            B = int(rng.choice([1, 4, 12]))
+            p = int(rng.integers(2, 9))
+            m = int(rng.integers(max(2, p // 2), 17))
+            r = int(rng.integers(1, min(m, 6) + 1))
+            ft = str(rng.choice(["standard", "cholesky"]))
+            w = W.random_dense(B, n, p, m, r, seed=seed, h_diag=False)
+            y = w["y"].copy()
+            for _ in range(int(rng.integers(0, 3))):
+                y[int(rng.integers(0, n))] = np.nan
+            redo = rng.integers(0, 6) == 0
+            H = w["H"].copy()
+            if redo:
+                if rng.integers(0, 2) and n > 3:
+                    y[int(rng.integers(0, n)), int(rng.integers(0, p))] = np.nan   # a partially missing row
+                else:
+                    H[int(rng.integers(0, B))] = 0.0                                   # not positive definite
+            c = 0.05 * rng.standard_normal((B, m)) if rng.integers(0, 2) else None
+            d = 0.1 * rng.standard_normal((B, p)) if rng.integers(0, 2) else None
+            gl = 1.0 + 0.3 * rng.standard_normal(B) if rng.integers(0, 2) else None
+            tag = f"denseh p={p} m={m} r={r} n={n} B={B} ft={ft} redo={redo} seed={seed}"
+            args = (y, w["a0"], w["P0"], w["T"], w["Z"], w["R"], H, w["Q"])
+            lp, info, g = eng.value_and_grad(*args, c=c, d=d, g_logp=gl, filter_type=ft, mvn_const="exact")
+            if info.cpu().numpy().any():
+                continue
+            rlp, _, rg = kt.logp_and_grads(*args, c=c, d=d, g_logp=gl, filter_type=ft, mvn_const="exact")
+            if not np.all(np.isfinite(rlp)):
+                continue
+            el = float(np.max(np.abs(lp.cpu().numpy() - rlp) / np.maximum(1.0, np.abs(rlp) / 1e4)))
+            eg = 0.0
+            for k in GRADS:
+                a = g[k].cpu().numpy()
+                rr = np.asarray(rg[k]).reshape(a.shape)
+                if k in ("P0", "H", "Q"):
+                    a, rr = 0.5 * (a + np.swapaxes(a, -1, -2)), 0.5 * (rr + np.swapaxes(rr, -1, -2))
+                eg = max(eg, rel_rows(a, rr))
+            worst["denseh_logp"] = max(worst["denseh_logp"], el)
+            worst["denseh_grad"] = max(worst["denseh_grad"], eg)
+            counts["denseh"] += 1
+            counts["denseh_redo"] += int(redo)
+            if not (el < 1e-8 and eg < 1e-7):
+                flagged.append((tag, "logp/grad", (el, eg)))
+        else:            # ---- block-sparse T in the workspace path ----------------------------------------------------------------------
+            m = int(rng.choice([65, 97, 130, 200]))
+            n = int(rng.choice([2, 5]))
+            B = int(rng.choice([1, 3, 9]))
+            w = W.random_dense(B, n, 1, m, 3, seed=seed)
+            T = np.zeros_like(w["T"])
+            for b in range(B):
+                kind_t = int(rng.integers(0, 3))
+                if kind_t == 0:      # shifted identity + a dense row
+                    idx = np.arange(m - 1)
+                    T[b, 1 + idx, idx] = 0.9
+                    T[b, int(rng.integers(0, m)), :] = 0.01 * rng.standard_normal(m)
+                elif kind_t == 1:    # random block-diagonal
+                    s0 = 0
+                    while s0 < m:
+                        k = int(rng.integers(1, 40))
+                        e0 = min(m, s0 + k)
+                        T[b, s0:e0, s0:e0] = w["T"][b, s0:e0, s0:e0]
+                        s0 = e0
+                else:                # dense
+                    T[b] = w["T"][b]
+            tag = f"tmask m={m} n={n} B={B} seed={seed}"
+            args = (w["y"], w["a0"], w["P0"], T, w["Z"], w["R"], w["H"], w["Q"])
+            got = eng.forward(*args, mvn_const="exact")
+            os.environ["KF_BIG_TMASK"] = "0"
+            try:
+                ref = eng.forward(*args, mvn_const="exact")
+            finally:
+                del os.environ["KF_BIG_TMASK"]
+            same = all(np.array_equal(getattr(got, k).cpu().numpy(), getattr(ref, k).cpu().numpy(), equal_nan=True)
+                       for k in ("logp", "ll_obs", "filtered_states", "predicted_states", "filtered_covs", "predicted_covs"))
+            counts["tmask"] += 1
+            if not same:
+                flagged.append((tag, "bitwise", None))
+    except Exception as e:  # noqa: BLE001
+        flagged.append((tag, "exception", repr(e)[:300]))
+print(f"fuzz_r05: {n_cases} cases in {time.time() - t0:.0f} s  counts {counts}")
+print("worst deviations:", {k: float(f"{v:.3g}") for k, v in worst.items()})
+print(f"flagged: {len(flagged)}")
+for f in flagged[:40]:
+    print("  ", f)

@@ -365,3 +365,27 @@ def test_dense_H_value_and_grad_c4_shard(eng):
     assert float(((lp[idx] - lp0).abs() / lp0.abs()).max()) < 1e-11
     err = _rel_grad_err({k: g[k][idx] for k in GRADS}, {k: g0[k].cpu().numpy() for k in GRADS})
     assert max(err.values()) < 1e-8, err
+
+
+def test_ill_conditioned_dense_H_goes_to_the_dense_path(eng):
+    """an H with a Cholesky pivot below 1e-8 of its largest diagonal entry (cond ~ 1e10) is not whitened -- L^-1 would
+    have norm ~1e5 -- but handed to the dense path by the same device flag as an H that is not positive definite; forward tapes and
+    value-and-gradient against the oracle."""
+    from oracle import kalman_torch as kt
+
+    w = W.random_dense(B=6, n=40, p=3, m=6, r=3, seed=11, h_diag=False)
+    H = w["H"].copy()
+    u = np.array([1.0, 1.0, 0.0]) / np.sqrt(2.0)
+    for b in (1, 4):   # two draws: H = I + (1e-10 - 1) u u' in the (y1, y2) plane -> eigenvalues 1, 1, 1e-10
+        H[b] = np.eye(3) + (1e-10 - 1.0) * np.outer(u, u)
+    args = (w["y"], w["a0"], w["P0"], w["T"], w["Z"], w["R"], H, w["Q"])
+    res = eng.forward(*args, mvn_const="exact")
+    ref = kn.kalman_filter(*args, mvn_const="exact")
+    assert np.all(np.abs(res.logp.cpu().numpy() - ref["logp"]) <= 1e-8 * np.maximum(1.0, np.abs(ref["logp"]) / 1e4))
+    assert_allclose(res.filtered_states.cpu().numpy(), ref["filtered_states"].reshape(6, 40, 6), rtol=1e-8, atol=1e-8)
+    lp, info, g = eng.value_and_grad(*args, mvn_const="exact")
+    rlp, _, rg = kt.logp_and_grads(*args, mvn_const="exact")
+    assert np.all(np.abs(lp.cpu().numpy() - rlp) <= 1e-8 * np.maximum(1.0, np.abs(rlp) / 1e4))
+    err = _rel_grad_err(g, rg)
+    assert max(v for k, v in err.items() if k != "H") < 1e-7, err   # (g_H of the near-singular draws: ~1e10-sized entries, 1e-6 relative)
+    assert err["H"] < 1e-5, err
