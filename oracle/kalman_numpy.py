@@ -14,7 +14,8 @@ What it restates (all paths relative to /root/reference/pymc_statespace):
 * ``filters/kalman_filter.py:321-351``  SingleTimeseriesFilter.update
 * ``filters/kalman_filter.py:444-505``  UnivariateFilter
 * ``filters/kalman_filter.py:165-193``  _postprocess_scan_results
-* ``filters/kalman_smoother.py:56-104``  KalmanSmoother
+* ``filters/kalman_smoother.py:56-104``  KalmanSmoother  (``kalman_smoother``; and ``smoother_from_filter``: the same moments by the
+  de Jong / Durbin-Koopman recursion on the filter's predicted tapes -- the checker of ``kf_smoother_from_filter``)
 
 The reference evaluates ONE parameter draw per graph call; here every system
 matrix may carry a leading batch axis ``B`` (the batch-of-draws axis the MI355X
@@ -522,6 +523,67 @@ def _kalman_smoother_tv(T, R, Q, filtered_states, filtered_covs, tv, shift=0):
         a_s = a + np.einsum("bij,bj->bi", gain, a_s - a_hat)
         P_s = P + gain @ (P_s - P_hat) @ _T(gain)
         sa[:, t], sP[:, t] = a_s, P_s
+    return sa, sP
+
+
+def smoother_from_filter(data, T, Z, H, predicted_states, predicted_covs, d=None, filter_type="standard"):
+    """The smoothed moments from the FILTER's predicted tapes, by the backward recursion of de Jong (1989) / Durbin & Koopman
+    (2012, section 4.4) -- the recursion statsmodels itself runs, i.e. the external oracle of the reference's only numeric test
+    (tests/test_kalman_filter.py:226-241); what ``kf_smoother_from_filter`` (csrc/kf_smoother_bf.hip) computes on the GPU:
+
+        v_t = y_t - Z a_t - d      F_t = Z P_t Z' + H      K_t = P_t Z' F_t^-1      L_t = T (I - K_t Z)
+        r_{t-1} = Z' F_t^-1 v_t + L_t' r_t       N_{t-1} = Z' F_t^-1 Z + L_t' N_t L_t       (r_{n-1} = 0, N_{n-1} = 0)
+        a_s[t] = a_t + P_t r_{t-1}               P_s[t] = P_t - P_t N_{t-1} P_t
+
+    with (a_t, P_t) = predicted_states[:, t], predicted_covs[:, t] (the (B, n+1, ..) tapes of ``kalman_filter``; slot n unused).
+    Missing entries of y_t are deleted from that step (rows of Z, rows / columns of H: the semantics statsmodels pins); a wholly
+    missing step has L_t = T and no Z terms.  Same E / Var of the state given all observations as ``kalman_smoother`` (the
+    reference's RTS form, kalman_smoother.py:56-104), without pinv(P_hat): the two agree to rounding where P_hat is well
+    conditioned, and this form stays bounded where the RTS recursion does not (a numerically singular P_hat: rank-deficient state
+    noise behind a long series -- scripts/r05/fuzz_r05.py found draws whose RTS covariances reach 1e22 .. 1e63 in float64).
+    Pinned against every statsmodels golden vector in tests/test_oracle_golden.py.  Any p; ``filter_type="single"`` flips the
+    sign of d (kalman_filter.py:335).  Returns (smoothed_states (B,n,m), smoothed_covs (B,n,m,m))."""
+    y = np.asarray(data, dtype=np.float64)
+    T_b, _ = _as_batch(T, 2)
+    Z_b, _ = _as_batch(Z, 2)
+    H_b, _ = _as_batch(H, 2)
+    pa = np.asarray(predicted_states, dtype=np.float64)
+    pP = np.asarray(predicted_covs, dtype=np.float64)
+    m, p = T_b.shape[-1], Z_b.shape[-2]
+    if pa.shape[-1] == 1 and pa.ndim >= 2 and pa.shape[-2] == m:
+        pa = pa[..., 0]
+    if pP.ndim == 3:
+        pa, pP = pa[None], pP[None]
+    B = pP.shape[0]
+    n = pP.shape[1] - 1
+    T_b = np.broadcast_to(T_b, (B, m, m))
+    Z_b = np.broadcast_to(Z_b, (B, p, m))
+    H_b = np.broadcast_to(H_b, (B, p, p))
+    dv = np.zeros((B, p)) if d is None else np.broadcast_to(np.asarray(d, dtype=np.float64).reshape(-1, p), (B, p))
+    dsign = 1.0 if filter_type == "single" else -1.0
+    per_draw = y.ndim == 3
+    sa = np.empty((B, n, m))
+    sP = np.empty((B, n, m, m))
+    for b in range(B):
+        Tm, r, N = T_b[b], np.zeros(m), np.zeros((m, m))
+        for t in range(n - 1, -1, -1):
+            yt = (y[b, t] if per_draw else y[t]).reshape(p)
+            ob = ~np.isnan(yt)
+            a, P = pa[b, t], pP[b, t]
+            if ob.any():
+                Zo = Z_b[b][ob]
+                F = Zo @ P @ Zo.T + H_b[b][np.ix_(ob, ob)]
+                Fi = np.linalg.inv(F)
+                v = yt[ob] - Zo @ a + dsign * dv[b][ob]
+                K = P @ Zo.T @ Fi
+                L = Tm @ (np.eye(m) - K @ Zo)
+                r = Zo.T @ (Fi @ v) + L.T @ r
+                N = Zo.T @ Fi @ Zo + L.T @ N @ L
+            else:
+                r = Tm.T @ r
+                N = Tm.T @ N @ Tm
+            sa[b, t] = a + P @ r
+            sP[b, t] = P - P @ N @ P
     return sa, sP
 
 

@@ -1258,7 +1258,7 @@ extern "C" int kf_smoother_from_filter(kf_handle* h, const kf_dims* dims, const 
     KF_SET_ERR(h, "kf_smoother_from_filter: all pointers but d must be non-NULL");
     return KF_ERR_ARG;
   }
-  if (!kf_smoother_bf_ok(dims->m, dims->p, dims->flags)) {
+  if (!kf_smoother_bf_ok(dims->m, dims->p, dims->flags & ~(unsigned)(KF_FLAG_EXACT_RECURSION | KF_FLAG_STEADY_STATE))) {
     KF_SET_ERR(h, "kf_smoother_from_filter: needs p == 1, m <= 15 and static matrices (p=%d m=%d flags=0x%x); use kf_smoother",
                dims->p, dims->m, dims->flags);
     return KF_ERR_UNSUPPORTED;
@@ -1267,6 +1267,11 @@ extern "C" int kf_smoother_from_filter(kf_handle* h, const kf_dims* dims, const 
   KfSmoothBfArgs a;
   a.B = dims->B; a.T = dims->T; a.m = dims->m; a.filter = dims->filter;
   a.flags = dims->flags & KF_FLAG_Y_PER_DRAW;
+  a.exact = (dims->flags & KF_FLAG_EXACT_RECURSION) ? 1 : 0;
+  {
+    const char* e = kf_env_switch("KF_SMOOTHER_STEADY");  // =0: as KF_FLAG_EXACT_RECURSION (A/B measurements), like kf_smoother
+    if (e && e[0] == '0') a.exact = 1;
+  }
   a.y = y; a.Tm = T; a.Z = Z; a.H = H; a.d = d; a.pred_a = pred_a; a.pred_P = pred_P;
   a.smooth_a = smooth_a; a.smooth_P = smooth_P;
   return kf_launch_smoother_bf(h, a, (hipStream_t)stream);

@@ -211,6 +211,7 @@ struct KfSmoothBfArgs {
   int T, m;
   int filter;      // KF_FILTER_SINGLE flips the sign of d (kalman_filter.py:335)
   unsigned flags;  // KF_FLAG_Y_PER_DRAW
+  int exact;       // KF_FLAG_EXACT_RECURSION: every step in full (no steady phase)
   const double* y;
   const double* Tm;
   const double* Z;

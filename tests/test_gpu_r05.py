@@ -3,8 +3,9 @@
 * kf_smoother_from_filter (csrc/kf_smoother_bf.hip): the smoothed moments of KalmanSmoother.build_graph
   (pymc_statespace/filters/kalman_smoother.py:56-104) from the filter's PREDICTED tapes and the observation side of the model,
   without pinv(P_hat).  Held to (i) the statsmodels golden vectors -- the reference's own external oracle,
-  tests/test_kalman_filter.py:226-241, at the reference's tolerances --, (ii) the restated reference recursion in
-  oracle/kalman_numpy.py on the filtered tapes of the same forward call (rtol = atol = 1e-9), (iii) kf_smoother itself at
+  tests/test_kalman_filter.py:226-241, at the reference's tolerances --, (ii) the numpy restatement of the same recursion
+  (oracle/kalman_numpy.py::smoother_from_filter, itself pinned to every golden vector: 1e-10) and the restated reference recursion
+  on the filtered tapes of the same forward call (rtol = atol = 1e-9), (iii) kf_smoother itself at
   BASELINE sizes (<= 1e-11 of a draw's largest entry), and the edge cases the reference tests: missing observations, the last
   step equal to the filtered moments, intercept d with SingleTimeseriesFilter's sign.
 * time-varying R / Q on the block tiles (kf_fwd_b4tv_kernel, r <= 4): reference filters/kalman_filter.py:79-124, 231-252 -- slice t of
@@ -89,6 +90,11 @@ def test_smoother_from_filter_matches_reference_recursion(eng, case, missing):
     res = eng.forward(*_args(w, y), mvn_const="exact")
     assert not res.info.cpu().numpy().any()
     sa, sP = eng.smooth_from_filter(y, w["T"], w["Z"], w["H"], res.predicted_states, res.predicted_covs)
+    # (i) the restatement of this very recursion (oracle/kalman_numpy.py::smoother_from_filter, pinned to statsmodels): 1e-10
+    da, dP = kn.smoother_from_filter(y, w["T"], w["Z"], w["H"], res.predicted_states.cpu().numpy(), res.predicted_covs.cpu().numpy())
+    assert_allclose(sa.cpu().numpy(), da, rtol=1e-10, atol=1e-10)
+    assert_allclose(sP.cpu().numpy(), dP, rtol=1e-10, atol=1e-10 * max(1.0, float(np.abs(res.filtered_covs.cpu().numpy()).max())))
+    # (ii) the reference's own recursion on the filtered tapes of the same call
     na, nP = kn.kalman_smoother(w["T"], w["R"], w["Q"], res.filtered_states.cpu().numpy(), res.filtered_covs.cpu().numpy())
     na = na.reshape(sa.shape)
     if case == "arma11":

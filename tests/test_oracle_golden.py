@@ -145,3 +145,35 @@ def test_missing_row_gives_no_nan(ft, p):
                                 w["Z"][0], w["R"][0], w["H"][0], w["Q"][0], filter_type=ft)
     for o in outs:
         assert not np.any(np.isnan(o))
+
+
+@pytest.mark.parametrize("name", golden_files())
+def test_smoother_from_filter_matches_statsmodels(name):
+    """The de Jong / Durbin-Koopman restatement (oracle/kalman_numpy.py::smoother_from_filter, the checker of
+    kf_smoother_from_filter) against EVERY golden vector -- p > 1, partially missing rows and the H = 0 ARMA case included --
+    at 1e-9, where the RTS restatement needs 1e-2 on arma11 (pinv's rank decision on an exactly singular P_hat)."""
+    g = load_golden(name)
+    out = _run(g, "standard", mvn_const="exact", partial_missing="delete")
+    sa, sP = kn.smoother_from_filter(g["y"], g["T"], g["Z"], g["H"], out["predicted_states"], out["predicted_covs"])
+    if _ill_conditioned(name):
+        assert_allclose(sa, g["smoothed_state"], rtol=1e-7, atol=1e-7)
+        assert_allclose(sP[:, 5:], g["smoothed_state_cov"][:, 5:], rtol=1e-7, atol=1e-7)
+    else:
+        assert_allclose(sa, g["smoothed_state"], rtol=1e-9, atol=1e-9)
+        assert_allclose(sP, g["smoothed_state_cov"], rtol=1e-9, atol=1e-9)
+
+
+def test_smoother_from_filter_equals_the_rts_restatement_where_it_is_well_conditioned():
+    import workloads as W
+
+    w = W.structural(B=5, n=90)
+    y = w["y"].copy()
+    y[[0, 7, 8, 89]] = np.nan
+    d = 0.1 * np.arange(5.0)[:, None]
+    for ft in ("standard", "single"):
+        out = kn.kalman_filter(y, *[w[k] for k in ("a0", "P0", "T", "Z", "R", "H", "Q")], d=d, filter_type=ft)
+        ra, rP = kn.kalman_smoother(w["T"], w["R"], w["Q"], out["filtered_states"], out["filtered_covs"])
+        sa, sP = kn.smoother_from_filter(y, w["T"], w["Z"], w["H"], out["predicted_states"], out["predicted_covs"], d=d,
+                                         filter_type=ft)
+        assert_allclose(sa, ra.reshape(sa.shape), rtol=1e-10, atol=1e-10)
+        assert_allclose(sP, rP, rtol=1e-10, atol=1e-10)
