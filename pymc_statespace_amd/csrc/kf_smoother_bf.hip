@@ -100,6 +100,19 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   // ---- per-draw constants ---------------------------------------------------------------------------------------------------
   double Tt[NB][NB];  // left-factor blocks of T_aug': lane (g = k, any b, q = i) holds T_aug[4K+g][4I+q]
   double Tr[NB];      // row-block registers of T_aug
+  auto load_T = [&]() {   // (again behind a steady phase: its constants take these registers meanwhile)
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+      const int rr = 4 * I + g;
+#pragma unroll
+      for (int K = 0; K < NB; ++K) {
+        const int ti = 4 * I + q, tk = 4 * K + g;
+        Tt[I][K] = (ti < m && tk < m) ? gT[tk * m + ti] : ((ti == JC && tk == JC) ? 1.0 : 0.0);
+      }
+      Tr[I] = (rr < m && bq < m) ? gT[rr * m + bq] : ((rr == JC && bq == JC) ? 1.0 : 0.0);
+    }
+  };
+  load_T();
   const double* src[NB];
   int stp[NB];
   bool on_tp[NB];
@@ -109,12 +122,6 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
 #pragma unroll
   for (int I = 0; I < NB; ++I) {
     const int rr = 4 * I + g;
-#pragma unroll
-    for (int K = 0; K < NB; ++K) {
-      const int ti = 4 * I + q, tk = 4 * K + g;
-      Tt[I][K] = (ti < m && tk < m) ? gT[tk * m + ti] : ((ti == JC && tk == JC) ? 1.0 : 0.0);
-    }
-    Tr[I] = (rr < m && bq < m) ? gT[rr * m + bq] : ((rr == JC && bq == JC) ? 1.0 : 0.0);
     // tape image of step t: the state block P_t, a_t in column JC and in row JC; zero elsewhere
     on_tp[I] = true;
     if (rr < m && bq < m) { src[I] = gpP + rr * m + bq; stp[I] = mm; }
@@ -173,10 +180,12 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
   const int nb128 = mm >> 1;
   const bool st1 = lane < nb128, st1b = (mm & 1) && lane == nb128;
   const bool st2 = lane + KF_WAVE < nb128, st2b = (mm & 1) && lane + KF_WAVE == nb128;
-  auto store_moments = [&](int t, const double (&S)[NB]) {
+  auto stage_image = [&](const double (&S)[NB]) {
 #pragma unroll
     for (int I = 0; I < NB; ++I) *reinterpret_cast<double*>(reinterpret_cast<char*>(smem) + img_off[I]) = S[I];
     wave_lds_fence();
+  };
+  auto emit_image = [&](int t) {
     double* dst = A.smooth_P + (b * (long)n + t) * mm;
     const double2_t v2 = *reinterpret_cast<const double2_t*>(IMG + 2 * lane);
     if (st1) *(reinterpret_cast<double2_t*>(dst) + lane) = v2;
@@ -188,6 +197,10 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(NB <= 3
     }
     if (lane < m) A.smooth_a[(b * (long)n + t) * m + lane] = IMA[lane];
     wave_lds_fence();
+  };
+  auto store_moments = [&](int t, const double (&S)[NB]) {
+    stage_image(S);
+    emit_image(t);
   };
   // left factor X(I, K) of a tile in LDS: lane (g = k, any b, q = i) gets X[4I+q][4K+g], K = 0 .. 3
   auto left_factor = [&](const double* tile, double (&Lf)[NB][4]) {
