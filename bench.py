@@ -656,6 +656,10 @@ def main():
                 ops["gradient_sweep_ms_per_step"] = _ms1(lambda: eng.backward(
                     *d40, predicted_states=r40.predicted_states, predicted_covs=r40.predicted_covs,
                     g_logp=torch.ones(B_local, dtype=torch.float64, device=dev), filter_type=ft, mvn_const="exact")) / ns
+                if eng.smooth_from_filter_ok(p, m):
+                    # the smoother from the predicted tapes (kf_smoother_from_filter, workspace path): no inverse of P_hat
+                    ops["smoother_from_filter_ms_per_step"] = _ms1(lambda: eng.smooth_from_filter(
+                        d40[0], d[3], d[4], d[6], r40.predicted_states, r40.predicted_covs, filter_type=ft)) / ns
                 del r40
                 torch.cuda.empty_cache()
                 ops["logp_and_gradient_one_call_ms_per_step"] = _ms1(lambda: eng.value_and_grad(

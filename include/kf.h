@@ -209,7 +209,8 @@ int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes);
  * does not hold the gradient's scratch.  The HBM-workspace kernels (m > 64) put the draw axis in
  * gridDim.y/z: B <= 65535 there (KF_ERR_UNSUPPORTED beyond; chunk the batch). */
 enum { KF_WS_FORWARD = 1, KF_WS_BACKWARD = 2, KF_WS_SMOOTHER = 4, KF_WS_ALL = 7,
-       KF_WS_VALUE_AND_GRAD = 8 /* kf_filter_value_and_grad: tapes + both passes (not part of KF_WS_ALL) */ };
+       KF_WS_VALUE_AND_GRAD = 8 /* kf_filter_value_and_grad: tapes + both passes (not part of KF_WS_ALL) */,
+       KF_WS_SMOOTHER_FROM_FILTER = 16 /* kf_smoother_from_filter: 0 for m <= 15 (not part of KF_WS_ALL) */ };
 int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, int which, size_t* bytes);
 
 /* Forward filter for B draws.  c, d may be NULL (= 0: initialize_intercepts,
@@ -316,11 +317,14 @@ int kf_smoother(kf_handle* h, const kf_dims* dims,
  * its comparison with statsmodels for this, tests/test_kalman_filter.py:236-241).  pred_a [B][T+1][m], pred_P [B][T+1][m][m] as kf_filter_forward wrote
  * them (slots 0 .. T-1 are read); y, Z, H, d, T as passed to it (d may be NULL); dims->filter: KF_FILTER_SINGLE keeps that
  * filter's sign of d (kalman_filter.py:335); dims->flags: KF_FLAG_Y_PER_DRAW only.  R, Q are not needed.
- * Supported: p == 1, m <= 15, static matrices; anything else returns KF_ERR_UNSUPPORTED (use kf_smoother on the filtered tapes).
- * No workspace. */
+ * Supported: p == 1, static matrices, m <= 15 on chip (no workspace) and 15 < m <= 1024 on the HBM workspace with the fp64-MFMA
+ * products of the m > 64 filter path (kf_smoother_bf_big.hip: two dense products and two with the block-sparse T per step instead of
+ * kf_smoother's four products + blocked Cholesky + two triangular solves; workspace: kf_workspace_bytes_for(h, dims,
+ * KF_WS_SMOOTHER_FROM_FILTER, &bytes) = 5 B m^2 doubles + vectors); anything else returns KF_ERR_UNSUPPORTED (use kf_smoother on
+ * the filtered tapes).  KF_FLAG_EXACT_RECURSION is accepted and has no effect (every step is done in full). */
 int kf_smoother_from_filter(kf_handle* h, const kf_dims* dims, const double* y, const double* T, const double* Z,
                             const double* H, const double* d, const double* pred_a, const double* pred_P,
-                            double* smooth_a, double* smooth_P, void* stream);
+                            double* smooth_a, double* smooth_P, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- the step before the filter ---------------------------
  * Batched theta -> matrix assembly: out[b][:] = tmpl[:], then out[b][dst[i]] = theta[b][src[i]]

@@ -25,6 +25,7 @@ KF_FLAG_TV = {"T": 1 << 4, "Z": 1 << 5, "R": 1 << 6, "H": 1 << 7, "Q": 1 << 8, "
 
 KF_WS_FORWARD, KF_WS_BACKWARD, KF_WS_SMOOTHER, KF_WS_ALL = 1, 2, 4, 7
 KF_WS_VALUE_AND_GRAD = 8
+KF_WS_SMOOTHER_FROM_FILTER = 16
 KF_OK, KF_ERR_ARG, KF_ERR_HIP, KF_ERR_WORKSPACE, KF_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 
 # every symbol include/kf.h declares (tests check the built library exports them all)
@@ -97,7 +98,7 @@ def load():
     lib.kf_filter_value_and_grad.restype = C.c_int
     lib.kf_smoother.argtypes = [vp, C.POINTER(KfDims)] + [dp] * 5 + [dp] * 2 + [vp, C.c_size_t, vp]
     lib.kf_smoother.restype = C.c_int
-    lib.kf_smoother_from_filter.argtypes = [vp, C.POINTER(KfDims)] + [dp] * 7 + [dp] * 2 + [vp]
+    lib.kf_smoother_from_filter.argtypes = [vp, C.POINTER(KfDims)] + [dp] * 7 + [dp] * 2 + [vp, C.c_size_t, vp]
     lib.kf_smoother_from_filter.restype = C.c_int
     lib.kf_assemble.argtypes = [vp, C.c_int64, C.c_int32, dp, C.c_int64, dp, C.c_int32, dp, dp, dp, vp]
     lib.kf_assemble.restype = C.c_int

@@ -695,6 +695,11 @@ static bool kf_vg_tile_steady_path(const kf_handle* h, const kf_dims* d) {
 
 extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, int which, size_t* bytes) {
   if (!h || !dims || !bytes) return KF_ERR_ARG;
+  if (which == KF_WS_SMOOTHER_FROM_FILTER) {
+    *bytes = kf_smoother_bf_big_ok(dims->m, dims->p, dims->flags & ~(unsigned)(KF_FLAG_EXACT_RECURSION | KF_FLAG_STEADY_STATE))
+                 ? kf_smoother_bf_big_workspace_bytes(dims->B, dims->m) : 0;
+    return KF_OK;
+  }
   if (which & KF_WS_VALUE_AND_GRAD) {
     size_t inner = 0;
     const int rc = kf_workspace_bytes_for(h, dims, KF_WS_FORWARD | KF_WS_BACKWARD, &inner);
@@ -1251,15 +1256,17 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
 
 extern "C" int kf_smoother_from_filter(kf_handle* h, const kf_dims* dims, const double* y, const double* T, const double* Z,
                                        const double* H, const double* d, const double* pred_a, const double* pred_P,
-                                       double* smooth_a, double* smooth_P, void* stream) {
+                                       double* smooth_a, double* smooth_P, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_dims(h, dims, true);
   if (rc) return rc;
   if (!y || !T || !Z || !H || !pred_a || !pred_P || !smooth_a || !smooth_P) {
     KF_SET_ERR(h, "kf_smoother_from_filter: all pointers but d must be non-NULL");
     return KF_ERR_ARG;
   }
-  if (!kf_smoother_bf_ok(dims->m, dims->p, dims->flags & ~(unsigned)(KF_FLAG_EXACT_RECURSION | KF_FLAG_STEADY_STATE))) {
-    KF_SET_ERR(h, "kf_smoother_from_filter: needs p == 1, m <= 15 and static matrices (p=%d m=%d flags=0x%x); use kf_smoother",
+  const unsigned fl = dims->flags & ~(unsigned)(KF_FLAG_EXACT_RECURSION | KF_FLAG_STEADY_STATE);
+  const bool big = kf_smoother_bf_big_ok(dims->m, dims->p, fl);
+  if (!big && !kf_smoother_bf_ok(dims->m, dims->p, fl)) {
+    KF_SET_ERR(h, "kf_smoother_from_filter: needs p == 1, m <= 1024 and static matrices (p=%d m=%d flags=0x%x); use kf_smoother",
                dims->p, dims->m, dims->flags);
     return KF_ERR_UNSUPPORTED;
   }
@@ -1274,6 +1281,7 @@ extern "C" int kf_smoother_from_filter(kf_handle* h, const kf_dims* dims, const 
   }
   a.y = y; a.Tm = T; a.Z = Z; a.H = H; a.d = d; a.pred_a = pred_a; a.pred_P = pred_P;
   a.smooth_a = smooth_a; a.smooth_P = smooth_P;
+  if (big) return kf_launch_smoother_bf_big(h, a, workspace, workspace_bytes, (hipStream_t)stream);
   return kf_launch_smoother_bf(h, a, (hipStream_t)stream);
 }
 

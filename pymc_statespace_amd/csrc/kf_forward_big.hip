@@ -85,6 +85,10 @@ struct BigGemmExtra {
   // the same map of E (R Q R': non-zero only where R has rows -- a 3 x 3 corner of the 367 x 367 matrix at C5, yet 138 MB per launch
   // as a dense read): a tile whose block of E is all zero does not load it
   const uint32_t* emask = nullptr;
+  // (kf_smoother_bf_big.hip) C = [-] A op(B) [+ E] + u1 v1' + u2 v2': the sign flips the product BEFORE E is added (E - A op(B)); the
+  // rank-one terms are per-draw vectors [B][m] (any of them NULL: that term is absent)
+  int neg_acc = 0;
+  const double *u1 = nullptr, *v1 = nullptr, *u2 = nullptr, *v2 = nullptr;
 };
 
 // tmask[b][rb]: which 32-column chunks of the 64-row block rb of T[b] hold a non-zero (m <= 1024: at most 32 chunks)
@@ -300,6 +304,28 @@ __global__ __launch_bounds__(GNT) __attribute__((amdgpu_waves_per_eu(4))) void b
   // ---- epilogue: D[row = (l>>4) + 4*reg][col = l&15] ---------------------------------------------
   double* Cb = Cm + b * strideC;
   const double* Eb = ADD_E ? E + b * strideE : nullptr;
+  if (x.neg_acc) {
+#pragma unroll
+    for (int i = 0; i < GTI; ++i)
+#pragma unroll
+      for (int j = 0; j < GTJ; ++j) acc[i][j] = -acc[i][j];
+  }
+  if (x.u1) {   // rank-one terms
+    const double *pu1 = x.u1 + b * m, *pv1 = x.v1 + b * m;
+    const double *pu2 = x.u2 ? x.u2 + b * m : nullptr, *pv2 = x.u2 ? x.v2 + b * m : nullptr;
+#pragma unroll
+    for (int j = 0; j < GTJ; ++j) {
+      const int gc = c0 + wc * (GTN / GWC) + j * 16 + li;
+      const double c1 = gc < m ? pv1[gc] : 0.0, c2 = (pu2 && gc < m) ? pv2[gc] : 0.0;
+#pragma unroll
+      for (int i = 0; i < GTI; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int gr = r0 + wr * (GTM / GWR) + i * 16 + lk + 4 * rg;
+          if (gr < m) acc[i][j][rg] = fma(pu1[gr], c1, fma(pu2 ? pu2[gr] : 0.0, c2, acc[i][j][rg]));
+        }
+    }
+  }
   bool e_here = ADD_E;
   if (ADD_E && x.emask) {   // (wave-uniform) any non-zero of E in this tile's rows x columns?
     const uint32_t* em = x.emask + b * x.tmask_rb;
@@ -963,6 +989,36 @@ int kf_big_gemm_launch(hipStream_t st, bool trans_b, bool add_e, bool upper_mirr
     hipLaunchKernelGGL((big_gemm_kernel<false, true>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x0);
   else
     return KF_ERR_UNSUPPORTED;
+  return hipGetLastError() == hipSuccess ? KF_OK : KF_ERR_HIP;
+}
+
+// the same product with what kf_smoother_bf_big.hip / kf_smoother_big.hip need on top: the block map of a static factor (which
+// operand it is: tmask_on_b), a sign, rank-one terms.  trans_b / add_e as above; never the mirrored forms.
+int kf_big_gemm_launch_x(hipStream_t st, bool trans_b, bool add_e, const double* A, long sA, const double* Bm, long sB, const double* E,
+                         long sE, double* C, long sC, int m, long draws, const uint32_t* tmask, int tmask_on_b, int neg_acc,
+                         const double* u1, const double* v1, const double* u2, const double* v2) {
+  const int tgm = (m + GTM - 1) / GTM, tgn = (m + GTN - 1) / GTN;
+  const unsigned ggrid = (unsigned)(8L * tgn * tgm * ((draws + 7) / 8));
+  BigGemmExtra x = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0L, nullptr, 0L, nullptr, nullptr, nullptr};
+  x.tmask = (m <= 1024) ? tmask : nullptr;
+  x.tmask_rb = (m + 63) / 64;
+  x.tmask_on_b = tmask_on_b;
+  x.neg_acc = neg_acc;
+  x.u1 = u1; x.v1 = v1; x.u2 = u2; x.v2 = v2;
+  if (!trans_b && !add_e)
+    hipLaunchKernelGGL((big_gemm_kernel<false, false>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x);
+  else if (!trans_b && add_e)
+    hipLaunchKernelGGL((big_gemm_kernel<false, true>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x);
+  else if (trans_b && !add_e)
+    hipLaunchKernelGGL((big_gemm_kernel<true, false>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x);
+  else
+    hipLaunchKernelGGL((big_gemm_kernel<true, true>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x);
+  return hipGetLastError() == hipSuccess ? KF_OK : KF_ERR_HIP;
+}
+
+// block map of a per-draw m x m matrix (64-row blocks x 32-column chunks, m <= 1024): tmask[B][ceil(m / 64)]
+int kf_big_tmask_launch(hipStream_t st, const double* T, int m, long B, uint32_t* tmask) {
+  hipLaunchKernelGGL(big_tmask_kernel, dim3((unsigned)((m + 63) / 64), (unsigned)B), dim3(256), 0, st, T, m, tmask);
   return hipGetLastError() == hipSuccess ? KF_OK : KF_ERR_HIP;
 }
 

@@ -224,6 +224,10 @@ struct KfSmoothBfArgs {
 };
 bool kf_smoother_bf_ok(int m, int p, unsigned flags);
 int kf_launch_smoother_bf(kf_handle* h, const KfSmoothBfArgs& a, hipStream_t stream);
+// the same recursion on the HBM workspace for 15 < m <= 1024 (kf_smoother_bf_big.hip)
+bool kf_smoother_bf_big_ok(int m, int p, unsigned flags);
+size_t kf_smoother_bf_big_workspace_bytes(long B, int m);
+int kf_launch_smoother_bf_big(kf_handle* h, const KfSmoothBfArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 // per-draw LDS footprints (in doubles) -- shared by host launchers and kernels
 __host__ __device__ inline int kf_fwd_region_doubles(int m, int p) {
@@ -327,6 +331,10 @@ size_t kf_forward_big_workspace_bytes(long B, int m, int p);
 // kf_forward_big.hip's 128 x 64-tile fp64-MFMA product for m x m operands (see there)
 int kf_big_gemm_launch(hipStream_t st, bool trans_b, bool add_e, bool upper_mirror, const double* A, long sA, const double* Bm,
                        long sB, const double* E, long sE, double* C, long sC, int m, long draws);
+int kf_big_gemm_launch_x(hipStream_t st, bool trans_b, bool add_e, const double* A, long sA, const double* Bm, long sB, const double* E,
+                         long sE, double* C, long sC, int m, long draws, const uint32_t* tmask, int tmask_on_b, int neg_acc,
+                         const double* u1, const double* v1, const double* u2, const double* v2);
+int kf_big_tmask_launch(hipStream_t st, const double* T, int m, long B, uint32_t* tmask);
 int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
                           hipStream_t stream);
 // dense H with p > 1 on the scalar-observation kernels by whitening (kf_forward_whiten.hip)

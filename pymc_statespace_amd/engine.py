@@ -415,14 +415,16 @@ class KalmanEngine:
 
 
     def smooth_from_filter_ok(self, p: int, m: int, time_varying=()) -> bool:
-        """Does kf_smoother_from_filter take this shape (p == 1, m <= 15, static matrices)?"""
-        return p == 1 and 1 <= m <= 15 and not tuple(time_varying)
+        """Does kf_smoother_from_filter take this shape (p == 1, m <= 1024, static matrices: on chip up to m = 15, on the HBM
+        workspace beyond)?"""
+        return p == 1 and 1 <= m <= 1024 and not tuple(time_varying)
 
     def smooth_from_filter(self, data, T, Z, H, predicted_states, predicted_covs, d=None, filter_type: str = "standard"):
         """kf_smoother_from_filter -> (smoothed_states (B,n,m), smoothed_covs (B,n,m,m)) from the FILTER's predicted tapes
         (B,n+1,m), (B,n+1,m,m) and the observation side of the model it ran on (data, Z, H, d) -- the same moments
         ``smooth`` computes from the filtered tapes (kalman_smoother.py:56-104) up to rounding, without inverting the prediction
-        covariance (include/kf.h).  p == 1, m <= 15, static matrices; ``filter_type="single"`` keeps that filter's sign of d."""
+        covariance (include/kf.h).  p == 1, static matrices, m <= 15 on chip and 15 < m <= 1024 on the workspace path;
+        ``filter_type="single"`` keeps that filter's sign of d."""
         if filter_type not in _lib.KF_FILTER:
             raise ValueError(f"unknown filter_type {filter_type!r}")
         T = self.to_device(T)
@@ -444,8 +446,9 @@ class KalmanEngine:
             dims.flags |= _lib.KF_FLAG_Y_PER_DRAW
         sa = torch.empty(B, n, m, device=self.device, dtype=torch.float64)
         sP = torch.empty(B, n, m, m, device=self.device, dtype=torch.float64)
+        ws, ws_bytes = self._workspace(dims, _lib.KF_WS_SMOOTHER_FROM_FILTER)   # (m > 15 only: 5 B m^2 doubles + vectors)
         rc = self.lib.kf_smoother_from_filter(self._h, C.byref(dims), _ptr(y), _ptr(T), _ptr(Z), _ptr(H), _ptr(d),
-                                              _ptr(pa), _ptr(pP), _ptr(sa), _ptr(sP), self._stream())
+                                              _ptr(pa), _ptr(pP), _ptr(sa), _ptr(sP), _ptr(ws), ws_bytes, self._stream())
         self._check(rc, "kf_smoother_from_filter")
         return sa, sP
 

@@ -356,17 +356,19 @@ def perform_smoother_batched(T, R, Q, filtered_states, filtered_covs, engine=Non
 
 
 def smoother_from_filter_applies(p, m, ndims):
-    """Should the smoothed moments come from the filter's predicted tapes (kf_smoother_from_filter)?  p == 1, 5 <= m <= 15 and
-    every system matrix static (``ndims``: the per-draw ranks of T, Z, H, R, Q).  The entry point takes m <= 4 too, but there the
-    lane-per-draw RTS kernel is the faster one (C2, 4096 x 1000, m = 2: 0.76 against 0.99 ms)."""
-    return p == 1 and 5 <= m <= 15 and all(nd == 2 for nd in ndims)
+    """Should the smoothed moments come from the filter's predicted tapes (kf_smoother_from_filter)?  p == 1, every system
+    matrix static (``ndims``: the per-draw ranks of T, Z, H, R, Q) and 5 <= m <= 15 (the on-chip kernel) or 64 < m <= 1024 (both
+    recursions run on the HBM workspace there and the one from the predicted tapes has no factorisation: C5, 128 draws, m = 367:
+    1.09 against 2.97 ms per step).  The entry point takes every m <= 1024, but at m <= 4 the lane-per-draw RTS kernel is the
+    faster one (C2, 4096 x 1000, m = 2: 0.76 against 0.99 ms) and at 16 <= m <= 64 so are the on-chip RTS kernels."""
+    return p == 1 and (5 <= m <= 15 or 64 < m <= 1024) and all(nd == 2 for nd in ndims)
 
 
 def perform_smoother_fused(data, T, Z, R, H, Q, d, filtered_states, filtered_covs, predicted_states, predicted_covs,
                            filter_type="standard", engine=None, batched=False):
     """The smoother behind THIS library's filter node (``kalman_smoother_graph`` finds it: the reference never smooths anything
     but its own filter's outputs, core/statespace.py:164-197).  All of the filter's tapes are at hand, so the numeric body picks
-    the cheaper recursion: for p == 1, 5 <= m <= 15 and static matrices ``kf_smoother_from_filter`` on the PREDICTED tapes (no
+    the cheaper recursion: for p == 1, 5 <= m <= 15 or 64 < m <= 1024, and static matrices ``kf_smoother_from_filter`` on the PREDICTED tapes (no
     pinv(P_hat): include/kf.h), otherwise ``kf_smoother`` on the filtered ones (kalman_smoother.py:56-104 as it stands).
     Shapes: the per-draw reference layouts, or with ONE leading draw axis on everything but a shared data when ``batched``."""
     eng = engine or get_engine()

@@ -144,7 +144,7 @@ int main(int argc, char** argv) {
     // the same moments from the filter's predicted tapes (ABI 6): no R, Q, no workspace
     double* sa2 = to_dev(std::vector<double>(n * m));
     double* sP2 = to_dev(std::vector<double>(n * m * m));
-    rc = smoother_ff(h, &dims, dy, T, Z, H, nullptr, pa, pP, sa2, sP2, nullptr);
+    rc = smoother_ff(h, &dims, dy, T, Z, H, nullptr, pa, pP, sa2, sP2, nullptr, 0, nullptr);
     if (rc != KF_OK) fprintf(stderr, "%s\n", last_error(h));
     CHECK(rc == KF_OK);
     CHECK(hipDeviceSynchronize() == hipSuccess);

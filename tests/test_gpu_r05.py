@@ -44,7 +44,7 @@ def _args(w, y=None):
 
 
 def _p1_golden():
-    return [f for f in golden_files() if load_golden(f)["Z"].shape[-2] == 1 and load_golden(f)["T"].shape[-1] <= 15]
+    return [f for f in golden_files() if load_golden(f)["Z"].shape[-2] == 1]
 
 
 @pytest.mark.parametrize("name", _p1_golden())
@@ -133,7 +133,7 @@ def test_smoother_from_filter_y_per_draw(eng):
 
 
 def test_smoother_from_filter_rejects_what_it_does_not_take(eng):
-    """p > 1 and m > 15 are kf_smoother's: KF_ERR_UNSUPPORTED with a message, nothing launched."""
+    """p > 1 and m > 1024 are kf_smoother's: KF_ERR_UNSUPPORTED with a message, nothing launched."""
     import ctypes as C
 
     import torch
@@ -142,14 +142,18 @@ def test_smoother_from_filter_rejects_what_it_does_not_take(eng):
     from pymc_statespace_amd.engine import KalmanError
 
     t = torch.zeros(8, device=eng.device, dtype=torch.float64)
-    for p_, m_ in ((5, 10), (1, 16)):
+    for p_, m_ in ((5, 10), (1, 1025)):
         dims = _lib.KfDims(3, 20, p_, m_, 2, 0, 0)
-        rc = eng.lib.kf_smoother_from_filter(eng._h, C.byref(dims), *([t.data_ptr()] * 9), None)
+        rc = eng.lib.kf_smoother_from_filter(eng._h, C.byref(dims), *([t.data_ptr()] * 9), None, 0, None)
         assert rc == _lib.KF_ERR_UNSUPPORTED
         with pytest.raises(KalmanError, match="p == 1"):
             eng._check(rc, "kf_smoother_from_filter")
         assert not eng.smooth_from_filter_ok(p_, m_)
-    assert eng.smooth_from_filter_ok(1, 10) and not eng.smooth_from_filter_ok(1, 10, time_varying=("T",))
+    # 15 < m <= 1024 runs on the HBM workspace: without it the call is refused (KF_ERR_WORKSPACE), nothing is launched
+    dims = _lib.KfDims(3, 20, 1, 40, 2, 0, 0)
+    assert eng.lib.kf_smoother_from_filter(eng._h, C.byref(dims), *([t.data_ptr()] * 9), None, 0, None) == _lib.KF_ERR_WORKSPACE
+    assert eng.smooth_from_filter_ok(1, 10) and eng.smooth_from_filter_ok(1, 367)
+    assert not eng.smooth_from_filter_ok(1, 10, time_varying=("T",))
 
 
 @pytest.mark.parametrize("name,B,n,ft", [("headline", 4096, 1000, "standard"), ("c3", 8192, 2000, "cholesky"),
@@ -395,3 +399,34 @@ def test_ill_conditioned_dense_H_goes_to_the_dense_path(eng):
     err = _rel_grad_err(g, rg)
     assert max(v for k, v in err.items() if k != "H") < 1e-7, err   # (g_H of the near-singular draws: ~1e10-sized entries, 1e-6 relative)
     assert err["H"] < 1e-5, err
+
+
+@pytest.mark.parametrize("case", ["dense_m16", "dense_m40", "dense_m70", "seasonal_m101", "seasonal_m151_missing", "seasonal_m367"])
+def test_smoother_from_filter_workspace_path(eng, monkeypatch, case):
+    """15 < m <= 1024 (kf_smoother_bf_big.hip; BASELINE config 5's smoother): the same recursion with the fp64-MFMA products of the
+    workspace path -- two dense, two with the block-sparse T -- against its numpy restatement (1e-9 of the draw's largest filtered
+    entry) and against kf_smoother on the filtered tapes; with every K chunk (KF_BIG_TMASK=0) bit for bit."""
+    if case.startswith("dense"):
+        m = int(case.split("_m")[1])
+        w = W.random_dense(4, 12, 1, m, min(m, 5), seed=40 + m)
+    else:
+        m = int(case.split("_m")[1].split("_")[0])
+        w = W.daily_seasonal(B=3, n=9 if m < 300 else 5, s=m - 1)
+    assert w["m"] == m
+    y = w["y"].copy()
+    if "missing" in case:
+        y[[2, 8]] = np.nan
+    res = eng.forward(*_args(w, y), mvn_const="exact")
+    assert not res.info.cpu().numpy().any()
+    sa, sP = eng.smooth_from_filter(y, w["T"], w["Z"], w["H"], res.predicted_states, res.predicted_covs)
+    da, dP = kn.smoother_from_filter(y, w["T"], w["Z"], w["H"], res.predicted_states.cpu().numpy(), res.predicted_covs.cpu().numpy())
+    scale = max(1.0, float(np.abs(res.filtered_covs.cpu().numpy()).max()))
+    assert_allclose(sa.cpu().numpy(), da, rtol=1e-9, atol=1e-9 * scale)
+    assert_allclose(sP.cpu().numpy(), dP, rtol=1e-9, atol=1e-9 * scale)
+    ra, rP = eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
+    assert_allclose(sa.cpu().numpy(), ra.cpu().numpy(), rtol=1e-7, atol=1e-7 * scale)
+    assert_allclose(sP.cpu().numpy(), rP.cpu().numpy(), rtol=1e-7, atol=1e-7 * scale)
+    monkeypatch.setenv("KF_BIG_TMASK", "0")
+    sa0, sP0 = eng.smooth_from_filter(y, w["T"], w["Z"], w["H"], res.predicted_states, res.predicted_covs)
+    monkeypatch.delenv("KF_BIG_TMASK")
+    assert np.array_equal(sa.cpu().numpy(), sa0.cpu().numpy()) and np.array_equal(sP.cpu().numpy(), sP0.cpu().numpy())
