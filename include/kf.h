@@ -196,6 +196,15 @@ int kf_set_forward_kernel(kf_handle* h, int kernel);
  * kernel (kf_fwd_b4p_kernel). */
 const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* dims);
 const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_dims* dims, size_t workspace_bytes);
+/* On the workspace path (m > 64) the kernel depends on the DATA: with p == 1, m <= 1024, no filtered covariance tape and a T of at
+ * most 4 m non-zeros per draw outside at most 4 rows of more than 32 (the structural models: seasonal dummies, trigonometric
+ * terms, companion forms), T P_f T' + R Q R' is evaluated as a gather over a CSR copy of T ("bsp_step_kernel": one pass over P per
+ * step, HBM bound) instead of two fp64 MFMA products ("big_gemm_kernel").  Results agree to rounding.  The verdict is found on the
+ * device: such a call reads 4 bytes back and SYNCHRONISES `stream` once, before the recursion is enqueued -- the one exception to
+ * "asynchronous on stream" above; while `stream` is being captured into a graph, or with KF_BIG_SPARSE=0 in the environment,
+ * there is no read-back and the MFMA path runs.  kf_last_forward_kernel: the kernel that carried the recursion of this handle's
+ * last kf_filter_forward on the workspace path ("" before the first). */
+const char* kf_last_forward_kernel(const kf_handle* h);
 
 /* Scratch the three entry points need for `dims` (max over them, for the kernel selection in force
  * on `h`); may be 0.  Non-zero for k_states too large for the on-chip kernels (m > 64, or m > ~45

@@ -285,6 +285,10 @@ static bool kf_vg_whiten_ok(const kf_handle* h, const kf_dims* d) {
          kf_whiten_shape_ok(h, d->m, d->p, d->r, d->T, d->filter, d->flags, d->B);
 }
 
+extern "C" const char* kf_last_forward_kernel(const kf_handle* h) {
+  return (h && h->last_forward_kernel) ? h->last_forward_kernel : "";
+}
+
 extern "C" const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* d) {
   return kf_forward_kernel_name_ws(h, d, (size_t)-1);
 }

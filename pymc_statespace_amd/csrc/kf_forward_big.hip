@@ -969,6 +969,452 @@ __global__ __launch_bounds__(256) void big_sym_kernel(const double* __restrict__
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Sparse transition (round 5).  The structural models that reach m > 64 -- seasonal dummies, trigonometric terms, companion
+// forms -- have a T with a handful of non-zeros per row (C5: 1 103 of 134 689), and T P_f T' + R Q R' with such a T is a
+// gather of rows and columns of P_f, not a product: m^2 nnz-per-row flops against 4 m^3, one pass over P instead of the
+// six of the two MFMA products (T, P -> W;  W, T, R Q R' -> P).  The recursion then runs at HBM speed: P does not fit on chip
+// (128 draws x 1.08 MB), so 2 m^2 doubles per draw and step -- read P, write P -- is the floor.
+//   bsp_csr_kernel   once per call: T -> CSR per draw (rows with more than BSP_TH non-zeros -- the seasonal sum row -- are
+//                    kept out of it as "dense rows", BSP_ND at most); *ok = 0 when a draw does not fit -> the MFMA path runs
+//   bsp_step_kernel  one time step: a workgroup owns R rows i of one draw.  Stage 1  w_i = sum_{k in nz(i)} T[i,k] P_f[k,:]
+//                    (coalesced reads of the rows k of P, P_f = P - k m' - m k' + (k f) k' formed on the fly with the MFMA
+//                    path's order of operations) into LDS; stage 2  S[i,j] = sum_{l in nz(j)} w_i[l] T[j,l] + (R Q R')[i,j]
+//                    for every j, written along rows.  The same workgroup leaves what the next step needs of its rows:
+//                    (S z)[i] (the next m = P z), a_hat[i], and (S t_d)[i] for every dense row d.
+//   dense rows       row d of T P_f is P_f t_d (P_f is symmetric up to rounding), i.e. P t_d corrected by three dot products
+//                    -- and P t_d was left by the previous step's row sums, so that no workgroup reads all of P; column d of S
+//                    is R dot products of length m per workgroup.
+constexpr int BSP_TH = 32;
+constexpr int BSP_ND = 4;
+constexpr int BSP_CAPF = 4;   // CSR capacity: BSP_CAPF * m entries per draw
+
+struct BspCsr {
+  int* rowptr;   // [B][m + 1]
+  int* col;      // [B][cap]
+  double* val;   // [B][cap]
+  int* drow;     // [B][BSP_ND]
+  int* nd;       // [B]
+  int* ok;       // [1]
+  int cap;
+};
+
+__global__ __launch_bounds__(256) void bsp_csr_kernel(const double* __restrict__ T, int m, BspCsr c) {
+  __shared__ int cnt[BIG_PFIX_M + 1];
+  __shared__ int s_fits;
+  const long b = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const double* Tb = T + b * (long)m * m;
+  for (int row = wave; row < m; row += 4) {
+    int n = 0;
+    for (int k0 = 0; k0 < m; k0 += 64) {
+      const int k = k0 + lane;
+      const double v = k < m ? Tb[(long)row * m + k] : 0.0;
+      n += __popcll(__ballot(v != 0.0 || v != v));   // (a NaN counts: it must reach the result)
+    }
+    if (lane == 0) cnt[row] = n;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int nd = 0, off = 0;
+    for (int row = 0; row < m; ++row) {
+      int n = cnt[row];
+      if (n > BSP_TH) {
+        if (nd < BSP_ND) c.drow[b * BSP_ND + nd] = row;
+        ++nd;
+        n = 0;
+      }
+      cnt[row] = off;
+      off += n;
+    }
+    cnt[m] = off;
+    const int fits = (nd <= BSP_ND && off <= c.cap) ? 1 : 0;
+    for (int d = nd; d < BSP_ND; ++d) c.drow[b * BSP_ND + d] = -1;
+    c.nd[b] = nd <= BSP_ND ? nd : BSP_ND;
+    s_fits = fits;
+    if (!fits) atomicAnd(c.ok, 0);
+  }
+  __syncthreads();
+  for (int e = tid; e <= m; e += 256) c.rowptr[b * (m + 1) + e] = cnt[e];
+  if (!s_fits) return;
+  for (int row = wave; row < m; row += 4) {
+    int off = cnt[row];
+    if (cnt[row + 1] == off) continue;   // empty, or a dense row
+    for (int k0 = 0; k0 < m; k0 += 64) {
+      const int k = k0 + lane;
+      const double v = k < m ? Tb[(long)row * m + k] : 0.0;
+      const bool nz = v != 0.0 || v != v;
+      const unsigned long long bal = __ballot(nz);
+      if (nz) {
+        const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+        c.col[b * c.cap + pos] = k;
+        c.val[b * c.cap + pos] = v;
+      }
+      off += __popcll(bal);
+    }
+  }
+}
+
+// pt[b][d][i] = sum_k P[i][k] T[drow_d][k]  (step 0; afterwards bsp_step_kernel leaves it): wave per row of P
+__global__ __launch_bounds__(256) void bsp_pt_kernel(const double* __restrict__ P, const double* __restrict__ T, int m, BspCsr c,
+                                                     double* __restrict__ pt) {
+  const long b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nd = c.nd[b];
+  if (nd == 0) return;
+  const double* Pb = P + b * (long)m * m;
+  const double* Tb = T + b * (long)m * m;
+  for (int rr = wave; rr < 16; rr += 4) {
+    const int i = blockIdx.x * 16 + rr;
+    if (i >= m) break;
+    for (int d = 0; d < nd; ++d) {
+      const int jd = c.drow[b * BSP_ND + d];
+      double s = 0.0;
+      for (int k = lane; k < m; k += 64) s = fma(Pb[(long)i * m + k], Tb[(long)jd * m + k], s);
+      s = wave_sum(s);
+      if (lane == 0) pt[(b * BSP_ND + d) * m + i] = s;
+    }
+  }
+}
+
+// Per-call vectors of the step kernel: with S = T P_f T' + E and w_i = row i of T P_f, a row sum of S against a fixed vector v is
+// (S v)[i] = w_i . (T' v) + (E v)[i] -- a dot product over the row the workgroup already holds in LDS.  v = z gives the next
+// step's m = P z, v = t_d (dense row d of T) the next step's P t_d.
+//   tz[b][l] = sum_j T[j][l] z[j]     ez[b][i] = sum_j E[i][j] z[j]     ttd[b][d][l] = sum_j T[j][l] T[d][j]     etd[b][d][i] = sum_j E[i][j] T[d][j]
+// grid (ceil(m / 64), B): 64 columns l (lanes) x rows j (waves) for the transposed products, then 64 rows i for the plain ones.
+__global__ __launch_bounds__(256) void bsp_vec_kernel(const double* __restrict__ T, const double* __restrict__ E, const double* __restrict__ Z,
+                                                      int m, BspCsr c, double* __restrict__ tz, double* __restrict__ ez,
+                                                      double* __restrict__ ttd, double* __restrict__ etd) {
+  __shared__ double part[4][1 + BSP_ND][64];
+  const long b = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const double* Tb = T + b * (long)m * m;
+  const double* Eb = E + b * (long)m * m;
+  const double* zb = Z + b * m;
+  const int nd = c.nd[b];
+  int dr[BSP_ND];
+#pragma unroll
+  for (int d = 0; d < BSP_ND; ++d) dr[d] = d < nd ? c.drow[b * BSP_ND + d] : -1;
+  const int l = blockIdx.x * 64 + lane;
+  double acc[1 + BSP_ND];
+#pragma unroll
+  for (int q = 0; q <= BSP_ND; ++q) acc[q] = 0.0;
+  for (int j = wave; j < m; j += 4) {
+    const double tv = l < m ? Tb[(long)j * m + l] : 0.0;
+    acc[0] = fma(tv, zb[j], acc[0]);
+#pragma unroll
+    for (int d = 0; d < BSP_ND; ++d)
+      if (d < nd) acc[1 + d] = fma(tv, Tb[(long)dr[d] * m + j], acc[1 + d]);
+  }
+#pragma unroll
+  for (int q = 0; q <= BSP_ND; ++q) part[wave][q][lane] = acc[q];
+  __syncthreads();
+  if (wave == 0 && l < m) {
+#pragma unroll
+    for (int q = 0; q <= BSP_ND; ++q) {
+      if (q > nd) break;
+      const double sv = ((part[0][q][lane] + part[1][q][lane]) + part[2][q][lane]) + part[3][q][lane];
+      if (q == 0) tz[b * m + l] = sv;
+      else ttd[(b * BSP_ND + q - 1) * m + l] = sv;
+    }
+  }
+  for (int rr = wave; rr < 64; rr += 4) {
+    const int i = blockIdx.x * 64 + rr;
+    if (i >= m) break;
+    double a2[1 + BSP_ND];
+#pragma unroll
+    for (int q = 0; q <= BSP_ND; ++q) a2[q] = 0.0;
+    for (int j = lane; j < m; j += 64) {
+      const double ev = Eb[(long)i * m + j];
+      a2[0] = fma(ev, zb[j], a2[0]);
+#pragma unroll
+      for (int d = 0; d < BSP_ND; ++d)
+        if (d < nd) a2[1 + d] = fma(ev, Tb[(long)dr[d] * m + j], a2[1 + d]);
+    }
+#pragma unroll
+    for (int q = 0; q <= BSP_ND; ++q) {
+      if (q > nd) break;
+      const double sv = wave_sum(a2[q]);
+      if (lane == 0) {
+        if (q == 0) ez[b * m + i] = sv;
+        else etd[(b * BSP_ND + q - 1) * m + i] = sv;
+      }
+    }
+  }
+}
+
+struct BspStep {
+  const double* P_in;    // [B][m][m]
+  double* P_out;         // [B][m][m]  (another buffer: other workgroups still read P_in)
+  const double* K;       // [B][m]  gain
+  const double* Mc;      // [B][m]  m = P z of this step (0 when the observation is missing)
+  const double* KF;      // [B][m]  k f
+  const double* af;      // [B][m]  filtered state
+  const double* pt_in;   // [B][BSP_ND][m]  P t_d
+  double* Mn;            // [B][m]  the next step's m
+  double* pt_out;        // [B][BSP_ND][m]
+  double* a_ws;          // [B][m]  a_hat (nobody reads the old one in this launch)
+  const double* E;       // [B][m][m]  R Q R'
+  const uint32_t* emask; // block map of E or NULL
+  int emask_rb;
+  const double* tz;      // bsp_vec_kernel's vectors
+  const double* ez;
+  const double* ttd;
+  const double* etd;
+};
+
+constexpr int BSP_CG = 6;   // columns per lane and pass of stage 1 (384 columns)
+
+template <int R>
+__global__ __launch_bounds__(256) void bsp_step_kernel(const KfFwdArgs A, int t, const BspCsr c, const BspStep x, int nblk) {
+  extern __shared__ double sm[];
+  constexpr int RW = R / 4;   // rows per wave in stage 1 and in the dot products
+  const int m = A.m, n = A.T;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // all row blocks of one draw on one XCD (they share rows of P, the CSR and the vectors in that L2): see big_gemm_kernel
+  const long L = blockIdx.x;
+  const long b = (L & 7) + 8 * (L / (8L * nblk));
+  if (b >= A.B) return;
+  const int i0 = (int)((L >> 3) % nblk) * R;
+  const long mm = (long)m * m;
+  double* w = sm;                    // [R][m]
+  double* vK = w + (long)R * m;      // [m]
+  double* vM = vK + m;
+  double* vKF = vM + m;
+  double* vAF = vKF + m;
+  double* sd = vAF + m;              // [BSP_ND][R]   column d of S for this block's rows
+  const double* Pb = x.P_in + b * mm;
+  const double* Tb = A.Tm + b * mm;
+  const int* rp = c.rowptr + b * (m + 1);
+  const int* col = c.col + b * (long)c.cap;
+  const double* val = c.val + b * (long)c.cap;
+  const int nd = c.nd[b];
+  int dr[BSP_ND];
+#pragma unroll
+  for (int d = 0; d < BSP_ND; ++d) dr[d] = d < nd ? c.drow[b * BSP_ND + d] : -1;
+  // the row pointers this wave needs in stage 1 (lanes 0 .. RW), and this thread's first stage-2 column: issued before anything waits
+  const int q0 = wave * RW;
+  const int rp_mine = rp[min(i0 + q0 + min(lane, RW), m)];
+  int s2_eb = 0, s2_ee = 0;
+  if (tid < m) {
+    s2_eb = rp[tid];
+    s2_ee = rp[tid + 1];
+  }
+  for (int k = tid; k < m; k += 256) {
+    vK[k] = x.K[b * m + k];
+    vM[k] = x.Mc[b * m + k];
+    vKF[k] = x.KF[b * m + k];
+    vAF[k] = x.af[b * m + k];
+  }
+  for (int e = tid; e < R * m; e += 256) w[e] = 0.0;
+  // stage-2 prefetch: the first two entries of this thread's first column
+  int s2_c0 = 0, s2_c1 = 0;
+  double s2_v0 = 0.0, s2_v1 = 0.0;
+  if (s2_eb < s2_ee) {
+    s2_c0 = col[s2_eb];
+    s2_v0 = val[s2_eb];
+  }
+  if (s2_eb + 1 < s2_ee) {
+    s2_c1 = col[s2_eb + 1];
+    s2_v1 = val[s2_eb + 1];
+  }
+  __syncthreads();
+  // ---- stage 1: rows q0 .. q0 + RW of the block by this wave: w_r += T[i,k] P_f[k,:] over the wave's contiguous CSR range
+  {
+    int rpw[RW + 1];
+#pragma unroll
+    for (int q = 0; q <= RW; ++q) rpw[q] = __builtin_amdgcn_readlane(rp_mine, q);
+    const int e_beg = rpw[0], e_end = rpw[RW];
+    for (int chunk = e_beg; chunk < e_end; chunk += 64) {
+      const int me = chunk + lane;
+      const bool have = me < e_end;
+      const int ck = have ? col[me] : 0;
+      const double cv = have ? val[me] : 0.0;
+      int cr = 0;
+#pragma unroll
+      for (int q = 1; q < RW; ++q) cr += (me >= rpw[q]) ? 1 : 0;
+      const int nloc = min(64, e_end - chunk);
+      for (int e = 0; e < nloc; e += 4) {
+        int kq[4], rq[4];
+        double tq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int src = min(e + u, nloc - 1);
+          kq[u] = __builtin_amdgcn_readlane(ck, src);
+          rq[u] = q0 + __builtin_amdgcn_readlane(cr, src);
+          const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(__double_as_longlong(cv) & 0xffffffffll), src);
+          const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)__double_as_longlong(cv) >> 32), src);
+          tq[u] = (e + u < nloc) ? __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)) : 0.0;
+        }
+        for (int cg = 0; cg < m; cg += 64 * BSP_CG) {
+          double pv[4][BSP_CG];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int g = 0; g < BSP_CG; ++g) {
+              const int l = cg + lane + 64 * g;
+              pv[u][g] = (l < m && e + u < nloc) ? Pb[(long)kq[u] * m + l] : 0.0;
+            }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (e + u < nloc) {
+              const double kk = vK[kq[u]], mk = vM[kq[u]], kf = vKF[kq[u]];
+#pragma unroll
+              for (int g = 0; g < BSP_CG; ++g) {
+                const int l = cg + lane + 64 * g;
+                if (l < m) {
+                  const double ml = vM[l], kl = vK[l];
+                  double sv = pv[u][g];
+                  sv -= kk * ml;
+                  sv -= mk * kl;
+                  sv += kf * kl;
+                  w[(long)rq[u] * m + l] = fma(tq[u], sv, w[(long)rq[u] * m + l]);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    // a_hat of the wave's rows, and its dense rows (none of their entries is in the CSR)
+    for (int q = 0; q < RW; ++q) {
+      const int r = q0 + q, i = i0 + r;
+      if (i >= m) break;
+      int dsel = -1;
+#pragma unroll
+      for (int d = 0; d < BSP_ND; ++d)
+        if (dr[d] == i) dsel = d;
+      if (dsel >= 0) {   // P_f t = P t - m (k.t) - k (m.t) + k (kf.t), a_hat[i] = t.a_f + c[i]
+        double sK = 0.0, sM = 0.0, sKF = 0.0, sA = 0.0;
+        for (int k = lane; k < m; k += 64) {
+          const double tv = Tb[(long)i * m + k];
+          sK = fma(tv, vK[k], sK);
+          sM = fma(tv, vM[k], sM);
+          sKF = fma(tv, vKF[k], sKF);
+          sA = fma(tv, vAF[k], sA);
+        }
+        sK = wave_sum(sK);
+        sM = wave_sum(sM);
+        sKF = wave_sum(sKF);
+        sA = wave_sum(sA);
+        const double* ptv = x.pt_in + (b * BSP_ND + dsel) * m;
+        for (int l = lane; l < m; l += 64) {
+          double sv = ptv[l];
+          sv -= sK * vM[l];
+          sv -= sM * vK[l];
+          sv += sKF * vK[l];
+          w[(long)r * m + l] = sv;
+        }
+        if (lane == 0) {
+          const double ah = sA + (A.c ? A.c[b * m + i] : 0.0);
+          x.a_ws[b * m + i] = ah;
+          if (A.pred_a) A.pred_a[(b * (long)(n + 1) + t + 1) * m + i] = ah;
+        }
+      } else {
+        double sA = 0.0;
+        for (int e = rpw[q] + lane; e < rpw[q + 1]; e += 64) sA = fma(val[e], vAF[col[e]], sA);
+        sA = wave_sum(sA);
+        if (lane == 0) {
+          const double ah = sA + (A.c ? A.c[b * m + i] : 0.0);
+          x.a_ws[b * m + i] = ah;
+          if (A.pred_a) A.pred_a[(b * (long)(n + 1) + t + 1) * m + i] = ah;
+        }
+      }
+    }
+    // ---- dot products of the wave's own rows (LDS written by this wave only: no barrier needed before them):
+    //      (S z)[i], column d of S, (S t_d)[i]
+    double yn = 0.0;
+    if (t + 1 < n) yn = A.y[((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n : 0L) + t + 1];
+    const double* tzb = x.tz + b * m;
+    for (int q = 0; q < RW; ++q) {
+      const int r = q0 + q, i = i0 + r;
+      if (i >= m) break;
+      double a0 = 0.0, ac[BSP_ND], at[BSP_ND];
+#pragma unroll
+      for (int d = 0; d < BSP_ND; ++d) ac[d] = at[d] = 0.0;
+      for (int l = lane; l < m; l += 64) {
+        const double wv = w[(long)r * m + l];
+        a0 = fma(wv, tzb[l], a0);
+#pragma unroll
+        for (int d = 0; d < BSP_ND; ++d)
+          if (d < nd) {
+            ac[d] = fma(wv, Tb[(long)dr[d] * m + l], ac[d]);
+            at[d] = fma(wv, x.ttd[(b * BSP_ND + d) * m + l], at[d]);
+          }
+      }
+      a0 = wave_sum(a0);
+      if (lane == 0) x.Mn[b * m + i] = (yn != yn) ? 0.0 : a0 + x.ez[b * m + i];
+#pragma unroll
+      for (int d = 0; d < BSP_ND; ++d)
+        if (d < nd) {
+          const double c1 = wave_sum(ac[d]), c2 = wave_sum(at[d]);
+          if (lane == 0) {
+            sd[d * R + r] = c1;
+            x.pt_out[(b * BSP_ND + d) * m + i] = c2 + x.etd[(b * BSP_ND + d) * m + i];
+          }
+        }
+    }
+  }
+  __syncthreads();
+  // ---- stage 2: a thread per column j:  S[i0 + r][j] = sum_{l in nz(j)} w_r[l] T[j][l] + E[i0 + r][j]
+  double* Pob = x.P_out + b * mm;
+  double* tape = A.pred_P ? A.pred_P + (b * (long)(n + 1) + t + 1) * mm : nullptr;
+  const double* Eb = x.E + b * mm;
+  unsigned ebits = 0xffffffffu;
+  if (x.emask) ebits = x.emask[b * x.emask_rb + i0 / 64];
+  for (int cb = 0; cb < m; cb += 256) {
+    const int j = cb + tid;
+    if (j >= m) break;
+    int eb, ee, c0_, c1_;
+    double v0_, v1_;
+    if (cb == 0) {
+      eb = s2_eb; ee = s2_ee; c0_ = s2_c0; c1_ = s2_c1; v0_ = s2_v0; v1_ = s2_v1;
+    } else {
+      eb = rp[j];
+      ee = rp[j + 1];
+      c0_ = eb < ee ? col[eb] : 0;
+      v0_ = eb < ee ? val[eb] : 0.0;
+      c1_ = eb + 1 < ee ? col[eb + 1] : 0;
+      v1_ = eb + 1 < ee ? val[eb + 1] : 0.0;
+    }
+    double s[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) s[r] = 0.0;
+    if (eb < ee) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) s[r] = fma(w[(long)r * m + c0_], v0_, s[r]);
+    }
+    if (eb + 1 < ee) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) s[r] = fma(w[(long)r * m + c1_], v1_, s[r]);
+    }
+    for (int e = eb + 2; e < ee; ++e) {
+      const int l = col[e];
+      const double tv = val[e];
+#pragma unroll
+      for (int r = 0; r < R; ++r) s[r] = fma(w[(long)r * m + l], tv, s[r]);
+    }
+#pragma unroll
+    for (int d = 0; d < BSP_ND; ++d)
+      if (dr[d] == j) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] = sd[d * R + r];
+      }
+    if ((ebits >> (j / 32)) & 1u) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (i0 + r < m) s[r] += Eb[(long)(i0 + r) * m + j];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (i0 + r < m) {
+        Pob[(long)(i0 + r) * m + j] = s[r];
+        if (tape) __builtin_nontemporal_store(s[r], tape + (long)(i0 + r) * m + j);
+      }
+  }
+}
+
 }  // namespace
 
 // The m x m x m product of this file for other callers (kf_smoother_big.hip): C = A op(B) (+ E) per draw, leading dimension m,
@@ -993,10 +1439,10 @@ int kf_big_gemm_launch(hipStream_t st, bool trans_b, bool add_e, bool upper_mirr
 }
 
 // the same product with what kf_smoother_bf_big.hip / kf_smoother_big.hip need on top: the block map of a static factor (which
-// operand it is: tmask_on_b), a sign, rank-one terms.  trans_b / add_e as above; never the mirrored forms.
+// operand it is: tmask_on_b), a sign, rank-one terms.  trans_b / add_e / upper_mirror as above.
 int kf_big_gemm_launch_x(hipStream_t st, bool trans_b, bool add_e, const double* A, long sA, const double* Bm, long sB, const double* E,
                          long sE, double* C, long sC, int m, long draws, const uint32_t* tmask, int tmask_on_b, int neg_acc,
-                         const double* u1, const double* v1, const double* u2, const double* v2) {
+                         const double* u1, const double* v1, const double* u2, const double* v2, bool upper_mirror) {
   const int tgm = (m + GTM - 1) / GTM, tgn = (m + GTN - 1) / GTN;
   const unsigned ggrid = (unsigned)(8L * tgn * tgm * ((draws + 7) / 8));
   BigGemmExtra x = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0L, nullptr, 0L, nullptr, nullptr, nullptr};
@@ -1005,7 +1451,14 @@ int kf_big_gemm_launch_x(hipStream_t st, bool trans_b, bool add_e, const double*
   x.tmask_on_b = tmask_on_b;
   x.neg_acc = neg_acc;
   x.u1 = u1; x.v1 = v1; x.u2 = u2; x.v2 = v2;
-  if (!trans_b && !add_e)
+  if (upper_mirror) {   // C symmetric (sign and rank-one terms included): the tiles that touch the upper triangle, written to both
+    if (!trans_b && add_e)
+      hipLaunchKernelGGL((big_gemm_kernel<false, true, true, false, true>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x);
+    else if (trans_b && !add_e)
+      hipLaunchKernelGGL((big_gemm_kernel<true, false, true, false, true>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x);
+    else
+      return KF_ERR_UNSUPPORTED;
+  } else if (!trans_b && !add_e)
     hipLaunchKernelGGL((big_gemm_kernel<false, false>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x);
   else if (!trans_b && add_e)
     hipLaunchKernelGGL((big_gemm_kernel<false, true>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x);
@@ -1099,6 +1552,73 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
       hipLaunchKernelGGL(big_tmask_kernel, dim3((unsigned)tmask_rb, (unsigned)a.B), dim3(256), 0, stream, RQR_ws, m, emask_ws);
     }
   }
+  // Sparse transition: T -> CSR once per call, then one HBM-bound gather kernel per step instead of the two products (see
+  // bsp_step_kernel).  Whether every draw's T fits the CSR is known on the device only: ONE 4-byte read-back and stream
+  // synchronisation per call (include/kf.h) -- skipped, with the MFMA path, while the stream is being captured into a graph
+  // or with KF_BIG_SPARSE=0 in the environment.
+  if (getenv("KF_BSP_DEBUG")) fprintf(stderr, "[bsp] enter m=%d B=%ld T=%d pfix=%d filt_P=%p fused_update=%d fuse=%d\n", m, a.B, a.T, (int)pfix, (void*)a.filt_P, (int)fused_update, (int)fuse);
+  if (pfix) {
+    const char* se = kf_env_switch("KF_BIG_SPARSE");
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap_status);
+    if (!(se && se[0] == '0') && cap_status == hipStreamCaptureStatusNone) {
+      BspCsr csr;
+      csr.cap = BSP_CAPF * m;
+      // carved from W_ws (B m^2 doubles, unused on this path; m > 64)
+      double* q = W_ws;
+      csr.val = q;                                 q += a.B * (size_t)csr.cap;
+      double* Mb[2] = {q, q + a.B * (size_t)m};    q += 2 * a.B * (size_t)m;
+      double* ptb[2] = {q, q + a.B * (size_t)BSP_ND * m};  q += 2 * a.B * (size_t)BSP_ND * m;
+      double* tz_ws = q;                           q += a.B * (size_t)m;
+      double* ez_ws = q;                           q += a.B * (size_t)m;
+      double* ttd_ws = q;                          q += a.B * (size_t)BSP_ND * m;
+      double* etd_ws = q;                          q += a.B * (size_t)BSP_ND * m;
+      int* qi = reinterpret_cast<int*>(q);
+      csr.rowptr = qi;                             qi += a.B * (size_t)(m + 1);
+      csr.col = qi;                                qi += a.B * (size_t)csr.cap;
+      csr.drow = qi;                               qi += a.B * (size_t)BSP_ND;
+      csr.nd = qi;                                 qi += a.B;
+      csr.ok = qi;
+      KF_HIP_CHECK(h, hipMemsetAsync(csr.ok, 1, sizeof(int), stream));   // (any non-zero value)
+      hipLaunchKernelGGL(bsp_csr_kernel, dim3((unsigned)a.B), dim3(256), 0, stream, a.Tm, m, csr);
+      int fits = 0;
+      KF_HIP_CHECK(h, hipMemcpyAsync(&fits, csr.ok, sizeof(int), hipMemcpyDeviceToHost, stream));
+      KF_HIP_CHECK(h, hipStreamSynchronize(stream));
+      if (getenv("KF_BSP_DEBUG")) fprintf(stderr, "[bsp] m=%d B=%ld fits=%d cap=%d\n", m, a.B, fits, csr.cap);
+      if (fits) {
+        int R = m <= 448 ? 16 : 8;
+        if (const char* re = kf_env_switch("KF_BSP_ROWS")) R = atoi(re) == 16 ? 16 : 8;
+        const size_t lds_sp = sizeof(double) * ((size_t)(R + 4) * m + (size_t)BSP_ND * R);
+        if (getenv("KF_BSP_DEBUG")) fprintf(stderr, "[bsp] R=%d lds=%zu\n", R, lds_sp);
+        if (lds_sp <= KF_LDS_BYTES_MAX) {
+          const void* fn = R == 16 ? reinterpret_cast<const void*>(bsp_step_kernel<16>) : reinterpret_cast<const void*>(bsp_step_kernel<8>);
+          KF_HIP_CHECK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp));
+          const int nblk = (m + R - 1) / R;
+          const unsigned sgrid = (unsigned)(8L * nblk * ((a.B + 7) / 8));
+          hipLaunchKernelGGL(big_mvec_kernel, dim3((m + MV_ROWS - 1) / MV_ROWS, (unsigned)a.B), dim3(256), 0, stream, a, 0, P_ws, Mb[0]);
+          hipLaunchKernelGGL(bsp_pt_kernel, dim3((m + 15) / 16, (unsigned)a.B), dim3(256), 0, stream, P_ws, a.Tm, m, csr, ptb[0]);
+          hipLaunchKernelGGL(bsp_vec_kernel, dim3((m + 63) / 64, (unsigned)a.B), dim3(256), 0, stream, a.Tm, RQR_ws, a.Z, m, csr, tz_ws, ez_ws,
+                             ttd_ws, etd_ws);
+          double* Pb[2] = {P_ws, Pf_ws};
+          for (int t = 0; t < a.T; ++t) {
+            const int c0 = t & 1, c1 = c0 ^ 1;
+            hipLaunchKernelGGL(big_gain_kernel, dim3((unsigned)a.B), dim3(256), lds_gain, stream, a, t, a_ws, Mb[c0], K_ws, KF_ws,
+                               af_ws, (const double*)nullptr, (const double*)nullptr, tgn, tgm, Mb[c0]);
+            const BspStep xs = {Pb[c0], Pb[c1], K_ws, Mb[c0], KF_ws, af_ws, ptb[c0], Mb[c1], ptb[c1], a_ws, RQR_ws, emask_ws, tmask_rb,
+                                tz_ws, ez_ws, ttd_ws, etd_ws};
+            if (R == 16)
+              hipLaunchKernelGGL(bsp_step_kernel<16>, dim3(sgrid), dim3(256), lds_sp, stream, a, t, csr, xs, nblk);
+            else
+              hipLaunchKernelGGL(bsp_step_kernel<8>, dim3(sgrid), dim3(256), lds_sp, stream, a, t, csr, xs, nblk);
+          }
+          KF_HIP_CHECK(h, hipGetLastError());
+          h->last_forward_kernel = "bsp_step_kernel";
+          return KF_OK;
+        }
+      }
+    }
+  }
+  h->last_forward_kernel = "big_gemm_kernel";
   for (int t = 0; t < a.T; ++t) {
     if (fused_update) {
       hipLaunchKernelGGL(big_update_kernel, dim3((unsigned)a.B), dim3(256), lds_upd, stream, a, t, a_ws,

@@ -61,6 +61,9 @@ struct kf_handle {
   // internal (kf_filter_value_and_grad on a dense-H model, kf_api.hip): while the whitened inner call runs, where its adjoints leave
   // sum_t vb_t y~_t' (KfBwdArgs::g_yy); NULL otherwise
   double* vg_gyy;
+  // name of the kernel that carried the recursion of the last kf_filter_forward on the HBM-workspace path (m > 64), where the choice
+  // depends on the data (T sparse or not); NULL before the first such call.  kf_last_forward_kernel()
+  const char* last_forward_kernel;
 };
 int kf_handle_aux(kf_handle* h);  // KF_OK once aux_stream / aux_ev exist (current device = the handle's)
 // Scope guard of a launcher that forks work onto the handle's streams: whichever way the function is left -- an error return in the
@@ -333,7 +336,7 @@ int kf_big_gemm_launch(hipStream_t st, bool trans_b, bool add_e, bool upper_mirr
                        long sB, const double* E, long sE, double* C, long sC, int m, long draws);
 int kf_big_gemm_launch_x(hipStream_t st, bool trans_b, bool add_e, const double* A, long sA, const double* Bm, long sB, const double* E,
                          long sE, double* C, long sC, int m, long draws, const uint32_t* tmask, int tmask_on_b, int neg_acc,
-                         const double* u1, const double* v1, const double* u2, const double* v2);
+                         const double* u1, const double* v1, const double* u2, const double* v2, bool upper_mirror);
 int kf_big_tmask_launch(hipStream_t st, const double* T, int m, long B, uint32_t* tmask);
 int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
                           hipStream_t stream);

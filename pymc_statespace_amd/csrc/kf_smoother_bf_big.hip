@@ -245,21 +245,21 @@ int kf_launch_smoother_bf_big(kf_handle* h, const KfSmoothBfArgs& a, void* works
     hipLaunchKernelGGL(bbb_prep_kernel, dim3((unsigned)B), dim3(BB_T), 0, st, a, t, ZT, V);
     hipLaunchKernelGGL(bbb_pf_kernel, dim3(rgrid, (unsigned)B), dim3(BB_T), 0, st, a, t, V, Pf);
     // Y = M_t P_f ;  smooth_P[t] = P_f - P_f Y
-    rc = kf_big_gemm_launch_x(st, false, false, M, mm, Pf, mm, nullptr, 0, Y, mm, m, B, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr);
+    rc = kf_big_gemm_launch_x(st, false, false, M, mm, Pf, mm, nullptr, 0, Y, mm, m, B, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, false);
     if (rc) return rc;
     rc = kf_big_gemm_launch_x(st, false, true, Pf, mm, Y, mm, Pf, mm, a.smooth_P + (long)t * mm, sTapeS, m, B, nullptr, 0, /*neg=*/1,
-                              nullptr, nullptr, nullptr, nullptr);
+                              nullptr, nullptr, nullptr, nullptr, /*upper_mirror=*/true);
     if (rc) return rc;
     // w = M_t kappa ;  X2 = T' M_t - (Z T)' w'
     hipLaunchKernelGGL(bbb_gemv_kernel, dim3(rgrid, (unsigned)B), dim3(BB_T), 0, st, M, (const uint32_t*)nullptr, mask_rb, V.kap, V.w, m);
-    rc = kf_big_gemm_launch_x(st, false, false, TT, mm, M, mm, nullptr, 0, X2, mm, m, B, mask, /*on_b=*/0, 0, V.negZT, V.w, nullptr, nullptr);
+    rc = kf_big_gemm_launch_x(st, false, false, TT, mm, M, mm, nullptr, 0, X2, mm, m, B, mask, /*on_b=*/0, 0, V.negZT, V.w, nullptr, nullptr, false);
     if (rc) return rc;
     // T' w, T' r~ ;  x2k, r~_{t-1}
     hipLaunchKernelGGL(bbb_gemv_kernel, dim3(rgrid, (unsigned)B), dim3(BB_T), 0, st, TT, mask, mask_rb, V.w, V.twv, m);
     hipLaunchKernelGGL(bbb_gemv_kernel, dim3(rgrid, (unsigned)B), dim3(BB_T), 0, st, TT, mask, mask_rb, V.r, V.trv, m);
     hipLaunchKernelGGL(bbb_vec_kernel, dim3((unsigned)B), dim3(BB_T), 0, st, m, ZT, V);
     // M_{t-1} = X2 T - (X2 kappa)(Z T) + ((Z T)' / F)(Z T):  op(B) = TT' = T, the tile's 64 columns are rows of TT
-    rc = kf_big_gemm_launch_x(st, true, false, X2, mm, TT, mm, nullptr, 0, M, mm, m, B, mask, /*on_b=*/1, 0, V.x2k, ZT, V.u2, ZT);
+    rc = kf_big_gemm_launch_x(st, true, false, X2, mm, TT, mm, nullptr, 0, M, mm, m, B, mask, /*on_b=*/1, 0, V.x2k, ZT, V.u2, ZT, /*upper_mirror=*/true);
     if (rc) return rc;
     double* tmp = V.r;
     V.r = V.rn;

@@ -89,6 +89,11 @@ class KalmanEngine:
         True passes KF_FLAG_EXACT_RECURSION, i.e. the forward kernels never switch to their steady-state phase."""
         self._exact_recursion = bool(on)
 
+    def last_forward_kernel(self) -> str:
+        """kf_last_forward_kernel: which kernel carried the recursion of the last ``forward`` on the workspace path (m > 64) --
+        "bsp_step_kernel" (T sparse: CSR gather) or "big_gemm_kernel" (fp64 MFMA products); "" before the first."""
+        return self.lib.kf_last_forward_kernel(self._h).decode()
+
     def forward_kernel_name(self, B, n, p, m, r, filter_type="standard", h_diagonal=False, time_varying=()) -> str:
         """Kernel ``forward`` launches for this shape (``forward`` always passes the workspace)."""
         dims = self._dims(B, n, p, m, r, filter_type)

@@ -3,7 +3,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT; O=$ROOT/gpurun_out/r05_bfbig; mkdir -p $O
 timeout 1200 python3 -m pytest tests/test_gpu_r05.py -q -x -k "workspace_path or rejects or golden or restatement" > $O/pytest.txt 2>&1; tail -15 $O/pytest.txt
 timeout 600 python3 -m pytest tests/test_abi.py tests/test_gpu_c5.py -q -x > $O/pytest_c5.txt 2>&1; tail -3 $O/pytest_c5.txt
-python3 bench.py --workload c5 --steps 2 --warmup 1 --no-cpu 2>$O/bench_err.txt | python3 -c "
+python3 bench.py --workload c5 --steps 2 --warmup 1 --no-cpu 2>$O/bench_err.txt | tee $O/bench_c5.json | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

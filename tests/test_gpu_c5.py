@@ -86,7 +86,10 @@ def test_workspace_forward_fused_steps(eng, case, predicted, monkeypatch):
         assert_allclose(res.predicted_states.cpu().numpy(), ref["predicted_states"], rtol=1e-9, atol=1e-9)
         assert_allclose(res.predicted_covs.cpu().numpy(), ref["predicted_covs"], rtol=1e-9, atol=1e-9)
         pc = res.predicted_covs[:, 1:]
-        assert bool((pc == pc.transpose(-1, -2)).all())
+        if eng.last_forward_kernel() == "big_gemm_kernel":   # one triangle mirrored: symmetric bit for bit
+            assert bool((pc == pc.transpose(-1, -2)).all())
+        else:                                                # the CSR gather (a sparse T): every element its own short sum
+            assert float((pc - pc.transpose(-1, -2)).abs().max()) <= 1e-13 * float(pc.abs().max())
     monkeypatch.setenv("KF_BIG_FUSE", "0")
     sep = eng.forward(*args, **kw)
     assert_allclose(res.logp.cpu().numpy(), sep.logp.cpu().numpy(), rtol=1e-11, atol=0.0)

@@ -264,13 +264,138 @@ def test_big_path_skips_zero_blocks_of_T_bit_for_bit(eng, monkeypatch, case):
     orc = kn.kalman_filter(*args, mvn_const="exact")
     assert np.max(np.abs(got["logp"] - orc["logp"])) <= 1e-8 * max(1.0, np.abs(orc["logp"]).max() / 1e4)
     assert_allclose(got["predicted_covs"], orc["predicted_covs"], rtol=1e-9, atol=1e-9)
-    # logp only (the P_f-on-the-way-into-LDS product): the same log-likelihoods
+    # logp only (the P_f-on-the-way-into-LDS product; KF_BIG_SPARSE=0: the MFMA path for a sparse T too): the same log-likelihoods
+    monkeypatch.setenv("KF_BIG_SPARSE", "0")
     lo = eng.forward(*args, mvn_const="exact", store_ll_obs=False, store_filtered=False, store_predicted=False)
+    assert eng.last_forward_kernel() == "big_gemm_kernel"
     assert np.max(np.abs(lo.logp.cpu().numpy() - orc["logp"])) <= 1e-8 * max(1.0, np.abs(orc["logp"]).max() / 1e4)
     monkeypatch.setenv("KF_BIG_TMASK", "0")
     lo0 = eng.forward(*args, mvn_const="exact", store_ll_obs=False, store_filtered=False, store_predicted=False)
     monkeypatch.delenv("KF_BIG_TMASK")
     assert np.array_equal(lo.logp.cpu().numpy(), lo0.logp.cpu().numpy())
+
+
+def _sparse_case(case):
+    """Models whose T is a few non-zeros per row: what the reference's structural components assemble (seasonal dummies: a row of
+    -1 over a shifted identity; trigonometric seasonality: 2 x 2 rotations; ARMA: a companion column over a shifted identity)."""
+    rng = np.random.default_rng(sum(map(ord, case)))
+    if case == "seasonal_m70":
+        return W.daily_seasonal(B=11, n=40, s=69), True
+    if case == "seasonal_m367":
+        return W.daily_seasonal(B=3, n=12), True
+    if case in ("two_seasonals_m150", "five_dense_rows_m150", "one_draw_dense_m150"):
+        w = W.daily_seasonal(B=4, n=30, s=80)   # m = 81: level, trend, 79 seasonal states
+        m = 150
+        T = np.zeros((4, m, m))
+        T[:, :81, :81] = w["T"]
+        T[:, 81, 81:] = -1.0                    # a second seasonal block (period 70): another dense row
+        idx = np.arange(m - 82)
+        T[:, 82 + idx, 81 + idx] = 1.0
+        Z = np.zeros((4, 1, m)); Z[:, 0, :81] = w["Z"][:, 0]; Z[:, 0, 81] = 1.0
+        R = np.zeros((4, m, 4)); R[:, :81, :3] = w["R"]; R[:, 81, 3] = 1.0
+        Q = np.zeros((4, 4, 4)); Q[:, :3, :3] = w["Q"]; Q[:, 3, 3] = 0.05 + rng.random(4)
+        if case == "five_dense_rows_m150":      # more dense rows than the CSR path keeps aside: the MFMA products
+            for row in (100, 110, 120):
+                T[:, row, 90:140] += 0.002 * rng.standard_normal((4, 50))
+        if case == "one_draw_dense_m150":       # one draw's T does not fit: the whole call takes the MFMA products
+            T[2] += 0.001 * rng.standard_normal((m, m))
+        P0 = np.broadcast_to(np.eye(m), (4, m, m)).copy()
+        out = dict(B=4, n=30, p=1, m=m, r=4, y=w["y"], a0=np.zeros((4, m)), P0=P0, T=T, Z=Z, R=R, H=w["H"], Q=Q)
+        return out, case == "two_seasonals_m150"
+    if case == "companion_trig_m96":            # ARMA companion (dense first COLUMN: two non-zeros per row) + rotations + random extras
+        B, m, n = 5, 96, 50
+        T = np.zeros((B, m, m))
+        T[:, :40, 0] = 0.5 * rng.standard_normal((B, 40)) / np.arange(1, 41)
+        i = np.arange(39)
+        T[:, i, i + 1] = 1.0
+        for k in range(28):
+            lam = 2 * np.pi * (k + 1) / 60.0
+            a = 40 + 2 * k
+            T[:, a, a], T[:, a, a + 1], T[:, a + 1, a], T[:, a + 1, a + 1] = np.cos(lam), np.sin(lam), -np.sin(lam), np.cos(lam)
+        T[:, 95, 95] = 0.7
+        T[:, 90, 3] = 0.1                                                   # stray entries: no special structure is assumed
+        T[:, 17, 80] = -0.05
+        w = W.random_dense(B, n, 1, m, 5, seed=77)
+        w["T"] = T
+        Z = np.zeros((B, 1, m)); Z[:, 0, 0] = 1.0; Z[:, 0, 40::2] = 1.0
+        w["Z"] = Z
+        return w, True
+    if case == "ten_per_row_m100":               # short rows, but 10 m entries in all: over the CSR's 4 m -> the MFMA products
+        w = W.random_dense(3, 20, 1, 100, 3, seed=79)
+        keep = np.zeros((100, 100), dtype=bool)
+        for k in range(10):
+            keep[np.arange(100), (np.arange(100) * 7 + 11 * k) % 100] = True
+        w["T"] = w["T"] * keep
+        return w, False
+    if case == "sparse_m1000":
+        B, m, n = 2, 1000, 3
+        w = W.random_dense(B, n, 1, m, 2, seed=78)
+        T = np.zeros((B, m, m))
+        i = np.arange(m - 1)
+        T[:, i + 1, i] = 0.9
+        T[:, 0, :] = -0.02 * rng.random((B, m))
+        T[:, 500, 100:700] = 0.01 * rng.standard_normal((B, 600))
+        w["T"] = T
+        w["y"] = np.nan_to_num(w["y"], nan=0.2)
+        return w, True
+    raise KeyError(case)
+
+
+@pytest.mark.parametrize("case", ["seasonal_m70", "seasonal_m367", "two_seasonals_m150", "five_dense_rows_m150", "one_draw_dense_m150",
+                                  "companion_trig_m96", "ten_per_row_m100", "sparse_m1000"])
+def test_workspace_forward_sparse_transition(eng, monkeypatch, case):
+    """m > 64, p = 1, no filtered covariance tape: a T of a few non-zeros per row runs T P_f T' + R Q R' as a CSR gather
+    (bsp_step_kernel: one pass over P per step) instead of two MFMA products.  Against the oracle, against the MFMA path
+    (KF_BIG_SPARSE=0), with missing observations, with and without the predicted tapes; a T that does not fit the CSR (more than
+    four dense rows, or one dense draw) takes the MFMA products."""
+    w, sparse = _sparse_case(case)
+    y = w["y"].copy()
+    if y.shape[0] > 20:
+        y[[0, 7, 19]] = np.nan
+    args = (y,) + tuple(w[k] for k in ("a0", "P0", "T", "Z", "R", "H", "Q"))
+    orc = kn.kalman_filter(*args, mvn_const="exact")
+    tol = 1e-8 * max(1.0, np.abs(orc["logp"]).max() / 1e4)
+    for predicted in (True, False):
+        kw = dict(mvn_const="exact", store_filtered=False, store_predicted=predicted)
+        res = eng.forward(*args, **kw)
+        on_workspace = predicted or w["m"] > 96   # (64 < m <= 96 without covariance tapes: kf_fwd_wgl_kernel, P resident in LDS)
+        if on_workspace:
+            assert eng.last_forward_kernel() == ("bsp_step_kernel" if sparse else "big_gemm_kernel"), case
+        assert not res.info.cpu().numpy().any()
+        assert np.max(np.abs(res.logp.cpu().numpy() - orc["logp"])) < tol
+        assert_allclose(res.ll_obs.cpu().numpy(), orc["ll_obs"], rtol=1e-9, atol=1e-9)
+        if predicted:
+            assert_allclose(res.predicted_states.cpu().numpy(), orc["predicted_states"], rtol=1e-9, atol=1e-10)
+            pc = res.predicted_covs.cpu().numpy()
+            assert_allclose(pc, orc["predicted_covs"], rtol=1e-9, atol=1e-10)
+            # symmetric up to rounding (every element is its own short sum; the MFMA path mirrors one triangle)
+            assert np.max(np.abs(pc - np.swapaxes(pc, -1, -2))) <= 1e-13 * np.abs(pc).max()
+        monkeypatch.setenv("KF_BIG_SPARSE", "0")
+        ref = eng.forward(*args, **kw)
+        assert eng.last_forward_kernel() == "big_gemm_kernel"   # (also what the previous workspace call left, when this one is not)
+        monkeypatch.delenv("KF_BIG_SPARSE")
+        assert_allclose(res.logp.cpu().numpy(), ref.logp.cpu().numpy(), rtol=1e-11, atol=1e-9)
+    # a call that asks for the filtered covariance tape keeps the products (P_f has to be written)
+    eng.forward(*args, mvn_const="exact")
+    assert eng.last_forward_kernel() == "big_gemm_kernel"
+
+
+def test_workspace_forward_sparse_transition_all_missing_and_one_step(eng):
+    w = W.daily_seasonal(B=3, n=1, s=100)
+    w["y"] = np.full((1, 1), 0.3)
+    args = (w["y"],) + tuple(w[k] for k in ("a0", "P0", "T", "Z", "R", "H", "Q"))
+    orc = kn.kalman_filter(*args, mvn_const="exact")
+    res = eng.forward(*args, mvn_const="exact", store_filtered=False)
+    assert eng.last_forward_kernel() == "bsp_step_kernel"
+    assert_allclose(res.logp.cpu().numpy(), orc["logp"], rtol=1e-11, atol=1e-12)
+    assert_allclose(res.predicted_covs.cpu().numpy(), orc["predicted_covs"], rtol=1e-11, atol=1e-12)
+    w = W.daily_seasonal(B=9, n=6, s=100)
+    y = np.full_like(w["y"], np.nan)
+    args = (y,) + tuple(w[k] for k in ("a0", "P0", "T", "Z", "R", "H", "Q"))
+    orc = kn.kalman_filter(*args, mvn_const="exact")
+    res = eng.forward(*args, mvn_const="exact", store_filtered=False)
+    assert np.array_equal(res.logp.cpu().numpy(), np.zeros(9))
+    assert_allclose(res.predicted_covs.cpu().numpy(), orc["predicted_covs"], rtol=1e-11, atol=1e-12)
 
 
 GRADS = ("a0", "P0", "T", "Z", "R", "H", "Q", "c", "d")
