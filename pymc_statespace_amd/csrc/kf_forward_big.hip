@@ -1144,6 +1144,29 @@ __global__ __launch_bounds__(256) void bsp_vec_kernel(const double* __restrict__
   }
 }
 
+__device__ __forceinline__ double bsp_readlane_f64(double v, int src) {   // src wave-uniform
+  const long long bits = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits & 0xffffffffll), src);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)bits >> 32), src);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// sum over the wavefront, the same value in every lane: four DPP rotations inside the rows of 16 lanes, then the four row totals
+// through SGPRs -- ~25 instructions, against six dependent ds_bpermute round trips for wave_sum()
+template <int CTRL>
+__device__ __forceinline__ double bsp_dpp(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bsp_wave_sum(double x) {
+  asm volatile("" : "+v"(x));
+  x += bsp_dpp<0x128>(x);   // row_ror:8
+  x += bsp_dpp<0x124>(x);
+  x += bsp_dpp<0x122>(x);
+  x += bsp_dpp<0x121>(x);
+  return ((bsp_readlane_f64(x, 0) + bsp_readlane_f64(x, 16)) + bsp_readlane_f64(x, 32)) + bsp_readlane_f64(x, 48);
+}
+
 struct BspStep {
   const double* P_in;    // [B][m][m]
   double* P_out;         // [B][m][m]  (another buffer: other workgroups still read P_in)
@@ -1167,9 +1190,10 @@ struct BspStep {
 constexpr int BSP_CG = 6;   // columns per lane and pass of stage 1 (384 columns)
 
 template <int R>
-__global__ __launch_bounds__(256) void bsp_step_kernel(const KfFwdArgs A, int t, const BspCsr c, const BspStep x, int nblk) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void bsp_step_kernel(const KfFwdArgs A, int t, const BspCsr c, const BspStep x, int nblk) {
   extern __shared__ double sm[];
   constexpr int RW = R / 4;   // rows per wave in stage 1 and in the dot products
+  constexpr int NE = R >= 16 ? 4 : 2;   // CSR entries per pass of stage 1 (a wave's rows hold ~1.1 RW of them at C5)
   const int m = A.m, n = A.T;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // all row blocks of one draw on one XCD (they share rows of P, the CSR and the vectors in that L2): see big_gemm_kernel
@@ -1183,7 +1207,8 @@ __global__ __launch_bounds__(256) void bsp_step_kernel(const KfFwdArgs A, int t,
   double* vM = vK + m;
   double* vKF = vM + m;
   double* vAF = vKF + m;
-  double* sd = vAF + m;              // [BSP_ND][R]   column d of S for this block's rows
+  double* vTZ = vAF + m;             // T' z (bsp_vec_kernel)
+  double* sd = vTZ + m;              // [BSP_ND][R]   column d of S for this block's rows
   const double* Pb = x.P_in + b * mm;
   const double* Tb = A.Tm + b * mm;
   const int* rp = c.rowptr + b * (m + 1);
@@ -1196,28 +1221,42 @@ __global__ __launch_bounds__(256) void bsp_step_kernel(const KfFwdArgs A, int t,
   // the row pointers this wave needs in stage 1 (lanes 0 .. RW), and this thread's first stage-2 column: issued before anything waits
   const int q0 = wave * RW;
   const int rp_mine = rp[min(i0 + q0 + min(lane, RW), m)];
-  int s2_eb = 0, s2_ee = 0;
-  if (tid < m) {
-    s2_eb = rp[tid];
-    s2_ee = rp[tid + 1];
+  // (every load whose address is known now is issued now: a workgroup lives ~12 us, most of it round trips to L2 / HBM)
+  int s2_eb[2] = {0, 0}, s2_ee[2] = {0, 0};
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (tid + 256 * h < m) {
+      s2_eb[h] = rp[tid + 256 * h];
+      s2_ee[h] = rp[tid + 256 * h + 1];
+    }
+  unsigned ebits = 0xffffffffu;
+  if (x.emask) ebits = x.emask[b * x.emask_rb + i0 / 64];
+  // per-row scalars of the wave's rows (lanes 0 .. RW - 1): E z, E t_0
+  double ez_mine = 0.0, etd0_mine = 0.0;
+  if (lane < RW && i0 + q0 + lane < m) {
+    ez_mine = x.ez[b * m + i0 + q0 + lane];
+    if (nd > 0) etd0_mine = x.etd[(b * BSP_ND + 0) * m + i0 + q0 + lane];
   }
   for (int k = tid; k < m; k += 256) {
     vK[k] = x.K[b * m + k];
     vM[k] = x.Mc[b * m + k];
     vKF[k] = x.KF[b * m + k];
     vAF[k] = x.af[b * m + k];
+    vTZ[k] = x.tz[b * m + k];
   }
-  for (int e = tid; e < R * m; e += 256) w[e] = 0.0;
-  // stage-2 prefetch: the first two entries of this thread's first column
-  int s2_c0 = 0, s2_c1 = 0;
-  double s2_v0 = 0.0, s2_v1 = 0.0;
-  if (s2_eb < s2_ee) {
-    s2_c0 = col[s2_eb];
-    s2_v0 = val[s2_eb];
-  }
-  if (s2_eb + 1 < s2_ee) {
-    s2_c1 = col[s2_eb + 1];
-    s2_v1 = val[s2_eb + 1];
+  // stage-2 prefetch: the first two entries of this thread's first two columns
+  int s2_c0[2] = {0, 0}, s2_c1[2] = {0, 0};
+  double s2_v0[2] = {0.0, 0.0}, s2_v1[2] = {0.0, 0.0};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (s2_eb[h] < s2_ee[h]) {
+      s2_c0[h] = col[s2_eb[h]];
+      s2_v0[h] = val[s2_eb[h]];
+    }
+    if (s2_eb[h] + 1 < s2_ee[h]) {
+      s2_c1[h] = col[s2_eb[h] + 1];
+      s2_v1[h] = val[s2_eb[h] + 1];
+    }
   }
   __syncthreads();
   // ---- stage 1: rows q0 .. q0 + RW of the block by this wave: w_r += T[i,k] P_f[k,:] over the wave's contiguous CSR range
@@ -1226,6 +1265,16 @@ __global__ __launch_bounds__(256) void bsp_step_kernel(const KfFwdArgs A, int t,
 #pragma unroll
     for (int q = 0; q <= RW; ++q) rpw[q] = __builtin_amdgcn_readlane(rp_mine, q);
     const int e_beg = rpw[0], e_end = rpw[RW];
+    // the first dense row's vectors for the dot products below (columns lane + 64 g < 64 BSP_CG), in flight during the gather
+    double tj0[BSP_CG], tt0[BSP_CG];
+#pragma unroll
+    for (int g = 0; g < BSP_CG; ++g) {
+      const int l = lane + 64 * g;
+      const bool on = nd > 0 && l < m;
+      tj0[g] = on ? Tb[(long)dr[0] * m + l] : 0.0;
+      tt0[g] = on ? x.ttd[(b * BSP_ND + 0) * m + l] : 0.0;
+    }
+    int prev_row = -1;
     for (int chunk = e_beg; chunk < e_end; chunk += 64) {
       const int me = chunk + lane;
       const bool have = me < e_end;
@@ -1235,11 +1284,11 @@ __global__ __launch_bounds__(256) void bsp_step_kernel(const KfFwdArgs A, int t,
 #pragma unroll
       for (int q = 1; q < RW; ++q) cr += (me >= rpw[q]) ? 1 : 0;
       const int nloc = min(64, e_end - chunk);
-      for (int e = 0; e < nloc; e += 4) {
-        int kq[4], rq[4];
-        double tq[4];
+      for (int e = 0; e < nloc; e += NE) {
+        int kq[NE], rq[NE];
+        double tq[NE];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NE; ++u) {
           const int src = min(e + u, nloc - 1);
           kq[u] = __builtin_amdgcn_readlane(ck, src);
           rq[u] = q0 + __builtin_amdgcn_readlane(cr, src);
@@ -1248,17 +1297,18 @@ __global__ __launch_bounds__(256) void bsp_step_kernel(const KfFwdArgs A, int t,
           tq[u] = (e + u < nloc) ? __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)) : 0.0;
         }
         for (int cg = 0; cg < m; cg += 64 * BSP_CG) {
-          double pv[4][BSP_CG];
+          double pv[NE][BSP_CG];
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+          for (int u = 0; u < NE; ++u)
 #pragma unroll
             for (int g = 0; g < BSP_CG; ++g) {
               const int l = cg + lane + 64 * g;
               pv[u][g] = (l < m && e + u < nloc) ? Pb[(long)kq[u] * m + l] : 0.0;
             }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < NE; ++u) {
             if (e + u < nloc) {
+              const bool first = rq[u] != (u == 0 ? prev_row : rq[u - 1]);   // (entries are sorted by row)
               const double kk = vK[kq[u]], mk = vM[kq[u]], kf = vKF[kq[u]];
 #pragma unroll
               for (int g = 0; g < BSP_CG; ++g) {
@@ -1269,15 +1319,16 @@ __global__ __launch_bounds__(256) void bsp_step_kernel(const KfFwdArgs A, int t,
                   sv -= kk * ml;
                   sv -= mk * kl;
                   sv += kf * kl;
-                  w[(long)rq[u] * m + l] = fma(tq[u], sv, w[(long)rq[u] * m + l]);
+                  w[(long)rq[u] * m + l] = first ? tq[u] * sv : fma(tq[u], sv, w[(long)rq[u] * m + l]);
                 }
               }
             }
           }
         }
+        prev_row = rq[min(NE, nloc - e) - 1];
       }
     }
-    // a_hat of the wave's rows, and its dense rows (none of their entries is in the CSR)
+    // a_hat of the wave's rows; its dense rows (none of their entries is in the CSR) and its empty rows
     for (int q = 0; q < RW; ++q) {
       const int r = q0 + q, i = i0 + r;
       if (i >= m) break;
@@ -1294,10 +1345,10 @@ __global__ __launch_bounds__(256) void bsp_step_kernel(const KfFwdArgs A, int t,
           sKF = fma(tv, vKF[k], sKF);
           sA = fma(tv, vAF[k], sA);
         }
-        sK = wave_sum(sK);
-        sM = wave_sum(sM);
-        sKF = wave_sum(sKF);
-        sA = wave_sum(sA);
+        sK = bsp_wave_sum(sK);
+        sM = bsp_wave_sum(sM);
+        sKF = bsp_wave_sum(sKF);
+        sA = bsp_wave_sum(sA);
         const double* ptv = x.pt_in + (b * BSP_ND + dsel) * m;
         for (int l = lane; l < m; l += 64) {
           double sv = ptv[l];
@@ -1312,9 +1363,11 @@ __global__ __launch_bounds__(256) void bsp_step_kernel(const KfFwdArgs A, int t,
           if (A.pred_a) A.pred_a[(b * (long)(n + 1) + t + 1) * m + i] = ah;
         }
       } else {
+        if (rpw[q] == rpw[q + 1])
+          for (int l = lane; l < m; l += 64) w[(long)r * m + l] = 0.0;
         double sA = 0.0;
         for (int e = rpw[q] + lane; e < rpw[q + 1]; e += 64) sA = fma(val[e], vAF[col[e]], sA);
-        sA = wave_sum(sA);
+        sA = bsp_wave_sum(sA);
         if (lane == 0) {
           const double ah = sA + (A.c ? A.c[b * m + i] : 0.0);
           x.a_ws[b * m + i] = ah;
@@ -1326,16 +1379,31 @@ __global__ __launch_bounds__(256) void bsp_step_kernel(const KfFwdArgs A, int t,
     //      (S z)[i], column d of S, (S t_d)[i]
     double yn = 0.0;
     if (t + 1 < n) yn = A.y[((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n : 0L) + t + 1];
-    const double* tzb = x.tz + b * m;
     for (int q = 0; q < RW; ++q) {
       const int r = q0 + q, i = i0 + r;
       if (i >= m) break;
       double a0 = 0.0, ac[BSP_ND], at[BSP_ND];
 #pragma unroll
       for (int d = 0; d < BSP_ND; ++d) ac[d] = at[d] = 0.0;
-      for (int l = lane; l < m; l += 64) {
+#pragma unroll
+      for (int g = 0; g < BSP_CG; ++g) {   // the first 64 BSP_CG columns: dense row 0 from the registers
+        const int l = lane + 64 * g;
+        if (l < m) {
+          const double wv = w[(long)r * m + l];
+          a0 = fma(wv, vTZ[l], a0);
+          ac[0] = fma(wv, tj0[g], ac[0]);
+          at[0] = fma(wv, tt0[g], at[0]);
+#pragma unroll
+          for (int d = 1; d < BSP_ND; ++d)
+            if (d < nd) {
+              ac[d] = fma(wv, Tb[(long)dr[d] * m + l], ac[d]);
+              at[d] = fma(wv, x.ttd[(b * BSP_ND + d) * m + l], at[d]);
+            }
+        }
+      }
+      for (int l = lane + 64 * BSP_CG; l < m; l += 64) {
         const double wv = w[(long)r * m + l];
-        a0 = fma(wv, tzb[l], a0);
+        a0 = fma(wv, vTZ[l], a0);
 #pragma unroll
         for (int d = 0; d < BSP_ND; ++d)
           if (d < nd) {
@@ -1343,15 +1411,17 @@ __global__ __launch_bounds__(256) void bsp_step_kernel(const KfFwdArgs A, int t,
             at[d] = fma(wv, x.ttd[(b * BSP_ND + d) * m + l], at[d]);
           }
       }
-      a0 = wave_sum(a0);
-      if (lane == 0) x.Mn[b * m + i] = (yn != yn) ? 0.0 : a0 + x.ez[b * m + i];
+      a0 = bsp_wave_sum(a0);
+      const double ezq = bsp_readlane_f64(ez_mine, q);
+      if (lane == 0) x.Mn[b * m + i] = (yn != yn) ? 0.0 : a0 + ezq;
 #pragma unroll
       for (int d = 0; d < BSP_ND; ++d)
         if (d < nd) {
-          const double c1 = wave_sum(ac[d]), c2 = wave_sum(at[d]);
+          const double c1 = bsp_wave_sum(ac[d]), c2 = bsp_wave_sum(at[d]);
+          const double ev = d == 0 ? bsp_readlane_f64(etd0_mine, q) : x.etd[(b * BSP_ND + d) * m + i];
           if (lane == 0) {
             sd[d * R + r] = c1;
-            x.pt_out[(b * BSP_ND + d) * m + i] = c2 + x.etd[(b * BSP_ND + d) * m + i];
+            x.pt_out[(b * BSP_ND + d) * m + i] = c2 + ev;
           }
         }
     }
@@ -1361,15 +1431,15 @@ __global__ __launch_bounds__(256) void bsp_step_kernel(const KfFwdArgs A, int t,
   double* Pob = x.P_out + b * mm;
   double* tape = A.pred_P ? A.pred_P + (b * (long)(n + 1) + t + 1) * mm : nullptr;
   const double* Eb = x.E + b * mm;
-  unsigned ebits = 0xffffffffu;
-  if (x.emask) ebits = x.emask[b * x.emask_rb + i0 / 64];
   for (int cb = 0; cb < m; cb += 256) {
     const int j = cb + tid;
     if (j >= m) break;
     int eb, ee, c0_, c1_;
     double v0_, v1_;
     if (cb == 0) {
-      eb = s2_eb; ee = s2_ee; c0_ = s2_c0; c1_ = s2_c1; v0_ = s2_v0; v1_ = s2_v1;
+      eb = s2_eb[0]; ee = s2_ee[0]; c0_ = s2_c0[0]; c1_ = s2_c1[0]; v0_ = s2_v0[0]; v1_ = s2_v1[0];
+    } else if (cb == 256) {
+      eb = s2_eb[1]; ee = s2_ee[1]; c0_ = s2_c0[1]; c1_ = s2_c1[1]; v0_ = s2_v0[1]; v1_ = s2_v1[1];
     } else {
       eb = rp[j];
       ee = rp[j + 1];
@@ -1556,7 +1626,6 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
   // bsp_step_kernel).  Whether every draw's T fits the CSR is known on the device only: ONE 4-byte read-back and stream
   // synchronisation per call (include/kf.h) -- skipped, with the MFMA path, while the stream is being captured into a graph
   // or with KF_BIG_SPARSE=0 in the environment.
-  if (getenv("KF_BSP_DEBUG")) fprintf(stderr, "[bsp] enter m=%d B=%ld T=%d pfix=%d filt_P=%p fused_update=%d fuse=%d\n", m, a.B, a.T, (int)pfix, (void*)a.filt_P, (int)fused_update, (int)fuse);
   if (pfix) {
     const char* se = kf_env_switch("KF_BIG_SPARSE");
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
@@ -1584,14 +1653,15 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
       int fits = 0;
       KF_HIP_CHECK(h, hipMemcpyAsync(&fits, csr.ok, sizeof(int), hipMemcpyDeviceToHost, stream));
       KF_HIP_CHECK(h, hipStreamSynchronize(stream));
-      if (getenv("KF_BSP_DEBUG")) fprintf(stderr, "[bsp] m=%d B=%ld fits=%d cap=%d\n", m, a.B, fits, csr.cap);
       if (fits) {
-        int R = m <= 448 ? 16 : 8;
-        if (const char* re = kf_env_switch("KF_BSP_ROWS")) R = atoi(re) == 16 ? 16 : 8;
-        const size_t lds_sp = sizeof(double) * ((size_t)(R + 4) * m + (size_t)BSP_ND * R);
-        if (getenv("KF_BSP_DEBUG")) fprintf(stderr, "[bsp] R=%d lds=%zu\n", R, lds_sp);
+        // rows per workgroup: 8 (measured at C5, 128 draws: 4 / 8 / 16 rows -> 98 / 92 / 112 ms), 4 when 8 would leave one workgroup per CU
+        auto lds_of = [&](int rows) { return sizeof(double) * ((size_t)(rows + 5) * m + (size_t)BSP_ND * rows); };
+        int R = lds_of(8) <= KF_LDS_BYTES_MAX / 2 ? 8 : 4;
+        if (const char* re = kf_env_experiment("KF_BSP_ROWS")) R = atoi(re) == 16 ? 16 : (atoi(re) == 4 ? 4 : 8);
+        const size_t lds_sp = lds_of(R);
         if (lds_sp <= KF_LDS_BYTES_MAX) {
-          const void* fn = R == 16 ? reinterpret_cast<const void*>(bsp_step_kernel<16>) : reinterpret_cast<const void*>(bsp_step_kernel<8>);
+          const void* fn = R == 16 ? reinterpret_cast<const void*>(bsp_step_kernel<16>)
+                           : (R == 8 ? reinterpret_cast<const void*>(bsp_step_kernel<8>) : reinterpret_cast<const void*>(bsp_step_kernel<4>));
           KF_HIP_CHECK(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp));
           const int nblk = (m + R - 1) / R;
           const unsigned sgrid = (unsigned)(8L * nblk * ((a.B + 7) / 8));
@@ -1608,8 +1678,10 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
                                 tz_ws, ez_ws, ttd_ws, etd_ws};
             if (R == 16)
               hipLaunchKernelGGL(bsp_step_kernel<16>, dim3(sgrid), dim3(256), lds_sp, stream, a, t, csr, xs, nblk);
-            else
+            else if (R == 8)
               hipLaunchKernelGGL(bsp_step_kernel<8>, dim3(sgrid), dim3(256), lds_sp, stream, a, t, csr, xs, nblk);
+            else
+              hipLaunchKernelGGL(bsp_step_kernel<4>, dim3(sgrid), dim3(256), lds_sp, stream, a, t, csr, xs, nblk);
           }
           KF_HIP_CHECK(h, hipGetLastError());
           h->last_forward_kernel = "bsp_step_kernel";
