@@ -9,7 +9,8 @@ HBM: the fused forward filter (reference pymc_statespace/filters/kalman_filter.p
 for every draw, writing the same six outputs the reference graph registers
 (filtered/predicted states + covariances, logp, ll_obs -- core/statespace.py:164-174), i.e.
 the "reference-equivalent op" of SURVEY.md section 8(d), which is HBM-write bound
-(workload c5, m = 367: logp only -- its tapes are 0.8 GB per draw -- and MFMA bound).
+(workload c5, m = 367: logp only -- its tapes are 0.8 GB per draw; its sparse T runs the CSR gather path,
+HBM bound on the covariance it streams per step; a dense T of that size would be MFMA bound).
 
 Multi-GPU (`--gpus N`, N > 1): one process per GPU over RCCL.  Started without a launcher
 (no WORLD_SIZE in the environment) this script spawns `python -m torch.distributed.run
@@ -579,7 +580,37 @@ def main():
         }
         diag = bool(p > 1 and np.all(base["H"] == base["H"] * np.eye(p)))
         kname = eng.forward_kernel_name(B_local, n, p, m, r, filter_type=ft, h_diagonal=diag, time_varying=tv)
-        if big:
+        sparse_T = big and eng.last_forward_kernel() == "bsp_step_kernel"
+        if sparse_T:
+            # T sparse (the structural models): T P_f T' + R Q R' as a gather over a CSR copy of T -- m^2 nnz-per-row flops, one pass
+            # over P.  P does not fit on chip (B_local x m^2 doubles), so every step reads it and writes it once: 2 m^2 doubles per
+            # draw and step is what the recursion must move, and HBM is the roofline
+            aflops = algorithmic_flops(B_local, n, p, m, r)
+            sbytes = 2.0 * 8.0 * B_local * m * m * n
+            achieved = sbytes / (kern_ms * 1e-3) / 1e9
+            traffic, tsrc = None, None
+            try:
+                ent = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"{args.workload}:logp:B{B_local}")
+                if ent and "bsp_step_kernel" in str(ent.get("kernels", ent.get("kernel"))):
+                    traffic, tsrc = ent["bytes"], ent.get("source")
+            except Exception:  # noqa: BLE001
+                pass
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": tsrc, "kernel": "bsp_step_kernel", "kernel_ms": kern_ms, "launches_per_step": 2 * n,
+                "algorithmic_bytes_per_launch": sbytes,
+                "reference_flops_per_launch": aflops,
+                "reference_flops_tflops": aflops / (kern_ms * 1e-3) / 1e12,
+                "note": "kernel_ms = the whole forward pass (2 launches per time step: gain, bsp_step_kernel); the library found every "
+                        "draw's T sparse (kf_last_forward_kernel) and evaluates T P_f T' + R Q R' as a CSR gather: achieved = the "
+                        "predicted covariance read once and written once per step (2 x 8 m^2 bytes per draw and step -- it cannot "
+                        "stay on chip) over that time; traffic = the whole pass's HBM bytes from the counters (profiles/traffic.json); "
+                        "KF_BIG_SPARSE=0 runs the two fp64 MFMA products instead (other_entry_points.mfma_products_ms: the "
+                        "round-4 path); reference_flops_tflops = SURVEY 8(d)'s dense flop count of the REFERENCE's sequence over "
+                        "the same time -- what a dense implementation would have to sustain to match (above the 78.6 TF peak), "
+                        "not a utilisation",
+            }
+        elif big:
             aflops = algorithmic_flops(B_local, n, p, m, r)
             xflops = executed_flops_big(B_local, n, m, w_mine["T"][lo_mine:lo_mine + B_local] if w_mine["T"].ndim == 3 else None)
             ach = xflops / (kern_ms * 1e-3) / 1e12
@@ -665,6 +696,13 @@ def main():
                 ops["logp_and_gradient_one_call_ms_per_step"] = _ms1(lambda: eng.value_and_grad(
                     *d40, filter_type=ft, mvn_const="exact")) / ns
                 ops["forward_ms_per_step"] = kern_ms / n
+                if sparse_T:   # the same prefix on the two MFMA products (the path a dense T takes)
+                    os.environ["KF_BIG_SPARSE"] = "0"
+                    try:
+                        ops["mfma_products_ms_per_step"] = _ms1(lambda: eng.forward(
+                            *d40, filter_type=ft, mvn_const="exact", store_ll_obs=False, store_filtered=False, store_predicted=False)) / ns
+                    finally:
+                        del os.environ["KF_BIG_SPARSE"]
             except Exception as e:  # noqa: BLE001 -- an extra must never break the contract line
                 ops["error"] = str(e)[:300]
             out["other_entry_points"] = ops

@@ -19,7 +19,8 @@
  *
  * Conventions
  *   - Plain C, no torch / HIP types in signatures.  `stream` is a hipStream_t passed
- *     as void* (NULL = the null stream).  All calls are asynchronous on `stream`.
+ *     as void* (NULL = the null stream).  All calls are asynchronous on `stream` (one exception, a
+ *     4-byte read-back in kf_filter_forward / kf_filter_value_and_grad on the m > 64 workspace path: kf_last_forward_kernel below).
  *   - Every data pointer is a DEVICE pointer to fp64 (the reference computes in
  *     float64: kalman_filter.py:16).  The caller owns all buffers; the library
  *     never allocates in a call, never frees and never keeps a pointer.

@@ -5,7 +5,10 @@
   tvrq    time-varying R / Q (+ random other flags) on the block kernel (m <= 10, r <= 4) against the numpy oracle
   denseh  kf_filter_value_and_grad on a dense H (2 <= p <= 8, m <= 16) against torch autograd of the joint recursion: whole-row missing
           steps, intercepts, per-draw cotangents; now and then a partially missing row / a singular H (the dense redo)
-  tmask   m > 64 workspace path with random block-sparse T against every chunk (KF_BIG_TMASK=0): bit for bit"""
+  tmask   m > 64 workspace path with random block-sparse T against every chunk (KF_BIG_TMASK=0): bit for bit
+  bsp     m > 64, p = 1, no filtered covariance tape, random SPARSE T (shifted identities, rotations, companion columns, stray entries,
+          0 .. 5 dense rows, missing observations, ragged batches): the CSR gather (bsp_step_kernel) against the numpy oracle and
+          against the MFMA products (KF_BIG_SPARSE=0); which path ran is read from kf_last_forward_kernel"""
 import os
 import sys
 import time
@@ -24,8 +27,9 @@ GRADS = ("a0", "P0", "T", "Z", "R", "H", "Q", "c", "d")
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 51)
 eng = KalmanEngine()
-worst = dict(sff_vs_oracle=0.0, sff_vs_kf_smoother=0.0, tvrq_logp=0.0, tvrq_tapes=0.0, denseh_logp=0.0, denseh_grad=0.0)
-counts = dict(sff=0, tvrq=0, denseh=0, denseh_redo=0, tmask=0)
+worst = dict(sff_vs_oracle=0.0, sff_vs_kf_smoother=0.0, tvrq_logp=0.0, tvrq_tapes=0.0, denseh_logp=0.0, denseh_grad=0.0, bsp_logp=0.0,
+             bsp_tapes=0.0, bsp_vs_mfma=0.0)
+counts = dict(sff=0, tvrq=0, denseh=0, denseh_redo=0, tmask=0, bsp_csr=0, bsp_mfma=0)
 flagged = []
 t0 = time.time()
 
@@ -46,7 +50,7 @@ def slow(w, idx):
 
 
 for case in range(n_cases):
-    kind = int(rng.integers(0, 4))
+    kind = int(rng.integers(0, 5))
     seed = int(rng.integers(1 << 30))
     tag = ""
     try:
@@ -188,7 +192,7 @@ for case in range(n_cases):
             counts["denseh_redo"] += int(redo)
             if not (el < 1e-8 and eg < 1e-7):
                 flagged.append((tag, "logp/grad", (el, eg)))
-        else:            # ---- block-sparse T in the workspace path ----------------------------------------------------------------------
+        elif kind == 3:  # ---- block-sparse T in the workspace path ----------------------------------------------------------------------
             m = int(rng.choice([65, 97, 130, 200]))
             n = int(rng.choice([2, 5]))
             B = int(rng.choice([1, 3, 9]))
@@ -222,6 +226,65 @@ for case in range(n_cases):
             counts["tmask"] += 1
             if not same:
                 flagged.append((tag, "bitwise", None))
+        elif kind == 4:   # ---- sparse transition on the workspace path ------------------------------------------------------------------
+            m = int(rng.choice([65, 97, 130, 200, 257, 400]))
+            n = int(rng.choice([1, 3, 12, 40]))
+            B = int(rng.choice([1, 3, 9, 17]))
+            w = W.random_dense(B, n, 1, m, 3, seed=seed)
+            T = np.zeros_like(w["T"])
+            n_dense = int(rng.choice([0, 0, 1, 2, 4, 5]))
+            for b in range(B):
+                s0 = 0
+                while s0 < m:   # blocks: shifted identity / rotation pairs / companion column / diagonal
+                    k = int(rng.integers(2, 60))
+                    e0 = min(m, s0 + k)
+                    bt = int(rng.integers(0, 4))
+                    idx = np.arange(s0, e0 - 1)
+                    if bt == 0:
+                        T[b, idx + 1, idx] = 0.95
+                    elif bt == 1:
+                        for a in range(s0, e0 - 1, 2):
+                            lam = float(rng.uniform(0.1, 3.0))
+                            T[b, a, a], T[b, a, a + 1], T[b, a + 1, a], T[b, a + 1, a + 1] = (0.98 * np.cos(lam), 0.98 * np.sin(lam),
+                                                                                               -0.98 * np.sin(lam), 0.98 * np.cos(lam))
+                    elif bt == 2:
+                        T[b, idx, idx + 1] = 0.9
+                        T[b, s0:e0, s0] += 0.3 * rng.standard_normal(e0 - s0) / np.arange(1, e0 - s0 + 1)
+                    else:
+                        T[b, np.arange(s0, e0), np.arange(s0, e0)] = rng.uniform(-0.9, 0.9, e0 - s0)
+                    s0 = e0
+                for _ in range(int(rng.integers(0, 4))):   # stray entries
+                    T[b, int(rng.integers(0, m)), int(rng.integers(0, m))] = 0.05 * rng.standard_normal()
+            for row in rng.choice(m, size=n_dense, replace=False):   # the same dense rows in every draw, different values
+                T[:, row, :] = (0.3 / m) * rng.standard_normal((B, m))
+            y = w["y"].copy()
+            y = np.nan_to_num(y, nan=0.2) if n < 3 else y
+            for _ in range(int(rng.integers(0, 3))):
+                y[int(rng.choice([0, n - 1, rng.integers(0, n)]))] = np.nan
+            predicted = bool(rng.integers(0, 2)) or m <= 96
+            tag = f"bsp m={m} n={n} B={B} dense_rows={n_dense} predicted={predicted} seed={seed}"
+            args = (y, w["a0"], w["P0"], T, w["Z"], w["R"], w["H"], w["Q"])
+            orc = kn.kalman_filter(*args, mvn_const="exact")
+            kw = dict(mvn_const="exact", store_filtered=False, store_predicted=predicted)
+            got = eng.forward(*args, **kw)
+            path = eng.last_forward_kernel()
+            counts["bsp_csr" if path == "bsp_step_kernel" else "bsp_mfma"] += 1
+            if (path == "bsp_step_kernel") != (n_dense <= 4):
+                flagged.append((tag, "path", path))
+            os.environ["KF_BIG_SPARSE"] = "0"
+            try:
+                ref = eng.forward(*args, **kw)
+            finally:
+                del os.environ["KF_BIG_SPARSE"]
+            scale = 1.0 + np.abs(orc["logp"])
+            e1 = float(np.max(np.abs(got.logp.cpu().numpy() - orc["logp"]) / scale))
+            e3 = float(np.max(np.abs(got.logp.cpu().numpy() - ref.logp.cpu().numpy()) / scale))
+            e2 = rel_rows(got.predicted_covs.cpu().numpy(), orc["predicted_covs"]) if predicted else 0.0
+            worst["bsp_logp"] = max(worst["bsp_logp"], e1)
+            worst["bsp_tapes"] = max(worst["bsp_tapes"], e2)
+            worst["bsp_vs_mfma"] = max(worst["bsp_vs_mfma"], e3)
+            if got.info.cpu().numpy().any() or not (e1 < 1e-9 and e2 < 1e-9 and e3 < 1e-9):
+                flagged.append((tag, "deviation", (e1, e2, e3)))
     except Exception as e:  # noqa: BLE001
         flagged.append((tag, "exception", repr(e)[:300]))
 print(f"fuzz_r05: {n_cases} cases in {time.time() - t0:.0f} s  counts {counts}")

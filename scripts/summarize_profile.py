@@ -77,8 +77,9 @@ def main():
     entries = []
     fetch = pmc(os.path.join(out, "pmc_fetch"), "FETCH_SIZE")
     write = pmc(os.path.join(out, "pmc_write"), "WRITE_SIZE")
+    ours = lambda name: any(t in name for t in ("kf_", "big_", "bsp_", "bbb_", "sb_"))   # noqa: E731  (this library's kernels)
     for k in sorted(set(fetch) | set(write)):
-        if "kf_" not in k:
+        if not ours(k):
             continue
         fk = fetch.get(k, [])
         wk = write.get(k, [])
@@ -113,8 +114,8 @@ def main():
             return 1 + int(spin) + int(j.get("warmup", 0)) + int(j.get("steps", 0))
 
         p_w, p_f = passes_of("write"), passes_of("fetch")
-        tot_w = sum(sum(v) for k, v in write.items() if "kf_" in k) * 1024 / p_w
-        tot_f = sum(sum(v) for k, v in fetch.items() if "kf_" in k) * 1024 / p_f
+        tot_w = sum(sum(v) for k, v in write.items() if ours(k)) * 1024 / p_w
+        tot_f = sum(sum(v) for k, v in fetch.items() if ours(k)) * 1024 / p_f
         if len(entries) > 1:
             print(f"\nwhole pass ({len(entries)} kernels; {p_w} / {p_f} passes in the write / fetch run, spin-up included): "
                   f"WRITE_SIZE = {tot_w / 1e9:.4f} GB, FETCH_SIZE raw = {tot_f / 1e9:.4f} GB, "

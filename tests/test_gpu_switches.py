@@ -69,6 +69,9 @@ FORWARD_CASES = [
     ("KF_BIG_FUSE", ("0",), lambda: W.random_dense(B=6, n=12, p=1, m=100, r=3, seed=5), {"store_filtered": False}),
     ("KF_FORWARD_WGL", ("0",), lambda: W.random_dense(B=6, n=12, p=1, m=70, r=3, seed=6),
      {"store_filtered": False, "store_predicted": False}),
+    ("KF_BIG_TMASK", ("0",), lambda: W.daily_seasonal(B=6, n=12, s=120), {}),
+    ("KF_BIG_SPARSE", ("0",), lambda: W.daily_seasonal(B=6, n=40, s=120), {"store_filtered": False}),
+    ("KF_BIG_SPARSE", ("0",), lambda: W.daily_seasonal(B=3, n=20), {"store_filtered": False, "store_predicted": False}),
 ]
 
 
