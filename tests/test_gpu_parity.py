@@ -1145,15 +1145,18 @@ def test_value_and_grad_single_call(eng, case):
     #  forward to the adjoint, and for p > 1 forward() may pick another kernel after detecting a diagonal H)
     for k in g:
         a_, b_ = g[k].cpu().numpy(), g2[k].cpu().numpy()
-        if k == "P0" and w["p"] > 1:
+        if k in ("P0", "H") and w["p"] > 1:
             # round 5: p > 1 without KF_FLAG_H_DIAGONAL takes the whitened path, whose scalar-observation adjoints return the
-            # SYMMETRIC part of the entrywise g_P0 (include/kf.h) -- all a symmetric P0 can see; eng.backward ran the dense adjoint
+            # SYMMETRIC part of the entrywise g_P0 and whose map back through L gives a symmetric g_H = L^-T sym(G*) L^-1
+            # (include/kf.h) -- all a symmetric P0 / H can see; eng.backward ran the dense adjoint (entrywise gradients)
             a_, b_ = 0.5 * (a_ + np.swapaxes(a_, 1, 2)), 0.5 * (b_ + np.swapaxes(b_, 1, 2))
         assert np.max(np.abs(a_ - b_)) / (1.0 + np.max(np.abs(b_))) < 1e-10, k
     rl, _, gt = kt.logp_and_grads(*args, mvn_const="exact", g_logp=gl)
     assert np.max(np.abs(logp.cpu().numpy() - rl)) < 1e-8
     for k in g:
         a_, b_ = g[k].cpu().numpy(), gt[k]
+        if k in ("P0", "H") and w["p"] > 1:
+            a_, b_ = 0.5 * (a_ + np.swapaxes(a_, 1, 2)), 0.5 * (b_ + np.swapaxes(b_, 1, 2))
         assert np.max(np.abs(a_ - b_)) / (1.0 + np.max(np.abs(b_))) < 1e-9, k
     # default cotangent: ones
     _, _, g1 = eng.value_and_grad(*args, mvn_const="exact")
