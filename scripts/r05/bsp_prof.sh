@@ -1,13 +1,13 @@
 #!/bin/bash
-# C5 forward on the sparse-transition path: timing per rows-per-workgroup and SQ / TCC counters of bsp_step_kernel
+# C5 forward on the sparse-transition path against the MFMA products; kernel stats and SQ / TCC counters of bsp_step_kernel
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT; O=$ROOT/gpurun_out/r05_bspprof; mkdir -p $O
-for rows in 4 8 16; do
-  KF_BSP_ROWS=$rows python3 bench.py --workload c5 --steps 2 --warmup 1 --no-cpu --no-ops 2>/dev/null | python3 -c "
+for sp in 1 0; do
+  KF_BIG_SPARSE=$sp python3 bench.py --workload c5 --steps 2 --warmup 1 --no-cpu --no-ops 2>/dev/null | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         j = json.loads(l)
-        print('rows=$rows c5:', round(j['ms_per_step'], 2), 'ms per 128 draws', round(j['value'], 1), j['unit'])
+        print('KF_BIG_SPARSE=$sp c5:', round(j['ms_per_step'], 2), 'ms per 128 draws', round(j['value'], 1), j['unit'], j['roofline']['kernel'])
 "
 done | tee $O/lines.txt
 cat > /tmp/c5_small.py <<'PY'
@@ -24,7 +24,6 @@ torch.cuda.synchronize()
 print(float(res.logp[0]), eng.last_forward_kernel())
 PY
 cd /tmp; export TMPDIR=/tmp
-export KF_BSP_ROWS=${BSP_PROF_ROWS:-8}
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 /tmp/c5_small.py > /dev/null 2>&1
 python3 $ROOT/scripts/kernel_stats.py $O/kt 4
 for c in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM" "GRBM_GUI_ACTIVE TCP_PENDING_STALL_CYCLES_sum SQ_WAIT_ANY" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
