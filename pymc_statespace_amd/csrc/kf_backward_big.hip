@@ -286,7 +286,7 @@ inline size_t bb_doubles(long B, int m, int p, int n, int r) {
 }  // namespace
 
 size_t kf_backward_big_workspace_bytes(long B, int m, int p, int n, int r) {
-  return sizeof(double) * bb_doubles(B, m, p, n, r) + 256;
+  return sizeof(double) * bb_doubles(B, m, p, n, r) + sizeof(uint32_t) * (size_t)B * ((m + 63) / 64) + 256;   // (+ the block map of T)
 }
 
 int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t st) {
@@ -345,6 +345,16 @@ int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, si
   const long sTape = (long)(n + 1) * mm;
   const char* bge = kf_env_switch("KF_SMOOTHER_BIG_GEMM");
   const bool big_full = m >= 128 && !(bge && bge[0] == '0');
+  // block map of T by columns (m <= 1024): the two products by T walk only the K chunks whose 32 x 64 block of T holds a non-zero
+  // (the skipped ones add exact zeros: bit for bit the same; KF_BIG_TMASK=0: every chunk)
+  uint32_t* tmaskc = nullptr;
+  {
+    const char* te = kf_env_switch("KF_BIG_TMASK");
+    if (big_full && m <= 1024 && !(te && te[0] == '0')) {
+      tmaskc = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(q) + 63) & ~(uintptr_t)63);
+      if (kf_big_tmask_cols_launch(st, a.Tm, m, B, tmaskc) != KF_OK) tmaskc = nullptr;
+    }
+  }
   for (int t = n - 1; t >= 0; --t) {
     // ab_f = T' ab'
     hipLaunchKernelGGL(bb_colmatvec_kernel, dim3(cc, (unsigned)B), dim3(NT), sh_mv, st, a.Tm, mm, W.abp, (long)m,
@@ -359,9 +369,11 @@ int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, si
     // X1 = Pb T ; Sb = X1' T ; Tb_m += X1 P_f
     // (m >= 128: on kf_forward_big.hip's 128 x 64-tile product, 270 against 335 us per launch at C5; KF_SMOOTHER_BIG_GEMM=0: this file's)
     if (big_full) {
-      kf_big_gemm_launch(st, false, false, false, W.PB, mm, a.Tm, mm, nullptr, 0, X1, mm, m, B);
+      kf_big_gemm_launch_x(st, false, false, W.PB, mm, a.Tm, mm, nullptr, 0, X1, mm, m, B, tmaskc, /*on_b=*/1, 0, nullptr, nullptr, nullptr,
+                           nullptr, false);
       kf_sb_transpose(st, B, X1, mm, X1t, mm, m);
-      kf_big_gemm_launch(st, false, false, false, X1t, mm, a.Tm, mm, nullptr, 0, W.SB, mm, m, B);
+      kf_big_gemm_launch_x(st, false, false, X1t, mm, a.Tm, mm, nullptr, 0, W.SB, mm, m, B, tmaskc, /*on_b=*/1, 0, nullptr, nullptr, nullptr,
+                           nullptr, false);
       kf_big_gemm_launch(st, false, true, false, X1, mm, W.Pc, mm, TBm, mm, TBm, mm, m, B);
     } else {
       kf_sb_gemm(st, B, false, 0, W.PB, mm, m, a.Tm, mm, m, nullptr, 0, 0, X1, mm, m, m, m, m);

@@ -109,6 +109,26 @@ __global__ __launch_bounds__(256) void big_tmask_kernel(const double* __restrict
   __syncthreads();
   if (threadIdx.x == 0) tmask[b * nrb + rb] = bits;
 }
+// the same map by COLUMNS: word [b][cb] bit kc set when T[32 kc .. +32][64 cb .. +64] holds a non-zero -- what a product A T (T the
+// untransposed B operand: K runs over its rows, a tile's 64 columns are columns of T) skips by.  grid (ceil(m / 64), B), m <= 1024
+__global__ __launch_bounds__(256) void big_tmask_cols_kernel(const double* __restrict__ T, int m, uint32_t* __restrict__ tmask) {
+  __shared__ unsigned bits;
+  const long b = blockIdx.y;
+  const int cb = blockIdx.x, ncb = gridDim.x;
+  if (threadIdx.x == 0) bits = 0u;
+  __syncthreads();
+  const double* Tb = T + b * (long)m * m;
+  const int c0 = cb * 64, lane = threadIdx.x & 63;
+  unsigned mine = 0u;
+  if (c0 + lane < m)
+    for (int k = threadIdx.x >> 6; k < m; k += 4) {   // rows 4 apart per wavefront, 64 consecutive columns per row: coalesced
+      const double v = Tb[(long)k * m + c0 + lane];
+      if (v != 0.0 || v != v) mine |= 1u << (unsigned)(k / 32);
+    }
+  if (mine) atomicOr(&bits, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) tmask[b * ncb + cb] = bits;
+}
 constexpr int BIG_PFIX_M = 1024;
 constexpr int BIG_AH_ROWS = 64;   // rows of a_hat = T a_f + c per workgroup ahead of the tiles
 template <bool TRANS_B, bool ADD_E, bool UPPER = false, bool PFIX = false, bool MIRROR = false>
@@ -1526,6 +1546,8 @@ int kf_big_gemm_launch_x(hipStream_t st, bool trans_b, bool add_e, const double*
       hipLaunchKernelGGL((big_gemm_kernel<false, true, true, false, true>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x);
     else if (trans_b && !add_e)
       hipLaunchKernelGGL((big_gemm_kernel<true, false, true, false, true>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x);
+    else if (trans_b && add_e)
+      hipLaunchKernelGGL((big_gemm_kernel<true, true, true, false, true>), dim3(ggrid), dim3(GNT), 0, st, A, sA, Bm, sB, E, sE, C, sC, m, draws, tgn, tgm, x);
     else
       return KF_ERR_UNSUPPORTED;
   } else if (!trans_b && !add_e)
@@ -1542,6 +1564,11 @@ int kf_big_gemm_launch_x(hipStream_t st, bool trans_b, bool add_e, const double*
 // block map of a per-draw m x m matrix (64-row blocks x 32-column chunks, m <= 1024): tmask[B][ceil(m / 64)]
 int kf_big_tmask_launch(hipStream_t st, const double* T, int m, long B, uint32_t* tmask) {
   hipLaunchKernelGGL(big_tmask_kernel, dim3((unsigned)((m + 63) / 64), (unsigned)B), dim3(256), 0, st, T, m, tmask);
+  return hipGetLastError() == hipSuccess ? KF_OK : KF_ERR_HIP;
+}
+
+int kf_big_tmask_cols_launch(hipStream_t st, const double* T, int m, long B, uint32_t* tmask) {
+  hipLaunchKernelGGL(big_tmask_cols_kernel, dim3((unsigned)((m + 63) / 64), (unsigned)B), dim3(256), 0, st, T, m, tmask);
   return hipGetLastError() == hipSuccess ? KF_OK : KF_ERR_HIP;
 }
 

@@ -338,6 +338,8 @@ int kf_big_gemm_launch_x(hipStream_t st, bool trans_b, bool add_e, const double*
                          long sE, double* C, long sC, int m, long draws, const uint32_t* tmask, int tmask_on_b, int neg_acc,
                          const double* u1, const double* v1, const double* u2, const double* v2, bool upper_mirror);
 int kf_big_tmask_launch(hipStream_t st, const double* T, int m, long B, uint32_t* tmask);
+// block map of T by columns (word per 64-column block, bit per 32-row chunk): for A T with T the untransposed B operand, tmask_on_b = 1
+int kf_big_tmask_cols_launch(hipStream_t st, const double* T, int m, long B, uint32_t* tmask);
 int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
                           hipStream_t stream);
 // dense H with p > 1 on the scalar-observation kernels by whitening (kf_forward_whiten.hip)

@@ -624,7 +624,8 @@ void kf_sb_transpose(hipStream_t st, long B, const double* src, long sS, double*
 size_t kf_smoother_big_workspace_bytes(long B, int m) {
   const long mm = (long)m * m;
   const int nblk = (m + NB - 1) / NB;
-  return sizeof(double) * (size_t)B * (size_t)(6 * mm + 2L * nblk * NB * NB + 2) + 256;  // + scale, flags per draw
+  return sizeof(double) * (size_t)B * (size_t)(6 * mm + 2L * nblk * NB * NB + 2) + sizeof(uint32_t) * (size_t)B * ((m + 63) / 64) +
+         320;  // + scale, flags per draw; the block map of T
 }
 
 int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace, size_t workspace_bytes,
@@ -670,6 +671,14 @@ int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace,
   // KF_SMOOTHER_BIG_GEMM=0: the four full-size products on this file's own kernel (A/B measurements); m < 128: its smaller tiles fit better
   const char* bge = kf_env_switch("KF_SMOOTHER_BIG_GEMM");
   const bool big_full = m >= 128 && !(bge && bge[0] == '0');
+  uint32_t* tmask = nullptr;   // block map of T (KF_BIG_TMASK=0: every chunk)
+  {
+    const char* te = kf_env_switch("KF_BIG_TMASK");
+    if (big_full && !(te && te[0] == '0')) {
+      tmask = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(flags + B) + 63) & ~(uintptr_t)63);
+      if (kf_big_tmask_launch(st, a.Tm, m, B, tmask) != KF_OK) tmask = nullptr;
+    }
+  }
   for (int t = n - 2; t >= 0; --t) {
     const double* Pf = a.filt_P + (long)t * mm;
     const double* Psn = a.smooth_P + (long)(t + 1) * mm;
@@ -678,8 +687,11 @@ int kf_launch_smoother_big(kf_handle* h, const KfSmoothArgs& a, void* workspace,
     // (the four full-size products on kf_forward_big.hip's 128 x 64-tile kernel, the symmetric ones on the tiles that touch the upper
     //  triangle with both triangles written: 334 / 346 / 335 / 419 us on this file's 64 x 64-tile kernel -> 270 / 255 / 270 / 255 at C5)
     if (big_full) {
-      kf_big_gemm_launch(st, false, false, false, a.Tm, mm, Pf, sTape, nullptr, 0, W, mm, m, B);
-      kf_big_gemm_launch(st, true, true, true, W, mm, a.Tm, mm, RQR, mm, PH, mm, m, B);
+      // (both products by T on the K chunks whose 64 x 32 block of T holds a non-zero: kf_forward_big.hip's map, bit for bit the same)
+      kf_big_gemm_launch_x(st, false, false, a.Tm, mm, Pf, sTape, nullptr, 0, W, mm, m, B, tmask, /*on_b=*/0, 0, nullptr, nullptr, nullptr,
+                           nullptr, false);
+      kf_big_gemm_launch_x(st, true, true, W, mm, a.Tm, mm, RQR, mm, PH, mm, m, B, tmask, /*on_b=*/1, 0, nullptr, nullptr, nullptr, nullptr,
+                           /*upper_mirror=*/true);
     } else {
       gemm<false, EPI_STORE>(st, B, a.Tm, mm, m, Pf, sTape, m, nullptr, 0, 0, W, mm, m, m, m, m);
       gemm<true, EPI_ADD>(st, B, W, mm, m, a.Tm, mm, m, RQR, mm, m, PH, mm, m, m, m, m);

@@ -275,6 +275,31 @@ def test_big_path_skips_zero_blocks_of_T_bit_for_bit(eng, monkeypatch, case):
     assert np.array_equal(lo.logp.cpu().numpy(), lo0.logp.cpu().numpy())
 
 
+def test_big_gradient_and_rts_smoother_skip_zero_blocks_of_T_bit_for_bit(eng, monkeypatch):
+    """The gradient sweep's two products by T (X1 = Pb T, Sb = X1' T: T the untransposed B operand, block map by columns) and the
+    RTS smoother's (W = T P_f, P_hat = W T' + R Q R') walk only the K chunks whose block of T holds a non-zero: the same bits as
+    every chunk (KF_BIG_TMASK=0), and the oracles' numbers are held by tests/test_gpu_c5.py."""
+    w = W.daily_seasonal(B=3, n=6, s=150)
+    rng = np.random.default_rng(4)
+    w["T"] = w["T"].copy()
+    w["T"][1, :, 100] = 0.01 * rng.standard_normal(w["m"])     # a dense column in one draw: per-draw maps
+    args = _args(w)
+    res = eng.forward(*args, mvn_const="exact")
+
+    def run():
+        g = eng.backward(*args, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs, g_logp=np.ones(w["B"]),
+                         mvn_const="exact")
+        sa, sP = eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
+        return {k: v.cpu().numpy() for k, v in g.items()}, sa.cpu().numpy(), sP.cpu().numpy()
+
+    g1, sa1, sP1 = run()
+    monkeypatch.setenv("KF_BIG_TMASK", "0")
+    g0, sa0, sP0 = run()
+    for k in g1:
+        assert np.array_equal(g1[k], g0[k]), k
+    assert np.array_equal(sa1, sa0) and np.array_equal(sP1, sP0)
+
+
 def _sparse_case(case):
     """Models whose T is a few non-zeros per row: what the reference's structural components assemble (seasonal dummies: a row of
     -1 over a shifted identity; trigonometric seasonality: 2 x 2 rotations; ARMA: a companion column over a shifted identity)."""
