@@ -501,6 +501,14 @@ int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t
                        hipStream_t stream) {
   // time-varying system matrices: the LDS-resident adjoint reloads slice t per step and writes gradient tapes
   if (a.flags & KF_FLAG_TV_ANY) {
+    // round 5: T / Z / H / c / d time-varying (R, Q static), m <= 16, scalar observations: the accumulator-layout adjoint with
+    // per-step slices and gradient tapes (kf_bwd_mfma_kernel<.., TV>); KF_BACKWARD_TV_MFMA=0 in the environment keeps the LDS adjoint
+    if (!(a.flags & (KF_FLAG_TV_R | KF_FLAG_TV_Q)) && !a.steps && !a.accumulate && a.m <= KF_MP_M_MAX && a.p <= KF_MP_P_MAX &&
+        (a.p == 1 || a.filter == KF_FILTER_UNIVARIATE || (a.flags & KF_FLAG_H_DIAGONAL)) &&
+        (h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_MFMA || h->forward_kernel == KF_KERNEL_B4)) {
+      const char* e = kf_env_switch("KF_BACKWARD_TV_MFMA");
+      if (!(e && e[0] == '0')) return kf_launch_backward_mfma(h, a, stream);
+    }
     if (!kf_backward_lds_fits(a.m, a.p)) {
       KF_SET_ERR(h, "kf_filter_backward: time-varying system matrices need the LDS-resident adjoint (m=%d p=%d does "
                  "not fit %d B of LDS)", a.m, a.p, KF_LDS_BYTES_MAX);

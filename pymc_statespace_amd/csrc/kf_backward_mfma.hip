@@ -40,8 +40,12 @@ __host__ __device__ inline int bwd_mfma_lds_doubles(int p) {
 // slower: 5.2 vs 3.9 ms at the north-star shape)
 // P1: p == 1 known at compile time -- Z, M, F, v of the step stay in registers between the
 // forward recompute and the adjoint instead of going through LDS
-template <int KS, bool P1>
-__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3 ? 4 : 3))) void kf_bwd_mfma_kernel(
+// TV (round 5): time-varying T / Z / H / c / d ([B][T][..], KF_FLAG_TV_*; R and Q static): step t loads slice t of every flagged
+// array -- T_t for the predict adjoint, Z_t / H_t / d_t for the update -- and its gradient is that step's term alone, written to slice
+// t of the gradient tape instead of accumulated (the indexing of kf_backward_lds.hip, which this replaces for m <= 16 and scalar
+// observations: 15 -> 4 ms at the headline shape).
+template <int KS, bool P1, bool TV = false>
+__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((KS <= 3 && !(TV && KS >= 2)) ? 4 : 3))) void kf_bwd_mfma_kernel(
     const KfBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
@@ -72,11 +76,15 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
   double* GY = ACC + 8 * KF_WAVE;       // (g_yy requested) sum_t vb_q (y -+ d)_q', 8 x 8
 
   const bool c_ok = c < m;
+  const unsigned tvf = TV ? (A.flags & KF_FLAG_TV_ANY) : 0u;
+  const bool tv_T = TV && (tvf & KF_FLAG_TV_T), tv_Z = TV && (tvf & KF_FLAG_TV_Z), tv_H = TV && (tvf & KF_FLAG_TV_H),
+             tv_C = TV && (tvf & KF_FLAG_TV_C), tv_D = TV && (tvf & KF_FLAG_TV_D);
+  const long bT = TV ? b * (long)A.T : 0L;   // slice (b, t) of a time-varying array is (bT + t)
   double TA[KS], TB[KS];  // T' tile (TA[s] = T[c][4s+g]) and T tile (TB[s] = T[4s+g][c])
   bool on[KS];
   int off[KS];
   {
-    const double* gT = A.Tm + b * (long)mm;
+    const double* gT = A.Tm + (tv_T ? bT : b) * (long)mm;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int k = 4 * s + g;
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
       TA[s] = on[s] ? gT[c * m + k] : 0.0;
       TB[s] = on[s] ? gT[k * m + c] : 0.0;
     }
-    const double* gZ = A.Z + b * (long)p * m;
+    const double* gZ = A.Z + (tv_Z ? bT : b) * (long)p * m;
     for (int e = lane; e < p * TILE; e += KF_WAVE) {
       const int q = e >> 4, k = e & 15;
       const double z = (k < m) ? gZ[q * m + k] : 0.0;
@@ -94,8 +102,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
       ZB[e] = 0.0;
     }
     if (lane < p) {
-      HD[lane] = A.H[b * (long)p * p + lane * p + lane];
-      DL[lane] = A.d ? A.d[b * (long)p + lane] : 0.0;
+      HD[lane] = A.H[(tv_H ? bT : b) * (long)p * p + lane * p + lane];
+      DL[lane] = A.d ? A.d[(tv_D ? bT : b) * (long)p + lane] : 0.0;
     }
   }
   const bool univariate = A.filter == KF_FILTER_UNIVARIATE;
@@ -109,12 +117,12 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
 
   double zc1 = 0.0, zr1[4] = {0.0, 0.0, 0.0, 0.0}, H1 = 0.0, d1 = 0.0;
   if (P1) {
-    const double* gZ = A.Z + b * (long)m;
+    const double* gZ = A.Z + (tv_Z ? bT : b) * (long)m;
     zc1 = c_ok ? gZ[c] : 0.0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) zr1[s] = (4 * s + g < m) ? gZ[4 * s + g] : 0.0;
-    H1 = A.H[b];
-    d1 = A.d ? A.d[b] : 0.0;
+    H1 = A.H[tv_H ? bT : b];
+    d1 = A.d ? A.d[tv_D ? bT : b] : 0.0;
   }
   // adjoint state and accumulators
   double PB[KS];
@@ -132,11 +140,29 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
   auto put = [&](double* dst, double v) { *dst = acc_out ? *dst + v : v; };
 
   double PN[KS], an;
+  double TN[KS], zcN = 0.0, zrN[4] = {0.0, 0.0, 0.0, 0.0}, HN = 0.0, dN = 0.0;   // TV: slice t of T (and, p == 1, of Z / H / d)
   auto prefetch = [&](int t) {
     const double* rp = gpP + (long)t * mm;
 #pragma unroll
     for (int s = 0; s < KS; ++s) PN[s] = on[s] ? rp[off[s]] : 0.0;
     an = c_ok ? gpa[(long)t * m + c] : 0.0;
+    if (TV) {
+      if (tv_T) {
+        const double* tp = A.Tm + (bT + t) * (long)mm;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) TN[s] = on[s] ? tp[off[s]] : 0.0;
+      }
+      if (P1) {
+        if (tv_Z) {
+          const double* zp = A.Z + (bT + t) * (long)m;
+          zcN = c_ok ? zp[c] : 0.0;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) zrN[s] = (4 * s + g < m) ? zp[4 * s + g] : 0.0;
+        }
+        if (tv_H) HN = A.H[bT + t];
+        if (tv_D && A.d) dN = A.d[bT + t];
+      }
+    }
   };
   auto stage_block = [&](int t) {  // y and g_ll_obs of the 64-step block that holds t
     const int t0 = t & ~63;
@@ -153,6 +179,37 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
 #pragma unroll
     for (int s = 0; s < KS; ++s) P[s] = PN[s];
     double ac = an;
+    if (TV) {
+      if (tv_T) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) TB[s] = TN[s];
+      }
+      if (P1) {
+        if (tv_Z) {
+          zc1 = zcN;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) zr1[s] = zrN[s];
+        }
+        if (tv_H) H1 = HN;
+        if (tv_D) d1 = dN;
+      } else if (tv_Z || tv_H || tv_D) {   // p > 1: slice t of Z / H / d into the LDS copies
+        __syncthreads();
+        if (tv_Z) {
+          const double* zp = A.Z + (bT + t) * (long)p * m;
+          for (int e = lane; e < p * TILE; e += KF_WAVE) {
+            const int q = e >> 4, k = e & 15;
+            const double z = (k < m) ? zp[q * m + k] : 0.0;
+            ZC[e] = z;
+            ZR[q * TILE + (k & 3) * 4 + (k >> 2)] = z;
+          }
+        }
+        if (lane < p) {
+          if (tv_H) HD[lane] = A.H[(bT + t) * (long)p * p + lane * p + lane];
+          if (tv_D && A.d) DL[lane] = A.d[(bT + t) * (long)p + lane];
+        }
+        __syncthreads();
+      }
+    }
     if (t > 0) prefetch(t - 1);
     if ((t & 63) == 63 && t != n - 1) stage_block(t);
     const double* yrow = YB + (t & 63) * p;
@@ -218,11 +275,15 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
       const double2_t a23 = *reinterpret_cast<const double2_t*>(EX + 4 * g + 2);
       abr[0] = a01.x; abr[1] = a01.y; abr[2] = a23.x; abr[3] = a23.y;
     }
-    cb += abp;
+    if (tv_C) {
+      if (g == 0 && c_ok && A.g_c) A.g_c[(bT + t) * (long)m + c] = abp;
+    } else {
+      cb += abp;
+    }
     double part = TB[0] * abr[0];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      ACC[(4 + s) * KF_WAVE + lane] = fma(abr[s], ac, ACC[(4 + s) * KF_WAVE + lane]);  // ab' a_f'
+      if (!tv_T) ACC[(4 + s) * KF_WAVE + lane] = fma(abr[s], ac, ACC[(4 + s) * KF_WAVE + lane]);  // ab' a_f'
       ACC[s * KF_WAVE + lane] += PB[s];                                                // adjoint of R Q R'
       if (s > 0) part = fma(TB[s], abr[s], part);
     }
@@ -244,6 +305,15 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
       const double X1t[4] = {t01.x, t01.y, t23.x, t23.y};
 #pragma unroll
       for (int s = 0; s < KS; ++s) TBm = __builtin_amdgcn_mfma_f64_16x16x4f64(X1t[s], P[s], TBm, 0, 0, 0);
+    }
+    if (tv_T) {   // g_T[t] = 2 X1' P_f + ab' a_f'  (this step's term alone)
+      if (A.g_T) {
+        double* o = A.g_T + (bT + t) * (long)mm;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+          if (on[s]) o[off[s]] = fma(2.0, TBm[s], abr[s] * ac);
+      }
+      TBm = (double4_t){0.0, 0.0, 0.0, 0.0};
     }
     double SB[KS];
 #pragma unroll
@@ -292,7 +362,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
 #pragma unroll
       for (int s = 1; s < KS; ++s) pp = fma(P[s], ur[s], pp);
       const double pdot = col_allsum(pp);  // P^q (m1b + m2b)
-      if (g == 0) ZB[q * TILE + c] += fma(-aq, vb, fma(2.0 * Fb, Mc, pdot));
+      if (tv_Z) {
+        if (g == 0 && c_ok && A.g_Z) A.g_Z[((bT + t) * (long)p + q) * m + c] = fma(-aq, vb, fma(2.0 * Fb, Mc, pdot));
+      } else if (g == 0) {
+        ZB[q * TILE + c] += fma(-aq, vb, fma(2.0 * Fb, Mc, pdot));
+      }
       if (p == 1 && t == 0 && A.g_P0) {  // (p == 1 at run time also takes this path)
         // exact (not symmetrised) entrywise gradient: Sb + (Fb z + m1b) z' - z s'/F
         __syncthreads();
@@ -320,8 +394,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
       }
       abf = fma(-zc, vb, abf);
       if (c == q) {
-        hbv += Fb;
-        dbv += dsign * vb;
+        hbv = tv_H ? Fb : hbv + Fb;
+        dbv = tv_D ? dsign * vb : dbv + dsign * vb;
       }
       if (want_yy && g == 0 && c < p) {   // (vb = 0 on a missing / skipped observation: its y never counts)
         const double yc = yrow[c];
@@ -331,6 +405,13 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
 #pragma unroll
     for (int s = 0; s < KS; ++s) PB[s] = SB[s];
     abp = abf;
+    if (tv_H || tv_D) {   // slice t of g_H (diagonal; the rest zeros) / g_d: lane (g = 0, c = q) holds this step's term
+      if (g == 0 && c < p) {
+        if (tv_D && A.g_d) A.g_d[(bT + t) * (long)p + c] = dbv;
+        if (tv_H && A.g_H)
+          for (int q2 = 0; q2 < p; ++q2) A.g_H[((bT + t) * (long)p + c) * p + q2] = (q2 == c) ? hbv : 0.0;
+      }
+    }
   }
 
   // ---- gradients out ----------------------------------------------------------------------------------------
@@ -344,25 +425,25 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(KS <= 3
   __syncthreads();
   if (g == 0 && c_ok) {
     if (A.g_a0) A.g_a0[b * (long)m + c] = abp;
-    if (A.g_c) put(A.g_c + b * (long)m + c, cb);
+    if (A.g_c && !tv_C) put(A.g_c + b * (long)m + c, cb);
   }
-  if (A.g_Z)
+  if (A.g_Z && !tv_Z)
     for (int e = lane; e < p * m; e += KF_WAVE) {
       const int q = e / m, k = e - q * m;
       put(A.g_Z + b * (long)p * m + e, ZB[q * TILE + k]);
     }
-  if (A.g_H)
+  if (A.g_H && !tv_H)
     for (int e = lane; e < p * p; e += KF_WAVE) {
       const int q1 = e / p, q2 = e - q1 * p;
       put(A.g_H + b * (long)p * p + e, (q1 == q2) ? HB[q1] : 0.0);
     }
-  if (A.g_d && lane < p) put(A.g_d + b * (long)p + lane, DB[lane]);
+  if (A.g_d && !tv_D && lane < p) put(A.g_d + b * (long)p + lane, DB[lane]);
   if (want_yy)
     for (int e = lane; e < p * p; e += KF_WAVE) put(A.g_yy + b * (long)p * p + e, GY[(e / p) * 8 + e % p]);
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     if (!on[s]) continue;
-    if (A.g_T) put(A.g_T + b * (long)mm + off[s], fma(2.0, TBm[s], ACC[(4 + s) * KF_WAVE + lane]));
+    if (A.g_T && !tv_T) put(A.g_T + b * (long)mm + off[s], fma(2.0, TBm[s], ACC[(4 + s) * KF_WAVE + lane]));
     if (A.g_P0 && p > 1) A.g_P0[b * (long)mm + off[s]] = PB[s];
   }
   // R_b = Gs R (Q + Q') ;  Q_b = R' Gs R   (Gs in tile FT)
@@ -401,8 +482,17 @@ int kf_launch_backward_mfma(kf_handle* h, const KfBwdArgs& a, hipStream_t stream
   }
   const size_t lds = sizeof(double) * (size_t)bwd_mfma_lds_doubles(a.p);
   const int ks = (a.m + 3) / 4;
+  const bool tv = (a.flags & KF_FLAG_TV_ANY) != 0;
+  if (tv && ((a.flags & (KF_FLAG_TV_R | KF_FLAG_TV_Q)) || a.steps || a.accumulate)) {
+    KF_SET_ERR(h, "backward(mfma): time-varying R / Q (and the steady-state hand-over) stay on the LDS adjoint");
+    return KF_ERR_UNSUPPORTED;
+  }
 #define KF_BWD_MFMA_LAUNCH(KS_)                                                                        \
-  if (a.p == 1)                                                                                        \
+  if (tv && a.p == 1)                                                                                  \
+    hipLaunchKernelGGL((kf_bwd_mfma_kernel<KS_, true, true>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);  \
+  else if (tv)                                                                                         \
+    hipLaunchKernelGGL((kf_bwd_mfma_kernel<KS_, false, true>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); \
+  else if (a.p == 1)                                                                                   \
     hipLaunchKernelGGL((kf_bwd_mfma_kernel<KS_, true>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);  \
   else                                                                                                 \
     hipLaunchKernelGGL((kf_bwd_mfma_kernel<KS_, false>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a)

@@ -300,6 +300,46 @@ def test_big_gradient_and_rts_smoother_skip_zero_blocks_of_T_bit_for_bit(eng, mo
     assert np.array_equal(sa1, sa0) and np.array_equal(sP1, sP0)
 
 
+@pytest.mark.parametrize("tv", [("T",), ("Z",), ("T", "Z", "H", "c", "d")], ids=lambda t: "".join(t))
+@pytest.mark.parametrize("pm", [(1, 3), (1, 10), (1, 15), (3, 10), (5, 16)], ids=lambda x: f"p{x[0]}m{x[1]}")
+def test_time_varying_gradient_on_the_tile_adjoint(eng, monkeypatch, tv, pm):
+    """T / Z / H / c / d time-varying (R, Q static), m <= 16, scalar observations: kf_bwd_mfma_kernel<.., TV> with per-step slices
+    and gradient tapes -- against the LDS adjoint it replaces (KF_BACKWARD_TV_MFMA=0) and torch autograd; a missing step, per-step
+    cotangents, 70 draws x 90 steps (more than one 64-step block of y)."""
+    from oracle import kalman_torch as kt
+
+    p, m = pm
+    B, n, r = 70, 90, 2
+    w = W.random_dense(B, n, p, m, r, seed=5 + m + p)
+    rng = np.random.default_rng(3)
+    mats = dict(T=w["T"], Z=w["Z"], R=w["R"], H=w["H"], Q=w["Q"], c=0.1 * rng.standard_normal((B, m)), d=0.1 * rng.standard_normal((B, p)))
+    for k, name in enumerate(tv):
+        x = np.repeat(mats[name][:, None], n, axis=1)
+        wave = (0.8 + 0.2 * np.cos(np.arange(n) + k))[None, :]
+        mats[name] = x * wave.reshape(wave.shape + (1,) * (x.ndim - 2))
+    y = w["y"].copy()
+    y[[5, 63, 64]] = np.nan
+    gl, gll = rng.standard_normal(B), 0.3 * rng.standard_normal((B, n))
+    args = (y, w["a0"], w["P0"], mats["T"], mats["Z"], mats["R"], mats["H"], mats["Q"], mats["c"], mats["d"])
+    kw = dict(mvn_const="exact", time_varying=tv, h_diagonal=p > 1)
+    res = eng.forward(*args, **kw)
+    bkw = dict(predicted_states=res.predicted_states, predicted_covs=res.predicted_covs, g_logp=gl, g_ll_obs=gll, want_cd=True, **kw)
+    g = {k: v.cpu().numpy() for k, v in eng.backward(*args, **bkw).items()}
+    monkeypatch.setenv("KF_BACKWARD_TV_MFMA", "0")
+    g0 = {k: v.cpu().numpy() for k, v in eng.backward(*args, **bkw).items()}
+    monkeypatch.delenv("KF_BACKWARD_TV_MFMA")
+    _, _, gt = kt.logp_and_grads(*args, mvn_const="exact", g_logp=gl, g_ll_obs=gll, time_varying=tv)
+    for k in GRADS:
+        assert g[k].shape == g0[k].shape == np.asarray(gt[k]).shape, k
+        a, b0, bt = g[k], g0[k], np.asarray(gt[k])
+        if p > 1 and k in ("P0", "H"):   # (scalar-observation adjoints: symmetric part of g_P0, diagonal of g_H)
+            a, b0, bt = (0.5 * (x + np.swapaxes(x, -1, -2)) for x in (a, b0, bt))
+            if k == "H":
+                a, b0, bt = (np.diagonal(x, axis1=-2, axis2=-1) for x in (a, b0, bt))
+        assert np.max(np.abs(a - b0)) / (1.0 + np.max(np.abs(b0))) < 1e-10, (k, "LDS adjoint")
+        assert np.max(np.abs(a - bt)) / (1.0 + np.max(np.abs(bt))) < 1e-9, (k, "autograd")
+
+
 def _sparse_case(case):
     """Models whose T is a few non-zeros per row: what the reference's structural components assemble (seasonal dummies: a row of
     -1 over a shifted identity; trigonometric seasonality: 2 x 2 rotations; ARMA: a companion column over a shifted identity)."""
