@@ -1217,7 +1217,14 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
   }
   if (a.flags) {
     a.flags |= dims->flags & KF_FLAG_TV_SMOOTHER_REFERENCE_PAIRING;
-    // time-varying T / R / Q (kalman_smoother.py:17-54,62-77): the LDS-resident kernel reloads the slices per step
+    // time-varying T / R / Q (kalman_smoother.py:17-54,62-77).  Round 5: 5 <= m <= 16 on the register-tile elimination kernel with
+    // per-step slices (kf_smooth_mfma_kernel<.., TV>; draws it flags go to the LDS kernel as for static models);
+    // KF_SMOOTHER_TV_MFMA=0 in the environment keeps the LDS kernel, which reloads the slices per step
+    if (a.m >= 5 && a.m <= KF_MP_M_MAX && h->forward_kernel != KF_KERNEL_LDS && workspace &&
+        workspace_bytes >= kf_smoother_mfma_workspace_bytes(a.B)) {
+      const char* e = kf_env_switch("KF_SMOOTHER_TV_MFMA");
+      if (!(e && e[0] == '0')) return kf_launch_smoother_mfma(h, a, workspace, workspace_bytes, (hipStream_t)stream);
+    }
     if (!kf_smoother_lds_fits(a.m)) {
       KF_SET_ERR(h, "kf_smoother: time-varying system matrices need the LDS-resident kernel (m=%d too large)", a.m);
       return KF_ERR_UNSUPPORTED;

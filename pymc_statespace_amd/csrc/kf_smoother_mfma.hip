@@ -21,8 +21,11 @@ namespace {
 
 constexpr int TILE = 16;
 
-template <int KS>
-__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) void kf_smooth_mfma_kernel(
+// TV (round 5): time-varying T / R / Q ([B][n][..], KF_FLAG_TV_*): the step that smooths t predicts from t with slice t (+ 1 with
+// KF_FLAG_TV_SMOOTHER_REFERENCE_PAIRING) -- kf_smoother_lds.hip's pairing, which this replaces for 5 <= m <= 16: T' tile reloaded
+// (prefetched a step ahead), R Q R' rebuilt per step when R or Q is flagged.
+template <int KS, bool TV = false>
+__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((TV && KS == 4) ? 3 : 4))) void kf_smooth_mfma_kernel(
     const KfSmoothArgs A, int32_t* flags) {
   __shared__ __attribute__((aligned(16))) double TR[TILE * TILE];  // transposes / tape staging
   __shared__ __attribute__((aligned(16))) double EX[TILE];         // column -> row re-indexing
@@ -35,19 +38,25 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   const int n = A.T, r_ = A.r, m = A.m, mm = m * m;
   const bool c_ok = c < m;
 
+  const bool tvT = TV && (A.flags & KF_FLAG_TV_T), tvR = TV && (A.flags & KF_FLAG_TV_R), tvQ = TV && (A.flags & KF_FLAG_TV_Q);
+  const int tsh = (TV && (A.flags & KF_FLAG_TV_SMOOTHER_REFERENCE_PAIRING)) ? 1 : 0;
+  const long bN = b * (long)n;   // slice (b, t) of a time-varying array is (bN + t)
   double TA[KS], RQ[KS];
   bool on[KS];
-  int off[KS];
-  {
-    const double* gT = A.Tm + b * (long)mm;
-    const double* gR = A.R + b * (long)m * r_;
-    const double* gQ = A.Q + b * (long)r_ * r_;
+  int off[KS], offT[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 4 * s + g;
+    on[s] = c_ok && k < m;
+    off[s] = k * m + c;
+    offT[s] = c * m + k;
+  }
+  auto load_RQ = [&](int t) {   // R Q R' of slice t (static: t ignored)
+    const double* gR = A.R + (tvR ? bN + t : b) * (long)m * r_;
+    const double* gQ = A.Q + (tvQ ? bN + t : b) * (long)r_ * r_;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int k = 4 * s + g;
-      on[s] = c_ok && k < m;
-      off[s] = k * m + c;
-      TA[s] = on[s] ? gT[c * m + k] : 0.0;  // T' tile: A operand = T, B operand = T'
       double sacc = 0.0;
       if (on[s]) {
         for (int l = 0; l < r_; ++l) {
@@ -58,6 +67,12 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
       }
       RQ[s] = sacc;
     }
+  };
+  {
+    const double* gT = A.Tm + (tvT ? bN : b) * (long)mm;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) TA[s] = on[s] ? gT[offT[s]] : 0.0;  // T' tile: A operand = T, B operand = T'
+    load_RQ(0);
   }
   const double* gfa = A.filt_a + b * (long)n * m;
   const double* gfP = A.filt_P + b * (long)n * mm;
@@ -93,11 +108,17 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
 
   double PS[KS], PN[KS];
   double as_c, an;
+  double TN[KS];   // TV: the T' tile of the step being prefetched
   auto prefetch = [&](int t) {
     const double* rp = gfP + (long)t * mm;
 #pragma unroll
     for (int s = 0; s < KS; ++s) PN[s] = on[s] ? rp[off[s]] : 0.0;
     an = c_ok ? gfa[(long)t * m + c] : 0.0;
+    if (tvT) {
+      const double* tp = A.Tm + (bN + t + tsh) * (long)mm;   // (t <= n - 2: slice t + 1 exists)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) TN[s] = on[s] ? tp[offT[s]] : 0.0;
+    }
   };
   prefetch(n - 1);
 #pragma unroll
@@ -113,6 +134,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
 #pragma unroll
     for (int s = 0; s < KS; ++s) PF[s] = PN[s];
     const double af_c = an;
+    if (tvT) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) TA[s] = TN[s];
+    }
+    if (tvR || tvQ) load_RQ(t + tsh);
     if (t > 0) prefetch(t - 1);
 
     // ---- P_hat = T P_f T' + RQR' ; W = T P_f ----------------------------------------------------------
@@ -230,8 +256,10 @@ int kf_launch_smoother_mfma(kf_handle* h, const KfSmoothArgs& a, void* workspace
   }
   int32_t* flags = reinterpret_cast<int32_t*>((reinterpret_cast<uintptr_t>(workspace) + 63) & ~(uintptr_t)63);
   const int ks = (a.m + 3) / 4;
-#define KF_SM_MFMA(KS_) \
-  hipLaunchKernelGGL((kf_smooth_mfma_kernel<KS_>), dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, flags)
+  const bool tv = (a.flags & (KF_FLAG_TV_T | KF_FLAG_TV_R | KF_FLAG_TV_Q)) != 0;
+#define KF_SM_MFMA(KS_)                                                                                                  \
+  if (tv) hipLaunchKernelGGL((kf_smooth_mfma_kernel<KS_, true>), dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, flags); \
+  else hipLaunchKernelGGL((kf_smooth_mfma_kernel<KS_>), dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, flags)
   switch (ks) {
     case 1: KF_SM_MFMA(1); break;
     case 2: KF_SM_MFMA(2); break;

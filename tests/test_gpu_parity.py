@@ -917,7 +917,7 @@ def test_time_varying_matches_oracle(eng, ft, tv):
 
 
 @pytest.mark.parametrize("tv", [("T",), ("R", "Q"), ("T", "R", "Q")])
-@pytest.mark.parametrize("m", [3, 10, 21])
+@pytest.mark.parametrize("m", [3, 5, 10, 16, 21])
 def test_time_varying_smoother_matches_oracle(eng, tv, m):
     """time-varying T / R / Q in the RTS smoother (kalman_smoother.py:17-54, 62-77): the step that
     smooths t predicts from t with slice t.  Fed with the tapes of the time-varying forward filter."""
@@ -957,10 +957,25 @@ def test_time_varying_smoother_matches_oracle(eng, tv, m):
         s0 = eng.smooth(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
     finally:
         eng.set_forward_kernel("auto")
-    s2 = eng.smooth(const["T"], const["R"], const["Q"], flt["filtered_states"], flt["filtered_covs"],
-                    time_varying=("T", "R", "Q"))
+    import os
+
+    os.environ["KF_SMOOTHER_TV_MFMA"] = "0"   # (round 5: 5 <= m <= 16 would take the register-tile kernel with per-step slices)
+    try:
+        s2 = eng.smooth(const["T"], const["R"], const["Q"], flt["filtered_states"], flt["filtered_covs"],
+                        time_varying=("T", "R", "Q"))
+    finally:
+        del os.environ["KF_SMOOTHER_TV_MFMA"]
     assert np.array_equal(s2[1].cpu().numpy(), s0[1].cpu().numpy())
     assert_allclose(s2[1].cpu().numpy(), s1[1].cpu().numpy(), rtol=1e-8, atol=1e-9)
+    if 5 <= m <= 16:   # ... which reproduces the static register-tile kernel (KF_SMOOTHER_B4=0) bit for bit
+        s3 = eng.smooth(const["T"], const["R"], const["Q"], flt["filtered_states"], flt["filtered_covs"],
+                        time_varying=("T", "R", "Q"))
+        os.environ["KF_SMOOTHER_B4"] = "0"
+        try:
+            s4 = eng.smooth(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
+        finally:
+            del os.environ["KF_SMOOTHER_B4"]
+        assert np.array_equal(s3[0].cpu().numpy(), s4[0].cpu().numpy()) and np.array_equal(s3[1].cpu().numpy(), s4[1].cpu().numpy())
     # the reference-shaped eager class: a per-draw 3-D matrix is a sequence (filters/utilities.py:1-20)
     ks = KalmanSmoother()
     a1, P1 = ks(mats["T"][0], mats["R"][0], mats["Q"][0], ref_f["filtered_states"][0][..., None], ref_f["filtered_covs"][0])
