@@ -279,12 +279,17 @@ for case in range(n_cases):
             for _ in range(int(rng.integers(0, 3))):
                 y[int(rng.choice([0, n - 1, rng.integers(0, n)]))] = np.nan
             predicted = bool(rng.integers(0, 2)) or m <= 96
-            tag = f"bsp m={m} n={n} B={B} dense_rows={n_dense} predicted={predicted} seed={seed}"
+            ft = str(rng.choice(["standard", "cholesky", "single"]))
+            c = 0.05 * rng.standard_normal((B, m)) if rng.integers(0, 2) else None
+            d = 0.1 * rng.standard_normal((B, 1)) if rng.integers(0, 2) else None
+            if rng.integers(0, 3) == 0 and n > 1:   # a series per draw ((B, 1, 1) would read as (n, p, 1))
+                y = y[None] + 0.1 * rng.standard_normal((B,) + y.shape)
+            tag = f"bsp m={m} n={n} B={B} dense_rows={n_dense} predicted={predicted} ft={ft} c={c is not None} d={d is not None} y{y.ndim} seed={seed}"
             if ONLY and ONLY not in tag:
                 continue
             args = (y, w["a0"], w["P0"], T, w["Z"], w["R"], w["H"], w["Q"])
-            orc = kn.kalman_filter(*args, mvn_const="exact")
-            kw = dict(mvn_const="exact", store_filtered=False, store_predicted=predicted)
+            orc = kn.kalman_filter(*args, c=c, d=d, filter_type=ft, mvn_const="exact")
+            kw = dict(c=c, d=d, filter_type=ft, mvn_const="exact", store_filtered=False, store_predicted=predicted)
             got = eng.forward(*args, **kw)
             path = eng.last_forward_kernel()
             counts["bsp_csr" if path == "bsp_step_kernel" else "bsp_mfma"] += 1
@@ -299,6 +304,9 @@ for case in range(n_cases):
             e1 = float(np.max(np.abs(got.logp.cpu().numpy() - orc["logp"]) / scale))
             e3 = float(np.max(np.abs(got.logp.cpu().numpy() - ref.logp.cpu().numpy()) / scale))
             e2 = rel_rows(got.predicted_covs.cpu().numpy(), orc["predicted_covs"]) if predicted else 0.0
+            if predicted:
+                e2 = max(e2, rel_rows(got.predicted_states.cpu().numpy(), orc["predicted_states"]))
+            e2 = max(e2, rel_rows(got.ll_obs.cpu().numpy(), orc["ll_obs"]))
             worst["bsp_logp"] = max(worst["bsp_logp"], e1)
             worst["bsp_tapes"] = max(worst["bsp_tapes"], e2)
             worst["bsp_vs_mfma"] = max(worst["bsp_vs_mfma"], e3)
