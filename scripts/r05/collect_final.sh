@@ -3,7 +3,8 @@
 # profiles/r05/ under fixed names; COMMIT.txt = the commit the leases ran at
 cd "$(dirname "$0")/../.."; F=gpurun_out/r05_final; P=profiles/r05
 for f in headline_pin headline_summary clock_ramp c2_summary c3_summary c4_summary c5_summary tv_lines denseh_lines vg_time \
-         smooth_from_filter_time smooth_from_filter_prof c5_smoother_from_filter c5_smoother_from_filter_kernels c5_sparse_step_counters; do
+         smooth_from_filter_time smooth_from_filter_prof c5_smoother_from_filter c5_smoother_from_filter_kernels c5_sparse_step_counters \
+         c5_value_and_grad_kernels tv_gradient_smoother_time denseh_same_data; do
   [ -f $F/$f.txt ] && cp $F/$f.txt $P/$f.txt
 done
 cp $F/strong_proxy.md $P/strong_proxy.md

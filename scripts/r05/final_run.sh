@@ -46,5 +46,10 @@ bash scripts/r05/smooth_prof.sh > $O/smooth_from_filter_prof.txt 2>&1
 bash scripts/r05/bfbig_run.sh > $O/c5_smoother_from_filter.txt 2>&1
 cp gpurun_out/r05_bfbig/kernels.txt $O/c5_smoother_from_filter_kernels.txt 2>/dev/null
 BSP_PROF_ROWS=8 bash scripts/r05/bsp_prof.sh > $O/c5_sparse_step_counters.txt 2>&1
+bash scripts/r05/c5_vg_prof.sh > $O/c5_value_and_grad_kernels.txt 2>&1
+python3 scripts/r05/tv_grad_time.py 4096 2>&1 | grep -v amdgpu > $O/tv_gradient_smoother_time.txt
+KF_BACKWARD_TV_MFMA=0 KF_SMOOTHER_TV_MFMA=0 python3 scripts/r05/tv_grad_time.py 4096 2>&1 | grep -v amdgpu | sed 's/^/KF_BACKWARD_TV_MFMA=0 KF_SMOOTHER_TV_MFMA=0  /' >> $O/tv_gradient_smoother_time.txt
+python3 scripts/r05/denseh_time.py 2>&1 | grep -v amdgpu > $O/denseh_same_data.txt
+bash scripts/r05/denseh_prof.sh >> $O/denseh_same_data.txt 2>&1
 cat .kf_commit
 find gpurun_out -name "*.csv" -size +1M -delete
