@@ -62,8 +62,10 @@ struct BbPtrs {
 
 // out_j = sum_i Mat[i][j] x_i for one chunk of 64 columns: coalesced reads of a row-major matrix;
 // for a symmetric Mat this is Mat x.  grid (ceil(m/64), B).
+// cmask (or NULL): Mat's block map by columns (kf_big_tmask_cols_launch: word per 64-column block, bit per 32-row chunk) -- rows of
+// all-zero blocks are skipped (they add exact zeros: the same bits; the row order inside a row group is unchanged)
 __global__ __launch_bounds__(NT) void bb_colmatvec_kernel(const double* Mat, long sM, const double* x, long sX,
-                                                          double* out, long sO, int m) {
+                                                          double* out, long sO, int m, const uint32_t* cmask = nullptr) {
   extern __shared__ double sh[];  // x (m) | partial sums RG x CW
   double* xs = sh;
   double* part = sh + m;
@@ -76,7 +78,17 @@ __global__ __launch_bounds__(NT) void bb_colmatvec_kernel(const double* Mat, lon
   double s = 0.0;
   if (j < m) {
     const double* Mb = Mat + b * sM + j;
-    for (int i = rg; i < m; i += RG) s = fma(Mb[(long)i * m], xs[i], s);
+    if (cmask) {
+      unsigned bits = cmask[b * gridDim.x + blockIdx.x];
+      while (bits) {
+        const int kc = __ffs((int)bits) - 1;
+        bits &= bits - 1u;
+        const int iend = min(m, 32 * kc + 32);
+        for (int i = 32 * kc + rg; i < iend; i += RG) s = fma(Mb[(long)i * m], xs[i], s);   // (32 kc + rg = rg mod RG: the same rows, in order)
+      }
+    } else {
+      for (int i = rg; i < m; i += RG) s = fma(Mb[(long)i * m], xs[i], s);
+    }
   }
   part[rg * CW + col] = s;
   __syncthreads();
@@ -286,7 +298,7 @@ inline size_t bb_doubles(long B, int m, int p, int n, int r) {
 }  // namespace
 
 size_t kf_backward_big_workspace_bytes(long B, int m, int p, int n, int r) {
-  return sizeof(double) * bb_doubles(B, m, p, n, r) + sizeof(uint32_t) * (size_t)B * ((m + 63) / 64) + 256;   // (+ the block map of T)
+  return sizeof(double) * bb_doubles(B, m, p, n, r) + 2 * sizeof(uint32_t) * (size_t)B * ((m + 63) / 64) + 320;   // (+ the block maps of T, T')
 }
 
 int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t st) {
@@ -347,34 +359,39 @@ int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, si
   const bool big_full = m >= 128 && !(bge && bge[0] == '0');
   // block map of T by columns (m <= 1024): the two products by T walk only the K chunks whose 32 x 64 block of T holds a non-zero
   // (the skipped ones add exact zeros: bit for bit the same; KF_BIG_TMASK=0: every chunk)
-  uint32_t* tmaskc = nullptr;
-  {
+  uint32_t *tmaskc = nullptr, *tmaskt = nullptr;
+  // m >= 128 (round 5): X1' = T' Pb is formed directly (T' once per call in the buffer X1 used to take; Pb is symmetric), Sb = X1' T,
+  // and the static part of g_T is accumulated TRANSPOSED, Tb' += P_f X1' (P_f symmetric) -- no transpose kernel per step
+  double* TT = X1;
+  if (big_full) {
+    kf_sb_transpose(st, B, a.Tm, mm, TT, mm, m);
     const char* te = kf_env_switch("KF_BIG_TMASK");
-    if (big_full && m <= 1024 && !(te && te[0] == '0')) {
+    if (m <= 1024 && !(te && te[0] == '0')) {
       tmaskc = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(q) + 63) & ~(uintptr_t)63);
+      tmaskt = tmaskc + B * (size_t)((m + 63) / 64);
       if (kf_big_tmask_cols_launch(st, a.Tm, m, B, tmaskc) != KF_OK) tmaskc = nullptr;
+      if (kf_big_tmask_launch(st, TT, m, B, tmaskt) != KF_OK) tmaskt = nullptr;
     }
   }
   for (int t = n - 1; t >= 0; --t) {
     // ab_f = T' ab'
     hipLaunchKernelGGL(bb_colmatvec_kernel, dim3(cc, (unsigned)B), dim3(NT), sh_mv, st, a.Tm, mm, W.abp, (long)m,
-                       W.abfA, (long)m, m);
+                       W.abfA, (long)m, m, (const uint32_t*)tmaskc);
     for (int qq = 0; qq < p; ++qq) {
       // M_q = P^q z_q  (P symmetric), then the rank-one update
       const double* src = (qq == 0) ? a.pred_P + (long)t * mm : W.Pc;
       hipLaunchKernelGGL(bb_colmatvec_kernel, dim3(cc, (unsigned)B), dim3(NT), sh_mv, st, src, (qq == 0) ? sTape : mm,
-                         a.Z + (long)qq * m, (long)p * m, W.MQ + (long)qq * m, (long)p * m, m);
+                         a.Z + (long)qq * m, (long)p * m, W.MQ + (long)qq * m, (long)p * m, m, (const uint32_t*)nullptr);
       hipLaunchKernelGGL(bb_fwd_update_kernel, dim3(rc, (unsigned)B), dim3(NT), sh_f, st, a, W, t, qq);
     }
     // X1 = Pb T ; Sb = X1' T ; Tb_m += X1 P_f
     // (m >= 128: on kf_forward_big.hip's 128 x 64-tile product, 270 against 335 us per launch at C5; KF_SMOOTHER_BIG_GEMM=0: this file's)
     if (big_full) {
-      kf_big_gemm_launch_x(st, false, false, W.PB, mm, a.Tm, mm, nullptr, 0, X1, mm, m, B, tmaskc, /*on_b=*/1, 0, nullptr, nullptr, nullptr,
+      kf_big_gemm_launch_x(st, false, false, TT, mm, W.PB, mm, nullptr, 0, X1t, mm, m, B, tmaskt, /*on_b=*/0, 0, nullptr, nullptr, nullptr,
                            nullptr, false);
-      kf_sb_transpose(st, B, X1, mm, X1t, mm, m);
       kf_big_gemm_launch_x(st, false, false, X1t, mm, a.Tm, mm, nullptr, 0, W.SB, mm, m, B, tmaskc, /*on_b=*/1, 0, nullptr, nullptr, nullptr,
                            nullptr, false);
-      kf_big_gemm_launch(st, false, true, false, X1, mm, W.Pc, mm, TBm, mm, TBm, mm, m, B);
+      kf_big_gemm_launch(st, false, true, false, W.Pc, mm, X1t, mm, TBm, mm, TBm, mm, m, B);   // (Tb' += P_f X1')
     } else {
       kf_sb_gemm(st, B, false, 0, W.PB, mm, m, a.Tm, mm, m, nullptr, 0, 0, X1, mm, m, m, m, m);
       kf_sb_transpose(st, B, X1, mm, X1t, mm, m);
@@ -386,7 +403,7 @@ int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, si
     for (int qq = p - 1; qq >= 0; --qq) {
       // s = Sb M_q, then the rank-one adjoint; the adjoint of a^0 is the ab' of the next step
       hipLaunchKernelGGL(bb_colmatvec_kernel, dim3(cc, (unsigned)B), dim3(NT), sh_mv, st, W.SB, mm,
-                         W.MQ + (long)qq * m, (long)p * m, W.SV, (long)m, m);
+                         W.MQ + (long)qq * m, (long)p * m, W.SV, (long)m, m, (const uint32_t*)nullptr);
       double* aout = (qq == 0) ? W.abp : aother;
       hipLaunchKernelGGL(bb_adj_update_kernel, dim3(cc, (unsigned)B), dim3(NT), sh_a, st, a, W, t, qq, ain, aout);
       aother = ain;
@@ -398,8 +415,13 @@ int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, si
   }
   // g_T = 2 Tb_m + sum_t ab'_t a_f,t'
   if (a.g_T) {
-    hipLaunchKernelGGL(bb_scale_kernel, dim3((unsigned)((B * mm + 255) / 256)), dim3(256), 0, st, TBm, B * mm, 2.0);
-    kf_sb_gemm(st, B, false, 1, W.AbT, (long)m * n, n, W.Af, (long)n * m, m, TBm, mm, m, a.g_T, mm, m, m, m, n);
+    double* Tb = TBm;
+    if (big_full) {   // (accumulated transposed)
+      kf_sb_transpose(st, B, TBm, mm, X1t, mm, m);
+      Tb = X1t;
+    }
+    hipLaunchKernelGGL(bb_scale_kernel, dim3((unsigned)((B * mm + 255) / 256)), dim3(256), 0, st, Tb, B * mm, 2.0);
+    kf_sb_gemm(st, B, false, 1, W.AbT, (long)m * n, n, W.Af, (long)n * m, m, Tb, mm, m, a.g_T, mm, m, m, m, n);
   }
   hipLaunchKernelGGL(bb_finish_kernel, dim3((unsigned)B), dim3(256), 0, st, a, W);
   KF_HIP_CHECK(h, hipGetLastError());
