@@ -1250,7 +1250,11 @@ extern "C" int kf_smoother(kf_handle* h, const kf_dims* dims, const double* T, c
     // m = 12 between 3072 and 8192 draws
     const char* e = kf_env_switch("KF_SMOOTHER_B4");
     const long wave3 = 3L * 4 * (h->n_cu > 0 ? h->n_cu : 256);
-    const bool pick = (e && e[0]) ? e[0] != '0' : (a.m != 12 || a.B <= wave3 || a.B >= 8192);
+    // round 5 (scripts/r05/smooth_dispatch_rn.py, profiles/r05/smoother_dispatch_rank.txt): with rank-one state noise from m = 6 on,
+    // and with rank-two noise on short series (m >= 8, <= 512 steps), the warm-started iteration needs more steps than the
+    // elimination costs (4096 draws x 300 steps, m = 8, r = 2: 2.3 against 1.6 ms; r = 1: 14.4 against 11.3)
+    const bool low_rank = (a.r == 1 && a.m >= 6) || (a.r == 2 && a.m >= 8 && a.T <= 512);
+    const bool pick = (e && e[0]) ? e[0] != '0' : ((a.m != 12 || a.B <= wave3 || a.B >= 8192) && !low_rank);
     if (pick) return kf_launch_smoother_b4(h, a, workspace, workspace_bytes, (hipStream_t)stream);
   }
   // 5 <= m <= 16: register-tile smoother when the caller provided the (tiny) flag workspace
