@@ -355,20 +355,30 @@ def perform_smoother_batched(T, R, Q, filtered_states, filtered_covs, engine=Non
     return [sa.cpu().numpy()[..., None], sP.cpu().numpy()]
 
 
-def smoother_from_filter_applies(p, m, ndims):
+def smoother_from_filter_applies(p, m, ndims, r=None):
     """Should the smoothed moments come from the filter's predicted tapes (kf_smoother_from_filter)?  p == 1, every system
     matrix static (``ndims``: the per-draw ranks of T, Z, H, R, Q) and 5 <= m <= 15 (the on-chip kernel) or 64 < m <= 1024 (both
     recursions run on the HBM workspace there and the one from the predicted tapes has no factorisation: C5, 128 draws, m = 367:
     1.09 against 2.97 ms per step).  The entry point takes every m <= 1024, but at m <= 4 the lane-per-draw RTS kernel is the
-    faster one (C2, 4096 x 1000, m = 2: 0.76 against 0.99 ms) and at 16 <= m <= 64 so are the on-chip RTS kernels."""
-    return p == 1 and (5 <= m <= 15 or 64 < m <= 1024) and all(nd == 2 for nd in ndims)
+    faster one (C2, 4096 x 1000, m = 2: 0.76 against 0.99 ms) and at 16 <= m <= 64 so are the on-chip RTS kernels -- UNLESS the
+    state noise has few columns (``r``, the width of R: every ARMA / SARIMA model has r = 1): then the prediction covariance sits on
+    the pseudo-inverse's cut-off, the RTS kernels hand most draws to the pinv kernel and take seconds (1024 draws x 300 steps,
+    r = 1: m = 20 / 32 / 48 / 64: 0.19 / 2.0 / 7.3 / 37.7 s) where the recursion from the predicted tapes, which inverts nothing,
+    takes 34 / 43 / 58 / 75 ms on the workspace; measured bad up to r = 2 / 3 / 4 at m = 20 / 32 / 48
+    (profiles/r05/smoother_mid_m_rank.txt): taken for 12 r <= m + 11."""
+    if p != 1 or not all(nd == 2 for nd in ndims):
+        return False
+    if 5 <= m <= 15 or 64 < m <= 1024:
+        return True
+    return 16 <= m <= 64 and r is not None and 12 * r <= m + 11
 
 
 def perform_smoother_fused(data, T, Z, R, H, Q, d, filtered_states, filtered_covs, predicted_states, predicted_covs,
                            filter_type="standard", engine=None, batched=False):
     """The smoother behind THIS library's filter node (``kalman_smoother_graph`` finds it: the reference never smooths anything
     but its own filter's outputs, core/statespace.py:164-197).  All of the filter's tapes are at hand, so the numeric body picks
-    the cheaper recursion: for p == 1, 5 <= m <= 15 or 64 < m <= 1024, and static matrices ``kf_smoother_from_filter`` on the PREDICTED tapes (no
+    the cheaper recursion: for p == 1, static matrices and 5 <= m <= 15, 64 < m <= 1024 or (16 <= m <= 64 with state noise of few
+    columns: ``smoother_from_filter_applies``) ``kf_smoother_from_filter`` on the PREDICTED tapes (no
     pinv(P_hat): include/kf.h), otherwise ``kf_smoother`` on the filtered ones (kalman_smoother.py:56-104 as it stands).
     Shapes: the per-draw reference layouts, or with ONE leading draw axis on everything but a shared data when ``batched``."""
     eng = engine or get_engine()
@@ -376,7 +386,7 @@ def perform_smoother_fused(data, T, Z, R, H, Q, d, filtered_states, filtered_cov
     Ta, Za, Ha = (np.asarray(x, dtype=np.float64) for x in (T, Z, H))
     p, m = Za.shape[-2], Ta.shape[-1]
     nds = [np.asarray(x).ndim - lead for x in (T, Z, H, R, Q)]
-    if not smoother_from_filter_applies(p, m, nds):
+    if not smoother_from_filter_applies(p, m, nds, r=np.asarray(R).shape[-1]):
         return (perform_smoother_batched if batched else perform_smoother)(T, R, Q, filtered_states, filtered_covs, engine=eng)
     y = np.asarray(data, dtype=np.float64)
     if y.ndim == 3 + lead or (batched and y.ndim == 3):  # (n,p,1) [shared] or (B,n,p,1)

@@ -346,6 +346,27 @@ def test_vectorized_smoother_nodes_one_c_abi_call_each(nile, monkeypatch):
     assert_allclose(sa10[..., 0], r10a.reshape(B, 60, 10), rtol=1e-9, atol=1e-9)
     assert_allclose(sP10, r10P, rtol=1e-9, atol=1e-9)
 
+    # (a3) 16 <= m <= 64 with rank-one state noise (every ARMA / SARIMA model): the RTS recursion would hand most draws to the pinv
+    # kernel (seconds); the node takes the recursion from the predicted tapes (workspace path).  Against its pinned restatement.
+    for k in n_calls:
+        n_calls[k] = 0
+    B3 = 5
+    w3 = W.random_dense(B3, 30, 1, 20, 1, seed=9)
+    v3 = [w3["y"][..., None], w3["a0"][0][:, None], w3["P0"][0], w3["T"][0], w3["Z"][0], w3["R"][0]]
+    sa20, sP20 = f(*v3, w3["H"], w3["Q"])
+    assert n_calls == {"fwd": 1, "rts": 0, "sff": 1}, n_calls
+    rep3 = lambda x: np.repeat(np.asarray(x)[None], B3, 0)  # noqa: E731
+    f20 = kn.kalman_filter(w3["y"], rep3(w3["a0"][0]), rep3(v3[2]), rep3(v3[3]), rep3(v3[4]), rep3(v3[5]), w3["H"], w3["Q"])
+    r20a, r20P = kn.smoother_from_filter(w3["y"], rep3(v3[3]), rep3(v3[4]), w3["H"], f20["predicted_states"], f20["predicted_covs"])
+    assert_allclose(sa20[..., 0], r20a.reshape(B3, 30, 20), rtol=1e-8, atol=1e-9)
+    assert_allclose(sP20, r20P, rtol=1e-8, atol=1e-9)
+    # ... and full-rank noise of the same size stays on the on-chip RTS kernels
+    for k in n_calls:
+        n_calls[k] = 0
+    w4 = W.random_dense(B3, 30, 1, 20, 20, seed=10)
+    f(w4["y"][..., None], w4["a0"][0][:, None], w4["P0"][0], w4["T"][0], w4["Z"][0], w4["R"][0], w4["H"], w4["Q"])
+    assert n_calls == {"fwd": 1, "rts": 1, "sff": 0}, n_calls
+
     # (b) free filtered tapes
     for k in n_calls:
         n_calls[k] = 0
