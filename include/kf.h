@@ -284,7 +284,8 @@ int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims,
  * kernels) g_H carries the diagonal only (off-diagonal entries 0) and g_P0 the symmetric part
  * of the entrywise gradient -- all a diagonal-H / symmetric-P0 parameterisation can see.
  * Time-varying matrices (KF_FLAG_TV_*): the gradient of a flagged matrix has that matrix's shape, [B][T][rows][cols]
- * (slice t = the partial w.r.t. the slice step t used); unflagged ones stay per draw.  Served by the LDS-resident adjoint
+ * (slice t = the partial w.r.t. the slice step t used); unflagged ones stay per draw.  T / Z / H / c / d flagged (R, Q static),
+ * m <= 16, scalar observations: the accumulator-layout adjoint with per-step slices (round 5); else the LDS-resident adjoint
  * (KF_ERR_UNSUPPORTED when m, p do not fit 160 KiB). */
 int kf_filter_backward(kf_handle* h, const kf_dims* dims,
                        const double* y, const double* a0, const double* P0,
@@ -304,7 +305,12 @@ int kf_filter_backward(kf_handle* h, const kf_dims* dims,
  * from the previous step's inverse (kf_smoother_b4.hip) -- whenever that covariance is safely
  * positive definite, a Jacobi eigen-decomposition otherwise (m <= 64: given the per-draw flag
  * workspace -- without it the 47 < m <= 64 kernel returns NaN for such a draw; m > 64: flagged draws
- * are redone, the whole series, by one workgroup each).  `workspace`: see kf_workspace_bytes. */
+ * are redone, the whole series, by one workgroup each).  `workspace`: see kf_workspace_bytes.
+ * Cost of that semantics: with state noise of few columns (r = 1: every ARMA / SARIMA model) the prediction covariance sits on the
+ * cut-off and most draws take the eigen-decomposition at every step -- 4096 x 1000, m = 10: 62 ms against 4 ms with full-rank
+ * noise; 1024 x 300, m = 32 / 64: 2 s / 38 s (profiles/r05/smoother_dispatch_rank.txt, smoother_mid_m_rank.txt).  A caller that has
+ * the filter's predicted tapes should use kf_smoother_from_filter below: no inverse, the same cost whatever the rank.
+ * Time-varying T / R / Q with 5 <= m <= 16 run on the register-tile elimination kernel with per-step slices (round 5). */
 int kf_smoother(kf_handle* h, const kf_dims* dims,
                 const double* T, const double* R, const double* Q,
                 const double* filt_a, const double* filt_P,
