@@ -59,9 +59,14 @@ for case in range(n_cases):
             n = int(rng.choice([1, 2, 31, 32, 33, 64, 65, 100, 200, 320]))
             B = int(rng.choice([1, 3, 20, 70]))
             m = int(rng.integers(1, 16))
+            big_m = os.environ.get("FUZZ_SFF_BIG") == "1" and rng.integers(0, 2) == 0   # the HBM-workspace path (15 < m <= 1024)
+            if big_m:
+                m = int(rng.choice([16, 17, 31, 40, 64, 65, 97, 130]))
+                n = min(n, 65)
+                B = min(B, 20)
             r = int(rng.integers(1, m + 1))
             ft = str(rng.choice(["standard", "cholesky", "univariate", "single"]))
-            struct = rng.integers(0, 3) == 0 and n >= 31
+            struct = rng.integers(0, 3) == 0 and n >= 31 and not big_m
             w = W.structural(B=B, n=n, seed=seed) if struct else W.random_dense(B, n, 1, m, r, seed=seed)
             m = w["m"]
             if struct and rng.integers(0, 2) == 0:
