@@ -1010,15 +1010,7 @@ constexpr int BSP_TH = 32;
 constexpr int BSP_ND = 4;
 constexpr int BSP_CAPF = 4;   // CSR capacity: BSP_CAPF * m entries per draw
 
-struct BspCsr {
-  int* rowptr;   // [B][m + 1]
-  int* col;      // [B][cap]
-  double* val;   // [B][cap]
-  int* drow;     // [B][BSP_ND]
-  int* nd;       // [B]
-  int* ok;       // [1]
-  int cap;
-};
+using BspCsr = KfBspCsr;   // (kf_internal.h: kf_smoother_bf_big.hip builds one of T' too)
 
 __global__ __launch_bounds__(256) void bsp_csr_kernel(const double* __restrict__ T, int m, BspCsr c) {
   __shared__ int cnt[BIG_PFIX_M + 1];
@@ -1054,6 +1046,7 @@ __global__ __launch_bounds__(256) void bsp_csr_kernel(const double* __restrict__
     c.nd[b] = nd <= BSP_ND ? nd : BSP_ND;
     s_fits = fits;
     if (!fits) atomicAnd(c.ok, 0);
+    atomicMax(c.ok + 1, nd <= BSP_ND ? nd : BSP_ND);
   }
   __syncthreads();
   for (int e = tid; e <= m; e += 256) c.rowptr[b * (m + 1) + e] = cnt[e];
@@ -1505,6 +1498,160 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
   }
 }
 
+
+// out = A X A' + u1 v1' + u2 v2' for a CSR A without dense rows (kf_smoother_bf_big.hip: M_{t-1} = T' M_t T + rank-one terms): the two
+// stages of bsp_step_kernel without its per-step vectors -- stage 1  w_i = sum_k A[i,k] X[k,:] into LDS, stage 2  out[i,j] = sum_l w_i[l] A[j,l]
+template <int R>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void bsp_sandwich_kernel(const BspCsr c, const double* __restrict__ X,
+                                                                                                 double* __restrict__ out, int m, long B,
+                                                                                                 const double* __restrict__ u1,
+                                                                                                 const double* __restrict__ v1,
+                                                                                                 const double* __restrict__ u2,
+                                                                                                 const double* __restrict__ v2, int nblk) {
+  extern __shared__ double sm[];
+  constexpr int RW = R / 4;
+  constexpr int NE = 2;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const long L = blockIdx.x;
+  const long b = (L & 7) + 8 * (L / (8L * nblk));
+  if (b >= B) return;
+  const int i0 = (int)((L >> 3) % nblk) * R;
+  const long mm = (long)m * m;
+  double* w = sm;                  // [R][m]
+  double* ru = w + (long)R * m;    // [2][R]  u1, u2 of the block's rows
+  const double* Xb = X + b * mm;
+  const int* rp = c.rowptr + b * (m + 1);
+  const int* col = c.col + b * (long)c.cap;
+  const double* val = c.val + b * (long)c.cap;
+  const int q0 = wave * RW;
+  const int rp_mine = rp[min(i0 + q0 + min(lane, RW), m)];
+  int s2_eb[2] = {0, 0}, s2_ee[2] = {0, 0};
+  double v1j[2] = {0.0, 0.0}, v2j[2] = {0.0, 0.0};
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (tid + 256 * h < m) {
+      s2_eb[h] = rp[tid + 256 * h];
+      s2_ee[h] = rp[tid + 256 * h + 1];
+      v1j[h] = u1 ? v1[b * m + tid + 256 * h] : 0.0;
+      v2j[h] = u2 ? v2[b * m + tid + 256 * h] : 0.0;
+    }
+  if (tid < 2 * R) {
+    const int r = tid % R, which = tid / R;
+    const double* u = which ? u2 : u1;
+    ru[tid] = (u && i0 + r < m) ? u[b * m + i0 + r] : 0.0;
+  }
+  int s2_c0[2] = {0, 0}, s2_c1[2] = {0, 0};
+  double s2_v0[2] = {0.0, 0.0}, s2_v1[2] = {0.0, 0.0};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (s2_eb[h] < s2_ee[h]) {
+      s2_c0[h] = col[s2_eb[h]];
+      s2_v0[h] = val[s2_eb[h]];
+    }
+    if (s2_eb[h] + 1 < s2_ee[h]) {
+      s2_c1[h] = col[s2_eb[h] + 1];
+      s2_v1[h] = val[s2_eb[h] + 1];
+    }
+  }
+  // ---- stage 1 (rows written by this wave only; the barrier below orders them before stage 2)
+  {
+    int rpw[RW + 1];
+#pragma unroll
+    for (int q = 0; q <= RW; ++q) rpw[q] = __builtin_amdgcn_readlane(rp_mine, q);
+    const int e_beg = rpw[0], e_end = rpw[RW];
+    int prev_row = -1;
+    for (int chunk = e_beg; chunk < e_end; chunk += 64) {
+      const int me = chunk + lane;
+      const bool have = me < e_end;
+      const int ck = have ? col[me] : 0;
+      const double cv = have ? val[me] : 0.0;
+      int cr = 0;
+#pragma unroll
+      for (int q = 1; q < RW; ++q) cr += (me >= rpw[q]) ? 1 : 0;
+      const int nloc = min(64, e_end - chunk);
+      for (int e = 0; e < nloc; e += NE) {
+        int kq[NE], rq[NE];
+        double tq[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+          const int src = min(e + u, nloc - 1);
+          kq[u] = __builtin_amdgcn_readlane(ck, src);
+          rq[u] = q0 + __builtin_amdgcn_readlane(cr, src);
+          tq[u] = bsp_readlane_f64(cv, src);
+        }
+        for (int cg = 0; cg < m; cg += 64 * BSP_CG) {
+          double pv[NE][BSP_CG];
+#pragma unroll
+          for (int u = 0; u < NE; ++u)
+#pragma unroll
+            for (int g = 0; g < BSP_CG; ++g) {
+              const int l = cg + lane + 64 * g;
+              pv[u][g] = (l < m && e + u < nloc) ? Xb[(long)kq[u] * m + l] : 0.0;
+            }
+#pragma unroll
+          for (int u = 0; u < NE; ++u) {
+            if (e + u < nloc) {
+              const bool first = rq[u] != (u == 0 ? prev_row : rq[u - 1]);
+#pragma unroll
+              for (int g = 0; g < BSP_CG; ++g) {
+                const int l = cg + lane + 64 * g;
+                if (l < m) w[(long)rq[u] * m + l] = first ? tq[u] * pv[u][g] : fma(tq[u], pv[u][g], w[(long)rq[u] * m + l]);
+              }
+            }
+          }
+        }
+        prev_row = rq[min(NE, nloc - e) - 1];
+      }
+    }
+    for (int q = 0; q < RW; ++q)   // empty rows
+      if (rpw[q] == rpw[q + 1])
+        for (int l = lane; l < m; l += 64) w[(long)(q0 + q) * m + l] = 0.0;
+  }
+  __syncthreads();
+  // ---- stage 2
+  double* ob = out + b * mm;
+  for (int cb = 0; cb < m; cb += 256) {
+    const int j = cb + tid;
+    if (j >= m) break;
+    int eb, ee, c0_, c1_;
+    double v0_, v1_, a1, a2;
+    if (cb == 0) {
+      eb = s2_eb[0]; ee = s2_ee[0]; c0_ = s2_c0[0]; c1_ = s2_c1[0]; v0_ = s2_v0[0]; v1_ = s2_v1[0]; a1 = v1j[0]; a2 = v2j[0];
+    } else if (cb == 256) {
+      eb = s2_eb[1]; ee = s2_ee[1]; c0_ = s2_c0[1]; c1_ = s2_c1[1]; v0_ = s2_v0[1]; v1_ = s2_v1[1]; a1 = v1j[1]; a2 = v2j[1];
+    } else {
+      eb = rp[j];
+      ee = rp[j + 1];
+      c0_ = eb < ee ? col[eb] : 0;
+      v0_ = eb < ee ? val[eb] : 0.0;
+      c1_ = eb + 1 < ee ? col[eb + 1] : 0;
+      v1_ = eb + 1 < ee ? val[eb + 1] : 0.0;
+      a1 = u1 ? v1[b * m + j] : 0.0;
+      a2 = u2 ? v2[b * m + j] : 0.0;
+    }
+    double s[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) s[r] = 0.0;
+    if (eb < ee) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) s[r] = fma(w[(long)r * m + c0_], v0_, s[r]);
+    }
+    if (eb + 1 < ee) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) s[r] = fma(w[(long)r * m + c1_], v1_, s[r]);
+    }
+    for (int e = eb + 2; e < ee; ++e) {
+      const int l = col[e];
+      const double tv = val[e];
+#pragma unroll
+      for (int r = 0; r < R; ++r) s[r] = fma(w[(long)r * m + l], tv, s[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (i0 + r < m) ob[(long)(i0 + r) * m + j] = fma(ru[r], a1, fma(ru[R + r], a2, s[r]));
+  }
+}
+
 }  // namespace
 
 // The m x m x m product of this file for other callers (kf_smoother_big.hip): C = A op(B) (+ E) per draw, leading dimension m,
@@ -1569,6 +1716,43 @@ int kf_big_tmask_launch(hipStream_t st, const double* T, int m, long B, uint32_t
 
 int kf_big_tmask_cols_launch(hipStream_t st, const double* T, int m, long B, uint32_t* tmask) {
   hipLaunchKernelGGL(big_tmask_cols_kernel, dim3((unsigned)((m + 63) / 64), (unsigned)B), dim3(256), 0, st, T, m, tmask);
+  return hipGetLastError() == hipSuccess ? KF_OK : KF_ERR_HIP;
+}
+
+size_t kf_bsp_csr_bytes(long B, int m) {
+  const size_t cap = (size_t)BSP_CAPF * m;
+  return (size_t)B * (8 * cap + 4 * ((size_t)m + 1 + cap + BSP_ND + 1)) + 8 + 256;
+}
+
+int kf_bsp_csr_build(hipStream_t st, const double* Tm, int m, long B, void* mem, KfBspCsr* c) {
+  if (m > BIG_PFIX_M) return KF_ERR_UNSUPPORTED;
+  c->cap = BSP_CAPF * m;
+  double* q = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(mem) + 63) & ~(uintptr_t)63);
+  c->val = q;
+  int* qi = reinterpret_cast<int*>(q + B * (size_t)c->cap);
+  c->rowptr = qi;  qi += B * (size_t)(m + 1);
+  c->col = qi;     qi += B * (size_t)c->cap;
+  c->drow = qi;    qi += B * (size_t)BSP_ND;
+  c->nd = qi;      qi += B;
+  c->ok = qi;
+  if (hipMemsetAsync(c->ok, 1, sizeof(int), st) != hipSuccess || hipMemsetAsync(c->ok + 1, 0, sizeof(int), st) != hipSuccess) return KF_ERR_HIP;
+  hipLaunchKernelGGL(bsp_csr_kernel, dim3((unsigned)B), dim3(256), 0, st, Tm, m, *c);
+  return hipGetLastError() == hipSuccess ? KF_OK : KF_ERR_HIP;
+}
+
+int kf_bsp_sandwich_launch(hipStream_t st, const KfBspCsr& c, const double* X, double* out, int m, long B, const double* u1,
+                           const double* v1, const double* u2, const double* v2) {
+  auto lds_of = [&](int rows) { return sizeof(double) * ((size_t)rows * m + 2 * (size_t)rows); };
+  const int R = lds_of(8) <= KF_LDS_BYTES_MAX / 2 ? 8 : 4;
+  const size_t lds = lds_of(R);
+  const void* fn = R == 8 ? reinterpret_cast<const void*>(bsp_sandwich_kernel<8>) : reinterpret_cast<const void*>(bsp_sandwich_kernel<4>);
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return KF_ERR_HIP;
+  const int nblk = (m + R - 1) / R;
+  const unsigned grid = (unsigned)(8L * nblk * ((B + 7) / 8));
+  if (R == 8)
+    hipLaunchKernelGGL(bsp_sandwich_kernel<8>, dim3(grid), dim3(256), lds, st, c, X, out, m, B, u1, v1, u2, v2, nblk);
+  else
+    hipLaunchKernelGGL(bsp_sandwich_kernel<4>, dim3(grid), dim3(256), lds, st, c, X, out, m, B, u1, v1, u2, v2, nblk);
   return hipGetLastError() == hipSuccess ? KF_OK : KF_ERR_HIP;
 }
 
@@ -1676,6 +1860,7 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
       csr.nd = qi;                                 qi += a.B;
       csr.ok = qi;
       KF_HIP_CHECK(h, hipMemsetAsync(csr.ok, 1, sizeof(int), stream));   // (any non-zero value)
+      KF_HIP_CHECK(h, hipMemsetAsync(csr.ok + 1, 0, sizeof(int), stream));   // (the largest number of dense rows: unused here)
       hipLaunchKernelGGL(bsp_csr_kernel, dim3((unsigned)a.B), dim3(256), 0, stream, a.Tm, m, csr);
       int fits = 0;
       KF_HIP_CHECK(h, hipMemcpyAsync(&fits, csr.ok, sizeof(int), hipMemcpyDeviceToHost, stream));

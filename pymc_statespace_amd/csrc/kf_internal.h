@@ -338,6 +338,23 @@ int kf_big_gemm_launch_x(hipStream_t st, bool trans_b, bool add_e, const double*
                          long sE, double* C, long sC, int m, long draws, const uint32_t* tmask, int tmask_on_b, int neg_acc,
                          const double* u1, const double* v1, const double* u2, const double* v2, bool upper_mirror);
 int kf_big_tmask_launch(hipStream_t st, const double* T, int m, long B, uint32_t* tmask);
+// CSR copy of a batch of per-draw m x m matrices (kf_forward_big.hip, round 5): at most cap = 4 m entries per draw; rows with more than 32
+// non-zeros are kept out of it as "dense rows" (drow, at most 4 per draw).  ok[0] stays non-zero while every draw fits, ok[1] = the
+// largest number of dense rows of a draw (both on the device: read them back before trusting the arrays).
+struct KfBspCsr {
+  int* rowptr;   // [B][m + 1]
+  int* col;      // [B][cap]
+  double* val;   // [B][cap]
+  int* drow;     // [B][4]
+  int* nd;       // [B]
+  int* ok;       // [2]
+  int cap;
+};
+size_t kf_bsp_csr_bytes(long B, int m);
+int kf_bsp_csr_build(hipStream_t st, const double* Tm, int m, long B, void* mem, KfBspCsr* c);   // carves `mem`, enqueues the build
+// out = A X A' + u1 v1' + u2 v2' per draw: A = the CSR matrices (NO dense rows: ok[1] == 0), X dense [B][m][m], out another buffer
+int kf_bsp_sandwich_launch(hipStream_t st, const KfBspCsr& c, const double* X, double* out, int m, long B, const double* u1,
+                           const double* v1, const double* u2, const double* v2);
 // block map of T by columns (word per 64-column block, bit per 32-row chunk): for A T with T the untransposed B operand, tmask_on_b = 1
 int kf_big_tmask_cols_launch(hipStream_t st, const double* T, int m, long B, uint32_t* tmask);
 int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,

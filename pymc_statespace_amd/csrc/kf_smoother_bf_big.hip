@@ -165,7 +165,7 @@ __global__ __launch_bounds__(BB_T) void bbb_gemv_kernel(const double* __restrict
 
 // per draw, behind w = M kappa, twv = T' w, trv = T' r~:  x2k = X2 kappa = T' w - (Z T)' (w . kappa)  (negated: the rank-one factor of the
 // last product),  r~_{t-1} = T' r~ - (Z T)' (kappa . r~) + (Z T)' v / F
-__global__ __launch_bounds__(BB_T) void bbb_vec_kernel(int m, const double* __restrict__ ZT, const BbbVec V) {
+__global__ __launch_bounds__(BB_T) void bbb_vec_kernel(int m, const double* __restrict__ ZT, const BbbVec V, int fold_u2) {
   __shared__ double red[4];
   const long b = blockIdx.x;
   double wk = 0.0, kr = 0.0;
@@ -179,7 +179,8 @@ __global__ __launch_bounds__(BB_T) void bbb_vec_kernel(int m, const double* __re
   const double vr = V.v[b] * V.rF[b];
   for (int j = threadIdx.x; j < m; j += BB_T) {
     const double zt = ZT[b * (long)m + j];
-    V.x2k[b * (long)m + j] = -(V.twv[b * (long)m + j] - zt * wk);
+    // (fold_u2: the CSR form adds both rank-one terms with (Z T)' as their right factor at once)
+    V.x2k[b * (long)m + j] = -(V.twv[b * (long)m + j] - zt * wk) + (fold_u2 ? V.u2[b * (long)m + j] : 0.0);
     V.rn[b * (long)m + j] = V.trv[b * (long)m + j] + zt * (vr - kr);
   }
 }
@@ -193,7 +194,7 @@ bool kf_smoother_bf_big_ok(int m, int p, unsigned flags) { return p == 1 && m > 
 size_t kf_smoother_bf_big_workspace_bytes(long B, int m) {
   const size_t mm = (size_t)m * m;
   return 5 * bb_round(8 * (size_t)B * mm) + 12 * bb_round(8 * (size_t)B * m) + 3 * bb_round(8 * (size_t)B) +
-         bb_round(4 * (size_t)B * ((m + 63) / 64)) + 512;
+         bb_round(4 * (size_t)B * ((m + 63) / 64)) + bb_round(kf_bsp_csr_bytes(B, m)) + 512;
 }
 
 int kf_launch_smoother_bf_big(kf_handle* h, const KfSmoothBfArgs& a, void* workspace, size_t workspace_bytes, hipStream_t st) {
@@ -239,6 +240,23 @@ int kf_launch_smoother_bf_big(kf_handle* h, const KfSmoothBfArgs& a, void* works
     const char* te = kf_env_switch("KF_BIG_TMASK");
     if (te && te[0] == '0') mask = nullptr;
   }
+  // T' with a few non-zeros per row and no dense row (the seasonal / trigonometric / companion-by-rows models): M_{t-1} = T' M_t T + rank-one
+  // terms as a CSR gather (kf_bsp_sandwich_launch) instead of the two block-sparse products.  As in kf_launch_forward_big the verdict is
+  // read back once per call (4 + 4 bytes, one stream synchronisation; not while the stream is being captured; KF_BIG_SPARSE=0: never)
+  KfBspCsr csr;
+  bool sparse = false;
+  {
+    void* cmem = take(kf_bsp_csr_bytes(B, m));
+    const char* se = kf_env_switch("KF_BIG_SPARSE");
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap_status);
+    if (!(se && se[0] == '0') && cap_status == hipStreamCaptureStatusNone && kf_bsp_csr_build(st, TT, m, B, cmem, &csr) == KF_OK) {
+      int verdict[2] = {0, 1};
+      KF_HIP_CHECK(h, hipMemcpyAsync(verdict, csr.ok, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+      KF_HIP_CHECK(h, hipStreamSynchronize(st));
+      sparse = verdict[0] != 0 && verdict[1] == 0;
+    }
+  }
   const unsigned rgrid = (unsigned)((m + 7) / 8);
   const long sTapeS = (long)n * mm;   // stride of the smoothed covariance tape per draw
   for (int t = n - 1; t >= 0; --t) {
@@ -252,15 +270,26 @@ int kf_launch_smoother_bf_big(kf_handle* h, const KfSmoothBfArgs& a, void* works
     if (rc) return rc;
     // w = M_t kappa ;  X2 = T' M_t - (Z T)' w'
     hipLaunchKernelGGL(bbb_gemv_kernel, dim3(rgrid, (unsigned)B), dim3(BB_T), 0, st, M, (const uint32_t*)nullptr, mask_rb, V.kap, V.w, m);
-    rc = kf_big_gemm_launch_x(st, false, false, TT, mm, M, mm, nullptr, 0, X2, mm, m, B, mask, /*on_b=*/0, 0, V.negZT, V.w, nullptr, nullptr, false);
-    if (rc) return rc;
+    if (!sparse) {
+      rc = kf_big_gemm_launch_x(st, false, false, TT, mm, M, mm, nullptr, 0, X2, mm, m, B, mask, /*on_b=*/0, 0, V.negZT, V.w, nullptr, nullptr, false);
+      if (rc) return rc;
+    }
     // T' w, T' r~ ;  x2k, r~_{t-1}
     hipLaunchKernelGGL(bbb_gemv_kernel, dim3(rgrid, (unsigned)B), dim3(BB_T), 0, st, TT, mask, mask_rb, V.w, V.twv, m);
     hipLaunchKernelGGL(bbb_gemv_kernel, dim3(rgrid, (unsigned)B), dim3(BB_T), 0, st, TT, mask, mask_rb, V.r, V.trv, m);
-    hipLaunchKernelGGL(bbb_vec_kernel, dim3((unsigned)B), dim3(BB_T), 0, st, m, ZT, V);
-    // M_{t-1} = X2 T - (X2 kappa)(Z T) + ((Z T)' / F)(Z T):  op(B) = TT' = T, the tile's 64 columns are rows of TT
-    rc = kf_big_gemm_launch_x(st, true, false, X2, mm, TT, mm, nullptr, 0, M, mm, m, B, mask, /*on_b=*/1, 0, V.x2k, ZT, V.u2, ZT, /*upper_mirror=*/true);
-    if (rc) return rc;
+    hipLaunchKernelGGL(bbb_vec_kernel, dim3((unsigned)B), dim3(BB_T), 0, st, m, ZT, V, sparse ? 1 : 0);
+    if (sparse) {
+      // M_{t-1} = T' M_t T - (Z T)' (T' w)' + (x2k + (Z T)' / F)(Z T),  x2k = -(T' w - (Z T)' (w . kappa)):  into the other buffer
+      rc = kf_bsp_sandwich_launch(st, csr, M, X2, m, B, V.negZT, V.twv, V.x2k, ZT);
+      if (rc) return rc;
+      double* tm = M;
+      M = X2;
+      X2 = tm;
+    } else {
+      // M_{t-1} = X2 T - (X2 kappa)(Z T) + ((Z T)' / F)(Z T):  op(B) = TT' = T, the tile's 64 columns are rows of TT
+      rc = kf_big_gemm_launch_x(st, true, false, X2, mm, TT, mm, nullptr, 0, M, mm, m, B, mask, /*on_b=*/1, 0, V.x2k, ZT, V.u2, ZT, /*upper_mirror=*/true);
+      if (rc) return rc;
+    }
     double* tmp = V.r;
     V.r = V.rn;
     V.rn = tmp;

@@ -69,6 +69,21 @@ for case in range(n_cases):
             struct = rng.integers(0, 3) == 0 and n >= 31 and not big_m
             w = W.structural(B=B, n=n, seed=seed) if struct else W.random_dense(B, n, 1, m, r, seed=seed)
             m = w["m"]
+            if big_m and rng.integers(0, 2) == 0:   # a sparse T: companion column / shifted identity / diagonal blocks (CSR form of T' M T,
+                Ts = np.zeros_like(w["T"])          # or, with a dense row of T', the block-sparse products)
+                kind_t = int(rng.integers(0, 3))
+                idx = np.arange(m - 1)
+                if kind_t == 0:
+                    Ts[:, :, 0] = 0.5 * rng.standard_normal((B, m)) / np.arange(1, m + 1)
+                    Ts[:, idx, idx + 1] = 1.0
+                elif kind_t == 1:
+                    Ts[:, idx + 1, idx] = 0.9
+                    Ts[:, int(rng.integers(0, m)), :] = (0.3 / m) * rng.standard_normal((B, m))
+                else:
+                    Ts[:, np.arange(m), np.arange(m)] = rng.uniform(-0.9, 0.9, (B, m))
+                    for _ in range(3):
+                        Ts[:, int(rng.integers(0, m)), int(rng.integers(0, m))] = 0.1
+                w["T"] = Ts
             if struct and rng.integers(0, 2) == 0:
                 slow(w, rng.integers(0, B, size=max(1, B // 8)))
             y = w["y"].copy()

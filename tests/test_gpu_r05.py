@@ -591,7 +591,8 @@ def test_ill_conditioned_dense_H_goes_to_the_dense_path(eng):
     assert err["H"] < 1e-5, err
 
 
-@pytest.mark.parametrize("case", ["dense_m16", "dense_m40", "dense_m70", "seasonal_m101", "seasonal_m151_missing", "seasonal_m367"])
+@pytest.mark.parametrize("case", ["dense_m16", "dense_m40", "dense_m70", "seasonal_m101", "seasonal_m151_missing", "seasonal_m367",
+                                  "companion_m24", "companion_m70"])
 def test_smoother_from_filter_workspace_path(eng, monkeypatch, case):
     """15 < m <= 1024 (kf_smoother_bf_big.hip; BASELINE config 5's smoother): the same recursion with the fp64-MFMA products of the
     workspace path -- two dense, two with the block-sparse T -- against its numpy restatement (1e-9 of the draw's largest filtered
@@ -599,6 +600,13 @@ def test_smoother_from_filter_workspace_path(eng, monkeypatch, case):
     if case.startswith("dense"):
         m = int(case.split("_m")[1])
         w = W.random_dense(4, 12, 1, m, min(m, 5), seed=40 + m)
+    elif case.startswith("companion"):   # ARMA companion form: a dense first COLUMN of T -- a row of T' with m entries (CSR up to 32,
+        m = int(case.split("_m")[1])     # a "dense row" beyond: the block-sparse products) -- over a shifted identity; rank-one noise
+        w = W.random_dense(4, 12, 1, m, 1, seed=60 + m)
+        T = np.zeros_like(w["T"])
+        T[:, :, 0] = 0.5 * np.random.default_rng(m).standard_normal((4, m)) / np.arange(1, m + 1)
+        T[:, np.arange(m - 1), np.arange(1, m)] = 1.0
+        w["T"] = T
     else:
         m = int(case.split("_m")[1].split("_")[0])
         w = W.daily_seasonal(B=3, n=9 if m < 300 else 5, s=m - 1)
@@ -613,10 +621,22 @@ def test_smoother_from_filter_workspace_path(eng, monkeypatch, case):
     scale = max(1.0, float(np.abs(res.filtered_covs.cpu().numpy()).max()))
     assert_allclose(sa.cpu().numpy(), da, rtol=1e-9, atol=1e-9 * scale)
     assert_allclose(sP.cpu().numpy(), dP, rtol=1e-9, atol=1e-9 * scale)
-    ra, rP = eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
-    assert_allclose(sa.cpu().numpy(), ra.cpu().numpy(), rtol=1e-7, atol=1e-7 * scale)
-    assert_allclose(sP.cpu().numpy(), rP.cpu().numpy(), rtol=1e-7, atol=1e-7 * scale)
+    if not case.startswith("companion"):   # (rank-one noise: the RTS recursion's pinv(P_hat) is another function of the tapes there)
+        ra, rP = eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
+        assert_allclose(sa.cpu().numpy(), ra.cpu().numpy(), rtol=1e-7, atol=1e-7 * scale)
+        assert_allclose(sP.cpu().numpy(), rP.cpu().numpy(), rtol=1e-7, atol=1e-7 * scale)
     monkeypatch.setenv("KF_BIG_TMASK", "0")
     sa0, sP0 = eng.smooth_from_filter(y, w["T"], w["Z"], w["H"], res.predicted_states, res.predicted_covs)
     monkeypatch.delenv("KF_BIG_TMASK")
     assert np.array_equal(sa.cpu().numpy(), sa0.cpu().numpy()) and np.array_equal(sP.cpu().numpy(), sP0.cpu().numpy())
+    # T' M T as a CSR gather (a sparse T' without dense rows: the seasonal models, companion forms up to m = 32) against the two
+    # block-sparse products (KF_BIG_SPARSE=0), which in turn skip no chunk with KF_BIG_TMASK=0
+    monkeypatch.setenv("KF_BIG_SPARSE", "0")
+    sa1, sP1 = eng.smooth_from_filter(y, w["T"], w["Z"], w["H"], res.predicted_states, res.predicted_covs)
+    monkeypatch.setenv("KF_BIG_TMASK", "0")
+    sa2, sP2 = eng.smooth_from_filter(y, w["T"], w["Z"], w["H"], res.predicted_states, res.predicted_covs)
+    assert np.array_equal(sa1.cpu().numpy(), sa2.cpu().numpy()) and np.array_equal(sP1.cpu().numpy(), sP2.cpu().numpy())
+    assert_allclose(sa.cpu().numpy(), sa1.cpu().numpy(), rtol=1e-10, atol=1e-10 * scale)
+    assert_allclose(sP.cpu().numpy(), sP1.cpu().numpy(), rtol=1e-10, atol=1e-10 * scale)
+    if case.startswith("dense") or case == "companion_m70":
+        assert np.array_equal(sP.cpu().numpy(), sP1.cpu().numpy())   # (no CSR form: the same products either way)
