@@ -359,7 +359,7 @@ def smoother_from_filter_applies(p, m, ndims, r=None):
     """Should the smoothed moments come from the filter's predicted tapes (kf_smoother_from_filter)?  p == 1, every system
     matrix static (``ndims``: the per-draw ranks of T, Z, H, R, Q) and 5 <= m <= 15 (the on-chip kernel) or 64 < m <= 1024 (both
     recursions run on the HBM workspace there and the one from the predicted tapes has no factorisation: C5, 128 draws, m = 367:
-    1.09 against 2.97 ms per step).  The entry point takes every m <= 1024, but at m <= 4 the lane-per-draw RTS kernel is the
+    0.80 against 2.78 ms per step).  The entry point takes every m <= 1024, but at m <= 4 the lane-per-draw RTS kernel is the
     faster one (C2, 4096 x 1000, m = 2: 0.76 against 0.99 ms) and at 16 <= m <= 64 so are the on-chip RTS kernels -- UNLESS the
     state noise has few columns (``r``, the width of R: every ARMA / SARIMA model has r = 1): then the prediction covariance sits on
     the pseudo-inverse's cut-off, the RTS kernels hand most draws to the pinv kernel and take seconds (1024 draws x 300 steps,
