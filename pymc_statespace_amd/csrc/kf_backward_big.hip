@@ -298,7 +298,9 @@ inline size_t bb_doubles(long B, int m, int p, int n, int r) {
 }  // namespace
 
 size_t kf_backward_big_workspace_bytes(long B, int m, int p, int n, int r) {
-  return sizeof(double) * bb_doubles(B, m, p, n, r) + 2 * sizeof(uint32_t) * (size_t)B * ((m + 63) / 64) + 320;   // (+ the block maps of T, T')
+  return sizeof(double) * bb_doubles(B, m, p, n, r) + 2 * sizeof(uint32_t) * (size_t)B * ((m + 63) / 64) + 640 +   // (+ the block maps of T, T')
+         (m <= 1024 ? kf_bsp_csr_bytes(B, m) + 64 : 0);                                                              //   and the CSR copy of T'
+
 }
 
 int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t st) {
@@ -373,6 +375,24 @@ int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, si
       if (kf_big_tmask_launch(st, TT, m, B, tmaskt) != KF_OK) tmaskt = nullptr;
     }
   }
+  // T' sparse without dense rows: X1' = T' Pb and Sb = X1' T = T' Pb T from ONE CSR gather (kf_bsp_sandwich_launch, which also leaves its
+  // first stage X1') instead of the two block-sparse products.  The verdict is read back once per call (as kf_launch_forward_big does;
+  // never while the stream is being captured; KF_BIG_SPARSE=0: the products)
+  KfBspCsr csrT;
+  bool sparse = false;
+  if (big_full && m <= 1024) {
+    const char* se = kf_env_switch("KF_BIG_SPARSE");
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap_status);
+    void* cmem = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(q) + 2 * sizeof(uint32_t) * (size_t)B * ((m + 63) / 64) + 256 + 63) &
+                                         ~(uintptr_t)63);
+    if (!(se && se[0] == '0') && cap_status == hipStreamCaptureStatusNone && kf_bsp_csr_build(st, TT, m, B, cmem, &csrT) == KF_OK) {
+      int verdict[2] = {0, 1};
+      KF_HIP_CHECK(h, hipMemcpyAsync(verdict, csrT.ok, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+      KF_HIP_CHECK(h, hipStreamSynchronize(st));
+      sparse = verdict[0] != 0 && verdict[1] == 0;
+    }
+  }
   for (int t = n - 1; t >= 0; --t) {
     // ab_f = T' ab'
     hipLaunchKernelGGL(bb_colmatvec_kernel, dim3(cc, (unsigned)B), dim3(NT), sh_mv, st, a.Tm, mm, W.abp, (long)m,
@@ -387,10 +407,14 @@ int kf_launch_backward_big(kf_handle* h, const KfBwdArgs& a, void* workspace, si
     // X1 = Pb T ; Sb = X1' T ; Tb_m += X1 P_f
     // (m >= 128: on kf_forward_big.hip's 128 x 64-tile product, 270 against 335 us per launch at C5; KF_SMOOTHER_BIG_GEMM=0: this file's)
     if (big_full) {
-      kf_big_gemm_launch_x(st, false, false, TT, mm, W.PB, mm, nullptr, 0, X1t, mm, m, B, tmaskt, /*on_b=*/0, 0, nullptr, nullptr, nullptr,
-                           nullptr, false);
-      kf_big_gemm_launch_x(st, false, false, X1t, mm, a.Tm, mm, nullptr, 0, W.SB, mm, m, B, tmaskc, /*on_b=*/1, 0, nullptr, nullptr, nullptr,
-                           nullptr, false);
+      if (sparse) {
+        kf_bsp_sandwich_launch(st, csrT, W.PB, W.SB, m, B, nullptr, nullptr, nullptr, nullptr, X1t);
+      } else {
+        kf_big_gemm_launch_x(st, false, false, TT, mm, W.PB, mm, nullptr, 0, X1t, mm, m, B, tmaskt, /*on_b=*/0, 0, nullptr, nullptr, nullptr,
+                             nullptr, false);
+        kf_big_gemm_launch_x(st, false, false, X1t, mm, a.Tm, mm, nullptr, 0, W.SB, mm, m, B, tmaskc, /*on_b=*/1, 0, nullptr, nullptr, nullptr,
+                             nullptr, false);
+      }
       kf_big_gemm_launch(st, false, true, false, W.Pc, mm, X1t, mm, TBm, mm, TBm, mm, m, B);   // (Tb' += P_f X1')
     } else {
       kf_sb_gemm(st, B, false, 0, W.PB, mm, m, a.Tm, mm, m, nullptr, 0, 0, X1, mm, m, m, m, m);

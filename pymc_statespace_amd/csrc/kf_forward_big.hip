@@ -1507,7 +1507,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
                                                                                                  const double* __restrict__ u1,
                                                                                                  const double* __restrict__ v1,
                                                                                                  const double* __restrict__ u2,
-                                                                                                 const double* __restrict__ v2, int nblk) {
+                                                                                                 const double* __restrict__ v2, int nblk,
+                                                                                                 double* __restrict__ wout) {
   extern __shared__ double sm[];
   constexpr int RW = R / 4;
   constexpr int NE = 2;
@@ -1606,6 +1607,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
     for (int q = 0; q < RW; ++q)   // empty rows
       if (rpw[q] == rpw[q + 1])
         for (int l = lane; l < m; l += 64) w[(long)(q0 + q) * m + l] = 0.0;
+    if (wout)   // the rows of A X themselves (kf_backward_big.hip: X1' = T' Pb is the left factor of another product)
+      for (int q = 0; q < RW; ++q)
+        if (i0 + q0 + q < m)
+          for (int l = lane; l < m; l += 64) wout[b * mm + (long)(i0 + q0 + q) * m + l] = w[(long)(q0 + q) * m + l];
   }
   __syncthreads();
   // ---- stage 2
@@ -1741,7 +1746,7 @@ int kf_bsp_csr_build(hipStream_t st, const double* Tm, int m, long B, void* mem,
 }
 
 int kf_bsp_sandwich_launch(hipStream_t st, const KfBspCsr& c, const double* X, double* out, int m, long B, const double* u1,
-                           const double* v1, const double* u2, const double* v2) {
+                           const double* v1, const double* u2, const double* v2, double* wout) {
   auto lds_of = [&](int rows) { return sizeof(double) * ((size_t)rows * m + 2 * (size_t)rows); };
   const int R = lds_of(8) <= KF_LDS_BYTES_MAX / 2 ? 8 : 4;
   const size_t lds = lds_of(R);
@@ -1750,9 +1755,9 @@ int kf_bsp_sandwich_launch(hipStream_t st, const KfBspCsr& c, const double* X, d
   const int nblk = (m + R - 1) / R;
   const unsigned grid = (unsigned)(8L * nblk * ((B + 7) / 8));
   if (R == 8)
-    hipLaunchKernelGGL(bsp_sandwich_kernel<8>, dim3(grid), dim3(256), lds, st, c, X, out, m, B, u1, v1, u2, v2, nblk);
+    hipLaunchKernelGGL(bsp_sandwich_kernel<8>, dim3(grid), dim3(256), lds, st, c, X, out, m, B, u1, v1, u2, v2, nblk, wout);
   else
-    hipLaunchKernelGGL(bsp_sandwich_kernel<4>, dim3(grid), dim3(256), lds, st, c, X, out, m, B, u1, v1, u2, v2, nblk);
+    hipLaunchKernelGGL(bsp_sandwich_kernel<4>, dim3(grid), dim3(256), lds, st, c, X, out, m, B, u1, v1, u2, v2, nblk, wout);
   return hipGetLastError() == hipSuccess ? KF_OK : KF_ERR_HIP;
 }
 

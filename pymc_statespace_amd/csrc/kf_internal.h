@@ -353,8 +353,9 @@ struct KfBspCsr {
 size_t kf_bsp_csr_bytes(long B, int m);
 int kf_bsp_csr_build(hipStream_t st, const double* Tm, int m, long B, void* mem, KfBspCsr* c);   // carves `mem`, enqueues the build
 // out = A X A' + u1 v1' + u2 v2' per draw: A = the CSR matrices (NO dense rows: ok[1] == 0), X dense [B][m][m], out another buffer
+// (wout, or NULL: the product A X itself, [B][m][m])
 int kf_bsp_sandwich_launch(hipStream_t st, const KfBspCsr& c, const double* X, double* out, int m, long B, const double* u1,
-                           const double* v1, const double* u2, const double* v2);
+                           const double* v1, const double* u2, const double* v2, double* wout = nullptr);
 // block map of T by columns (word per 64-column block, bit per 32-row chunk): for A T with T the untransposed B operand, tmask_on_b = 1
 int kf_big_tmask_cols_launch(hipStream_t st, const double* T, int m, long B, uint32_t* tmask);
 int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes,
