@@ -439,3 +439,18 @@ def test_batched_filter_differentiates_ll_obs(monkeypatch):
     few = StandardFilter().build_graph(*sym3, batched=True, outputs=("ll_obs",))
     with pytest.raises(Exception, match="(?i)not implemented|undefined|null|predicted"):
         pytensor.grad((pt.as_tensor_variable(burn) * few[5]).sum(), sym3[6])
+
+
+def test_which_recursion_the_fused_smoother_node_takes():
+    """op.smoother_from_filter_applies: the smoother from the filter's predicted tapes for p == 1, static matrices and 5 <= m <= 15 (on chip)
+    or 64 < m <= 1024 (workspace); between 16 and 64 only with state noise of few columns (12 r <= m + 11: every ARMA / SARIMA model has
+    r = 1), where the RTS kernels would hand most draws to the pinv kernel (profiles/r05/smoother_mid_m_rank.txt); else kf_smoother."""
+    from pymc_statespace_amd.op import smoother_from_filter_applies as f
+
+    static = [2, 2, 2, 2, 2]
+    assert not f(2, 10, static) and not f(1, 10, [3, 2, 2, 2, 2]) and not f(1, 10, [2, 2, 2, 3, 2])   # p > 1; a time-varying T; R
+    assert [m for m in range(1, 17) if f(1, m, static)] == list(range(5, 16))
+    assert f(1, 65, static) and f(1, 367, static) and f(1, 1024, static) and not f(1, 1025, static)
+    assert not f(1, 20, static) and not f(1, 20, static, r=20) and not f(1, 20, static, r=3)
+    assert f(1, 16, static, r=1) and f(1, 20, static, r=2) and f(1, 32, static, r=3) and f(1, 48, static, r=4) and f(1, 64, static, r=6)
+    assert not f(1, 32, static, r=4) and not f(1, 48, static, r=5)
