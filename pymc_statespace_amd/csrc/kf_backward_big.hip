@@ -11,6 +11,9 @@
 //                   (two length-m dot products) instead of a cross-workgroup reduction; workgroup 0
 //                   keeps the vectors (a^q, a_f, the parked rows of the rank-one part of T_b); Gs += Pb
 //   sb_gemm x3      X1 = Pb T ;  Sb = X1' T (X1' from a transpose kernel) ;  Tb_m += X1 P_f
+//                   (m >= 128, round 5: X1' = T' Pb formed directly and Tb_m' += P_f X1' accumulated transposed -- no transpose kernel
+//                   per step --; the two products by T on its non-zero blocks, or, T' sparse without dense rows, X1' and
+//                   Sb = T' Pb T from ONE CSR gather: kf_bsp_sandwich_launch)
 //   bb_adj_update   columns chunk, observations backwards: beta, gamma, F_b, v_b, u recomputed per
 //                   workgroup; P^q rebuilt in the pass that also forms P^q u;
 //                   Sb += F_b z z' + (u z' + z u')/2
