@@ -20,7 +20,7 @@
  * Conventions
  *   - Plain C, no torch / HIP types in signatures.  `stream` is a hipStream_t passed
  *     as void* (NULL = the null stream).  All calls are asynchronous on `stream` (one exception, a
- *     4-byte read-back in kf_filter_forward / kf_filter_value_and_grad on the m > 64 workspace path: kf_last_forward_kernel below).
+ *     4- / 8-byte read-back on the m > 64 workspace paths of the filter, its gradient and kf_smoother_from_filter: kf_last_forward_kernel below).
  *   - Every data pointer is a DEVICE pointer to fp64 (the reference computes in
  *     float64: kalman_filter.py:16).  The caller owns all buffers; the library
  *     never allocates in a call, never frees and never keeps a pointer.
@@ -204,7 +204,11 @@ const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_dims* dims, s
  * device: such a call reads 4 bytes back and SYNCHRONISES `stream` once, before the recursion is enqueued -- the one exception to
  * "asynchronous on stream" above; while `stream` is being captured into a graph, or with KF_BIG_SPARSE=0 in the environment,
  * there is no read-back and the MFMA path runs.  kf_last_forward_kernel: the kernel that carried the recursion of this handle's
- * last kf_filter_forward on the workspace path ("" before the first). */
+ * last kf_filter_forward on the workspace path ("" before the first).
+ * The same holds for kf_filter_backward / kf_filter_value_and_grad with m >= 128 and for kf_smoother_from_filter with m > 15: they
+ * compact T' and, when it is sparse without dense rows, evaluate T' X T (X the adjoint / the smoother's carried matrix) as one CSR
+ * gather instead of two block-sparse products -- one 8-byte read-back + stream synchronisation per call, skipped under capture or
+ * KF_BIG_SPARSE=0. */
 const char* kf_last_forward_kernel(const kf_handle* h);
 
 /* Scratch the three entry points need for `dims` (max over them, for the kernel selection in force
