@@ -1305,6 +1305,11 @@ extern "C" int kf_smoother_from_filter(kf_handle* h, const kf_dims* dims, const 
   a.y = y; a.Tm = T; a.Z = Z; a.H = H; a.d = d; a.pred_a = pred_a; a.pred_P = pred_P;
   a.smooth_a = smooth_a; a.smooth_P = smooth_P;
   if (big) return kf_launch_smoother_bf_big(h, a, workspace, workspace_bytes, (hipStream_t)stream);
+  // m <= 4 (C1, C2): one lane per draw (kf_smoother_bf_lane.hip); KF_SMOOTHER_BF_LANE=0 keeps the block-tile kernel (A/B measurements)
+  if (kf_smoother_bf_lane_ok(a.m, dims->p, fl) && h->forward_kernel != KF_KERNEL_B4) {
+    const char* e = kf_env_switch("KF_SMOOTHER_BF_LANE");
+    if (!(e && e[0] == '0')) return kf_launch_smoother_bf_lane(h, a, (hipStream_t)stream);
+  }
   return kf_launch_smoother_bf(h, a, (hipStream_t)stream);
 }
 

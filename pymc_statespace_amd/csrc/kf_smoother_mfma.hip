@@ -114,8 +114,9 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((TV && 
 #pragma unroll
     for (int s = 0; s < KS; ++s) PN[s] = on[s] ? rp[off[s]] : 0.0;
     an = c_ok ? gfa[(long)t * m + c] : 0.0;
-    if (tvT) {
-      const double* tp = A.Tm + (bN + t + tsh) * (long)mm;   // (t <= n - 2: slice t + 1 exists)
+    if (tvT && t + tsh < n) {   // the first call, prefetch(n - 1), with the reference's pairing (tsh = 1) would read slice n: past the
+                                // end of the last draw's [n][m][m] block; the loop's first step reloads TN anyway
+      const double* tp = A.Tm + (bN + t + tsh) * (long)mm;
 #pragma unroll
       for (int s = 0; s < KS; ++s) TN[s] = on[s] ? tp[offT[s]] : 0.0;
     }

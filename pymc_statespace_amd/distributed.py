@@ -131,10 +131,16 @@ class ShardedKalman:
     def value_and_grad_local(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, **kw):
         """kf_filter_value_and_grad on this rank's draws -> (logp, info, dict of gradients).  An empty shard skips the
         launch and returns empty tensors of the right trailing shapes."""
+        if kw.get("time_varying"):
+            # (ADVICE round 5) kf_filter_value_and_grad takes static models only: a time-varying gradient has (b, n, rows, cols)
+            # arrays, whose packed row width would differ between an empty and a non-empty shard -- reject it on EVERY rank
+            raise NotImplementedError("the sharded value-and-gradient takes static system matrices (use engine.forward + "
+                                      "engine.backward with time_varying=... on each rank's shard)")
         if T.shape[0] == 0:
             dev, f64 = self.engine.device, torch.float64
-            m, p, r = T.shape[-1], Z.shape[-2], R.shape[-1]
-            shp = dict(a0=(m,), P0=(m, m), T=(m, m), Z=(p, m), R=(m, r), H=(p, p), Q=(r, r), c=(m,), d=(p,))
+            # trailing shapes from the inputs themselves (an empty shard still carries them): what the non-empty ranks pack
+            shp = dict(a0=tuple(a0.shape[1:]), P0=tuple(P0.shape[1:]), T=tuple(T.shape[1:]), Z=tuple(Z.shape[1:]),
+                       R=tuple(R.shape[1:]), H=tuple(H.shape[1:]), Q=tuple(Q.shape[1:]), c=(T.shape[-1],), d=(Z.shape[-2],))
             return (torch.empty(0, device=dev, dtype=f64), torch.empty(0, device=dev, dtype=torch.int32),
                     {k: torch.empty((0,) + shp[k], device=dev, dtype=f64) for k in self.GRAD_KEYS})
         return self.engine.value_and_grad(y, a0, P0, T, Z, R, H, Q, c, d, **kw)
@@ -178,22 +184,26 @@ class ShardedKalman:
         return self.engine.smooth(T, R, Q, filtered_states, filtered_covs, **kw)
 
     def smooth_from_filter_local(self, data, T, Z, H, predicted_states, predicted_covs, **kw):
-        """kf_smoother_from_filter on this rank's predicted tapes (p == 1, m <= 15); nothing is exchanged."""
+        """kf_smoother_from_filter on this rank's predicted tapes (p == 1, static matrices, m <= 1024: include/kf.h); nothing is
+        exchanged."""
         if T.shape[0] == 0:
             dev, f64 = self.engine.device, torch.float64
             n, m = predicted_states.shape[1] - 1, T.shape[-1]
             return torch.empty(0, n, m, device=dev, dtype=f64), torch.empty(0, n, m, m, device=dev, dtype=f64)
         return self.engine.smooth_from_filter(data, T, Z, H, predicted_states, predicted_covs, **kw)
 
-    def filter_and_smooth(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, B_global: int, **fkw):
+    def filter_and_smooth(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, B_global: int, route: str = "auto", **fkw):
         """Forward filter + smoother of this rank's draws: (gathered logp (B_global,), this rank's FilterResult, this rank's
         smoothed states and covariances) -- build_statespace_graph + build_smoother_graph (core/statespace.py:164-197) for a
-        shard.  The only exchange is the logp all-gather."""
+        shard.  The only exchange is the logp all-gather.  The smoother runs on the filter's PREDICTED tapes wherever that is the
+        cheaper recursion (``KalmanEngine.smooth_result``: p == 1, static matrices, zero c -- no pinv(P_hat)), else on the filtered
+        ones; ``route="rts"`` forces the reference's recursion."""
         res = self.forward_local(y, a0, P0, T, Z, R, H, Q, c, d, **fkw)
         full = self.gather_logp(res.logp, B_global)
         if T.shape[0] == 0:
             dev, f64 = self.engine.device, torch.float64
             n, m = y.shape[-2], T.shape[-1]
             return full, res, torch.empty(0, n, m, device=dev, dtype=f64), torch.empty(0, n, m, m, device=dev, dtype=f64)
-        sa, sP = self.engine.smooth(T, R, Q, res.filtered_states, res.filtered_covs)
+        sa, sP = self.engine.smooth_result(res, y, T, Z, R, H, Q, c, d, filter_type=fkw.get("filter_type", "standard"),
+                                           time_varying=tuple(fkw.get("time_varying", ())), route=route)
         return full, res, sa, sP

@@ -34,6 +34,34 @@ class FilterResult:
     info: torch.Tensor                       # (B,) int32
 
 
+def smoother_from_filter_applies(p, m, ndims, r=None):
+    """Should the smoothed moments come from the filter's PREDICTED tapes (kf_smoother_from_filter) rather than from the
+    reference's recursion on the filtered ones (kf_smoother, kalman_smoother.py:56-104)?  The one rule every caller that holds
+    a filter's result uses: the fused PyTensor node (op.perform_smoother_fused), ``KalmanEngine.smooth_result``,
+    ``KalmanSmoother.__call__(..., filter_result=...)``, ``BaseFilter.filter_and_smooth`` and ``ShardedKalman.filter_and_smooth``.
+    p == 1 and every system matrix static (``ndims``: the per-draw ranks of T, Z, H, R, Q -- and of d when given as a sixth
+    entry, 1), and
+      * m <= 4   the lane-per-draw kernel (round 6, kf_smoother_bf_lane.hip): no pseudo-inverse -- an ARMA model (r = 1, H = 0) puts
+                 the prediction covariance on pinv's cut-off at almost every step and the RTS lane kernel's Jacobi fallback agrees with
+                 statsmodels only to 1e-2 there, this recursion to 1e-9 (tests/golden/arma11.npz);
+      * 5 <= m <= 15   the on-chip block-tile kernel (kf_smoother_bf.hip);
+      * 64 < m <= 1024  both recursions run on the HBM workspace and this one has no factorisation (C5, 128 draws, m = 367:
+                 0.80 against 2.78 ms per step);
+      * 16 <= m <= 64   only when the state noise has few columns (``r``, the width of R: every ARMA / SARIMA model has r = 1): the
+                 RTS kernels then hand most draws to the pinv kernel and take seconds (1024 draws x 300 steps, r = 1, m = 20 / 32 /
+                 48 / 64: 0.19 / 2.0 / 7.3 / 37.7 s) where this recursion takes 34 / 43 / 58 / 75 ms on the workspace; measured bad up
+                 to r = 2 / 3 / 4 at m = 20 / 32 / 48 (profiles/r05/smoother_mid_m_rank.txt): taken for 12 r <= m + 11.
+    A non-zero state intercept c is the CALLER's business: the reference's smoother predicts with a_hat = T a_f, without c
+    (kalman_smoother.py:99-104), while the filter's predicted tapes contain it, so the two recursions differ by O(c) and a caller that
+    wants the reference's numbers must keep kf_smoother (``smooth_result`` and the fused node check c themselves)."""
+    nds = list(ndims)
+    if p != 1 or not all(nd == 2 for nd in nds[:5]) or any(nd != 1 for nd in nds[5:]):
+        return False
+    if 1 <= m <= 15 or 64 < m <= 1024:
+        return True
+    return 16 <= m <= 64 and r is not None and 12 * r <= m + 11
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -420,15 +448,15 @@ class KalmanEngine:
 
 
     def smooth_from_filter_ok(self, p: int, m: int, time_varying=()) -> bool:
-        """Does kf_smoother_from_filter take this shape (p == 1, m <= 1024, static matrices: on chip up to m = 15, on the HBM
-        workspace beyond)?"""
+        """Does kf_smoother_from_filter take this shape (p == 1, m <= 1024, static matrices: one lane per draw up to m = 4, on chip up
+        to m = 15, on the HBM workspace beyond)?  (Whether it is the FASTER recursion: ``smoother_from_filter_applies``.)"""
         return p == 1 and 1 <= m <= 1024 and not tuple(time_varying)
 
     def smooth_from_filter(self, data, T, Z, H, predicted_states, predicted_covs, d=None, filter_type: str = "standard"):
         """kf_smoother_from_filter -> (smoothed_states (B,n,m), smoothed_covs (B,n,m,m)) from the FILTER's predicted tapes
         (B,n+1,m), (B,n+1,m,m) and the observation side of the model it ran on (data, Z, H, d) -- the same moments
         ``smooth`` computes from the filtered tapes (kalman_smoother.py:56-104) up to rounding, without inverting the prediction
-        covariance (include/kf.h).  p == 1, static matrices, m <= 15 on chip and 15 < m <= 1024 on the workspace path;
+        covariance (include/kf.h).  p == 1, static matrices, m <= 4 one lane per draw, m <= 15 on chip and 15 < m <= 1024 on the workspace path;
         ``filter_type="single"`` keeps that filter's sign of d."""
         if filter_type not in _lib.KF_FILTER:
             raise ValueError(f"unknown filter_type {filter_type!r}")
@@ -457,6 +485,38 @@ class KalmanEngine:
         self._check(rc, "kf_smoother_from_filter")
         return sa, sP
 
+
+    def smooth_result(self, res: FilterResult, data, T, Z, R, H, Q, c=None, d=None, *, filter_type: str = "standard",
+                      time_varying=(), route: str = "auto", **smooth_kw):
+        """Smoothed moments of the model whose ``forward`` produced ``res`` -- build_statespace_graph + build_smoother_graph
+        (core/statespace.py:164-197) for a caller that holds the filter's result: from the PREDICTED tapes (kf_smoother_from_filter: no
+        pinv, every draw at the same cost) wherever ``smoother_from_filter_applies`` says so, the tapes are in ``res`` and the state
+        intercept c is absent or all zero (one device reduction + host sync when c is given); else the reference's recursion on the
+        filtered tapes (kf_smoother).  ``route``: "auto" | "from_filter" (raise if it does not apply) | "rts".  Returns
+        (smoothed_states (B,n,m), smoothed_covs (B,n,m,m))."""
+        if route not in ("auto", "from_filter", "rts"):
+            raise ValueError("route must be 'auto', 'from_filter' or 'rts'")
+        tv = tuple(time_varying)
+        T_ = self.to_device(T)
+        Z_ = self.to_device(Z)
+        R_ = self.to_device(R)
+        m, p, r = T_.shape[-1], Z_.shape[-2], R_.shape[-1]
+        ok = route != "rts" and not tv and res.predicted_states is not None and res.predicted_covs is not None
+        if ok:
+            ok = smoother_from_filter_applies(p, m, (2,) * 5, r=r) if route == "auto" else self.smooth_from_filter_ok(p, m)
+        if ok and c is not None:
+            ok = not bool(torch.any(self.to_device(c) != 0))
+        if ok:
+            dv = None if d is None else self.to_device(d).reshape(T_.shape[0], p)
+            return self.smooth_from_filter(data, T_, Z_, H, res.predicted_states, res.predicted_covs, d=dv,
+                                           filter_type=filter_type)
+        if route == "from_filter":
+            raise KalmanError("smooth_result(route='from_filter'): needs p == 1, static matrices, m <= 1024, the predicted tapes in "
+                              "the filter result and a zero state intercept c")
+        if res.filtered_states is None or res.filtered_covs is None:
+            raise KalmanError("smooth_result: the filter result holds no filtered tapes (forward(..., store_filtered=True))")
+        return self.smooth(T_, R_, Q, res.filtered_states, res.filtered_covs,
+                           time_varying=tuple(nm for nm in tv if nm in ("T", "R", "Q")), **smooth_kw)
 
     # ------------------------------------------------- before the filter (section 8f row 1)
     def lyapunov(self, T, R=None, Q=None, S=None):

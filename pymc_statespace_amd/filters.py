@@ -97,10 +97,8 @@ class BaseFilter:
         raise NotImplementedError
 
     # -- eager ---------------------------------------------------------------------------------
-    def __call__(self, data, a0, P0, T, Z, R, H, Q, c=None, d=None, *, outputs="all"):
-        """Evaluate on the GPU.  Returns the reference's list
-        [filtered_states, predicted_states, filtered_covs, predicted_covs, logp, ll_obs]
-        (or only ``[logp]`` for ``outputs="logp"``)."""
+    def _forward(self, data, a0, P0, T, Z, R, H, Q, c, d, outputs):
+        """The eager call's common part: (FilterResult in HBM, finisher, the batch-leading inputs as handed to the engine)."""
         as_torch = _is_torch(data, a0, P0, T, Z, R, H, Q)
         T_, Z_, R_, H_, Q_ = map(_np_or_t, (T, Z, R, H, Q))
         batched = P0 is not None and _np_or_t(P0).ndim == 3
@@ -122,9 +120,10 @@ class BaseFilter:
             raise ValueError(f"data has {data_.shape[1]} columns but Z has {p} rows")
 
         eng = self.engine
+        args = dict(data=data_, a0=lead(a0, 1), P0=lead(P0, 2), T=lead(T_, 2), Z=lead(Z_, 2), R=lead(R_, 2), H=lead(H_, 2),
+                    Q=lead(Q_, 2), c=None if c is None else lead(c, 1), d=None if d is None else lead(d, 1))
         res = eng.forward(
-            data_, lead(a0, 1), lead(P0, 2), lead(T_, 2), lead(Z_, 2), lead(R_, 2), lead(H_, 2),
-            lead(Q_, 2), None if c is None else lead(c, 1), None if d is None else lead(d, 1),
+            args["data"], args["a0"], args["P0"], args["T"], args["Z"], args["R"], args["H"], args["Q"], args["c"], args["d"],
             filter_type=self.filter_type, mvn_const=self.mvn_const,
             store_ll_obs=outputs == "all", store_filtered=outputs == "all",
             store_predicted=outputs == "all", time_varying=seq,
@@ -143,10 +142,31 @@ class BaseFilter:
                 x = x[0]
             return x if as_torch else x.cpu().numpy()
 
+        return res, fin, args
+
+    def __call__(self, data, a0, P0, T, Z, R, H, Q, c=None, d=None, *, outputs="all"):
+        """Evaluate on the GPU.  Returns the reference's list
+        [filtered_states, predicted_states, filtered_covs, predicted_covs, logp, ll_obs]
+        (or only ``[logp]`` for ``outputs="logp"``)."""
+        res, fin, _ = self._forward(data, a0, P0, T, Z, R, H, Q, c, d, outputs)
         if outputs != "all":
             return [fin(res.logp)]
         return [fin(res.filtered_states, True), fin(res.predicted_states, True),
                 fin(res.filtered_covs), fin(res.predicted_covs), fin(res.logp), fin(res.ll_obs)]
+
+    def filter_and_smooth(self, data, a0, P0, T, Z, R, H, Q, c=None, d=None, *, route="auto"):
+        """Filter AND smoother of one model in one eager call -- build_statespace_graph + build_smoother_graph
+        (core/statespace.py:164-197): the reference's six filter outputs followed by (smoothed_states, smoothed_covariances).
+        The tapes stay in HBM between the two kernels, and because the filter's own result is at hand the smoother takes the
+        recursion on the PREDICTED tapes wherever it is the cheaper one (``engine.smoother_from_filter_applies``: p == 1, static
+        matrices, zero c -- no pinv(P_hat), every draw at the same cost; an ARMA model's smoothed covariances then agree with
+        statsmodels to 1e-9 instead of the pinv recursion's 1e-2), else ``kf_smoother`` on the filtered ones.
+        ``route``: "auto" | "from_filter" | "rts" (``KalmanEngine.smooth_result``)."""
+        res, fin, a = self._forward(data, a0, P0, T, Z, R, H, Q, c, d, "all")
+        sa, sP = self.engine.smooth_result(res, a["data"], a["T"], a["Z"], a["R"], a["H"], a["Q"], a["c"], a["d"],
+                                           filter_type=self.filter_type, time_varying=tuple(self.seq_names), route=route)
+        return [fin(res.filtered_states, True), fin(res.predicted_states, True), fin(res.filtered_covs), fin(res.predicted_covs),
+                fin(res.logp), fin(res.ll_obs), fin(sa, True), fin(sP)]
 
 
 class StandardFilter(BaseFilter):
@@ -267,7 +287,15 @@ class KalmanSmoother:
         self.mode = mode
         return kalman_smoother_graph(T, R, Q, filtered_states, filtered_covariances)
 
-    def __call__(self, T, R, Q, filtered_states, filtered_covariances):
+    def __call__(self, T, R, Q, filtered_states, filtered_covariances, *, filter_result=None, data=None, Z=None, H=None,
+                 c=None, d=None, filter_type="standard", route="auto"):
+        """Reference signature (kalman_smoother.py:56) plus, as keywords, what lets the smoother use the filter's own result
+        (extension): ``filter_result`` = the list a filter's eager call returned ([filtered_states, predicted_states, filtered_covs,
+        predicted_covs, logp, ll_obs]) together with that model's ``data``, ``Z``, ``H`` (and ``c``, ``d`` when it had intercepts;
+        ``filter_type="single"`` for SingleTimeseriesFilter).  With them the smoothed moments come from the PREDICTED tapes wherever
+        that recursion is the cheaper one (``engine.smoother_from_filter_applies``; zero c): no pinv(P_hat) -- for ARMA / SARIMA models
+        (k_posdef = 1) the difference is 20x - 1000x (include/kf.h) and smoothed covariances that agree with statsmodels to 1e-9
+        instead of 1e-2.  Without them: the reference's recursion on the filtered tapes, as before."""
         as_torch = _is_torch(T, R, Q, filtered_states, filtered_covariances)
         T_, R_, Q_ = map(_np_or_t, (T, R, Q))
         fP = _np_or_t(filtered_covariances)
@@ -278,11 +306,40 @@ class KalmanSmoother:
         self.seq_names = _check_ndim([T_, R_, Q_], ["T", "R", "Q"], batched)
         self.non_seq_names = [nm for nm in ("T", "R", "Q") if nm not in self.seq_names]
         m = T_.shape[-1]
+
         if fa.shape[-1] == 1 and fa.ndim >= 2 and fa.shape[-2] == m:
             fa = fa[..., 0]
-        if not batched:
-            T_, R_, Q_, fa, fP = T_[None], R_[None], Q_[None], fa[None], fP[None]
-        sa, sP = self.engine.smooth(T_, R_, Q_, fa, fP, time_varying=tuple(self.seq_names))
+        lead = (lambda x: x) if batched else (lambda x: x[None])
+        eng = self.engine
+        if filter_result is not None and not self.seq_names:
+            if data is None or Z is None or H is None:
+                raise ValueError("filter_result needs the filter's data, Z and H as well (and c, d when the model had intercepts)")
+            from .engine import FilterResult
+
+            ps, pc = _np_or_t(filter_result[1]), _np_or_t(filter_result[3])
+            if ps.shape[-1] == 1 and ps.shape[-2] == m:
+                ps = ps[..., 0]
+            Z_, H_ = _np_or_t(Z), _np_or_t(H)
+            p = Z_.shape[-2]
+            data_ = _np_or_t(data)
+            if data_.ndim == 4 or (data_.ndim == 3 and data_.shape[-1] == 1 and data_.shape[-2] == p):
+                data_ = data_[..., 0]  # reference data layout (n,p,1), as in the filters' eager call
+
+            def vec(x, k):   # (k,1) / (B,k,1) column or (k,) / (B,k) vector -> (B,k)
+                if x is None:
+                    return None
+                x = _np_or_t(x)
+                if x.shape[-1] == 1 and x.ndim == (3 if batched else 2):
+                    x = x[..., 0]
+                return lead(x)
+
+            res = FilterResult(logp=None, ll_obs=None, filtered_states=eng.to_device(lead(fa)),
+                               predicted_states=eng.to_device(lead(ps)), filtered_covs=eng.to_device(lead(fP)),
+                               predicted_covs=eng.to_device(lead(pc)), info=None)
+            sa, sP = eng.smooth_result(res, data_, lead(T_), lead(Z_), lead(R_), lead(H_), lead(Q_), vec(c, m), vec(d, p),
+                                       filter_type=filter_type, route=route)
+        else:
+            sa, sP = eng.smooth(lead(T_), lead(R_), lead(Q_), lead(fa), lead(fP), time_varying=tuple(self.seq_names))
         sa = sa[..., None]
         if not batched:
             sa, sP = sa[0], sP[0]

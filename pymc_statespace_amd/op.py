@@ -29,7 +29,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .engine import FilterResult, get_engine
+from .engine import FilterResult, get_engine, smoother_from_filter_applies  # noqa: F401  (the rule: re-exported)
 
 GRAD_INPUT_NAMES = ("a0", "P0", "T", "Z", "R", "H", "Q", "c", "d")
 
@@ -355,38 +355,27 @@ def perform_smoother_batched(T, R, Q, filtered_states, filtered_covs, engine=Non
     return [sa.cpu().numpy()[..., None], sP.cpu().numpy()]
 
 
-def smoother_from_filter_applies(p, m, ndims, r=None):
-    """Should the smoothed moments come from the filter's predicted tapes (kf_smoother_from_filter)?  p == 1, every system
-    matrix static (``ndims``: the per-draw ranks of T, Z, H, R, Q) and 5 <= m <= 15 (the on-chip kernel) or 64 < m <= 1024 (both
-    recursions run on the HBM workspace there and the one from the predicted tapes has no factorisation: C5, 128 draws, m = 367:
-    0.80 against 2.78 ms per step).  The entry point takes every m <= 1024, but at m <= 4 the lane-per-draw RTS kernel is the
-    faster one (C2, 4096 x 1000, m = 2: 0.76 against 0.99 ms) and at 16 <= m <= 64 so are the on-chip RTS kernels -- UNLESS the
-    state noise has few columns (``r``, the width of R: every ARMA / SARIMA model has r = 1): then the prediction covariance sits on
-    the pseudo-inverse's cut-off, the RTS kernels hand most draws to the pinv kernel and take seconds (1024 draws x 300 steps,
-    r = 1: m = 20 / 32 / 48 / 64: 0.19 / 2.0 / 7.3 / 37.7 s) where the recursion from the predicted tapes, which inverts nothing,
-    takes 34 / 43 / 58 / 75 ms on the workspace; measured bad up to r = 2 / 3 / 4 at m = 20 / 32 / 48
-    (profiles/r05/smoother_mid_m_rank.txt): taken for 12 r <= m + 11."""
-    if p != 1 or not all(nd == 2 for nd in ndims):
-        return False
-    if 5 <= m <= 15 or 64 < m <= 1024:
-        return True
-    return 16 <= m <= 64 and r is not None and 12 * r <= m + 11
-
-
-def perform_smoother_fused(data, T, Z, R, H, Q, d, filtered_states, filtered_covs, predicted_states, predicted_covs,
+def perform_smoother_fused(data, T, Z, R, H, Q, c, d, filtered_states, filtered_covs, predicted_states, predicted_covs,
                            filter_type="standard", engine=None, batched=False):
     """The smoother behind THIS library's filter node (``kalman_smoother_graph`` finds it: the reference never smooths anything
     but its own filter's outputs, core/statespace.py:164-197).  All of the filter's tapes are at hand, so the numeric body picks
-    the cheaper recursion: for p == 1, static matrices and 5 <= m <= 15, 64 < m <= 1024 or (16 <= m <= 64 with state noise of few
-    columns: ``smoother_from_filter_applies``) ``kf_smoother_from_filter`` on the PREDICTED tapes (no
+    the cheaper recursion: where ``engine.smoother_from_filter_applies`` says so (p == 1, static matrices and a static d; m <= 15,
+    64 < m <= 1024, or 16 <= m <= 64 with state noise of few columns) ``kf_smoother_from_filter`` on the PREDICTED tapes (no
     pinv(P_hat): include/kf.h), otherwise ``kf_smoother`` on the filtered ones (kalman_smoother.py:56-104 as it stands).
+    A non-zero state intercept ``c`` keeps the reference's recursion too: the reference's smoother predicts with
+    a_hat = T a_f, WITHOUT c (kalman_smoother.py:99-104), the filter's predicted tapes contain it, and the two recursions then
+    differ by O(c) -- the node returns what the reference returns, whatever m is.
     Shapes: the per-draw reference layouts, or with ONE leading draw axis on everything but a shared data when ``batched``."""
     eng = engine or get_engine()
     lead = 1 if batched else 0
     Ta, Za, Ha = (np.asarray(x, dtype=np.float64) for x in (T, Z, H))
     p, m = Za.shape[-2], Ta.shape[-1]
-    nds = [np.asarray(x).ndim - lead for x in (T, Z, H, R, Q)]
-    if not smoother_from_filter_applies(p, m, nds, r=np.asarray(R).shape[-1]):
+    dv = np.asarray(d, dtype=np.float64)
+    if dv.ndim >= 2 and dv.shape[-1] == 1:
+        dv = dv[..., 0]  # (p,1) column, (n,p,1) when time-varying
+    nds = [np.asarray(x).ndim - lead for x in (T, Z, H, R, Q)] + [dv.ndim - lead]
+    cv = np.asarray(c, dtype=np.float64)
+    if not smoother_from_filter_applies(p, m, nds, r=np.asarray(R).shape[-1]) or np.any(cv != 0.0):
         return (perform_smoother_batched if batched else perform_smoother)(T, R, Q, filtered_states, filtered_covs, engine=eng)
     y = np.asarray(data, dtype=np.float64)
     if y.ndim == 3 + lead or (batched and y.ndim == 3):  # (n,p,1) [shared] or (B,n,p,1)
@@ -395,9 +384,6 @@ def perform_smoother_fused(data, T, Z, R, H, Q, d, filtered_states, filtered_cov
     if pa.ndim == 3 + lead:
         pa = pa[..., 0]
     pP = np.asarray(predicted_covs, dtype=np.float64)
-    dv = np.asarray(d, dtype=np.float64)
-    if dv.ndim == 2 + lead:
-        dv = dv[..., 0]
     if not batched:
         Ta, Za, Ha, pa, pP, dv = Ta[None], Za[None], Ha[None], pa[None], pP[None], dv[None]
     sa, sP = eng.smooth_from_filter(y, Ta, Za, Ha, pa, pP, d=dv, filter_type=filter_type)
@@ -857,10 +843,11 @@ def _build_ops():
                     for k in range(5)]
 
     class KalmanSmootherFusedOp(Op):
-        """(smoothed_states, smoothed_covs) = Op(data, T, Z, R, H, Q, d, filtered_states, filtered_covs, predicted_states,
+        """(smoothed_states, smoothed_covs) = Op(data, T, Z, R, H, Q, c, d, filtered_states, filtered_covs, predicted_states,
         predicted_covs): the smoother of a model whose tapes come from ``KalmanFilterOp`` on the same graph -- what
         ``kalman_smoother_graph`` builds when it finds that node behind ``filtered_states`` (perform_smoother_fused: the
-        predicted-tape recursion where it applies, the reference's recursion on the filtered tapes otherwise).
+        predicted-tape recursion where it applies and the state intercept c is zero, the reference's recursion on the filtered
+        tapes otherwise).
         ``batched``: every input but a shared ``data`` carries ONE leading draw axis (the ``vectorize_graph`` image)."""
         __props__ = ("filter_type", "batched")
 
@@ -869,8 +856,8 @@ def _build_ops():
 
         def make_node(self, *args):
             ins = [pt.as_tensor_variable(x) for x in args]
-            if len(ins) != 11:
-                raise TypeError("KalmanSmootherFusedOp takes 11 inputs")
+            if len(ins) != 12:
+                raise TypeError("KalmanSmootherFusedOp takes 12 inputs")
             out = pt.tensor4 if self.batched else pt.tensor3
             return Apply(self, ins, [out(dtype=f64), out(dtype=f64)])
 
@@ -880,10 +867,10 @@ def _build_ops():
                 storage[0] = _out(o)
 
         def infer_shape(self, fgraph, node, shapes):
-            return [shapes[7], shapes[8]]
+            return [shapes[8], shapes[9]]
 
         def L_op(self, inputs, outputs, output_grads):
-            return [grad_not_implemented(self, k, inputs[k], "the smoother is not differentiated") for k in range(11)]
+            return [grad_not_implemented(self, k, inputs[k], "the smoother is not differentiated") for k in range(12)]
 
     try:
         from pytensor.graph.replace import _vectorize_node as _vn
@@ -913,7 +900,7 @@ def _build_ops():
         def _vectorize_kalman_smoother_fused(op, node, *ins):
             if op.batched:
                 raise NotImplementedError("one leading batch axis only")
-            if any(v.type.ndim != 2 for v in node.inputs[1:6]):
+            if any(v.type.ndim != 2 for v in node.inputs[1:8]):
                 raise NotImplementedError("vectorize_graph over a time-varying smoother node")
             led = _lead_all(node.inputs, ins, shared=(0,))
             if led is None:
@@ -998,25 +985,42 @@ def steady_state_filter_graph(data, a0, P0, T, Z, R, H, Q, c=None, d=None, mvn_c
     return list(ops["SteadyStateFilterOp"](mvn_const, want_mask(outputs))(data, a0, P0, T, Z, R, H, Q, c, d))
 
 
+def _same_variable(x, fx):
+    """Is the smoother's matrix ``x`` the filter node's input ``fx``?  The same variable, or two constants holding the same values
+    (``as_tensor_variable`` of one numpy array twice gives two equal constants)."""
+    if x is fx:
+        return True
+    dx, dfx = getattr(x, "data", None), getattr(fx, "data", None)  # TensorConstant.data
+    if dx is None or dfx is None or getattr(x, "owner", None) is not None or getattr(fx, "owner", None) is not None:
+        return False
+    return np.shape(dx) == np.shape(dfx) and bool(np.all(np.asarray(dx) == np.asarray(dfx)))
+
+
 def kalman_smoother_graph(T, R, Q, filtered_states, filtered_covariances, fuse=True):
     """Symbolic KalmanSmoother.build_graph (reference kalman_smoother.py:56-85).  The reference only ever smooths the outputs of
     its own filter on the same model (core/statespace.py:164-197); when ``filtered_states`` and ``filtered_covariances`` ARE
     outputs 0 and 2 of one ``KalmanFilterOp`` / ``KalmanFilterBatchedOp`` node that also computes its predicted tapes, the
-    smoother node takes that node's inputs and predicted tapes along (``KalmanSmootherFusedOp``): for p == 1, 5 <= m <= 15 and static
-    matrices its body is ``kf_smoother_from_filter`` -- same moments, no pinv(P_hat).  ``fuse=False`` (or tapes of any other
-    origin): the reference's recursion on the filtered tapes."""
+    smoother node takes that node's inputs and predicted tapes along (``KalmanSmootherFusedOp``) -- provided T, R, Q ARE that node's
+    T, R, Q: for p == 1, static matrices, a zero state intercept c (checked at run time: the reference's smoother ignores c,
+    kalman_smoother.py:99-104, the predicted tapes do not) and the shapes of ``engine.smoother_from_filter_applies`` its body is
+    ``kf_smoother_from_filter`` -- same moments, no pinv(P_hat).  ``fuse=False`` (or tapes of any other origin, or another T / R / Q):
+    the reference's recursion on the filtered tapes."""
     ops = _build_ops()
     pt = ops["pt"]
     fs, fc = pt.as_tensor_variable(filtered_states), pt.as_tensor_variable(filtered_covariances)
+    T, R, Q = (pt.as_tensor_variable(x) for x in (T, R, Q))
     own = getattr(fs, "owner", None)
     if fuse and own is not None and getattr(fc, "owner", None) is own and isinstance(
             own.op, (ops["KalmanFilterOp"], ops["KalmanFilterBatchedOp"])):
         batched = isinstance(own.op, ops["KalmanFilterBatchedOp"])
         want = own.op.want
         if own.outputs[0] is fs and own.outputs[2] is fc and want[1] and want[3]:
-            data, _a0, _P0, fT, fZ, fR, fH, fQ, _c, fd = own.inputs
-            return tuple(ops["KalmanSmootherFusedOp"](own.op.filter_type, batched)(
-                data, T, fZ, R, fH, Q, fd, fs, fc, own.outputs[1], own.outputs[3]))
+            data, _a0, _P0, fT, fZ, fR, fH, fQ, fc_, fd = own.inputs
+            # the predicted tapes are the FILTER's model: fuse only when the smoother is given that very model (the reference hands
+            # both the same variables, core/statespace.py:164-197); anything else smooths the filtered tapes with the caller's T, R, Q
+            if all(_same_variable(x, fx) for x, fx in ((T, fT), (R, fR), (Q, fQ))):
+                return tuple(ops["KalmanSmootherFusedOp"](own.op.filter_type, batched)(
+                    data, fT, fZ, fR, fH, fQ, fc_, fd, fs, fc, own.outputs[1], own.outputs[3]))
     if fs.type.ndim == 4:
         return tuple(ops["KalmanSmootherBatchedOp"]()(T, R, Q, fs, fc))
     return tuple(ops["KalmanSmootherOp"]()(T, R, Q, fs, fc))

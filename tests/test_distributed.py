@@ -168,6 +168,24 @@ class _OracleGradEngine(_OracleEngine):
         sa, sP = kn.kalman_smoother(T.numpy(), R.numpy(), Q.numpy(), fa.numpy(), fP.numpy())
         return torch.from_numpy(sa).reshape(fa.shape), torch.from_numpy(sP)
 
+    # the REAL dispatch (KalmanEngine.smooth_result: which recursion a caller that holds the filter's result gets) over oracle bodies
+    from pymc_statespace_amd.engine import KalmanEngine as _KE
+
+    smooth_result = _KE.smooth_result
+    smooth_from_filter_ok = _KE.smooth_from_filter_ok
+
+    def to_device(self, x, shape=None):
+        return None if x is None else torch.as_tensor(x)
+
+    def smooth_from_filter(self, data, T, Z, H, pa, pP, d=None, filter_type="standard"):
+        from oracle import kalman_numpy as kn
+
+        if T.shape[0] < 1:
+            raise RuntimeError("kf_smoother_from_filter failed (-1): bad dims: B=0")
+        sa, sP = kn.smoother_from_filter(data.numpy(), T.numpy(), Z.numpy(), H.numpy(), pa.numpy(), pP.numpy(),
+                                         d=None if d is None else d.numpy(), filter_type=filter_type)
+        return torch.from_numpy(sa), torch.from_numpy(sP)
+
 
 def _worker_sharded_grad_and_smooth(rank, world, port, B, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -188,12 +206,29 @@ def _worker_sharded_grad_and_smooth(rank, world, port, B, ret):
         assert all(g[k].shape[0] == B for k in sk.GRAD_KEYS)
         lp2, info2, g_loc = sk.value_and_grad(y, *shard, B_global=B, g_logp=gl[lo:hi], gather_grads=False)
         assert torch.equal(lp2, lp) and all(torch.equal(g_loc[k], g[k][lo:hi]) for k in sk.GRAD_KEYS)
-        full, res, sa, sP = sk.filter_and_smooth(y, *shard, B_global=B)
+        # the reference's recursion on the filtered tapes ...
+        full, res, sa, sP = sk.filter_and_smooth(y, *shard, B_global=B, route="rts")
         assert sa.shape[0] == hi - lo and sP.shape[0] == hi - lo and torch.equal(full, lp)
         if hi > lo:
             sa2, sP2 = sk.smooth_local(shard[2], shard[4], shard[6], res.filtered_states, res.filtered_covs)
             assert torch.equal(sa2, sa) and torch.equal(sP2, sP)
-        ret[rank] = dict(logp=lp.numpy(), grads={k: v.numpy() for k, v in g.items()}, lo=lo, hi=hi, sa=sa.numpy(), sP=sP.numpy())
+        # ... and what a caller gets by default (round 6): the filter's result is at hand, p == 1, static, no c -> the predicted tapes
+        full_b, res_b, sa_b, sP_b = sk.filter_and_smooth(y, *shard, B_global=B)
+        assert torch.equal(full_b, lp) and sa_b.shape == sa.shape and sP_b.shape == sP.shape
+        if hi > lo:
+            sa3, sP3 = sk.smooth_from_filter_local(y, shard[2], shard[3], shard[5], res_b.predicted_states, res_b.predicted_covs)
+            assert torch.equal(sa3, sa_b) and torch.equal(sP3, sP_b)
+            # a non-zero state intercept keeps the reference's recursion (it ignores c: kalman_smoother.py:99-104)
+            c1 = torch.full((hi - lo, shard[0].shape[1]), 0.25, dtype=torch.float64)
+            _, res_c, sa_c, sP_c = sk.filter_and_smooth(y, *shard, c1, B_global=B)
+            sa_r, sP_r = sk.smooth_local(shard[2], shard[4], shard[6], res_c.filtered_states, res_c.filtered_covs)
+            assert torch.equal(sa_c, sa_r) and torch.equal(sP_c, sP_r)
+        else:
+            sk.filter_and_smooth(y, *shard, torch.zeros(0, shard[0].shape[1], dtype=torch.float64), B_global=B)  # (joins the gather)
+        with pytest.raises(NotImplementedError):   # every rank, empty or not
+            sk.value_and_grad(y, *shard, B_global=B, time_varying=("T",))
+        ret[rank] = dict(logp=lp.numpy(), grads={k: v.numpy() for k, v in g.items()}, lo=lo, hi=hi, sa=sa.numpy(), sP=sP.numpy(),
+                         sa_b=sa_b.numpy(), sP_b=sP_b.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -216,12 +251,14 @@ def test_sharded_value_and_grad_and_smoother_gloo(B):
     g = ka.logp_grads(w["y"], *mats, g_logp=gl)
     sa, sP = kn.kalman_smoother(w["T"], w["R"], w["Q"], flt["filtered_states"], flt["filtered_covs"])
     sa = sa.reshape(B, -1, w["m"])
+    sb, sPb = kn.smoother_from_filter(w["y"], w["T"], w["Z"], w["H"], flt["predicted_states"], flt["predicted_covs"])
     for r in range(world):
         assert np.array_equal(ret[r]["logp"], flt["logp"]), f"rank {r}"
         for k in g:
             assert np.array_equal(ret[r]["grads"][k], g[k]), (r, k)
         lo, hi = ret[r]["lo"], ret[r]["hi"]
         assert np.array_equal(ret[r]["sa"], sa[lo:hi]) and np.array_equal(ret[r]["sP"], sP[lo:hi])
+        assert np.array_equal(ret[r]["sa_b"], sb[lo:hi]) and np.array_equal(ret[r]["sP_b"], sPb[lo:hi])
 
 
 def test_bench_launcher_builds_a_torchrun_command(monkeypatch):

@@ -143,7 +143,7 @@ def test_graphs_evaluate_end_to_end_with_oracle_backed_bodies(monkeypatch):
 
     monkeypatch.setattr(op, "perform_filter", fake_filter)
     monkeypatch.setattr(op, "perform_logp_and_grad", fake_logp_and_grad)
-    def fake_fused(data, T, Z, R, H, Q, d, fs, fP, ps, pP, filter_type="standard", engine=None, batched=False):
+    def fake_fused(data, T, Z, R, H, Q, c, d, fs, fP, ps, pP, filter_type="standard", engine=None, batched=False):
         assert not batched and np.asarray(ps).shape[0] == np.asarray(fs).shape[0] + 1   # the filter node's predicted tapes came along
         return fake_smoother(T, R, Q, fs, fP)
 
@@ -170,6 +170,11 @@ def test_graphs_evaluate_end_to_end_with_oracle_backed_bodies(monkeypatch):
     assert_allclose(r2[1], res[7], rtol=1e-12)
     sm3 = op.kalman_smoother_graph(sym[3], sym[5], sym[7], outs[0], outs[2], fuse=False)
     assert "KalmanSmootherFusedOp" not in _op_names(pytensor.function(sym, list(sm3), on_unused_input="ignore"))
+    # another T than the filter node's: the predicted tapes belong to the FILTER's model -- no fusion
+    T_other = pt.matrix("T_other")
+    sm5 = op.kalman_smoother_graph(T_other, sym[5], sym[7], outs[0], outs[2])
+    names5 = _op_names(pytensor.function(sym + [T_other], list(sm5), on_unused_input="ignore"))
+    assert "KalmanSmootherOp" in names5 and "KalmanSmootherFusedOp" not in names5
     # a filter node that does not compute its predicted tapes cannot feed the fused smoother
     few2 = StandardFilter().build_graph(*sym, outputs=("filtered_states", "filtered_covariances"))
     sm4 = KalmanSmoother().build_graph(sym[3], sym[5], sym[7], few2[0], few2[2])
@@ -309,7 +314,7 @@ def test_vectorize_graph_over_the_smoother_reaches_one_batched_call(monkeypatch)
         sa, sP = kn.kalman_smoother(T, R, Q, np.asarray(fs)[..., 0], np.asarray(fP))
         return [sa.reshape(np.asarray(fs).shape), sP]
 
-    def fake_fused(data, T, Z, R, H, Q, d, fs, fP, ps, pP, filter_type="standard", engine=None, batched=False):
+    def fake_fused(data, T, Z, R, H, Q, c, d, fs, fP, ps, pP, filter_type="standard", engine=None, batched=False):
         assert batched and np.asarray(data).ndim == 3 and all(np.asarray(x).ndim == 3 for x in (T, Z, R, H, Q, d))
         assert np.asarray(ps).shape[:2] == (np.asarray(T).shape[0], np.asarray(fs).shape[1] + 1)
         calls.append(("fused", np.asarray(T).shape[0]))
@@ -442,15 +447,60 @@ def test_batched_filter_differentiates_ll_obs(monkeypatch):
 
 
 def test_which_recursion_the_fused_smoother_node_takes():
-    """op.smoother_from_filter_applies: the smoother from the filter's predicted tapes for p == 1, static matrices and 5 <= m <= 15 (on chip)
+    """op.smoother_from_filter_applies: the smoother from the filter's predicted tapes for p == 1, static matrices and m <= 15 (on chip)
     or 64 < m <= 1024 (workspace); between 16 and 64 only with state noise of few columns (12 r <= m + 11: every ARMA / SARIMA model has
     r = 1), where the RTS kernels would hand most draws to the pinv kernel (profiles/r05/smoother_mid_m_rank.txt); else kf_smoother."""
     from pymc_statespace_amd.op import smoother_from_filter_applies as f
 
     static = [2, 2, 2, 2, 2]
     assert not f(2, 10, static) and not f(1, 10, [3, 2, 2, 2, 2]) and not f(1, 10, [2, 2, 2, 3, 2])   # p > 1; a time-varying T; R
-    assert [m for m in range(1, 17) if f(1, m, static)] == list(range(5, 16))
+    assert [m for m in range(1, 17) if f(1, m, static)] == list(range(1, 16))   # (round 6: m <= 4 on the lane-per-draw kernel)
+    assert f(1, 10, static + [1]) and not f(1, 10, static + [2])   # a sixth entry: d -- (p,) static, (n,p) time-varying
     assert f(1, 65, static) and f(1, 367, static) and f(1, 1024, static) and not f(1, 1025, static)
     assert not f(1, 20, static) and not f(1, 20, static, r=20) and not f(1, 20, static, r=3)
     assert f(1, 16, static, r=1) and f(1, 20, static, r=2) and f(1, 32, static, r=3) and f(1, 48, static, r=4) and f(1, 64, static, r=6)
     assert not f(1, 32, static, r=4) and not f(1, 48, static, r=5)
+
+
+def test_fused_smoother_body_keeps_the_reference_recursion_for_a_nonzero_c_or_a_time_varying_d():
+    """ADVICE round 5 (high / medium): the reference's smoother predicts with a_hat = T a_f -- no state intercept c
+    (kalman_smoother.py:99-104) -- while the filter's predicted tapes contain c, so kf_smoother_from_filter on them differs by O(c);
+    and a time-varying d (n,p,1) is not something kf_smoother_from_filter takes.  perform_smoother_fused must hand both to kf_smoother
+    on the filtered tapes, whatever m is; c == 0 with a static d goes to the predicted-tape recursion."""
+    import numpy as np
+    import torch
+
+    from pymc_statespace_amd import op
+
+    class FakeEngine:
+        def __init__(self):
+            self.calls = []
+
+        def smooth(self, T, R, Q, fa, fP, time_varying=()):
+            self.calls.append("rts")
+            return torch.zeros(fa.shape), torch.zeros(fP.shape)
+
+        def smooth_from_filter(self, y, T, Z, H, pa, pP, d=None, filter_type="standard"):
+            self.calls.append("from_filter")
+            B, n1, m = pa.shape
+            return torch.zeros(B, n1 - 1, m), torch.zeros(B, n1 - 1, m, m)
+
+    n, m, r = 7, 10, 4
+    rng = np.random.default_rng(0)
+    data = rng.normal(size=(n, 1, 1))
+    T, Z, R, H, Q = rng.normal(size=(m, m)), rng.normal(size=(1, m)), rng.normal(size=(m, r)), np.eye(1), np.eye(r)
+    fs, fP, ps, pP = np.zeros((n, m, 1)), np.zeros((n, m, m)), np.zeros((n + 1, m, 1)), np.zeros((n + 1, m, m))
+    c0, d0 = np.zeros((m, 1)), np.zeros((1, 1))
+    for c, d, want in ((c0, d0, "from_filter"), (c0 + 0.5, d0, "rts"), (c0, np.zeros((n, 1, 1)), "rts"), (c0, d0 + 2.0, "from_filter")):
+        eng = FakeEngine()
+        out = op.perform_smoother_fused(data, T, Z, R, H, Q, c, d, fs, fP, ps, pP, engine=eng)
+        assert eng.calls == [want], (eng.calls, want)
+        assert out[0].shape == (n, m, 1) and out[1].shape == (n, m, m)
+    # the batched image: one leading draw axis on everything but the shared data
+    B = 3
+    lead = lambda x: np.broadcast_to(x, (B,) + x.shape).copy()  # noqa: E731
+    for c, want in ((lead(c0), "from_filter"), (lead(c0) + np.array([0.0, 0.0, 1e-3])[:, None, None], "rts")):
+        eng = FakeEngine()
+        out = op.perform_smoother_fused(data, lead(T), lead(Z), lead(R), lead(H), lead(Q), c, lead(d0), lead(fs), lead(fP), lead(ps),
+                                        lead(pP), engine=eng, batched=True)
+        assert eng.calls == [want] and out[0].shape == (B, n, m, 1)
