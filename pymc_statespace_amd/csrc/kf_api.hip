@@ -762,6 +762,15 @@ extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, i
     const size_t sw = kf_b4_split_workspace_bytes(dims->B, m, dims->T);
     if (sw > *bytes) *bytes = sw;
   }
+  // forward, block kernel on a small batch: the time-chunked pipeline's buffers (kf_forward_b4c.hip); without them the sequential kernel runs
+  if ((which & KF_WS_FORWARD) && dims->T >= 1 && kf_b4_selected(h, m, p, r, dims->B) &&
+      kf_forward_b4c_shape_ok(h, dims->B, dims->T, p, m, r, dims->flags)) {
+    int cs = 0, cn = 0;
+    kf_forward_b4c_plan(h, dims->B, dims->T, &cs, &cn);
+    B4cWs Wc;
+    const size_t cw = kf_forward_b4c_carve(nullptr, dims->B, dims->T, m, cn, &Wc);
+    if (cw > *bytes) *bytes = cw;
+  }
   // forward, multi-observation block kernel with its steady-state phase: hand-over buffers + per-draw constants of the split phase
   if ((which & KF_WS_FORWARD) && !(dims->flags & (KF_FLAG_TV_ANY | KF_FLAG_EXACT_RECURSION)) && p >= 3 && p <= 5 && m >= 8 && m <= 15 &&
       dims->T >= 64 && (kf_b4q_selected(h, m, p, r, dims->filter, dims->flags, dims->B) ||

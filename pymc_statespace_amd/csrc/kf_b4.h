@@ -166,15 +166,18 @@ struct B4Const {
 // synchronisation is wave-local (LDS executes a wavefront's instructions in order).  On return
 // scratch[0 .. 16 TRS) is a zeroed transpose tile except for the entries the registers wrote.
 // `tile` (default: scratch itself): where the zeroed transpose tile is left, anywhere inside the scratch.
+// `P0w` / `a0w` (default: the draw's P0 / a0): another initial covariance (m x m, row-major) and mean (m; with `a0_zero` set: zeros) --
+// the time-chunked pipeline starts chunk j > 0 of a draw from ck_start[b][j] and the mean c (kf_forward_b4c.hip).
 template <int NB, bool HALF_>
 __device__ __forceinline__ void b4_setup(const KfFwdArgs& A, long b, double* scratch, int lane, B4Const<NB, HALF_>& K,
-                                         double* tile = nullptr) {
+                                         double* tile = nullptr, const double* P0w = nullptr, const double* a0w = nullptr,
+                                         bool a0_zero = false) {
   constexpr int N4 = 4 * NB, JA = N4 - 2, JC = N4 - 1;
   constexpr bool HALF_STATIC = HALF_;
   const int g = lane >> 4, bq = lane & 15;
   const int fb = (lane & 3) * 4 + ((lane >> 2) & 3);
   const int r_ = A.r, m = A.m, mm = m * m;
-  const double* gP = A.P0 + b * (long)mm;
+  const double* gP = P0w ? P0w : A.P0 + b * (long)mm;
   {
     double* sT = scratch;              // T    m x m
     double* sP = sT + mm;              // P0   m x m (as given; the upper triangle is used)
@@ -201,7 +204,7 @@ __device__ __forceinline__ void b4_setup(const KfFwdArgs& A, long b, double* scr
       for (int e = lane; e < r_ * r_; e += KF_WAVE) sQ[e] = gQ[e];
       if (lane < m) {
         sZ[lane] = gZ[lane];
-        sa[lane] = A.a0[b * (long)m + lane];
+        sa[lane] = a0_zero ? 0.0 : (a0w ? a0w[lane] : A.a0[b * (long)m + lane]);
         sc[lane] = A.c ? A.c[b * (long)m + lane] : 0.0;
       }
     }

@@ -86,6 +86,11 @@ __device__ __forceinline__ void sfor(F&& f) {
 // (kf_backward_steady.hip): the tile tape is written for the steps of the covariance recursion only; from the convergence point ts
 // on the mean recursion leaves a_t in the compact predicted-state tape (slots ts .. n) -- all the steady-state adjoint reads -- and
 // the draw reports ts (A.hs_ts) and its converged predicted covariance (A.vg_P)
+// SS == 3 (round 6): one TIME CHUNK of the chunked pipeline for small batches (kf_forward_b4c.hip; KfFwdArgs::ck_*): workgroup i runs
+// chunk i % ck_nc of draw i / ck_nc from that chunk's own predicted covariance -- the covariance sequence of a static model without
+// missing observations does not depend on y, and its value at the chunk boundaries comes from log2(s) squarings of the s-step
+// Riccati map -- with the mean started at c; the steps are the very arithmetic of SS == 0.  Covariance tapes are final; the state
+// tapes hold the zero-start trajectory until the mean pass adds the draw's own; (F, v) and the gains go to the workspace
 template <int NB, bool STREAM, int TM, int SS>
 __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) void kf_fwd_b4_kernel(const KfFwdArgs A) {
   // (waves_per_eu(4): <= 128 registers, and the compiler then keeps MFMA results in VGPRs -- no v_accvgpr moves)
@@ -108,6 +113,15 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   }
   if constexpr (VGS) {
     if (A.order) b = A.order[blockIdx.x];
+  }
+  if (A.run_if && *A.run_if == 0) return;   // (the sequential redo behind the chunked pipeline: only when that raised its flag)
+  int cj = 0;   // (SS == 3) this workgroup's chunk
+  if constexpr (SS == 3) {
+    if (*A.ck_flag) return;
+    cj = (int)(blockIdx.x % (unsigned)A.ck_nc);
+    b = blockIdx.x / (unsigned)A.ck_nc;
+    t0 = cj ? cj * A.ck_s + 1 : 0;
+    t1 = (cj + 1) * A.ck_s + 1 < n ? (cj + 1) * A.ck_s + 1 : n;
   }
 
   // The tape rings' absolute slot addresses need the dynamic block on a multiple of the ring size -- true while it is the kernel's
@@ -148,7 +162,10 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     }
     wave_lds_fence();
   } else {
-    b4_setup(A, b, smem, lane, KC, TR);
+    if (SS == 3 && cj > 0)
+      b4_setup(A, b, smem, lane, KC, TR, A.ck_start + ((long)b * A.ck_nc + cj) * mm, A.c ? A.c + b * (long)m : nullptr, A.c == nullptr);
+    else
+      b4_setup(A, b, smem, lane, KC, TR);
     if (SS == 2 && t1 < n) {
       double* hc = A.hs_const + b * (long)B4_HC_STRIDE + lane;
 #pragma unroll
@@ -331,9 +348,17 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     __syncthreads();
     const int ls = lane & (LB - 1);
     const double2_t fq = *reinterpret_cast<const double2_t*>(RG + 2 * ls);
-    const bool act = lane < cnt;
+    const bool act = lane < cnt && (SS != 3 || tb + lane >= t0);   // (a chunk may start inside a block: the ring's earlier slots are not its own)
     const bool observed = act && YB[2 * ls + 1] != 0.0;
     const double Fv = fq.x;
+    if constexpr (SS == 3) {
+      // the likelihood is the mean pass's (v of the draw's own mean); a missing observation, a skipped step or an F that is not
+      // positive is the sequential kernel's business: raise the flag
+      if (__ballot(act && !(observed && Fv > 0.0)) != 0ull && lane == 0) *A.ck_flag = 1;
+      if (act) *reinterpret_cast<double2_t*>(A.ck_fv + 2 * (b * (long)n + tb + lane)) = fq;
+      __syncthreads();
+      return;
+    }
     const bool skipped = observed && univariate && Fv == 0.0;      // :468-471
     const bool notpd = observed && !skipped && !(Fv > 0.0);
     const unsigned long long bad = __ballot(notpd);
@@ -368,7 +393,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   // the gain, F and both covariances are constants and only the mean is left: a_{t+1} = (T - T K Z) a_t + T K (y_t -+ d) + c
   // -- the loop at the end of this kernel.  (statsmodels' Kalman filter does the same by default, `tolerance`; the
   // reference recomputes everything every step, results agree to ~1e-13 relative.  KF_FLAG_EXACT_RECURSION switches it off.)
-  const bool steady_en = SS != 0 && STREAM && (!w_tile || VGS) && n >= 64;
+  const bool steady_en = (SS == 1 || SS == 2) && STREAM && (!w_tile || VGS) && n >= 64;
   int t_free = 0;  // first step after the last missing observation
   if (SS == 2 && t0 > 0) {
     t_free = A.hs_tfree[b];
@@ -389,7 +414,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
   int npass = 0;       // consecutive convergence checks passed
   bool handed = false; // (SS == 2) the covariance has converged: the steady kernels take over at step t
   for (; t < t1; ++t) {
-    if ((t & (LB - 1)) == 0) load_y_block(t);
+    if ((t & (LB - 1)) == 0 || (SS == 3 && t == t0)) load_y_block(t & ~(LB - 1));
     const bool chk = steady_en && (t & 7) == 7 && t >= t_free && t + 16 < n;  // wave-uniform
     if (chk && !w_pP) {  // the predicted covariance this step starts from, parked in the (unused) tape ring
 #pragma unroll
@@ -420,6 +445,10 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     // tile -= u_hat u_hat'
 #pragma unroll
     for (int I = 0; I < NB; ++I) P[I] = mfma4_nega(urep[I] * rs, uh, P[I]);
+    if constexpr (SS == 3) {
+      if (g == 2 && bq < m) A.ck_K[(b * (long)n + t) * m + bq] = uh * rs;                                  // K_t = P_t Z' / F_t
+      if (t == t1 - 1 && vec_on) A.ck_zend[((long)b * A.ck_nc + cj) * m + bq] = 0.5 * P[NB - 1];          // a_f of the chunk's last step
+    }
     if (w_tile) {
       const double rs_t = (univariate && F == 0.0) ? 0.0 : rs;  // a skipped step has no adjoint terms (:468-471)
       const double rowv = (lane == 32 + JA) ? rs_t : uh;          // (u_hat sits in row JA of the last register already)
@@ -634,6 +663,24 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) vo
     s_pP.finish(lane, 1.0);
   }
   if (t & (LB - 1)) flush_ring(t & ~(LB - 1), t & (LB - 1));  // (t == n, or the step a chunk stopped at)
+  if constexpr (SS == 3) {
+    // P is the predicted tile of step t1 -- where the next chunk of this draw started from the doubling's covariance: the two must
+    // agree (ck_tol of the largest entry), else nobody vouches for the batch and the sequential kernel redoes it
+    if (cj + 1 < A.ck_nc) {
+      const double* ns = A.ck_start + ((long)b * A.ck_nc + cj + 1) * mm;
+      unsigned pm = 0;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+        if (on[I]) pm = max(pm, abs_hi(P[I]));
+      const double lim = A.ck_tol * wave_absmax_hi(pm);
+      bool bad = false;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+        if (on[I]) bad = bad || !(fabs(P[I] - ns[(4 * I + g) * m + bq]) <= lim);
+      if (__ballot(bad) != 0ull && lane == 0) *A.ck_flag = 1;
+    }
+    return;   // (logp, info, ll_obs and the draw's own means: kf_b4c_mean_kernel)
+  }
   if constexpr (SS == 2) {
     if (t < n) {  // hand-over: to the next chunk (-1) or, converged, to the steady kernels (step t)
       double* ht = A.hs_tile + b * (long)B4_HS_STRIDE + lane;
@@ -1043,10 +1090,65 @@ static int b4_split_chunk(int n) {
   return ch;
 }
 
-int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  if (!kf_forward_b4_ok(a.m, a.p, a.r) || (a.flags & KF_FLAG_TV_ANY)) {
-    KF_SET_ERR(h, "forward(b4): needs p == 1, m <= 14, static matrices (got p=%d m=%d r=%d)", a.p, a.m, a.r);
+// the chunk instantiation of the block kernel (SS == 3), B x nc wavefronts
+static int b4_launch_chunks(kf_handle* h, const KfFwdArgs& a, hipStream_t stream) {
+  const int lds_setup = b4_setup_doubles(a.m, a.r);
+  const size_t lds = sizeof(double) * (size_t)(B4_LOOP_DOUBLES > lds_setup ? B4_LOOP_DOUBLES : lds_setup);
+  const int nb = (a.m + 2 + 3) / 4;
+  const int mask = (a.filt_a ? 1 : 0) | (a.pred_a ? 2 : 0) | (a.filt_P ? 4 : 0) | (a.pred_P ? 8 : 0);
+  const unsigned grid = (unsigned)(a.B * a.ck_nc);
+#define KF_B4C_GO(NB_, TM_)                                                                          \
+  do {                                                                                               \
+    auto kfn_ = kf_fwd_b4_kernel<NB_, true, TM_, 3>;                                                 \
+    const int rc_ = b4_static_lds_free(h, reinterpret_cast<const void*>(kfn_));                      \
+    if (rc_) return rc_;                                                                             \
+    hipLaunchKernelGGL(kfn_, dim3(grid), dim3(KF_WAVE), lds, stream, a);                             \
+  } while (0)
+#define KF_B4C_LAUNCH(NB_)                        \
+  do {                                            \
+    if (mask == 15) KF_B4C_GO(NB_, 15);           \
+    else if (mask == 0) KF_B4C_GO(NB_, 0);        \
+    else KF_B4C_GO(NB_, -1);                      \
+  } while (0)
+  switch (nb) {
+    case 1: KF_B4C_LAUNCH(1); break;
+    case 2: KF_B4C_LAUNCH(2); break;
+    default: KF_B4C_LAUNCH(3); break;
+  }
+#undef KF_B4C_LAUNCH
+#undef KF_B4C_GO
+  KF_HIP_CHECK(h, hipGetLastError());
+  return KF_OK;
+}
+
+int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a_in, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!kf_forward_b4_ok(a_in.m, a_in.p, a_in.r) || (a_in.flags & KF_FLAG_TV_ANY)) {
+    KF_SET_ERR(h, "forward(b4): needs p == 1, m <= 14, static matrices (got p=%d m=%d r=%d)", a_in.p, a_in.m, a_in.r);
     return KF_ERR_UNSUPPORTED;
+  }
+  KfFwdArgs a = a_in;
+  // Round 6: small batches through the time-chunked pipeline (kf_forward_b4c.hip) -- doubling for the chunk-start covariances, B x nc
+  // chunk wavefronts, the mean pass -- and, behind it, the sequential kernel with run_if = the pipeline's flag (a missing observation,
+  // a chunk whose end does not meet its successor's start: rare, and then the whole batch is redone; nothing synchronises the host)
+  if (!a.tile_tape && !a.list && !a.hs_ts && !a.run_if && a.t_end == 0 && workspace &&
+      kf_forward_b4c_shape_ok(h, a.B, a.T, a.p, a.m, a.r, a.flags)) {
+    int cs = 0, cn = 0;
+    kf_forward_b4c_plan(h, a.B, a.T, &cs, &cn);
+    B4cWs W;
+    const size_t need = kf_forward_b4c_carve(nullptr, a.B, a.T, a.m, cn, &W);
+    if (cn >= 2 && workspace_bytes >= need) {
+      void* wbase = (void*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+      kf_forward_b4c_carve(wbase, a.B, a.T, a.m, cn, &W);
+      KfFwdArgs ac = a;
+      ac.ck_nc = cn; ac.ck_s = cs; ac.ck_start = W.start; ac.ck_K = W.K; ac.ck_fv = W.fv; ac.ck_zend = W.zend; ac.ck_flag = W.flag;
+      int rc = kf_launch_b4c_starts(h, ac, W, cs, cn, stream);
+      if (rc) return rc;
+      rc = b4_launch_chunks(h, ac, stream);
+      if (rc) return rc;
+      rc = kf_launch_b4c_means(h, ac, W, cs, cn, stream);
+      if (rc) return rc;
+      a.run_if = W.flag;   // the sequential kernel below: a no-op unless the pipeline raised its flag
+    }
   }
   // Small batches with covariance tapes: the pair kernel (kf_forward_b4p.hip) from step 0.  With at most one draw per SIMD the
   // step time is one wavefront's dependency chain, and a writer wavefront takes the tape path off it (measured, 1000 steps:
@@ -1059,12 +1161,12 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size
     // in the environment, which include/kf.h documents as the same request -- gets the kernels that have one)
     const char* sreq = kf_env_switch("KF_STEADY_STATE");
     const bool steady_requested = !(a.flags & KF_FLAG_EXACT_RECURSION) && ((a.flags & KF_FLAG_STEADY_STATE) || (sreq && atoi(sreq) != 0));
-    bool pair = a.B <= B4_PAIR_MAX && (a.filt_P || a.pred_P) && !steady_requested;
+    bool pair = a.B <= B4_PAIR_MAX && (a.filt_P || a.pred_P) && !steady_requested && !a.run_if;
     if (e && *e) {
       pair = atoi(e) != 0;
       pair_env_off = !pair;
     }
-    if (pair && !a.tile_tape && kf_forward_b4p_ok(a.m, a.p, a.r)) return kf_launch_forward_b4p(h, a, stream);
+    if (pair && !a.tile_tape && !a.run_if && kf_forward_b4p_ok(a.m, a.p, a.r)) return kf_launch_forward_b4p(h, a, stream);
   }
   const int lds_setup = b4_setup_doubles(a.m, a.r);
   const size_t lds = sizeof(double) * (size_t)(B4_LOOP_DOUBLES > lds_setup ? B4_LOOP_DOUBLES : lds_setup);
@@ -1087,7 +1189,7 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size
   // (tried: capping the residency of this instantiation at 3 / 2 wavefronts per SIMD so that the dispatcher hands queued draws to the
   // SIMDs whose draws converged early -- headline 2.29 / 2.44 ms against 1.63: the queued wavefronts run as a second round)
   // split pipeline: recursion chunks over compacted draw lists + the time-parallel steady kernels on the second stream
-  const bool split = ss && nb <= 3 && workspace && kf_forward_b4_split_ok(h, a.B, a.T, a.p, a.m, a.r, a.flags) &&
+  const bool split = ss && nb <= 3 && workspace && !a.run_if && kf_forward_b4_split_ok(h, a.B, a.T, a.p, a.m, a.r, a.flags) &&
                      workspace_bytes >= kf_b4_split_workspace_bytes(a.B, a.m, a.T);
   KfFwdArgs ac = a;  // (the chunk's arguments in split mode)
 #define KF_B4_LAUNCH2(NB_, ST_, TM_)                                                                                       \

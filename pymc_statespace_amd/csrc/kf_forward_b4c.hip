@@ -1,0 +1,565 @@
+// kf_forward_b4c.hip -- the time-chunked forward pipeline for SMALL batches (p == 1, m <= 10, static matrices, no missing observation):
+// the two kernels either side of the block kernel's chunk instantiation (kf_forward_b4.hip, SS == 3).
+//
+// What it is for.  The reference evaluates one draw at a time (core/statespace.py:230-236 around the scan of
+// filters/kalman_filter.py:126-163); this library's batch axis fills the chip from ~4096 draws on.  One GPU's share of the north-star
+// batch is 512 draws -- one wavefront per TWO SIMDs -- and a launch then lasts as long as one wavefront's chain of T dependent steps
+// (1000 x 0.58 us = 0.58 ms whatever the batch: the >= 6x strong-scaling clause of BASELINE.json stood at 2.7x, profiles/r05/strong_proxy.md).
+// The chain can be cut: for a static model without missing observations the covariance sequence (predict :215-223, update :255-284) does
+// not depend on y, and the map of the FILTERED covariance over s steps is ONE element (A, C, J) of the associative operator of
+// Sarkka & Garcia-Fernandez (2021, "Temporal parallelization of Bayesian smoothers", Lemma 8),
+//     Phi(P) = A (I + P J)^-1 P A' + C,
+// raised to the s-th power.  Because every step's element is the SAME, Phi_s costs log2(s) SQUARINGS per draw -- the structure-
+// preserving doubling iteration of the Riccati literature -- not one combine per time step (what DESIGN section 6 costed and rejected):
+//     one step:   S0 = Z Qt Z' + H,  K0 = Qt Z' / S0,  A1 = (I - K0 Z) T,  C1 = (I - K0 Z) Qt,  J1 = (Z T)' (Z T) / S0      (Qt = R Q R')
+//     squaring:   D = (I + C J)^-1,  A <- A D A,  C <- A D C A' + C,  J <- A' J D A + J
+//     applying:   D = (I + P_f J)^-1,  Psi = A D,  P_f <- Psi P_f A' + C      and the MEAN of the same steps:  a_f <- Psi a_f + (zero-start response)
+// (needs S0 > 0 -- H > 0 or state noise the observation sees: every model of the reference; else the flag below).  Prototype and error
+// budget: scripts/r06/chunk_proto.py (chunk-start covariances within 1e-15 of the sequential recursion on the BASELINE workloads, a
+// P0 = 1e6 I start included).
+//
+// Pipeline (kf_launch_forward_b4, kf_forward_b4.hip):
+//   1. kf_b4c_starts_kernel   one wavefront per draw: the doubling (plain fp64 FMAs on LDS-resident m x m matrices, Gauss-Jordan with
+//                             partial pivoting for D), then P_f(k s) for k = 1 .. nc-1 one after the other; leaves the predicted
+//                             covariance T P_f(k s) T' + Qt every chunk starts from and Psi_k
+//   2. kf_fwd_b4_kernel<.., SS = 3>   B x nc wavefronts: chunk k of a draw runs steps [k s + 1, (k + 1) s + 1) (chunk 0 from step 0)
+//                             -- the unchanged arithmetic of the sequential kernel -- with its mean started at c: covariance tapes final,
+//                             state tapes hold the zero-start trajectory, gains / (F, v) / last filtered mean go to the workspace
+//   3. kf_b4c_mean_kernel     one workgroup per draw, one wavefront per chunk: a_f(k s) = Psi_{k-1} a_f((k-1) s) + z_{k-1} chains the
+//                             chunks (nc matrix-vector products), then each wavefront adds the homogeneous response h_t of its chunk's
+//                             start (h <- T (h - K_t Z h): one m x m matrix-vector product per step) to the state tapes and evaluates
+//                             the likelihood with v_t = v_t(zero start) - Z h_t
+// Self-check instead of trust: every chunk compares the covariance it ENDS with against the one its successor STARTED from (1e-12 of the
+// largest entry); a mismatch, a missing observation, S0 <= 0 or an F <= 0 raises a device flag and the sequential kernel, launched
+// behind with run_if = flag, redoes the batch -- no host synchronisation, the call stays asynchronous.
+// KF_FLAG_EXACT_RECURSION (or KF_FORWARD_CHUNKED=0 in the environment) keeps the sequential kernel: the chunked covariances are the
+// recursion's own up to rounding (<= 1e-13 relative), but not bit for bit.
+#include <type_traits>
+
+#include "kf_b4.h"
+#include "kf_b4_split.h"
+
+namespace {
+
+constexpr int B4C_MAXM = 10;   // (the block kernel's ring-streamed range, NB <= 3)
+
+// ---- small dense helpers on LDS-resident M x M matrices (row-major, leading dimension M), one wavefront; M is a compile-time constant:
+// every loop unrolls, the LDS reads of a product are issued back to back (first version: run-time m, 183 us for 512 draws; now ~50)
+// out = op(X) op(Y) [+ E], element per lane and round.  `out` may alias an operand: every lane reads all it needs before any lane writes
+template <int M, bool TX, bool TY>
+__device__ __forceinline__ void b4c_mul(double* out, const double* X, const double* Y, const double* E, int lane) {
+  constexpr int MM = M * M, RD = (MM + KF_WAVE - 1) / KF_WAVE;
+  double acc[RD];
+#pragma unroll
+  for (int rd = 0; rd < RD; ++rd) {
+    int e = lane + KF_WAVE * rd;
+    const bool on = MM % KF_WAVE == 0 || e < MM;
+    e = on ? e : 0;
+    const int i = e / M, j = e - i * M;
+    double a0 = E ? E[e] : 0.0, a1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < M; k += 2) {
+      a0 = fma(TX ? X[k * M + i] : X[i * M + k], TY ? Y[j * M + k] : Y[k * M + j], a0);
+      if (k + 1 < M) a1 = fma(TX ? X[(k + 1) * M + i] : X[i * M + k + 1], TY ? Y[j * M + k + 1] : Y[(k + 1) * M + j], a1);
+    }
+    acc[rd] = a0 + a1;
+  }
+  wave_lds_fence();
+#pragma unroll
+  for (int rd = 0; rd < RD; ++rd) {
+    const int e = lane + KF_WAVE * rd;
+    if (MM % KF_WAVE == 0 || e < MM) out[e] = acc[rd];
+  }
+  wave_lds_fence();
+}
+// X <- (X + X') / 2
+template <int M>
+__device__ __forceinline__ void b4c_sym(double* X, int lane) {
+  constexpr int MM = M * M, RD = (MM + KF_WAVE - 1) / KF_WAVE;
+  double v[RD];
+#pragma unroll
+  for (int rd = 0; rd < RD; ++rd) {
+    int e = lane + KF_WAVE * rd;
+    e = e < MM ? e : 0;
+    const int i = e / M, j = e - i * M;
+    v[rd] = 0.5 * (X[e] + X[j * M + i]);
+  }
+  wave_lds_fence();
+#pragma unroll
+  for (int rd = 0; rd < RD; ++rd) {
+    const int e = lane + KF_WAVE * rd;
+    if (e < MM) X[e] = v[rd];
+  }
+  wave_lds_fence();
+}
+// D <- (I + X Y)^-1 by Gauss-Jordan with partial pivoting on the augmented [I + X Y | I] (AUG: M x 2M); false: singular
+template <int M>
+__device__ __forceinline__ bool b4c_inv_ipxy(double* D, double* AUG, const double* X, const double* Y, int lane) {
+  constexpr int MM = M * M, W2 = 2 * M, RD = (MM + KF_WAVE - 1) / KF_WAVE, RE = (M * W2 + KF_WAVE - 1) / KF_WAVE;
+#pragma unroll
+  for (int rd = 0; rd < RD; ++rd) {
+    const int e = lane + KF_WAVE * rd;
+    if (e < MM) {
+      const int i = e / M, j = e - i * M;
+      double a0 = (i == j) ? 1.0 : 0.0, a1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < M; k += 2) {
+        a0 = fma(X[i * M + k], Y[k * M + j], a0);
+        if (k + 1 < M) a1 = fma(X[i * M + k + 1], Y[(k + 1) * M + j], a1);
+      }
+      AUG[i * W2 + j] = a0 + a1;
+      AUG[i * W2 + M + j] = (i == j) ? 1.0 : 0.0;
+    }
+  }
+  wave_lds_fence();
+  bool ok = true;
+#pragma unroll 1
+  for (int k = 0; k < M; ++k) {
+    // pivot: the largest |entry| of column k in rows k .. M-1 (M <= 16: the lanes of one DPP row)
+    double v = (lane >= k && lane < M) ? fabs(AUG[lane * W2 + k]) : -1.0;
+    int idx = lane;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+      const double v2 = __shfl_xor(v, off, KF_WAVE);
+      const int i2 = __shfl_xor(idx, off, KF_WAVE);
+      const bool take = v2 > v || (v2 == v && i2 < idx);
+      v = take ? v2 : v;
+      idx = take ? i2 : idx;
+    }
+    const int p = __builtin_amdgcn_readfirstlane(idx);
+    const double pv = uniform_f64(v);
+    if (!(pv > 0.0)) {
+      ok = false;
+      break;
+    }
+    // rows k <-> p, row k scaled by 1 / pivot
+    if (lane < W2) {
+      const double rk = AUG[k * W2 + lane], rp = AUG[p * W2 + lane];
+      const double piv = AUG[p * W2 + k];
+      wave_lds_fence();
+      AUG[p * W2 + lane] = rk;
+      AUG[k * W2 + lane] = rp * fast_rcp(fabs(piv)) * (piv < 0.0 ? -1.0 : 1.0);
+    }
+    wave_lds_fence();
+    // eliminate column k from every other row: all reads, then all writes (LDS is in order within the wavefront)
+    double f[RE], rkj[RE], x[RE];
+#pragma unroll
+    for (int rd = 0; rd < RE; ++rd) {
+      int e = lane + KF_WAVE * rd;
+      e = e < M * W2 ? e : 0;
+      const int i = e / W2, j = e - i * W2;
+      f[rd] = AUG[i * W2 + k];
+      rkj[rd] = AUG[k * W2 + j];
+      x[rd] = AUG[e];
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int rd = 0; rd < RE; ++rd) {
+      const int e = lane + KF_WAVE * rd;
+      const int i = e / W2;
+      if (e < M * W2 && i != k) AUG[e] = fma(-f[rd], rkj[rd], x[rd]);
+    }
+    wave_lds_fence();
+  }
+#pragma unroll
+  for (int rd = 0; rd < RD; ++rd) {
+    const int e = lane + KF_WAVE * rd;
+    if (e < MM) {
+      const int i = e / M, j = e - i * M;
+      D[e] = AUG[i * W2 + M + j];
+    }
+  }
+  wave_lds_fence();
+  return ok;
+}
+
+// ---- 1. chunk-start covariances by doubling --------------------------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(KF_WAVE) void kf_b4c_starts_kernel(const KfFwdArgs A, const B4cWs W, int s, int nc) {
+  constexpr int MM = M * M;
+  __shared__ double sT[MM], sQ[MM], sA[MM], sC[MM], sJ[MM], sD[MM], sX[MM], sY[MM], sV[MM], sP[MM], sAUG[2 * MM], sv[4 * 16];
+  const int lane = threadIdx.x;
+  const long b = blockIdx.x;
+  const int n = A.T, r_ = A.r;
+  double* sZ = sv;
+  double* sK0 = sv + 16;
+  double* sZT = sv + 32;
+  double* sMv = sv + 48;
+  // a missing observation makes the covariance path depend on the data: the sequential kernel's business
+  {
+    const double* yb = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n : 0L);
+    bool nan = false;
+    for (int e = lane; e < n; e += KF_WAVE) {
+      const double yv = yb[e];
+      nan = nan || (yv != yv);
+    }
+    if (__ballot(nan) != 0ull) {
+      if (lane == 0) *W.flag = 1;
+      return;
+    }
+  }
+  {
+    const double* gT = A.Tm + b * (long)MM;
+    const double* gR = A.R + b * (long)M * r_;
+    const double* gQ = A.Q + b * (long)r_ * r_;
+    const double* gP = A.P0 + b * (long)MM;
+    for (int e = lane; e < MM; e += KF_WAVE) {
+      const int i = e / M, j = e - i * M;
+      sT[e] = gT[e];
+      sP[e] = (j >= i) ? gP[e] : gP[j * M + i];   // the upper triangle, as b4_setup reads P0
+      double acc = 0.0;
+      for (int l = 0; l < r_; ++l) {
+        double rq = 0.0;
+        for (int k = 0; k < r_; ++k) rq = fma(gR[i * r_ + k], gQ[k * r_ + l], rq);
+        acc = fma(rq, gR[j * r_ + l], acc);
+      }
+      sQ[e] = acc;
+    }
+    if (lane < M) sZ[lane] = A.Z[b * (long)M + lane];
+  }
+  wave_lds_fence();
+  b4c_sym<M>(sQ, lane);
+  const double H1 = A.H[b];
+  // ---- the one-step element --------------------------------------------------------------------------------------------------------
+  if (lane < M) {
+    double qz = 0.0, zt = 0.0;
+#pragma unroll
+    for (int l = 0; l < M; ++l) {
+      qz = fma(sQ[lane * M + l], sZ[l], qz);
+      zt = fma(sZ[l], sT[l * M + lane], zt);
+    }
+    sK0[lane] = qz;   // Qt Z'
+    sZT[lane] = zt;   // Z T
+  }
+  wave_lds_fence();
+  double S0 = H1;
+#pragma unroll
+  for (int l = 0; l < M; ++l) S0 = fma(sZ[l], sK0[l], S0);
+  if (!(S0 > 0.0)) {
+    if (lane == 0) *W.flag = 1;
+    return;
+  }
+  const double rS0 = 1.0 / S0;
+  for (int e = lane; e < MM; e += KF_WAVE) {
+    const int i = e / M, j = e - i * M;
+    const double k0 = sK0[i] * rS0;
+    sA[e] = fma(-k0, sZT[j], sT[e]);          // (I - K0 Z) T
+    sC[e] = fma(-k0, sK0[j], sQ[e]);          // Qt - Qt Z' Z Qt / S0
+    sJ[e] = sZT[i] * sZT[j] * rS0;
+  }
+  wave_lds_fence();
+  b4c_sym<M>(sC, lane);
+  // ---- log2(s) squarings ----------------------------------------------------------------------------------------------------------------
+#pragma unroll 1
+  for (int k = 1; k < s; k <<= 1) {
+    if (!b4c_inv_ipxy<M>(sD, sAUG, sC, sJ, lane)) {
+      if (lane == 0) *W.flag = 1;
+      return;
+    }
+    b4c_mul<M, false, false>(sX, sA, sD, nullptr, lane);   // X = A D
+    b4c_mul<M, false, false>(sY, sX, sC, nullptr, lane);   // Y = A D C
+    b4c_mul<M, false, false>(sV, sJ, sD, nullptr, lane);   // V = J D
+    b4c_mul<M, true, false>(sD, sA, sV, nullptr, lane);    // D = A' J D
+    b4c_mul<M, false, false>(sJ, sD, sA, sJ, lane);        // J <- A' J D A + J
+    b4c_mul<M, false, true>(sC, sY, sA, sC, lane);         // C <- A D C A' + C
+    b4c_mul<M, false, false>(sA, sX, sA, nullptr, lane);   // A <- A D A
+    b4c_sym<M>(sC, lane);
+    b4c_sym<M>(sJ, lane);
+  }
+  // ---- P_f(0): the update of step 0 ------------------------------------------------------------------------------------------------------
+  if (lane < M) {
+    double mv = 0.0;
+#pragma unroll
+    for (int l = 0; l < M; ++l) mv = fma(sP[lane * M + l], sZ[l], mv);
+    sMv[lane] = mv;
+  }
+  wave_lds_fence();
+  double F0 = H1;
+#pragma unroll
+  for (int l = 0; l < M; ++l) F0 = fma(sZ[l], sMv[l], F0);
+  if (!(F0 > 0.0)) {
+    if (lane == 0) *W.flag = 1;
+    return;
+  }
+  {
+    const double rF = 1.0 / F0;
+    constexpr int RD = (MM + KF_WAVE - 1) / KF_WAVE;
+    double v[RD];
+#pragma unroll
+    for (int rd = 0; rd < RD; ++rd) {
+      int e = lane + KF_WAVE * rd;
+      e = e < MM ? e : 0;
+      const int i = e / M, j = e - i * M;
+      v[rd] = fma(-sMv[i] * rF, sMv[j], sP[e]);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int rd = 0; rd < RD; ++rd) {
+      const int e = lane + KF_WAVE * rd;
+      if (e < MM) sP[e] = v[rd];
+    }
+    wave_lds_fence();
+  }
+  // ---- P_f(k s), k = 1 .. nc - 1, and what chunk k starts from ------------------------------------------------------------------------------
+#pragma unroll 1
+  for (int k = 1; k < nc; ++k) {
+    if (!b4c_inv_ipxy<M>(sD, sAUG, sP, sJ, lane)) {
+      if (lane == 0) *W.flag = 1;
+      return;
+    }
+    b4c_mul<M, false, false>(sX, sA, sD, nullptr, lane);   // Psi_{k-1} = A D: a_f(k s) = Psi_{k-1} a_f((k-1) s) + ...
+    b4c_mul<M, false, false>(sY, sX, sP, nullptr, lane);   // Psi P_f
+    b4c_mul<M, false, true>(sP, sY, sA, sC, lane);         // P_f(k s)
+    b4c_sym<M>(sP, lane);
+    b4c_mul<M, false, false>(sY, sT, sP, nullptr, lane);   // T P_f
+    b4c_mul<M, false, true>(sD, sY, sT, sQ, lane);         // T P_f T' + Qt
+    b4c_sym<M>(sD, lane);
+    double* gs = W.start + ((long)b * nc + k) * MM;
+    double* gp = W.psi + ((long)b * nc + k - 1) * MM;
+    for (int e = lane; e < MM; e += KF_WAVE) {
+      gs[e] = sD[e];
+      gp[e] = sX[e];
+    }
+  }
+}
+
+// ---- 3. the mean pass ----------------------------------------------------------------------------------------------------------------------
+// lane L of every DPP row -> all sixteen lanes of its row (row_newbcast: one v_mov_dpp per dword, no trip through the LDS crossbar)
+template <int LSRC>
+__device__ __forceinline__ double row_bcast(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0x150 + LSRC, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0x150 + LSRC, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int I = 0, typename F>
+__device__ __forceinline__ void sfor10(F&& f) {
+  if constexpr (I < B4C_MAXM) {
+    f(std::integral_constant<int, I>{});
+    sfor10<I + 1>(f);
+  }
+}
+constexpr int MB = 32;   // steps per LDS block
+struct B4cMeanLds {
+  // per wavefront: K block [MB][12], zero-start filtered / predicted means [MB][12] each (in place: the draw's own on the way out),
+  // per-step scalars [MB][4] = {v (zero start), 1 / F, log F, v^2 / F}
+  static constexpr int LDK = 12;
+  static constexpr int O_K = 0, O_ZF = MB * LDK, O_ZP = 2 * MB * LDK, O_S = 3 * MB * LDK, PER_WAVE = O_S + 4 * MB;
+};
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void kf_b4c_mean_kernel(const KfFwdArgs A, const B4cWs W, int s, int nc) {
+  using L = B4cMeanLds;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long b = blockIdx.x;
+  const int n = A.T, m = A.m, mm = m * m;
+  double* part = smem + (size_t)nc * L::PER_WAVE;   // [nc] partial log-likelihoods
+  const bool run = *W.flag == 0;
+  if (run) {
+    double* blk = smem + (size_t)wave * L::PER_WAVE;
+    const int cj = wave;
+    const int t0 = cj ? cj * s + 1 : 0;
+    const int t1 = (cj + 1) * s + 1 < n ? (cj + 1) * s + 1 : n;
+    const int i = lane & 15;          // state index (every DPP row holds a copy)
+    const bool ion = i < m;
+    double Tr[B4C_MAXM];              // row i of T
+    const double* gT = A.Tm + b * (long)mm;
+#pragma unroll
+    for (int l = 0; l < B4C_MAXM; ++l) Tr[l] = (ion && l < m) ? gT[i * m + l] : 0.0;
+    const double Zi = ion ? A.Z[b * (long)m + i] : 0.0;
+    // ---- a_f(cj s) from the chunks before this one; h = homogeneous part of the PREDICTED mean at step t0 ------------------------------
+    double h = 0.0;   // (chunk 0: none -- its trajectory is the draw's own)
+    if (cj > 0) {
+      double af = ion ? W.zend[((long)b * nc + 0) * m + i] : 0.0;   // a_f(s): chunk 0 ran from (a0, P0)
+      for (int k = 1; k < cj; ++k) {
+        const double* psi = W.psi + ((long)b * nc + k) * mm;         // a_f((k + 1) s) = Psi_k a_f(k s) + z_k
+        double pr[B4C_MAXM];                                         // row i of Psi_k: ten independent loads, not a chain of them
+#pragma unroll
+        for (int l = 0; l < B4C_MAXM; ++l) pr[l] = (ion && l < m) ? psi[i * m + l] : 0.0;
+        double acc = ion ? W.zend[((long)b * nc + k) * m + i] : 0.0;
+#pragma unroll
+        for (int l = 0; l < B4C_MAXM; ++l) acc = fma(pr[l], __shfl(af, l, KF_WAVE), acc);
+        af = acc;
+      }
+      double acc = 0.0;
+#pragma unroll
+      for (int l = 0; l < B4C_MAXM; ++l) acc = fma(Tr[l], __shfl(af, l, KF_WAVE), acc);
+      h = acc;   // T a_f(cj s)  (the intercept c is part of the zero-start trajectory)
+    }
+    const bool w_fa = A.filt_a != nullptr, w_pa = A.pred_a != nullptr;
+    const double* gK = W.K + b * (long)n * m;
+    const double* gfv = W.fv + b * (long)n * 2;
+    double* gfa = w_fa ? A.filt_a + b * (long)n * m : nullptr;
+    double* gpa = w_pa ? A.pred_a + b * (long)(n + 1) * m : nullptr;
+    double lsum = 0.0;
+    // the next block's rows are fetched into registers while this block's steps run (HBM / L2 latency beside the chain)
+    constexpr int NE = (MB * B4C_MAXM + KF_WAVE - 1) / KF_WAVE;
+    double pK[NE], pF[NE], pP[NE];
+    double2_t pfv = {1.0, 0.0};
+    auto fetch = [&](int tb) {
+      const int cnt = (t1 - tb) < MB ? (t1 - tb) : MB;
+#pragma unroll
+      for (int k = 0; k < NE; ++k) {
+        const int e = lane + KF_WAVE * k;
+        const bool on = e < cnt * m;
+        pK[k] = on ? gK[(long)tb * m + e] : 0.0;
+        pF[k] = (on && w_fa) ? gfa[(long)tb * m + e] : 0.0;
+        pP[k] = (on && w_pa) ? gpa[(long)(tb + 1) * m + e] : 0.0;
+      }
+      if (lane < cnt) pfv = *reinterpret_cast<const double2_t*>(gfv + 2 * ((long)tb + lane));   // {F, -2 v / sqrt F}
+    };
+    fetch(t0);
+    for (int tb = t0; tb < t1; tb += MB) {
+      const int cnt = (t1 - tb) < MB ? (t1 - tb) : MB;
+      // block in: gains, the zero-start means of steps [tb, tb + cnt), the per-step scalars (one step per lane)
+#pragma unroll
+      for (int k = 0; k < NE; ++k) {
+        const int e = lane + KF_WAVE * k;
+        if (e < cnt * m) {
+          const int st = e / m, l = e - st * m;
+          blk[L::O_K + st * L::LDK + l] = pK[k];
+          blk[L::O_ZF + st * L::LDK + l] = pF[k];
+          blk[L::O_ZP + st * L::LDK + l] = pP[k];
+        }
+      }
+      if (lane < cnt) {
+        double4_t sc = {-0.5 * pfv.y * sqrt(pfv.x), 1.0 / pfv.x, log(pfv.x), 0.0};
+        *reinterpret_cast<double4_t*>(blk + L::O_S + 4 * lane) = sc;
+      }
+      wave_lds_fence();
+      if (tb + MB < t1) fetch(tb + MB);
+      // one step ahead: the tape values of step st + 1 are read while step st computes
+      double Kt = blk[L::O_K + i], zf = blk[L::O_ZF + i], zp = blk[L::O_ZP + i];
+      double2_t vr = *reinterpret_cast<const double2_t*>(blk + L::O_S);   // {v (zero start), 1 / F}
+      for (int st = 0; st < cnt; ++st) {
+        const int sn = st + 1 < cnt ? st + 1 : st;
+        const double Kn = blk[L::O_K + sn * L::LDK + i], zfn = blk[L::O_ZF + sn * L::LDK + i], zpn = blk[L::O_ZP + sn * L::LDK + i];
+        const double2_t vrn = *reinterpret_cast<const double2_t*>(blk + L::O_S + 4 * sn);
+        const double zh = row_allsum(Zi * h);           // Z h_t
+        const double v = vr.x - zh;                     // the draw's own innovation
+        const double hf = fma(-Kt, zh, h);              // (I - K_t Z) h_t
+        double acc0 = 0.0, acc1 = 0.0;
+        sfor10([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          const double hb = row_bcast<l>(hf);
+          if (l & 1) acc1 = fma(Tr[l], hb, acc1);
+          else acc0 = fma(Tr[l], hb, acc0);
+        });
+        h = acc0 + acc1;                                // h_{t+1} = T (I - K_t Z) h_t
+        if (ion) {
+          blk[L::O_ZF + st * L::LDK + i] = zf + hf;
+          blk[L::O_ZP + st * L::LDK + i] = zp + h;
+        }
+        if (lane == 0) blk[L::O_S + 4 * st + 3] = v * v * vr.y;
+        Kt = Kn; zf = zfn; zp = zpn; vr = vrn;
+      }
+      wave_lds_fence();
+      // block out: the draw's own means, the log-likelihood terms
+#pragma unroll
+      for (int k = 0; k < NE; ++k) {
+        const int e = lane + KF_WAVE * k;
+        if (e < cnt * m) {
+          const int st = e / m, l = e - st * m;
+          if (w_fa) gfa[(long)tb * m + e] = blk[L::O_ZF + st * L::LDK + l];
+          if (w_pa) gpa[(long)(tb + 1) * m + e] = blk[L::O_ZP + st * L::LDK + l];
+        }
+      }
+      if (lane < cnt) {
+        const double llv = -0.5 * (KF_LOG_2PI + blk[L::O_S + 4 * lane + 2] + blk[L::O_S + 4 * lane + 3]);
+        if (A.ll_obs) A.ll_obs[b * (long)n + tb + lane] = llv;
+        lsum += llv;
+      }
+      wave_lds_fence();
+    }
+    lsum = col_allsum(row_allsum(lsum));
+    if (lane == 0) part[wave] = lsum;
+  }
+  __syncthreads();
+  if (run && threadIdx.x == 0) {
+    double lp = 0.0;
+    for (int k = 0; k < nc; ++k) lp += part[k];   // (fixed order: a draw's bits do not depend on the schedule)
+    A.logp[b] = lp;
+    if (A.info) A.info[b] = 0;
+  }
+}
+
+}  // namespace
+
+// ---- host side -----------------------------------------------------------------------------------------------------------------------------
+// shapes the pipeline takes: the ring-streamed block kernel's (p == 1, m <= 10), static matrices, no internal tapes; from 256 steps on
+bool kf_forward_b4c_shape_ok(const kf_handle* h, long B, int T, int p, int m, int r, unsigned flags) {
+  (void)h;
+  if (p != 1 || m < 1 || m > B4C_MAXM || r < 1 || r > 64 || T < 256) return false;
+  if (flags & (KF_FLAG_TV_ANY | KF_FLAG_EXACT_RECURSION)) return false;
+  const char* e = kf_env_switch("KF_FORWARD_CHUNKED");
+  if (e && *e) return e[0] != '0';
+  // worth it while the batch leaves SIMDs idle: at most one wavefront per SIMD (beyond that the sequential kernel's chains already
+  // overlap and the pipeline's three launches only add work)
+  const long simds = (h && h->n_cu > 0 ? h->n_cu : 256) * 4L;
+  return B <= simds;
+}
+
+// chunk length s (a power of two: squarings only) and count: enough chunks to give every SIMD its four wavefronts, at most 8 (one
+// workgroup of the mean pass), at least 64 steps each
+void kf_forward_b4c_plan(const kf_handle* h, long B, int T, int* s_out, int* nc_out) {
+  const long slots = (h && h->n_cu > 0 ? h->n_cu : 256) * 16L;
+  long want = (T * B + slots - 1) / slots;          // steps per chunk that fill the slots
+  if (want < (T + 7) / 8) want = (T + 7) / 8;       // nc <= 8
+  if (want < 64) want = 64;
+  int s = 64;
+  while (s < want) s <<= 1;
+  int nc = 1;
+  while (nc * s + 1 < T) ++nc;                      // chunk k covers steps [k s + 1, (k + 1) s + 1), chunk 0 from step 0
+  if (nc > 8) {                                     // (the power-of-two rounding can only lower nc; kept as a guard)
+    s <<= 1;
+    nc = 1;
+    while (nc * s + 1 < T) ++nc;
+  }
+  *s_out = s;
+  *nc_out = nc;
+}
+
+size_t kf_forward_b4c_carve(void* base, long B, int T, int m, int nc, B4cWs* W) {
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  char* p = (char*)base;
+  size_t off = 0;
+  W->flag = (int32_t*)(p + off); off += up(64);
+  W->start = (double*)(p + off); off += up(sizeof(double) * (size_t)B * nc * m * m);
+  W->psi = (double*)(p + off); off += up(sizeof(double) * (size_t)B * nc * m * m);
+  W->zend = (double*)(p + off); off += up(sizeof(double) * (size_t)B * nc * m);
+  W->fv = (double*)(p + off); off += up(sizeof(double) * (size_t)B * T * 2);
+  W->K = (double*)(p + off); off += up(sizeof(double) * (size_t)B * T * m);
+  return off + 256;
+}
+
+int kf_launch_b4c_starts(kf_handle* h, const KfFwdArgs& a, const B4cWs& W, int s, int nc, hipStream_t stream) {
+  KF_HIP_CHECK(h, hipMemsetAsync(W.flag, 0, 64, stream));
+#define KF_B4C_ST(M_) hipLaunchKernelGGL(kf_b4c_starts_kernel<M_>, dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, W, s, nc)
+  switch (a.m) {
+    case 1: KF_B4C_ST(1); break;
+    case 2: KF_B4C_ST(2); break;
+    case 3: KF_B4C_ST(3); break;
+    case 4: KF_B4C_ST(4); break;
+    case 5: KF_B4C_ST(5); break;
+    case 6: KF_B4C_ST(6); break;
+    case 7: KF_B4C_ST(7); break;
+    case 8: KF_B4C_ST(8); break;
+    case 9: KF_B4C_ST(9); break;
+    default: KF_B4C_ST(10); break;
+  }
+#undef KF_B4C_ST
+  KF_HIP_CHECK(h, hipGetLastError());
+  return KF_OK;
+}
+
+int kf_launch_b4c_means(kf_handle* h, const KfFwdArgs& a, const B4cWs& W, int s, int nc, hipStream_t stream) {
+  const size_t lds = sizeof(double) * ((size_t)nc * B4cMeanLds::PER_WAVE + 8);
+  static KfAttrOnce once;
+  if (lds > 48 * 1024 && once.need(h->device)) {
+    KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kf_b4c_mean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(sizeof(double) * (8 * B4cMeanLds::PER_WAVE + 8))));
+    once.mark(h->device);
+  }
+  hipLaunchKernelGGL(kf_b4c_mean_kernel, dim3((unsigned)a.B), dim3((unsigned)(KF_WAVE * nc)), lds, stream, a, W, s, nc);
+  KF_HIP_CHECK(h, hipGetLastError());
+  return KF_OK;
+}

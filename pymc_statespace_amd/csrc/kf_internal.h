@@ -134,6 +134,18 @@ struct KfFwdArgs {
   const int32_t* order = nullptr;  // internal, with vg_P: workgroup i runs draw order[i] (kf_vg_order_kernel, kf_api.hip: placement only)
   int vg_stop = 0;              // internal, with vg_P: the kernel ends at hs_ts[b] (logp / info up to there, a_ts in pred_a) -- the steps behind it are
                                 // kf_bwd_steady_scan_kernel's, forward and backward (kf_backward_steady.hip)
+  // internal (round 6, the time-chunked pipeline: kf_forward_b4c.hip): workgroup i of the block kernel's chunk instantiation runs chunk
+  // j = i % ck_nc of draw i / ck_nc -- steps [j ck_s + 1, (j + 1) ck_s + 1) (chunk 0: from step 0) -- from the predicted covariance
+  // ck_start[b][j] (chunk 0: P0) and, j > 0, the predicted mean c ("zero start": the draw's true mean joins in the mean pass); it writes
+  // the covariance tapes and leaves the gain, (F, -2 v / sqrt F) and the chunk's last filtered mean for the mean pass
+  int ck_nc = 0, ck_s = 0;
+  const double* ck_start = nullptr;  // [B][ck_nc][m][m]
+  double* ck_K = nullptr;            // [B][T][m]      K_t = P_t Z' / F_t (0 on a missing step: never here)
+  double* ck_fv = nullptr;           // [B][T][2]      {F_t, -2 v_t / sqrt(F_t)} of the zero-start recursion
+  double* ck_zend = nullptr;         // [B][ck_nc][m]  filtered mean of the chunk's last step (zero start)
+  int32_t* ck_flag = nullptr;        // [1] set non-zero by any kernel of the pipeline that cannot vouch for its result: the batch is then
+                                     // redone by the sequential kernel launched behind (run_if = ck_flag)
+  double ck_tol = 1e-12;             // a chunk's last predicted covariance against the next chunk's start, relative to the largest entry
 };
 
 struct KfBwdArgs {
@@ -286,6 +298,20 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a, void* workspace, size
 // time-varying T / Z / H / c / d on the block tiles (kf_forward_b4.hip, kf_fwd_b4tv_kernel)
 bool kf_forward_b4tv_ok(int m, int p, int r, unsigned flags);
 int kf_launch_forward_b4tv(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);
+// time-chunked pipeline for small batches (kf_forward_b4c.hip, round 6): chunk-start covariances by doubling + the mean pass
+struct B4cWs {
+  double* start;   // [B][nc][m][m] predicted covariance chunk j starts from (slot 0 unused)
+  double* psi;     // [B][nc][m][m] Psi_k: a_f((k + 1) s) = Psi_k a_f(k s) + (zero-start response), k >= 1
+  double* K;       // [B][T][m]
+  double* fv;      // [B][T][2]
+  double* zend;    // [B][nc][m]
+  int32_t* flag;   // [16]
+};
+bool kf_forward_b4c_shape_ok(const kf_handle* h, long B, int T, int p, int m, int r, unsigned flags);
+void kf_forward_b4c_plan(const kf_handle* h, long B, int T, int* s, int* nc);
+size_t kf_forward_b4c_carve(void* base, long B, int T, int m, int nc, B4cWs* W);
+int kf_launch_b4c_starts(kf_handle* h, const KfFwdArgs& a, const B4cWs& W, int s, int nc, hipStream_t stream);
+int kf_launch_b4c_means(kf_handle* h, const KfFwdArgs& a, const B4cWs& W, int s, int nc, hipStream_t stream);
 // recursion + tape-writer wavefront per draw (kf_forward_b4p.hip)
 bool kf_forward_b4p_ok(int m, int p, int r);
 int kf_launch_forward_b4p(kf_handle* h, const KfFwdArgs& a, hipStream_t stream);

@@ -273,8 +273,8 @@ def test_vectorized_smoother_nodes_one_c_abi_call_each(nile, monkeypatch):
     """VERDICT round 4, missing #2: the batch-of-draws axis reaches the smoother kernels through ``vectorize_graph``.
     (a) behind this library's filter node (build_statespace_graph + build_smoother_graph, reference core/statespace.py:164-197,
     vectorised over B = 48 Nile-LLT draws as sample_conditional_posterior's loop :283-302 would need): ONE kf_filter_forward and
-    ONE smoother call -- kf_smoother_from_filter for 5 <= m <= 15 (a structural m = 10 model), the lane RTS kernel behind kf_smoother for
-    Nile's m = 2 --; (b) filtered tapes of free origin: ONE kf_smoother call.  Draw 0 against
+    ONE smoother call -- kf_smoother_from_filter for m <= 15 (Nile's m = 2: the lane-per-draw kernel, round 6; a structural m = 10
+    model: the block-tile kernel) --; (b) filtered tapes of free origin: ONE kf_smoother call.  Draw 0 against
     the statsmodels golden vector at the reference's tolerances (tests/test_kalman_filter.py:236-241), every draw against the
     restated reference recursion."""
     import pytensor.tensor as pt
@@ -319,8 +319,8 @@ def test_vectorized_smoother_nodes_one_c_abi_call_each(nile, monkeypatch):
     kal = sorted(type(nd.op).__name__ for nd in f.maker.fgraph.toposort() if "Kalman" in type(nd.op).__name__)
     assert kal == ["KalmanFilterBatchedOp", "KalmanSmootherFusedOp"], kal
     sa, sP = f(*vals[:6], Hs, Qs)
-    # (Nile LLT has m = 2: the fused node's body keeps the lane-per-draw RTS kernel there -- faster for m <= 4 -- ; m = 10 below)
-    assert n_calls == {"fwd": 1, "rts": 1, "sff": 0}, n_calls
+    # (Nile LLT has m = 2: round 6's lane-per-draw kernel behind kf_smoother_from_filter; m = 10 below)
+    assert n_calls == {"fwd": 1, "rts": 0, "sff": 1}, n_calls
     assert sa.shape == (B, g["y"].shape[0], m, 1) and sP.shape == (B, g["y"].shape[0], m, m)
     assert_allclose(sa[0, ..., 0], g["smoothed_state"][0], rtol=1e-7, atol=1e-7)
     assert_allclose(sP[0, 5:], g["smoothed_state_cov"][0, 5:], rtol=1e-7, atol=1e-7)
@@ -380,6 +380,26 @@ def test_vectorized_smoother_nodes_one_c_abi_call_each(nile, monkeypatch):
     sa2, sP2 = f2(vals[3], vals[5], Qs, flt["filtered_states"].reshape(B, -1, m, 1), flt["filtered_covs"])
     assert n_calls == {"fwd": 0, "rts": 1, "sff": 0}, n_calls
     assert np.max(np.abs(sa2[..., 0] - ref_a) / scale_a) < 1e-9 and np.max(np.abs(sP2 - ref_P) / scale_P) < 1e-9
+
+
+def test_arma_smoother_through_the_graph_matches_statsmodels_at_1e_9():
+    """BayesianARMA (k_posdef = 1, H = 0: models/SARIMAX.py:23-49) through build_statespace_graph +
+    build_smoother_graph (core/statespace.py:164-197).  The reference's pinv recursion decides a rank at rounding level there and the
+    RTS kernels are held to 1e-2 on the smoothed covariances (tests/test_gpu_parity.py); the fused node now takes the recursion
+    statsmodels itself runs (kf_smoother_from_filter, lane-per-draw for m = 2): 1e-9, every draw of arma11.npz."""
+    from conftest import load_golden
+    from pymc_statespace_amd.filters import KalmanSmoother, StandardFilter
+
+    g = load_golden("arma11.npz")
+    sym = _symbols()
+    outs = StandardFilter(mvn_const="exact").build_graph(*sym)
+    sm = KalmanSmoother().build_graph(sym[3], sym[5], sym[7], outs[0], outs[2])
+    f = pytensor.function(sym, list(sm) + [outs[4]])
+    for b in range(g["T"].shape[0]):
+        sa, sP, lp = f(g["y"][..., None], g["a0"][b][:, None], g["P0"][b], g["T"][b], g["Z"][b], g["R"][b], g["H"][b], g["Q"][b])
+        assert_allclose(sa[..., 0], g["smoothed_state"][b], rtol=1e-9, atol=1e-9)
+        assert_allclose(sP, g["smoothed_state_cov"][b], rtol=1e-9, atol=1e-9)
+        assert_allclose(lp, g["llf_obs"][b].sum(), rtol=1e-10)
 
 
 def test_batched_filter_differentiates_a_masked_ll_obs(nile):
