@@ -90,7 +90,7 @@ __device__ __forceinline__ void sfor(F&& f) {
 // chunk i % ck_nc of draw i / ck_nc from that chunk's own predicted covariance -- the covariance sequence of a static model without
 // missing observations does not depend on y, and its value at the chunk boundaries comes from log2(s) squarings of the s-step
 // Riccati map -- with the mean started at c; the steps are the very arithmetic of SS == 0.  Covariance tapes are final; the state
-// tapes hold the zero-start trajectory until the mean pass adds the draw's own; (F, v) and the gains go to the workspace
+// tapes, ll_obs and logp are the mean pass's (kf_b4c_mean_kernel: the mean recursion with the gains this kernel leaves in the workspace)
 template <int NB, bool STREAM, int TM, int SS>
 __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu(4))) void kf_fwd_b4_kernel(const KfFwdArgs A) {
   // (waves_per_eu(4): <= 128 registers, and the compiler then keeps MFMA results in VGPRs -- no v_accvgpr moves)
@@ -1106,7 +1106,7 @@ static int b4_launch_chunks(kf_handle* h, const KfFwdArgs& a, hipStream_t stream
   } while (0)
 #define KF_B4C_LAUNCH(NB_)                        \
   do {                                            \
-    if (mask == 15) KF_B4C_GO(NB_, 15);           \
+    if (mask == 12) KF_B4C_GO(NB_, 12);           \
     else if (mask == 0) KF_B4C_GO(NB_, 0);        \
     else KF_B4C_GO(NB_, -1);                      \
   } while (0)
@@ -1140,11 +1140,13 @@ int kf_launch_forward_b4(kf_handle* h, const KfFwdArgs& a_in, void* workspace, s
       void* wbase = (void*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
       kf_forward_b4c_carve(wbase, a.B, a.T, a.m, cn, &W);
       KfFwdArgs ac = a;
+      ac.filt_a = nullptr; ac.pred_a = nullptr;   // the state tapes (and ll_obs, logp, info) are the mean pass's
       ac.ck_nc = cn; ac.ck_s = cs; ac.ck_start = W.start; ac.ck_K = W.K; ac.ck_fv = W.fv; ac.ck_zend = W.zend; ac.ck_flag = W.flag;
       int rc = kf_launch_b4c_starts(h, ac, W, cs, cn, stream);
       if (rc) return rc;
       rc = b4_launch_chunks(h, ac, stream);
       if (rc) return rc;
+      ac.filt_a = a.filt_a; ac.pred_a = a.pred_a;
       rc = kf_launch_b4c_means(h, ac, W, cs, cn, stream);
       if (rc) return rc;
       a.run_if = W.flag;   // the sequential kernel below: a no-op unless the pipeline raised its flag

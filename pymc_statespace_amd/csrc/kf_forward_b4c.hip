@@ -23,12 +23,11 @@
 //                             partial pivoting for D), then P_f(k s) for k = 1 .. nc-1 one after the other; leaves the predicted
 //                             covariance T P_f(k s) T' + Qt every chunk starts from and Psi_k
 //   2. kf_fwd_b4_kernel<.., SS = 3>   B x nc wavefronts: chunk k of a draw runs steps [k s + 1, (k + 1) s + 1) (chunk 0 from step 0)
-//                             -- the unchanged arithmetic of the sequential kernel -- with its mean started at c: covariance tapes final,
-//                             state tapes hold the zero-start trajectory, gains / (F, v) / last filtered mean go to the workspace
-//   3. kf_b4c_mean_kernel     one workgroup per draw, one wavefront per chunk: a_f(k s) = Psi_{k-1} a_f((k-1) s) + z_{k-1} chains the
-//                             chunks (nc matrix-vector products), then each wavefront adds the homogeneous response h_t of its chunk's
-//                             start (h <- T (h - K_t Z h): one m x m matrix-vector product per step) to the state tapes and evaluates
-//                             the likelihood with v_t = v_t(zero start) - Z h_t
+//                             -- the unchanged arithmetic of the sequential kernel -- with its mean started at c ("zero start"):
+//                             covariance tapes final; gains K_t, F_t and the chunk's last filtered mean go to the workspace
+//   3. kf_b4c_mean_kernel     one workgroup per draw, four chunks per wavefront: a_f(k s) = Psi_{k-1} a_f((k-1) s) + z_{k-1} chains the
+//                             chunks (nc matrix-vector products), then every chunk runs the mean recursion from its own start with the
+//                             stored gains (one m x m matrix-vector product per step), writes the state tapes and the likelihood
 // Self-check instead of trust: every chunk compares the covariance it ENDS with against the one its successor STARTED from (1e-12 of the
 // largest entry); a mismatch, a missing observation, S0 <= 0 or an F <= 0 raises a device flag and the sequential kernel, launched
 // behind with run_if = flag, redoes the batch -- no host synchronisation, the call stays asynchronous.
@@ -42,18 +41,20 @@
 namespace {
 
 constexpr int B4C_MAXM = 10;   // (the block kernel's ring-streamed range, NB <= 3)
+constexpr int B4C_NT = 256;    // threads of the doubling kernel's workgroup: an element of a 10 x 20 elimination tableau each
 
-// ---- small dense helpers on LDS-resident M x M matrices (row-major, leading dimension M), one wavefront; M is a compile-time constant:
-// every loop unrolls, the LDS reads of a product are issued back to back (first version: run-time m, 183 us for 512 draws; now ~50)
+// ---- small dense helpers on LDS-resident M x M matrices (row-major, leading dimension M), one workgroup of B4C_NT threads per draw; M is a
+// compile-time constant: every loop unrolls, the LDS reads of a product are issued back to back, an element per thread (first version:
+// run-time m on one wavefront, 183 us for 512 draws; unrolled 125; four wavefronts: see profiles/r06)
 // out = op(X) op(Y) [+ E], element per lane and round.  `out` may alias an operand: every lane reads all it needs before any lane writes
 template <int M, bool TX, bool TY>
-__device__ __forceinline__ void b4c_mul(double* out, const double* X, const double* Y, const double* E, int lane) {
-  constexpr int MM = M * M, RD = (MM + KF_WAVE - 1) / KF_WAVE;
+__device__ __forceinline__ void b4c_mul(double* out, const double* X, const double* Y, const double* E, int tid) {
+  constexpr int MM = M * M, RD = (MM + B4C_NT - 1) / B4C_NT;
   double acc[RD];
 #pragma unroll
   for (int rd = 0; rd < RD; ++rd) {
-    int e = lane + KF_WAVE * rd;
-    const bool on = MM % KF_WAVE == 0 || e < MM;
+    int e = tid + B4C_NT * rd;
+    const bool on = MM % B4C_NT == 0 || e < MM;
     e = on ? e : 0;
     const int i = e / M, j = e - i * M;
     double a0 = E ? E[e] : 0.0, a1 = 0.0;
@@ -64,41 +65,41 @@ __device__ __forceinline__ void b4c_mul(double* out, const double* X, const doub
     }
     acc[rd] = a0 + a1;
   }
-  wave_lds_fence();
+  __syncthreads();
 #pragma unroll
   for (int rd = 0; rd < RD; ++rd) {
-    const int e = lane + KF_WAVE * rd;
-    if (MM % KF_WAVE == 0 || e < MM) out[e] = acc[rd];
+    const int e = tid + B4C_NT * rd;
+    if (MM % B4C_NT == 0 || e < MM) out[e] = acc[rd];
   }
-  wave_lds_fence();
+  __syncthreads();
 }
 // X <- (X + X') / 2
 template <int M>
-__device__ __forceinline__ void b4c_sym(double* X, int lane) {
-  constexpr int MM = M * M, RD = (MM + KF_WAVE - 1) / KF_WAVE;
+__device__ __forceinline__ void b4c_sym(double* X, int tid) {
+  constexpr int MM = M * M, RD = (MM + B4C_NT - 1) / B4C_NT;
   double v[RD];
 #pragma unroll
   for (int rd = 0; rd < RD; ++rd) {
-    int e = lane + KF_WAVE * rd;
+    int e = tid + B4C_NT * rd;
     e = e < MM ? e : 0;
     const int i = e / M, j = e - i * M;
     v[rd] = 0.5 * (X[e] + X[j * M + i]);
   }
-  wave_lds_fence();
+  __syncthreads();
 #pragma unroll
   for (int rd = 0; rd < RD; ++rd) {
-    const int e = lane + KF_WAVE * rd;
+    const int e = tid + B4C_NT * rd;
     if (e < MM) X[e] = v[rd];
   }
-  wave_lds_fence();
+  __syncthreads();
 }
 // D <- (I + X Y)^-1 by Gauss-Jordan with partial pivoting on the augmented [I + X Y | I] (AUG: M x 2M); false: singular
 template <int M>
-__device__ __forceinline__ bool b4c_inv_ipxy(double* D, double* AUG, const double* X, const double* Y, int lane) {
-  constexpr int MM = M * M, W2 = 2 * M, RD = (MM + KF_WAVE - 1) / KF_WAVE, RE = (M * W2 + KF_WAVE - 1) / KF_WAVE;
+__device__ __forceinline__ bool b4c_inv_ipxy(double* D, double* AUG, const double* X, const double* Y, int tid) {
+  constexpr int MM = M * M, W2 = 2 * M, RD = (MM + B4C_NT - 1) / B4C_NT, RE = (M * W2 + B4C_NT - 1) / B4C_NT;
 #pragma unroll
   for (int rd = 0; rd < RD; ++rd) {
-    const int e = lane + KF_WAVE * rd;
+    const int e = tid + B4C_NT * rd;
     if (e < MM) {
       const int i = e / M, j = e - i * M;
       double a0 = (i == j) ? 1.0 : 0.0, a1 = 0.0;
@@ -111,74 +112,67 @@ __device__ __forceinline__ bool b4c_inv_ipxy(double* D, double* AUG, const doubl
       AUG[i * W2 + M + j] = (i == j) ? 1.0 : 0.0;
     }
   }
-  wave_lds_fence();
+  __syncthreads();
   bool ok = true;
 #pragma unroll 1
   for (int k = 0; k < M; ++k) {
-    // pivot: the largest |entry| of column k in rows k .. M-1 (M <= 16: the lanes of one DPP row)
-    double v = (lane >= k && lane < M) ? fabs(AUG[lane * W2 + k]) : -1.0;
-    int idx = lane;
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) {
-      const double v2 = __shfl_xor(v, off, KF_WAVE);
-      const int i2 = __shfl_xor(idx, off, KF_WAVE);
-      const bool take = v2 > v || (v2 == v && i2 < idx);
-      v = take ? v2 : v;
-      idx = take ? i2 : idx;
-    }
-    const int p = __builtin_amdgcn_readfirstlane(idx);
+    // pivot: the largest |entry| of column k in rows k .. M-1 -- a max over the sixteen lanes of DPP row 0 (four row rotations), then
+    // the first lane that holds it
+    const int lane = tid & 63;   // (every wavefront searches for itself: the same column, the same verdict)
+    const double mine = (lane >= k && lane < M) ? fabs(AUG[lane * W2 + k]) : -1.0;
+    double v = mine;
+    v = fmax(v, dpp_mov<0x128>(v));
+    v = fmax(v, dpp_mov<0x124>(v));
+    v = fmax(v, dpp_mov<0x122>(v));
+    v = fmax(v, dpp_mov<0x121>(v));
     const double pv = uniform_f64(v);
     if (!(pv > 0.0)) {
       ok = false;
       break;
     }
-    // rows k <-> p, row k scaled by 1 / pivot
-    if (lane < W2) {
-      const double rk = AUG[k * W2 + lane], rp = AUG[p * W2 + lane];
-      const double piv = AUG[p * W2 + k];
-      wave_lds_fence();
-      AUG[p * W2 + lane] = rk;
-      AUG[k * W2 + lane] = rp * fast_rcp(fabs(piv)) * (piv < 0.0 ? -1.0 : 1.0);
-    }
-    wave_lds_fence();
-    // eliminate column k from every other row: all reads, then all writes (LDS is in order within the wavefront)
-    double f[RE], rkj[RE], x[RE];
+    const unsigned long long hit = __ballot(lane < M && mine == pv);
+    const int p = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)hit) - 1);
+    // One read phase, one write phase (LDS is in order within the wavefront).  With q = (old row p) / pivot:
+    //   new row k = q;   new row p (p != k) = (old row k) - (old row k)[k] q;   every other row i: (old row i) - (old row i)[k] q
+    const double piv = AUG[p * W2 + k];
+    const double rpiv = fast_rcp(fabs(piv)) * (piv < 0.0 ? -1.0 : 1.0);
+    double nv[RE];
 #pragma unroll
     for (int rd = 0; rd < RE; ++rd) {
-      int e = lane + KF_WAVE * rd;
+      int e = tid + B4C_NT * rd;
       e = e < M * W2 ? e : 0;
       const int i = e / W2, j = e - i * W2;
-      f[rd] = AUG[i * W2 + k];
-      rkj[rd] = AUG[k * W2 + j];
-      x[rd] = AUG[e];
+      const int src = (i == p) ? k : i;              // the row whose OLD values become row i (rows k and p trade places)
+      const double q = AUG[p * W2 + j] * rpiv;
+      const double x = AUG[src * W2 + j], f = AUG[src * W2 + k];
+      nv[rd] = (i == k) ? q : fma(-f, q, x);
     }
-    wave_lds_fence();
+    __syncthreads();
 #pragma unroll
     for (int rd = 0; rd < RE; ++rd) {
-      const int e = lane + KF_WAVE * rd;
-      const int i = e / W2;
-      if (e < M * W2 && i != k) AUG[e] = fma(-f[rd], rkj[rd], x[rd]);
+      const int e = tid + B4C_NT * rd;
+      if (e < M * W2) AUG[e] = nv[rd];
     }
-    wave_lds_fence();
+    __syncthreads();
   }
 #pragma unroll
   for (int rd = 0; rd < RD; ++rd) {
-    const int e = lane + KF_WAVE * rd;
+    const int e = tid + B4C_NT * rd;
     if (e < MM) {
       const int i = e / M, j = e - i * M;
       D[e] = AUG[i * W2 + M + j];
     }
   }
-  wave_lds_fence();
+  __syncthreads();
   return ok;
 }
 
 // ---- 1. chunk-start covariances by doubling --------------------------------------------------------------------------------------------
 template <int M>
-__global__ __launch_bounds__(KF_WAVE) void kf_b4c_starts_kernel(const KfFwdArgs A, const B4cWs W, int s, int nc) {
+__global__ __launch_bounds__(B4C_NT) void kf_b4c_starts_kernel(const KfFwdArgs A, const B4cWs W, int s, int nc) {
   constexpr int MM = M * M;
   __shared__ double sT[MM], sQ[MM], sA[MM], sC[MM], sJ[MM], sD[MM], sX[MM], sY[MM], sV[MM], sP[MM], sAUG[2 * MM], sv[4 * 16];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const long b = blockIdx.x;
   const int n = A.T, r_ = A.r;
   double* sZ = sv;
@@ -189,12 +183,12 @@ __global__ __launch_bounds__(KF_WAVE) void kf_b4c_starts_kernel(const KfFwdArgs 
   {
     const double* yb = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n : 0L);
     bool nan = false;
-    for (int e = lane; e < n; e += KF_WAVE) {
+    for (int e = lane; e < n; e += KF_WAVE) {   // (every wavefront scans the whole series: the same verdict in each)
       const double yv = yb[e];
       nan = nan || (yv != yv);
     }
     if (__ballot(nan) != 0ull) {
-      if (lane == 0) *W.flag = 1;
+      if (tid == 0) *W.flag = 1;
       return;
     }
   }
@@ -203,7 +197,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_b4c_starts_kernel(const KfFwdArgs 
     const double* gR = A.R + b * (long)M * r_;
     const double* gQ = A.Q + b * (long)r_ * r_;
     const double* gP = A.P0 + b * (long)MM;
-    for (int e = lane; e < MM; e += KF_WAVE) {
+    for (int e = tid; e < MM; e += B4C_NT) {
       const int i = e / M, j = e - i * M;
       sT[e] = gT[e];
       sP[e] = (j >= i) ? gP[e] : gP[j * M + i];   // the upper triangle, as b4_setup reads P0
@@ -215,108 +209,108 @@ __global__ __launch_bounds__(KF_WAVE) void kf_b4c_starts_kernel(const KfFwdArgs 
       }
       sQ[e] = acc;
     }
-    if (lane < M) sZ[lane] = A.Z[b * (long)M + lane];
+    if (tid < M) sZ[tid] = A.Z[b * (long)M + tid];
   }
-  wave_lds_fence();
-  b4c_sym<M>(sQ, lane);
+  __syncthreads();
+  b4c_sym<M>(sQ, tid);
   const double H1 = A.H[b];
   // ---- the one-step element --------------------------------------------------------------------------------------------------------
-  if (lane < M) {
+  if (tid < M) {
     double qz = 0.0, zt = 0.0;
 #pragma unroll
     for (int l = 0; l < M; ++l) {
-      qz = fma(sQ[lane * M + l], sZ[l], qz);
-      zt = fma(sZ[l], sT[l * M + lane], zt);
+      qz = fma(sQ[tid * M + l], sZ[l], qz);
+      zt = fma(sZ[l], sT[l * M + tid], zt);
     }
-    sK0[lane] = qz;   // Qt Z'
-    sZT[lane] = zt;   // Z T
+    sK0[tid] = qz;   // Qt Z'
+    sZT[tid] = zt;   // Z T
   }
-  wave_lds_fence();
+  __syncthreads();
   double S0 = H1;
 #pragma unroll
   for (int l = 0; l < M; ++l) S0 = fma(sZ[l], sK0[l], S0);
   if (!(S0 > 0.0)) {
-    if (lane == 0) *W.flag = 1;
+    if (tid == 0) *W.flag = 1;
     return;
   }
   const double rS0 = 1.0 / S0;
-  for (int e = lane; e < MM; e += KF_WAVE) {
+  for (int e = tid; e < MM; e += B4C_NT) {
     const int i = e / M, j = e - i * M;
     const double k0 = sK0[i] * rS0;
     sA[e] = fma(-k0, sZT[j], sT[e]);          // (I - K0 Z) T
     sC[e] = fma(-k0, sK0[j], sQ[e]);          // Qt - Qt Z' Z Qt / S0
     sJ[e] = sZT[i] * sZT[j] * rS0;
   }
-  wave_lds_fence();
-  b4c_sym<M>(sC, lane);
+  __syncthreads();
+  b4c_sym<M>(sC, tid);
   // ---- log2(s) squarings ----------------------------------------------------------------------------------------------------------------
 #pragma unroll 1
   for (int k = 1; k < s; k <<= 1) {
-    if (!b4c_inv_ipxy<M>(sD, sAUG, sC, sJ, lane)) {
-      if (lane == 0) *W.flag = 1;
+    if (!b4c_inv_ipxy<M>(sD, sAUG, sC, sJ, tid)) {
+      if (tid == 0) *W.flag = 1;
       return;
     }
-    b4c_mul<M, false, false>(sX, sA, sD, nullptr, lane);   // X = A D
-    b4c_mul<M, false, false>(sY, sX, sC, nullptr, lane);   // Y = A D C
-    b4c_mul<M, false, false>(sV, sJ, sD, nullptr, lane);   // V = J D
-    b4c_mul<M, true, false>(sD, sA, sV, nullptr, lane);    // D = A' J D
-    b4c_mul<M, false, false>(sJ, sD, sA, sJ, lane);        // J <- A' J D A + J
-    b4c_mul<M, false, true>(sC, sY, sA, sC, lane);         // C <- A D C A' + C
-    b4c_mul<M, false, false>(sA, sX, sA, nullptr, lane);   // A <- A D A
-    b4c_sym<M>(sC, lane);
-    b4c_sym<M>(sJ, lane);
+    b4c_mul<M, false, false>(sX, sA, sD, nullptr, tid);   // X = A D
+    b4c_mul<M, false, false>(sY, sX, sC, nullptr, tid);   // Y = A D C
+    b4c_mul<M, false, false>(sV, sJ, sD, nullptr, tid);   // V = J D
+    b4c_mul<M, true, false>(sD, sA, sV, nullptr, tid);    // D = A' J D
+    b4c_mul<M, false, false>(sJ, sD, sA, sJ, tid);        // J <- A' J D A + J
+    b4c_mul<M, false, true>(sC, sY, sA, sC, tid);         // C <- A D C A' + C
+    b4c_mul<M, false, false>(sA, sX, sA, nullptr, tid);   // A <- A D A
+    b4c_sym<M>(sC, tid);
+    b4c_sym<M>(sJ, tid);
   }
   // ---- P_f(0): the update of step 0 ------------------------------------------------------------------------------------------------------
-  if (lane < M) {
+  if (tid < M) {
     double mv = 0.0;
 #pragma unroll
-    for (int l = 0; l < M; ++l) mv = fma(sP[lane * M + l], sZ[l], mv);
-    sMv[lane] = mv;
+    for (int l = 0; l < M; ++l) mv = fma(sP[tid * M + l], sZ[l], mv);
+    sMv[tid] = mv;
   }
-  wave_lds_fence();
+  __syncthreads();
   double F0 = H1;
 #pragma unroll
   for (int l = 0; l < M; ++l) F0 = fma(sZ[l], sMv[l], F0);
   if (!(F0 > 0.0)) {
-    if (lane == 0) *W.flag = 1;
+    if (tid == 0) *W.flag = 1;
     return;
   }
   {
     const double rF = 1.0 / F0;
-    constexpr int RD = (MM + KF_WAVE - 1) / KF_WAVE;
+    constexpr int RD = (MM + B4C_NT - 1) / B4C_NT;
     double v[RD];
 #pragma unroll
     for (int rd = 0; rd < RD; ++rd) {
-      int e = lane + KF_WAVE * rd;
+      int e = tid + B4C_NT * rd;
       e = e < MM ? e : 0;
       const int i = e / M, j = e - i * M;
       v[rd] = fma(-sMv[i] * rF, sMv[j], sP[e]);
     }
-    wave_lds_fence();
+    __syncthreads();
 #pragma unroll
     for (int rd = 0; rd < RD; ++rd) {
-      const int e = lane + KF_WAVE * rd;
+      const int e = tid + B4C_NT * rd;
       if (e < MM) sP[e] = v[rd];
     }
-    wave_lds_fence();
+    __syncthreads();
   }
   // ---- P_f(k s), k = 1 .. nc - 1, and what chunk k starts from ------------------------------------------------------------------------------
 #pragma unroll 1
   for (int k = 1; k < nc; ++k) {
-    if (!b4c_inv_ipxy<M>(sD, sAUG, sP, sJ, lane)) {
-      if (lane == 0) *W.flag = 1;
+    if (!b4c_inv_ipxy<M>(sD, sAUG, sP, sJ, tid)) {
+      if (tid == 0) *W.flag = 1;
       return;
     }
-    b4c_mul<M, false, false>(sX, sA, sD, nullptr, lane);   // Psi_{k-1} = A D: a_f(k s) = Psi_{k-1} a_f((k-1) s) + ...
-    b4c_mul<M, false, false>(sY, sX, sP, nullptr, lane);   // Psi P_f
-    b4c_mul<M, false, true>(sP, sY, sA, sC, lane);         // P_f(k s)
-    b4c_sym<M>(sP, lane);
-    b4c_mul<M, false, false>(sY, sT, sP, nullptr, lane);   // T P_f
-    b4c_mul<M, false, true>(sD, sY, sT, sQ, lane);         // T P_f T' + Qt
-    b4c_sym<M>(sD, lane);
+    b4c_mul<M, false, false>(sX, sA, sD, nullptr, tid);   // Psi_{k-1} = A D: a_f(k s) = Psi_{k-1} a_f((k-1) s) + ...
+    b4c_mul<M, false, false>(sY, sX, sP, nullptr, tid);   // Psi P_f
+    b4c_mul<M, false, true>(sP, sY, sA, sC, tid);         // P_f(k s)
+    b4c_sym<M>(sP, tid);
+    b4c_mul<M, false, false>(sY, sT, sP, nullptr, tid);   // T P_f
+    b4c_mul<M, false, true>(sD, sY, sT, sQ, tid);         // T P_f T' + Qt
+    b4c_sym<M>(sD, tid);
     double* gs = W.start + ((long)b * nc + k) * MM;
     double* gp = W.psi + ((long)b * nc + k - 1) * MM;
-    for (int e = lane; e < MM; e += KF_WAVE) {
+    for (int e = tid; e < MM; e += B4C_NT) {
       gs[e] = sD[e];
       gp[e] = sX[e];
     }
@@ -338,136 +332,158 @@ __device__ __forceinline__ void sfor10(F&& f) {
     sfor10<I + 1>(f);
   }
 }
-constexpr int MB = 32;   // steps per LDS block
+constexpr int MB = 36;   // steps per LDS block (chunks of 2^k and 2^k + 1 steps: no block with a single step)
 struct B4cMeanLds {
-  // per wavefront: K block [MB][12], zero-start filtered / predicted means [MB][12] each (in place: the draw's own on the way out),
-  // per-step scalars [MB][4] = {v (zero start), 1 / F, log F, v^2 / F}
-  static constexpr int LDK = 12;
-  static constexpr int O_K = 0, O_ZF = MB * LDK, O_ZP = 2 * MB * LDK, O_S = 3 * MB * LDK, PER_WAVE = O_S + 4 * MB;
+  // per chunk: K block [MB][10], the filtered / predicted means of the block [MB][10] each, per-step scalars
+  // [MB][4] = {y -+ d, 1 / F, log F, v^2 / F}
+  static constexpr int LDK = B4C_MAXM;
+  static constexpr int O_K = 0, O_AF = MB * LDK, O_AP = 2 * MB * LDK, O_S = 3 * MB * LDK, PER_CHUNK = O_S + 4 * MB;
 };
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void kf_b4c_mean_kernel(const KfFwdArgs A, const B4cWs W, int s, int nc) {
+// One workgroup per draw, FOUR chunks per wavefront -- one per DPP row (first version: one chunk per wavefront, every row a replica:
+// 4096 wavefronts x ~70 instructions per step were issue bound, 125 us; the row sums and broadcasts below are per row anyway).
+// The mean recursion itself (kalman_filter.py:219, :272 at p = 1) with the gains the chunk kernel left:
+//     v_t = (y_t -+ d) - Z a_t,   a_f = a_t + K_t v_t,   a_{t+1} = T a_f + c
+// from the chunk's own start  a_{k s + 1} = T a_f(k s) + c,  a_f(k s) chained over the chunks before it (second version: the chunk
+// kernel wrote zero-start trajectories to the state tapes and this kernel added the homogeneous part -- a read-modify-write of both
+// tapes whose loads it waited for, 106 us; now the state tapes are written once, here).
+__global__ __launch_bounds__(128) void kf_b4c_mean_kernel(const KfFwdArgs A, const B4cWs W, int s, int nc) {
   using L = B4cMeanLds;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nw = (int)(blockDim.x >> 6);
   const long b = blockIdx.x;
   const int n = A.T, m = A.m, mm = m * m;
-  double* part = smem + (size_t)nc * L::PER_WAVE;   // [nc] partial log-likelihoods
+  double* part = smem + (size_t)(4 * nw) * L::PER_CHUNK;   // [nw] partial log-likelihoods
   const bool run = *W.flag == 0;
   if (run) {
-    double* blk = smem + (size_t)wave * L::PER_WAVE;
-    const int cj = wave;
-    const int t0 = cj ? cj * s + 1 : 0;
-    const int t1 = (cj + 1) * s + 1 < n ? (cj + 1) * s + 1 : n;
-    const int i = lane & 15;          // state index (every DPP row holds a copy)
+    const int g = lane >> 4, i = lane & 15;   // DPP row = chunk slot, state index
+    const int cj = 4 * wave + g;              // this row's chunk (>= nc: idle row)
+    const bool act = cj < nc;
+    double* blk = smem + (size_t)cj * L::PER_CHUNK;
+    const int t0 = !act ? 0 : (cj ? cj * s + 1 : 0);
+    const int t1 = !act ? 0 : ((cj + 1) * s + 1 < n ? (cj + 1) * s + 1 : n);
     const bool ion = i < m;
     double Tr[B4C_MAXM];              // row i of T
     const double* gT = A.Tm + b * (long)mm;
 #pragma unroll
     for (int l = 0; l < B4C_MAXM; ++l) Tr[l] = (ion && l < m) ? gT[i * m + l] : 0.0;
     const double Zi = ion ? A.Z[b * (long)m + i] : 0.0;
-    // ---- a_f(cj s) from the chunks before this one; h = homogeneous part of the PREDICTED mean at step t0 ------------------------------
-    double h = 0.0;   // (chunk 0: none -- its trajectory is the draw's own)
-    if (cj > 0) {
+    const double ci = (ion && A.c) ? A.c[b * (long)m + i] : 0.0;
+    const double dsign = (A.filter == KF_FILTER_SINGLE) ? 1.0 : -1.0;  // kalman_filter.py:335 quirk: y_hat = Z a - d
+    const double dd = A.d ? dsign * A.d[b] : 0.0;
+    auto matvec = [&](const double (&Mr)[B4C_MAXM], double x, double acc0) {   // acc0 + (row i of a matrix) . x, x spread over the row's lanes
+      double a0 = acc0, a1 = 0.0;
+      sfor10([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        const double xb = row_bcast<l>(x);
+        if (l & 1) a1 = fma(Mr[l], xb, a1);
+        else a0 = fma(Mr[l], xb, a0);
+      });
+      return a0 + a1;
+    };
+    // ---- the predicted mean this chunk starts from: a0, or T a_f(cj s) + c with a_f(cj s) chained over the chunks before ---------------
+    double a = ion ? A.a0[b * (long)m + i] : 0.0;
+    {
       double af = ion ? W.zend[((long)b * nc + 0) * m + i] : 0.0;   // a_f(s): chunk 0 ran from (a0, P0)
-      for (int k = 1; k < cj; ++k) {
+      const int kmax = 4 * wave + 3 < nc - 1 ? 4 * wave + 3 : nc - 1;
+      for (int k = 1; k < kmax; ++k) {
         const double* psi = W.psi + ((long)b * nc + k) * mm;         // a_f((k + 1) s) = Psi_k a_f(k s) + z_k
-        double pr[B4C_MAXM];                                         // row i of Psi_k: ten independent loads, not a chain of them
+        double pr[B4C_MAXM];
 #pragma unroll
         for (int l = 0; l < B4C_MAXM; ++l) pr[l] = (ion && l < m) ? psi[i * m + l] : 0.0;
-        double acc = ion ? W.zend[((long)b * nc + k) * m + i] : 0.0;
-#pragma unroll
-        for (int l = 0; l < B4C_MAXM; ++l) acc = fma(pr[l], __shfl(af, l, KF_WAVE), acc);
-        af = acc;
+        const double nx = matvec(pr, af, ion ? W.zend[((long)b * nc + k) * m + i] : 0.0);
+        af = (k < cj) ? nx : af;      // (a row whose chunk starts earlier keeps its own)
       }
-      double acc = 0.0;
-#pragma unroll
-      for (int l = 0; l < B4C_MAXM; ++l) acc = fma(Tr[l], __shfl(af, l, KF_WAVE), acc);
-      h = acc;   // T a_f(cj s)  (the intercept c is part of the zero-start trajectory)
+      const double as = matvec(Tr, af, ci);   // T a_f(cj s) + c
+      a = (act && cj > 0) ? as : a;
     }
     const bool w_fa = A.filt_a != nullptr, w_pa = A.pred_a != nullptr;
     const double* gK = W.K + b * (long)n * m;
     const double* gfv = W.fv + b * (long)n * 2;
+    const double* gy = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n : 0L);
     double* gfa = w_fa ? A.filt_a + b * (long)n * m : nullptr;
     double* gpa = w_pa ? A.pred_a + b * (long)(n + 1) * m : nullptr;
+    if (w_pa && act && cj == 0 && ion) gpa[i] = a;   // predicted slot 0 = a0
     double lsum = 0.0;
-    // the next block's rows are fetched into registers while this block's steps run (HBM / L2 latency beside the chain)
-    constexpr int NE = (MB * B4C_MAXM + KF_WAVE - 1) / KF_WAVE;
-    double pK[NE], pF[NE], pP[NE];
-    double2_t pfv = {1.0, 0.0};
+    constexpr int NE = (MB * B4C_MAXM + 15) / 16;   // elements of a block per lane of its row
+    constexpr int NS = (MB + 15) / 16;              // steps of a block per lane of its row
+    int steps_max = t1 - t0;                        // the longest chunk of this wavefront (wave-uniform loop bound)
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) steps_max = max(steps_max, __shfl_xor(steps_max, off, KF_WAVE));
+    // the next block's gains, F and y are fetched into registers while this block's steps run
+    double pK[NE], pF[NS], pY[NS];
     auto fetch = [&](int tb) {
-      const int cnt = (t1 - tb) < MB ? (t1 - tb) : MB;
+      const int cnt = min(max(t1 - tb, 0), MB);
 #pragma unroll
       for (int k = 0; k < NE; ++k) {
-        const int e = lane + KF_WAVE * k;
-        const bool on = e < cnt * m;
-        pK[k] = on ? gK[(long)tb * m + e] : 0.0;
-        pF[k] = (on && w_fa) ? gfa[(long)tb * m + e] : 0.0;
-        pP[k] = (on && w_pa) ? gpa[(long)(tb + 1) * m + e] : 0.0;
+        const int e = i + 16 * k;
+        pK[k] = (e < cnt * m) ? gK[(long)tb * m + e] : 0.0;
       }
-      if (lane < cnt) pfv = *reinterpret_cast<const double2_t*>(gfv + 2 * ((long)tb + lane));   // {F, -2 v / sqrt F}
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const bool on = i + 16 * k < cnt;
+        pF[k] = on ? gfv[2 * ((long)tb + i + 16 * k)] : 1.0;
+        pY[k] = on ? gy[(long)tb + i + 16 * k] : 0.0;
+      }
     };
     fetch(t0);
-    for (int tb = t0; tb < t1; tb += MB) {
-      const int cnt = (t1 - tb) < MB ? (t1 - tb) : MB;
-      // block in: gains, the zero-start means of steps [tb, tb + cnt), the per-step scalars (one step per lane)
+    for (int o = 0; o < steps_max; o += MB) {
+      const int tb = t0 + o;
+      const int cnt = min(max(t1 - tb, 0), MB);
+      // block in (each row its own chunk's block): gains, per-step scalars
 #pragma unroll
       for (int k = 0; k < NE; ++k) {
-        const int e = lane + KF_WAVE * k;
-        if (e < cnt * m) {
-          const int st = e / m, l = e - st * m;
-          blk[L::O_K + st * L::LDK + l] = pK[k];
-          blk[L::O_ZF + st * L::LDK + l] = pF[k];
-          blk[L::O_ZP + st * L::LDK + l] = pP[k];
-        }
+        const int e = i + 16 * k;
+        if (e < cnt * m) blk[L::O_K + e] = pK[k];       // (rows of m doubles, packed as on the tape)
       }
-      if (lane < cnt) {
-        double4_t sc = {-0.5 * pfv.y * sqrt(pfv.x), 1.0 / pfv.x, log(pfv.x), 0.0};
-        *reinterpret_cast<double4_t*>(blk + L::O_S + 4 * lane) = sc;
+#pragma unroll
+      for (int k = 0; k < NS; ++k)
+        if (i + 16 * k < cnt) {
+          double4_t sc = {pY[k] + dd, 1.0 / pF[k], log(pF[k]), 0.0};
+          *reinterpret_cast<double4_t*>(blk + L::O_S + 4 * (i + 16 * k)) = sc;
+        }
+      wave_lds_fence();
+      if (o + MB < steps_max) fetch(tb + MB);
+      // one step ahead: the block's values of step st + 1 are read while step st computes
+      double Kt = blk[L::O_K + i];
+      double2_t yr = *reinterpret_cast<const double2_t*>(blk + L::O_S);   // {y -+ d, 1 / F}
+      for (int st = 0; st < MB; ++st) {
+        const int sn = st + 1 < MB ? st + 1 : st;
+        const double Kn = blk[L::O_K + sn * m + i];
+        const double2_t yrn = *reinterpret_cast<const double2_t*>(blk + L::O_S + 4 * sn);
+        const bool on = st < cnt;
+        const double za = row_allsum(Zi * a);           // Z a_t
+        const double v = yr.x - za;                     // the innovation
+        const double af = ion ? fma(Kt, v, a) : 0.0;    // a_t + K_t v_t
+        const double an = matvec(Tr, af, ci);           // T a_f + c
+        if (ion && on) {
+          blk[L::O_AF + st * m + i] = af;
+          blk[L::O_AP + st * m + i] = an;
+        }
+        if (i == 0 && on) blk[L::O_S + 4 * st + 3] = v * v * yr.y;
+        a = on ? an : a;
+        Kt = Kn;
+        yr = yrn;
       }
       wave_lds_fence();
-      if (tb + MB < t1) fetch(tb + MB);
-      // one step ahead: the tape values of step st + 1 are read while step st computes
-      double Kt = blk[L::O_K + i], zf = blk[L::O_ZF + i], zp = blk[L::O_ZP + i];
-      double2_t vr = *reinterpret_cast<const double2_t*>(blk + L::O_S);   // {v (zero start), 1 / F}
-      for (int st = 0; st < cnt; ++st) {
-        const int sn = st + 1 < cnt ? st + 1 : st;
-        const double Kn = blk[L::O_K + sn * L::LDK + i], zfn = blk[L::O_ZF + sn * L::LDK + i], zpn = blk[L::O_ZP + sn * L::LDK + i];
-        const double2_t vrn = *reinterpret_cast<const double2_t*>(blk + L::O_S + 4 * sn);
-        const double zh = row_allsum(Zi * h);           // Z h_t
-        const double v = vr.x - zh;                     // the draw's own innovation
-        const double hf = fma(-Kt, zh, h);              // (I - K_t Z) h_t
-        double acc0 = 0.0, acc1 = 0.0;
-        sfor10([&](auto lc) {
-          constexpr int l = decltype(lc)::value;
-          const double hb = row_bcast<l>(hf);
-          if (l & 1) acc1 = fma(Tr[l], hb, acc1);
-          else acc0 = fma(Tr[l], hb, acc0);
-        });
-        h = acc0 + acc1;                                // h_{t+1} = T (I - K_t Z) h_t
-        if (ion) {
-          blk[L::O_ZF + st * L::LDK + i] = zf + hf;
-          blk[L::O_ZP + st * L::LDK + i] = zp + h;
-        }
-        if (lane == 0) blk[L::O_S + 4 * st + 3] = v * v * vr.y;
-        Kt = Kn; zf = zfn; zp = zpn; vr = vrn;
-      }
-      wave_lds_fence();
-      // block out: the draw's own means, the log-likelihood terms
+      // block out: the state tapes (stores only), the log-likelihood terms
 #pragma unroll
       for (int k = 0; k < NE; ++k) {
-        const int e = lane + KF_WAVE * k;
+        const int e = i + 16 * k;
         if (e < cnt * m) {
-          const int st = e / m, l = e - st * m;
-          if (w_fa) gfa[(long)tb * m + e] = blk[L::O_ZF + st * L::LDK + l];
-          if (w_pa) gpa[(long)(tb + 1) * m + e] = blk[L::O_ZP + st * L::LDK + l];
+          if (w_fa) gfa[(long)tb * m + e] = blk[L::O_AF + e];
+          if (w_pa) gpa[(long)(tb + 1) * m + e] = blk[L::O_AP + e];
         }
       }
-      if (lane < cnt) {
-        const double llv = -0.5 * (KF_LOG_2PI + blk[L::O_S + 4 * lane + 2] + blk[L::O_S + 4 * lane + 3]);
-        if (A.ll_obs) A.ll_obs[b * (long)n + tb + lane] = llv;
-        lsum += llv;
-      }
+#pragma unroll
+      for (int k = 0; k < NS; ++k)
+        if (i + 16 * k < cnt) {
+          const int st = i + 16 * k;
+          const double llv = -0.5 * (KF_LOG_2PI + blk[L::O_S + 4 * st + 2] + blk[L::O_S + 4 * st + 3]);
+          if (A.ll_obs) A.ll_obs[b * (long)n + tb + st] = llv;
+          lsum += llv;
+        }
       wave_lds_fence();
     }
     lsum = col_allsum(row_allsum(lsum));
@@ -476,7 +492,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
   __syncthreads();
   if (run && threadIdx.x == 0) {
     double lp = 0.0;
-    for (int k = 0; k < nc; ++k) lp += part[k];   // (fixed order: a draw's bits do not depend on the schedule)
+    for (int k = 0; k < nw; ++k) lp += part[k];   // (fixed order: a draw's bits do not depend on the schedule)
     A.logp[b] = lp;
     if (A.info) A.info[b] = 0;
   }
@@ -533,7 +549,7 @@ size_t kf_forward_b4c_carve(void* base, long B, int T, int m, int nc, B4cWs* W) 
 
 int kf_launch_b4c_starts(kf_handle* h, const KfFwdArgs& a, const B4cWs& W, int s, int nc, hipStream_t stream) {
   KF_HIP_CHECK(h, hipMemsetAsync(W.flag, 0, 64, stream));
-#define KF_B4C_ST(M_) hipLaunchKernelGGL(kf_b4c_starts_kernel<M_>, dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, W, s, nc)
+#define KF_B4C_ST(M_) hipLaunchKernelGGL(kf_b4c_starts_kernel<M_>, dim3((unsigned)a.B), dim3(B4C_NT), 0, stream, a, W, s, nc)
   switch (a.m) {
     case 1: KF_B4C_ST(1); break;
     case 2: KF_B4C_ST(2); break;
@@ -552,14 +568,15 @@ int kf_launch_b4c_starts(kf_handle* h, const KfFwdArgs& a, const B4cWs& W, int s
 }
 
 int kf_launch_b4c_means(kf_handle* h, const KfFwdArgs& a, const B4cWs& W, int s, int nc, hipStream_t stream) {
-  const size_t lds = sizeof(double) * ((size_t)nc * B4cMeanLds::PER_WAVE + 8);
+  const int nw = (nc + 3) / 4;   // four chunks per wavefront (nc <= 8: at most two)
+  const size_t lds = sizeof(double) * ((size_t)(4 * nw) * B4cMeanLds::PER_CHUNK + 8);
   static KfAttrOnce once;
-  if (lds > 48 * 1024 && once.need(h->device)) {
+  if (once.need(h->device)) {
     KF_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kf_b4c_mean_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(sizeof(double) * (8 * B4cMeanLds::PER_WAVE + 8))));
+                                        (int)(sizeof(double) * (8 * B4cMeanLds::PER_CHUNK + 8))));
     once.mark(h->device);
   }
-  hipLaunchKernelGGL(kf_b4c_mean_kernel, dim3((unsigned)a.B), dim3((unsigned)(KF_WAVE * nc)), lds, stream, a, W, s, nc);
+  hipLaunchKernelGGL(kf_b4c_mean_kernel, dim3((unsigned)a.B), dim3((unsigned)(KF_WAVE * nw)), lds, stream, a, W, s, nc);
   KF_HIP_CHECK(h, hipGetLastError());
   return KF_OK;
 }
