@@ -508,10 +508,11 @@ bool kf_forward_b4c_shape_ok(const kf_handle* h, long B, int T, int p, int m, in
   if (flags & (KF_FLAG_TV_ANY | KF_FLAG_EXACT_RECURSION)) return false;
   const char* e = kf_env_switch("KF_FORWARD_CHUNKED");
   if (e && *e) return e[0] != '0';
-  // worth it while the batch leaves SIMDs idle: at most one wavefront per SIMD (beyond that the sequential kernel's chains already
-  // overlap and the pipeline's three launches only add work)
+  // worth it while the batch leaves SIMDs idle (measured, profiles/r06/chunk_check.txt, full tapes, chunked against sequential ms:
+  // 256 x 1000: 0.31 / 0.54; 512 x 1000: 0.40 / 0.58; 1024 x 1000: 0.62 / 0.60; 1024 x 2000: 1.05 / 1.19): up to three wavefronts
+  // per four SIMDs, a full round of SIMDs for long series
   const long simds = (h && h->n_cu > 0 ? h->n_cu : 256) * 4L;
-  return B <= simds;
+  return B <= (3 * simds) / 4 || (B <= simds && T >= 1536);
 }
 
 // chunk length s (a power of two: squarings only) and count: enough chunks to give every SIMD its four wavefronts, at most 8 (one
