@@ -727,6 +727,27 @@ def main():
                                      store_predicted=False, **xkw)
                 ops["logp_only_ms"] = _ms(lambda: eng.forward(*d, filter_type=ft, mvn_const="exact", store_ll_obs=False,
                                                               store_filtered=False, store_predicted=False, out=lo_res, **xkw))
+                # the logp-only call moves almost no bytes -- priced against the fp64 peak with the reference's own dense
+                # flop count (algorithmic_flops: what the reference would execute, not what the kernels issue)
+                ops["roofline_logp_only"] = {
+                    "bound": "fp64", "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TF,
+                    "achieved": algorithmic_flops(B_local, n, p, m, r) / (ops["logp_only_ms"] * 1e-3) / 1e12,
+                    "frac": algorithmic_flops(B_local, n, p, m, r) / (ops["logp_only_ms"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF,
+                    "note": "reference dense flops (SURVEY 8d) / logp_only_ms / fp64 peak"}
+                if not tv and os.environ.get("KF_FORWARD_CHUNKED", "")[:1] != "0":
+                    # small batches (one GPU's share of a sharded job) run the time-chunked pipeline (kf_forward_b4c.hip); the
+                    # sequential kernel on the same inputs, for the record
+                    os.environ["KF_FORWARD_CHUNKED"] = "0"
+                    try:
+                        sq_res = eng.forward(*d, **fkw)
+                        ops["forward_sequential_kernel_ms"] = _ms(lambda: eng.forward(*d, out=sq_res, **fkw))
+                        ops["max_rel_dlogp_sequential_vs_default"] = float(((sq_res.logp - res.logp).abs() / sq_res.logp.abs()).max())
+                        ops["logp_only_sequential_kernel_ms"] = _ms(lambda: eng.forward(
+                            *d, filter_type=ft, mvn_const="exact", store_ll_obs=False, store_filtered=False, store_predicted=False,
+                            out=lo_res, **xkw))
+                        del sq_res
+                    finally:
+                        del os.environ["KF_FORWARD_CHUNKED"]
                 if not tv:
                     ops["logp_and_gradient_one_call_ms"] = _ms(lambda: eng.value_and_grad(
                         *d, filter_type=ft, mvn_const="exact", h_diagonal=not args.dense_h))

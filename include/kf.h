@@ -53,6 +53,13 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: these entry points are its whole dynamic symbol table. */
+#if defined(__GNUC__) || defined(__clang__)
+#define KF_API __attribute__((visibility("default")))
+#else
+#define KF_API
+#endif
+
 #define KF_ABI_VERSION 6 /* 6: kf_smoother_from_filter. \
                           * 5: KF_FLAG_STEADY_STATE; the block kernel's steady-state phase off by default below 1536 steps; kf_workspace_bytes_for(KF_WS_FORWARD) covers the split pipeline. \
                           * 2: KF_FLAG_H_DIAGONAL, KF_KERNEL_MFMA, kf_dare, kf_simulate_statespace, workspace use by smoother/backward; \
@@ -126,7 +133,11 @@ enum {
    * filtered covariance is the last step's within 1e-14 of its largest entry -- every covariance of that range is read and compared --
    * are smoothed with one gain: the mean by a prefix scan over time, the covariance recursed to its fixpoint and written as a
    * constant; <= 6e-13 of a draw's largest entry away from every step in full on the BASELINE workloads.  Not with this flag
-   * (KF_SMOOTHER_SPLIT=0 / 1 in the environment: never / for any series length). */
+   * (KF_SMOOTHER_SPLIT=0 / 1 in the environment: never / for any series length).
+   * Round 6: the flag also keeps a SMALL batch on the sequential kernel -- without it kf_filter_forward runs p == 1, m <= 10, static models
+   * of at most 3/4 wavefront per SIMD (768 draws on an MI355X; a full round, 1024, from 1536 steps on) and >= 256 steps through the
+   * time-chunked pipeline described at kf_filter_forward: the same recursion at every step, but each chunk of the series starts from a
+   * covariance computed by doubling instead of from its predecessor's last step (<= 1e-13 relative apart, not bit for bit). */
   KF_FLAG_EXACT_RECURSION = 1u << 12,
   /* Forward filter: use the steady-state phase wherever the selected kernel has one, whatever the series length (the block
    * kernel's default depends on it, see above).  KF_FLAG_EXACT_RECURSION wins when both are set. */
@@ -156,18 +167,18 @@ typedef struct kf_dims {
   uint32_t flags; /* KF_FLAG_* */
 } kf_dims;
 
-int kf_abi_version(void);
+KF_API int kf_abi_version(void);
 
 /* One handle per (process, device): holds the device id, kernel tuning and the last
  * error text.  `device` is the HIP ordinal. */
-int kf_create(kf_handle** out, int device);
-void kf_destroy(kf_handle* h);
-const char* kf_last_error(const kf_handle* h);
+KF_API int kf_create(kf_handle** out, int device);
+KF_API void kf_destroy(kf_handle* h);
+KF_API const char* kf_last_error(const kf_handle* h);
 
 /* Tuning knob: lanes of a wavefront that cooperate on one draw (0 = choose from dims).
  * LDS kernels take 4, 8, 16, 32 or 64; the row-split forward kernels take m*H (H lanes per
  * row of P) for the compiled H; other values fall back to the automatic choice. */
-int kf_set_lanes_per_draw(kf_handle* h, int lanes);
+KF_API int kf_set_lanes_per_draw(kf_handle* h, int lanes);
 
 /* Forward-kernel selection.  AUTO (static matrices): p == 1, m <= 14 -> 4x4x4-block MFMA kernel with
  * the state vector carried in the covariance tile, one wavefront per draw ("b4": always for m >= 9;
@@ -188,15 +199,15 @@ int kf_set_lanes_per_draw(kf_handle* h, int lanes);
  * 16 < m <= 48 / 47, workgroup kernels up to m = 64).  Results agree to
  * rounding. */
 enum { KF_KERNEL_AUTO = 0, KF_KERNEL_LDS = 1, KF_KERNEL_ROW = 2, KF_KERNEL_LANE = 3, KF_KERNEL_MFMA = 4, KF_KERNEL_B4 = 5 };
-int kf_set_forward_kernel(kf_handle* h, int kernel);
+KF_API int kf_set_forward_kernel(kf_handle* h, int kernel);
 /* Name of the kernel kf_filter_forward would launch for `dims` (for profiles / bench logs), assuming
  * the caller passes the workspace kf_workspace_bytes asks for; the _ws form takes the size of the
  * workspace the caller will actually pass (0 = none).  The name is that of the call WITH covariance tapes: for 64 < m <= 96,
  * p == 1 a call without them (filt_P == pred_P == NULL) runs kf_fwd_wgl_kernel (covariance resident in LDS) instead of the
  * workspace path this reports; for p = 1, m <= 10 a batch of <= 1024 draws with covariance tapes runs the recursion + writer pair
  * kernel (kf_fwd_b4p_kernel). */
-const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* dims);
-const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_dims* dims, size_t workspace_bytes);
+KF_API const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims* dims);
+KF_API const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_dims* dims, size_t workspace_bytes);
 /* On the workspace path (m > 64) the kernel depends on the DATA: with p == 1, m <= 1024, no filtered covariance tape and a T of at
  * most 4 m non-zeros per draw outside at most 4 rows of more than 32 (the structural models: seasonal dummies, trigonometric
  * terms, companion forms), T P_f T' + R Q R' is evaluated as a gather over a CSR copy of T ("bsp_step_kernel": one pass over P per
@@ -209,7 +220,7 @@ const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_dims* dims, s
  * compact T' and, when it is sparse without dense rows, evaluate T' X T (X the adjoint / the smoother's carried matrix) as one CSR
  * gather instead of two block-sparse products -- one 8-byte read-back + stream synchronisation per call, skipped under capture or
  * KF_BIG_SPARSE=0. */
-const char* kf_last_forward_kernel(const kf_handle* h);
+KF_API const char* kf_last_forward_kernel(const kf_handle* h);
 
 /* Scratch the three entry points need for `dims` (max over them, for the kernel selection in force
  * on `h`); may be 0.  Non-zero for k_states too large for the on-chip kernels (m > 64, or m > ~45
@@ -218,18 +229,31 @@ const char* kf_last_forward_kernel(const kf_handle* h);
  * smoothers
  * (5 <= m <= 64: per-draw flags; without them kf_smoother uses the slower LDS kernel, m <= 47, or
  * cannot redo singular draws with the pseudo-inverse, 47 < m <= 64). */
-int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes);
+KF_API int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* bytes);
 /* The same per entry point (`which`: OR of KF_WS_*), so that a forward-only or smoother-only caller
  * does not hold the gradient's scratch.  The HBM-workspace kernels (m > 64) put the draw axis in
  * gridDim.y/z: B <= 65535 there (KF_ERR_UNSUPPORTED beyond; chunk the batch). */
 enum { KF_WS_FORWARD = 1, KF_WS_BACKWARD = 2, KF_WS_SMOOTHER = 4, KF_WS_ALL = 7,
        KF_WS_VALUE_AND_GRAD = 8 /* kf_filter_value_and_grad: tapes + both passes (not part of KF_WS_ALL) */,
        KF_WS_SMOOTHER_FROM_FILTER = 16 /* kf_smoother_from_filter: 0 for m <= 15 (not part of KF_WS_ALL) */ };
-int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, int which, size_t* bytes);
+KF_API int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, int which, size_t* bytes);
 
 /* Forward filter for B draws.  c, d may be NULL (= 0: initialize_intercepts,
- * kalman_filter.py:36-51).  ll_obs / filt_* / pred_* / info may be NULL. */
-int kf_filter_forward(kf_handle* h, const kf_dims* dims,
+ * kalman_filter.py:36-51).  ll_obs / filt_* / pred_* / info may be NULL.
+ * Small batches (round 6, csrc/kf_forward_b4c.hip).  One GPU's share of a sharded job -- 512 draws of the north-star batch -- is one
+ * wavefront per two SIMDs, and a launch then lasts as long as ONE wavefront's chain of T dependent steps (0.58 ms at T = 1000
+ * whatever the batch).  For p == 1, m <= 10, static matrices and a series without missing observations the covariance sequence does not
+ * depend on y, and the s-step map of the filtered covariance is one element (A, C, J) of Sarkka & Garcia-Fernandez' associative
+ * operator raised to the s-th power: log2(s) squarings per draw.  Given the workspace kf_workspace_bytes_for(KF_WS_FORWARD) asks for
+ * (B T (m + 2) doubles + a few m x m matrices per chunk) the call runs: (1) the doubling and the chunk-start covariances, (2) the
+ * block kernel's recursion over B x nc chunks side by side (nc <= 8 chunks of s = 2^k steps; the unchanged step arithmetic), (3) the
+ * mean recursion per chunk with the gains of (2), chunk starts chained through Psi_k = A_s (I + P_f J_s)^-1.  Every chunk checks the
+ * covariance it ends with against the one its successor started from (1e-12 of the largest entry); a mismatch, a missing observation,
+ * Z R Q R' Z' + H <= 0 or an F <= 0 raises a device flag and the sequential kernel, launched behind with that flag as its run
+ * condition, redoes the batch: no host synchronisation, capturable into a hipGraph.  Measured (profiles/r06/): 512 x 1000, m = 10, all
+ * six outputs 0.58 -> 0.40 ms, 256 draws 0.54 -> 0.31; outputs within 1e-13 of the sequential kernel's (|dlogp| <= 3e-12), asserted at
+ * 1e-11 / 1e-8.  KF_FLAG_EXACT_RECURSION or KF_FORWARD_CHUNKED=0 in the environment: the sequential kernel. */
+KF_API int kf_filter_forward(kf_handle* h, const kf_dims* dims,
                       const double* y, const double* a0, const double* P0,
                       const double* T, const double* Z, const double* R,
                       const double* H, const double* Q,
@@ -269,7 +293,7 @@ int kf_filter_forward(kf_handle* h, const kf_dims* dims,
  * call left in the same workspace (same B, T, m: a sampler's successive calls) -- draws that will run long are spread over the
  * SIMDs.  This decides only WHERE a draw runs: every output is bitwise the same with a fresh, a reused or an overwritten
  * workspace (KF_VG_SCHED_HINT=0 in the environment: natural order). */
-int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims,
+KF_API int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims,
                              const double* y, const double* a0, const double* P0,
                              const double* T, const double* Z, const double* R,
                              const double* H, const double* Q,
@@ -291,7 +315,7 @@ int kf_filter_value_and_grad(kf_handle* h, const kf_dims* dims,
  * (slice t = the partial w.r.t. the slice step t used); unflagged ones stay per draw.  T / Z / H / c / d flagged (R, Q static),
  * m <= 16, scalar observations: the accumulator-layout adjoint with per-step slices (round 5); else the LDS-resident adjoint
  * (KF_ERR_UNSUPPORTED when m, p do not fit 160 KiB). */
-int kf_filter_backward(kf_handle* h, const kf_dims* dims,
+KF_API int kf_filter_backward(kf_handle* h, const kf_dims* dims,
                        const double* y, const double* a0, const double* P0,
                        const double* T, const double* Z, const double* R,
                        const double* H, const double* Q,
@@ -315,7 +339,7 @@ int kf_filter_backward(kf_handle* h, const kf_dims* dims,
  * noise; 1024 x 300, m = 32 / 64: 2 s / 38 s (profiles/r05/smoother_dispatch_rank.txt, smoother_mid_m_rank.txt).  A caller that has
  * the filter's predicted tapes should use kf_smoother_from_filter below: no inverse, the same cost whatever the rank.
  * Time-varying T / R / Q with 5 <= m <= 16 run on the register-tile elimination kernel with per-step slices (round 5). */
-int kf_smoother(kf_handle* h, const kf_dims* dims,
+KF_API int kf_smoother(kf_handle* h, const kf_dims* dims,
                 const double* T, const double* R, const double* Q,
                 const double* filt_a, const double* filt_P,
                 double* smooth_a, double* smooth_P,
@@ -337,12 +361,14 @@ int kf_smoother(kf_handle* h, const kf_dims* dims,
  * its comparison with statsmodels for this, tests/test_kalman_filter.py:236-241).  pred_a [B][T+1][m], pred_P [B][T+1][m][m] as kf_filter_forward wrote
  * them (slots 0 .. T-1 are read); y, Z, H, d, T as passed to it (d may be NULL); dims->filter: KF_FILTER_SINGLE keeps that
  * filter's sign of d (kalman_filter.py:335); dims->flags: KF_FLAG_Y_PER_DRAW only.  R, Q are not needed.
- * Supported: p == 1, static matrices, m <= 15 on chip (no workspace) and 15 < m <= 1024 on the HBM workspace with the fp64-MFMA
+ * Supported: p == 1, static matrices, m <= 4 one lane per draw in three phases per block of steps (round 6, kf_smoother_bf_lane.hip: only
+ * (r, N) is a recursion -- the filter's quantities of a block and its smoothed moments are computed side by side; C2 0.755 -> 0.246 ms and,
+ * unlike the RTS lane kernel's pinv, 1e-9 from statsmodels on an ARMA model with H = 0), 5 <= m <= 15 on chip (no workspace) and 15 < m <= 1024 on the HBM workspace with the fp64-MFMA
  * products of the m > 64 filter path (kf_smoother_bf_big.hip: two dense products and two with the block-sparse T per step instead of
  * kf_smoother's four products + blocked Cholesky + two triangular solves; workspace: kf_workspace_bytes_for(h, dims,
  * KF_WS_SMOOTHER_FROM_FILTER, &bytes) = 5 B m^2 doubles + vectors); anything else returns KF_ERR_UNSUPPORTED (use kf_smoother on
  * the filtered tapes).  KF_FLAG_EXACT_RECURSION is accepted and has no effect (every step is done in full). */
-int kf_smoother_from_filter(kf_handle* h, const kf_dims* dims, const double* y, const double* T, const double* Z,
+KF_API int kf_smoother_from_filter(kf_handle* h, const kf_dims* dims, const double* y, const double* T, const double* Z,
                             const double* H, const double* d, const double* pred_a, const double* pred_P,
                             double* smooth_a, double* smooth_P, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -352,7 +378,7 @@ int kf_smoother_from_filter(kf_handle* h, const kf_dims* dims, const double* y, 
  * into (a0, P0, T, Z, R, H, Q); dst/src are device int32 index maps built once on the host from
  * the model structure.  Replaces the per-draw set_subtensor sequence of the models' update()
  * (pymc_statespace/models/SARIMAX.py:59-98, models/VARMAX.py:95-143). */
-int kf_assemble(kf_handle* h, int64_t B, int32_t n_theta, const double* theta, int64_t total,
+KF_API int kf_assemble(kf_handle* h, int64_t B, int32_t n_theta, const double* theta, int64_t total,
                 const double* tmpl, int32_t n_map, const int32_t* dst, const int32_t* src,
                 double* out, void* stream);
 
@@ -361,7 +387,7 @@ int kf_assemble(kf_handle* h, int64_t B, int32_t n_theta, const double* theta, i
  * solve_discrete_lyapunov(T, R Q R', method="bilinear") of the stationary initialisation
  * (models/SARIMAX.py:100-107, models/VARMAX.py:145-150).  info[b] = 0 ok, 1 = the doubling
  * iteration did not converge (spectral radius of T >= 1). */
-int kf_lyapunov(kf_handle* h, int64_t B, int32_t m, int32_t r, const double* T, const double* R,
+KF_API int kf_lyapunov(kf_handle* h, int64_t B, int32_t m, int32_t r, const double* T, const double* R,
                 const double* Q, const double* S, double* P, int32_t* info, void* stream);
 
 /* ---- the step after the filter ----------------------------
@@ -371,7 +397,7 @@ int kf_lyapunov(kf_handle* h, int64_t B, int32_t m, int32_t r, const double* T, 
  * normals supplied by the caller.  Replaces conditional_simulation / numba_mvn_draws
  * (pymc_statespace/utils/simulation.py:7-26).  info[b] != 0: a block was not positive
  * definite even with the jitter (encoded like kf_filter_forward's info). */
-int kf_conditional_simulation(kf_handle* h, int64_t B, int32_t n, int32_t k, int32_t n_sims,
+KF_API int kf_conditional_simulation(kf_handle* h, int64_t B, int32_t n, int32_t k, int32_t n_sims,
                               const double* mu, const double* cov, const double* z, double jitter,
                               double* out, int32_t* info, void* stream);
 
@@ -384,7 +410,7 @@ int kf_conditional_simulation(kf_handle* h, int64_t B, int32_t n, int32_t k, int
  * max_iter steps.  info[b]: 0 converged, 1 max_iter reached, 2 Z P Z' + H not positive
  * definite.  A SteadyStateFilter is then kf_filter_forward started from P (same results: at the
  * fixed point the reference's frozen F_inv equals the F^-1 of every step). */
-int kf_dare(kf_handle* h, int64_t B, int32_t m, int32_t p, int32_t r, const double* T,
+KF_API int kf_dare(kf_handle* h, int64_t B, int32_t m, int32_t p, int32_t r, const double* T,
             const double* Z, const double* R, const double* H, const double* Q,
             const double* P_init, double* P, int32_t* info, int32_t max_iter, double tol,
             void* stream);
@@ -396,7 +422,7 @@ int kf_dare(kf_handle* h, int64_t B, int32_t m, int32_t p, int32_t r, const doub
  * SteadyStateFilter.build_graph (filters/kalman_filter.py:388).  Any output may be NULL; accumulate != 0 adds to what
  * the outputs hold -- the direct gradient kf_filter_backward wrote for the filter started from P, with g_P = its g_P0.
  * info[b] (may be NULL): 0 ok, 1 = the Lyapunov iteration did not converge, 2 = Z P Z' + H not positive definite. */
-int kf_dare_backward(kf_handle* h, int64_t B, int32_t m, int32_t p, int32_t r, const double* T,
+KF_API int kf_dare_backward(kf_handle* h, int64_t B, int32_t m, int32_t p, int32_t r, const double* T,
                      const double* Z, const double* R, const double* H, const double* Q,
                      const double* P, const double* g_P, double* g_T, double* g_Z, double* g_R,
                      double* g_H, double* g_Q, int32_t accumulate, int32_t* info, void* stream);
@@ -408,7 +434,7 @@ int kf_dare_backward(kf_handle* h, int64_t B, int32_t m, int32_t p, int32_t r, c
  * observation noise.  z_state [B][n_sims][n][r], z_obs [B][n_sims][n][p]: standard normals from
  * the caller; states [B*n_sims][n][m], obs [B*n_sims][n][p].  info[b]: 1 = Q, 2 = H not
  * positive definite.  m <= 64, r <= 16. */
-int kf_simulate_statespace(kf_handle* h, int64_t B, int32_t n_sims, int32_t n, int32_t p,
+KF_API int kf_simulate_statespace(kf_handle* h, int64_t B, int32_t n_sims, int32_t n, int32_t p,
                            int32_t m, int32_t r, const double* T, const double* Z,
                            const double* R, const double* H, const double* Q, const double* x0,
                            const double* z_state, const double* z_obs, double* states,

@@ -515,22 +515,16 @@ bool kf_forward_b4c_shape_ok(const kf_handle* h, long B, int T, int p, int m, in
   return B <= (3 * simds) / 4 || (B <= simds && T >= 1536);
 }
 
-// chunk length s (a power of two: squarings only) and count: enough chunks to give every SIMD its four wavefronts, at most 8 (one
-// workgroup of the mean pass), at least 64 steps each
+// chunk length s (a power of two: squarings only) and count: eight chunks -- one workgroup of the mean pass, four wavefronts per SIMD at
+// 512 draws -- of at least 64 steps.  A function of the series length ALONE: a draw's bits must not depend on how many other draws
+// share the call (sharding a batch over ranks leaves every log-likelihood bit for bit: tests/test_gpu_distributed.py)
 void kf_forward_b4c_plan(const kf_handle* h, long B, int T, int* s_out, int* nc_out) {
-  const long slots = (h && h->n_cu > 0 ? h->n_cu : 256) * 16L;
-  long want = (T * B + slots - 1) / slots;          // steps per chunk that fill the slots
-  if (want < (T + 7) / 8) want = (T + 7) / 8;       // nc <= 8
-  if (want < 64) want = 64;
+  (void)h;
+  (void)B;
   int s = 64;
-  while (s < want) s <<= 1;
+  while (8 * s + 1 < T) s <<= 1;                    // chunk k covers steps [k s + 1, (k + 1) s + 1), chunk 0 from step 0
   int nc = 1;
-  while (nc * s + 1 < T) ++nc;                      // chunk k covers steps [k s + 1, (k + 1) s + 1), chunk 0 from step 0
-  if (nc > 8) {                                     // (the power-of-two rounding can only lower nc; kept as a guard)
-    s <<= 1;
-    nc = 1;
-    while (nc * s + 1 < T) ++nc;
-  }
+  while (nc * s + 1 < T) ++nc;
   *s_out = s;
   *nc_out = nc;
 }

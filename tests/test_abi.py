@@ -139,3 +139,16 @@ def test_steady_state_filter_has_a_symbolic_entry_and_a_gradient():
             filters.SteadyStateFilter(engine=object()).build_graph(None, None, None, None, None, None, None, None)
         else:
             raise ImportError("pytensor present: nothing to check here")
+
+
+def test_the_dynamic_symbol_table_is_the_header():
+    """-fvisibility=hidden (round 6): libkf_hip.so exports the entry points include/kf.h declares and nothing of its own making --
+    what remains beside them are hipcc's per-translation-unit __hip_cuid_* markers and weak libstdc++ template instantiations."""
+    import subprocess
+
+    from pymc_statespace_amd import _lib
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    ours = {nm for nm in names if not nm.startswith("__hip_cuid_") and not nm.startswith("_ZNSt") and not nm.startswith("_ZSt")}
+    assert ours == set(_lib.EXPORTS), sorted(ours ^ set(_lib.EXPORTS))
