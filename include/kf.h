@@ -213,9 +213,12 @@ KF_API const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_dims* 
  * terms, companion forms), T P_f T' + R Q R' is evaluated as a gather over a CSR copy of T ("bsp_step_kernel": one pass over P per
  * step, HBM bound) instead of two fp64 MFMA products ("big_gemm_kernel").  Results agree to rounding.  The verdict is found on the
  * device: such a call reads 4 bytes back and SYNCHRONISES `stream` once, before the recursion is enqueued -- the one exception to
- * "asynchronous on stream" above; while `stream` is being captured into a graph, or with KF_BIG_SPARSE=0 in the environment,
- * there is no read-back and the MFMA path runs.  kf_last_forward_kernel: the kernel that carried the recursion of this handle's
- * last kf_filter_forward on the workspace path ("" before the first).
+ * "asynchronous on stream" above.  While `stream` is being CAPTURED into a graph nothing can be read back: the call then takes the
+ * path the handle's last un-captured call on the same (T pointer, B, m) took (round 6: the warm-up call every capture needs decides) --
+ * the CSR gather under a device-side guard: the replay rebuilds the CSR from the T it finds and, should that T no longer fit, every
+ * draw comes back with logp = NaN and info = 0x7fffff02 (re-capture), never with a wrong number; a capture without such a call before
+ * it, or KF_BIG_SPARSE=0 in the environment: the MFMA path.  kf_last_forward_kernel: the kernel that carried the recursion of this
+ * handle's last kf_filter_forward on the workspace path ("" before the first).
  * The same holds for kf_filter_backward / kf_filter_value_and_grad with m >= 128 and for kf_smoother_from_filter with m > 15: they
  * compact T' and, when it is sparse without dense rows, evaluate T' X T (X the adjoint / the smoother's carried matrix) as one CSR
  * gather instead of two block-sparse products -- one 8-byte read-back + stream synchronisation per call, skipped under capture or

@@ -1074,6 +1074,7 @@ __global__ __launch_bounds__(256) void bsp_pt_kernel(const double* __restrict__ 
                                                      double* __restrict__ pt) {
   const long b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (c.ok[0] == 0) return;   // (a captured call replayed on a T that no longer fits the CSR: bsp_guard_kernel reports it)
   const int nd = c.nd[b];
   if (nd == 0) return;
   const double* Pb = P + b * (long)m * m;
@@ -1102,6 +1103,7 @@ __global__ __launch_bounds__(256) void bsp_vec_kernel(const double* __restrict__
   __shared__ double part[4][1 + BSP_ND][64];
   const long b = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (c.ok[0] == 0) return;
   const double* Tb = T + b * (long)m * m;
   const double* Eb = E + b * (long)m * m;
   const double* zb = Z + b * m;
@@ -1202,6 +1204,14 @@ struct BspStep {
 
 constexpr int BSP_CG = 6;   // columns per lane and pass of stage 1 (384 columns)
 
+// behind a CAPTURED sparse chain: if the CSR build of this replay found a T that does not fit, no draw has a result
+__global__ void bsp_guard_kernel(const int* ok, double* logp, int32_t* info, long B) {
+  const long b = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (ok[0] != 0 || b >= B) return;
+  logp[b] = __builtin_nan("");
+  if (info) info[b] = 0x7fffff02;
+}
+
 template <int R>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void bsp_step_kernel(const KfFwdArgs A, int t, const BspCsr c, const BspStep x, int nblk) {
   extern __shared__ double sm[];
@@ -1213,6 +1223,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
   const long L = blockIdx.x;
   const long b = (L & 7) + 8 * (L / (8L * nblk));
   if (b >= A.B) return;
+  if (c.ok[0] == 0) return;
   const int i0 = (int)((L >> 3) % nblk) * R;
   const long mm = (long)m * m;
   double* w = sm;                    // [R][m]
@@ -1846,7 +1857,9 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
     const char* se = kf_env_switch("KF_BIG_SPARSE");
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cap_status);
-    if (!(se && se[0] == '0') && cap_status == hipStreamCaptureStatusNone) {
+    const bool capturing = cap_status != hipStreamCaptureStatusNone;
+    const bool cached_sparse = h->big_cache_sparse && h->big_cache_T == a.Tm && h->big_cache_B == a.B && h->big_cache_m == m;
+    if (!(se && se[0] == '0') && (!capturing || cached_sparse)) {
       BspCsr csr;
       csr.cap = BSP_CAPF * m;
       // carved from W_ws (B m^2 doubles, unused on this path; m > 64)
@@ -1868,8 +1881,13 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
       KF_HIP_CHECK(h, hipMemsetAsync(csr.ok + 1, 0, sizeof(int), stream));   // (the largest number of dense rows: unused here)
       hipLaunchKernelGGL(bsp_csr_kernel, dim3((unsigned)a.B), dim3(256), 0, stream, a.Tm, m, csr);
       int fits = 0;
-      KF_HIP_CHECK(h, hipMemcpyAsync(&fits, csr.ok, sizeof(int), hipMemcpyDeviceToHost, stream));
-      KF_HIP_CHECK(h, hipStreamSynchronize(stream));
+      if (capturing) {
+        fits = 1;   // the verdict of the last un-captured call on this (T pointer, B, m); the replay checks it again on the device
+      } else {
+        KF_HIP_CHECK(h, hipMemcpyAsync(&fits, csr.ok, sizeof(int), hipMemcpyDeviceToHost, stream));
+        KF_HIP_CHECK(h, hipStreamSynchronize(stream));
+        h->big_cache_T = a.Tm; h->big_cache_B = a.B; h->big_cache_m = m; h->big_cache_sparse = fits != 0;
+      }
       if (fits) {
         // rows per workgroup: 8 (measured at C5, 128 draws: 4 / 8 / 16 rows -> 98 / 92 / 112 ms), 4 when 8 would leave one workgroup per CU
         auto lds_of = [&](int rows) { return sizeof(double) * ((size_t)(rows + 5) * m + (size_t)BSP_ND * rows); };
@@ -1900,6 +1918,8 @@ int kf_launch_forward_big(kf_handle* h, const KfFwdArgs& a, void* workspace, siz
             else
               hipLaunchKernelGGL(bsp_step_kernel<4>, dim3(sgrid), dim3(256), lds_sp, stream, a, t, csr, xs, nblk);
           }
+          if (capturing)
+            hipLaunchKernelGGL(bsp_guard_kernel, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, stream, csr.ok, a.logp, a.info, (long)a.B);
           KF_HIP_CHECK(h, hipGetLastError());
           h->last_forward_kernel = "bsp_step_kernel";
           return KF_OK;

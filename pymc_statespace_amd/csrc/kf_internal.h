@@ -64,6 +64,13 @@ struct kf_handle {
   // name of the kernel that carried the recursion of the last kf_filter_forward on the HBM-workspace path (m > 64), where the choice
   // depends on the data (T sparse or not); NULL before the first such call.  kf_last_forward_kernel()
   const char* last_forward_kernel;
+  // verdict of the last read-back on that path (kf_forward_big.hip): a call that is being CAPTURED into a hipGraph cannot read back, and
+  // takes the sparse chain when the last un-captured call on the same (T pointer, B, m) did -- under a device-side guard (the CSR
+  // build's ok word): replayed on a T that no longer fits, every draw comes back NaN with info 0x7fffff02 instead of a wrong number
+  const double* big_cache_T;
+  long big_cache_B;
+  int big_cache_m;
+  int big_cache_sparse;
 };
 int kf_handle_aux(kf_handle* h);  // KF_OK once aux_stream / aux_ev exist (current device = the handle's)
 // Scope guard of a launcher that forks work onto the handle's streams: whichever way the function is left -- an error return in the

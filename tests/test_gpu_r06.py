@@ -344,3 +344,46 @@ def test_chunked_forward_is_capturable_and_leaves_the_big_batches_alone(eng):
     a = eng.forward(*_args(wb), mvn_const="exact")
     b = eng.forward(*_args(wb), mvn_const="exact", exact_recursion=True)
     assert torch.equal(a.logp, b.logp) and torch.equal(a.predicted_covs, b.predicted_covs)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# C5's sparse path under hipGraph capture: the verdict "T fits the CSR" needs a read-back, which a capturing
+# stream cannot do -- round 5 then silently took the 3.6x slower MFMA path
+# ------------------------------------------------------------------------------------------------------------------------------------
+def test_sparse_workspace_path_is_taken_under_graph_capture(eng):
+    """A captured call takes the CSR gather (bsp_step_kernel) when the last un-captured call on the same (T pointer, B, m) did, under
+    a device-side guard: replayed on a dense T in the same buffer every draw comes back NaN with info 0x7fffff02 -- loud, never a
+    wrong number; a first call that is captured has no verdict yet and keeps the MFMA path (results equal to rounding)."""
+    import torch
+
+    w = W.daily_seasonal(B=8, n=24, s=110)         # m = 111 (> 96: past the LDS-resident kernel): the workspace path, 2 non-zeros per row
+    dv = [eng.to_device(w["y"])] + [eng.to_device(w[k]) for k in KEYS]
+    kw = dict(mvn_const="exact", store_filtered=False, store_predicted=False)
+    eng.release_workspace()
+    out = eng.forward(*dv, **kw)                    # un-captured: read-back, verdict cached
+    assert eng.last_forward_kernel() == "bsp_step_kernel"
+    ref_logp = out.logp.clone()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        eng.forward(*dv, out=out, **kw)             # (workspace of this stream allocated outside the capture)
+        s.synchronize()
+        out.logp.zero_()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            eng.forward(*dv, out=out, **kw)
+        assert eng.last_forward_kernel() == "bsp_step_kernel"     # the captured call took the sparse chain
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out.logp, ref_logp) and not out.info.any()
+        # the same graph on a T that no longer fits (dense rows everywhere): the guard speaks up
+        T_keep = dv[3].clone()
+        dv[3].copy_(torch.rand_like(dv[3]) * 0.01)
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.isnan(out.logp).all() and (out.info == 0x7fffff02).all()
+        dv[3].copy_(T_keep)
+        gr.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out.logp, ref_logp) and not out.info.any()
