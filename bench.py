@@ -734,7 +734,7 @@ def main():
                     "achieved": algorithmic_flops(B_local, n, p, m, r) / (ops["logp_only_ms"] * 1e-3) / 1e12,
                     "frac": algorithmic_flops(B_local, n, p, m, r) / (ops["logp_only_ms"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF,
                     "note": "reference dense flops (SURVEY 8d) / logp_only_ms / fp64 peak"}
-                if not tv and os.environ.get("KF_FORWARD_CHUNKED", "")[:1] != "0":
+                if not tv and B_local <= 1024 and p == 1 and m <= 10 and os.environ.get("KF_FORWARD_CHUNKED", "")[:1] != "0":
                     # small batches (one GPU's share of a sharded job) run the time-chunked pipeline (kf_forward_b4c.hip); the
                     # sequential kernel on the same inputs, for the record
                     os.environ["KF_FORWARD_CHUNKED"] = "0"
