@@ -238,7 +238,7 @@ KF_API int kf_workspace_bytes(const kf_handle* h, const kf_dims* dims, size_t* b
  * gridDim.y/z: B <= 65535 there (KF_ERR_UNSUPPORTED beyond; chunk the batch). */
 enum { KF_WS_FORWARD = 1, KF_WS_BACKWARD = 2, KF_WS_SMOOTHER = 4, KF_WS_ALL = 7,
        KF_WS_VALUE_AND_GRAD = 8 /* kf_filter_value_and_grad: tapes + both passes (not part of KF_WS_ALL) */,
-       KF_WS_SMOOTHER_FROM_FILTER = 16 /* kf_smoother_from_filter: 0 for m <= 15 (not part of KF_WS_ALL) */ };
+       KF_WS_SMOOTHER_FROM_FILTER = 16 /* kf_smoother_from_filter: 0 for m <= 15; 16 <= m <= 79 run on chip and use none of it (not part of KF_WS_ALL) */ };
 KF_API int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, int which, size_t* bytes);
 
 /* Forward filter for B draws.  c, d may be NULL (= 0: initialize_intercepts,
@@ -366,7 +366,10 @@ KF_API int kf_smoother(kf_handle* h, const kf_dims* dims,
  * filter's sign of d (kalman_filter.py:335); dims->flags: KF_FLAG_Y_PER_DRAW only.  R, Q are not needed.
  * Supported: p == 1, static matrices, m <= 4 one lane per draw in three phases per block of steps (round 6, kf_smoother_bf_lane.hip: only
  * (r, N) is a recursion -- the filter's quantities of a block and its smoothed moments are computed side by side; C2 0.755 -> 0.246 ms and,
- * unlike the RTS lane kernel's pinv, 1e-9 from statsmodels on an ARMA model with H = 0), 5 <= m <= 15 on chip (no workspace) and 15 < m <= 1024 on the HBM workspace with the fp64-MFMA
+ * unlike the RTS lane kernel's pinv, 1e-9 from statsmodels on an ARMA model with H = 0), 5 <= m <= 15 one wavefront per draw on 4x4x4 block
+ * MFMAs, 16 <= m <= 79 one workgroup of ceil((m + 1) / 16) wavefronts per draw on 16 x 16 fp64 MFMA tiles (round 6, kf_smoother_bf_wg.hip:
+ * 1024 x 300, m = 32 / 63: 8.2 / 13.3 ms whatever the rank, against 43 / 77 on the workspace and 2.0 / 37.7 s of kf_smoother with r = 1; all
+ * three without workspace) and 79 < m <= 1024 on the HBM workspace (also 16 <= m <= 79 with KF_SMOOTHER_BF_WG=0) with the fp64-MFMA
  * products of the m > 64 filter path (kf_smoother_bf_big.hip: two dense products and two with the block-sparse T per step instead of
  * kf_smoother's four products + blocked Cholesky + two triangular solves; workspace: kf_workspace_bytes_for(h, dims,
  * KF_WS_SMOOTHER_FROM_FILTER, &bytes) = 5 B m^2 doubles + vectors); anything else returns KF_ERR_UNSUPPORTED (use kf_smoother on

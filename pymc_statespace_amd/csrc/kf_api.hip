@@ -1313,6 +1313,12 @@ extern "C" int kf_smoother_from_filter(kf_handle* h, const kf_dims* dims, const 
   }
   a.y = y; a.Tm = T; a.Z = Z; a.H = H; a.d = d; a.pred_a = pred_a; a.pred_P = pred_P;
   a.smooth_a = smooth_a; a.smooth_P = smooth_P;
+  // 16 <= m <= 79: the recursion on chip, 16 x 16 fp64 MFMA tiles, one workgroup per draw (round 6, kf_smoother_bf_wg.hip);
+  // KF_SMOOTHER_BF_WG=0 keeps the HBM-workspace path (A/B measurements)
+  if (kf_smoother_bf_wg_ok(a.m, dims->p, fl)) {
+    const char* e = kf_env_switch("KF_SMOOTHER_BF_WG");
+    if (!(e && e[0] == '0')) return kf_launch_smoother_bf_wg(h, a, (hipStream_t)stream);
+  }
   if (big) return kf_launch_smoother_bf_big(h, a, workspace, workspace_bytes, (hipStream_t)stream);
   // m <= 4 (C1, C2): one lane per draw (kf_smoother_bf_lane.hip); KF_SMOOTHER_BF_LANE=0 keeps the block-tile kernel (A/B measurements)
   if (kf_smoother_bf_lane_ok(a.m, dims->p, fl) && h->forward_kernel != KF_KERNEL_B4) {

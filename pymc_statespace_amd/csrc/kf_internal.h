@@ -249,6 +249,9 @@ int kf_launch_smoother_bf(kf_handle* h, const KfSmoothBfArgs& a, hipStream_t str
 // one lane per draw for m <= 4 (kf_smoother_bf_lane.hip)
 bool kf_smoother_bf_lane_ok(int m, int p, unsigned flags);
 int kf_launch_smoother_bf_lane(kf_handle* h, const KfSmoothBfArgs& a, hipStream_t stream);
+// 16 <= m <= 79 on 16 x 16 fp64 MFMA tiles, one workgroup per draw (kf_smoother_bf_wg.hip)
+bool kf_smoother_bf_wg_ok(int m, int p, unsigned flags);
+int kf_launch_smoother_bf_wg(kf_handle* h, const KfSmoothBfArgs& a, hipStream_t stream);
 // the same recursion on the HBM workspace for 15 < m <= 1024 (kf_smoother_bf_big.hip)
 bool kf_smoother_bf_big_ok(int m, int p, unsigned flags);
 size_t kf_smoother_bf_big_workspace_bytes(long B, int m);

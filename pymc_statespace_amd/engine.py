@@ -40,26 +40,27 @@ def smoother_from_filter_applies(p, m, ndims, r=None):
     a filter's result uses: the fused PyTensor node (op.perform_smoother_fused), ``KalmanEngine.smooth_result``,
     ``KalmanSmoother.__call__(..., filter_result=...)``, ``BaseFilter.filter_and_smooth`` and ``ShardedKalman.filter_and_smooth``.
     p == 1 and every system matrix static (``ndims``: the per-draw ranks of T, Z, H, R, Q -- and of d when given as a sixth
-    entry, 1), and
-      * m <= 4   the lane-per-draw kernel (round 6, kf_smoother_bf_lane.hip): no pseudo-inverse -- an ARMA model (r = 1, H = 0) puts
-                 the prediction covariance on pinv's cut-off at almost every step and the RTS lane kernel's Jacobi fallback agrees with
-                 statsmodels only to 1e-2 there, this recursion to 1e-9 (tests/golden/arma11.npz);
-      * 5 <= m <= 15   the on-chip block-tile kernel (kf_smoother_bf.hip);
-      * 64 < m <= 1024  both recursions run on the HBM workspace and this one has no factorisation (C5, 128 draws, m = 367:
-                 0.80 against 2.78 ms per step);
-      * 16 <= m <= 64   only when the state noise has few columns (``r``, the width of R: every ARMA / SARIMA model has r = 1): the
-                 RTS kernels then hand most draws to the pinv kernel and take seconds (1024 draws x 300 steps, r = 1, m = 20 / 32 /
-                 48 / 64: 0.19 / 2.0 / 7.3 / 37.7 s) where this recursion takes 34 / 43 / 58 / 75 ms on the workspace; measured bad up
-                 to r = 2 / 3 / 4 at m = 20 / 32 / 48 (profiles/r05/smoother_mid_m_rank.txt): taken for 12 r <= m + 11.
+    entry, 1), and m <= 1024: every range has an inverse-free kernel now --
+      * m <= 4   one lane per draw (round 6, kf_smoother_bf_lane.hip): an ARMA model (r = 1, H = 0) puts the prediction covariance on
+                 pinv's cut-off at almost every step and the RTS lane kernel's Jacobi fallback agrees with statsmodels only to 1e-2
+                 there, this recursion to 1e-9 (tests/golden/arma11.npz);
+      * 5 <= m <= 15   the block-tile kernel (kf_smoother_bf.hip);
+      * 16 <= m <= 79  16 x 16 fp64 MFMA tiles, one workgroup per draw (round 6, kf_smoother_bf_wg.hip): 1024 draws x 300 steps,
+                 m = 20 / 32 / 48 / 63: 1.9 / 8.2 / 13.0 / 13.3 ms whatever the rank of the state noise, against 3.6 / 7.8 / 22 / 42 ms of
+                 the RTS tile kernels with full-rank noise and 0.19 / 2.0 / 7.3 / 37.7 SECONDS with r = 1 (every ARMA / SARIMA model:
+                 most draws go to the pinv kernel), 34 / 43 / 58 / 77 ms on round 5's workspace path (profiles/r06/smooth_wg_time.txt);
+      * 64 < m <= 1024  (beyond 79 on the HBM workspace) no factorisation: C5, 128 draws, m = 367: 0.80 against 2.78 ms per step.
+    The one exception is m == 64 exactly (the vector carrier needs a 65th tile index: five wavefronts on four SIMDs, 49.5 ms): the RTS
+    workgroup kernel is the faster one there with full-rank noise (42.7 ms), so m == 64 keeps round 5's rank rule, 12 r <= m + 11.
     A non-zero state intercept c is the CALLER's business: the reference's smoother predicts with a_hat = T a_f, without c
     (kalman_smoother.py:99-104), while the filter's predicted tapes contain it, so the two recursions differ by O(c) and a caller that
     wants the reference's numbers must keep kf_smoother (``smooth_result`` and the fused node check c themselves)."""
     nds = list(ndims)
     if p != 1 or not all(nd == 2 for nd in nds[:5]) or any(nd != 1 for nd in nds[5:]):
         return False
-    if 1 <= m <= 15 or 64 < m <= 1024:
-        return True
-    return 16 <= m <= 64 and r is not None and 12 * r <= m + 11
+    if m == 64:
+        return r is not None and 12 * r <= m + 11
+    return 1 <= m <= 1024
 
 
 def _ptr(t: Optional[torch.Tensor]):

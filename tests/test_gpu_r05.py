@@ -149,8 +149,8 @@ def test_smoother_from_filter_rejects_what_it_does_not_take(eng):
         with pytest.raises(KalmanError, match="p == 1"):
             eng._check(rc, "kf_smoother_from_filter")
         assert not eng.smooth_from_filter_ok(p_, m_)
-    # 15 < m <= 1024 runs on the HBM workspace: without it the call is refused (KF_ERR_WORKSPACE), nothing is launched
-    dims = _lib.KfDims(3, 20, 1, 40, 2, 0, 0)
+    # 79 < m <= 1024 runs on the HBM workspace: without it the call is refused (KF_ERR_WORKSPACE), nothing is launched
+    dims = _lib.KfDims(3, 20, 1, 100, 2, 0, 0)
     assert eng.lib.kf_smoother_from_filter(eng._h, C.byref(dims), *([t.data_ptr()] * 9), None, 0, None) == _lib.KF_ERR_WORKSPACE
     assert eng.smooth_from_filter_ok(1, 10) and eng.smooth_from_filter_ok(1, 367)
     assert not eng.smooth_from_filter_ok(1, 10, time_varying=("T",))
@@ -596,7 +596,9 @@ def test_ill_conditioned_dense_H_goes_to_the_dense_path(eng):
 def test_smoother_from_filter_workspace_path(eng, monkeypatch, case):
     """15 < m <= 1024 (kf_smoother_bf_big.hip; BASELINE config 5's smoother): the same recursion with the fp64-MFMA products of the
     workspace path -- two dense, two with the block-sparse T -- against its numpy restatement (1e-9 of the draw's largest filtered
-    entry) and against kf_smoother on the filtered tapes; with every K chunk (KF_BIG_TMASK=0) bit for bit."""
+    entry) and against kf_smoother on the filtered tapes; with every K chunk (KF_BIG_TMASK=0) bit for bit.
+    (Round 6: 16 <= m <= 79 run on chip by default -- kf_smoother_bf_wg.hip, tests/test_gpu_r06.py --; KF_SMOOTHER_BF_WG=0 keeps this path.)"""
+    monkeypatch.setenv("KF_SMOOTHER_BF_WG", "0")
     if case.startswith("dense"):
         m = int(case.split("_m")[1])
         w = W.random_dense(4, 12, 1, m, min(m, 5), seed=40 + m)

@@ -387,3 +387,49 @@ def test_sparse_workspace_path_is_taken_under_graph_capture(eng):
         gr.replay()
         torch.cuda.synchronize()
         assert torch.equal(out.logp, ref_logp) and not out.info.any()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# kf_smoother_from_filter on 16 x 16 fp64 MFMA tiles, one workgroup per draw (csrc/kf_smoother_bf_wg.hip, 16 <= m <= 79)
+# ------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m", [16, 17, 31, 32, 40, 47, 48, 63, 64, 79])   # 2 / 2 / 2 / 3 / 3 / 3 / 4 / 4 / 5 / 5 wavefronts per draw
+@pytest.mark.parametrize("rank", ["one", "full"])
+def test_tile_smoother_from_filter_matches_restatement(eng, m, rank):
+    """kalman_smoother.py:56-104 on the filter's own tapes for the SARIMA-sized models (k_posdef = 1: the RTS kernels' pinv case, seconds)
+    and full-rank noise alike: the numpy restatement pinned to statsmodels at 1e-10 of the draw's largest filtered entry; missing
+    observations (first, last, middle), an intercept d; and the reference's own recursion where that is well posed (full rank)."""
+    r = 1 if rank == "one" else m
+    w = W.random_dense(4, 37, 1, m, r, seed=300 + m + r)
+    y = w["y"].copy()
+    y[[0, 11, 36]] = np.nan
+    d = 0.1 * np.random.default_rng(m).standard_normal((4, 1))
+    res = eng.forward(y, *[w[k] for k in KEYS], d=d, mvn_const="exact")
+    assert not res.info.cpu().numpy().any()
+    sa, sP = eng.smooth_from_filter(y, w["T"], w["Z"], w["H"], res.predicted_states, res.predicted_covs, d=d)
+    da, dP = kn.smoother_from_filter(y, w["T"], w["Z"], w["H"], res.predicted_states.cpu().numpy(), res.predicted_covs.cpu().numpy(), d=d)
+    scale = max(1.0, float(np.abs(res.filtered_covs.cpu().numpy()).max()))
+    assert_allclose(sa.cpu().numpy(), da, rtol=1e-10, atol=1e-10 * scale)
+    assert_allclose(sP.cpu().numpy(), dP, rtol=1e-10, atol=1e-10 * scale)
+    if rank == "full":
+        ra, rP = eng.smooth(w["T"], w["R"], w["Q"], res.filtered_states, res.filtered_covs)
+        assert_allclose(sa.cpu().numpy(), ra.cpu().numpy(), rtol=1e-7, atol=1e-7 * scale)
+        assert_allclose(sP.cpu().numpy(), rP.cpu().numpy(), rtol=1e-7, atol=1e-7 * scale)
+
+
+def test_tile_smoother_from_filter_variants(eng, monkeypatch):
+    """SingleTimeseriesFilter's sign of d, one series per draw, and the workspace path it replaced (KF_SMOOTHER_BF_WG=0) on the same tapes."""
+    w = W.random_dense(5, 50, 1, 24, 2, seed=77)
+    rng = np.random.default_rng(6)
+    d = 0.2 * rng.standard_normal((5, 1))
+    yb = w["y"][None] + 0.1 * rng.standard_normal((5,) + w["y"].shape)
+    res = eng.forward(yb, *[w[k] for k in KEYS], d=d, filter_type="single", mvn_const="exact")
+    sa, sP = eng.smooth_from_filter(yb, w["T"], w["Z"], w["H"], res.predicted_states, res.predicted_covs, d=d, filter_type="single")
+    for b in (0, 4):
+        da, dP = kn.smoother_from_filter(yb[b], w["T"][b:b + 1], w["Z"][b:b + 1], w["H"][b:b + 1], res.predicted_states[b:b + 1].cpu().numpy(),
+                                         res.predicted_covs[b:b + 1].cpu().numpy(), d=d[b:b + 1], filter_type="single")
+        assert_allclose(sa[b:b + 1].cpu().numpy(), da, rtol=1e-10, atol=1e-10)
+        assert_allclose(sP[b:b + 1].cpu().numpy(), dP, rtol=1e-10, atol=1e-10)
+    monkeypatch.setenv("KF_SMOOTHER_BF_WG", "0")
+    wa, wP = eng.smooth_from_filter(yb, w["T"], w["Z"], w["H"], res.predicted_states, res.predicted_covs, d=d, filter_type="single")
+    assert_allclose(sa.cpu().numpy(), wa.cpu().numpy(), rtol=1e-10, atol=1e-10)
+    assert_allclose(sP.cpu().numpy(), wP.cpu().numpy(), rtol=1e-10, atol=1e-10)

@@ -447,19 +447,17 @@ def test_batched_filter_differentiates_ll_obs(monkeypatch):
 
 
 def test_which_recursion_the_fused_smoother_node_takes():
-    """op.smoother_from_filter_applies: the smoother from the filter's predicted tapes for p == 1, static matrices and m <= 15 (on chip)
-    or 64 < m <= 1024 (workspace); between 16 and 64 only with state noise of few columns (12 r <= m + 11: every ARMA / SARIMA model has
-    r = 1), where the RTS kernels would hand most draws to the pinv kernel (profiles/r05/smoother_mid_m_rank.txt); else kf_smoother."""
+    """engine.smoother_from_filter_applies (re-exported by op): the smoother from the filter's predicted tapes for p == 1, static matrices
+    (and a static d) and every m <= 1024 -- lane kernel, block tiles, 16 x 16 MFMA tiles (round 6), workspace --; m == 64 alone keeps
+    round 5's rank rule (12 r <= m + 11: its on-chip form needs five wavefronts on four SIMDs); else kf_smoother."""
     from pymc_statespace_amd.op import smoother_from_filter_applies as f
 
     static = [2, 2, 2, 2, 2]
     assert not f(2, 10, static) and not f(1, 10, [3, 2, 2, 2, 2]) and not f(1, 10, [2, 2, 2, 3, 2])   # p > 1; a time-varying T; R
-    assert [m for m in range(1, 17) if f(1, m, static)] == list(range(1, 16))   # (round 6: m <= 4 on the lane-per-draw kernel)
+    assert all(f(1, m, static) for m in range(1, 64)) and all(f(1, m, static, r=m) for m in (16, 20, 32, 48, 63, 65, 79, 80, 367, 1024))
     assert f(1, 10, static + [1]) and not f(1, 10, static + [2])   # a sixth entry: d -- (p,) static, (n,p) time-varying
-    assert f(1, 65, static) and f(1, 367, static) and f(1, 1024, static) and not f(1, 1025, static)
-    assert not f(1, 20, static) and not f(1, 20, static, r=20) and not f(1, 20, static, r=3)
-    assert f(1, 16, static, r=1) and f(1, 20, static, r=2) and f(1, 32, static, r=3) and f(1, 48, static, r=4) and f(1, 64, static, r=6)
-    assert not f(1, 32, static, r=4) and not f(1, 48, static, r=5)
+    assert not f(1, 1025, static) and not f(1, 0, static)
+    assert not f(1, 64, static) and not f(1, 64, static, r=64) and not f(1, 64, static, r=7) and f(1, 64, static, r=6) and f(1, 64, static, r=1)
 
 
 def test_fused_smoother_body_keeps_the_reference_recursion_for_a_nonzero_c_or_a_time_varying_d():

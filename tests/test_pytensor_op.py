@@ -347,7 +347,7 @@ def test_vectorized_smoother_nodes_one_c_abi_call_each(nile, monkeypatch):
     assert_allclose(sP10, r10P, rtol=1e-9, atol=1e-9)
 
     # (a3) 16 <= m <= 64 with rank-one state noise (every ARMA / SARIMA model): the RTS recursion would hand most draws to the pinv
-    # kernel (seconds); the node takes the recursion from the predicted tapes (workspace path).  Against its pinned restatement.
+    # kernel (seconds); the node takes the recursion from the predicted tapes (round 6: on chip).  Against its pinned restatement.
     for k in n_calls:
         n_calls[k] = 0
     B3 = 5
@@ -360,11 +360,17 @@ def test_vectorized_smoother_nodes_one_c_abi_call_each(nile, monkeypatch):
     r20a, r20P = kn.smoother_from_filter(w3["y"], rep3(v3[3]), rep3(v3[4]), w3["H"], f20["predicted_states"], f20["predicted_covs"])
     assert_allclose(sa20[..., 0], r20a.reshape(B3, 30, 20), rtol=1e-8, atol=1e-9)
     assert_allclose(sP20, r20P, rtol=1e-8, atol=1e-9)
-    # ... and full-rank noise of the same size stays on the on-chip RTS kernels
+    # ... and so does full-rank noise of the same size (round 6: the recursion runs on chip for 16 <= m <= 79, kf_smoother_bf_wg.hip --
+    # faster than the RTS tile kernels whatever the rank); only m == 64 with full-rank noise keeps the RTS workgroup kernel
     for k in n_calls:
         n_calls[k] = 0
     w4 = W.random_dense(B3, 30, 1, 20, 20, seed=10)
     f(w4["y"][..., None], w4["a0"][0][:, None], w4["P0"][0], w4["T"][0], w4["Z"][0], w4["R"][0], w4["H"], w4["Q"])
+    assert n_calls == {"fwd": 1, "rts": 0, "sff": 1}, n_calls
+    for k in n_calls:
+        n_calls[k] = 0
+    w5 = W.random_dense(2, 12, 1, 64, 64, seed=12)
+    f(w5["y"][..., None], w5["a0"][0][:, None], w5["P0"][0], w5["T"][0], w5["Z"][0], w5["R"][0], w5["H"], w5["Q"])
     assert n_calls == {"fwd": 1, "rts": 1, "sff": 0}, n_calls
 
     # (b) free filtered tapes
