@@ -317,7 +317,6 @@ __global__ __launch_bounds__(B4C_NT) void kf_b4c_starts_kernel(const KfFwdArgs A
   }
 }
 
-// ---- 3. the mean pass ----------------------------------------------------------------------------------------------------------------------
 // lane L of every DPP row -> all sixteen lanes of its row (row_newbcast: one v_mov_dpp per dword, no trip through the LDS crossbar)
 template <int LSRC>
 __device__ __forceinline__ double row_bcast(double x) {
@@ -332,6 +331,252 @@ __device__ __forceinline__ void sfor10(F&& f) {
     sfor10<I + 1>(f);
   }
 }
+// ---- 1b. the same on 16 x 16 fp64 MFMA tiles, ONE wavefront per draw, nothing in LDS (round 6, second version) --------------------------------
+// Every matrix is a tile in the accumulator layout of v_mfma_f64_16x16x4 (kf_tile.h: lane = 16 g + c, register s holds X[4 s + g][c]);
+// a tile used as the A operand is its transpose, so  tn(U, V) = U' V  is KS = ceil(m / 4) instructions and no matrix is ever moved:
+//     squaring:  D = (I + C J)^-1   Xt = tn(D, At)   A <- tn(Xt, A)   At <- tn(A, Xt)   C <- tn(tn(C, Xt), At) + C   J <- tn(tn(tn(J, D), A), A) + J
+//     applying:  D = (I + P J)^-1   Psi' = tn(D, At)   Psi = tn(At, D)   P <- tn(tn(P, Psi'), At) + C   start = tn(tn(P, Tt), Tt) + Qt
+// (A and A' are both carried; C, J, P, Qt are symmetric and re-symmetrised with one more product, X' = tn(X, I)).  The inverse is a
+// Gauss-Jordan elimination with IMPLICIT partial pivoting in registers: column k by row index is one DPP broadcast per register, the
+// pivot search a max over the four lane groups (v_permlane swaps), the pivot row a select + a group broadcast; rows are never
+// exchanged -- the left tile ends as a permutation Pi and the inverse is tn(Pi, right tile).  No LDS round trip, no barrier on the
+// chain: 110 us (four wavefronts on LDS, a barrier per pivot phase) -> see profiles/r06/.
+template <int KS>
+__device__ __forceinline__ double4_t b4c_tn(const double4_t& U, const double4_t& V, double4_t acc) {
+#pragma unroll
+  for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(U[s], V[s], acc, 0, 0, 0);
+  return acc;
+}
+// all-reduce max over the four lane groups (lanes c, c + 16, c + 32, c + 48)
+__device__ __forceinline__ double b4c_col_allmax(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  x = fmax(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+  lo = __double2loint(x);
+  hi = __double2hiint(x);
+  auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return fmax(__hiloint2double(d[0], c[0]), __hiloint2double(d[1], c[1]));
+}
+__device__ __forceinline__ int b4c_col_allmin_i(int x) {
+  auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  x = min((int)a[0], (int)a[1]);
+  auto c = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return min((int)c[0], (int)c[1]);
+}
+// D = M^-1 for the leading m x m block of a tile (rows / columns >= m: identity); false: singular
+template <int KS, int K = 0>
+__device__ __forceinline__ void b4c_gj_pivots(double4_t& Lt, double4_t& Rt, unsigned& used, bool& ok, int m, int g) {
+  if constexpr (K < 4 * KS) {
+    if (K < m) {   // (wave-uniform)
+      double f[KS];
+      double best = -1.0;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        f[s] = row_bcast<K>(Lt[s]);                        // M[4 s + g][K]
+        const bool cand = 4 * s + g < m && !((used >> (4 * s + g)) & 1u);
+        best = fmax(best, cand ? fabs(f[s]) : -1.0);
+      }
+      const double vmax = b4c_col_allmax(best);
+      int mine = 64;
+#pragma unroll
+      for (int s = KS - 1; s >= 0; --s) {
+        const bool cand = 4 * s + g < m && !((used >> (4 * s + g)) & 1u);
+        if (cand && fabs(f[s]) == vmax) mine = 4 * s + g;
+      }
+      const int p = __builtin_amdgcn_readfirstlane(b4c_col_allmin_i(mine));
+      if (!(vmax > 0.0) || p >= 64) ok = false;
+      const int sp = p >> 2, gp = p & 3;
+      double rl = Lt[0], rr = Rt[0];
+#pragma unroll
+      for (int s = 1; s < KS; ++s) {
+        rl = (sp == s) ? Lt[s] : rl;
+        rr = (sp == s) ? Rt[s] : rr;
+      }
+      rl = group_bcast_sel(rl, gp);                        // row p of the left / right tile, by column
+      rr = group_bcast_sel(rr, gp);
+      const double piv = row_bcast<K>(rl);
+      const double rp = fast_rcp(fabs(piv)) * (piv < 0.0 ? -1.0 : 1.0);
+      const double ql = rl * rp, qr = rr * rp;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bool isp = 4 * s + g == p;
+        Lt[s] = isp ? ql : fma(-f[s], ql, Lt[s]);
+        Rt[s] = isp ? qr : fma(-f[s], qr, Rt[s]);
+      }
+      used |= 1u << (p & 31);
+    }
+    b4c_gj_pivots<KS, K + 1>(Lt, Rt, used, ok, m, g);
+  }
+}
+template <int KS>
+__device__ __forceinline__ bool b4c_tile_inverse(const double4_t& M, const double4_t& Id, double4_t& D, int m, int g) {
+  double4_t Lt = M, Rt = Id;
+  unsigned used = 0u;
+  bool ok = true;
+  b4c_gj_pivots<KS>(Lt, Rt, used, ok, m, g);
+  const double4_t z = {0.0, 0.0, 0.0, 0.0};
+  D = b4c_tn<KS>(Lt, Rt, z);   // Pi' (Pi M^-1 ... ) = M^-1
+  return ok;
+}
+
+template <int KS>
+__global__ __launch_bounds__(KF_WAVE) void kf_b4c_starts_mfma_kernel(const KfFwdArgs A, const B4cWs W, int s_len, int nc) {
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const long b = blockIdx.x;
+  const int n = A.T, m = A.m, mm = m * m, r_ = A.r;
+  const double4_t z4 = {0.0, 0.0, 0.0, 0.0};
+  {
+    const double* yb = A.y + ((A.flags & KF_FLAG_Y_PER_DRAW) ? b * (long)n : 0L);
+    bool nan = false;
+    for (int e = lane; e < n; e += KF_WAVE) {
+      const double yv = yb[e];
+      nan = nan || (yv != yv);
+    }
+    if (__ballot(nan) != 0ull) {
+      if (lane == 0) *W.flag = 1;
+      return;
+    }
+  }
+  const double* gT = A.Tm + b * (long)mm;
+  const double* gP = A.P0 + b * (long)mm;
+  // R Q through LDS for r <= 16 (first version: R and Q read from global memory inside the r x r loops -- a chain of dependent loads;
+  // kept for wider state noise, which no model of the reference has)
+  __shared__ double sR[12 * 16 + 16 * 16], sRQ[12 * 16];   // R [m][r], then Q [r][r]; R Q [m][r]
+  const double* gR = A.R + b * (long)m * r_;
+  const double* gQ = A.Q + b * (long)r_ * r_;
+  const bool rq_lds = r_ <= 16;
+  if (rq_lds) {
+    double* sQ = sR + m * r_;
+    for (int e = lane; e < m * r_; e += KF_WAVE) sR[e] = gR[e];
+    for (int e = lane; e < r_ * r_; e += KF_WAVE) sQ[e] = gQ[e];
+    wave_lds_fence();
+    for (int e = lane; e < m * r_; e += KF_WAVE) {
+      const int i = e / r_, l = e - i * r_;
+      double rq = 0.0;
+      for (int k = 0; k < r_; ++k) rq = fma(sR[i * r_ + k], sQ[k * r_ + l], rq);
+      sRQ[e] = rq;
+    }
+    wave_lds_fence();
+  }
+  double4_t Tt, Tn, Qt, Pm, Id;
+  double Zr[KS];
+  const double Zc = c < m ? A.Z[b * (long)m + c] : 0.0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int row = 4 * s + g;
+    const bool on = s < KS && row < m && c < m;
+    Tn[s] = on ? gT[row * m + c] : 0.0;
+    Tt[s] = on ? gT[c * m + row] : 0.0;
+    Pm[s] = on ? (c >= row ? gP[row * m + c] : gP[c * m + row]) : 0.0;   // the upper triangle, as b4_setup reads P0
+    Id[s] = (s < KS && row == c) ? 1.0 : 0.0;
+    double acc = 0.0;
+    if (on && rq_lds) {
+      for (int l = 0; l < r_; ++l) acc = fma(sRQ[row * r_ + l], sR[c * r_ + l], acc);
+    } else if (on) {
+      for (int l = 0; l < r_; ++l) {
+        double rq = 0.0;
+        for (int k = 0; k < r_; ++k) rq = fma(gR[row * r_ + k], gQ[k * r_ + l], rq);
+        acc = fma(rq, gR[c * r_ + l], acc);
+      }
+    }
+    Qt[s] = acc;
+    if (s < KS) Zr[s] = (row < m) ? A.Z[b * (long)m + row] : 0.0;
+  }
+  auto symm = [&](double4_t& X) {
+    const double4_t Xt = b4c_tn<KS>(X, Id, z4);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) X[s] = 0.5 * (X[s] + Xt[s]);
+  };
+  symm(Qt);
+  const double H1 = A.H[b];
+  // ---- the one-step element: vectors by row index (row sums) and by column index (column sums) ----------------------------------------
+  double qzr[KS], ztr[KS], part_q = 0.0, part_t = 0.0;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    qzr[s] = row_allsum(Qt[s] * Zc);        // (Qt Z')[4 s + g]
+    ztr[s] = row_allsum(Tt[s] * Zc);        // (Z T)[4 s + g] = sum_c T[c][4 s + g] Z[c]
+    part_q = fma(Zr[s], Qt[s], part_q);
+    part_t = fma(Zr[s], Tn[s], part_t);
+  }
+  const double qzc = col_allsum(part_q);    // (Qt Z')[c]   (Qt symmetric)
+  const double ztc = col_allsum(part_t);    // (Z T)[c]
+  const double S0 = H1 + row_allsum(qzc * Zc);
+  if (!(S0 > 0.0)) {
+    if (lane == 0) *W.flag = 1;
+    return;
+  }
+  const double rS0 = 1.0 / S0;
+  double4_t Am = z4, At = z4, Cm = z4, Jm = z4;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    Am[s] = fma(-qzr[s] * rS0, ztc, Tn[s]);        // (I - K0 Z) T
+    At[s] = fma(-ztr[s] * rS0, qzc, Tt[s]);        // its transpose
+    Cm[s] = fma(-qzr[s] * rS0, qzc, Qt[s]);        // Qt - Qt Z' Z Qt / S0
+    Jm[s] = ztr[s] * ztc * rS0;
+  }
+  // ---- log2(s) squarings ----------------------------------------------------------------------------------------------------------------
+  bool ok = true;
+#pragma unroll 1
+  for (int k = 1; k < s_len; k <<= 1) {
+    double4_t D;
+    ok = b4c_tile_inverse<KS>(b4c_tn<KS>(Cm, Jm, Id), Id, D, m, g) && ok;
+    const double4_t Xt = b4c_tn<KS>(D, At, z4);                 // (A D)'
+    const double4_t Vv = b4c_tn<KS>(Jm, D, z4);                 // J D
+    const double4_t Yt = b4c_tn<KS>(Cm, Xt, z4);                // (A D C)'
+    const double4_t Wt = b4c_tn<KS>(Vv, Am, z4);                // (A' J D)'
+    Cm = b4c_tn<KS>(Yt, At, Cm);                                // A D C A' + C
+    Jm = b4c_tn<KS>(Wt, Am, Jm);                                // A' J D A + J
+    const double4_t An = b4c_tn<KS>(Xt, Am, z4);                // A D A
+    At = b4c_tn<KS>(Am, Xt, z4);                                // its transpose
+    Am = An;
+    symm(Cm);
+    symm(Jm);
+  }
+  // ---- P_f(0): the update of step 0 ------------------------------------------------------------------------------------------------------
+  {
+    double part = 0.0, mvr[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      mvr[s] = row_allsum(Pm[s] * Zc);
+      part = fma(Zr[s], Pm[s], part);
+    }
+    const double mvc = col_allsum(part);
+    const double F0 = H1 + row_allsum(mvc * Zc);
+    if (!(F0 > 0.0)) ok = false;
+    const double rF = 1.0 / F0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) Pm[s] = fma(-mvr[s] * rF, mvc, Pm[s]);
+  }
+  // ---- P_f(k s), k = 1 .. nc - 1, and what chunk k starts from ------------------------------------------------------------------------------
+#pragma unroll 1
+  for (int k = 1; k < nc; ++k) {
+    double4_t D;
+    ok = b4c_tile_inverse<KS>(b4c_tn<KS>(Pm, Jm, Id), Id, D, m, g) && ok;
+    const double4_t Pst = b4c_tn<KS>(D, At, z4);                // Psi' = (A D)'
+    const double4_t Psi = b4c_tn<KS>(At, D, z4);                // Psi = A D: a_f(k s) = Psi_{k-1} a_f((k-1) s) + ...
+    const double4_t Yt = b4c_tn<KS>(Pm, Pst, z4);               // (Psi P_f)'
+    Pm = b4c_tn<KS>(Yt, At, Cm);                                // P_f(k s)
+    symm(Pm);
+    const double4_t Z1 = b4c_tn<KS>(Pm, Tt, z4);                // (T P_f)'
+    double4_t St = b4c_tn<KS>(Z1, Tt, Qt);                      // T P_f T' + Qt
+    symm(St);
+    double* gs = W.start + ((long)b * nc + k) * mm;
+    double* gp = W.psi + ((long)b * nc + k - 1) * mm;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int row = 4 * s + g;
+      if (row < m && c < m) {
+        gs[row * m + c] = St[s];
+        gp[row * m + c] = Psi[s];
+      }
+    }
+  }
+  if (!ok && lane == 0) *W.flag = 1;
+}
+
+// ---- 3. the mean pass ----------------------------------------------------------------------------------------------------------------------
 constexpr int MB = 36;   // steps per LDS block (chunks of 2^k and 2^k + 1 steps: no block with a single step)
 struct B4cMeanLds {
   // per chunk: K block [MB][10], the filtered / predicted means of the block [MB][10] each, per-step scalars
@@ -544,6 +789,15 @@ size_t kf_forward_b4c_carve(void* base, long B, int T, int m, int nc, B4cWs* W) 
 
 int kf_launch_b4c_starts(kf_handle* h, const KfFwdArgs& a, const B4cWs& W, int s, int nc, hipStream_t stream) {
   KF_HIP_CHECK(h, hipMemsetAsync(W.flag, 0, 64, stream));
+  // the doubling on MFMA tiles, one wavefront per draw (KF_B4C_STARTS_LDS=1 in the environment: the LDS version on four wavefronts)
+  const char* le = kf_env_switch("KF_B4C_STARTS_LDS");
+  if (!(le && le[0] == '1')) {
+    if (a.m <= 4) hipLaunchKernelGGL(kf_b4c_starts_mfma_kernel<1>, dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, W, s, nc);
+    else if (a.m <= 8) hipLaunchKernelGGL(kf_b4c_starts_mfma_kernel<2>, dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, W, s, nc);
+    else hipLaunchKernelGGL(kf_b4c_starts_mfma_kernel<3>, dim3((unsigned)a.B), dim3(KF_WAVE), 0, stream, a, W, s, nc);
+    KF_HIP_CHECK(h, hipGetLastError());
+    return KF_OK;
+  }
 #define KF_B4C_ST(M_) hipLaunchKernelGGL(kf_b4c_starts_kernel<M_>, dim3((unsigned)a.B), dim3(B4C_NT), 0, stream, a, W, s, nc)
   switch (a.m) {
     case 1: KF_B4C_ST(1); break;
