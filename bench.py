@@ -2,7 +2,7 @@
 """bench.py -- Kalman log-likelihood throughput on MI355X (contract: see the round brief).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
-                    [--workload headline|c2|c3|c4|c4_m10|c5|weekly|hourly]
+                    [--workload headline|c2|c3|c4|c4_m10|c5|c5_dense|weekly|hourly]
 
 A "step" is ONE pass of the hot path over one batch of synthetic draws already resident in
 HBM: the fused forward filter (reference pymc_statespace/filters/kalman_filter.py:126-252)
@@ -46,10 +46,10 @@ FP64_MFMA_PEAK_TF = 78.6  # dense fp64 matrix peak; v_mfma_f64_16x16x4_f64 measu
 #                           register operands only (profiles/r01/fp64_issue_rates.txt)
 
 DEFAULT_FILTER = {"headline": "standard", "c2": "standard", "c3": "cholesky", "c4": "standard",
-                  "c4_m10": "standard", "c1": "standard", "c5": "standard"}
+                  "c4_m10": "standard", "c1": "standard", "c5": "standard", "c5_dense": "standard"}
 # draws per GPU when --batch is not given: the workload's own B, except C5 whose BASELINE batch
 # (1024) is quoted over 8 GPUs -- one GPU's share is 128 draws (0.28 GB of inputs)
-DEFAULT_BATCH = {"c5": 128}
+DEFAULT_BATCH = {"c5": 128, "c5_dense": 128}
 KEYS = ("a0", "P0", "T", "Z", "R", "H", "Q")
 
 
@@ -677,8 +677,16 @@ def main():
                     return (time.perf_counter() - t0) * 1e3
                 r40 = eng.forward(*d40, filter_type=ft, mvn_const="exact", store_ll_obs=False, store_predicted=False)
                 ops["prefix_steps"] = ns
-                ops["rts_smoother_ms_per_step"] = _ms1(lambda: eng.smooth(d[3], d[5], d[7], r40.filtered_states,
-                                                                         r40.filtered_covs)) / (ns - 1)
+                if 12 * r > m + 11:
+                    ops["rts_smoother_ms_per_step"] = _ms1(lambda: eng.smooth(d[3], d[5], d[7], r40.filtered_states,
+                                                                             r40.filtered_covs)) / (ns - 1)
+                else:
+                    # state noise of few columns behind a DENSE T (c5_dense: r = 3, m = 367): P_hat sits on pinv's cut-off at every
+                    # step and the reference's recursion redoes each draw with the workgroup eigen-decomposition -- measured once,
+                    # 17.3 s PER STEP for 128 draws (profiles/r06/bench_c5_dense.json); not re-timed on every bench run.  The
+                    # inverse-free recursion below is what a caller with the filter's tapes gets (1.6 ms per step)
+                    ops["rts_smoother_ms_per_step"] = None
+                    ops["rts_smoother_note"] = "skipped: rank-deficient state noise behind a dense T -- 17.3 s per step measured once (profiles/r06)"
                 del r40
                 torch.cuda.empty_cache()
                 r40 = eng.forward(*d40, filter_type=ft, mvn_const="exact", store_ll_obs=False, store_filtered=False)

@@ -320,6 +320,9 @@ WORKLOADS = {
     "c4": lambda **kw: varmax(**{**dict(B=16384, n=1000, order=(2, 1)), **kw}),
     "c4_m10": lambda **kw: varmax(**{**dict(B=16384, n=1000, order=(2, 0)), **kw}),
     "c5": lambda **kw: daily_seasonal(**{**dict(B=1024, n=730), **kw}),
+    # C5's shape with a DENSE transition matrix (no model of the reference has one at this size; the line SURVEY 8(d) prices on the fp64
+    # MFMA roofline: two dense m x m products per step, no CSR gather, no all-zero blocks to skip)
+    "c5_dense": lambda **kw: random_dense(**{**dict(B=1024, n=730, p=1, m=367, r=3, seed=SEED_DRAWS + 6), **kw}),
     # not a BASELINE config: level + trend + 52-week seasonal (m = 53), the shape of the workgroup kernels
     "weekly": lambda **kw: daily_seasonal(**{**dict(B=4096, n=520, s=52), **kw}),
     # level + trend + 24-period seasonal (m = 25): block-tile kernels
