@@ -138,6 +138,29 @@ def perform_logp_and_grad(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standa
     return [np.asarray(res.logp[0].item(), dtype=np.float64)] + [out[k] for k in GRAD_INPUT_NAMES]
 
 
+def _lead_system_batched(T, Z, R, H, Q, c, d):
+    """The system of a batch of draws -> (arrays as ``engine.forward`` takes them, names of the time-varying ones).  ONE leading draw
+    axis on everything; behind it a matrix is (rows, cols) when static and (n, rows, cols) when time-varying (the reference's 3-D
+    convention per draw, filters/utilities.py:1-20), c / d are (m,1) / (p,1) columns or (n,m,1) / (n,p,1) -- round 6: what
+    ``vectorize_graph`` makes of a per-draw node with time-varying inputs."""
+    out, tv = [], []
+    for name, x in zip(_TV_ORDER, (T, Z, R, H, Q, c, d)):
+        x = np.asarray(x, dtype=np.float64)
+        if name in ("c", "d"):
+            if x.ndim >= 3 and x.shape[-1] == 1:
+                x = x[..., 0]          # columns: (B,m,1) -> (B,m); (B,n,m,1) -> (B,n,m)
+            if x.ndim == 3:
+                tv.append(name)
+            elif x.ndim != 2:
+                raise ValueError(f"{name}: expected (B,k[,1]) or (B,n,k[,1]), got {x.shape}")
+        elif x.ndim == 4:
+            tv.append(name)
+        elif x.ndim != 3:
+            raise ValueError(f"Matrix {name} of a batch has {x.ndim} dimensions: 3 (draws, rows, columns) or 4 (draws, time, rows, columns).")
+        out.append(x)
+    return out, tuple(tv)
+
+
 def perform_filter_batched(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="standard",
                            mvn_const="reference", h_diagonal=False, engine=None, want=(True,) * 6):
     """B draws at once: data (n,p,1) shared, every other input with a leading axis B in the reference
@@ -151,9 +174,9 @@ def perform_filter_batched(data, a0, P0, T, Z, R, H, Q, c, d, filter_type="stand
         x = np.asarray(x, dtype=np.float64)
         return x[..., 0] if x.ndim == 3 and x.shape[-1] == 1 else x
 
-    res = eng.forward(data, vec(a0), np.asarray(P0), np.asarray(T), np.asarray(Z), np.asarray(R),
-                      np.asarray(H), np.asarray(Q), vec(c), vec(d), filter_type=filter_type,
-                      mvn_const=mvn_const, h_diagonal=bool(h_diagonal),
+    sysm, tv = _lead_system_batched(T, Z, R, H, Q, c, d)
+    res = eng.forward(data, vec(a0), np.asarray(P0), *sysm, filter_type=filter_type,
+                      mvn_const=mvn_const, h_diagonal=bool(h_diagonal), time_varying=tv,
                       store_filtered=bool(want[0] or want[2]), store_predicted=bool(want[1] or want[3]),
                       store_ll_obs=bool(want[5]))
     _raise_if_not_pd(res.info)
@@ -184,11 +207,18 @@ def perform_logp_and_grad_batched(data, a0, P0, T, Z, R, H, Q, c, d, filter_type
         x = np.asarray(x, dtype=np.float64)
         return x[..., 0] if x.ndim == 3 and x.shape[-1] == 1 else x
 
-    mats = [np.asarray(x, dtype=np.float64) for x in (P0, T, Z, R, H, Q)]
-    if any(x.ndim != 3 for x in mats):
-        raise NotImplementedError("the batched log-likelihood Op takes static system matrices with ONE leading draw axis")
-    logp, info, g = eng.value_and_grad(data, vec(a0), *mats, vec(c), vec(d), filter_type=filter_type,
-                                       mvn_const=mvn_const, h_diagonal=bool(h_diagonal))
+    sysm, tv = _lead_system_batched(T, Z, R, H, Q, c, d)
+    if not tv:   # one C-ABI call: the predicted tapes never leave the workspace (kf_filter_value_and_grad)
+        logp, info, g = eng.value_and_grad(data, vec(a0), np.asarray(P0, dtype=np.float64), *sysm, filter_type=filter_type,
+                                           mvn_const=mvn_const, h_diagonal=bool(h_diagonal))
+    else:        # time-varying matrices (round 6): forward with the predicted tapes in HBM, then the adjoint sweep -- two calls for all draws
+        dev = [eng.to_device(x) for x in (data, vec(a0), np.asarray(P0, dtype=np.float64), *sysm)]
+        res = eng.forward(*dev, filter_type=filter_type, mvn_const=mvn_const, h_diagonal=bool(h_diagonal),
+                          store_filtered=False, store_ll_obs=False, time_varying=tv)
+        g = eng.backward(*dev, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
+                         g_logp=np.ones(dev[2].shape[0]), filter_type=filter_type, mvn_const=mvn_const, want_cd=True,
+                         h_diagonal=bool(h_diagonal), time_varying=tv)
+        logp, info = res.logp, res.info
     _raise_if_not_pd(info)
     out = {k: g[k].cpu().numpy() for k in GRAD_INPUT_NAMES}
     for k in ("a0", "c", "d"):
@@ -239,16 +269,14 @@ def perform_filter_grad_batched(data, a0, P0, T, Z, R, H, Q, c, d, predicted_sta
         x = np.asarray(x, dtype=np.float64)
         return x[..., 0] if x.ndim == 3 and x.shape[-1] == 1 else x
 
-    mats = [np.asarray(x, dtype=np.float64) for x in (P0, T, Z, R, H, Q)]
-    if any(x.ndim != 3 for x in mats):
-        raise NotImplementedError("the batched gradient Op takes static system matrices with ONE leading draw axis")
+    sysm, tv = _lead_system_batched(T, Z, R, H, Q, c, d)
     pa = np.asarray(predicted_states, dtype=np.float64)
     if pa.ndim == 4:
         pa = pa[..., 0]
-    g = eng.backward(data, vec(a0), *mats, vec(c), vec(d), predicted_states=pa,
+    g = eng.backward(data, vec(a0), np.asarray(P0, dtype=np.float64), *sysm, predicted_states=pa,
                      predicted_covs=np.asarray(predicted_covs, dtype=np.float64),
                      g_logp=np.asarray(g_logp, dtype=np.float64), g_ll_obs=np.asarray(g_ll_obs, dtype=np.float64),
-                     filter_type=filter_type, mvn_const=mvn_const, want_cd=True, h_diagonal=h_diagonal)
+                     filter_type=filter_type, mvn_const=mvn_const, want_cd=True, h_diagonal=h_diagonal, time_varying=tv)
     out = {k: g[k].cpu().numpy() for k in GRAD_INPUT_NAMES}
     for k in ("a0", "c", "d"):
         out[k] = out[k][..., None]
@@ -346,12 +374,13 @@ def perform_smoother_batched(T, R, Q, filtered_states, filtered_covs, engine=Non
     per posterior draw (reference core/statespace.py:283-302 over :176-197)."""
     eng = engine or get_engine()
     T, R, Q = (np.asarray(x, dtype=np.float64) for x in (T, R, Q))
-    if T.ndim != 3 or R.ndim != 3 or Q.ndim != 3:
-        raise NotImplementedError("the batched smoother Op takes static T, R, Q with ONE leading draw axis")
+    if any(x.ndim not in (3, 4) for x in (T, R, Q)):
+        raise ValueError("the batched smoother Op takes T, R, Q with ONE leading draw axis: (B,rows,cols), or (B,n,rows,cols) time-varying")
+    tv = tuple(nm for nm, x in zip(("T", "R", "Q"), (T, R, Q)) if x.ndim == 4)   # (round 6: the vectorize_graph image of a time-varying node)
     fa = np.asarray(filtered_states, dtype=np.float64)
     if fa.ndim == 4:
         fa = fa[..., 0]
-    sa, sP = eng.smooth(T, R, Q, fa, np.asarray(filtered_covs, dtype=np.float64))
+    sa, sP = eng.smooth(T, R, Q, fa, np.asarray(filtered_covs, dtype=np.float64), time_varying=tv)
     return [sa.cpu().numpy()[..., None], sP.cpu().numpy()]
 
 
@@ -574,8 +603,10 @@ def _build_ops():
 
         def make_node(self, data, a0, P0, T, Z, R, H, Q, c, d):
             ins = [pt.as_tensor_variable(x) for x in (data, a0, P0, T, Z, R, H, Q, c, d)]
-            if any(v.type.ndim != 3 for v in ins[1:]) or ins[0].type.ndim not in (3, 4):
-                raise TypeError("KalmanLogpBatchedOp: a0 .. d carry one leading draw axis (3-D each); data is (n,p,1) or (B,n,p,1)")
+            if any(v.type.ndim not in (3, 4) for v in ins[1:]) or ins[1].type.ndim != 3 or ins[2].type.ndim != 3 \
+                    or ins[0].type.ndim not in (3, 4):
+                raise TypeError("KalmanLogpBatchedOp: a0 .. d carry one leading draw axis (3-D each; a time-varying matrix, c or d: "
+                                "4-D, time behind the draw axis); data is (n,p,1) or (B,n,p,1)")
             return Apply(self, ins, [pt.vector(dtype=f64)] + [ins[i].type() for i in range(1, 10)])
 
         def perform(self, node, inputs, output_storage):
@@ -637,7 +668,7 @@ def _build_ops():
                 storage[0] = _out(o) if o is not None else _placeholder(var.type.ndim)
 
         def infer_shape(self, fgraph, node, shapes):
-            n, B, m = shapes[0][-3], shapes[3][0], shapes[3][1]
+            n, B, m = shapes[0][-3], shapes[3][0], shapes[3][-1]   # T is (B,m,m), or (B,n,m,m) when time-varying
             want = tuple(self.want[:4]) + (True, self.want[5])
             return _shapes_following_want([(B, n, m, 1), (B, n + 1, m, 1), (B, n, m, m), (B, n + 1, m, m), (B,), (B, n)], want)
 
@@ -762,9 +793,11 @@ def _build_ops():
         def _batched_inputs(node, data, mats):
             """Inputs of a per-draw node after vectorize_graph gave some of them ONE leading draw axis -> (data, B-leading mats),
             or None when nothing is batched.  Unbatched matrices are broadcast along the new axis."""
-            core = [v.type.ndim for v in node.inputs[1:]]  # a0, c, d are (m,1) / (p,1) columns: 2-D per draw
-            if any(nd != 2 for nd in core):
-                raise NotImplementedError("vectorize_graph over a time-varying Kalman filter node")
+            # per draw: a0, c, d are (m,1) / (p,1) columns and the matrices 2-D; a time-varying matrix, c or d is 3-D, time on axis 0
+            # (round 6: such nodes vectorise too -- the batched kernels take (B, n, ...) inputs)
+            core = [v.type.ndim for v in node.inputs[1:]]
+            if core[0] != 2 or core[1] != 2 or any(nd not in (2, 3) for nd in core):
+                raise NotImplementedError("vectorize_graph: a0 and P0 are static; system matrices are 2-D (static) or 3-D (time-varying)")
             d_extra = data.type.ndim - node.inputs[0].type.ndim
             if d_extra not in (0, 1):
                 raise NotImplementedError("one leading batch axis only")
@@ -826,8 +859,9 @@ def _build_ops():
 
         def make_node(self, T, R, Q, filtered_states, filtered_covs):
             ins = [pt.as_tensor_variable(x) for x in (T, R, Q, filtered_states, filtered_covs)]
-            if [v.type.ndim for v in ins] != [3, 3, 3, 4, 4]:
-                raise TypeError("KalmanSmootherBatchedOp: static T, R, Q and the filtered tapes, ONE leading draw axis each")
+            nds = [v.type.ndim for v in ins]
+            if any(nd not in (3, 4) for nd in nds[:3]) or nds[3:] != [4, 4]:
+                raise TypeError("KalmanSmootherBatchedOp: T, R, Q (3-D; time-varying: 4-D) and the filtered tapes, ONE leading draw axis each")
             return Apply(self, ins, [pt.tensor4(dtype=f64), pt.tensor4(dtype=f64)])
 
         def perform(self, node, inputs, output_storage):
@@ -889,9 +923,7 @@ def _build_ops():
 
         @_vn.register(KalmanSmootherOp)
         def _vectorize_kalman_smoother(op, node, *ins):
-            if any(v.type.ndim != 2 for v in node.inputs[:3]):
-                raise NotImplementedError("vectorize_graph over a time-varying smoother node")
-            led = _lead_all(node.inputs, ins)
+            led = _lead_all(node.inputs, ins)   # (round 6: a time-varying T / R / Q keeps its time axis behind the draw axis)
             if led is None:
                 return op.make_node(*ins)
             return KalmanSmootherBatchedOp().make_node(*led)
@@ -900,9 +932,7 @@ def _build_ops():
         def _vectorize_kalman_smoother_fused(op, node, *ins):
             if op.batched:
                 raise NotImplementedError("one leading batch axis only")
-            if any(v.type.ndim != 2 for v in node.inputs[1:8]):
-                raise NotImplementedError("vectorize_graph over a time-varying smoother node")
-            led = _lead_all(node.inputs, ins, shared=(0,))
+            led = _lead_all(node.inputs, ins, shared=(0,))   # (time-varying inputs: the body falls back to kf_smoother on the filtered tapes)
             if led is None:
                 return op.make_node(*ins)
             return KalmanSmootherFusedOp(op.filter_type, batched=True).make_node(*led)

@@ -502,3 +502,31 @@ def test_fused_smoother_body_keeps_the_reference_recursion_for_a_nonzero_c_or_a_
         out = op.perform_smoother_fused(data, lead(T), lead(Z), lead(R), lead(H), lead(Q), c, lead(d0), lead(fs), lead(fP), lead(ps),
                                         lead(pP), engine=eng, batched=True)
         assert eng.calls == [want] and out[0].shape == (B, n, m, 1)
+
+
+def test_vectorize_graph_over_time_varying_nodes_builds_batched_nodes():
+    """Round 6 (missing #5): a per-draw node with a time-varying (3-D) matrix vectorises -- the batched nodes take the
+    draw axis in FRONT of the time axis ((B, n, rows, cols)); only a0 / P0 must be static.  Node classes and output ranks (CPU; the numeric half:
+    tests/test_pytensor_op.py::test_vectorize_graph_over_time_varying_nodes)."""
+    import pytensor.tensor as pt
+    from pytensor.graph.replace import vectorize_graph
+
+    from pymc_statespace_amd.filters import KalmanSmoother, StandardFilter
+
+    sym = _symbols()
+    Tt = pt.tensor3("Tt")
+    ins = [sym[0], sym[1], sym[2], Tt] + sym[4:]
+    outs = StandardFilter().build_graph(*ins)
+    sm = KalmanSmoother().build_graph(Tt, sym[5], sym[7], outs[0], outs[2])
+    logp = StandardFilter().build_graph(*ins, outputs="logp")
+    bT = pt.tensor4("T_draws")
+    vec = vectorize_graph([outs[4], outs[2], sm[1], logp], replace={Tt: bT})
+    assert [v.type.ndim for v in vec] == [1, 4, 4, 1]
+    f = pytensor.function([sym[0], sym[1], sym[2], bT] + sym[4:], vec, on_unused_input="ignore")
+    names = _op_names(f)
+    assert "KalmanFilterBatchedOp" in names and "KalmanLogpBatchedOp" in names and "KalmanSmootherFusedOp" in names
+    assert not any(nm in names for nm in ("KalmanFilterOp", "KalmanLogpOp", "KalmanSmootherOp"))
+    # a batched a0 WITH a time-varying T is fine; a time-varying a0 is not a thing
+    ba0 = pt.tensor3("a0_draws")
+    v2 = vectorize_graph(logp, replace={sym[1]: ba0})
+    assert v2.type.ndim == 1
