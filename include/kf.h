@@ -60,7 +60,7 @@ extern "C" {
 #define KF_API
 #endif
 
-#define KF_ABI_VERSION 6 /* 6: kf_smoother_from_filter. \
+#define KF_ABI_VERSION 7 /* 7: kf_filter_backward_tapes.  6: kf_smoother_from_filter. \
                           * 5: KF_FLAG_STEADY_STATE; the block kernel's steady-state phase off by default below 1536 steps; kf_workspace_bytes_for(KF_WS_FORWARD) covers the split pipeline. \
                           * 2: KF_FLAG_H_DIAGONAL, KF_KERNEL_MFMA, kf_dare, kf_simulate_statespace, workspace use by smoother/backward; \
                             3: kf_workspace_bytes_for, kf_forward_kernel_name_ws; every entry point runs on the handle's device; \
@@ -328,6 +328,30 @@ KF_API int kf_filter_backward(kf_handle* h, const kf_dims* dims,
                        double* g_a0, double* g_P0, double* g_T, double* g_Z,
                        double* g_R, double* g_H, double* g_Q, double* g_c, double* g_d,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* kf_filter_backward with cotangents of the filter's TAPE outputs as well (round 6; ABI 7): the gradient of
+ *   sum_b g_logp[b] logp[b] + sum g_ll_obs . ll_obs + sum g_filt_a . filtered_states + sum g_pred_a . predicted_states
+ *   + sum g_filt_P . filtered_covs + sum g_pred_P . predicted_covs
+ * with respect to every input -- what autodiff of the reference's scan gives for a loss on any of the filter's outputs
+ * (README.md:6; filters/kalman_filter.py:166-212 returns all six).  Shapes as the forward's outputs: g_filt_a [B][T][m],
+ * g_pred_a [B][T+1][m], g_filt_P [B][T][m][m], g_pred_P [B][T+1][m][m]; any of the six cotangents may be NULL (= 0), not all.
+ * Covariance cotangents need not be symmetric (the filter's covariances are: only the symmetric part acts); predicted slot 0 is
+ * (a0, P0) as given, so its cotangent goes to g_a0 / g_P0 unchanged.  Everything else as kf_filter_backward.
+ * Kernel: the LDS-resident adjoint (one draw per lane group, csrc/kf_backward_lds.hip) -- every filter type, missing
+ * observations, time-varying matrices; KF_ERR_UNSUPPORTED when m, p do not fit 160 KiB of LDS (m > ~45).  With all four tape
+ * cotangents NULL the call IS kf_filter_backward (same dispatch). */
+KF_API int kf_filter_backward_tapes(kf_handle* h, const kf_dims* dims,
+                             const double* y, const double* a0, const double* P0,
+                             const double* T, const double* Z, const double* R,
+                             const double* H, const double* Q,
+                             const double* c, const double* d,
+                             const double* pred_a, const double* pred_P,
+                             const double* g_logp, const double* g_ll_obs,
+                             const double* g_filt_a, const double* g_pred_a,
+                             const double* g_filt_P, const double* g_pred_P,
+                             double* g_a0, double* g_P0, double* g_T, double* g_Z,
+                             double* g_R, double* g_H, double* g_Q, double* g_c, double* g_d,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* RTS smoother over the filtered tapes: smooth_a [B][T][m], smooth_P [B][T][m][m].
  * Only dims->B, T, m, r and the KF_FLAG_TV_T / _R / _Q flags are used.  The gain uses the Moore-Penrose

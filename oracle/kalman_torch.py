@@ -28,10 +28,13 @@ def _t(x):
 
 
 def kalman_logp(y, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type="standard",
-                mvn_const="reference", time_varying=()):
+                mvn_const="reference", time_varying=(), tapes=None):
     """Batched (leading B) torch tensors -> (logp (B,), ll_obs (B,n)). y: (n,p) numpy/tensor.
     Names in ``time_varying`` (subset of T,Z,R,H,Q,c,d) carry a time axis after the draw axis and step t uses slice t
-    for its update and its predict (reference filters/kalman_filter.py:231-252)."""
+    for its update and its predict (reference filters/kalman_filter.py:231-252).
+    ``tapes``: a dict that receives the other four outputs of the reference's scan (filters/kalman_filter.py:166-212) --
+    filtered_states (B,n,m), predicted_states (B,n+1,m), filtered_covs (B,n,m,m), predicted_covs (B,n+1,m,m), slot 0 of the
+    predicted tapes = (a0, P0) -- as differentiable tensors."""
     y = torch.as_tensor(np.asarray(y), dtype=torch.float64)
     B, m = a0.shape
     tv = set(time_varying)
@@ -44,6 +47,7 @@ def kalman_logp(y, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type="standard"
     d = torch.zeros(B, p, dtype=torch.float64) if d is None else d
     full = dict(T=T, Z=Z, R=R, H=H, Q=Q, c=c, d=d)
     lls = []
+    fa, pa, fP, pP = [], [a0], [], [P0]
     for t in range(n):
         T, Z, R, H, Q, cz, dz = (full[k][:, t] if k in tv else full[k] for k in ("T", "Z", "R", "H", "Q", "c", "d"))
         RQR = R @ Q @ _t(R)
@@ -94,7 +98,14 @@ def kalman_logp(y, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type="standard"
         a = torch.einsum("bij,bj->bi", T, a_f) + cz
         S = T @ P_f @ _t(T) + RQR
         P = 0.5 * (S + _t(S))
+        fa.append(a_f)
+        fP.append(P_f)
+        pa.append(a)
+        pP.append(P)
     ll_obs = torch.stack(lls, dim=1)
+    if tapes is not None:
+        tapes.update(filtered_states=torch.stack(fa, dim=1), predicted_states=torch.stack(pa, dim=1),
+                     filtered_covs=torch.stack(fP, dim=1), predicted_covs=torch.stack(pP, dim=1))
     return ll_obs.sum(dim=1), ll_obs
 
 
@@ -102,9 +113,10 @@ NAMES = ("a0", "P0", "T", "Z", "R", "H", "Q", "c", "d")
 
 
 def logp_and_grads(y, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type="standard",
-                   mvn_const="reference", g_logp=None, g_ll_obs=None, time_varying=()):
+                   mvn_const="reference", g_logp=None, g_ll_obs=None, time_varying=(), g_tapes=None):
     """Returns (logp, ll_obs, grads dict) with numpy arrays; grads of
-    sum_b g_logp[b] logp[b] + sum_{b,t} g_ll_obs[b,t] ll_obs[b,t].  The gradient of a matrix named in
+    sum_b g_logp[b] logp[b] + sum_{b,t} g_ll_obs[b,t] ll_obs[b,t] (+ sum over ``g_tapes``: a dict of cotangents keyed by the
+    tape names of ``kalman_logp``; then ``g_logp=None`` means 0, not ones).  The gradient of a matrix named in
     ``time_varying`` has that matrix's (B,n,.,.) shape."""
     B, m = np.asarray(a0).shape
     p = np.asarray(Z).shape[-2]
@@ -114,10 +126,16 @@ def logp_and_grads(y, a0, P0, T, Z, R, H, Q, c=None, d=None, filter_type="standa
                 c=np.zeros((B, n, m) if "c" in tv else (B, m)) if c is None else c,
                 d=np.zeros((B, n, p) if "d" in tv else (B, p)) if d is None else d)
     ts = {k: torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True) for k, v in vals.items()}
+    tapes = {} if g_tapes else None
     logp, ll_obs = kalman_logp(y, ts["a0"], ts["P0"], ts["T"], ts["Z"], ts["R"], ts["H"], ts["Q"],
-                               ts["c"], ts["d"], filter_type=filter_type, mvn_const=mvn_const, time_varying=tv)
-    gl = torch.ones(B, dtype=torch.float64) if g_logp is None else torch.as_tensor(g_logp)
+                               ts["c"], ts["d"], filter_type=filter_type, mvn_const=mvn_const, time_varying=tv, tapes=tapes)
+    if g_logp is None:
+        gl = torch.zeros(B, dtype=torch.float64) if g_tapes else torch.ones(B, dtype=torch.float64)
+    else:
+        gl = torch.as_tensor(g_logp)
     obj = (gl * logp).sum()
+    for k, gk in (g_tapes or {}).items():
+        obj = obj + (torch.as_tensor(np.asarray(gk, dtype=np.float64)) * tapes[k]).sum()
     if g_ll_obs is not None:
         obj = obj + (torch.as_tensor(g_ll_obs) * ll_obs).sum()
     obj.backward()

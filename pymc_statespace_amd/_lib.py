@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # KF_LIB_PATH: developer override for A/B experiments with instrumented builds of the same ABI
 LIB_PATH = os.environ.get("KF_LIB_PATH") or os.path.join(_HERE, "libkf_hip.so")
 
-KF_ABI_VERSION = 6
+KF_ABI_VERSION = 7
 
 KF_FILTER = {"standard": 0, "cholesky": 1, "univariate": 2, "single": 3}
 KF_FLAG_MVN_CONST_EXACT = 1 << 0
@@ -32,7 +32,7 @@ KF_OK, KF_ERR_ARG, KF_ERR_HIP, KF_ERR_WORKSPACE, KF_ERR_UNSUPPORTED = 0, -1, -2,
 EXPORTS = (
     "kf_abi_version", "kf_create", "kf_destroy", "kf_last_error", "kf_set_lanes_per_draw",
     "kf_set_forward_kernel", "kf_forward_kernel_name", "kf_forward_kernel_name_ws", "kf_last_forward_kernel",
-    "kf_workspace_bytes", "kf_workspace_bytes_for", "kf_filter_forward", "kf_filter_backward", "kf_filter_value_and_grad", "kf_smoother", "kf_smoother_from_filter",
+    "kf_workspace_bytes", "kf_workspace_bytes_for", "kf_filter_forward", "kf_filter_backward", "kf_filter_backward_tapes", "kf_filter_value_and_grad", "kf_smoother", "kf_smoother_from_filter",
     "kf_assemble", "kf_lyapunov", "kf_conditional_simulation", "kf_dare", "kf_dare_backward", "kf_simulate_statespace",
 )
 
@@ -95,6 +95,9 @@ def load():
     lib.kf_filter_backward.argtypes = [vp, C.POINTER(KfDims)] + [dp] * 10 + [dp] * 4 + [dp] * 9 + [
         vp, C.c_size_t, vp]
     lib.kf_filter_backward.restype = C.c_int
+    lib.kf_filter_backward_tapes.argtypes = [vp, C.POINTER(KfDims)] + [dp] * 10 + [dp] * 8 + [dp] * 9 + [
+        vp, C.c_size_t, vp]
+    lib.kf_filter_backward_tapes.restype = C.c_int
     lib.kf_filter_value_and_grad.argtypes = [vp, C.POINTER(KfDims)] + [dp] * 10 + [dp, dp, ip] + [dp] * 9 + [
         vp, C.c_size_t, vp]
     lib.kf_filter_value_and_grad.restype = C.c_int

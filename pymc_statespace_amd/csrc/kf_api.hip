@@ -499,6 +499,15 @@ int kf_launch_backward_lds(kf_handle* h, const KfBwdArgs& a, hipStream_t stream)
 
 int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t workspace_bytes,
                        hipStream_t stream) {
+  // cotangents of the tape outputs (kf_filter_backward_tapes): the LDS-resident adjoint is the one that carries them
+  if (a.g_filt_a || a.g_pred_a || a.g_filt_P || a.g_pred_P) {
+    if (!kf_backward_lds_fits(a.m, a.p)) {
+      KF_SET_ERR(h, "kf_filter_backward_tapes: cotangents of the tape outputs need the LDS-resident adjoint (m=%d p=%d does "
+                 "not fit %d B of LDS)", a.m, a.p, KF_LDS_BYTES_MAX);
+      return KF_ERR_UNSUPPORTED;
+    }
+    return kf_launch_backward_lds(h, a, stream);
+  }
   // time-varying system matrices: the LDS-resident adjoint reloads slice t per step and writes gradient tapes
   if (a.flags & KF_FLAG_TV_ANY) {
     // round 5: T / Z / H / c / d time-varying (R, Q static), m <= 16, scalar observations: the accumulator-layout adjoint with
@@ -854,6 +863,37 @@ extern "C" int kf_filter_backward(kf_handle* h, const kf_dims* dims, const doubl
   a.tape_T = dims->T; a.y_T = dims->T; a.tile_tape = nullptr; a.init_ab = nullptr; a.init_Pb = nullptr; a.accumulate = 0;
   // (internal: the whitened inner call of kf_filter_value_and_grad on a dense-H model asks the scalar-observation adjoint for Gamma~ too)
   if (h->vg_gyy && a.p > 1 && (a.flags & KF_FLAG_H_DIAGONAL) && a.m <= KF_MP_M_MAX && a.p <= KF_MP_P_MAX) a.g_yy = h->vg_gyy;
+  return kf_launch_backward(h, a, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int kf_filter_backward_tapes(kf_handle* h, const kf_dims* dims, const double* y, const double* a0,
+                                        const double* P0, const double* T, const double* Z, const double* R,
+                                        const double* H, const double* Q, const double* c, const double* d,
+                                        const double* pred_a, const double* pred_P, const double* g_logp,
+                                        const double* g_ll_obs, const double* g_filt_a, const double* g_pred_a,
+                                        const double* g_filt_P, const double* g_pred_P, double* g_a0, double* g_P0,
+                                        double* g_T, double* g_Z, double* g_R, double* g_H, double* g_Q, double* g_c,
+                                        double* g_d, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_dims(h, dims, true);
+  if (rc) return rc;
+  if (!y || !a0 || !P0 || !T || !Z || !R || !H || !Q || !pred_a || !pred_P) {
+    KF_SET_ERR(h, "kf_filter_backward_tapes: inputs and the predicted tapes must be non-NULL");
+    return KF_ERR_ARG;
+  }
+  if (!g_logp && !g_ll_obs && !g_filt_a && !g_pred_a && !g_filt_P && !g_pred_P) {
+    KF_SET_ERR(h, "kf_filter_backward_tapes: every cotangent is NULL");
+    return KF_ERR_ARG;
+  }
+  KF_ON_DEVICE(h);
+  KfBwdArgs a;
+  a.B = dims->B; a.T = dims->T; a.p = dims->p; a.m = dims->m; a.r = dims->r;
+  a.filter = dims->filter; a.flags = dims->flags;
+  a.y = y; a.a0 = a0; a.P0 = P0; a.Tm = T; a.Z = Z; a.R = R; a.H = H; a.Q = Q; a.c = c; a.d = d;
+  a.pred_a = pred_a; a.pred_P = pred_P; a.g_logp = g_logp; a.g_ll_obs = g_ll_obs;
+  a.g_filt_a = g_filt_a; a.g_pred_a = g_pred_a; a.g_filt_P = g_filt_P; a.g_pred_P = g_pred_P;
+  a.g_a0 = g_a0; a.g_P0 = g_P0; a.g_T = g_T; a.g_Z = g_Z; a.g_R = g_R; a.g_H = g_H; a.g_Q = g_Q;
+  a.g_c = g_c; a.g_d = g_d;
+  a.tape_T = dims->T; a.y_T = dims->T; a.tile_tape = nullptr; a.init_ab = nullptr; a.init_Pb = nullptr; a.accumulate = 0;
   return kf_launch_backward(h, a, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

@@ -237,6 +237,16 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_lds_kernel(const KfBwdArgs A) 
   const double* gpa = A.pred_a + b * (long)(n + 1) * m;
   const double* gpP = A.pred_P + b * (long)(n + 1) * mm;
   const double g_all = A.g_logp ? A.g_logp[b] : 0.0;
+  // cotangents of the tape outputs (kf_filter_backward_tapes): (ab, Pb) -- the adjoint of the predicted moments of step t + 1 when
+  // step t starts -- begins at the cotangent of predicted slot T and collects slot t's at the end of step t; the filtered
+  // moments' cotangents join abf = T' ab and Sb = T' Gm T (P_f is symmetric by construction: its cotangent's symmetric part)
+  const double* gfa = A.g_filt_a ? A.g_filt_a + b * (long)n * m : nullptr;
+  const double* gpa_c = A.g_pred_a ? A.g_pred_a + b * (long)(n + 1) * m : nullptr;
+  const double* gfP = A.g_filt_P ? A.g_filt_P + b * (long)n * mm : nullptr;
+  const double* gpP_c = A.g_pred_P ? A.g_pred_P + b * (long)(n + 1) * mm : nullptr;
+  if (gpa_c) for (int e = lig; e < m; e += G) ab[e] = gpa_c[(long)n * m + e];
+  if (gpP_c) for (int e = lig; e < mm; e += G) Pb[e] = gpP_c[(long)n * mm + e];
+  if (gpa_c || gpP_c) wsync();
   const unsigned tv = A.flags & KF_FLAG_TV_ANY;
   const bool tv_rq = (tv & (KF_FLAG_TV_R | KF_FLAG_TV_Q)) != 0;
   const int mr = m * r, rr = r * r;
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_lds_kernel(const KfBwdArgs A) 
     for (int i = lig; i < m; i += G) {
       double s = 0.0;
       for (int k = 0; k < m; ++k) s += Tl[k * m + i] * ab[k];
-      abf[i] = s;
+      abf[i] = gfa ? s + gfa[(long)t * m + i] : s;
       cb[i] += ab[i];
     }
     wsync();
@@ -398,6 +408,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_lds_kernel(const KfBwdArgs A) 
       int i = e / m, j = e - i * m;
       double s = 0.0;
       for (int k = 0; k < m; ++k) s += Tl[k * m + i] * Pf[k * m + j];
+      if (gfP) s += 0.5 * (gfP[(long)t * mm + e] + gfP[(long)t * mm + j * m + i]);
       Wb[e] = s;
     }
     wsync();
@@ -488,7 +499,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_lds_kernel(const KfBwdArgs A) 
         s += zqi * KZ[q * m + j];
         s += Mb[i * p + q] * zqj;
       }
-      Pb[e] = s;
+      Pb[e] = gpP_c ? s + gpP_c[(long)t * mm + e] : s;
     }
     for (int e = lig; e < pm; e += G) {
       int q = e / m, j = e - q * m;
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_bwd_lds_kernel(const KfBwdArgs A) 
       double s = abf[j];
       for (int q = 0; q < p; ++q)
         if (ob[q] != 0.0) s -= Zl[q * m + j] * vb[q];
-      ab[j] = s;
+      ab[j] = gpa_c ? s + gpa_c[(long)t * m + j] : s;
     }
     for (int q = lig; q < p; q += G)
       if (ob[q] != 0.0) db[q] += dsign * vb[q];

@@ -174,6 +174,13 @@ struct KfBwdArgs {
   const double* pred_P;
   const double* g_logp;
   const double* g_ll_obs;
+  // cotangents of the filter's tape outputs (kf_filter_backward_tapes; NULL = 0): filtered / predicted states [B][T][m] /
+  // [B][T+1][m], filtered / predicted covariances [B][T][m][m] / [B][T+1][m][m].  Honoured by the LDS-resident adjoint only
+  // (kf_backward_lds.hip): kf_launch_backward routes there when one of them is set
+  const double* g_filt_a = nullptr;
+  const double* g_pred_a = nullptr;
+  const double* g_filt_P = nullptr;
+  const double* g_pred_P = nullptr;
   double* g_a0;
   double* g_P0;
   double* g_T;

@@ -291,9 +291,14 @@ class KalmanEngine:
 
     # --------------------------------------------------------------- backward
     def backward(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, predicted_states,
-                 predicted_covs, g_logp=None, g_ll_obs=None, filter_type="standard",
+                 predicted_covs, g_logp=None, g_ll_obs=None, g_filtered_states=None, g_predicted_states=None,
+                 g_filtered_covs=None, g_predicted_covs=None, filter_type="standard",
                  mvn_const="reference", want_cd=False, h_diagonal=False, time_varying=()):
         """kf_filter_backward -> dict of per-draw gradients (a0,P0,T,Z,R,H,Q[,c,d]).
+
+        ``g_filtered_states`` (B,n,m), ``g_predicted_states`` (B,n+1,m), ``g_filtered_covs`` (B,n,m,m),
+        ``g_predicted_covs`` (B,n+1,m,m): cotangents of the forward's tape outputs -- with any of them the call is
+        kf_filter_backward_tapes (the LDS-resident adjoint; KF_ERR_UNSUPPORTED beyond m ~ 45).
 
         ``h_diagonal=True`` (KF_FLAG_H_DIAGONAL) lets Standard/Cholesky with p > 1, m <= 48 use the
         scalar-observation adjoint kernel: g["H"] then carries the diagonal only and g["P0"] the
@@ -330,6 +335,11 @@ class KalmanEngine:
         pP = self.to_device(predicted_covs, (B, n + 1, m, m))
         g_logp = self.to_device(g_logp, (B,)) if g_logp is not None else None
         g_ll = self.to_device(g_ll_obs, (B, n)) if g_ll_obs is not None else None
+        g_fa = self.to_device(g_filtered_states, (B, n, m)) if g_filtered_states is not None else None
+        g_pa = self.to_device(g_predicted_states, (B, n + 1, m)) if g_predicted_states is not None else None
+        g_fP = self.to_device(g_filtered_covs, (B, n, m, m)) if g_filtered_covs is not None else None
+        g_pP = self.to_device(g_predicted_covs, (B, n + 1, m, m)) if g_predicted_covs is not None else None
+        tapes = any(x is not None for x in (g_fa, g_pa, g_fP, g_pP))
         dims = self._dims(B, n, p, m, r, filter_type, mvn_const, y_per_draw)
         for name in tv:
             dims.flags |= _lib.KF_FLAG_TV[name]
@@ -348,12 +358,16 @@ class KalmanEngine:
             g["c"] = empty("c", m)
             g["d"] = empty("d", p)
         ws, ws_bytes = self._workspace(dims, _lib.KF_WS_BACKWARD)  # large m only (kf_backward_big.hip)
-        rc = self.lib.kf_filter_backward(
-            self._h, C.byref(dims), _ptr(y), _ptr(a0), _ptr(P0), _ptr(T), _ptr(Z), _ptr(R), _ptr(H),
-            _ptr(Q), _ptr(c), _ptr(d), _ptr(pa), _ptr(pP), _ptr(g_logp), _ptr(g_ll),
-            _ptr(g["a0"]), _ptr(g["P0"]), _ptr(g["T"]), _ptr(g["Z"]), _ptr(g["R"]), _ptr(g["H"]),
-            _ptr(g["Q"]), _ptr(g.get("c")), _ptr(g.get("d")), _ptr(ws), ws_bytes, self._stream())
-        self._check(rc, "kf_filter_backward")
+        outs = (_ptr(g["a0"]), _ptr(g["P0"]), _ptr(g["T"]), _ptr(g["Z"]), _ptr(g["R"]), _ptr(g["H"]),
+                _ptr(g["Q"]), _ptr(g.get("c")), _ptr(g.get("d")), _ptr(ws), ws_bytes, self._stream())
+        ins = (self._h, C.byref(dims), _ptr(y), _ptr(a0), _ptr(P0), _ptr(T), _ptr(Z), _ptr(R), _ptr(H),
+               _ptr(Q), _ptr(c), _ptr(d), _ptr(pa), _ptr(pP), _ptr(g_logp), _ptr(g_ll))
+        if tapes:
+            rc = self.lib.kf_filter_backward_tapes(*ins, _ptr(g_fa), _ptr(g_pa), _ptr(g_fP), _ptr(g_pP), *outs)
+            self._check(rc, "kf_filter_backward_tapes")
+        else:
+            rc = self.lib.kf_filter_backward(*ins, *outs)
+            self._check(rc, "kf_filter_backward")
         return g
 
     def value_and_grad(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, g_logp=None, filter_type="standard",

@@ -433,3 +433,143 @@ def test_tile_smoother_from_filter_variants(eng, monkeypatch):
     wa, wP = eng.smooth_from_filter(yb, w["T"], w["Z"], w["H"], res.predicted_states, res.predicted_covs, d=d, filter_type="single")
     assert_allclose(sa.cpu().numpy(), wa.cpu().numpy(), rtol=1e-10, atol=1e-10)
     assert_allclose(sP.cpu().numpy(), wP.cpu().numpy(), rtol=1e-10, atol=1e-10)
+
+
+# ---- gradients through the filter's tape outputs (kf_filter_backward_tapes; VERDICT round 5, missing #5) ------------------------------
+# The reference differentiates a loss on ANY of the scan's outputs for free (README.md:6; filters/kalman_filter.py:166-212 returns the
+# six of them); checker: torch.autograd through the torch restatement of the same scan (oracle/kalman_torch.py, its tapes pinned
+# to the numpy oracle in tests/test_oracle_torch.py).  Tolerance: 1e-8 of the largest entry of each gradient.
+TAPE_CASES = {
+    "dense_p1m3": (lambda: W.random_dense(5, 20, 1, 3, 2, seed=21), "standard"),
+    "dense_p2m4_fullH": (lambda: W.random_dense(4, 15, 2, 4, 2, seed=22, h_diag=False), "standard"),
+    "dense_p3m6_univariate": (lambda: W.random_dense(3, 12, 3, 6, 3, seed=23), "univariate"),
+    "structural_m10": (lambda: W.structural(B=3, n=25), "standard"),
+    "arma11_cholesky": (lambda: W.arma11(B=6, n=30), "cholesky"),
+}
+
+
+def _tape_cotangents(rng, B, n, m, which):
+    g = {}
+    if "fa" in which:
+        g["filtered_states"] = rng.standard_normal((B, n, m))
+    if "pa" in which:
+        g["predicted_states"] = rng.standard_normal((B, n + 1, m))
+    if "fP" in which:
+        x = rng.standard_normal((B, n, m, m))
+        g["filtered_covs"] = 0.5 * (x + np.swapaxes(x, -1, -2))
+    if "pP" in which:
+        x = rng.standard_normal((B, n + 1, m, m))
+        g["predicted_covs"] = 0.5 * (x + np.swapaxes(x, -1, -2))
+    return g
+
+
+def _backward_tapes(eng, w, ft, gt, y=None, c=None, d=None, g_logp=None, g_ll=None, tv=(), T=None):
+    args = [w["y"] if y is None else y, w["a0"], w["P0"], w["T"] if T is None else T, w["Z"], w["R"], w["H"], w["Q"]]
+    res = eng.forward(*args, c=c, d=d, filter_type=ft, mvn_const="exact", time_varying=tv)
+    return eng.backward(*args, c=c, d=d, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
+                        g_logp=g_logp, g_ll_obs=g_ll, g_filtered_states=gt.get("filtered_states"),
+                        g_predicted_states=gt.get("predicted_states"), g_filtered_covs=gt.get("filtered_covs"),
+                        g_predicted_covs=gt.get("predicted_covs"), filter_type=ft, mvn_const="exact", want_cd=True,
+                        time_varying=tv)
+
+
+def _assert_grads(g, ref, names=("a0", "P0", "T", "Z", "R", "H", "Q", "c", "d"), tol=1e-8, sym_P0=False):
+    for k in names:
+        got = g[k].cpu().numpy()
+        if k == "P0" and sym_P0:   # (the Univariate restatement reads P z where the kernels' shared adjoint reads z' P: the two agree
+            # on symmetric P0 -- all a covariance can be -- and differ in the antisymmetric part of the entrywise gradient)
+            got = 0.5 * (got + np.swapaxes(got, -1, -2))
+            ref = dict(ref, P0=0.5 * (ref["P0"] + np.swapaxes(ref["P0"], -1, -2)))
+        scale = 1.0 + np.max(np.abs(ref[k]))
+        assert np.max(np.abs(got - ref[k])) / scale < tol, (k, np.max(np.abs(got - ref[k])) / scale)
+
+
+@pytest.mark.parametrize("case", sorted(TAPE_CASES))
+@pytest.mark.parametrize("which", ["fa", "pa", "fP", "pP", "fa+pa+fP+pP"])
+def test_backward_tapes_matches_autograd(eng, case, which):
+    from oracle import kalman_torch as kt
+
+    make, ft = TAPE_CASES[case]
+    w = make()
+    rng = np.random.default_rng(5)
+    gt = _tape_cotangents(rng, w["B"], w["n"], w["m"], which.split("+"))
+    g = _backward_tapes(eng, w, ft, gt)
+    oft = "standard" if ft == "cholesky" else ft
+    _, _, ref = kt.logp_and_grads(w["y"], w["a0"], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"], filter_type=oft,
+                                  mvn_const="exact", g_tapes=gt)
+    _assert_grads(g, ref, sym_P0=(ft == "univariate"))
+
+
+def test_backward_tapes_with_logp_ll_c_d_and_missing(eng):
+    """All six cotangents at once, c and d given, observations missing (whole steps and single entries)."""
+    from oracle import kalman_torch as kt
+
+    w = W.random_dense(4, 18, 2, 5, 2, seed=31)
+    rng = np.random.default_rng(6)
+    y = w["y"].copy()
+    y[3] = np.nan
+    y[7, 1] = np.nan
+    y[-1] = np.nan
+    c = 0.2 * rng.standard_normal((4, 5))
+    d = 0.3 * rng.standard_normal((4, 2))
+    g_logp = rng.standard_normal(4)
+    g_ll = rng.standard_normal((4, 18))
+    gt = _tape_cotangents(rng, 4, 18, 5, ("fa", "pa", "fP", "pP"))
+    g = _backward_tapes(eng, w, "standard", gt, y=y, c=c, d=d, g_logp=g_logp, g_ll=g_ll)
+    _, _, ref = kt.logp_and_grads(y, w["a0"], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"], c=c, d=d, mvn_const="exact",
+                                  g_logp=g_logp, g_ll_obs=g_ll, g_tapes=gt)
+    _assert_grads(g, ref)
+
+
+def test_backward_tapes_time_varying_T(eng):
+    from oracle import kalman_torch as kt
+
+    w = W.random_dense(3, 14, 1, 4, 2, seed=32)
+    rng = np.random.default_rng(7)
+    Tt = w["T"][:, None] * (1.0 + 0.05 * rng.standard_normal((3, 14, 1, 1)))
+    gt = _tape_cotangents(rng, 3, 14, 4, ("fa", "pP"))
+    g = _backward_tapes(eng, w, "standard", gt, tv=("T",), T=Tt)
+    _, _, ref = kt.logp_and_grads(w["y"], w["a0"], w["P0"], Tt, w["Z"], w["R"], w["H"], w["Q"], mvn_const="exact",
+                                  time_varying=("T",), g_tapes=gt)
+    assert g["T"].shape == (3, 14, 4, 4)
+    _assert_grads(g, ref)
+
+
+def test_backward_tapes_only_the_symmetric_part_of_a_covariance_cotangent_acts(eng):
+    """include/kf.h: the filter's covariances are symmetric by construction, so G and (G + G') / 2 give the same gradients --
+    except g_P0 from predicted slot 0, which is P0 as given and takes its cotangent unchanged."""
+    w = W.random_dense(3, 10, 1, 4, 2, seed=33)
+    rng = np.random.default_rng(8)
+    G = rng.standard_normal((3, 10, 4, 4))
+    a = _backward_tapes(eng, w, "standard", {"filtered_covs": G})
+    b = _backward_tapes(eng, w, "standard", {"filtered_covs": 0.5 * (G + np.swapaxes(G, -1, -2))})
+    for k in a:
+        assert_allclose(a[k].cpu().numpy(), b[k].cpu().numpy(), rtol=1e-13, atol=1e-13, err_msg=k)
+    Gp = np.zeros((3, 11, 4, 4))
+    Gp[:, 0] = rng.standard_normal((3, 4, 4))
+    c = _backward_tapes(eng, w, "standard", {"predicted_covs": Gp})
+    assert np.allclose(c["P0"].cpu().numpy(), Gp[:, 0], rtol=0, atol=1e-14)
+    assert float(c["T"].abs().max()) == 0.0
+
+
+def test_backward_tapes_without_tape_cotangents_is_kf_filter_backward(eng):
+    w = W.structural(B=8, n=40)
+    args = [w["y"], w["a0"], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"]]
+    res = eng.forward(*args, mvn_const="exact")
+    g_logp = np.linspace(0.5, 1.5, 8)
+    a = eng.backward(*args, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs, g_logp=g_logp, mvn_const="exact")
+    zero = np.zeros((8, 40, 10))
+    b = eng.backward(*args, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs, g_logp=g_logp,
+                     g_filtered_states=zero, mvn_const="exact")
+    for k in a:   # (different kernels: the block adjoint against the LDS-resident one)
+        ref = a[k].cpu().numpy()
+        assert np.max(np.abs(b[k].cpu().numpy() - ref)) <= 1e-9 * (1.0 + np.max(np.abs(ref))), k
+
+
+def test_backward_tapes_beyond_lds_is_refused(eng):
+    w = W.random_dense(2, 6, 1, 60, 2, seed=34)
+    args = [w["y"], w["a0"], w["P0"], w["T"], w["Z"], w["R"], w["H"], w["Q"]]
+    res = eng.forward(*args, mvn_const="exact")
+    with pytest.raises(Exception, match="LDS"):
+        eng.backward(*args, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
+                     g_filtered_states=np.ones((2, 6, 60)), mvn_const="exact")
