@@ -226,11 +226,40 @@ def perform_logp_and_grad_batched(data, a0, P0, T, Z, R, H, Q, c, d, filter_type
     return [logp.cpu().numpy()] + [out[k] for k in GRAD_INPUT_NAMES]
 
 
+def _tape_cotangent(g, lead):
+    """A tape cotangent as the C-ABI wants it -- trailing unit axis of the state tapes dropped, ``lead`` draw axes in front -- or
+    None for the zero-size placeholder that stands for "no cotangent on this output"."""
+    if g is None:
+        return None
+    g = np.asarray(g, dtype=np.float64)
+    if g.size == 0:
+        return None
+    return g
+
+
+def _state_cotangent(g, batched):
+    g = _tape_cotangent(g, 0)
+    if g is None:
+        return None
+    if g.ndim == (4 if batched else 3):   # (.., n, m, 1): the graph's state tapes are columns
+        g = g[..., 0]
+    return g if batched else g[None]
+
+
+def _cov_cotangent(g, batched):
+    g = _tape_cotangent(g, 0)
+    if g is None:
+        return None
+    return g if batched else g[None]
+
+
 def perform_filter_grad(data, a0, P0, T, Z, R, H, Q, c, d, predicted_states, predicted_covs,
-                        g_logp, g_ll_obs, filter_type="standard", mvn_const="reference",
+                        g_logp, g_ll_obs, g_filtered_states=None, g_predicted_states=None, g_filtered_covs=None,
+                        g_predicted_covs=None, filter_type="standard", mvn_const="reference",
                         h_diagonal=False, engine=None):
-    """Gradients of g_logp*logp + <g_ll_obs, ll_obs> w.r.t. (a0,P0,T,Z,R,H,Q,c,d), shaped like
-    the inputs (a0 (m,1), c (m,1), d (p,1))."""
+    """Gradients of g_logp*logp + <g_ll_obs, ll_obs> (+ <cotangent, tape> for the four tape outputs: round 6,
+    kf_filter_backward_tapes) w.r.t. (a0,P0,T,Z,R,H,Q,c,d), shaped like the inputs (a0 (m,1), c (m,1), d (p,1)).
+    A zero-size tape cotangent means none; zero-size predicted tapes (the node was built without them) are recomputed here."""
     eng = engine or get_engine()
     data = np.asarray(data, dtype=np.float64)
     if data.ndim == 3:
@@ -241,10 +270,21 @@ def perform_filter_grad(data, a0, P0, T, Z, R, H, Q, c, d, predicted_states, pre
     if pa.ndim == 3:
         pa = pa[..., 0]
     sysm, tv = _lead_system(T, Z, R, H, Q, c, d)
+    pP = np.asarray(predicted_covs, dtype=np.float64)
+    if pa.size == 0 or pP.size == 0:
+        res = eng.forward(data, _col(a0)[None], np.asarray(P0)[None], *sysm, filter_type=filter_type, mvn_const=mvn_const,
+                          store_ll_obs=False, store_filtered=False, time_varying=tv)
+        pa_b, pP_b = res.predicted_states, res.predicted_covs
+    else:
+        pa_b, pP_b = pa[None], pP[None]
     g = eng.backward(data, _col(a0)[None], np.asarray(P0)[None], *sysm,
-                     predicted_states=pa[None], predicted_covs=np.asarray(predicted_covs)[None],
+                     predicted_states=pa_b, predicted_covs=pP_b,
                      g_logp=np.atleast_1d(np.asarray(g_logp, dtype=np.float64)),
                      g_ll_obs=np.asarray(g_ll_obs, dtype=np.float64)[None],
+                     g_filtered_states=_state_cotangent(g_filtered_states, False),
+                     g_predicted_states=_state_cotangent(g_predicted_states, False),
+                     g_filtered_covs=_cov_cotangent(g_filtered_covs, False),
+                     g_predicted_covs=_cov_cotangent(g_predicted_covs, False),
                      filter_type=filter_type, mvn_const=mvn_const, want_cd=True,
                      h_diagonal=h_diagonal, time_varying=tv)
     out = {k: g[k][0].cpu().numpy() for k in GRAD_INPUT_NAMES}
@@ -254,7 +294,8 @@ def perform_filter_grad(data, a0, P0, T, Z, R, H, Q, c, d, predicted_states, pre
 
 
 def perform_filter_grad_batched(data, a0, P0, T, Z, R, H, Q, c, d, predicted_states, predicted_covs,
-                                g_logp, g_ll_obs, filter_type="standard", mvn_const="reference",
+                                g_logp, g_ll_obs, g_filtered_states=None, g_predicted_states=None, g_filtered_covs=None,
+                                g_predicted_covs=None, filter_type="standard", mvn_const="reference",
                                 h_diagonal=False, engine=None):
     """``perform_filter_grad`` with ONE leading draw axis on a0 .. d, the predicted tapes, g_logp (B,) and g_ll_obs (B,n): the
     gradients of sum_b (g_logp[b] logp[b] + <g_ll_obs[b], ll_obs[b]>) from ONE kf_filter_backward call, row b of each = draw b's.
@@ -273,9 +314,18 @@ def perform_filter_grad_batched(data, a0, P0, T, Z, R, H, Q, c, d, predicted_sta
     pa = np.asarray(predicted_states, dtype=np.float64)
     if pa.ndim == 4:
         pa = pa[..., 0]
+    pP = np.asarray(predicted_covs, dtype=np.float64)
+    if pa.size == 0 or pP.size == 0:   # (the node was built without the predicted tapes: recomputed here)
+        res = eng.forward(data, vec(a0), np.asarray(P0, dtype=np.float64), *sysm, filter_type=filter_type, mvn_const=mvn_const,
+                          store_ll_obs=False, store_filtered=False, time_varying=tv)
+        pa, pP = res.predicted_states, res.predicted_covs
     g = eng.backward(data, vec(a0), np.asarray(P0, dtype=np.float64), *sysm, predicted_states=pa,
-                     predicted_covs=np.asarray(predicted_covs, dtype=np.float64),
+                     predicted_covs=pP,
                      g_logp=np.asarray(g_logp, dtype=np.float64), g_ll_obs=np.asarray(g_ll_obs, dtype=np.float64),
+                     g_filtered_states=_state_cotangent(g_filtered_states, True),
+                     g_predicted_states=_state_cotangent(g_predicted_states, True),
+                     g_filtered_covs=_cov_cotangent(g_filtered_covs, True),
+                     g_predicted_covs=_cov_cotangent(g_predicted_covs, True),
                      filter_type=filter_type, mvn_const=mvn_const, want_cd=True, h_diagonal=h_diagonal, time_varying=tv)
     out = {k: g[k].cpu().numpy() for k in GRAD_INPUT_NAMES}
     for k in ("a0", "c", "d"):
@@ -482,6 +532,7 @@ def _build_ops():
         def make_node(self, *args):
             args = [pt.as_tensor_variable(a) for a in args]
             # inputs: data a0 P0 T Z R H Q c d predicted_states predicted_covs g_logp g_ll_obs
+            #         [g_filtered_states g_predicted_states g_filtered_covs g_predicted_covs]   (round 6; zero-size = none)
             outs = [args[i].type() for i in range(1, 10)]
             return Apply(self, args, outs)
 
@@ -528,15 +579,20 @@ def _build_ops():
             return [[False] * 6] + [[True] * 6 for _ in range(9)]
 
         def L_op(self, inputs, outputs, output_grads):
-            for i in range(4):
-                if not isinstance(output_grads[i].type, DisconnectedType):
-                    return [DisconnectedType()()] + [
-                        grad_not_implemented(
-                            self, k, inputs[k],
-                            "gradients flow through log_likelihood / ll_obs only; the state and "
-                            "covariance tapes are not differentiated by the HIP backward kernel")
-                        for k in range(1, 10)]
             g_logp, g_ll = output_grads[4], output_grads[5]
+            if any(not isinstance(output_grads[i].type, DisconnectedType) for i in range(4)):
+                # round 6: a cotangent on a state / covariance tape -- kf_filter_backward_tapes behind one node that takes all six
+                # cotangents (a zero-size placeholder where nothing is connected; the predicted tapes are recomputed inside when
+                # this node was built without them)
+                if isinstance(g_logp.type, DisconnectedType):
+                    g_logp = pt.zeros(())
+                if isinstance(g_ll.type, DisconnectedType):
+                    g_ll = pt.zeros((inputs[0].shape[0],))
+                tape_g = [pt.zeros((0, 0, 0)) if isinstance(output_grads[i].type, DisconnectedType) else output_grads[i]
+                          for i in range(4)]
+                grads = KalmanFilterGradOp(self.filter_type, self.mvn_const, self.h_diagonal)(
+                    *inputs, outputs[1], outputs[3], g_logp, g_ll, *tape_g)
+                return [DisconnectedType()()] + list(grads)
             if not (self.want[1] and self.want[3]):
                 # the predicted tapes the adjoint kernel reads were not requested from this node: differentiate logp
                 # through the fused value-and-gradient node instead (ll_obs cotangents need the tapes)
@@ -680,11 +736,16 @@ def _build_ops():
             # fused batched value-and-gradient node (one kf_filter_value_and_grad call for all B draws); one on ll_obs (ADVICE
             # round 4: a burn-in mask after vectorize_graph) from the batched adjoint over this node's predicted tapes
             others = [output_grads[i] for i in (0, 1, 2, 3)]
-            if any(not isinstance(g.type, DisconnectedType) for g in others):
-                return [DisconnectedType()()] + [
-                    grad_not_implemented(self, k, inputs[k], "the batched filter is differentiated through log_likelihood / ll_obs only")
-                    for k in range(1, 10)]
             g_logp, g_ll = output_grads[4], output_grads[5]
+            if any(not isinstance(g.type, DisconnectedType) for g in others):   # (round 6: as the per-draw node)
+                if isinstance(g_logp.type, DisconnectedType):
+                    g_logp = pt.zeros((inputs[2].shape[0],))
+                if isinstance(g_ll.type, DisconnectedType):
+                    g_ll = pt.zeros((inputs[2].shape[0], inputs[0].shape[-3]))
+                tape_g = [pt.zeros((0, 0, 0, 0)) if isinstance(g.type, DisconnectedType) else g for g in others]
+                grads = KalmanFilterBatchedGradOp(self.filter_type, self.mvn_const, self.h_diagonal)(
+                    *inputs, outputs[1], outputs[3], g_logp, g_ll, *tape_g)
+                return [DisconnectedType()()] + list(grads)
             if isinstance(g_ll.type, DisconnectedType):
                 fused = KalmanLogpBatchedOp(self.filter_type, self.mvn_const, self.h_diagonal)(*inputs)
                 return [DisconnectedType()()] + [_bcast_rows(g_logp, fused[1 + k]) for k in range(9)]

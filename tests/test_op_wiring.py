@@ -87,8 +87,19 @@ def test_grad_and_vectorize_create_the_intended_nodes():
     outs = StandardFilter().build_graph(*sym)
     f = pytensor.function(sym, pytensor.grad(outs[4], sym[3]), on_unused_input="ignore")
     assert "KalmanFilterGradOp" in _op_names(f) and "KalmanFilterOp" in _op_names(f)
-    with pytest.raises(Exception, match="(?i)not implemented|undefined|null"):   # the tapes are not differentiated
-        pytensor.grad(outs[0].sum(), sym[3])
+    # round 6: a loss on a tape output is differentiated too (kf_filter_backward_tapes behind the same gradient node, which then
+    # takes the four tape cotangents as well -- a zero-size placeholder for the unconnected ones)
+    f = pytensor.function(sym, pytensor.grad(outs[0].sum() + outs[3].sum(), sym[3]), on_unused_input="ignore")
+    gnodes = [nd for nd in f.maker.fgraph.toposort() if type(nd.op).__name__ == "KalmanFilterGradOp"]
+    assert len(gnodes) == 1 and len(gnodes[0].inputs) == 18
+    lean = StandardFilter().build_graph(*sym, outputs=("filtered_states",))   # (no predicted tapes on the node: recomputed inside)
+    f = pytensor.function(sym, pytensor.grad(lean[0].sum(), sym[3]), on_unused_input="ignore")
+    assert "KalmanFilterGradOp" in _op_names(f)
+    sm_op_outs = StandardFilter().build_graph(*sym)
+    from pymc_statespace_amd.filters import KalmanSmoother
+    sm = KalmanSmoother().build_graph(sym[3], sym[5], sym[7], sm_op_outs[0], sm_op_outs[2])
+    with pytest.raises(Exception, match="(?i)not implemented|undefined|null|not differentiated"):   # the smoother still is not
+        pytensor.grad(sm[0].sum(), sym[3])
     few = StandardFilter().build_graph(*sym, outputs=("log_likelihood", "filtered_states"))
     f = pytensor.function(sym, pytensor.grad(few[4], sym[3]), on_unused_input="ignore")
     assert "KalmanLogpOp" in _op_names(f) and "KalmanFilterGradOp" not in _op_names(f)
@@ -283,8 +294,10 @@ def test_the_batch_axis_reaches_one_value_and_gradient_node(monkeypatch):
                                       np.repeat(g["Z"], B, 0), np.repeat(g["R"], B, 0), Hs, Qs)
     assert got.shape == (B, 2, 2) and calls == [B]
     assert_allclose(got, ref_g1["T"], rtol=1e-9, atol=1e-9)
-    with pytest.raises(Exception, match="(?i)not implemented|undefined|null"):   # tapes stay undifferentiated
-        pytensor.grad(outs[0].sum(), sym3[3])
+    # (round 6) a loss on a tape of the batched node: the batched gradient node with the four tape cotangents
+    f2 = pytensor.function(sym3, pytensor.grad(outs[0].sum(), sym3[3]), on_unused_input="ignore")
+    gn = [nd for nd in f2.maker.fgraph.toposort() if type(nd.op).__name__ == "KalmanFilterBatchedGradOp"]
+    assert len(gn) == 1 and len(gn[0].inputs) == 18
     # (c) built directly: logp (B,) from the batched node
     blp = StandardFilter().build_graph(*sym3, outputs="logp", batched=True)
     f = pytensor.function(sym3, blp)
