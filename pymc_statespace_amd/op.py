@@ -267,7 +267,7 @@ def perform_filter_grad(data, a0, P0, T, Z, R, H, Q, c, d, predicted_states, pre
     # (host arrays here: PyTensor hands the forward node's outputs back through the graph; the fused
     # KalmanLogpOp exists so that the sampler's value-and-gradient path never does this)
     pa = np.asarray(predicted_states, dtype=np.float64)
-    if pa.ndim == 3:
+    if pa.ndim == 3 and pa.size:
         pa = pa[..., 0]
     sysm, tv = _lead_system(T, Z, R, H, Q, c, d)
     pP = np.asarray(predicted_covs, dtype=np.float64)
@@ -312,7 +312,7 @@ def perform_filter_grad_batched(data, a0, P0, T, Z, R, H, Q, c, d, predicted_sta
 
     sysm, tv = _lead_system_batched(T, Z, R, H, Q, c, d)
     pa = np.asarray(predicted_states, dtype=np.float64)
-    if pa.ndim == 4:
+    if pa.ndim == 4 and pa.size:
         pa = pa[..., 0]
     pP = np.asarray(predicted_covs, dtype=np.float64)
     if pa.size == 0 or pP.size == 0:   # (the node was built without the predicted tapes: recomputed here)
