@@ -337,9 +337,10 @@ KF_API int kf_filter_backward(kf_handle* h, const kf_dims* dims,
  * g_pred_a [B][T+1][m], g_filt_P [B][T][m][m], g_pred_P [B][T+1][m][m]; any of the six cotangents may be NULL (= 0), not all.
  * Covariance cotangents need not be symmetric (the filter's covariances are: only the symmetric part acts); predicted slot 0 is
  * (a0, P0) as given, so its cotangent goes to g_a0 / g_P0 unchanged.  Everything else as kf_filter_backward.
- * Kernel: the LDS-resident adjoint (one draw per lane group, csrc/kf_backward_lds.hip) -- every filter type, missing
- * observations, time-varying matrices; KF_ERR_UNSUPPORTED when m, p do not fit 160 KiB of LDS (m > ~45).  With all four tape
- * cotangents NULL the call IS kf_filter_backward (same dispatch). */
+ * Kernels: static matrices, m <= 16, scalar observations (p == 1, the Univariate filter, or KF_FLAG_H_DIAGONAL; then g_H / g_P0 as
+ * kf_filter_backward documents for those): the accumulator-layout adjoint (csrc/kf_backward_mfma.hip, one wavefront per draw); else
+ * the LDS-resident adjoint (csrc/kf_backward_lds.hip) -- every filter type, dense H, time-varying matrices; KF_ERR_UNSUPPORTED when
+ * m, p do not fit 160 KiB of LDS (m > ~45).  With all four tape cotangents NULL the call IS kf_filter_backward (same dispatch). */
 KF_API int kf_filter_backward_tapes(kf_handle* h, const kf_dims* dims,
                              const double* y, const double* a0, const double* P0,
                              const double* T, const double* Z, const double* R,

@@ -501,6 +501,12 @@ int kf_launch_backward(kf_handle* h, const KfBwdArgs& a, void* workspace, size_t
                        hipStream_t stream) {
   // cotangents of the tape outputs (kf_filter_backward_tapes): the LDS-resident adjoint is the one that carries them
   if (a.g_filt_a || a.g_pred_a || a.g_filt_P || a.g_pred_P) {
+    // static matrices, m <= 16, scalar observations: the accumulator-layout adjoint's TP instantiation (kf_backward_mfma.hip;
+    // KF_FORWARD_KERNEL=lds keeps the LDS adjoint, for A/B tests)
+    if (!(a.flags & KF_FLAG_TV_ANY) && !a.steps && !a.accumulate && a.m <= KF_MP_M_MAX && a.p <= KF_MP_P_MAX &&
+        (a.p == 1 || a.filter == KF_FILTER_UNIVARIATE || (a.flags & KF_FLAG_H_DIAGONAL)) &&
+        (h->forward_kernel == KF_KERNEL_AUTO || h->forward_kernel == KF_KERNEL_MFMA || h->forward_kernel == KF_KERNEL_B4))
+      return kf_launch_backward_mfma(h, a, stream);
     if (!kf_backward_lds_fits(a.m, a.p)) {
       KF_SET_ERR(h, "kf_filter_backward_tapes: cotangents of the tape outputs need the LDS-resident adjoint (m=%d p=%d does "
                  "not fit %d B of LDS)", a.m, a.p, KF_LDS_BYTES_MAX);

@@ -44,8 +44,13 @@ __host__ __device__ inline int bwd_mfma_lds_doubles(int p) {
 // array -- T_t for the predict adjoint, Z_t / H_t / d_t for the update -- and its gradient is that step's term alone, written to slice
 // t of the gradient tape instead of accumulated (the indexing of kf_backward_lds.hip, which this replaces for m <= 16 and scalar
 // observations: 15 -> 4 ms at the headline shape).
-template <int KS, bool P1, bool TV = false>
-__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((KS <= 3 && !(TV && KS >= 2)) ? 4 : 3))) void kf_bwd_mfma_kernel(
+// TP (round 6): cotangents of the filter's TAPE outputs (kf_filter_backward_tapes; KfBwdArgs::g_filt_a / g_pred_a / g_filt_P / g_pred_P,
+// any of them NULL = 0) -- the predicted slots' join (abp, PB) at the end of each step (slot T before the sweep), the filtered ones'
+// join T' ab' and Sb; covariance cotangents enter by their symmetric part (the adjoint tile is kept symmetric, see above), except
+// predicted slot 0 = P0 as given, whose cotangent goes to g_P0 unchanged.  Loaded at the top of the step, used behind the forward
+// recompute.  A separate instantiation: the log-likelihood-only adjoint is the kernel it was.
+template <int KS, bool P1, bool TV = false, bool TP = false>
+__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((KS <= 3 && !(TV && KS >= 2) && !TP) ? 4 : 3))) void kf_bwd_mfma_kernel(
     const KfBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
@@ -134,6 +139,21 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((KS <= 
   }
   double4_t TBm = {0.0, 0.0, 0.0, 0.0};
   double abp = (A.init_ab && c_ok) ? A.init_ab[b * (long)m + c] : 0.0, cb = 0.0, hbv = 0.0, dbv = 0.0;
+  const double* c_fa = (TP && A.g_filt_a) ? A.g_filt_a + b * (long)nt * m : nullptr;
+  const double* c_pa = (TP && A.g_pred_a) ? A.g_pred_a + b * (long)(nt + 1) * m : nullptr;
+  const double* c_fP = (TP && A.g_filt_P) ? A.g_filt_P + b * (long)nt * mm : nullptr;
+  const double* c_pP = (TP && A.g_pred_P) ? A.g_pred_P + b * (long)(nt + 1) * mm : nullptr;
+  auto sym_at = [&](const double* tape, long slot, int s) -> double {   // symmetric part of a covariance cotangent at [4 s + g][c]
+    const double* q = tape + slot * mm;
+    return on[s] ? 0.5 * (q[off[s]] + q[c * m + 4 * s + g]) : 0.0;
+  };
+  if (TP) {   // the cotangent of predicted slot T
+    if (c_pa && c_ok) abp += c_pa[(long)n * m + c];
+    if (c_pP) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) PB[s] += sym_at(c_pP, n, s);
+    }
+  }
   const bool acc_out = A.accumulate != 0;
   const bool want_yy = A.g_yy != nullptr;
   GY[lane] = 0.0;
@@ -211,6 +231,16 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((KS <= 
       }
     }
     if (t > 0) prefetch(t - 1);
+    double k_fa = 0.0, k_pa = 0.0, k_fP[KS], k_pP[KS];   // (TP) this step's tape cotangents
+    if (TP) {
+      k_fa = (c_fa && c_ok) ? c_fa[(long)t * m + c] : 0.0;
+      k_pa = (c_pa && c_ok) ? c_pa[(long)t * m + c] : 0.0;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        k_fP[s] = c_fP ? sym_at(c_fP, t, s) : 0.0;
+        k_pP[s] = (c_pP && t > 0) ? sym_at(c_pP, t, s) : 0.0;   // (slot 0: straight into g_P0, below)
+      }
+    }
     if ((t & 63) == 63 && t != n - 1) stage_block(t);
     const double* yrow = YB + (t & 63) * p;
     const double gt = g_all + GL[t & 63];
@@ -288,6 +318,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((KS <= 
       if (s > 0) part = fma(TB[s], abr[s], part);
     }
     double abf = col_allsum(part);  // T' ab'
+    if (TP) abf += k_fa;
     // X1 = Gm T ; Sb = T' X1 ; Tb += 2 X1 P_f  (A operand = X1' registers, from an LDS transpose:
     // cheaper than the fourth product W = T P_f, Gm W)
     double4_t X1 = {0.0, 0.0, 0.0, 0.0}, SBv = {0.0, 0.0, 0.0, 0.0};
@@ -317,7 +348,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((KS <= 
     }
     double SB[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) SB[s] = SBv[s];
+    for (int s = 0; s < KS; ++s) SB[s] = TP ? SBv[s] + k_fP[s] : SBv[s];
 
     // ---- adjoint of the scalar updates, last observation first ---------------------------------------
 #pragma unroll 1
@@ -380,6 +411,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((KS <= 
           double gp = SB[s];
           gp = fma(fma(Fb, zr[s], m1r[s]), zc, gp);
           gp = fma(-zr[s] * invF, sc, gp);
+          if (TP && c_pP && on[s]) gp += c_pP[off[s]];
           if (on[s]) A.g_P0[b * (long)mm + off[s]] = gp;
         }
       }
@@ -403,8 +435,8 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((KS <= 
       }
     }
 #pragma unroll
-    for (int s = 0; s < KS; ++s) PB[s] = SB[s];
-    abp = abf;
+    for (int s = 0; s < KS; ++s) PB[s] = TP ? SB[s] + k_pP[s] : SB[s];
+    abp = TP ? abf + k_pa : abf;
     if (tv_H || tv_D) {   // slice t of g_H (diagonal; the rest zeros) / g_d: lane (g = 0, c = q) holds this step's term
       if (g == 0 && c < p) {
         if (tv_D && A.g_d) A.g_d[(bT + t) * (long)p + c] = dbv;
@@ -444,7 +476,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((KS <= 
   for (int s = 0; s < KS; ++s) {
     if (!on[s]) continue;
     if (A.g_T && !tv_T) put(A.g_T + b * (long)mm + off[s], fma(2.0, TBm[s], ACC[(4 + s) * KF_WAVE + lane]));
-    if (A.g_P0 && p > 1) A.g_P0[b * (long)mm + off[s]] = PB[s];
+    if (A.g_P0 && p > 1) A.g_P0[b * (long)mm + off[s]] = (TP && c_pP) ? PB[s] + c_pP[off[s]] : PB[s];
   }
   // R_b = Gs R (Q + Q') ;  Q_b = R' Gs R   (Gs in tile FT)
   const double* gR = A.R + b * (long)m * r_;
@@ -487,8 +519,17 @@ int kf_launch_backward_mfma(kf_handle* h, const KfBwdArgs& a, hipStream_t stream
     KF_SET_ERR(h, "backward(mfma): time-varying R / Q (and the steady-state hand-over) stay on the LDS adjoint");
     return KF_ERR_UNSUPPORTED;
   }
+  const bool tp = a.g_filt_a || a.g_pred_a || a.g_filt_P || a.g_pred_P;
+  if (tp && (tv || a.steps || a.accumulate || a.init_ab || a.init_Pb || a.g_yy)) {
+    KF_SET_ERR(h, "backward(mfma): tape cotangents with time-varying matrices or a hand-over stay on the LDS adjoint");
+    return KF_ERR_UNSUPPORTED;
+  }
 #define KF_BWD_MFMA_LAUNCH(KS_)                                                                        \
-  if (tv && a.p == 1)                                                                                  \
+  if (tp && a.p == 1)                                                                                  \
+    hipLaunchKernelGGL((kf_bwd_mfma_kernel<KS_, true, false, true>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);  \
+  else if (tp)                                                                                         \
+    hipLaunchKernelGGL((kf_bwd_mfma_kernel<KS_, false, false, true>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); \
+  else if (tv && a.p == 1)                                                                                  \
     hipLaunchKernelGGL((kf_bwd_mfma_kernel<KS_, true, true>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);  \
   else if (tv)                                                                                         \
     hipLaunchKernelGGL((kf_bwd_mfma_kernel<KS_, false, true>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); \

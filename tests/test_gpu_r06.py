@@ -573,3 +573,28 @@ def test_backward_tapes_beyond_lds_is_refused(eng):
     with pytest.raises(Exception, match="LDS"):
         eng.backward(*args, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
                      g_filtered_states=np.ones((2, 6, 60)), mvn_const="exact")
+
+
+@pytest.mark.parametrize("case", ["structural_m10", "dense_p3m6_univariate", "arma11_cholesky"])
+def test_backward_tapes_tile_adjoint_against_the_lds_adjoint(eng, case):
+    """The two kernels that carry tape cotangents (kf_backward_mfma.hip's TP instantiation: static, m <= 16, scalar observations; the
+    LDS-resident adjoint: everything else, forced here with the handle's kernel selector) on the same call."""
+    make, ft = TAPE_CASES[case]
+    w = make()
+    rng = np.random.default_rng(9)
+    gt = _tape_cotangents(rng, w["B"], w["n"], w["m"], ("fa", "pa", "fP", "pP"))
+    g_logp = rng.standard_normal(w["B"])
+    a = _backward_tapes(eng, w, ft, gt, g_logp=g_logp)
+    eng.set_forward_kernel("lds")
+    try:
+        b = _backward_tapes(eng, w, ft, gt, g_logp=g_logp)
+    finally:
+        eng.set_forward_kernel("auto")
+    for k in a:
+        x, y = a[k].cpu().numpy(), b[k].cpu().numpy()
+        if k == "P0" and w["p"] > 1:   # (p > 1 on the tile adjoint: the symmetric part, include/kf.h)
+            y = 0.5 * (y + np.swapaxes(y, -1, -2))
+            x = 0.5 * (x + np.swapaxes(x, -1, -2))
+        if k == "H" and w["p"] > 1:
+            y = y * np.eye(w["p"])
+        assert np.max(np.abs(x - y)) <= 1e-9 * (1.0 + np.max(np.abs(y))), k
