@@ -60,7 +60,7 @@ extern "C" {
 #define KF_API
 #endif
 
-#define KF_ABI_VERSION 7 /* 7: kf_filter_backward_tapes.  6: kf_smoother_from_filter. \
+#define KF_ABI_VERSION 7 /* 7: kf_filter_backward_tapes, kf_set_option / kf_get_option.  6: kf_smoother_from_filter. \
                           * 5: KF_FLAG_STEADY_STATE; the block kernel's steady-state phase off by default below 1536 steps; kf_workspace_bytes_for(KF_WS_FORWARD) covers the split pipeline. \
                           * 2: KF_FLAG_H_DIAGONAL, KF_KERNEL_MFMA, kf_dare, kf_simulate_statespace, workspace use by smoother/backward; \
                             3: kf_workspace_bytes_for, kf_forward_kernel_name_ws; every entry point runs on the handle's device; \
@@ -174,6 +174,15 @@ KF_API int kf_abi_version(void);
 KF_API int kf_create(kf_handle** out, int device);
 KF_API void kf_destroy(kf_handle* h);
 KF_API const char* kf_last_error(const kf_handle* h);
+
+/* Path switches per HANDLE (round 6).  Every documented KF_* selector between complete, parity-tested paths (INTEGRATION.md,
+ * "Environment switches": KF_STEADY_STATE, KF_FORWARD_CHUNKED, KF_SMOOTHER_BF_WG, ...) can be set on a handle; the value then wins
+ * over the process environment for every call made through THAT handle (value "" = behave as if the variable were unset, whatever
+ * the environment says; value NULL = remove the override, the environment counts again).  Names the library does not read are
+ * refused (KF_ERR_ARG), values longer than 23 characters too.  kf_get_option: the value a call through this handle would see
+ * (handle first, then the environment; NULL = unset).  A handle is used by one thread at a time, as before. */
+KF_API int kf_set_option(kf_handle* h, const char* name, const char* value);
+KF_API const char* kf_get_option(const kf_handle* h, const char* name);
 
 /* Tuning knob: lanes of a wavefront that cooperate on one draw (0 = choose from dims).
  * LDS kernels take 4, 8, 16, 32 or 64; the row-split forward kernels take m*H (H lanes per

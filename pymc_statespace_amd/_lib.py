@@ -30,7 +30,7 @@ KF_OK, KF_ERR_ARG, KF_ERR_HIP, KF_ERR_WORKSPACE, KF_ERR_UNSUPPORTED = 0, -1, -2,
 
 # every symbol include/kf.h declares (tests check the built library exports them all)
 EXPORTS = (
-    "kf_abi_version", "kf_create", "kf_destroy", "kf_last_error", "kf_set_lanes_per_draw",
+    "kf_abi_version", "kf_create", "kf_destroy", "kf_last_error", "kf_set_option", "kf_get_option", "kf_set_lanes_per_draw",
     "kf_set_forward_kernel", "kf_forward_kernel_name", "kf_forward_kernel_name_ws", "kf_last_forward_kernel",
     "kf_workspace_bytes", "kf_workspace_bytes_for", "kf_filter_forward", "kf_filter_backward", "kf_filter_backward_tapes", "kf_filter_value_and_grad", "kf_smoother", "kf_smoother_from_filter",
     "kf_assemble", "kf_lyapunov", "kf_conditional_simulation", "kf_dare", "kf_dare_backward", "kf_simulate_statespace",
@@ -87,6 +87,10 @@ def load():
     lib.kf_forward_kernel_name_ws.restype = C.c_char_p
     lib.kf_last_forward_kernel.argtypes = [C.c_void_p]
     lib.kf_last_forward_kernel.restype = C.c_char_p
+    lib.kf_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    lib.kf_set_option.restype = C.c_int
+    lib.kf_get_option.argtypes = [C.c_void_p, C.c_char_p]
+    lib.kf_get_option.restype = C.c_char_p
     lib.kf_workspace_bytes_for.argtypes = [C.c_void_p, C.POINTER(KfDims), C.c_int, C.POINTER(C.c_size_t)]
     lib.kf_workspace_bytes_for.restype = C.c_int
     lib.kf_filter_forward.argtypes = [vp, C.POINTER(KfDims)] + [dp] * 10 + [dp] * 6 + [ip, vp,

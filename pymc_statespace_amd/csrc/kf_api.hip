@@ -80,6 +80,96 @@ int kf_handle_aux(kf_handle* h) {
 
 extern "C" const char* kf_last_error(const kf_handle* h) { return h ? h->err : g_err; }
 
+thread_local const kf_handle* kf_tls_handle = nullptr;
+
+// every switch the library reads (kf_env_switch call sites; tests/test_abi.py checks this table against the sources)
+static const char* const kf_option_names[] = {
+    "KF_B4C_STARTS_LDS",
+    "KF_B4Q_GROUP",
+    "KF_B4Q_SPLIT",
+    "KF_B4_SPLIT",
+    "KF_BACKWARD_B4",
+    "KF_BACKWARD_TV_MFMA",
+    "KF_BIG_FUSE",
+    "KF_BIG_SPARSE",
+    "KF_BIG_TMASK",
+    "KF_FORWARD_B4P",
+    "KF_FORWARD_B4Q",
+    "KF_FORWARD_B4TV",
+    "KF_FORWARD_CHUNKED",
+    "KF_FORWARD_KERNEL",
+    "KF_FORWARD_WGL",
+    "KF_FORWARD_WHITEN",
+    "KF_LANES_PER_DRAW",
+    "KF_SMOOTHER_B4",
+    "KF_SMOOTHER_BF_LANE",
+    "KF_SMOOTHER_BF_WG",
+    "KF_SMOOTHER_BIG_GEMM",
+    "KF_SMOOTHER_LANE",
+    "KF_SMOOTHER_SPLIT",
+    "KF_SMOOTHER_STEADY",
+    "KF_SMOOTHER_TV_MFMA",
+    "KF_STEADY_STATE",
+    "KF_VG_SCHED_HINT",
+    "KF_VG_STEADY",
+    "KF_VG_STEADY_SCAN",
+    "KF_VG_TILE_TAPE"};
+
+const char* kf_handle_option(const kf_handle* h, const char* name) {
+  for (int i = 0; i < h->n_options; ++i)
+    if (!strcmp(h->options[i].name, name)) return h->options[i].value;
+  return nullptr;
+}
+
+extern "C" int kf_set_option(kf_handle* h, const char* name, const char* value) {
+  if (!h) return KF_ERR_ARG;
+  if (!name) {
+    KF_SET_ERR(h, "kf_set_option: name is NULL");
+    return KF_ERR_ARG;
+  }
+  bool known = false;
+  for (const char* nm : kf_option_names) known = known || !strcmp(nm, name);
+  if (!known) {
+    KF_SET_ERR(h, "kf_set_option: '%s' is not a switch of this library (INTEGRATION.md lists them)", name);
+    return KF_ERR_ARG;
+  }
+  if (value && strlen(value) >= sizeof(h->options[0].value)) {
+    KF_SET_ERR(h, "kf_set_option: value of %s is longer than %d characters", name, (int)sizeof(h->options[0].value) - 1);
+    return KF_ERR_ARG;
+  }
+  int at = -1;
+  for (int i = 0; i < h->n_options; ++i)
+    if (!strcmp(h->options[i].name, name)) at = i;
+  if (!value) {   // back to the environment
+    if (at >= 0) h->options[at] = h->options[--h->n_options];
+    return KF_OK;
+  }
+  if (at < 0) {
+    if (h->n_options == KF_MAX_OPTIONS) {
+      KF_SET_ERR(h, "kf_set_option: more than %d options on one handle", KF_MAX_OPTIONS);
+      return KF_ERR_ARG;
+    }
+    at = h->n_options++;
+    snprintf(h->options[at].name, sizeof(h->options[at].name), "%s", name);
+  }
+  snprintf(h->options[at].value, sizeof(h->options[at].value), "%s", value);
+  if (!strcmp(name, "KF_FORWARD_KERNEL")) {   // (read once, at kf_create: the handle's selector is what it sets)
+    static const struct { const char* s; int k; } ks[] = {{"auto", KF_KERNEL_AUTO}, {"lds", KF_KERNEL_LDS}, {"row", KF_KERNEL_ROW},
+                                                          {"lane", KF_KERNEL_LANE}, {"mfma", KF_KERNEL_MFMA}, {"b4", KF_KERNEL_B4}};
+    for (const auto& e : ks)
+      if (!strcmp(value, e.s)) h->forward_kernel = e.k;
+  }
+  return KF_OK;
+}
+
+extern "C" const char* kf_get_option(const kf_handle* h, const char* name) {
+  if (!h || !name) return nullptr;
+  const char* o = kf_handle_option(h, name);
+  if (o) return *o ? o : nullptr;
+  const char* e = getenv(name);
+  return (e && *e) ? e : nullptr;
+}
+
 extern "C" int kf_set_lanes_per_draw(kf_handle* h, int lanes) {
   if (!h) return KF_ERR_ARG;
   if (lanes < 0 || lanes > 64) {
@@ -294,6 +384,7 @@ extern "C" const char* kf_forward_kernel_name(const kf_handle* h, const kf_dims*
 }
 
 extern "C" const char* kf_forward_kernel_name_ws(const kf_handle* h, const kf_dims* d, size_t workspace_bytes) {
+  KfTlsHandle kf_tls_guard_(h);
   if (!h || !d) return "";
   if (kf_whiten_shape_ok(h, d->m, d->p, d->r, d->T, d->filter, d->flags, d->B) && workspace_bytes >= kf_whiten_total_bytes(h, d)) {
     kf_dims d2 = *d;  // dense H, whitened: the diagonal-H kernel of the shape (behind kf_whiten_kernel)
@@ -721,6 +812,7 @@ static bool kf_vg_tile_steady_path(const kf_handle* h, const kf_dims* d) {
 }
 
 extern "C" int kf_workspace_bytes_for(const kf_handle* h, const kf_dims* dims, int which, size_t* bytes) {
+  KfTlsHandle kf_tls_guard_(h);
   if (!h || !dims || !bytes) return KF_ERR_ARG;
   if (which == KF_WS_SMOOTHER_FROM_FILTER) {
     *bytes = kf_smoother_bf_big_ok(dims->m, dims->p, dims->flags & ~(unsigned)(KF_FLAG_EXACT_RECURSION | KF_FLAG_STEADY_STATE))

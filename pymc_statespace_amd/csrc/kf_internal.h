@@ -30,7 +30,17 @@ struct KfAttrOnce {
 //                      tests/test_gpu_switches.py
 //   kf_env_experiment  tuning knobs of the measurement scripts (chunk sizes, workgroup counts, the convergence tolerance): compiled in
 //                      only with -DKF_EXPERIMENTS (make XFLAGS=-DKF_EXPERIMENTS); a product build ignores them
+// Round 6: a switch set on the HANDLE (kf_set_option) wins over the environment -- a server that holds several handles (models,
+// tenants) configures each of them and never touches the process environment; the entry point's KfDeviceGuard publishes its handle
+// to the thread for the duration of the call, so the ~30 call sites below the API need no handle argument.
+struct kf_handle;
+extern thread_local const kf_handle* kf_tls_handle;
+const char* kf_handle_option(const kf_handle* h, const char* name);   // NULL: not set on the handle
 inline const char* kf_env_switch(const char* name) {
+  if (kf_tls_handle) {
+    const char* o = kf_handle_option(kf_tls_handle, name);
+    if (o) return *o ? o : nullptr;
+  }
   const char* e = getenv(name);
   return (e && *e) ? e : nullptr;
 }
@@ -44,8 +54,15 @@ inline const char* kf_env_experiment(const char* name) {
 }
 
 #define KF_AUX_EVENTS 38  // 0 .. 33: the split pipelines' own; 34 .. 36: KfAuxJoinGuard
+#define KF_MAX_OPTIONS 40
+struct KfOption {
+  char name[32];
+  char value[24];
+};
 struct kf_handle {
   int device;
+  int n_options;                       // kf_set_option: switches set on this handle (kf_env_switch reads them before the environment)
+  KfOption options[KF_MAX_OPTIONS];
   int lanes_per_draw;  // 0 = auto
   int forward_kernel;  // KF_KERNEL_AUTO / _LDS / _ROW / _LANE
   int n_cu;
@@ -520,7 +537,10 @@ struct KfDeviceGuard {
   int prev = -1;
   bool switched = false;
   hipError_t err = hipSuccess;
+  const kf_handle* prev_tls = nullptr;
   explicit KfDeviceGuard(const kf_handle* h) {
+    prev_tls = kf_tls_handle;
+    kf_tls_handle = h;
     if (!h) return;
     err = hipGetDevice(&prev);
     if (err == hipSuccess && prev != h->device) {
@@ -529,10 +549,20 @@ struct KfDeviceGuard {
     }
   }
   ~KfDeviceGuard() {
+    kf_tls_handle = prev_tls;
     if (switched) (void)hipSetDevice(prev);
   }
   KfDeviceGuard(const KfDeviceGuard&) = delete;
   KfDeviceGuard& operator=(const KfDeviceGuard&) = delete;
+};
+// (entry points that only ANSWER questions about dispatch -- kf_forward_kernel_name, kf_workspace_bytes_for -- read the same switches
+// without touching the device: they publish their handle's options the same way)
+struct KfTlsHandle {
+  const kf_handle* prev;
+  explicit KfTlsHandle(const kf_handle* h) : prev(kf_tls_handle) { kf_tls_handle = h; }
+  ~KfTlsHandle() { kf_tls_handle = prev; }
+  KfTlsHandle(const KfTlsHandle&) = delete;
+  KfTlsHandle& operator=(const KfTlsHandle&) = delete;
 };
 #define KF_ON_DEVICE(h)                                                                        \
   KfDeviceGuard kf_dev_guard_(h);                                                              \

@@ -103,6 +103,17 @@ class KalmanEngine:
     def set_lanes_per_draw(self, lanes: int):
         self._check(self.lib.kf_set_lanes_per_draw(self._h, int(lanes)), "kf_set_lanes_per_draw")
 
+    def set_option(self, name: str, value):
+        """kf_set_option: a KF_* path switch on THIS engine's handle -- it wins over the process environment for
+        every call made through this engine.  ``value`` None removes the override, '' means 'as if unset'."""
+        v = None if value is None else str(value).encode()
+        self._check(self.lib.kf_set_option(self._h, name.encode(), v), "kf_set_option")
+
+    def get_option(self, name: str):
+        """The value a call through this engine would see for the switch (handle first, then the environment); None = unset."""
+        v = self.lib.kf_get_option(self._h, name.encode())
+        return None if v is None else v.decode()
+
     def set_forward_kernel(self, kernel: str):
         """'auto' | 'lds' (generic LDS-resident) | 'row' (register-resident: p == 1, m <= 10; or
         m <= 16, p <= 8 with the Univariate filter / diagonal H) | 'lane' (one lane per draw,

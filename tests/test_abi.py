@@ -152,3 +152,24 @@ def test_the_dynamic_symbol_table_is_the_header():
     names = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
     ours = {nm for nm in names if not nm.startswith("__hip_cuid_") and not nm.startswith("_ZNSt") and not nm.startswith("_ZSt")}
     assert ours == set(_lib.EXPORTS), sorted(ours ^ set(_lib.EXPORTS))
+
+
+def test_option_table_is_the_set_of_switches_the_sources_read():
+    """kf_set_option refuses names the library does not read; its table (csrc/kf_api.hip) must therefore be exactly the
+    kf_env_switch("...") call sites of the sources -- and every one of them has a row in INTEGRATION.md's switch table."""
+    import glob
+    import re
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    src = ""
+    for f in glob.glob(os.path.join(root, "pymc_statespace_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "pymc_statespace_amd", "csrc", "*.h")):
+        src += open(f).read()
+    read = set(re.findall(r'kf_env_switch\("([A-Z0-9_]+)"\)', src))
+    api = open(os.path.join(root, "pymc_statespace_amd", "csrc", "kf_api.hip")).read()
+    tbl = re.search(r"kf_option_names\[\] = \{(.*?)\};", api, re.S).group(1)
+    table = set(re.findall(r'"([A-Z0-9_]+)"', tbl))
+    assert table == read, (sorted(table - read), sorted(read - table))
+    assert all(len(n) < 32 for n in table)
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(n for n in table if n not in doc)
+    assert not missing, f"switches without a row in INTEGRATION.md: {missing}"

@@ -598,3 +598,50 @@ def test_backward_tapes_tile_adjoint_against_the_lds_adjoint(eng, case):
         if k == "H" and w["p"] > 1:
             y = y * np.eye(w["p"])
         assert np.max(np.abs(x - y)) <= 1e-9 * (1.0 + np.max(np.abs(y))), k
+
+
+# ---- path switches per handle (kf_set_option; VERDICT round 5 #8: per-handle options instead of getenv) ---------------------------------
+def test_set_option_wins_over_the_environment_and_is_per_handle(eng, monkeypatch):
+    from pymc_statespace_amd import KalmanEngine
+
+    other = KalmanEngine()
+    tv = ("T",)
+    assert eng.forward_kernel_name(64, 50, 1, 6, 2, time_varying=tv) == "kf_fwd_b4tv_kernel"
+    eng.set_option("KF_FORWARD_B4TV", "0")
+    try:
+        assert eng.get_option("KF_FORWARD_B4TV") == "0"
+        assert eng.forward_kernel_name(64, 50, 1, 6, 2, time_varying=tv) == "kf_fwd_lds_kernel"
+        assert other.forward_kernel_name(64, 50, 1, 6, 2, time_varying=tv) == "kf_fwd_b4tv_kernel"   # another handle: untouched
+        monkeypatch.setenv("KF_FORWARD_B4TV", "1")
+        assert eng.forward_kernel_name(64, 50, 1, 6, 2, time_varying=tv) == "kf_fwd_lds_kernel"       # the handle wins
+        eng.set_option("KF_FORWARD_B4TV", None)
+        assert eng.get_option("KF_FORWARD_B4TV") == "1"                                               # back to the environment
+        monkeypatch.setenv("KF_FORWARD_B4TV", "0")
+        assert eng.forward_kernel_name(64, 50, 1, 6, 2, time_varying=tv) == "kf_fwd_lds_kernel"
+        eng.set_option("KF_FORWARD_B4TV", "")                                                         # "" = as if unset
+        assert eng.get_option("KF_FORWARD_B4TV") is None
+        assert eng.forward_kernel_name(64, 50, 1, 6, 2, time_varying=tv) == "kf_fwd_b4tv_kernel"
+    finally:
+        eng.set_option("KF_FORWARD_B4TV", None)
+    with pytest.raises(Exception, match="not a switch"):
+        eng.set_option("KF_NO_SUCH_SWITCH", "1")
+    with pytest.raises(Exception, match="longer"):
+        eng.set_option("KF_STEADY_STATE", "x" * 40)
+
+
+def test_set_option_selects_the_path_of_a_call(eng):
+    """The chunked pipeline switched off on the handle: the call is the sequential kernel's, bit for bit what
+    KF_FLAG_EXACT_RECURSION gives -- and on again: the pipeline's numbers (within 1e-11)."""
+    import torch
+
+    w = W.structural(B=128, n=600)
+    a = eng.forward(*_args(w), mvn_const="exact", exact_recursion=True)
+    eng.set_option("KF_FORWARD_CHUNKED", "0")
+    try:
+        b = eng.forward(*_args(w), mvn_const="exact")
+    finally:
+        eng.set_option("KF_FORWARD_CHUNKED", None)
+    c = eng.forward(*_args(w), mvn_const="exact")
+    assert torch.equal(a.filtered_covs, b.filtered_covs) and torch.equal(a.logp, b.logp)
+    assert not torch.equal(a.filtered_covs, c.filtered_covs)
+    assert float((a.logp - c.logp).abs().max()) < 1e-8
