@@ -62,6 +62,9 @@ int main(int argc, char** argv) {
   auto smoother = sym<decltype(&kf_smoother)>(lib, "kf_smoother");
   auto smoother_ff = sym<decltype(&kf_smoother_from_filter)>(lib, "kf_smoother_from_filter");
   auto ws_bytes = sym<decltype(&kf_workspace_bytes)>(lib, "kf_workspace_bytes");
+  auto backward_tapes = sym<decltype(&kf_filter_backward_tapes)>(lib, "kf_filter_backward_tapes");
+  auto set_option = sym<decltype(&kf_set_option)>(lib, "kf_set_option");
+  auto get_option = sym<decltype(&kf_get_option)>(lib, "kf_get_option");
   auto abi = sym<decltype(&kf_abi_version)>(lib, "kf_abi_version");
   CHECK(abi() == KF_ABI_VERSION);
 
@@ -172,6 +175,38 @@ int main(int argc, char** argv) {
     }
     const double fd = (lpm[1] - lpm[0]) / (2 * eps);
     CHECK(fabs(fd - dH) < 1e-4 * (1.0 + fabs(fd)));
+    // ABI 7: a cotangent on ONE entry of the filtered-state tape -- d filtered_states[n-1][0] / dH against a central difference
+    {
+      hipMemcpy(H, Hh.data(), sizeof(double), hipMemcpyHostToDevice);
+      CHECK(forward(h, &dims, dy, a0, P0, T, Z, R, H, Q, nullptr, nullptr, logp, nullptr, fa, pa, fP, pP, nullptr, ws, wsb, nullptr) == KF_OK);
+      std::vector<double> gfa(n * m, 0.0);
+      gfa[(n - 1) * m] = 1.0;
+      double* dgfa = to_dev(gfa);
+      rc = backward_tapes(h, &dims, dy, a0, P0, T, Z, R, H, Q, nullptr, nullptr, pa, pP, nullptr, nullptr, dgfa, nullptr, nullptr,
+                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, gH, nullptr, nullptr, nullptr, ws, wsb, nullptr);
+      if (rc != KF_OK) fprintf(stderr, "%s\n", last_error(h));
+      CHECK(rc == KF_OK);
+      CHECK(hipDeviceSynchronize() == hipSuccess);
+      const double dHt = to_host(gH, 1)[0];
+      double fam[2];
+      for (int k = 0; k < 2; ++k) {
+        std::vector<double> Hp = {0.8 + (k ? eps : -eps)};
+        hipMemcpy(H, Hp.data(), sizeof(double), hipMemcpyHostToDevice);
+        CHECK(forward(h, &dims, dy, a0, P0, T, Z, R, H, Q, nullptr, nullptr, logp, nullptr, fa, nullptr, nullptr, nullptr, nullptr, ws, wsb,
+                      nullptr) == KF_OK);
+        CHECK(hipDeviceSynchronize() == hipSuccess);
+        fam[k] = to_host(fa, n * m)[(n - 1) * m];
+      }
+      const double fdt = (fam[1] - fam[0]) / (2 * eps);
+      CHECK(fabs(fdt - dHt) < 1e-5 * (1.0 + fabs(fdt)));
+      CHECK(backward_tapes(h, &dims, dy, a0, P0, T, Z, R, H, Q, nullptr, nullptr, pa, pP, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, gH, nullptr, nullptr, nullptr, ws, wsb, nullptr) == KF_ERR_ARG);
+    }
+    // ABI 7: path switches per handle
+    CHECK(set_option(h, "KF_STEADY_STATE", "0") == KF_OK);
+    CHECK(get_option(h, "KF_STEADY_STATE") != nullptr && !strcmp(get_option(h, "KF_STEADY_STATE"), "0"));
+    CHECK(set_option(h, "KF_STEADY_STATE", nullptr) == KF_OK);
+    CHECK(set_option(h, "KF_NOT_A_SWITCH", "1") == KF_ERR_ARG);
     // argument checking without a crash
     CHECK(forward(h, &dims, nullptr, a0, P0, T, Z, R, H, Q, nullptr, nullptr, logp, nullptr, nullptr, nullptr, nullptr,
                   nullptr, nullptr, nullptr, 0, nullptr) == KF_ERR_ARG);
