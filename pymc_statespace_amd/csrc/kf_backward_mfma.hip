@@ -49,8 +49,11 @@ __host__ __device__ inline int bwd_mfma_lds_doubles(int p) {
 // join T' ab' and Sb; covariance cotangents enter by their symmetric part (the adjoint tile is kept symmetric, see above), except
 // predicted slot 0 = P0 as given, whose cotangent goes to g_P0 unchanged.  Loaded at the top of the step, used behind the forward
 // recompute.  A separate instantiation: the log-likelihood-only adjoint is the kernel it was.
-template <int KS, bool P1, bool TV = false, bool TP = false>
-__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((KS <= 3 && !(TV && KS >= 2) && !TP) ? 4 : 3))) void kf_bwd_mfma_kernel(
+// W4 (TP only): four wavefronts per SIMD at the price of spills -- the cotangents are then loaded where they are used, not at the top
+// of the step.  Pays when the batch does not fit one round of three (measured, profiles/r06/tape_grad_time.txt: headline 4096 draws
+// 8.4 -> 6.7 ms; the 2048-draw C4 shard 3.9 -> 4.7, so only beyond 3 x SIMDs draws).
+template <int KS, bool P1, bool TV = false, bool TP = false, bool W4 = false>
+__global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((KS <= 3 && !(TV && KS >= 2) && (!TP || W4)) ? 4 : 3))) void kf_bwd_mfma_kernel(
     const KfBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((KS <= 
     }
     if (t > 0) prefetch(t - 1);
     double k_fa = 0.0, k_pa = 0.0, k_fP[KS], k_pP[KS];   // (TP) this step's tape cotangents
-    if (TP) {
+    if (TP && !W4) {
       k_fa = (c_fa && c_ok) ? c_fa[(long)t * m + c] : 0.0;
       k_pa = (c_pa && c_ok) ? c_pa[(long)t * m + c] : 0.0;
 #pragma unroll
@@ -318,6 +321,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((KS <= 
       if (s > 0) part = fma(TB[s], abr[s], part);
     }
     double abf = col_allsum(part);  // T' ab'
+    if (TP && W4) {
+      k_fa = (c_fa && c_ok) ? c_fa[(long)t * m + c] : 0.0;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) k_fP[s] = c_fP ? sym_at(c_fP, t, s) : 0.0;
+    }
     if (TP) abf += k_fa;
     // X1 = Gm T ; Sb = T' X1 ; Tb += 2 X1 P_f  (A operand = X1' registers, from an LDS transpose:
     // cheaper than the fourth product W = T P_f, Gm W)
@@ -434,6 +442,11 @@ __global__ __launch_bounds__(KF_WAVE) __attribute__((amdgpu_waves_per_eu((KS <= 
         GY[q * 8 + c] = fma(vb, (yc != yc) ? 0.0 : yc + dsign * DL[c], GY[q * 8 + c]);
       }
     }
+    if (TP && W4) {
+      k_pa = (c_pa && c_ok) ? c_pa[(long)t * m + c] : 0.0;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) k_pP[s] = (c_pP && t > 0) ? sym_at(c_pP, t, s) : 0.0;
+    }
 #pragma unroll
     for (int s = 0; s < KS; ++s) PB[s] = TP ? SB[s] + k_pP[s] : SB[s];
     abp = TP ? abf + k_pa : abf;
@@ -524,8 +537,13 @@ int kf_launch_backward_mfma(kf_handle* h, const KfBwdArgs& a, hipStream_t stream
     KF_SET_ERR(h, "backward(mfma): tape cotangents with time-varying matrices or a hand-over stay on the LDS adjoint");
     return KF_ERR_UNSUPPORTED;
   }
+  const bool w4 = tp && ks <= 3 && a.B > 12L * (h->n_cu > 0 ? h->n_cu : 256);   // more draws than one round of three per SIMD
 #define KF_BWD_MFMA_LAUNCH(KS_)                                                                        \
-  if (tp && a.p == 1)                                                                                  \
+  if (tp && w4 && a.p == 1)                                                                            \
+    hipLaunchKernelGGL((kf_bwd_mfma_kernel<KS_, true, false, true, (KS_ <= 3)>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);  \
+  else if (tp && w4)                                                                                   \
+    hipLaunchKernelGGL((kf_bwd_mfma_kernel<KS_, false, false, true, (KS_ <= 3)>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); \
+  else if (tp && a.p == 1)                                                                             \
     hipLaunchKernelGGL((kf_bwd_mfma_kernel<KS_, true, false, true>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a);  \
   else if (tp)                                                                                         \
     hipLaunchKernelGGL((kf_bwd_mfma_kernel<KS_, false, false, true>), dim3((unsigned)a.B), dim3(KF_WAVE), lds, stream, a); \

@@ -645,3 +645,25 @@ def test_set_option_selects_the_path_of_a_call(eng):
     assert torch.equal(a.filtered_covs, b.filtered_covs) and torch.equal(a.logp, b.logp)
     assert not torch.equal(a.filtered_covs, c.filtered_covs)
     assert float((a.logp - c.logp).abs().max()) < 1e-8
+
+
+@pytest.mark.parametrize("case", ["structural_m10", "dense_p3m6_univariate", "dense_p1m3"])
+def test_backward_tapes_large_batch_variant_is_the_small_batch_kernel(eng, case):
+    """Beyond three draws per SIMD the tile adjoint with tape cotangents runs its four-wavefront instantiation (cotangents loaded where
+    they are used, csrc/kf_backward_mfma.hip W4): same numbers as the three-wavefront one, draw for draw."""
+    make, ft = TAPE_CASES[case]
+    w = make()
+    rng = np.random.default_rng(12)
+    B0, reps = w["B"], 3300 // w["B"] + 1
+    gt = _tape_cotangents(rng, B0, w["n"], w["m"], ("fa", "pa", "fP", "pP"))
+    g_logp = rng.standard_normal(B0)
+    small = _backward_tapes(eng, w, ft, gt, g_logp=g_logp)
+    big_w = dict(w, B=B0 * reps, **{k: np.tile(w[k], (reps,) + (1,) * (w[k].ndim - 1)) for k in KEYS})
+    big_gt = {k: np.tile(v, (reps,) + (1,) * (v.ndim - 1)) for k, v in gt.items()}
+    big = _backward_tapes(eng, big_w, ft, big_gt, g_logp=np.tile(g_logp, reps))
+    assert big_w["B"] > 3072
+    for k in small:
+        a, b = small[k].cpu().numpy(), big[k].cpu().numpy()
+        for rblk in (0, reps // 2, reps - 1):
+            got = b[rblk * B0:(rblk + 1) * B0]
+            assert np.max(np.abs(got - a)) <= 1e-12 * (1.0 + np.max(np.abs(a))), (k, rblk)
