@@ -226,28 +226,26 @@ def perform_logp_and_grad_batched(data, a0, P0, T, Z, R, H, Q, c, d, filter_type
     return [logp.cpu().numpy()] + [out[k] for k in GRAD_INPUT_NAMES]
 
 
-def _tape_cotangent(g, lead):
-    """A tape cotangent as the C-ABI wants it -- trailing unit axis of the state tapes dropped, ``lead`` draw axes in front -- or
-    None for the zero-size placeholder that stands for "no cotangent on this output"."""
+def _tape_cotangent(g):
+    """A tape cotangent from the graph, or None for the zero-size placeholder that stands for "no cotangent on this output"."""
     if g is None:
         return None
     g = np.asarray(g, dtype=np.float64)
-    if g.size == 0:
-        return None
-    return g
+    return g if g.size else None
 
 
 def _state_cotangent(g, batched):
-    g = _tape_cotangent(g, 0)
+    """(n, m, 1) / (B, n, m, 1) columns of the graph -> the C-ABI's [B][n][m]."""
+    g = _tape_cotangent(g)
     if g is None:
         return None
-    if g.ndim == (4 if batched else 3):   # (.., n, m, 1): the graph's state tapes are columns
+    if g.ndim == (4 if batched else 3):
         g = g[..., 0]
     return g if batched else g[None]
 
 
 def _cov_cotangent(g, batched):
-    g = _tape_cotangent(g, 0)
+    g = _tape_cotangent(g)
     if g is None:
         return None
     return g if batched else g[None]
