@@ -175,6 +175,24 @@ class ShardedKalman:
         full = all_gather_draws(torch.stack([logp, info.to(logp.dtype)], dim=1).reshape(b, 2), B_global, self.group)
         return full[:, 0].contiguous(), full[:, 1].to(torch.int32), g
 
+    def backward_local(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, predicted_states, predicted_covs, **kw):
+        """kf_filter_backward / kf_filter_backward_tapes on this rank's draws and ITS tapes: the cotangents of a tape live where the
+        tape does (``g_logp``, ``g_ll_obs``, ``g_filtered_states`` ... are this rank's shards), nothing is exchanged.  Returns the
+        dict of gradients (a0, P0, T, Z, R, H, Q, c, d) -- ``gather_value_and_grad``'s packing applies to it as it stands.  An empty
+        shard skips the launch and returns empty tensors of the right trailing shapes (static models; a time-varying gradient has
+        its matrix's (b, n, ..) shape: call the engine on each rank's shard)."""
+        if kw.get("time_varying"):
+            raise NotImplementedError("the sharded backward takes static system matrices (use engine.backward with "
+                                      "time_varying=... on each rank's shard)")
+        if T.shape[0] == 0:
+            dev, f64 = self.engine.device, torch.float64
+            shp = dict(a0=tuple(a0.shape[1:]), P0=tuple(P0.shape[1:]), T=tuple(T.shape[1:]), Z=tuple(Z.shape[1:]),
+                       R=tuple(R.shape[1:]), H=tuple(H.shape[1:]), Q=tuple(Q.shape[1:]), c=(T.shape[-1],), d=(Z.shape[-2],))
+            return {k: torch.empty((0,) + shp[k], device=dev, dtype=f64) for k in self.GRAD_KEYS}
+        kw.setdefault("want_cd", True)
+        return self.engine.backward(y, a0, P0, T, Z, R, H, Q, c, d, predicted_states=predicted_states,
+                                    predicted_covs=predicted_covs, **kw)
+
     # ------------------------------------------------------------------ smoother: tapes stay where they were filtered
     def smooth_local(self, T, R, Q, filtered_states, filtered_covs, **kw):
         """kf_smoother on this rank's tapes; nothing is exchanged (a smoothed tape is as large as the filtered one it came

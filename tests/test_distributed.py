@@ -160,6 +160,21 @@ class _OracleGradEngine(_OracleEngine):
         return (torch.from_numpy(lp), torch.zeros(T.shape[0], dtype=torch.int32),
                 {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in g.items()})
 
+    def backward(self, y, a0, P0, T, Z, R, H, Q, c=None, d=None, *, predicted_states, predicted_covs, g_logp=None, g_ll_obs=None,
+                 g_filtered_states=None, g_predicted_states=None, g_filtered_covs=None, g_predicted_covs=None, want_cd=False, **kw):
+        """torch.autograd through the torch restatement (oracle/kalman_torch.py): the checker of kf_filter_backward_tapes."""
+        from oracle import kalman_torch as kt
+
+        if T.shape[0] < 1:
+            raise RuntimeError("kf_filter_backward_tapes failed (-1): bad dims: B=0")
+        gt = {k: v.numpy() for k, v in (("filtered_states", g_filtered_states), ("predicted_states", g_predicted_states),
+                                        ("filtered_covs", g_filtered_covs), ("predicted_covs", g_predicted_covs)) if v is not None}
+        B = T.shape[0]
+        _, _, g = kt.logp_and_grads(y.numpy(), *[x.numpy() for x in (a0, P0, T, Z, R, H, Q)],
+                                    g_logp=np.zeros(B) if g_logp is None else g_logp.numpy(),
+                                    g_ll_obs=None if g_ll_obs is None else g_ll_obs.numpy(), g_tapes=gt or None)
+        return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in g.items()}
+
     def smooth(self, T, R, Q, fa, fP, **kw):
         from oracle import kalman_numpy as kn
 
@@ -227,8 +242,22 @@ def _worker_sharded_grad_and_smooth(rank, world, port, B, ret):
             sk.filter_and_smooth(y, *shard, torch.zeros(0, shard[0].shape[1], dtype=torch.float64), B_global=B)  # (joins the gather)
         with pytest.raises(NotImplementedError):   # every rank, empty or not
             sk.value_and_grad(y, *shard, B_global=B, time_varying=("T",))
+        # (round 6) gradients through the tapes: cotangents sharded like the tapes, nothing exchanged; an empty shard returns
+        # empty arrays that pack into the same all-gather as the log-likelihood gradients
+        gen = torch.Generator().manual_seed(5)
+        n, m = y.shape[0], shard[0].shape[1]
+        g_fa = torch.randn(B, n, m, dtype=torch.float64, generator=gen)
+        g_pP = torch.randn(B, n + 1, m, m, dtype=torch.float64, generator=gen)
+        g_pP = 0.5 * (g_pP + g_pP.transpose(-1, -2))
+        gtl = sk.backward_local(y, *shard, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
+                                g_filtered_states=g_fa[lo:hi], g_predicted_covs=g_pP[lo:hi])
+        assert all(gtl[k].shape[0] == hi - lo for k in sk.GRAD_KEYS)
+        _, _, gt_full = sk.gather_value_and_grad(lp[lo:hi], info[lo:hi], gtl, B)
+        with pytest.raises(NotImplementedError):
+            sk.backward_local(y, *shard, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs, time_varying=("T",))
         ret[rank] = dict(logp=lp.numpy(), grads={k: v.numpy() for k, v in g.items()}, lo=lo, hi=hi, sa=sa.numpy(), sP=sP.numpy(),
-                         sa_b=sa_b.numpy(), sP_b=sP_b.numpy())
+                         sa_b=sa_b.numpy(), sP_b=sP_b.numpy(), tape_grads={k: v.numpy() for k, v in gt_full.items()},
+                         g_fa=g_fa.numpy(), g_pP=g_pP.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -259,6 +288,12 @@ def test_sharded_value_and_grad_and_smoother_gloo(B):
         lo, hi = ret[r]["lo"], ret[r]["hi"]
         assert np.array_equal(ret[r]["sa"], sa[lo:hi]) and np.array_equal(ret[r]["sP"], sP[lo:hi])
         assert np.array_equal(ret[r]["sa_b"], sb[lo:hi]) and np.array_equal(ret[r]["sP_b"], sPb[lo:hi])
+    from oracle import kalman_torch as kt
+
+    _, _, gref = kt.logp_and_grads(w["y"], *mats, g_tapes=dict(filtered_states=ret[0]["g_fa"], predicted_covs=ret[0]["g_pP"]))
+    for r in range(world):   # every draw's tape gradient, whichever rank computed it
+        for k in gref:
+            assert np.allclose(ret[r]["tape_grads"][k], gref[k], rtol=1e-12, atol=1e-12), (r, k)
 
 
 def test_bench_launcher_builds_a_torchrun_command(monkeypatch):
