@@ -140,8 +140,16 @@ extern "C" int kf_set_option(kf_handle* h, const char* name, const char* value) 
   int at = -1;
   for (int i = 0; i < h->n_options; ++i)
     if (!strcmp(h->options[i].name, name)) at = i;
+  static const struct { const char* s; int k; } fwd_kernels[] = {{"auto", KF_KERNEL_AUTO}, {"lds", KF_KERNEL_LDS}, {"row", KF_KERNEL_ROW},
+                                                                {"lane", KF_KERNEL_LANE}, {"mfma", KF_KERNEL_MFMA}, {"b4", KF_KERNEL_B4}};
   if (!value) {   // back to the environment
     if (at >= 0) h->options[at] = h->options[--h->n_options];
+    if (!strcmp(name, "KF_FORWARD_KERNEL")) {   // (the selector kf_create would have chosen)
+      h->forward_kernel = KF_KERNEL_AUTO;
+      const char* e = getenv(name);
+      for (const auto& k : fwd_kernels)
+        if (e && !strcmp(e, k.s)) h->forward_kernel = k.k;
+    }
     return KF_OK;
   }
   if (at < 0) {
@@ -154,9 +162,7 @@ extern "C" int kf_set_option(kf_handle* h, const char* name, const char* value) 
   }
   snprintf(h->options[at].value, sizeof(h->options[at].value), "%s", value);
   if (!strcmp(name, "KF_FORWARD_KERNEL")) {   // (read once, at kf_create: the handle's selector is what it sets)
-    static const struct { const char* s; int k; } ks[] = {{"auto", KF_KERNEL_AUTO}, {"lds", KF_KERNEL_LDS}, {"row", KF_KERNEL_ROW},
-                                                          {"lane", KF_KERNEL_LANE}, {"mfma", KF_KERNEL_MFMA}, {"b4", KF_KERNEL_B4}};
-    for (const auto& e : ks)
+    for (const auto& e : fwd_kernels)
       if (!strcmp(value, e.s)) h->forward_kernel = e.k;
   }
   return KF_OK;

@@ -667,3 +667,35 @@ def test_backward_tapes_large_batch_variant_is_the_small_batch_kernel(eng, case)
         for rblk in (0, reps // 2, reps - 1):
             got = b[rblk * B0:(rblk + 1) * B0]
             assert np.max(np.abs(got - a)) <= 1e-12 * (1.0 + np.max(np.abs(a))), (k, rblk)
+
+
+def test_backward_tapes_time_varying_Q_and_R(eng):
+    """Time-varying state noise with tape cotangents: each step's R_t Q_t R_t' enters predicted slot t + 1 only, whose adjoint now
+    carries that slot's cotangent (the LDS-resident adjoint's per-step g_R / g_Q)."""
+    from oracle import kalman_torch as kt
+
+    w = W.random_dense(3, 12, 1, 4, 2, seed=41)
+    rng = np.random.default_rng(14)
+    Qt = w["Q"][:, None] * (1.0 + 0.1 * rng.random((3, 12, 1, 1)))
+    Rt = w["R"][:, None] * (1.0 + 0.1 * rng.standard_normal((3, 12, 1, 1)))
+    gt = _tape_cotangents(rng, 3, 12, 4, ("pa", "fP", "pP"))
+    args = [w["y"], w["a0"], w["P0"], w["T"], w["Z"], Rt, w["H"], Qt]
+    tv = ("R", "Q")
+    res = eng.forward(*args, mvn_const="exact", time_varying=tv)
+    g = eng.backward(*args, predicted_states=res.predicted_states, predicted_covs=res.predicted_covs,
+                     g_predicted_states=gt["predicted_states"], g_filtered_covs=gt["filtered_covs"],
+                     g_predicted_covs=gt["predicted_covs"], mvn_const="exact", want_cd=True, time_varying=tv)
+    _, _, ref = kt.logp_and_grads(*args, mvn_const="exact", time_varying=tv, g_tapes=gt)
+    assert g["Q"].shape == (3, 12, 2, 2) and g["R"].shape == (3, 12, 4, 2)
+    _assert_grads(g, ref)
+
+
+def test_set_option_forward_kernel_selector_and_its_removal(eng):
+    name = lambda: eng.forward_kernel_name(64, 50, 1, 10, 2)  # noqa: E731
+    assert name() == "kf_fwd_b4_kernel"
+    eng.set_option("KF_FORWARD_KERNEL", "mfma")
+    try:
+        assert name() == "kf_fwd_mfma_kernel"
+    finally:
+        eng.set_option("KF_FORWARD_KERNEL", None)
+    assert name() == "kf_fwd_b4_kernel"
