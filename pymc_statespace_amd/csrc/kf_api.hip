@@ -101,6 +101,7 @@ static const char* const kf_option_names[] = {
     "KF_FORWARD_WGL",
     "KF_FORWARD_WHITEN",
     "KF_LANES_PER_DRAW",
+    "KF_LANE_PRECHUNK",
     "KF_SMOOTHER_B4",
     "KF_SMOOTHER_BF_LANE",
     "KF_SMOOTHER_BF_WG",

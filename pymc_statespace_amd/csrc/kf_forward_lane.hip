@@ -213,10 +213,392 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
     if (t0 + cnt < n) y_commit();
   };
 
-  y_fetch(0);
-  y_commit();
-
   int info = 0;
+  int t = 0;
+  constexpr bool SCAN = SS && M <= 2 && DPW == 4 && S == 16;
+  // ---- round 6: the first 256 steps as SIXTEEN CHUNKS of 16 steps on the slot's sixteen lanes --------------------------------------------
+  // The launch lasts as long as its slowest wavefront, and that is one whose draw needs ~300 sequential steps before its covariance
+  // stops moving (C2: median 16 steps, slowest of 4096 draws 312; 0.5 us per step with one wavefront on the SIMD) -- the lanes of a
+  // slot replicate that chain sixteen times.  For a static model without missing observations the covariance sequence does not depend
+  // on y: P_f(16 j - 1) = E16^(j - 1)(P_f(15)) with E16 the fourth square of the one-step element (A, C, J) of the filtered
+  // covariance's Riccati map (kf_forward_b4c.hip has the derivation; here m <= 2 and everything is a register).  Lane j of the slot
+  //   pass 1: runs ITS 16 steps from its own predicted covariance and a zero mean: transition Phi_j, response z_j, every F > 0, and
+  //           its last predicted covariance against lane j + 1's start (1e-12 of the largest entry);
+  //   the means are chained over the lanes (a_{16 (j + 1)} = Phi_j a_{16 j} + z_j, fifteen shuffles);
+  //   pass 2: the same 16 steps from its true start, every output written straight from the registers (a lane's rows are
+  //           consecutive: the lines complete in L2), the log-likelihood terms summed over the slot.
+  // Chunk 0 is the sequential kernel's arithmetic bit for bit; the others agree with it to ~1e-14 (the doubling).  Any doubt -- a
+  // missing observation in the first 256 steps, F <= 0, S0 <= 0, a failed check, in ANY slot of the wavefront -- and nothing has
+  // been written: the loop below starts at step 0 as before.  KF_LANE_PRECHUNK=0 switches it off.
+  if constexpr (SCAN) {
+    constexpr int PL = 16, PN = 16 * PL;
+    if (A.lane_pre && n >= 2 * PN && !A.hs_ts) {
+      const int jj = lane / DPW;
+      const double* yb = A.y + (y_per_draw ? b * (long)n : 0L);
+      double yc[PL];
+      bool okl = true;
+#pragma unroll
+      for (int ss = 0; ss < PL; ++ss) {
+        yc[ss] = yb[PL * jj + ss];
+        okl = okl && !(yc[ss] != yc[ss]);
+      }
+      // one step of the recursion in the main loop's own arithmetic; returns F as computed (before any degenerate-step handling)
+      auto kstep = [&](double (&Pq)[M][M], double (&aq)[M], double yv, double (&af)[M], double (&Pf)[M][M], double& quad,
+                       double (&Kq)[M]) -> double {
+        double Mv[M];
+        double F = Hs, za = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          double sm = 0.0;
+#pragma unroll
+          for (int k = 0; k < M; ++k) sm = fma(Pq[i][k], Z[k], sm);
+          Mv[i] = sm;
+          F = fma(Z[i], sm, F);
+          za = fma(Z[i], aq[i], za);
+        }
+        const double v = (yv + dsign * ds) - za;
+        const double invF = fast_rcp(F);
+        quad = v * v * invF;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          Kq[i] = Mv[i] * invF;
+          af[i] = fma(Kq[i], v, aq[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int j = i; j < M; ++j) {
+            double sm;
+            if (univariate) {
+              sm = Pq[i][j] - Kq[i] * Kq[j] * F;
+            } else {
+              sm = Pq[i][j] - Kq[i] * Mv[j];
+              sm = fma(-Mv[i], Kq[j], sm);
+              sm = fma(F * Kq[i], Kq[j], sm);
+            }
+            Pf[i][j] = sm;
+            Pf[j][i] = sm;
+          }
+        double Wq[M][M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          double sm = c[i];
+#pragma unroll
+          for (int k = 0; k < M; ++k) sm = fma(T[i][k], af[k], sm);
+          aq[i] = sm;
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            double w = 0.0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) w = fma(T[i][k], Pf[k][j], w);
+            Wq[i][j] = w;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int j = i; j < M; ++j) {
+            double sij = RQR[i][j], sji = RQR[j][i];
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+              sij = fma(Wq[i][k], T[j][k], sij);
+              sji = fma(Wq[j][k], T[i][k], sji);
+            }
+            const double sm = 0.5 * (sij + sji);
+            Pq[i][j] = sm;
+            Pq[j][i] = sm;
+          }
+        return F;
+      };
+      // small dense helpers (M <= 2)
+      auto mul = [&](const double (&X)[M][M], const double (&Y)[M][M], double (&O)[M][M]) {   // O = X Y
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            double sm = 0.0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) sm = fma(X[i][k], Y[k][j], sm);
+            O[i][j] = sm;
+          }
+      };
+      auto mul_t = [&](const double (&X)[M][M], const double (&Y)[M][M], double (&O)[M][M]) {   // O = X Y'
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            double sm = 0.0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) sm = fma(X[i][k], Y[j][k], sm);
+            O[i][j] = sm;
+          }
+      };
+      auto tmul = [&](const double (&X)[M][M], const double (&Y)[M][M], double (&O)[M][M]) {   // O = X' Y
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            double sm = 0.0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) sm = fma(X[k][i], Y[k][j], sm);
+            O[i][j] = sm;
+          }
+      };
+      auto inv_ipxy = [&](const double (&X)[M][M], const double (&Y)[M][M], double (&D)[M][M]) -> bool {   // D = (I + X Y)^-1
+        double Wm[M][M];
+        mul(X, Y, Wm);
+#pragma unroll
+        for (int i = 0; i < M; ++i) Wm[i][i] += 1.0;
+        if constexpr (M == 1) {
+          D[0][0] = 1.0 / Wm[0][0];
+          return Wm[0][0] > 0.0;
+        } else {
+          const double det = Wm[0][0] * Wm[1][1] - Wm[0][1] * Wm[1][0];
+          const double rd = 1.0 / det;
+          D[0][0] = Wm[1][1] * rd;
+          D[0][1] = -Wm[0][1] * rd;
+          D[1][0] = -Wm[1][0] * rd;
+          D[1][1] = Wm[0][0] * rd;
+          return det > 0.0;   // (X, Y positive semi-definite: every eigenvalue of I + X Y is >= 1)
+        }
+      };
+      auto symm = [&](double (&X)[M][M]) {
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int j = i + 1; j < M; ++j) {
+            const double sm = 0.5 * (X[i][j] + X[j][i]);
+            X[i][j] = sm;
+            X[j][i] = sm;
+          }
+      };
+      // (i) P_f(15): the covariance recursion of steps 0 .. 15 (every lane of the slot, redundantly: 16 of the 256 steps)
+      double a_in[M], P_in[M][M], Pf15[M][M];
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        a_in[i] = a[i];
+#pragma unroll
+        for (int j = 0; j < M; ++j) P_in[i][j] = P[i][j];
+      }
+      {
+        double Pq[M][M], aq[M], af[M], Kq[M], quad;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          aq[i] = 0.0;
+#pragma unroll
+          for (int j = 0; j < M; ++j) Pq[i][j] = P_in[i][j];
+        }
+        for (int ss = 0; ss < PL; ++ss) {
+          const double F = kstep(Pq, aq, 0.0, af, Pf15, quad, Kq);
+          okl = okl && (F > 0.0);
+        }
+      }
+      // (ii) the one-step element, squared up; P_f(16 jj - 1) by the bits of jj - 1
+      double Ae[M][M], Ce[M][M], Je[M][M];
+      {
+        double qz[M], zt[M];
+        double S0 = Hs;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+          for (int k = 0; k < M; ++k) {
+            s1 = fma(0.5 * (RQR[i][k] + RQR[k][i]), Z[k], s1);
+            s2 = fma(Z[k], T[k][i], s2);
+          }
+          qz[i] = s1;
+          zt[i] = s2;
+          S0 = fma(Z[i], s1, S0);
+        }
+        okl = okl && (S0 > 0.0);
+        const double rS0 = 1.0 / S0;
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            Ae[i][j] = fma(-qz[i] * rS0, zt[j], T[i][j]);
+            Ce[i][j] = fma(-qz[i] * rS0, qz[j], 0.5 * (RQR[i][j] + RQR[j][i]));
+            Je[i][j] = zt[i] * zt[j] * rS0;
+          }
+      }
+      auto square = [&]() {
+        double D[M][M], X[M][M], Y[M][M], V[M][M], Wm[M][M], N1[M][M];
+        okl = inv_ipxy(Ce, Je, D) && okl;
+        mul(Ae, D, X);          // A D
+        mul(X, Ce, Y);          // A D C
+        mul_t(Y, Ae, N1);       // A D C A'
+        mul(Je, D, V);          // J D
+        tmul(Ae, V, Wm);        // A' J D
+        double N2[M][M], N3[M][M];
+        mul(Wm, Ae, N2);        // A' J D A
+        mul(X, Ae, N3);         // A D A
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            Ce[i][j] += N1[i][j];
+            Je[i][j] += N2[i][j];
+            Ae[i][j] = N3[i][j];
+          }
+        symm(Ce);
+        symm(Je);
+      };
+      double Pfs[M][M];   // P_f(16 jj - 1)
+#pragma unroll
+      for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) Pfs[i][j] = Pf15[i][j];
+      for (int q = 0; q < 4; ++q) square();   // E16
+      const int pw = jj > 0 ? jj - 1 : 0;
+      for (int q = 0; q < 4; ++q) {
+        double D[M][M], Psi[M][M], Y[M][M], Nn[M][M];
+        const bool dok = inv_ipxy(Pfs, Je, D);
+        mul(Ae, D, Psi);
+        mul(Psi, Pfs, Y);
+        mul_t(Y, Ae, Nn);
+        const bool bit = ((pw >> q) & 1) != 0;
+        okl = okl && (dok || !bit);
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int j = 0; j < M; ++j) Pfs[i][j] = bit ? Nn[i][j] + Ce[i][j] : Pfs[i][j];
+        symm(Pfs);
+        if (q < 3) square();   // E32, E64, E128
+      }
+      double Pst[M][M];   // the predicted covariance this lane's chunk starts from
+      {
+        double Wq[M][M];
+        mul(T, Pfs, Wq);
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int j = i; j < M; ++j) {
+            double sij = RQR[i][j], sji = RQR[j][i];
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+              sij = fma(Wq[i][k], T[j][k], sij);
+              sji = fma(Wq[j][k], T[i][k], sji);
+            }
+            const double sm = 0.5 * (sij + sji);
+            Pst[i][j] = (jj == 0) ? P_in[i][j] : sm;
+            Pst[j][i] = (jj == 0) ? P_in[j][i] : sm;
+          }
+      }
+      // (iii) pass 1: transition and zero-start response of the lane's 16 steps
+      double Phi[M][M], zr[M];
+      {
+        double Pq[M][M], aq[M], af[M], Pf[M][M], Kq[M], quad;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          aq[i] = 0.0;
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            Pq[i][j] = Pst[i][j];
+            Phi[i][j] = (i == j) ? 1.0 : 0.0;
+          }
+        }
+#pragma unroll
+        for (int ss = 0; ss < PL; ++ss) {
+          const double F = kstep(Pq, aq, yc[ss], af, Pf, quad, Kq);
+          okl = okl && (F > 0.0);
+          // a_{t+1} = (T - T K Z) a_t + ...: the transition of this step
+          double TK[M], At[M][M], Nn[M][M];
+#pragma unroll
+          for (int i = 0; i < M; ++i) {
+            double sm = 0.0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) sm = fma(T[i][k], Kq[k], sm);
+            TK[i] = sm;
+          }
+#pragma unroll
+          for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j) At[i][j] = fma(-TK[i], Z[j], T[i][j]);
+          mul(At, Phi, Nn);
+#pragma unroll
+          for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j) Phi[i][j] = Nn[i][j];
+        }
+#pragma unroll
+        for (int i = 0; i < M; ++i) zr[i] = aq[i];
+        // the chunk's last predicted covariance against the next lane's start
+        double pmax = 0.0, dmax = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            const double nx = __shfl_down(Pst[i][j], DPW, KF_WAVE);
+            pmax = fmax(pmax, fabs(Pq[i][j]));
+            dmax = fmax(dmax, fabs(Pq[i][j] - nx));
+          }
+        if (jj < 15) okl = okl && (dmax <= 1e-12 * pmax);
+      }
+      if (__all(okl)) {   // (wave-uniform)
+        // (iv) the predicted mean each chunk starts from
+        double cur[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) cur[i] = a_in[i];
+        for (int k = 0; k < 15; ++k) {
+          double nx[M];
+#pragma unroll
+          for (int i = 0; i < M; ++i) {
+            double sm = zr[i];
+#pragma unroll
+            for (int l = 0; l < M; ++l) sm = fma(Phi[i][l], cur[l], sm);
+            nx[i] = sm;
+          }
+#pragma unroll
+          for (int i = 0; i < M; ++i) {
+            const double rv = __shfl_up(nx[i], DPW, KF_WAVE);
+            cur[i] = (jj == k + 1) ? rv : cur[i];
+          }
+        }
+        // (v) pass 2: the lane's 16 steps for real, outputs straight from the registers
+        double Pq[M][M], aq[M], lacc = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          aq[i] = cur[i];
+#pragma unroll
+          for (int j = 0; j < M; ++j) Pq[i][j] = Pst[i][j];
+        }
+#pragma unroll
+        for (int ss = 0; ss < PL; ++ss) {
+          const int tt = PL * jj + ss;
+          double af[M], Pf[M][M], Kq[M], quad;
+          const double F = kstep(Pq, aq, yc[ss], af, Pf, quad, Kq);
+          const double llv = (univariate && !exact_const && F == 1.0 && quad == 0.0) ? 0.0 : -0.5 * (KF_LOG_2PI + log(F) + quad);  // :497-500
+          lacc += llv;
+          if (live) {
+            if (A.ll_obs) A.ll_obs[b * (long)n + tt] = llv;
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+              if (w_fa) A.filt_a[(b * (long)n + tt) * M + i] = af[i];
+              if (w_pa) A.pred_a[(b * (long)(n + 1) + tt + 1) * M + i] = aq[i];
+#pragma unroll
+              for (int j = 0; j < M; ++j) {
+                if (w_fP) A.filt_P[(b * (long)n + tt) * MM + i * M + j] = Pf[i][j];
+                if (w_pP) A.pred_P[(b * (long)(n + 1) + tt + 1) * MM + i * M + j] = Pq[i][j];
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int off = DPW; off < KF_WAVE; off <<= 1) lacc += __shfl_xor(lacc, off, KF_WAVE);
+        if (owner) smem[L::OFF_ACC + d] += lacc;
+        // (vi) the loop below goes on from step 256 with the last lane's predicted moments
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          a[i] = __shfl(aq[i], d + DPW * 15, KF_WAVE);
+#pragma unroll
+          for (int j = 0; j < M; ++j) P[i][j] = __shfl(Pq[i][j], d + DPW * 15, KF_WAVE);
+        }
+        t = PN;
+      }
+    }
+  }
+  y_fetch(t);
+  y_commit();
   double ycur = s_yb[0];
   // ---- steady state (kf_forward_b4.hip has the long version): once every draw of the wavefront has a predicted covariance that
   // stopped moving (3e-16 of its largest entry, tested at the end of each block of S steps, no missing observation ahead) the
@@ -247,7 +629,6 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
   // step from its own a_{t+j} and writes its row of the LDS block.  (A is the closed-loop matrix of the converged filter: stable.)
   // A slot changes over at the block boundary behind ITS OWN convergence, whatever the other slots of the wavefront do (they keep
   // stepping with the frozen slots' lanes idle), so a draw's bits do not depend on its neighbours.
-  constexpr bool SCAN = SS && M <= 2 && DPW == 4 && S == 16;
   const int jj = lane / DPW;
   double zK[M], zTK[M], zAp[4][M][M], zAj[M][M], zInvF = 0.0, zFraw = 0.0;
   bool zDegen = false;
@@ -400,7 +781,6 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
 #pragma unroll
     for (int i = 0; i < M; ++i) a[i] = __shfl(ap[i], d + DPW * (S - 1), KF_WAVE);  // the next block starts from the last lane's prediction
   };
-  int t = 0;
   int npass = 0;  // consecutive convergence checks this lane's draw has passed
   for (; t < n; ++t) {
     const int s = t & (S - 1);
@@ -646,6 +1026,10 @@ int KF_CAT(kf_launch_forward_lane_m, KF_LANE_M)(kf_handle* h, const KfFwdArgs& a
     if (sse && *sse && atoi(sse) == 0) a_.flags |= KF_FLAG_EXACT_RECURSION;
   }
   const bool ss = !(a_.flags & KF_FLAG_EXACT_RECURSION) && a.T >= 64;
+  {
+    const char* e = kf_env_switch("KF_LANE_PRECHUNK");   // =0: every step one after the other from step 0 (A/B measurements)
+    a_.lane_pre = (e && *e && atoi(e) == 0) ? 0 : 1;
+  }
 #define KF_LANE_LAUNCH2(D_, TM_)                                                                                             \
   do {                                                                                                                       \
     if (ss)                                                                                                                  \

@@ -162,6 +162,7 @@ struct KfFwdArgs {
   // j = i % ck_nc of draw i / ck_nc -- steps [j ck_s + 1, (j + 1) ck_s + 1) (chunk 0: from step 0) -- from the predicted covariance
   // ck_start[b][j] (chunk 0: P0) and, j > 0, the predicted mean c ("zero start": the draw's true mean joins in the mean pass); it writes
   // the covariance tapes and leaves the gain, (F, -2 v / sqrt F) and the chunk's last filtered mean for the mean pass
+  int lane_pre = 0;   // kf_forward_lane.hip: the first 256 steps as sixteen 16-step chunks on a slot's sixteen lanes (KF_LANE_PRECHUNK)
   int ck_nc = 0, ck_s = 0;
   const double* ck_start = nullptr;  // [B][ck_nc][m][m]
   double* ck_K = nullptr;            // [B][T][m]      K_t = P_t Z' / F_t (0 on a missing step: never here)
