@@ -69,6 +69,9 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
   constexpr int MM = M * M, S = L::S;
   constexpr int NK = (DPW * S + KF_WAVE - 1) / KF_WAVE;  // log-likelihood terms per lane and block
   __shared__ double smem[L::TOTAL];
+  // (round 6) stage of the chunked first 256 steps: per lane four steps of the five outputs, odd strides
+  constexpr bool PRE_OK = SS && M <= 2 && DPW == 4 && S == 16;
+  __shared__ double pstage[PRE_OK ? KF_WAVE * (2 * (4 * M + 1) + 2 * (4 * MM + 1) + 5) : 1];
   const int lane = threadIdx.x;
   const int d = lane % DPW;
   const bool owner = lane < DPW;
@@ -138,13 +141,26 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
   auto copy_out = [&](double* tape, const double* lds, int stride, auto wtag, int rows, int row0, int cnt) {
     constexpr int W = decltype(wtag)::value;
     if (cnt == S) {
+      // (round 6: every LDS read of the block first, then the stores -- with the bounds test inside, each of the up to twelve copies
+      // of a flush was a basic block of its own: read, wait for it, store; one wavefront per SIMD has nothing else to run meanwhile)
       constexpr int CW = S * W;
+      constexpr int NI = (DPW * CW + KF_WAVE - 1) / KF_WAVE;
+      double vals[NI];
 #pragma unroll
-      for (int e0 = 0; e0 < DPW * CW; e0 += KF_WAVE) {
-        const int e = e0 + lane;
+      for (int k = 0; k < NI; ++k) {
+        int e = k * KF_WAVE + lane;
+        if ((DPW * CW) % KF_WAVE != 0 && e >= DPW * CW) e = DPW * CW - 1;
         const int dd = e / CW, off = e - dd * CW;
-        if ((DPW * CW) % KF_WAVE == 0 || e < DPW * CW)
-          if (b0 + dd < A.B) tape[((b0 + dd) * (long)rows + row0) * W + off] = lds[dd * stride + off];
+        vals[k] = lds[dd * stride + off];
+      }
+#pragma unroll
+      for (int k = 0; k < NI; ++k) asm volatile("" : "+v"(vals[k]));   // (pinned here: the compiler sinks each load into its store's branch)
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int e = k * KF_WAVE + lane;
+        const int dd = e / CW, off = e - dd * CW;
+        if (((DPW * CW) % KF_WAVE == 0 || e < DPW * CW) && b0 + dd < A.B)
+          tape[((b0 + dd) * (long)rows + row0) * W + off] = vals[k];
       }
     } else {
       const int cw = cnt * W;
@@ -554,7 +570,34 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
             cur[i] = (jj == k + 1) ? rv : cur[i];
           }
         }
-        // (v) pass 2: the lane's 16 steps for real, outputs straight from the registers
+        // (v) pass 2: the lane's 16 steps for real.  Rows leave through an LDS stage four steps at a time: a lane's four rows of a
+        // tape are adjacent in memory, so sixteen (covariances) or eight (states) consecutive lanes of a copy write one whole line --
+        // straight from the registers every store instruction touched 64 lines (0.08 ms of partial-line traffic at C2)
+        constexpr int PG = 4;                                  // steps per stage
+        constexpr int ST_A = PG * M + 1, ST_P = PG * MM + 1, ST_L = PG + 1;   // odd lane strides: no bank conflicts
+        double* g_fa = pstage;
+        double* g_pa = g_fa + KF_WAVE * ST_A;
+        double* g_fP = g_pa + KF_WAVE * ST_A;
+        double* g_pP = g_fP + KF_WAVE * ST_P;
+        double* g_ll = g_pP + KF_WAVE * ST_P;
+        auto stage_out = [&](double* tape, const double* lds, int lstride, auto wtag, int rows, int rshift, int ss0) {
+          constexpr int W = decltype(wtag)::value;   // doubles per row
+          constexpr int CW = PG * W, NI = CW;        // 64 lane-chunks x CW doubles = CW rounds of 64
+          double vals[NI];
+#pragma unroll
+          for (int k = 0; k < NI; ++k) {
+            const int e = k * KF_WAVE + lane;
+            const int cl = e / CW, wi = e - cl * CW;
+            vals[k] = lds[cl * lstride + wi];
+          }
+#pragma unroll
+          for (int k = 0; k < NI; ++k) {
+            const int e = k * KF_WAVE + lane;
+            const int cl = e / CW, wi = e - cl * CW;   // chunk lane cl: slot cl % DPW, chunk cl / DPW
+            const long bb = b0 + (cl % DPW);
+            if (bb < A.B) tape[(bb * (long)rows + PL * (cl / DPW) + ss0 + rshift) * W + wi] = vals[k];
+          }
+        };
         double Pq[M][M], aq[M], lacc = 0.0;
 #pragma unroll
         for (int i = 0; i < M; ++i) {
@@ -564,23 +607,31 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
         }
 #pragma unroll
         for (int ss = 0; ss < PL; ++ss) {
-          const int tt = PL * jj + ss;
           double af[M], Pf[M][M], Kq[M], quad;
           const double F = kstep(Pq, aq, yc[ss], af, Pf, quad, Kq);
           const double llv = (univariate && !exact_const && F == 1.0 && quad == 0.0) ? 0.0 : -0.5 * (KF_LOG_2PI + log(F) + quad);  // :497-500
           lacc += llv;
-          if (live) {
-            if (A.ll_obs) A.ll_obs[b * (long)n + tt] = llv;
+          const int sg = ss % PG;
+          g_ll[lane * ST_L + sg] = llv;
 #pragma unroll
-            for (int i = 0; i < M; ++i) {
-              if (w_fa) A.filt_a[(b * (long)n + tt) * M + i] = af[i];
-              if (w_pa) A.pred_a[(b * (long)(n + 1) + tt + 1) * M + i] = aq[i];
+          for (int i = 0; i < M; ++i) {
+            g_fa[lane * ST_A + sg * M + i] = af[i];
+            g_pa[lane * ST_A + sg * M + i] = aq[i];
 #pragma unroll
-              for (int j = 0; j < M; ++j) {
-                if (w_fP) A.filt_P[(b * (long)n + tt) * MM + i * M + j] = Pf[i][j];
-                if (w_pP) A.pred_P[(b * (long)(n + 1) + tt + 1) * MM + i * M + j] = Pq[i][j];
-              }
+            for (int j = 0; j < M; ++j) {
+              g_fP[lane * ST_P + sg * MM + i * M + j] = Pf[i][j];
+              g_pP[lane * ST_P + sg * MM + i * M + j] = Pq[i][j];
             }
+          }
+          if (sg == PG - 1) {
+            const int ss0 = ss - (PG - 1);
+            wave_lds_fence();
+            if (A.ll_obs) stage_out(A.ll_obs, g_ll, ST_L, std::integral_constant<int, 1>{}, n, 0, ss0);
+            if (w_fa) stage_out(A.filt_a, g_fa, ST_A, std::integral_constant<int, M>{}, n, 0, ss0);
+            if (w_pa) stage_out(A.pred_a, g_pa, ST_A, std::integral_constant<int, M>{}, n + 1, 1, ss0);
+            if (w_fP) stage_out(A.filt_P, g_fP, ST_P, std::integral_constant<int, MM>{}, n, 0, ss0);
+            if (w_pP) stage_out(A.pred_P, g_pP, ST_P, std::integral_constant<int, MM>{}, n + 1, 1, ss0);
+            wave_lds_fence();
           }
         }
 #pragma unroll
