@@ -174,7 +174,9 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
   // y reaches the recursion through LDS, a block of S steps at a time: the loads of block k + 1 are issued when block k
   // is flushed and land in LDS after its copy-out (a per-step global load would put L2 latency on every step)
   const bool y_per_draw = (A.flags & KF_FLAG_Y_PER_DRAW) != 0;
-  double ynx[NK];
+  // (round 6: TWO blocks ahead -- the loads of block k + 2 are issued at the flush of block k and committed at the flush of block
+  // k + 1: with the covariance frozen a block of sixteen steps is ~1.4 us, less than a load from HBM under load takes)
+  double ynx[NK], yn2[NK];
   auto y_fetch = [&](int t0) {
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
       long bb = b0 + dd;
       if (bb >= A.B) bb = A.B - 1;
       const int tt = (t0 + ss < n) ? t0 + ss : n - 1;
-      ynx[k] = ((DPW * S) % KF_WAVE == 0 || e < DPW * S) ? A.y[(y_per_draw ? bb * (long)n : 0L) + tt] : 0.0;
+      yn2[k] = ((DPW * S) % KF_WAVE == 0 || e < DPW * S) ? A.y[(y_per_draw ? bb * (long)n : 0L) + tt] : 0.0;
     }
   };
   auto y_commit = [&]() {
@@ -195,13 +197,17 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
     }
     wave_lds_fence();
   };
+  auto y_shift = [&]() {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) ynx[k] = yn2[k];
+  };
   const double* s_yb = smem + L::OFF_YB + d * L::W_L;
   double lsum[NK];
 #pragma unroll
   for (int k = 0; k < NK; ++k) lsum[k] = 0.0;
   auto flush = [&](int t0, int cnt) {
     wave_lds_fence();
-    if (t0 + cnt < n) y_fetch(t0 + cnt);
+    if (t0 + 2 * cnt < n) y_fetch(t0 + 2 * cnt);   // (a partial block is the last one: cnt == S whenever another block follows)
     if (w_fa) copy_out(A.filt_a, smem + L::OFF_FA, L::W_A, std::integral_constant<int, M>{}, n, t0, cnt);
     if (w_pa) copy_out(A.pred_a, smem + L::OFF_PA, L::W_A, std::integral_constant<int, M>{}, n + 1, t0 + 1, cnt);
     if (w_fP) copy_out(A.filt_P, smem + L::OFF_FP, L::W_P, std::integral_constant<int, MM>{}, n, t0, cnt);
@@ -226,7 +232,10 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
       }
     }
     wave_lds_fence();
-    if (t0 + cnt < n) y_commit();
+    if (t0 + cnt < n) {
+      y_commit();    // block t0 + cnt, fetched one flush ago
+      y_shift();
+    }
   };
 
   int info = 0;
@@ -649,7 +658,12 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
     }
   }
   y_fetch(t);
+  y_shift();
   y_commit();
+  if (t + S < n) {
+    y_fetch(t + S);
+    y_shift();
+  }
   double ycur = s_yb[0];
   // ---- steady state (kf_forward_b4.hip has the long version): once every draw of the wavefront has a predicted covariance that
   // stopped moving (3e-16 of its largest entry, tested at the end of each block of S steps, no missing observation ahead) the

@@ -699,3 +699,59 @@ def test_set_option_forward_kernel_selector_and_its_removal(eng):
     finally:
         eng.set_option("KF_FORWARD_KERNEL", None)
     assert name() == "kf_fwd_b4_kernel"
+
+
+# ---- the lane-per-draw forward kernel's chunked first 256 steps (csrc/kf_forward_lane.hip, KF_LANE_PRECHUNK) ---------------------------------
+# BaseFilter.build_graph's scan (filters/kalman_filter.py:126-252) at p = 1, m <= 2: the first 256 steps as sixteen 16-step chunks on a
+# draw slot's sixteen lanes -- chunk-start covariances from four squarings of the one-step Riccati element, means chained over the
+# lanes.  Tolerances: the numpy oracle at 1e-9 (every output), the same kernel stepping from step 0 at 1e-11.
+@pytest.mark.parametrize("case", ["arma11", "local_level_m1", "dense_m2_r2", "dense_m2_c_d_single"])
+def test_lane_prechunk_against_the_oracle_and_the_sequential_steps(eng, case):
+    rng = np.random.default_rng(3)
+    kw = {}
+    if case == "arma11":
+        w = W.arma11(B=9, n=530)
+    elif case == "local_level_m1":
+        w = W.random_dense(6, 600, 1, 1, 1, seed=51)
+    elif case == "dense_m2_r2":
+        w = W.random_dense(7, 515, 1, 2, 2, seed=52)
+    else:
+        w = W.random_dense(5, 640, 1, 2, 1, seed=53)
+        kw = dict(c=0.2 * rng.standard_normal((5, 2)), d=0.3 * rng.standard_normal((5, 1)), filter_type="single")
+    assert eng.forward_kernel_name(w["B"], w["n"], 1, w["m"], w["r"]) == "kf_fwd_lane_kernel"
+    got = eng.forward(*_args(w), mvn_const="exact", **kw)
+    eng.set_option("KF_LANE_PRECHUNK", "0")
+    try:
+        seq = eng.forward(*_args(w), mvn_const="exact", **kw)
+    finally:
+        eng.set_option("KF_LANE_PRECHUNK", None)
+    ref = kn.kalman_filter(*_args(w), mvn_const="exact", **kw)
+    m = w["m"]
+    for k in ("logp", "ll_obs", "filtered_states", "predicted_states", "filtered_covs", "predicted_covs"):
+        a, s_, r_ = getattr(got, k).cpu().numpy(), getattr(seq, k).cpu().numpy(), np.asarray(ref[k]).reshape(getattr(got, k).shape)
+        scale = 1.0 + np.max(np.abs(r_))
+        assert np.max(np.abs(a - r_)) <= 1e-9 * scale, (k, "oracle", np.max(np.abs(a - r_)) / scale)
+        assert np.max(np.abs(a - s_)) <= 1e-11 * scale, (k, "sequential", np.max(np.abs(a - s_)) / scale)
+    if case.startswith("dense_m2"):   # (the chunked path ran: slowly converging covariances differ in their last bits; an ARMA(1,1)
+        # covariance has reached its fixed point after 16 steps and the doubling lands on the same bits)
+        assert not np.array_equal(got.filtered_covs.cpu().numpy(), seq.filtered_covs.cpu().numpy())
+
+
+def test_lane_prechunk_leaves_the_sequential_path_alone_when_in_doubt(eng):
+    """A missing observation in the first 256 steps, a series shorter than 512 steps, KF_FLAG_EXACT_RECURSION: bit for bit the kernel
+    stepping from step 0."""
+    import torch
+
+    w = W.arma11(B=13, n=600)
+    y = w["y"].copy()
+    y[77] = np.nan
+    short = W.arma11(B=13, n=511)
+    for args, kw in (((y,) + _args(w)[1:], {}), (_args(short), {}), (_args(w), dict(exact_recursion=True))):
+        got = eng.forward(*args, mvn_const="exact", **kw)
+        eng.set_option("KF_LANE_PRECHUNK", "0")
+        try:
+            seq = eng.forward(*args, mvn_const="exact", **kw)
+        finally:
+            eng.set_option("KF_LANE_PRECHUNK", None)
+        for k in ("logp", "ll_obs", "filtered_states", "predicted_states", "filtered_covs", "predicted_covs"):
+            assert torch.equal(torch.nan_to_num(getattr(got, k), nan=-7.0), torch.nan_to_num(getattr(seq, k), nan=-7.0)), k

@@ -58,6 +58,8 @@ FORWARD_CASES = [
     ("KF_STEADY_STATE", ("0", "1"), lambda: W.structural(B=1500, n=400), {}),
     ("KF_STEADY_STATE", ("0", "1"), lambda: W.arma11(B=300, n=300), {}),
     ("KF_STEADY_STATE", ("0", "1"), lambda: W.varmax(B=64, n=200), {"h_diagonal": True}),
+    ("KF_LANE_PRECHUNK", ("0",), lambda: W.arma11(B=300, n=700), {}),
+    ("KF_LANE_PRECHUNK", ("0",), lambda: W.random_dense(B=77, n=600, p=1, m=1, r=1, seed=9), {}),
     ("KF_B4_SPLIT", ("0", "1"), lambda: W.structural(B=1500, n=400), {"exact_recursion": False}),
     ("KF_FORWARD_B4P", ("0", "1"), lambda: W.structural(B=200, n=150), {}),
     ("KF_FORWARD_B4P", ("1",), lambda: W.structural(B=1500, n=150), {}),
