@@ -73,8 +73,28 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
   constexpr bool PRE_OK = SS && M <= 2 && DPW == 4 && S == 16;
   __shared__ double pstage[PRE_OK ? KF_WAVE * (2 * (4 * M + 1) + 2 * (4 * MM + 1) + 5) : 1];
   const int lane = threadIdx.x;
-  const int d = lane % DPW;
-  const bool owner = lane < DPW;
+  // Round 6, DPW == 4 ("ROWMAP"): a draw slot is one DPP ROW of sixteen lanes (slot = lane / 16, replica / chunk / step index = lane % 16),
+  // so that what the sixteen lanes of a slot exchange -- the prefix scan of the frozen phase, the chained means of the chunked first
+  // 256 steps -- are row_shr / row_newbcast moves instead of ds_bpermute round trips (the frozen phase's block of sixteen steps was six
+  // dependent LDS-crossbar stages).  The other widths keep slot = lane % DPW.
+  constexpr bool ROWMAP = DPW == 4;
+  const int d = ROWMAP ? lane / 16 : lane % DPW;
+  const int jrep = ROWMAP ? lane % 16 : lane / DPW;   // which of the slot's lanes this is
+  const bool owner = jrep == 0;
+  // the value of the slot's lane K places down / one place up / of its last lane (ROWMAP: lanes without a source keep their own value)
+  auto slot_up = [&](double x, auto kc) -> double {
+    constexpr int K = decltype(kc)::value;
+    if constexpr (ROWMAP) return dpp_mov<0x110 + K>(x);   // row_shr:K
+    else return __shfl_up(x, K * DPW, KF_WAVE);
+  };
+  auto slot_next = [&](double x) -> double {
+    if constexpr (ROWMAP) return dpp_mov<0x101>(x);       // row_shl:1
+    else return __shfl_down(x, DPW, KF_WAVE);
+  };
+  auto slot_last = [&](double x) -> double {
+    if constexpr (ROWMAP) return dpp_mov<0x15F>(x);       // row_newbcast:15
+    else return __shfl(x, d + DPW * (KF_WAVE / DPW - 1), KF_WAVE);
+  };
   const long b0 = (long)blockIdx.x * DPW;
   long b = b0 + d;
   const bool live = b < A.B;
@@ -258,7 +278,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
   if constexpr (SCAN) {
     constexpr int PL = 16, PN = 16 * PL;
     if (A.lane_pre && n >= 2 * PN && !A.hs_ts) {
-      const int jj = lane / DPW;
+      const int jj = jrep;
       const double* yb = A.y + (y_per_draw ? b * (long)n : 0L);
       double yc[PL];
       bool okl = true;
@@ -553,7 +573,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
         for (int i = 0; i < M; ++i)
 #pragma unroll
           for (int j = 0; j < M; ++j) {
-            const double nx = __shfl_down(Pst[i][j], DPW, KF_WAVE);
+            const double nx = slot_next(Pst[i][j]);
             pmax = fmax(pmax, fabs(Pq[i][j]));
             dmax = fmax(dmax, fabs(Pq[i][j] - nx));
           }
@@ -575,7 +595,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
           }
 #pragma unroll
           for (int i = 0; i < M; ++i) {
-            const double rv = __shfl_up(nx[i], DPW, KF_WAVE);
+            const double rv = slot_up(nx[i], std::integral_constant<int, 1>{});
             cur[i] = (jj == k + 1) ? rv : cur[i];
           }
         }
@@ -602,9 +622,9 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
 #pragma unroll
           for (int k = 0; k < NI; ++k) {
             const int e = k * KF_WAVE + lane;
-            const int cl = e / CW, wi = e - cl * CW;   // chunk lane cl: slot cl % DPW, chunk cl / DPW
-            const long bb = b0 + (cl % DPW);
-            if (bb < A.B) tape[(bb * (long)rows + PL * (cl / DPW) + ss0 + rshift) * W + wi] = vals[k];
+            const int cl = e / CW, wi = e - cl * CW;   // the stage of lane cl: slot cl / 16, chunk cl % 16 (ROWMAP)
+            const long bb = b0 + (cl / 16);
+            if (bb < A.B) tape[(bb * (long)rows + PL * (cl % 16) + ss0 + rshift) * W + wi] = vals[k];
           }
         };
         double Pq[M][M], aq[M], lacc = 0.0;
@@ -643,15 +663,14 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
             wave_lds_fence();
           }
         }
-#pragma unroll
-        for (int off = DPW; off < KF_WAVE; off <<= 1) lacc += __shfl_xor(lacc, off, KF_WAVE);
+        lacc = row_allsum(lacc);   // (ROWMAP: the slot's sixteen lanes)
         if (owner) smem[L::OFF_ACC + d] += lacc;
         // (vi) the loop below goes on from step 256 with the last lane's predicted moments
 #pragma unroll
         for (int i = 0; i < M; ++i) {
-          a[i] = __shfl(aq[i], d + DPW * 15, KF_WAVE);
+          a[i] = slot_last(aq[i]);
 #pragma unroll
-          for (int j = 0; j < M; ++j) P[i][j] = __shfl(Pq[i][j], d + DPW * 15, KF_WAVE);
+          for (int j = 0; j < M; ++j) P[i][j] = slot_last(Pq[i][j]);
         }
         t = PN;
       }
@@ -677,12 +696,12 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
     constexpr int LPD = KF_WAVE / DPW;  // lanes that share a draw slot: lane, lane + DPW, ...
     int tn = -1;
     const double* yb = A.y + (y_per_draw ? b * (long)n : 0L);
-    for (int tt = lane / DPW; tt < n; tt += LPD) {
+    for (int tt = jrep; tt < n; tt += LPD) {
       const double yv = yb[tt];
       if (yv != yv) tn = tt;
     }
 #pragma unroll
-    for (int off = DPW; off < KF_WAVE; off <<= 1) tn = max(tn, __shfl_xor(tn, off));
+    for (int off = ROWMAP ? 1 : DPW; off < (ROWMAP ? 16 : KF_WAVE); off <<= 1) tn = max(tn, __shfl_xor(tn, off));
     t_free = tn + 1;
   }
   bool fz = false;
@@ -694,7 +713,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
   // step from its own a_{t+j} and writes its row of the LDS block.  (A is the closed-loop matrix of the converged filter: stable.)
   // A slot changes over at the block boundary behind ITS OWN convergence, whatever the other slots of the wavefront do (they keep
   // stepping with the frozen slots' lanes idle), so a draw's bits do not depend on its neighbours.
-  const int jj = lane / DPW;
+  const int jj = jrep;
   double zK[M], zTK[M], zAp[4][M][M], zAj[M][M], zInvF = 0.0, zFraw = 0.0;
   bool zDegen = false;
   auto freeze_consts = [&](int t_at) {
@@ -798,7 +817,9 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
     for (int q = 0; q < 4; ++q) {
       double rv[M];
 #pragma unroll
-      for (int i = 0; i < M; ++i) rv[i] = __shfl_up(Sv[i], (1 << q) * DPW, KF_WAVE);
+      for (int i = 0; i < M; ++i)
+        rv[i] = q == 0 ? slot_up(Sv[i], std::integral_constant<int, 1>{}) : q == 1 ? slot_up(Sv[i], std::integral_constant<int, 2>{})
+              : q == 2 ? slot_up(Sv[i], std::integral_constant<int, 4>{}) : slot_up(Sv[i], std::integral_constant<int, 8>{});
       const bool has = jj >= (1 << q);
 #pragma unroll
       for (int i = 0; i < M; ++i) {
@@ -811,7 +832,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
     double x[M], af[M], ap[M];
 #pragma unroll
     for (int i = 0; i < M; ++i) {
-      const double ev = __shfl_up(Sv[i], DPW, KF_WAVE);
+      const double ev = slot_up(Sv[i], std::integral_constant<int, 1>{});
       double sm = (jj >= 1) ? ev : 0.0;
 #pragma unroll
       for (int l = 0; l < M; ++l) sm = fma(zAj[i][l], a[l], sm);
@@ -844,7 +865,7 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
       }
     }
 #pragma unroll
-    for (int i = 0; i < M; ++i) a[i] = __shfl(ap[i], d + DPW * (S - 1), KF_WAVE);  // the next block starts from the last lane's prediction
+    for (int i = 0; i < M; ++i) a[i] = slot_last(ap[i]);  // the next block starts from the last lane's prediction (S == 16 == the slot's lanes)
   };
   int npass = 0;  // consecutive convergence checks this lane's draw has passed
   for (; t < n; ++t) {
