@@ -163,24 +163,38 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
     if (cnt == S) {
       // (round 6: every LDS read of the block first, then the stores -- with the bounds test inside, each of the up to twelve copies
       // of a flush was a basic block of its own: read, wait for it, store; one wavefront per SIMD has nothing else to run meanwhile)
+      // ... and sixteen bytes per lane: a slot's S rows are S * W consecutive doubles on both sides (S * W is even)
       constexpr int CW = S * W;
-      constexpr int NI = (DPW * CW + KF_WAVE - 1) / KF_WAVE;
-      double vals[NI];
+      constexpr int NP = DPW * CW / 2;                          // pairs of doubles
+      constexpr int NI = (NP + KF_WAVE - 1) / KF_WAVE;
+      static_assert(CW % 2 == 0, "pairs never straddle two slots");
+      double2_t vals[NI];
 #pragma unroll
       for (int k = 0; k < NI; ++k) {
-        int e = k * KF_WAVE + lane;
-        if ((DPW * CW) % KF_WAVE != 0 && e >= DPW * CW) e = DPW * CW - 1;
+        int pi = k * KF_WAVE + lane;
+        if (NP % KF_WAVE != 0 && pi >= NP) pi = NP - 1;
+        const int e = 2 * pi;
         const int dd = e / CW, off = e - dd * CW;
-        vals[k] = lds[dd * stride + off];
+        vals[k] = double2_t{lds[dd * stride + off], lds[dd * stride + off + 1]};
       }
 #pragma unroll
-      for (int k = 0; k < NI; ++k) asm volatile("" : "+v"(vals[k]));   // (pinned here: the compiler sinks each load into its store's branch)
+      for (int k = 0; k < NI; ++k) {
+        asm volatile("" : "+v"(vals[k]));   // (pinned here: the compiler sinks each load into its store's branch)
+      }
 #pragma unroll
       for (int k = 0; k < NI; ++k) {
-        const int e = k * KF_WAVE + lane;
+        const int pi = k * KF_WAVE + lane;
+        const int e = 2 * pi;
         const int dd = e / CW, off = e - dd * CW;
-        if (((DPW * CW) % KF_WAVE == 0 || e < DPW * CW) && b0 + dd < A.B)
-          tape[((b0 + dd) * (long)rows + row0) * W + off] = vals[k];
+        if ((NP % KF_WAVE == 0 || pi < NP) && b0 + dd < A.B) {
+          double* dst = tape + ((b0 + dd) * (long)rows + row0) * W + off;
+          if ((W % 2 == 0) || ((reinterpret_cast<unsigned long long>(dst) & 15ull) == 0ull)) {
+            *reinterpret_cast<double2_t*>(dst) = vals[k];
+          } else {   // (W odd: an odd row start is 8-byte aligned only)
+            dst[0] = vals[k].x;
+            dst[1] = vals[k].y;
+          }
+        }
       }
     } else {
       const int cw = cnt * W;
