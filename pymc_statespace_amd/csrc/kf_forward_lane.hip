@@ -291,6 +291,8 @@ __global__ __launch_bounds__(KF_WAVE) void kf_fwd_lane_kernel(const KfFwdArgs A)
   // been written: the loop below starts at step 0 as before.  KF_LANE_PRECHUNK=0 switches it off.
   if constexpr (SCAN) {
     constexpr int PL = 16, PN = 16 * PL;
+    // (not ahead of the steady-state adjoint, KfFwdArgs::hs_ts: a slot then freezes behind step 256 at the earliest and the exact
+    // adjoint sweeps >= 288 steps of EVERY draw -- measured at C2: forward 222 -> 128 us, kf_bwd_b4_kernel 203 -> 351)
     if (A.lane_pre && n >= 2 * PN && !A.hs_ts) {
       const int jj = jrep;
       const double* yb = A.y + (y_per_draw ? b * (long)n : 0L);
